@@ -1,0 +1,1187 @@
+/*
+ * mpm_oracle.c -- CPU restatement of the g1n0st/drake GPU cloth-MPM substep.
+ *
+ * THIS IS TEST INFRASTRUCTURE, NOT PRODUCT CODE.  Only tests/, the smoke check
+ * in __graft_entry__.py and the cpu_baseline leg of bench.py may load it.  The
+ * shipped engine (drake_amd/csrc) never links or calls anything in here.
+ *
+ * What it is: a plain-C (C99 + optional OpenMP) restatement of the algorithm
+ * that the reference implements as CUDA kernels in
+ *   multibody/gpu_mpm/cuda_mpm_kernels.cuh, math_tools.cuh,
+ *   cuda_mpm_solver.cu, cuda_mpm_model.cu, radix_sort.cuh
+ * Each function cites the reference file:line it follows.  Data layouts are
+ * the reference's (array-of-small-vectors, dense grid indexed by cell key).
+ *
+ * Pinning status: the reference is CUDA-only (needs nvcc, cuda_runtime.h and
+ * Eigen, none of which exist in this image) so it cannot be built here, and
+ * it ships no golden vectors or numeric unit tests.  The
+ * restatement is pinned by the known answers that the survey captured from
+ * the reference kernels (stored in
+ * tests/golden/survey_known_answers.json) and by physical invariants.
+ * Anything not covered by those known answers is "parity unpinned".
+ *
+ * With OMP_NUM_THREADS=1 (or orc_set_threads(1)) every sum is evaluated in
+ * particle / contact order, i.e. deterministically.
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#include <stdio.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+#define ORC_API __attribute__((visibility("default")))
+
+/* Runtime version of the compile-time constants in settings.h:36-127. */
+typedef struct {
+    int domain_bits;    /* settings.h:49  DOMAIN_BITS            */
+    int wall;           /* settings.h:56  G_BOUNDARY_CONDITION   */
+    int gravity_axis;   /* settings.h:118 GRAVITY_AXIS           */
+    float youngs;       /* settings.h:73  */
+    float poisson;      /* settings.h:77  */
+    float density;      /* settings.h:81  */
+    float gamma;        /* settings.h:85  */
+    float K;            /* settings.h:92  */
+    float V;            /* settings.h:99  */
+    float cF;           /* settings.h:103 */
+    float sdf_friction; /* settings.h:110 */
+    float gravity;      /* settings.h:121 */
+    float epsv;         /* settings.h:125 */
+} orc_params;
+
+ORC_API void orc_default_params(orc_params *p) {
+    p->domain_bits = 7;
+    p->wall = 3;
+    p->gravity_axis = 2;
+    p->youngs = 400000.f;
+    p->poisson = .3f;
+    p->density = 2000.f;
+    p->gamma = 0.f;
+    p->K = 100000.f;
+    p->V = .8f;
+    p->cF = 0.f;
+    p->sdf_friction = .3f;
+    p->gravity = -9.8f;
+    p->epsv = 1e-3f;
+}
+
+ORC_API void orc_set_threads(int n) {
+#ifdef _OPENMP
+    if (n > 0) omp_set_num_threads(n);
+#else
+    (void)n;
+#endif
+}
+
+ORC_API int orc_max_threads(void) {
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}
+
+/* settings.h:50,57-59 */
+static inline float p_dxinv(const orc_params *p) { return (float)(1 << p->domain_bits); }
+static inline float p_dx(const orc_params *p) { return 1.f / p_dxinv(p); }
+static inline float p_dinv(const orc_params *p) { return 4.f * p_dxinv(p) * p_dxinv(p); }
+/* settings.h:114-115 */
+static inline float p_mu(const orc_params *p) { return p->youngs / (2.f * (1.f + p->poisson)); }
+static inline float p_lambda(const orc_params *p) {
+    return p->youngs * p->poisson / ((1.f + p->poisson) * (1.f - 2.f * p->poisson));
+}
+
+/* CUDA float->uint32 conversion saturates; negative inputs give 0. */
+static inline uint32_t f2u(float f) { return f > 0.f ? (uint32_t)f : 0u; }
+
+/* ------------------------------------------------------------------ */
+/* small dense helpers (math_tools.cuh:11-149), row-major              */
+/* ------------------------------------------------------------------ */
+
+/* c[n,l] = a[n,m] * b[m,l]   (math_tools.cuh:11-24) */
+static void mm(int n, int m, int l, const float *a, const float *b, float *c) {
+    for (int i = 0; i < n; ++i)
+        for (int k = 0; k < l; ++k) {
+            float s = 0.f;
+            for (int j = 0; j < m; ++j) s += a[i * m + j] * b[j * l + k];
+            c[i * l + k] = s;
+        }
+}
+/* c[n,l] = a[n,m] * b[l,m]^T (math_tools.cuh:27-39) */
+static void mmT(int n, int m, int l, const float *a, const float *b, float *c) {
+    for (int i = 0; i < n; ++i)
+        for (int k = 0; k < l; ++k) {
+            float s = 0.f;
+            for (int j = 0; j < m; ++j) s += a[i * m + j] * b[k * m + j];
+            c[i * l + k] = s;
+        }
+}
+static float dotn(int n, const float *x, const float *y) {
+    float s = 0.f;
+    for (int i = 0; i < n; ++i) s += x[i] * y[i];
+    return s;
+}
+static float norm_sqr_n(int n, const float *x) { return dotn(n, x, x); }
+static float norm_n(int n, const float *x) { return sqrtf(norm_sqr_n(n, x)); }
+
+/* math_tools.cuh:113-119 */
+static float det3(const float *m) {
+    return m[0] * (m[4] * m[8] - m[7] * m[5]) - m[3] * (m[1] * m[8] - m[7] * m[2]) +
+           m[6] * (m[1] * m[5] - m[4] * m[2]);
+}
+/* math_tools.cuh:121-134; "1. / det" is a double division rounded to float */
+static void inv3(const float *m, float *o) {
+    float di = (float)(1.0 / (double)det3(m));
+    o[0] = (m[4] * m[8] - m[5] * m[7]) * di;
+    o[3] = (m[5] * m[6] - m[3] * m[8]) * di;
+    o[6] = (m[3] * m[7] - m[4] * m[6]) * di;
+    o[1] = (m[2] * m[7] - m[1] * m[8]) * di;
+    o[4] = (m[0] * m[8] - m[2] * m[6]) * di;
+    o[7] = (m[1] * m[6] - m[0] * m[7]) * di;
+    o[2] = (m[1] * m[5] - m[2] * m[4]) * di;
+    o[5] = (m[2] * m[3] - m[0] * m[5]) * di;
+    o[8] = (m[0] * m[4] - m[1] * m[3]) * di;
+}
+/* math_tools.cuh:136-149 */
+static float det2(const float *m) { return m[0] * m[3] - m[1] * m[2]; }
+static void inv2(const float *m, float *o) {
+    float di = (float)(1.0 / (double)det2(m));
+    o[0] = m[3] * di;
+    o[1] = -m[1] * di;
+    o[2] = -m[2] * di;
+    o[3] = m[0] * di;
+}
+
+/* Givens QR of A[n,m] -> Q[n,n], R[n,m]  (math_tools.cuh:456-510) */
+static void givens_qr(int n, int m, const float *A, float *Q, float *R) {
+    for (int i = 0; i < n * m; ++i) R[i] = A[i];
+    for (int i = 0; i < n * n; ++i) Q[i] = 0.f;
+    for (int i = 0; i < n; ++i) Q[i * n + i] = 1.f;
+    for (int j = 0; j < m; ++j) {
+        for (int i = n - 1; i > j; --i) {
+            const int ri = i - 1, rk = i;
+            const float a = R[ri * m + j], b = R[rk * m + j];
+            const float d = a * a + b * b;
+            float c = 1.f, s = 0.f;
+            const float sq = sqrtf(d);
+            if (sq > 0.f) {
+                const float t = (float)(1.0 / (double)sq);
+                c = a * t;
+                s = -b * t;
+            }
+            for (int jj = 0; jj < m; ++jj) {
+                const float t1 = R[ri * m + jj], t2 = R[rk * m + jj];
+                R[ri * m + jj] = c * t1 - s * t2;
+                R[rk * m + jj] = s * t1 + c * t2;
+            }
+            for (int jj = 0; jj < n; ++jj) {
+                const float t1 = Q[ri * n + jj], t2 = Q[rk * n + jj];
+                Q[ri * n + jj] = c * t1 - s * t2;
+                Q[rk * n + jj] = s * t1 + c * t2;
+            }
+        }
+    }
+    for (int i = 0; i < n; ++i)
+        for (int j = i + 1; j < n; ++j) {
+            const float t = Q[i * n + j];
+            Q[i * n + j] = Q[j * n + i];
+            Q[j * n + i] = t;
+        }
+}
+
+/* math_tools.cuh:512-549 */
+static void polar2(const float *A, float *U, float *P) {
+    U[0] = 1.f; U[1] = 0.f; U[2] = 0.f; U[3] = 1.f;
+    P[0] = A[0]; P[1] = A[1]; P[2] = A[2]; P[3] = A[3];
+    if (A[0] == 0.f && A[1] == 0.f && A[2] == 0.f && A[3] == 0.f) return;
+    const float detA = det2(A);
+    const float adetA = fabsf(detA);
+    float B[4] = {A[0] + A[3], A[1] - A[2], A[2] - A[1], A[3] + A[0]};
+    if (detA < 0.f) {
+        B[0] = A[0] - A[3];
+        B[1] = A[1] + A[2];
+        B[2] = A[2] + A[1];
+        B[3] = A[3] - A[0];
+    }
+    const float adetB = fabsf(det2(B));
+    const float k = 1.f / sqrtf(adetB);
+    U[0] = B[0] * k; U[1] = B[1] * k; U[2] = B[2] * k; U[3] = B[3] * k;
+    P[0] = (A[0] * A[0] + A[2] * A[2] + adetA) * k;
+    P[1] = (A[0] * A[1] + A[2] * A[3]) * k;
+    P[2] = (A[0] * A[1] + A[2] * A[3]) * k;
+    P[3] = (A[1] * A[1] + A[3] * A[3] + adetA) * k;
+}
+
+/* math_tools.cuh:551-597 */
+static void svd2(const float *A, float *U, float *sig, float *V) {
+    float R[4], S[4];
+    polar2(A, R, S);
+    float c, s, s1, s2;
+    if (fabsf(S[1]) < 1e-5f) {
+        c = 1.f; s = 0.f; s1 = S[0]; s2 = S[3];
+    } else {
+        const float tao = .5f * (S[0] - S[3]);
+        const float w = sqrtf(tao * tao + S[1] * S[1]);
+        const float t = (tao > 0.f) ? S[1] / (tao + w) : S[1] / (tao - w);
+        c = 1.f / sqrtf(t * t + 1.f);
+        s = -t * c;
+        s1 = c * c * S[0] - 2.f * c * s * S[1] + s * s * S[3];
+        s2 = s * s * S[0] + 2.f * c * s * S[1] + c * c * S[3];
+    }
+    if (s1 < s2) {
+        const float t = s1; s1 = s2; s2 = t;
+        V[0] = -s; V[1] = c; V[2] = -c; V[3] = -s;
+    } else {
+        V[0] = c; V[1] = s; V[2] = -s; V[3] = c;
+    }
+    mm(2, 2, 2, R, V, U);
+    sig[0] = s1; sig[1] = 0.f; sig[2] = 0.f; sig[3] = s2;
+}
+
+/* math_tools.cuh:599-638 (Drake's RotationMatrix::MakeFromOneUnitVector) */
+static void frame_from_unit(const float u[3], int axis, float *J) {
+    int i = 0;
+    if (fabsf(u[1]) < fabsf(u[i])) i = 1;
+    if (fabsf(u[2]) < fabsf(u[i])) i = 2;
+    const int j = (i + 1) % 3, k = (j + 1) % 3;
+    const float uu = u[i] * u[i];
+    const float mag = (float)sqrt(1.0 - (double)uu);
+    const float r = 1.f / mag;
+    const float s = -r * u[i];
+    J[axis * 3 + 0] = u[0]; J[axis * 3 + 1] = u[1]; J[axis * 3 + 2] = u[2];
+    float v[3] = {0.f, 0.f, 0.f};
+    v[j] = -r * u[k];
+    v[k] = r * u[j];
+    const int vi = (axis + 1) % 3;
+    J[vi * 3 + i] = 0.f; J[vi * 3 + j] = v[j]; J[vi * 3 + k] = v[k];
+    float w[3];
+    w[i] = mag; w[j] = s * u[j]; w[k] = s * u[k];
+    const int wi = (axis + 2) % 3;
+    J[wi * 3 + 0] = w[0]; J[wi * 3 + 1] = w[1]; J[wi * 3 + 2] = w[2];
+}
+
+/* ------------------------------------------------------------------ */
+/* index maps (cuda_mpm_kernels.cuh:296-363)                           */
+/* ------------------------------------------------------------------ */
+static inline uint32_t expand_bits(uint32_t v) {           /* :306-313 */
+    v = (v * 0x00010001u) & 0xFF0000FFu;
+    v = (v * 0x00000101u) & 0x0F00F00Fu;
+    v = (v * 0x00000011u) & 0xC30C30C3u;
+    v = (v * 0x00000005u) & 0x49249249u;
+    return v;
+}
+static inline uint32_t contract_bits(uint32_t v) {         /* :296-304 */
+    v &= 0x09249249u;
+    v = (v ^ (v >> 2)) & 0x030C30C3u;
+    v = (v ^ (v >> 4)) & 0x0300F00Fu;
+    v = (v ^ (v >> 8)) & 0xFF0000FFu;
+    v = (v ^ (v >> 16)) & 0x000003FFu;
+    return v;
+}
+ORC_API uint32_t orc_morton_code(uint32_t x, uint32_t y, uint32_t z) { /* :317-323 */
+    return expand_bits(x) * 4u + expand_bits(y) * 2u + expand_bits(z);
+}
+ORC_API uint32_t orc_cell_index(uint32_t x, uint32_t y, uint32_t z) {  /* :334-341 */
+    const uint32_t hi = orc_morton_code(x >> 2, y >> 2, z >> 2);
+    const uint32_t lo = ((x & 3u) << 4) | ((y & 3u) << 2) | (z & 3u);
+    return (hi << 6) | lo;
+}
+ORC_API void orc_inverse_cell_index(uint32_t key, uint32_t *xyz) {     /* :343-363 */
+    const uint32_t hi = key >> 6, lo = key & 63u;
+    xyz[0] = (contract_bits(hi >> 2) << 2) | ((lo >> 4) & 3u);
+    xyz[1] = (contract_bits(hi >> 1) << 2) | ((lo >> 2) & 3u);
+    xyz[2] = (contract_bits(hi) << 2) | (lo & 3u);
+}
+
+/* compute_base_cell_node_index_kernel (:365-382) */
+ORC_API void orc_compute_keys(const orc_params *p, size_t n, const float *pos, uint32_t *keys,
+                              uint32_t *ids) {
+    const float dxinv = p_dxinv(p);
+#pragma omp parallel for schedule(static)
+    for (long i = 0; i < (long)n; ++i) {
+        const uint32_t xi = f2u(pos[i * 3 + 0] * dxinv - .5f);
+        const uint32_t yi = f2u(pos[i * 3 + 1] * dxinv - .5f);
+        const uint32_t zi = f2u(pos[i * 3 + 2] * dxinv - .5f);
+        keys[i] = orc_cell_index(xi, yi, zi);
+        if (ids) ids[i] = (uint32_t)i;
+    }
+}
+
+/* radix_sort (radix_sort.cuh:202-286) as called at cuda_mpm_solver.cu:49-58:
+ * a stable LSD sort of (key,id) pairs on the low `nbits` bits of the key.  The
+ * reference does it 2 bits at a time; stability makes the outcome independent
+ * of the digit width, so this uses 8-bit digits. Both key arrays and both id
+ * arrays hold the result on exit (radix_sort.cuh:284-285). */
+ORC_API void orc_sort_pairs_low_bits(size_t n, uint32_t *keys_io, uint32_t *ids_io,
+                                     uint32_t *keys_out, uint32_t *ids_out, int nbits) {
+    uint32_t *ka = keys_io, *ia = ids_io, *kb = keys_out, *ib = ids_out;
+    for (int shift = 0; shift < nbits; shift += 8) {
+        const int w = (nbits - shift) < 8 ? (nbits - shift) : 8;
+        const uint32_t mask = (1u << w) - 1u;
+        size_t cnt[257];
+        memset(cnt, 0, sizeof(cnt));
+        for (size_t i = 0; i < n; ++i) cnt[((ka[i] >> shift) & mask) + 1]++;
+        for (int d = 0; d < 256; ++d) cnt[d + 1] += cnt[d];
+        for (size_t i = 0; i < n; ++i) {
+            const size_t dst = cnt[(ka[i] >> shift) & mask]++;
+            kb[dst] = ka[i];
+            ib[dst] = ia[i];
+        }
+        uint32_t *t = ka; ka = kb; kb = t;
+        t = ia; ia = ib; ib = t;
+    }
+    if (ka != keys_out) {
+        memcpy(keys_out, ka, n * sizeof(uint32_t));
+        memcpy(ids_out, ia, n * sizeof(uint32_t));
+    } else {
+        memcpy(keys_io, ka, n * sizeof(uint32_t));
+        memcpy(ids_io, ia, n * sizeof(uint32_t));
+    }
+}
+
+/* compute_sorted_state_kernel (:384-416) */
+ORC_API void orc_compute_sorted_state(size_t n, const float *pos, const float *vel,
+                                      const float *vol, const float *C, const int *pids,
+                                      const uint32_t *sort_ids, float *npos, float *nvel,
+                                      float *nvol, float *nC, int *npids, int *index_mappings) {
+    for (size_t i = 0; i < n; ++i) {
+        const uint32_t s = sort_ids[i];
+        nvol[i] = vol[s];
+        npids[i] = pids[s];
+        index_mappings[npids[i]] = (int)i;
+        for (int d = 0; d < 3; ++d) {
+            npos[i * 3 + d] = pos[s * 3 + d];
+            nvel[i * 3 + d] = vel[s * 3 + d];
+        }
+        for (int d = 0; d < 9; ++d) nC[i * 9 + d] = C[s * 9 + d];
+    }
+}
+
+/* ------------------------------------------------------------------ */
+/* cloth constitutive model (cuda_mpm_kernels.cuh:72-181)              */
+/* ------------------------------------------------------------------ */
+static void fixed_corotated_pk1_2d(const orc_params *p, const float *F, float *P) { /* :72-86 */
+    float U[4], sig[4], V[4], R[4], Finv[4];
+    svd2(F, U, sig, V);
+    mmT(2, 2, 2, U, V, R);
+    const float J = det2(F);
+    inv2(F, Finv);
+    const float mu = p_mu(p), la = p_lambda(p);
+    P[0] = 2.f * mu * (F[0] - R[0]) + la * (J - 1.f) * J * Finv[0];
+    P[1] = 2.f * mu * (F[1] - R[1]) + la * (J - 1.f) * J * Finv[2];
+    P[2] = 2.f * mu * (F[2] - R[2]) + la * (J - 1.f) * J * Finv[1];
+    P[3] = 2.f * mu * (F[3] - R[3]) + la * (J - 1.f) * J * Finv[3];
+}
+
+static void compute_dphi_dF(const orc_params *p, const float *F, float *out) {     /* :88-144 */
+    float Q[9], R[9];
+    givens_qr(3, 3, F, Q, R);
+    const float Rhat[4] = {R[0], R[1], R[3], R[4]};
+    float P2[4];
+    fixed_corotated_pk1_2d(p, Rhat, P2);
+    const float Phat[9] = {P2[0], P2[1], 0.f, P2[2], P2[3], 0.f, 0.f, 0.f, 0.f};
+    float Pplane[9];
+    mm(3, 3, 3, Q, Phat, Pplane);
+    const float gp = p->gamma;
+    float fp = 0.f;
+    if (R[8] < 1.f) fp = -p->K * (1.f - R[8]) * (1.f - R[8]);
+    float A[9];
+    A[0] = gp * R[2] * R[2];
+    A[1] = gp * R[2] * R[5];
+    A[2] = gp * R[8] * R[2];
+    A[4] = gp * R[5] * R[5];
+    A[5] = gp * R[8] * R[8];
+    A[8] = fp * R[8];
+    A[3] = A[1];
+    A[6] = A[2];
+    A[7] = A[5];
+    float Rinv[9], QA[9], Pn[9];
+    inv3(R, Rinv);
+    mm(3, 3, 3, Q, A, QA);
+    mmT(3, 3, 3, QA, Rinv, Pn);
+    for (int i = 0; i < 9; ++i) out[i] = Pplane[i] + Pn[i];
+}
+
+static void project_strain(const orc_params *p, float *F) {                        /* :146-181 */
+    float Q[9], R[9];
+    givens_qr(3, 3, F, Q, R);
+    if (p->gamma == 0.f) {
+        R[8] = fminf(R[8], 1.f);
+        R[2] = 0.f;
+        R[5] = 0.f;
+    } else if (R[8] > 1.f) {
+        R[8] = fminf(R[8], 1.f);
+        R[2] = 0.f;
+        R[5] = 0.f;
+    } else if (R[8] <= 0.f) {
+        R[2] = 0.f;
+        R[5] = 0.f;
+        R[8] = fmaxf(R[8], -1.f);
+    } else {
+        const float rr = R[2] * R[2] + R[5] * R[5];
+        const float gok = p->gamma / p->K;
+        const float zz = p->cF * (R[8] - 1.f) * (R[8] - 1.f);
+        const float f = (gok * gok) * rr - (zz * zz);
+        if (f > 0.f) {
+            const float c = zz / (gok * sqrtf(rr));
+            R[2] *= c;
+            R[5] *= c;
+        }
+    }
+    mm(3, 3, 3, Q, R, F);
+}
+
+/* initialize_fem_state_kernel (:13-70); vertex volumes are summed in face order */
+ORC_API void orc_initialize_fem_state(const orc_params *p, size_t n_faces, const int *indices,
+                                      float *pos, float *vel, float *vol, float *F, float *DmInv) {
+    const float dx = p_dx(p);
+    for (size_t f = 0; f < n_faces; ++f) {
+        const int v0 = indices[f * 3], v1 = indices[f * 3 + 1], v2 = indices[f * 3 + 2];
+        for (int i = 0; i < 3; ++i) {
+            pos[f * 3 + i] = (pos[v0 * 3 + i] + pos[v1 * 3 + i] + pos[v2 * 3 + i]) / 3.f;
+            vel[f * 3 + i] = (vel[v0 * 3 + i] + vel[v1 * 3 + i] + vel[v2 * 3 + i]) / 3.f;
+        }
+        float D0[3], D1[3];
+        for (int i = 0; i < 3; ++i) {
+            D0[i] = pos[v1 * 3 + i] - pos[v0 * 3 + i];
+            D1[i] = pos[v2 * 3 + i] - pos[v0 * 3 + i];
+        }
+        const float Ds[6] = {D0[0], D1[0], D0[1], D1[1], D0[2], D1[2]};
+        float Q[9], R[6];
+        givens_qr(3, 2, Ds, Q, R);
+        const float Dm[4] = {R[0], R[1], 0.f, R[3]};
+        inv2(Dm, &DmInv[f * 4]);
+        for (int i = 0; i < 9; ++i) F[f * 9 + i] = Q[i];
+        const float cx = D0[1] * D1[2] - D1[1] * D0[2];
+        const float cy = D0[2] * D1[0] - D1[2] * D0[0];
+        const float cz = D0[0] * D1[1] - D1[0] * D0[1];
+        const float c[3] = {cx, cy, cz};
+        const float v4 = norm_n(3, c) / 8.f * dx;
+        vol[f] += v4;
+        vol[v0] += v4;
+        vol[v1] += v4;
+        vol[v2] += v4;
+    }
+}
+
+/* calc_fem_state_and_force_kernel (:183-294).  forces/taus must be zeroed by
+ * the caller (cuda_mpm_solver.cu:74-75).  Vertex forces are summed in face
+ * order when single-threaded. */
+ORC_API void orc_calc_fem_state_and_force(const orc_params *p, size_t n_faces, const int *indices,
+                                          const int *imap, const float *vol, const float *Caff,
+                                          const float *DmInv, float *pos, float *vel, float *Fdef,
+                                          float *forces, float *taus, float dt) {
+#pragma omp parallel for schedule(static)
+    for (long f = 0; f < (long)n_faces; ++f) {
+        const int fp = imap[f];
+        const int v0 = imap[indices[f * 3]], v1 = imap[indices[f * 3 + 1]],
+                  v2 = imap[indices[f * 3 + 2]];
+        for (int i = 0; i < 3; ++i) {
+            pos[fp * 3 + i] = (pos[v0 * 3 + i] + pos[v1 * 3 + i] + pos[v2 * 3 + i]) / 3.f;
+            vel[fp * 3 + i] = (vel[v0 * 3 + i] + vel[v1 * 3 + i] + vel[v2 * 3 + i]) / 3.f;
+        }
+        float *F = &Fdef[f * 9];
+        const float *C = &Caff[fp * 9];
+        float ctF[9];
+        ctF[0] = F[0];
+        ctF[1] = F[1];
+        ctF[2] = (1.f + dt * C[0]) * F[2] + dt * C[1] * F[5] + dt * C[2] * F[8];
+        ctF[3] = F[3];
+        ctF[4] = F[4];
+        ctF[5] = dt * C[3] * F[2] + (1.f + dt * C[4]) * F[5] + dt * C[5] * F[8];
+        ctF[6] = F[6];
+        ctF[7] = F[7];
+        ctF[8] = dt * C[6] * F[2] + dt * C[7] * F[5] + (1.f + dt * C[8]) * F[8];
+        project_strain(p, ctF);
+
+        float ds[6];
+        for (int i = 0; i < 3; ++i) {
+            ds[i * 2 + 0] = pos[v1 * 3 + i] - pos[v0 * 3 + i];
+            ds[i * 2 + 1] = pos[v2 * 3 + i] - pos[v0 * 3 + i];
+        }
+        const float *Dmi = &DmInv[f * 4];
+        float tF[6];
+        mm(3, 2, 2, ds, Dmi, tF);
+        ctF[0] = tF[0]; ctF[1] = tF[1];
+        ctF[3] = tF[2]; ctF[4] = tF[3];
+        ctF[6] = tF[4]; ctF[7] = tF[5];
+        for (int i = 0; i < 9; ++i) F[i] = ctF[i];
+
+        float VP[9];
+        compute_dphi_dF(p, ctF, VP);
+        for (int i = 0; i < 9; ++i) VP[i] *= vol[fp];
+
+        const float a[3] = {VP[2], VP[5], VP[8]};
+        const float b[3] = {ctF[2], ctF[5], ctF[8]};
+        for (int i = 0; i < 3; ++i)
+            for (int j = 0; j < 3; ++j) taus[fp * 9 + i * 3 + j] = a[i] * b[j];
+
+        const float gNh[6] = {-1.f, 1.f, 0.f, -1.f, 0.f, 1.f};
+        const float DmiT[4] = {Dmi[0], Dmi[2], Dmi[1], Dmi[3]};
+        float gN[6];
+        mm(2, 2, 3, DmiT, gNh, gN);
+        const float VP01[6] = {VP[0], VP[1], VP[3], VP[4], VP[6], VP[7]};
+        float G[9];
+        mm(3, 2, 3, VP01, gN, G);
+        for (int i = 0; i < 3; ++i) {
+#pragma omp atomic
+            forces[v0 * 3 + i] += -G[i * 3 + 0];
+#pragma omp atomic
+            forces[v1 * 3 + i] += -G[i * 3 + 1];
+#pragma omp atomic
+            forces[v2 * 3 + i] += -G[i * 3 + 2];
+        }
+    }
+}
+
+/* ------------------------------------------------------------------ */
+/* transfers                                                           */
+/* ------------------------------------------------------------------ */
+static inline void bspline(float fx, float *w0, float *w1, float *w2) { /* :470-476 */
+    *w0 = .5f * (1.5f - fx) * (1.5f - fx);
+    *w1 = .75f - (fx - 1.f) * (fx - 1.f);
+    *w2 = .5f * (fx - .5f) * (fx - .5f);
+}
+
+/* clean_grid_kernel (:585-602) */
+ORC_API void orc_clean_grid(uint32_t touched_cells, const uint32_t *ids, uint32_t *flags,
+                            float *gm, float *gmv) {
+    for (uint32_t i = 0; i < touched_cells; ++i) {
+        const uint32_t b = ids[i >> 6];
+        const uint32_t c = (b << 6) | (i & 63u);
+        flags[b] = 0;
+        gm[c] = 0.f;
+        gmv[c * 3] = gmv[c * 3 + 1] = gmv[c * 3 + 2] = 0.f;
+    }
+}
+
+/* particle_to_grid_kernel (:418-543), with every particle its own segment
+ * (the warp-level run reduction of :438-457,520-528 only regroups the same
+ * additions).  Grid sums are accumulated in particle order when single
+ * threaded. */
+ORC_API void orc_particle_to_grid(const orc_params *p, size_t n, const float *pos, const float *vel,
+                                  const float *vol, const float *Caff, const float *forces,
+                                  const float *taus, uint32_t *flags, float *gm, float *gmv,
+                                  float dt) {
+    const float dxinv = p_dxinv(p), dx = p_dx(p), dinv = p_dinv(p);
+    const int gax = p->gravity_axis;
+#pragma omp parallel for schedule(static)
+    for (long q = 0; q < (long)n; ++q) {
+        uint32_t base[3];
+        float fx[3], w[3][3];
+        for (int d = 0; d < 3; ++d) {
+            base[d] = f2u(pos[q * 3 + d] * dxinv - .5f);
+            fx[d] = pos[q * 3 + d] * dxinv - (float)base[d];
+            bspline(fx[d], &w[0][d], &w[1][d], &w[2][d]);
+        }
+        const float mass = vol[q] * p->density;
+        const float *v = &vel[q * 3];
+        float B[9];
+        for (int i = 0; i < 9; ++i) B[i] = (-dt * dinv) * taus[q * 9 + i] + Caff[q * 9 + i] * mass;
+        const float *frc = &forces[q * 3];
+        for (int i = 0; i < 3; ++i)
+            for (int j = 0; j < 3; ++j)
+                for (int k = 0; k < 3; ++k) {
+                    const float xr[3] = {((float)i - fx[0]) * dx, ((float)j - fx[1]) * dx,
+                                         ((float)k - fx[2]) * dx};
+                    const float wt = w[i][0] * w[j][1] * w[k][2];
+                    float val[4];
+                    val[0] = mass * wt;
+                    val[1] = v[0] * val[0];
+                    val[2] = v[1] * val[0];
+                    val[3] = v[2] * val[0];
+                    val[gax + 1] += val[0] * p->gravity * dt;
+                    val[1] += (B[0] * xr[0] + B[1] * xr[1] + B[2] * xr[2]) * wt;
+                    val[2] += (B[3] * xr[0] + B[4] * xr[1] + B[5] * xr[2]) * wt;
+                    val[3] += (B[6] * xr[0] + B[7] * xr[1] + B[8] * xr[2]) * wt;
+                    val[1] += frc[0] * dt * wt;
+                    val[2] += frc[1] * dt * wt;
+                    val[3] += frc[2] * dt * wt;
+                    const uint32_t c = orc_cell_index(base[0] + i, base[1] + j, base[2] + k);
+                    flags[c >> 6] = 1;
+#pragma omp atomic
+                    gm[c] += val[0];
+#pragma omp atomic
+                    gmv[c * 3 + 0] += val[1];
+#pragma omp atomic
+                    gmv[c * 3 + 1] += val[2];
+#pragma omp atomic
+                    gmv[c * 3 + 2] += val[3];
+                }
+    }
+}
+
+/* gather_touched_grid_kernel (:545-583): the reference compacts flagged blocks
+ * in a nondeterministic order; the restatement emits them in ascending id. */
+ORC_API uint32_t orc_gather_touched(uint32_t n_blocks, const uint32_t *flags, uint32_t *ids) {
+    uint32_t cnt = 0;
+    for (uint32_t b = 0; b < n_blocks; ++b)
+        if (flags[b]) ids[cnt++] = b;
+    return cnt;
+}
+
+static int sphere_hit(const float *pos, float cx, float cy, float cz, float r, float *nrm,
+                      float *dist) {
+    const float d[3] = {pos[0] - cx, pos[1] - cy, pos[2] - cz};
+    const float len = sqrtf(norm_sqr_n(3, d));
+    *dist = len - r;
+    const float inv = (float)(1.0 / (double)len); /* normalize<3> (math_tools.cuh:77-84) */
+    nrm[0] = d[0] * inv; nrm[1] = d[1] * inv; nrm[2] = d[2] * inv;
+    return *dist < 0.f;
+}
+
+/* update_grid_kernel<T,BC> (:632-796) */
+ORC_API void orc_update_grid(const orc_params *p, int bc, uint32_t touched_cells,
+                             const uint32_t *ids, const float *gm, float *gmv, float *gvs) {
+    const int N = 1 << p->domain_bits, wall = p->wall;
+    const float dx = p_dx(p);
+#pragma omp parallel for schedule(static)
+    for (long t = 0; t < (long)touched_cells; ++t) {
+        const uint32_t c = (ids[t >> 6] << 6) | ((uint32_t)t & 63u);
+        if (!(gm[c] > 0.f)) continue;
+        float *gv = &gmv[c * 3];
+        gv[0] /= gm[c];
+        gv[1] /= gm[c];
+        gv[2] /= gm[c];
+        uint32_t xyz[3];
+        orc_inverse_cell_index(c, xyz);
+        for (int d = 0; d < 3; ++d) {
+            if ((int)xyz[d] < wall && gv[d] < 0.f) gv[d] = 0.f;
+            if ((int)xyz[d] >= N - wall && gv[d] > 0.f) gv[d] = 0.f;
+        }
+        const float pos[3] = {((float)xyz[0] + .5f) * dx, ((float)xyz[1] + .5f) * dx,
+                              ((float)xyz[2] + .5f) * dx};
+        int fixed = 0, inside = 0;
+        float dist = 0.f, dv[3] = {0.f, 0.f, 0.f}, nrm[3] = {0.f, 0.f, 0.f}, dotnv = 0.f;
+        if (bc == 0) {                                         /* :673-692 */
+            if (sphere_hit(pos, .5f, .5f, .5f, .08f, nrm, &dist)) {
+                dv[0] = -gv[0]; dv[1] = -gv[1]; dv[2] = -gv[2];
+                dotnv = dotn(3, nrm, dv);
+                if (dotnv > 0.f || fixed) inside = 1;
+            }
+        } else if (bc == 1) {                                  /* :694-734 */
+            fixed = 1;
+            if (sphere_hit(pos, .38f, .38f, .75f, .04f, nrm, &dist)) {
+                dv[0] = -gv[0]; dv[1] = -gv[1]; dv[2] = -gv[2];
+                dotnv = dotn(3, nrm, dv);
+                inside = 1;
+            } else if (sphere_hit(pos, .38f, .62f, .75f, .04f, nrm, &dist)) {
+                dv[0] = -gv[0]; dv[1] = -gv[1]; dv[2] = -gv[2];
+                dotnv = dotn(3, nrm, dv);
+                inside = 1;
+            }
+        } else if (bc == 2) {                                  /* :737-749 */
+            nrm[0] = 0.f; nrm[1] = 0.f; nrm[2] = 1.f;
+            dist = pos[2] - .11f;
+            if (dist < 0.f) {
+                inside = 1;
+                dv[0] = -gv[0]; dv[1] = -gv[1]; dv[2] = -gv[2];
+                dotnv = dotn(3, dv, nrm);
+            }
+        } else if (bc == 3) {                                  /* :752-774 */
+            fixed = 1;
+            const float span[2] = {.3f, .7f};
+            for (int s = 0; s < 4; ++s) {
+                if (sphere_hit(pos, span[s % 2], span[s / 2], .5f, .02f, nrm, &dist)) {
+                    dv[0] = -gv[0]; dv[1] = -gv[1]; dv[2] = -gv[2];
+                    dotnv = dotn(3, nrm, dv);
+                    inside = 1;
+                    break;
+                }
+            }
+        }
+        if (inside) {                                          /* :777-788 */
+            if (fixed) {
+                gv[0] += dv[0]; gv[1] += dv[1]; gv[2] += dv[2];
+            } else {
+                const float fr = p->sdf_friction;
+                const float frac = (float)((double)dotnv * (1.0 - (double)fr));
+                gv[0] += dv[0] * fr + nrm[0] * frac;
+                gv[1] += dv[1] * fr + nrm[1] * frac;
+                gv[2] += dv[2] * fr + nrm[2] * frac;
+            }
+        }
+        gvs[c * 3 + 0] = gv[0];
+        gvs[c * 3 + 1] = gv[1];
+        gvs[c * 3 + 2] = gv[2];
+    }
+}
+
+/* grid_to_particle_kernel<T,BLOCK,CONTACT_TRANSFER> (:798-924) */
+ORC_API void orc_grid_to_particle(const orc_params *p, size_t n, float *pos, float *vel,
+                                  float *Caff, const float *gm, const float *gv, float dt,
+                                  int contact_transfer) {
+    const float dxinv = p_dxinv(p);
+    const float ca = (p->V + 1.f) * .5f, cb = (p->V - 1.f) * .5f;
+#pragma omp parallel for schedule(static)
+    for (long q = 0; q < (long)n; ++q) {
+        uint32_t base[3];
+        float fx[3], w[3][3];
+        for (int d = 0; d < 3; ++d) {
+            base[d] = f2u(pos[q * 3 + d] * dxinv - .5f);
+            fx[d] = pos[q * 3 + d] * dxinv - (float)base[d];
+            bspline(fx[d], &w[0][d], &w[1][d], &w[2][d]);
+        }
+        float nv[3] = {0.f, 0.f, 0.f}, nC[9] = {0.f};
+        for (int i = 0; i < 3; ++i)
+            for (int j = 0; j < 3; ++j)
+                for (int k = 0; k < 3; ++k) {
+                    const float xr[3] = {(float)i - fx[0], (float)j - fx[1], (float)k - fx[2]};
+                    const uint32_t c = orc_cell_index(base[0] + i, base[1] + j, base[2] + k);
+                    const float *g = &gv[c * 3];
+                    const float wt = w[i][0] * w[j][1] * w[k][2];
+                    if (contact_transfer) {
+                        if (gm[c] > 1e-7f) {
+                            nv[0] += wt * g[0];
+                            nv[1] += wt * g[1];
+                            nv[2] += wt * g[2];
+                        }
+                    } else {
+                        nv[0] += wt * g[0];
+                        nv[1] += wt * g[1];
+                        nv[2] += wt * g[2];
+                        for (int a = 0; a < 3; ++a)
+                            for (int b = 0; b < 3; ++b)
+                                nC[a * 3 + b] += 4.f * dxinv * wt * g[a] * xr[b];
+                    }
+                }
+        vel[q * 3 + 0] = nv[0];
+        vel[q * 3 + 1] = nv[1];
+        vel[q * 3 + 2] = nv[2];
+        if (!contact_transfer) {
+            for (int a = 0; a < 3; ++a)
+                for (int b = 0; b < 3; ++b)
+                    Caff[q * 9 + a * 3 + b] = ca * nC[a * 3 + b] + cb * nC[b * 3 + a];
+            pos[q * 3 + 0] += nv[0] * dt;
+            pos[q * 3 + 1] += nv[1] * dt;
+            pos[q * 3 + 2] += nv[2] * dt;
+        }
+    }
+}
+
+/* ------------------------------------------------------------------ */
+/* contact (cuda_mpm_kernels.cuh:926-1658, cuda_mpm_solver.cu:193-621) */
+/* ------------------------------------------------------------------ */
+
+/* initialize_contact_velocities (:926-938) */
+ORC_API void orc_initialize_contact_velocities(size_t nk, float *cvel, const uint32_t *cid,
+                                               const float *vel) {
+    for (size_t k = 0; k < nk; ++k)
+        for (int i = 0; i < 3; ++i) cvel[k * 3 + i] = vel[cid[k] * 3 + i];
+}
+
+/* compute_contact_grad_and_hess (:956-1040) */
+static void contact_grad_hess(const orc_params *p, float phi0, float dt, float k, float d, float mu,
+                              const float *v0, const float *vn, float *H, float *g) {
+    const float v_hat = fminf(phi0 / dt, 1.f / d);
+    if (v0[2] > v_hat) {
+        for (int i = 0; i < 9; ++i) H[i] = 0.f;
+        for (int i = 0; i < 3; ++i) g[i] = 0.f;
+        return;
+    }
+    const float yn = k * dt * (phi0 - dt * vn[2]) * (1.f - d * vn[2]);
+    const float d2n = k * dt * (-dt - d * phi0 + 2.f * d * dt * vn[2]);
+    const float yn0 = fmaxf(k * dt * phi0 * (1.f - d * v0[2]), 0.f);
+    const float ts = sqrtf(vn[0] * vn[0] + vn[1] * vn[1] + p->epsv * p->epsv);
+    const float th[2] = {vn[0] / ts, vn[1] / ts};
+    const float yt[2] = {-mu * yn0 * th[0], -mu * yn0 * th[1]};
+    const float Pt[4] = {th[0] * th[0], th[0] * th[1], th[1] * th[0], th[1] * th[1]};
+    const float Pp[4] = {1.f - Pt[0], -Pt[1], -Pt[2], 1.f - Pt[3]};
+    const float co = -mu * yn0 / ts;
+    H[0] = co * Pp[0]; H[1] = co * Pp[1]; H[2] = 0.f;
+    H[3] = co * Pp[2]; H[4] = co * Pp[3]; H[5] = 0.f;
+    H[6] = 0.f; H[7] = 0.f; H[8] = d2n;
+    g[0] = yt[0]; g[1] = yt[1]; g[2] = yn;
+}
+
+/* contact cost l(v) (:1425-1435) */
+static float contact_cost(const orc_params *p, float phi0, float dt, float k, float d, float mu,
+                          const float *v0, const float *v) {
+    const float v_hat = fminf(phi0 / dt, 1.f / d);
+    const float yn0 = fmaxf(k * dt * phi0 * (1.f - d * v0[2]), 0.f);
+    const float lt = mu * yn0 * (sqrtf(v[0] * v[0] + v[1] * v[1] + p->epsv * p->epsv) - p->epsv);
+    const float vn = fminf(v_hat, v[2]);
+    const float a = k * d * dt * dt;
+    const float b = -(k * dt * (dt + d * phi0));
+    const float c = k * dt * phi0;
+    const float third = (float)(1. / 3.), half = (float)(1. / 2.);
+    const float ln = -(third * a * vn * vn * vn + half * b * vn * vn + c * vn);
+    return lt + ln;
+}
+
+typedef struct {
+    float base_w[3][3];
+    uint32_t base[3];
+} stencil_t;
+
+static void make_stencil(const orc_params *p, const float *x, stencil_t *s) {
+    const float dxinv = p_dxinv(p);
+    for (int d = 0; d < 3; ++d) {
+        s->base[d] = f2u(x[d] * dxinv - .5f);
+        const float fx = x[d] * dxinv - (float)s->base[d];
+        bspline(fx, &s->base_w[0][d], &s->base_w[1][d], &s->base_w[2][d]);
+    }
+}
+
+/* contact_particle_to_grid_kernel<T,32,JACOBI=true> (:1042-1215) */
+ORC_API void orc_contact_p2g(const orc_params *p, size_t nk, const float *cpos, const float *cvel,
+                             const float *vel, const float *vol, const uint32_t *cid,
+                             const float *cdist, const float *cnormal, const float *crv,
+                             float *gH, float *gG, float dt, float mu, float k, float d) {
+    for (size_t q = 0; q < nk; ++q) {
+        stencil_t st;
+        make_stencil(p, &cpos[q * 3], &st);
+        const float mass = vol[cid[q]] * p->density;
+        const float *pv0 = &vel[cid[q] * 3];
+        const float *pv = &cvel[q * 3];
+        const float nh[3] = {-cnormal[q * 3], -cnormal[q * 3 + 1], -cnormal[q * 3 + 2]};
+        const float phi0 = -cdist[q];
+        const float v0r[3] = {pv0[0] - crv[q * 3], pv0[1] - crv[q * 3 + 1], pv0[2] - crv[q * 3 + 2]};
+        const float vr[3] = {pv[0] - crv[q * 3], pv[1] - crv[q * 3 + 1], pv[2] - crv[q * 3 + 2]};
+        float RWC[9], RCW[9];
+        frame_from_unit(nh, 2, RWC);
+        for (int i = 0; i < 3; ++i)
+            for (int j = 0; j < 3; ++j) RCW[j * 3 + i] = RWC[i * 3 + j];
+        float v0[3], vn[3];
+        mm(3, 3, 1, RWC, v0r, v0);
+        mm(3, 3, 1, RWC, vr, vn);
+        float CH[9], CG[3];
+        contact_grad_hess(p, phi0, dt, k, d, mu, v0, vn, CH, CG);
+        float WH[9], WG[3], tmp[9];
+        mm(3, 3, 1, RCW, CG, WG);
+        mm(3, 3, 3, RCW, CH, tmp);
+        mm(3, 3, 3, tmp, RWC, WH);
+        for (int i = 0; i < 3; ++i)
+            for (int j = 0; j < 3; ++j)
+                for (int kk = 0; kk < 3; ++kk) {
+                    const float wt = st.base_w[i][0] * st.base_w[j][1] * st.base_w[kk][2];
+                    const uint32_t c =
+                        orc_cell_index(st.base[0] + i, st.base[1] + j, st.base[2] + kk);
+                    for (int a = 0; a < 9; ++a) gH[c * 9 + a] += mass * wt * wt * WH[a];
+                    for (int a = 0; a < 3; ++a) gG[c * 3 + a] += mass * wt * WG[a];
+                }
+    }
+}
+
+/* clean_grid_contact_kernel (:604-630) */
+ORC_API void orc_clean_grid_contact(uint32_t touched_cells, const uint32_t *ids, float *gH,
+                                    float *gG, float *gD, float *galpha, float *gE0, float *gE1) {
+    for (uint32_t t = 0; t < touched_cells; ++t) {
+        const uint32_t c = (ids[t >> 6] << 6) | (t & 63u);
+        galpha[c] = -1.f;
+        for (int i = 0; i < 3; ++i) gG[c * 3 + i] = 0.f, gD[c * 3 + i] = 0.f;
+        for (int i = 0; i < 9; ++i) gH[c * 9 + i] = 0.f;
+        gE0[c] = 0.f;
+        gE1[c] = 0.f;
+    }
+}
+
+/* update_grid_contact_coordinate_descent_kernel<T,JACOBI=true> (:1217-1274).
+ * Returns the two global scalars through norm_dir / dofs. */
+ORC_API void orc_contact_grid_direction(uint32_t touched_cells, const uint32_t *ids,
+                                        const float *gm, const float *gvs, float *gH, float *gG,
+                                        const float *gv, float *gD, float *galpha, float *gE0,
+                                        float *gE1, float relax, float *norm_dir, uint32_t *dofs) {
+    for (uint32_t t = 0; t < touched_cells; ++t) {
+        const uint32_t c = (ids[t >> 6] << 6) | (t & 63u);
+        if (!(gm[c] > 0.f)) continue;
+        if (!((double)norm_n(9, &gH[c * 9]) > 1e-7 || (double)norm_n(3, &gG[c * 3]) > 1e-7))
+            continue;
+        const float m = gm[c];
+        float *H = &gH[c * 9], *G = &gG[c * 3], *D = &gD[c * 3];
+        H[0] -= m; H[4] -= m; H[8] -= m;
+        for (int i = 0; i < 3; ++i) G[i] -= m * (gv[c * 3 + i] - gvs[c * 3 + i]);
+        float Hi[9];
+        inv3(H, Hi);
+        mm(3, 3, 1, Hi, G, D);
+        *norm_dir += norm_sqr_n(3, D);
+        *dofs += 1u;
+        for (int i = 0; i < 3; ++i) D[i] *= relax;
+        galpha[c] = 1.f;
+        gE0[c] = 0.f;
+        gE1[c] = 0.f;
+    }
+}
+
+/* grid_to_particle_vdb_line_search_kernel<T,32,JACOBI=true,SOLVE_DF_DDF> with
+ * global_line_search=true (:1276-1473).  E0 is accumulated only if eval_E0;
+ * dE/d2E only if want_derivs. */
+ORC_API void orc_contact_line_search_eval(const orc_params *p, size_t nk, const float *cpos,
+                                          const float *vel, const float *vol, const uint32_t *cid,
+                                          const float *cdist, const float *cnormal,
+                                          const float *crv, const float *gv, const float *gD,
+                                          float dt, float mu, float k, float d, int eval_E0,
+                                          int want_derivs, float alpha, float *E0, float *E1,
+                                          float *dE1, float *d2E1) {
+    for (size_t q = 0; q < nk; ++q) {
+        stencil_t st;
+        make_stencil(p, &cpos[q * 3], &st);
+        float ov[3] = {0.f, 0.f, 0.f}, nv[3] = {0.f, 0.f, 0.f}, gd[3] = {0.f, 0.f, 0.f};
+        for (int i = 0; i < 3; ++i)
+            for (int j = 0; j < 3; ++j)
+                for (int kk = 0; kk < 3; ++kk) {
+                    const uint32_t c =
+                        orc_cell_index(st.base[0] + i, st.base[1] + j, st.base[2] + kk);
+                    const float wt = st.base_w[i][0] * st.base_w[j][1] * st.base_w[kk][2];
+                    for (int a = 0; a < 3; ++a) {
+                        ov[a] += wt * gv[c * 3 + a];
+                        nv[a] += wt * (gv[c * 3 + a] - alpha * gD[c * 3 + a]);
+                        gd[a] += wt * gD[c * 3 + a];
+                    }
+                }
+        const float mass = vol[cid[q]] * p->density;
+        const float *pv0 = &vel[cid[q] * 3];
+        const float nh[3] = {-cnormal[q * 3], -cnormal[q * 3 + 1], -cnormal[q * 3 + 2]};
+        const float phi0 = -cdist[q];
+        float v0r[3], vor[3], vnr[3];
+        for (int a = 0; a < 3; ++a) {
+            v0r[a] = pv0[a] - crv[q * 3 + a];
+            vor[a] = ov[a] - crv[q * 3 + a];
+            vnr[a] = nv[a] - crv[q * 3 + a];
+        }
+        float RWC[9];
+        frame_from_unit(nh, 2, RWC);
+        float v0[3], vol_[3], vnl[3];
+        mm(3, 3, 1, RWC, v0r, v0);
+        mm(3, 3, 1, RWC, vor, vol_);
+        mm(3, 3, 1, RWC, vnr, vnl);
+        *E1 += mass * contact_cost(p, phi0, dt, k, d, mu, v0, vnl);
+        if (want_derivs) {
+            float CH[9], CG[3], Rd[3], tmp[3];
+            contact_grad_hess(p, phi0, dt, k, d, mu, v0, vnl, CH, CG);
+            mm(3, 3, 1, RWC, gd, Rd);
+            *dE1 += mass * dotn(3, CG, Rd);
+            mm(1, 3, 3, Rd, CH, tmp);
+            *d2E1 += mass * dotn(3, tmp, Rd);
+        }
+        if (eval_E0) *E0 += mass * contact_cost(p, phi0, dt, k, d, mu, v0, vol_);
+    }
+}
+
+/* update_global_energy_grid_kernel<T,JACOBI=true,SOLVE_DF_DDF> (:1536-1589) */
+ORC_API void orc_contact_grid_energy(uint32_t touched_cells, const uint32_t *ids, const float *gm,
+                                     const float *gvs, const float *gv, const float *gD,
+                                     float alpha, int eval_E0, int want_derivs, float *E0,
+                                     float *E1, float *dE1, float *d2E1) {
+    for (uint32_t t = 0; t < touched_cells; ++t) {
+        const uint32_t c = (ids[t >> 6] << 6) | (t & 63u);
+        if (!(gm[c] > 0.f)) continue;
+        const float m = gm[c];
+        float o[3], n[3];
+        for (int a = 0; a < 3; ++a) {
+            o[a] = gv[c * 3 + a] - gvs[c * 3 + a];
+            n[a] = gv[c * 3 + a] - alpha * gD[c * 3 + a] - gvs[c * 3 + a];
+        }
+        if (eval_E0) *E0 += .5f * m * norm_sqr_n(3, o);
+        *E1 += .5f * m * norm_sqr_n(3, n);
+        if (want_derivs) {
+            *dE1 += -m * dotn(3, n, &gD[c * 3]);
+            *d2E1 += m * norm_sqr_n(3, &gD[c * 3]);
+        }
+    }
+}
+
+/* apply_global_line_search_grid_kernel<T,JACOBI=true> (:1591-1614) */
+ORC_API void orc_contact_apply_alpha(uint32_t touched_cells, const uint32_t *ids, const float *gm,
+                                     float *gv, const float *gD, float alpha) {
+    for (uint32_t t = 0; t < touched_cells; ++t) {
+        const uint32_t c = (ids[t >> 6] << 6) | (t & 63u);
+        if (!(gm[c] > 0.f)) continue;
+        for (int a = 0; a < 3; ++a) gv[c * 3 + a] -= alpha * gD[c * 3 + a];
+    }
+}
+
+/* apply_contact_impulse_to_rigid_bodies (:1616-1658) */
+ORC_API void orc_contact_rigid_impulse(const orc_params *p, size_t nk, const float *cpos,
+                                       const float *cvel0, const float *cvel, const float *vol,
+                                       const uint32_t *cid, const uint32_t *crid,
+                                       const float *cpwb, float *tau, float *frc) {
+    for (size_t q = 0; q < nk; ++q) {
+        const float m = vol[cid[q]] * p->density;
+        float l[3], r[3];
+        for (int a = 0; a < 3; ++a) {
+            const float dv = cvel[q * 3 + a] - cvel0[q * 3 + a];
+            l[a] = m * -dv;
+            r[a] = cpos[q * 3 + a] - cpwb[q * 3 + a];
+        }
+        const float h[3] = {r[1] * l[2] - l[1] * r[2], r[2] * l[0] - l[2] * r[0],
+                            r[0] * l[1] - l[0] * r[1]};
+        for (int a = 0; a < 3; ++a) {
+            tau[crid[q] * 3 + a] += h[a];
+            frc[crid[q] * 3 + a] += l[a];
+        }
+    }
+}
+
+typedef struct {
+    float E, dE, d2E;
+} ls_eval;
+
+typedef struct {
+    const orc_params *p;
+    size_t nk;
+    uint32_t tc;
+    const uint32_t *ids;
+    const float *cpos, *vel, *vol, *cdist, *cnormal, *crv, *gm, *gvs;
+    const uint32_t *cid;
+    float *gv, *gD;
+    float dt, mu, k, d;
+} ls_ctx;
+
+/* the `line_search` lambda of cuda_mpm_solver.cu:323-365 */
+static ls_eval ls_full(const ls_ctx *c, float alpha) {
+    float E1 = 0.f, dE = 0.f, d2E = 0.f, E0 = 0.f;
+    orc_contact_line_search_eval(c->p, c->nk, c->cpos, c->vel, c->vol, c->cid, c->cdist,
+                                 c->cnormal, c->crv, c->gv, c->gD, c->dt, c->mu, c->k, c->d, 0, 1,
+                                 alpha, &E0, &E1, &dE, &d2E);
+    orc_contact_grid_energy(c->tc, c->ids, c->gm, c->gvs, c->gv, c->gD, alpha, 0, 1, &E0, &E1, &dE,
+                            &d2E);
+    ls_eval r = {E1, dE, d2E};
+    return r;
+}
+static int sgn(float v) { return v > 0.f ? 1 : (v < 0.f ? -1 : 0); }
+
+/* GpuMpmSolver::UpdateContact (cuda_mpm_solver.cu:214-621), Jacobi branch.
+ * Grid arrays are dense, indexed by cell key.  On exit gv holds the post
+ * contact grid velocities, cvel/cvel0 the contact velocities, tau/frc the
+ * accumulated rigid impulses.  Returns the Newton iteration count. */
+ORC_API int orc_update_contact(const orc_params *p, size_t nk, const float *cpos, float *cvel,
+                               float *cvel0, const float *vel, const float *vol,
+                               const uint32_t *cid, const uint32_t *crid, const float *cdist,
+                               const float *cnormal, const float *crv, const float *cpwb,
+                               uint32_t touched_blocks, const uint32_t *ids, const float *gm,
+                               float *gv, const float *gvs, float *gH, float *gG, float *gD,
+                               float *galpha, float *gE0, float *gE1, float *tau, float *frc,
+                               float dt, float mu, float k, float d, int exact_line_search,
+                               int max_iters, float *residual_out, float *ls_avg_out,
+                               float *energy_out) {
+    if (!nk) return 0;                                           /* :216-217 */
+    const uint32_t tc = touched_blocks * 64u;
+    const float kTol = 1e-4f, relax = 0.3f;                      /* :236,239 */
+    if (max_iters <= 0) max_iters = 2000;                        /* :234 */
+    float norm_dir = 1e10f;
+    int count = 0;
+    long ls_total = 0;
+    float last_energy = 0.f;
+    size_t n3 = nk * 3;
+    float *pos_tmp = (float *)malloc(n3 * sizeof(float));
+    /* pre-contact velocity at contact points (:267-272) */
+    memcpy(pos_tmp, cpos, n3 * sizeof(float));
+    orc_grid_to_particle(p, nk, pos_tmp, cvel0, NULL, gm, gv, dt, 1);
+    ls_ctx ctx = {p, nk, tc, ids, cpos, vel, vol, cdist, cnormal, crv, gm, gvs, cid, gv, gD,
+                  dt, mu, k, d};
+    while (norm_dir > kTol && count < max_iters) {               /* :274 */
+        float nd = 0.f, E0 = 0.f, E1 = 0.f;
+        uint32_t dofs = 0;
+        if (tc > 0) orc_clean_grid_contact(tc, ids, gH, gG, gD, galpha, gE0, gE1);
+        orc_contact_p2g(p, nk, cpos, cvel, vel, vol, cid, cdist, cnormal, crv, gH, gG, dt, mu, k,
+                        d);
+        orc_contact_grid_direction(tc, ids, gm, gvs, gH, gG, gv, gD, galpha, gE0, gE1, relax, &nd,
+                                   &dofs);
+        int ls_cnt = 0;
+        float alpha = 1.f;
+        if (exact_line_search) {                                 /* :383-471 */
+            const float f_tol = 1e-8f;
+            const float x_tol = f_tol * relax;
+            float x_lo = 0.f, x_hi = 1.f, root;
+            ls_eval f_lo = ls_full(&ctx, 0.f), f_hi = ls_full(&ctx, 1.f), f_root = {0, 0, 0};
+            if (f_lo.dE < 0.f && f_hi.dE < 0.f) {
+                x_lo = 1.f;
+                f_lo = f_hi;
+            }
+            (void)f_lo;
+            root = x_hi;
+            float mdx = x_lo - x_hi, mdx_prev = mdx;
+            int done = 0;
+            while (!done) {
+                f_root = ls_full(&ctx, root);
+                if (sgn(f_root.dE) != sgn(f_hi.dE)) {
+                    x_lo = root;
+                    f_lo = f_root;
+                } else {
+                    x_hi = root;
+                    f_hi = f_root;
+                }
+                if (fabsf(f_root.dE) < f_tol) done = 1;
+                const int slow = 2.f * fabsf(f_root.dE) > fabsf(mdx_prev * f_root.d2E);
+                mdx_prev = mdx;
+                if (slow) {
+                    mdx = .5f * (x_lo - x_hi);
+                    root = x_lo - mdx;
+                } else {
+                    mdx = f_root.dE / f_root.d2E;
+                    const float x = root - mdx;
+                    if (x_lo <= x && x <= x_hi) {
+                        root = x;
+                    } else {
+                        mdx = .5f * (x_lo - x_hi);
+                        root = x_lo - mdx;
+                    }
+                }
+                if (fabsf(mdx) < x_tol) done = 1;
+                if (done) {
+                    E1 = f_root.E;
+                    alpha = root;
+                }
+                ls_cnt += 1;
+            }
+        } else {                                                 /* :472-528 */
+            int done = 0;
+            while (!done) {
+                E1 = 0.f;
+                float dE = 0.f, d2E = 0.f;
+                orc_contact_line_search_eval(p, nk, cpos, vel, vol, cid, cdist, cnormal, crv, gv, gD,
+                                             dt, mu, k, d, ls_cnt == 0, 0, alpha, &E0, &E1, &dE,
+                                             &d2E);
+                orc_contact_grid_energy(tc, ids, gm, gvs, gv, gD, alpha, ls_cnt == 0, 0, &E0, &E1,
+                                        &dE, &d2E);
+                if (E1 <= E0) {
+                    done = 1;
+                } else {
+                    alpha /= 2.f;
+                    if (alpha < 1e-8f) done = 1; /* "Tiny Alpha" (:523-526) */
+                }
+                ls_cnt += 1;
+            }
+        }
+        ls_total += ls_cnt;
+        last_energy = E1;
+        orc_contact_apply_alpha(tc, ids, gm, gv, gD, alpha);     /* :532-539 */
+        memcpy(pos_tmp, cpos, n3 * sizeof(float));
+        orc_grid_to_particle(p, nk, pos_tmp, cvel, NULL, gm, gv, dt, 1); /* :557-562 */
+        norm_dir = sqrtf(nd) / (float)(int)dofs;                 /* :567-569 */
+        count += 1;
+    }
+    free(pos_tmp);
+    orc_contact_rigid_impulse(p, nk, cpos, cvel0, cvel, vol, cid, crid, cpwb, tau, frc); /* :615 */
+    if (residual_out) *residual_out = norm_dir;
+    if (ls_avg_out) *ls_avg_out = count ? (float)ls_total / (float)count : 0.f;
+    if (energy_out) *energy_out = last_energy;
+    return count;
+}
+
+/* ------------------------------------------------------------------ */
+/* thin wrappers so the known-answer tests can reach the static helpers */
+/* ------------------------------------------------------------------ */
+ORC_API void orc_kat_givens_qr33(const float *A, float *Q, float *R) { givens_qr(3, 3, A, Q, R); }
+ORC_API void orc_kat_givens_qr32(const float *A, float *Q, float *R) { givens_qr(3, 2, A, Q, R); }
+ORC_API void orc_kat_dphi_dF(const orc_params *p, const float *F, float *P) {
+    compute_dphi_dF(p, F, P);
+}
+ORC_API void orc_kat_project_strain(const orc_params *p, float *F) { project_strain(p, F); }
+ORC_API void orc_kat_svd2(const float *A, float *U, float *s, float *V) { svd2(A, U, s, V); }
+ORC_API void orc_kat_pk1_2d(const orc_params *p, const float *F, float *P) {
+    fixed_corotated_pk1_2d(p, F, P);
+}
+ORC_API void orc_kat_frame(const float *u, int axis, float *J) { frame_from_unit(u, axis, J); }
+ORC_API void orc_kat_contact_grad_hess(const orc_params *p, float phi0, float dt, float k, float d,
+                                       float mu, const float *v0, const float *vn, float *H,
+                                       float *g) {
+    contact_grad_hess(p, phi0, dt, k, d, mu, v0, vn, H, g);
+}
+ORC_API float orc_kat_contact_cost(const orc_params *p, float phi0, float dt, float k, float d,
+                                   float mu, const float *v0, const float *v) {
+    return contact_cost(p, phi0, dt, k, d, mu, v0, v);
+}

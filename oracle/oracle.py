@@ -1,0 +1,310 @@
+"""ctypes front end of the CPU oracle (oracle/mpm_oracle.c).
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and the
+cpu_baseline leg of bench.py.  Nothing under drake_amd/ may import this module.
+
+`OracleMpm` mirrors the reference's GpuMpmState + GpuMpmSolver pair
+(multibody/gpu_mpm/cuda_mpm_model.cuh:37-260, cuda_mpm_solver.cuh:19-35) on
+numpy arrays laid out like the reference's device buffers (array of small
+vectors, dense grid indexed by cell key).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "libmpm_oracle.so")
+_lib = None
+
+
+class Params(C.Structure):
+    _fields_ = [
+        ("domain_bits", C.c_int),
+        ("wall", C.c_int),
+        ("gravity_axis", C.c_int),
+        ("youngs", C.c_float),
+        ("poisson", C.c_float),
+        ("density", C.c_float),
+        ("gamma", C.c_float),
+        ("K", C.c_float),
+        ("V", C.c_float),
+        ("cF", C.c_float),
+        ("sdf_friction", C.c_float),
+        ("gravity", C.c_float),
+        ("epsv", C.c_float),
+    ]
+
+
+def build(force: bool = False) -> str:
+    """Compile the oracle with gcc (a few seconds)."""
+    src = os.path.join(_HERE, "mpm_oracle.c")
+    if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", _HERE, "-s", "-B", "libmpm_oracle.so"])
+    return _LIB_PATH
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        _lib = C.CDLL(_LIB_PATH)
+        _lib.orc_cell_index.restype = C.c_uint32
+        _lib.orc_cell_index.argtypes = [C.c_uint32] * 3
+        _lib.orc_morton_code.restype = C.c_uint32
+        _lib.orc_morton_code.argtypes = [C.c_uint32] * 3
+        _lib.orc_gather_touched.restype = C.c_uint32
+        _lib.orc_update_contact.restype = C.c_int
+        _lib.orc_kat_contact_cost.restype = C.c_float
+        _lib.orc_max_threads.restype = C.c_int
+    return _lib
+
+
+def default_params(domain_bits: int = 7) -> Params:
+    p = Params()
+    lib().orc_default_params(C.byref(p))
+    p.domain_bits = domain_bits
+    return p
+
+
+def _f(a):
+    return a.ctypes.data_as(C.POINTER(C.c_float))
+
+
+def _u(a):
+    return a.ctypes.data_as(C.POINTER(C.c_uint32))
+
+
+def _i(a):
+    return a.ctypes.data_as(C.POINTER(C.c_int))
+
+
+def _cf(x):
+    return C.c_float(float(x))
+
+
+def set_threads(n: int) -> None:
+    lib().orc_set_threads(C.c_int(n))
+
+
+def max_threads() -> int:
+    return int(lib().orc_max_threads())
+
+
+def cell_index(x, y, z) -> int:
+    return int(lib().orc_cell_index(int(x), int(y), int(z)))
+
+
+def morton_code(x, y, z) -> int:
+    return int(lib().orc_morton_code(int(x), int(y), int(z)))
+
+
+def inverse_cell_index(key) -> tuple:
+    out = (C.c_uint32 * 3)()
+    lib().orc_inverse_cell_index(C.c_uint32(int(key)), out)
+    return (int(out[0]), int(out[1]), int(out[2]))
+
+
+class ContactPairs:
+    """MpmParticleContactPairs (cpu_mpm_model.h:73-114) as numpy SoA."""
+
+    def __init__(self, particle, body, dist, normal, pos, rigid_v, rigid_p_WB):
+        self.particle = np.ascontiguousarray(particle, dtype=np.uint32)
+        self.body = np.ascontiguousarray(body, dtype=np.uint32)
+        self.dist = np.ascontiguousarray(dist, dtype=np.float32)
+        self.normal = np.ascontiguousarray(normal, dtype=np.float32).reshape(-1, 3)
+        self.pos = np.ascontiguousarray(pos, dtype=np.float32).reshape(-1, 3)
+        self.rigid_v = np.ascontiguousarray(rigid_v, dtype=np.float32).reshape(-1, 3)
+        self.rigid_p_WB = np.ascontiguousarray(rigid_p_WB, dtype=np.float32).reshape(-1, 3)
+
+    def __len__(self):
+        return int(self.body.shape[0])
+
+
+class OracleMpm:
+    """GpuMpmState + GpuMpmSolver restated on the CPU."""
+
+    def __init__(self, domain_bits: int = 7, params: Params | None = None):
+        self.L = lib()
+        self.p = params if params is not None else default_params(domain_bits)
+        self.p.domain_bits = domain_bits
+        self.domain_bits = domain_bits
+        self.n_cells = 1 << (3 * domain_bits)
+        self.n_blocks = self.n_cells >> 6
+        self._pos, self._vel, self._idx = [], [], []
+        self.n_verts = self.n_faces = self.n_particles = 0
+        self.finalized = False
+        self.contacts = None
+        self.n_bodies = 0
+
+    # -- GpuMpmState::AddQRCloth (cuda_mpm_model.cu:16-33)
+    def add_qr_cloth(self, pos, vel, indices):
+        pos = np.asarray(pos, dtype=np.float32).reshape(-1, 3)
+        vel = np.asarray(vel, dtype=np.float32).reshape(-1, 3)
+        indices = np.asarray(indices, dtype=np.int32).reshape(-1)
+        assert indices.size % 3 == 0
+        self._pos.append(pos)
+        self._vel.append(vel)
+        self._idx.append(indices + self.n_verts)
+        self.n_verts += pos.shape[0]
+        self.n_faces += indices.size // 3
+        self.n_particles = self.n_verts + self.n_faces
+
+    # -- GpuMpmState::Finalize (cuda_mpm_model.cu:36-122)
+    def finalize(self):
+        nf, nv, n = self.n_faces, self.n_verts, self.n_particles
+        self.pos = np.zeros((n, 3), np.float32)
+        self.vel = np.zeros((n, 3), np.float32)
+        self.pos[nf:] = np.concatenate(self._pos) if self._pos else 0
+        self.vel[nf:] = np.concatenate(self._vel) if self._vel else 0
+        self.indices = (np.concatenate(self._idx) + nf).astype(np.int32)
+        self.vol = np.zeros(n, np.float32)
+        self.C = np.zeros((n, 9), np.float32)
+        self.pids = np.arange(n, dtype=np.int32)
+        self.index_mappings = np.arange(n, dtype=np.int32)
+        self.sort_keys = np.zeros(n, np.uint32)
+        self.sort_ids = np.zeros(n, np.uint32)
+        self.forces = np.zeros((n, 3), np.float32)
+        self.taus = np.zeros((n, 9), np.float32)
+        self.F = np.zeros((nf, 9), np.float32)
+        self.DmInv = np.zeros((nf, 4), np.float32)
+        nc = self.n_cells
+        self.g_m = np.zeros(nc, np.float32)
+        self.g_mv = np.zeros((nc, 3), np.float32)
+        self.g_vstar = np.zeros((nc, 3), np.float32)
+        self.g_flags = np.zeros(self.n_blocks, np.uint32)
+        self.g_ids = np.zeros(self.n_blocks, np.uint32)
+        self.g_cnt = 0
+        self._contact_grid = False
+        self.L.orc_initialize_fem_state(C.byref(self.p), C.c_size_t(nf), _i(self.indices), _f(self.pos),
+                                        _f(self.vel), _f(self.vol), _f(self.F), _f(self.DmInv))
+        self.finalized = True
+
+    def _ensure_contact_grid(self):
+        if not self._contact_grid:
+            nc = self.n_cells
+            self.g_H = np.zeros((nc, 9), np.float32)
+            self.g_G = np.zeros((nc, 3), np.float32)
+            self.g_D = np.zeros((nc, 3), np.float32)
+            self.g_alpha = np.zeros(nc, np.float32)
+            self.g_E0 = np.zeros(nc, np.float32)
+            self.g_E1 = np.zeros(nc, np.float32)
+            self._contact_grid = True
+
+    # -- GpuMpmSolver::RebuildMapping (cuda_mpm_solver.cu:17-70)
+    def rebuild_mapping(self, sort: bool):
+        n = self.n_particles
+        self.L.orc_compute_keys(C.byref(self.p), C.c_size_t(n), _f(self.pos), _u(self.sort_keys), _u(self.sort_ids))
+        if sort:
+            nk = np.zeros(n, np.uint32)
+            ni = np.zeros(n, np.uint32)
+            nbits = min(3 * self.domain_bits, 16)
+            self.L.orc_sort_pairs_low_bits(C.c_size_t(n), _u(self.sort_keys), _u(self.sort_ids), _u(nk), _u(ni),
+                                           C.c_int(nbits))
+            npos = np.empty_like(self.pos)
+            nvel = np.empty_like(self.vel)
+            nvol = np.empty_like(self.vol)
+            nC = np.empty_like(self.C)
+            npid = np.empty_like(self.pids)
+            self.L.orc_compute_sorted_state(C.c_size_t(n), _f(self.pos), _f(self.vel), _f(self.vol), _f(self.C),
+                                            _i(self.pids), _u(ni), _f(npos), _f(nvel), _f(nvol), _f(nC), _i(npid),
+                                            _i(self.index_mappings))
+            self.pos, self.vel, self.vol, self.C, self.pids = npos, nvel, nvol, nC, npid
+            self.sort_keys, self.sort_ids = nk, ni
+
+    # -- GpuMpmSolver::CalcFemStateAndForce (cuda_mpm_solver.cu:72-84)
+    def calc_fem_state_and_force(self, dt: float):
+        self.forces[:] = 0
+        self.taus[:] = 0
+        self.L.orc_calc_fem_state_and_force(C.byref(self.p), C.c_size_t(self.n_faces), _i(self.indices),
+                                            _i(self.index_mappings), _f(self.vol), _f(self.C), _f(self.DmInv),
+                                            _f(self.pos), _f(self.vel), _f(self.F), _f(self.forces), _f(self.taus),
+                                            _cf(dt))
+
+    # -- GpuMpmSolver::ParticleToGrid (cuda_mpm_solver.cu:86-105)
+    def particle_to_grid(self, dt: float):
+        if self.g_cnt > 0:
+            self.L.orc_clean_grid(C.c_uint32(self.g_cnt * 64), _u(self.g_ids), _u(self.g_flags), _f(self.g_m),
+                                  _f(self.g_mv))
+        self.L.orc_particle_to_grid(C.byref(self.p), C.c_size_t(self.n_particles), _f(self.pos), _f(self.vel),
+                                    _f(self.vol), _f(self.C), _f(self.forces), _f(self.taus), _u(self.g_flags),
+                                    _f(self.g_m), _f(self.g_mv), _cf(dt))
+
+    # -- GpuMpmSolver::UpdateGrid (cuda_mpm_solver.cu:107-151)
+    def update_grid(self, mpm_bc: int = -1):
+        self.g_cnt = int(self.L.orc_gather_touched(C.c_uint32(self.n_blocks), _u(self.g_flags), _u(self.g_ids)))
+        self.L.orc_update_grid(C.byref(self.p), C.c_int(mpm_bc), C.c_uint32(self.g_cnt * 64), _u(self.g_ids),
+                               _f(self.g_m), _f(self.g_mv), _f(self.g_vstar))
+
+    # -- GpuMpmSolver::GridToParticle (cuda_mpm_solver.cu:153-161)
+    def grid_to_particle(self, dt: float):
+        self.L.orc_grid_to_particle(C.byref(self.p), C.c_size_t(self.n_particles), _f(self.pos), _f(self.vel),
+                                    _f(self.C), _f(self.g_m), _f(self.g_mv), _cf(dt), C.c_int(0))
+
+    def substep(self, dt: float, mpm_bc: int = -1, sort: bool = False):
+        """The five solver calls of cuda_mpm_test.cc:66-72."""
+        self.rebuild_mapping(sort)
+        self.calc_fem_state_and_force(dt)
+        self.particle_to_grid(dt)
+        self.update_grid(mpm_bc)
+        self.grid_to_particle(dt)
+
+    # -- GpuMpmState::ReallocateExternelBodies (cuda_mpm_model.cu:319-338)
+    def reallocate_external_bodies(self, n: int):
+        self.n_bodies = n
+        self.F_tau = np.zeros((n, 3), np.float32)
+        self.F_f = np.zeros((n, 3), np.float32)
+
+    # -- GpuMpmSolver::CopyContactPairs (cuda_mpm_solver.cu:193-212)
+    def copy_contact_pairs(self, pairs: ContactPairs):
+        self.contacts = pairs
+        nk = len(pairs)
+        self.c_vel = np.zeros((nk, 3), np.float32)
+        self.c_vel0 = np.zeros((nk, 3), np.float32)
+        if nk:
+            self.L.orc_initialize_contact_velocities(C.c_size_t(nk), _f(self.c_vel), _u(pairs.particle), _f(self.vel))
+
+    # -- GpuMpmSolver::UpdateContact (cuda_mpm_solver.cu:214-621)
+    def update_contact(self, dt, friction_mu, stiffness, damping, exact_line_search=False, max_iters=2000):
+        pc = self.contacts
+        nk = 0 if pc is None else len(pc)
+        if nk == 0:
+            return dict(iterations=0, residual=0.0, line_search_avg=0.0, energy=0.0)
+        self._ensure_contact_grid()
+        if self.n_bodies == 0:
+            self.reallocate_external_bodies(int(pc.body.max()) + 1)
+        res = C.c_float(0)
+        lsa = C.c_float(0)
+        en = C.c_float(0)
+        it = self.L.orc_update_contact(
+            C.byref(self.p), C.c_size_t(nk), _f(pc.pos), _f(self.c_vel), _f(self.c_vel0), _f(self.vel), _f(self.vol),
+            _u(pc.particle), _u(pc.body), _f(pc.dist), _f(pc.normal), _f(pc.rigid_v), _f(pc.rigid_p_WB),
+            C.c_uint32(self.g_cnt), _u(self.g_ids), _f(self.g_m), _f(self.g_mv), _f(self.g_vstar), _f(self.g_H),
+            _f(self.g_G), _f(self.g_D), _f(self.g_alpha), _f(self.g_E0), _f(self.g_E1), _f(self.F_tau), _f(self.F_f),
+            _cf(dt), _cf(friction_mu), _cf(stiffness), _cf(damping), C.c_int(1 if exact_line_search else 0),
+            C.c_int(max_iters), C.byref(res), C.byref(lsa), C.byref(en))
+        return dict(iterations=int(it), residual=float(res.value), line_search_avg=float(lsa.value),
+                    energy=float(en.value))
+
+    # -- GpuMpmState::DumpCpuState (cuda_mpm_model.cu:244-265)
+    def dump_cpu_state(self):
+        orig = np.empty_like(self.pos)
+        orig[self.pids] = self.pos
+        return orig[self.n_faces:].copy(), (self.indices - self.n_faces).astype(np.int32)
+
+    # helpers for tests ------------------------------------------------
+    def state_in_original_order(self):
+        """x, v, C, vol un-permuted to the Finalize() order [faces | verts]."""
+        out = {}
+        for name in ("pos", "vel", "C", "vol"):
+            a = getattr(self, name)
+            o = np.empty_like(a)
+            o[self.pids] = a
+            out[name] = o
+        return out
+
+    def touched_blocks(self):
+        return np.sort(self.g_ids[: self.g_cnt].copy())
