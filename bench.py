@@ -1,0 +1,142 @@
+#!/usr/bin/env python3
+"""Benchmark of the MPM substep hot path (BASELINE.json metric).
+
+One "step" = one contact-free MPM substep (RebuildMapping, CalcFemStateAndForce,
+ParticleToGrid, UpdateGrid, GridToParticle) of the 1M-particle cloth stack on a
+128^3 grid (BASELINE.json configs[1]), state resident in HBM.
+
+Prints ONE JSON line (rank 0).  See DESIGN.md "Measurement" for the definition
+of the roofline and cpu_baseline objects.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def algorithmic_bytes(np_, nf, nv, ncells):
+    """bytes one substep has to move, fp32, one pass per phase."""
+    fem = 200 * nf + 36 * nv
+    p2g = 116 * np_ + 16 * ncells
+    grid = 40 * ncells
+    g2p = 72 * np_ + 12 * ncells
+    return dict(fem=fem, p2g=p2g, grid=grid, g2p=g2p, total=fem + p2g + grid + g2p)
+
+
+def cpu_baseline(domain_bits, layers, res, dt, budget_s=20.0):
+    """The oracle (a port, OpenMP) timed on the host cores on a bounded sample: the same
+    cloth-stack recipe at a size that keeps the run near `budget_s`, scaled per particle."""
+    from drake_amd import scenes
+    from oracle import oracle as orc
+    threads = orc.max_threads()
+    orc.set_threads(threads)
+    o = orc.OracleMpm(domain_bits)
+    # sample: fewer layers of the same sheets (same particle density per cell column)
+    sl = max(2, layers // 4)
+    for pos, vel, idx in scenes.cloth_stack(sl, res, domain_bits):
+        o.add_qr_cloth(pos, vel, idx)
+    o.finalize()
+    o.substep(dt, -1)  # warm-up
+    n, t0 = 0, time.perf_counter()
+    while True:
+        o.substep(dt, -1)
+        n += 1
+        el = time.perf_counter() - t0
+        if el > budget_s or n >= 50:
+            break
+    per_particle_step = el / n / o.n_particles
+    nv, nf, npart = scenes.particle_count(layers, res)
+    sps = 1.0 / (per_particle_step * npart)
+    return dict(value=sps, unit="substeps/s", cores=threads, kind="port",
+                sample=f"{n} substeps of a {sl}-layer slice ({o.n_particles} particles, same sheets and grid), "
+                       f"scaled per particle to {npart}; OpenMP oracle, {threads} threads")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=400)
+    ap.add_argument("--warmup", type=int, default=40)
+    ap.add_argument("--config", default="cloth_1m")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-budget", type=float, default=20.0)
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    assert torch.cuda.is_available(), "bench.py needs a GPU (the engine has no CPU fallback)"
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    from drake_amd import GpuMpm, scenes
+    bits, layers, res = scenes.CONFIGS[args.config]
+    dt = 1e-3
+    g = GpuMpm(bits, device=local_rank)
+    # every rank owns one full copy of the workload (weak scaling: per-GPU work is fixed)
+    scenes.populate(g, scenes.cloth_stack(layers, res, bits, seed=1234 + rank))
+    nv, nf, npart = g.n_verts, g.n_faces, g.n_particles
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    g.run_substeps(args.warmup, dt, -1)
+    g.gpu_sync()
+    barrier()
+    t0 = time.perf_counter()
+    g.run_substeps(args.steps, dt, -1)
+    g.gpu_sync()
+    barrier()
+    el = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([el], device="cuda", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        el = float(t.item())
+    st = g.stats()
+    assert st["error_flags"] == 0, st
+
+    # per-kernel timing with HIP events on the engine's stream (separate, un-timed pass)
+    phases, tot_ms = g.profile_substeps(min(args.steps, 200), dt, -1)
+    g.gpu_sync()
+    ncells = 64 * st["touched_blocks"]
+    ab = algorithmic_bytes(npart, nf, nv, ncells)
+    dom = max(("fem", "p2g", "grid", "g2p"), key=lambda k: phases[k])
+    ach = ab[dom] / (phases[dom] * 1e-3) / 1e9
+    roofline = dict(bound="hbm", kernel=dom, achieved=ach, peak=HBM_PEAK_GBS, unit="GB/s", frac=ach / HBM_PEAK_GBS,
+                    traffic=None, algorithmic_bytes_per_launch=ab[dom], kernel_ms=phases[dom],
+                    substep_achieved=ab["total"] / (el / args.steps) / 1e9,
+                    substep_frac=ab["total"] / (el / args.steps) / 1e9 / HBM_PEAK_GBS, phase_ms=phases)
+
+    if rank == 0:
+        out = dict(metric="mpm_substeps_per_sec_1M_particles", value=world * args.steps / el, unit="substeps/s",
+                   n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=el / args.steps * 1e3,
+                   higher_is_better=True, scaling="weak", vs_baseline=None, dtype="f32", data="synthetic",
+                   config=dict(workload=f"{args.config}: {npart} particles ({nf} faces + {nv} vertices), "
+                                        f"{1 << bits}^3 grid, corotated cloth, no contact, dt={dt}",
+                               particles_per_gpu=npart, grid=f"{1 << bits}^3", touched_blocks=st["touched_blocks"],
+                               rebuilds=st["rebuilds"], parallelism=f"replicated x{world}"),
+                   roofline=roofline)
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(bits, layers, res, dt, args.cpu_budget)
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

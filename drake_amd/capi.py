@@ -1,0 +1,282 @@
+"""ctypes binding of include/mpm_hip.h.
+
+`GpuMpm` mirrors the reference's GpuMpmState<float> + GpuMpmSolver<float> pair
+(multibody/gpu_mpm/cuda_mpm_model.cuh:37-260, cuda_mpm_solver.cuh:19-35) with
+snake_case method names; argument meaning and call order are the reference's.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import _build
+
+_LIB = None
+
+
+class MpmError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__(f"mpm_hip error {code}: {msg}")
+        self.code = code
+
+
+class Material(C.Structure):
+    _fields_ = [
+        ("youngs_modulus", C.c_float), ("poisson_ratio", C.c_float), ("density", C.c_float), ("gamma", C.c_float),
+        ("K", C.c_float), ("V", C.c_float), ("c_F", C.c_float), ("sdf_friction", C.c_float), ("gravity", C.c_float),
+        ("epsv", C.c_float), ("gravity_axis", C.c_int32), ("wall_cells", C.c_int32),
+    ]
+
+
+class Stats(C.Structure):
+    _fields_ = [
+        ("substeps", C.c_uint64), ("rebuilds", C.c_uint64), ("home_blocks", C.c_uint32), ("active_blocks", C.c_uint32),
+        ("touched_blocks", C.c_uint32), ("error_flags", C.c_uint32),
+    ]
+
+
+class ARR:
+    POSITIONS, VELOCITIES, VOLUMES, AFFINE, PIDS, INDEX_MAPPINGS, SORT_KEYS, FORCES, TAUS = range(9)
+    DEFORMATION_GRADIENTS, DM_INVERSES, INDICES, GRID_MASSES, GRID_MOMENTUM, GRID_V_STAR = range(9, 15)
+    GRID_TOUCHED_FLAGS, GRID_TOUCHED_IDS, CONTACT_VEL, CONTACT_VEL0, GRID_DIR = range(15, 20)
+
+
+PHASES = ("rebuild", "fem", "p2g", "grid", "g2p")
+
+# every symbol include/mpm_hip.h declares (checked by tests/test_capi_symbols.py)
+SYMBOLS = [
+    "mpm_last_error", "mpm_default_material", "mpm_create", "mpm_add_qr_cloth", "mpm_finalize", "mpm_destroy",
+    "mpm_counts", "mpm_grid_touched_cnt", "mpm_dump_cpu_state", "mpm_reallocate_external_bodies",
+    "mpm_external_body_force_to_host", "mpm_rebuild_mapping", "mpm_calc_fem_state_and_force", "mpm_particle_to_grid",
+    "mpm_update_grid", "mpm_grid_to_particle", "mpm_sync", "mpm_sync_particle_state_to_cpu", "mpm_dump_obj",
+    "mpm_copy_contact_pairs", "mpm_update_contact", "mpm_set_dump_dir", "mpm_substep", "mpm_run_substeps",
+    "mpm_profile_substeps", "mpm_set_stream", "mpm_get_stats", "mpm_download_array", "mpm_upload_particle_state",
+]
+
+
+def library_path() -> str:
+    return _build.LIB
+
+
+def load_library(build: bool = True):
+    """Loads drake_amd/libmpm_hip.so, building it with hipcc first if needed.
+    Raises if the library cannot be produced: there is no fallback path."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    path = _build.build() if build else _build.LIB
+    if not os.path.exists(path):
+        raise RuntimeError(f"{path} is missing: build it with `python -m drake_amd._build` (no CPU fallback exists)")
+    lib = C.CDLL(path)
+    lib.mpm_last_error.restype = C.c_char_p
+    vp, f, i, sz = C.c_void_p, C.c_float, C.c_int, C.c_size_t
+    P = C.POINTER
+    sigs = {
+        "mpm_default_material": [P(Material)],
+        "mpm_create": [i, P(Material), i, P(vp)],
+        "mpm_add_qr_cloth": [vp, vp, vp, sz, vp, sz],
+        "mpm_finalize": [vp], "mpm_destroy": [vp],
+        "mpm_counts": [vp, P(sz), P(sz), P(sz)],
+        "mpm_grid_touched_cnt": [vp, P(C.c_uint32)],
+        "mpm_dump_cpu_state": [vp, vp, vp],
+        "mpm_reallocate_external_bodies": [vp, sz],
+        "mpm_external_body_force_to_host": [vp, vp, vp],
+        "mpm_rebuild_mapping": [vp, i],
+        "mpm_calc_fem_state_and_force": [vp, f],
+        "mpm_particle_to_grid": [vp, f],
+        "mpm_update_grid": [vp, i],
+        "mpm_grid_to_particle": [vp, f],
+        "mpm_sync": [vp],
+        "mpm_sync_particle_state_to_cpu": [vp, vp],
+        "mpm_dump_obj": [vp, C.c_char_p],
+        "mpm_copy_contact_pairs": [vp, sz, vp, vp, vp, vp, vp, vp, vp],
+        "mpm_update_contact": [vp, i, i, f, f, f, f, i, i, i, P(i), P(f)],
+        "mpm_set_dump_dir": [vp, C.c_char_p],
+        "mpm_substep": [vp, f, i],
+        "mpm_run_substeps": [vp, i, f, i],
+        "mpm_profile_substeps": [vp, i, f, i, P(f), P(f)],
+        "mpm_set_stream": [vp, vp],
+        "mpm_get_stats": [vp, P(Stats)],
+        "mpm_download_array": [vp, i, vp, sz, P(sz)],
+        "mpm_upload_particle_state": [vp, vp, vp, vp, vp, vp],
+    }
+    for name, args in sigs.items():
+        fn = getattr(lib, name)
+        fn.argtypes = args
+        fn.restype = C.c_int
+    _LIB = lib
+    return lib
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def _f32(a, shape=None):
+    if a is None:
+        return None
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    return a if shape is None else a.reshape(shape)
+
+
+class GpuMpm:
+    """One GpuMpmState + the GpuMpmSolver calls that act on it."""
+
+    def __init__(self, domain_bits: int = 7, material: Material | None = None, device: int = 0):
+        self.lib = load_library()
+        self.h = C.c_void_p()
+        self.domain_bits = domain_bits
+        self.n_cells = 1 << (3 * domain_bits)
+        self.n_blocks = self.n_cells >> 6
+        self._ck(self.lib.mpm_create(domain_bits, C.byref(material) if material is not None else None, device,
+                                     C.byref(self.h)))
+
+    def _ck(self, rc: int):
+        if rc != 0:
+            raise MpmError(rc, (self.lib.mpm_last_error() or b"").decode())
+
+    @staticmethod
+    def default_material() -> Material:
+        m = Material()
+        load_library().mpm_default_material(C.byref(m))
+        return m
+
+    # ---- GpuMpmState --------------------------------------------------------
+    def add_qr_cloth(self, pos, vel, indices):
+        pos = _f32(pos, (-1, 3))
+        vel = _f32(vel, (-1, 3))
+        idx = np.ascontiguousarray(indices, dtype=np.int32).reshape(-1)
+        self._ck(self.lib.mpm_add_qr_cloth(self.h, _ptr(pos), _ptr(vel), pos.shape[0], _ptr(idx), idx.size // 3))
+
+    def finalize(self):
+        self._ck(self.lib.mpm_finalize(self.h))
+        nv, nf, n = C.c_size_t(), C.c_size_t(), C.c_size_t()
+        self._ck(self.lib.mpm_counts(self.h, C.byref(nv), C.byref(nf), C.byref(n)))
+        self.n_verts, self.n_faces, self.n_particles = nv.value, nf.value, n.value
+
+    def destroy(self):
+        if self.h:
+            self.lib.mpm_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.destroy()
+        except Exception:
+            pass
+
+    def grid_touched_cnt(self) -> int:
+        c = C.c_uint32()
+        self._ck(self.lib.mpm_grid_touched_cnt(self.h, C.byref(c)))
+        return int(c.value)
+
+    def dump_cpu_state(self):
+        pos = np.empty((self.n_verts, 3), np.float32)
+        idx = np.empty(self.n_faces * 3, np.int32)
+        self._ck(self.lib.mpm_dump_cpu_state(self.h, _ptr(pos), _ptr(idx)))
+        return pos, idx
+
+    def reallocate_external_bodies(self, n: int):
+        self._ck(self.lib.mpm_reallocate_external_bodies(self.h, n))
+        self._n_bodies = n
+
+    def external_body_force_to_host(self):
+        n = getattr(self, "_n_bodies", 0)
+        tau = np.zeros((n, 3), np.float32)
+        frc = np.zeros((n, 3), np.float32)
+        self._ck(self.lib.mpm_external_body_force_to_host(self.h, _ptr(tau), _ptr(frc)))
+        return tau, frc
+
+    # ---- GpuMpmSolver -------------------------------------------------------
+    def rebuild_mapping(self, sort: bool = False):
+        self._ck(self.lib.mpm_rebuild_mapping(self.h, 1 if sort else 0))
+
+    def calc_fem_state_and_force(self, dt: float):
+        self._ck(self.lib.mpm_calc_fem_state_and_force(self.h, dt))
+
+    def particle_to_grid(self, dt: float):
+        self._ck(self.lib.mpm_particle_to_grid(self.h, dt))
+
+    def update_grid(self, mpm_bc: int = -1):
+        self._ck(self.lib.mpm_update_grid(self.h, mpm_bc))
+
+    def grid_to_particle(self, dt: float):
+        self._ck(self.lib.mpm_grid_to_particle(self.h, dt))
+
+    def gpu_sync(self):
+        self._ck(self.lib.mpm_sync(self.h))
+
+    def sync_particle_state_to_cpu(self):
+        pos = np.empty((self.n_particles, 3), np.float32)
+        self._ck(self.lib.mpm_sync_particle_state_to_cpu(self.h, _ptr(pos)))
+        return pos
+
+    def dump(self, filename: str):
+        self._ck(self.lib.mpm_dump_obj(self.h, filename.encode()))
+
+    def copy_contact_pairs(self, particle, body, dist, normal, pos, rigid_v, rigid_p_WB):
+        particle = np.ascontiguousarray(particle, dtype=np.uint32)
+        body = np.ascontiguousarray(body, dtype=np.uint32)
+        n = int(body.shape[0])
+        arrs = [_f32(dist), _f32(normal, (-1, 3)), _f32(pos, (-1, 3)), _f32(rigid_v, (-1, 3)), _f32(rigid_p_WB, (-1, 3))]
+        self._ck(self.lib.mpm_copy_contact_pairs(self.h, n, _ptr(particle), _ptr(body), *[_ptr(a) for a in arrs]))
+        self._n_contacts = n
+
+    def update_contact(self, dt, friction_mu, stiffness, damping, exact_line_search=False, frame=0, substep=0,
+                       dump=False, max_newton_iterations=0):
+        it = C.c_int()
+        res = C.c_float()
+        self._ck(self.lib.mpm_update_contact(self.h, frame, substep, dt, friction_mu, stiffness, damping,
+                                             1 if dump else 0, 1 if exact_line_search else 0, max_newton_iterations,
+                                             C.byref(it), C.byref(res)))
+        return dict(iterations=int(it.value), residual=float(res.value))
+
+    # ---- conveniences -------------------------------------------------------
+    def substep(self, dt: float, mpm_bc: int = -1):
+        self._ck(self.lib.mpm_substep(self.h, dt, mpm_bc))
+
+    def run_substeps(self, n: int, dt: float, mpm_bc: int = -1):
+        self._ck(self.lib.mpm_run_substeps(self.h, n, dt, mpm_bc))
+
+    def profile_substeps(self, n: int, dt: float, mpm_bc: int = -1):
+        ph = (C.c_float * len(PHASES))()
+        tot = C.c_float()
+        self._ck(self.lib.mpm_profile_substeps(self.h, n, dt, mpm_bc, ph, C.byref(tot)))
+        return {k: float(ph[i]) for i, k in enumerate(PHASES)}, float(tot.value)
+
+    def set_stream(self, stream_handle: int | None):
+        self._ck(self.lib.mpm_set_stream(self.h, C.c_void_p(stream_handle) if stream_handle else None))
+
+    def stats(self) -> dict:
+        s = Stats()
+        self._ck(self.lib.mpm_get_stats(self.h, C.byref(s)))
+        return {k: int(getattr(s, k)) for k, _ in Stats._fields_}
+
+    _SHAPES = {
+        ARR.POSITIONS: ("np", 3, np.float32), ARR.VELOCITIES: ("np", 3, np.float32), ARR.VOLUMES: ("np", 1, np.float32),
+        ARR.AFFINE: ("np", 9, np.float32), ARR.PIDS: ("np", 1, np.int32), ARR.INDEX_MAPPINGS: ("np", 1, np.int32),
+        ARR.SORT_KEYS: ("np", 1, np.uint32), ARR.FORCES: ("np", 3, np.float32), ARR.TAUS: ("np", 9, np.float32),
+        ARR.DEFORMATION_GRADIENTS: ("nf", 9, np.float32), ARR.DM_INVERSES: ("nf", 4, np.float32),
+        ARR.INDICES: ("nf", 3, np.int32), ARR.GRID_MASSES: ("cells", 1, np.float32),
+        ARR.GRID_MOMENTUM: ("cells", 3, np.float32), ARR.GRID_V_STAR: ("cells", 3, np.float32),
+        ARR.GRID_TOUCHED_FLAGS: ("blocks", 1, np.uint32), ARR.GRID_TOUCHED_IDS: ("blocks", 1, np.uint32),
+        ARR.CONTACT_VEL: ("nk", 3, np.float32), ARR.CONTACT_VEL0: ("nk", 3, np.float32),
+        ARR.GRID_DIR: ("cells", 3, np.float32),
+    }
+
+    def download(self, which: int) -> np.ndarray:
+        kind, nc, dt = self._SHAPES[which]
+        n = {"np": self.n_particles, "nf": self.n_faces, "cells": self.n_cells, "blocks": self.n_blocks,
+             "nk": getattr(self, "_n_contacts", 0)}[kind]
+        out = np.zeros((n, nc) if nc > 1 else (n,), dt)
+        written = C.c_size_t(out.nbytes)
+        self._ck(self.lib.mpm_download_array(self.h, which, _ptr(out), out.nbytes, C.byref(written)))
+        if which == ARR.GRID_TOUCHED_IDS:
+            out = out[: written.value // 4]
+        return out
+
+    def upload_particle_state(self, pos=None, vel=None, affine=None, volumes=None, deformation_gradients=None):
+        a = [_f32(pos), _f32(vel), _f32(affine), _f32(volumes), _f32(deformation_gradients)]
+        self._ck(self.lib.mpm_upload_particle_state(self.h, *[_ptr(x) for x in a]))

@@ -1,0 +1,112 @@
+// Device-side data model of the engine (see DESIGN.md "Data layout in HBM").
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "mpm_math.h"
+
+namespace mpm {
+
+// A home block's LDS tile covers its own 4^3 cells plus a free zone of
+// FREE_ZONE cells on every side, plus the 2 extra nodes a quadratic stencil
+// reaches beyond its base cell: 4 + 2*FREE_ZONE + 2 nodes per axis.
+constexpr int FREE_ZONE = 2;
+constexpr int TILE_W = 4 + 2 * FREE_ZONE + 2;        // 10
+constexpr int TILE_N = TILE_W * TILE_W * TILE_W;     // 1000 nodes (16 KB of float4)
+// A particle may sit up to FREE_ZONE cells outside its home block (hard limit);
+// one that is more than SOFT_ZONE cells outside asks for a re-sort.
+constexpr int SOFT_ZONE = 1;
+
+constexpr unsigned ERR_DRIFT = 1u;      // particle outside the hard free zone
+constexpr unsigned ERR_CAPACITY = 2u;   // home/active table overflow
+constexpr unsigned ERR_DOMAIN = 4u;     // particle base cell outside the grid
+
+// One of the two ping-pong particle sets.  Structure of arrays: one plane per
+// component, slots [0,Nf) are face particles, [Nf,Np) vertex particles, each
+// range sorted by cell key at the last rebuild.
+struct PSet {
+    float* x[3];
+    float* v[3];
+    float* vol;
+    float* C[9];
+    int* pid;      // slot -> original particle id ([faces | verts] order of Finalize)
+    float* F[9];   // face slots only
+    float* Dm[4];  // face slots only
+};
+
+// Device-resident control block; everything the host would otherwise have to
+// read back between kernels.
+struct Ctl {
+    int cur;               // index of the current PSet
+    int need_rebuild;      // raised by P2G when a particle leaves the soft zone
+    unsigned error;        // sticky ERR_* bits
+    unsigned n_home;       // blocks owning particles (tiles)
+    unsigned n_active;     // blocks whose nodes are updated
+    unsigned rebuilds;
+    unsigned ticket;
+    unsigned pad;
+};
+
+struct DP {
+    int Np, Nf, Nv;
+    int bits;              // grid is (1<<bits)^3 cells
+    int nb;                // blocks per axis
+    unsigned nblocks, ncells;
+    unsigned capH, capA;
+    float dx, dxinv, Dinv;
+    Material M;
+    Ctl* ctl;
+    PSet set[2];
+    // per-substep scratch
+    float* ab[6];          // faces: tau = a (x) b  (a = vol*P[:,2], b = F[:,2])
+    float* G[9];           // faces: G[i*3+c] = force component i on corner c (negated when applied)
+    float* f[3];           // vertices: internal force
+    // topology (original ids)
+    const int* idx_orig[3];  // face -> original particle ids of its corners
+    const int* adj_off;      // vertex (original, 0-based) -> range in adj_fc
+    const int* adj_fc;       // (original face id << 2) | corner
+    int* imap;               // original particle id -> slot
+    int* fv[3];              // face slot -> slots of its corner vertices
+    // rebuild scratch
+    uint32_t* pkey;
+    uint32_t* prank;
+    int* cellcnt[2];       // [type][cell key]; zero outside a rebuild
+    int* blkcnt[2];        // [type][block id]; zero outside a rebuild
+    int* blkstart[2];
+    int* lut_home;         // block id -> home slot or -1
+    int* lut_act;          // block id -> active slot or -1
+    int* act_flag;
+    // tables
+    uint32_t* home_block;  // home slot -> block id
+    int4* home_range;      // (face begin, face end, vertex begin, vertex end) slots
+    int* home_nbr_act;     // [home][27] active slot of block + offset, or -1
+    uint32_t* act_block;
+    int* act_nbr_home;     // [active][27] home slot of block + offset, or -1
+    // grid
+    float4* slab;          // [home][TILE_N] (mvx, mvy, mvz, m) partial sums of one tile
+    uint32_t* slab_mask;   // [home] 27-bit set of neighbour blocks reached by a stencil
+    float4* gv;            // [active][64] (vx, vy, vz, m)  (momentum before the grid update)
+    float4* gvs;           // [active][64] v* (velocity after the explicit update, before contact)
+};
+
+MPM_DEV int off_index(int ox, int oy, int oz) { return (ox + 1) * 9 + (oy + 1) * 3 + (oz + 1); }
+
+// id of the block at coords(b) + (ox,oy,oz), or -1 outside the grid
+MPM_DEV int neighbor_block(uint32_t b, int o, int nb) {
+    int bx, by, bz;
+    block_coords(b, bx, by, bz);
+    bx += o / 9 - 1;
+    by += (o / 3) % 3 - 1;
+    bz += o % 3 - 1;
+    if (bx < 0 || by < 0 || bz < 0 || bx >= nb || by >= nb || bz >= nb) return -1;
+    return (int)block_id((uint32_t)bx, (uint32_t)by, (uint32_t)bz);
+}
+
+// base cell of a position (float -> uint conversion saturates at 0 like the
+// reference's CUDA cast, cuda_mpm_kernels.cuh:372-374)
+MPM_DEV uint32_t base_cell(float x, float dxinv) {
+    const float t = x * dxinv - .5f;
+    return t > 0.f ? (uint32_t)t : 0u;
+}
+
+}  // namespace mpm

@@ -1,0 +1,487 @@
+// Host side of the engine and the C ABI declared in include/mpm_hip.h.
+// One translation unit: the kernels are header-only so hipcc can inline the
+// device math into them.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <fstream>
+#include <numeric>
+#include <string>
+#include <vector>
+
+#include "../../include/mpm_hip.h"
+#include "mpm_host.h"
+#include "mpm_io.h"
+#include "mpm_contact.h"
+
+extern "C" {
+
+const char* mpm_last_error(void) { return g_last_error.c_str(); }
+
+int mpm_default_material(mpm_material_t* m) {
+    REQUIRE(m, "null material");
+    m->youngs_modulus = 400000.f;
+    m->poisson_ratio = .3f;
+    m->density = 2000.f;
+    m->gamma = 0.f;
+    m->K = 100000.f;
+    m->V = .8f;
+    m->c_F = 0.f;
+    m->sdf_friction = .3f;
+    m->gravity = -9.8f;
+    m->epsv = 1e-3f;
+    m->gravity_axis = 2;
+    m->wall_cells = 3;
+    return 0;
+}
+
+int mpm_create(int domain_bits, const mpm_material_t* material, int device, mpm_handle_t* out) {
+    REQUIRE(out, "null handle pointer");
+    REQUIRE(domain_bits >= 4 && domain_bits <= 10, "domain_bits must be in [4,10]");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return fail(MPM_ERR_NO_DEVICE, "no HIP device visible: the engine has no CPU fallback");
+    REQUIRE(device >= 0 && device < ndev, "device ordinal out of range");
+    mpm_engine* e = new mpm_engine();
+    e->device = device;
+    e->bits = domain_bits;
+    if (material) e->mat = *material; else mpm_default_material(&e->mat);
+    if (e->mat.gravity_axis < 0 || e->mat.gravity_axis > 2) {
+        delete e;
+        return fail(MPM_ERR_INVALID, "gravity_axis must be 0, 1 or 2");
+    }
+    hipError_t err = hipSetDevice(device);
+    if (err == hipSuccess) err = hipStreamCreateWithFlags(&e->own_stream, hipStreamNonBlocking);
+    if (err != hipSuccess) {
+        delete e;
+        return fail(MPM_ERR_HIP, std::string("mpm_create: ") + hipGetErrorString(err));
+    }
+    e->stream = e->own_stream;
+    *out = e;
+    return 0;
+}
+
+int mpm_add_qr_cloth(mpm_handle_t e, const float* pos, const float* vel, size_t n_verts, const int32_t* indices,
+                     size_t n_faces) {
+    REQUIRE(e, "null handle");
+    REQUIRE(!e->finalized, "AddQRCloth after Finalize");
+    REQUIRE(pos && vel && (indices || n_faces == 0), "null input array");
+    for (size_t i = 0; i < n_faces * 3; ++i) {
+        REQUIRE(indices[i] >= 0 && (size_t)indices[i] < n_verts, "triangle index out of range");
+        e->h_idx.push_back(indices[i] + (int)e->nv);
+    }
+    e->h_pos.insert(e->h_pos.end(), pos, pos + 3 * n_verts);
+    e->h_vel.insert(e->h_vel.end(), vel, vel + 3 * n_verts);
+    e->nv += n_verts;
+    e->nf += n_faces;
+    e->np = e->nv + e->nf;
+    return 0;
+}
+
+static void launch_rebuild(mpm_engine* e) {
+    const DP& p = e->dp;
+    hipLaunchKernelGGL(k_rb_count, dim3(e->g_np), dim3(256), 0, e->stream, p);
+    hipLaunchKernelGGL(k_rb_tables, dim3(1), dim3(1024), 0, e->stream, p);
+    hipLaunchKernelGGL(k_rb_scatter, dim3(e->g_np), dim3(256), 0, e->stream, p);
+    hipLaunchKernelGGL(k_rb_finish, dim3(e->g_np), dim3(256), 0, e->stream, p);
+}
+static void launch_fem(mpm_engine* e, float dt) {
+    const DP& p = e->dp;
+    if (e->nf) hipLaunchKernelGGL(k_fem, dim3(e->g_nf), dim3(256), 0, e->stream, p, dt);
+    if (e->nv) hipLaunchKernelGGL(k_vforce, dim3(e->g_nv), dim3(256), 0, e->stream, p);
+}
+static void launch_p2g(mpm_engine* e, float dt) {
+    hipLaunchKernelGGL(k_p2g, dim3(e->g_tile), dim3(512), 0, e->stream, e->dp, dt);
+}
+static void launch_grid(mpm_engine* e, int bc) {
+    hipLaunchKernelGGL(k_grid<1>, dim3(e->g_grid), dim3(256), 0, e->stream, e->dp, bc);
+}
+static void launch_g2p(mpm_engine* e, float dt) {
+    hipLaunchKernelGGL(k_g2p, dim3(e->g_tile), dim3(512), 0, e->stream, e->dp, dt);
+}
+
+int mpm_finalize(mpm_handle_t e) {
+    REQUIRE(e, "null handle");
+    REQUIRE(!e->finalized, "Finalize called twice");
+    REQUIRE(e->np > 0, "no particles: call mpm_add_qr_cloth first");
+    if (int rc = use(e)) return rc;
+    const size_t np = e->np, nf = e->nf, nv = e->nv;
+    REQUIRE(np < (size_t)1 << 30, "too many particles");
+    DP& p = e->dp;
+    p.Np = (int)np; p.Nf = (int)nf; p.Nv = (int)nv;
+    p.bits = e->bits;
+    p.nb = 1 << (e->bits - 2);
+    p.ncells = 1u << (3 * e->bits);
+    p.nblocks = p.ncells >> 6;
+    p.capH = (unsigned)std::min<size_t>(p.nblocks, np);
+    p.capA = (unsigned)std::min<size_t>(p.nblocks, (size_t)27 * p.capH);
+    p.dxinv = (float)(1 << e->bits);
+    p.dx = 1.f / p.dxinv;
+    p.Dinv = 4.f * p.dxinv * p.dxinv;
+    const mpm_material_t& m = e->mat;
+    p.M.mu = m.youngs_modulus / (2.f * (1.f + m.poisson_ratio));
+    p.M.lambda = m.youngs_modulus * m.poisson_ratio / ((1.f + m.poisson_ratio) * (1.f - 2.f * m.poisson_ratio));
+    p.M.density = m.density; p.M.gamma = m.gamma; p.M.K = m.K; p.M.V = m.V; p.M.cF = m.c_F;
+    p.M.sdf_friction = m.sdf_friction; p.M.gravity = m.gravity; p.M.epsv = m.epsv;
+    p.M.gravity_axis = m.gravity_axis; p.M.wall = m.wall_cells;
+
+    // ---- device buffers ---------------------------------------------------
+    int rc = 0;
+#define ALLOC(ptr, n, zero)                         \
+    if ((rc = e->dalloc(&(ptr), (n), (zero)))) return rc
+    ALLOC(p.ctl, 1, true);
+    for (int s = 0; s < 2; ++s) {
+        PSet& S = p.set[s];
+        for (int d = 0; d < 3; ++d) { ALLOC(S.x[d], np, true); ALLOC(S.v[d], np, true); }
+        ALLOC(S.vol, np, true);
+        for (int d = 0; d < 9; ++d) { ALLOC(S.C[d], np, true); ALLOC(S.F[d], nf, true); }
+        for (int d = 0; d < 4; ++d) ALLOC(S.Dm[d], nf, true);
+        ALLOC(S.pid, np, true);
+    }
+    for (int d = 0; d < 6; ++d) ALLOC(p.ab[d], nf, true);
+    for (int d = 0; d < 9; ++d) ALLOC(p.G[d], nf, true);
+    for (int d = 0; d < 3; ++d) ALLOC(p.f[d], np, true);
+    int* idx_orig[3];
+    int *adj_off, *adj_fc;
+    for (int d = 0; d < 3; ++d) { ALLOC(idx_orig[d], nf, false); p.idx_orig[d] = idx_orig[d]; ALLOC(p.fv[d], nf, false); }
+    ALLOC(adj_off, nv + 1, false);
+    ALLOC(adj_fc, 3 * nf, false);
+    p.adj_off = adj_off; p.adj_fc = adj_fc;
+    ALLOC(p.imap, np, false);
+    ALLOC(p.pkey, np, false);
+    ALLOC(p.prank, np, false);
+    for (int t = 0; t < 2; ++t) {
+        ALLOC(p.cellcnt[t], p.ncells, true);
+        ALLOC(p.blkcnt[t], p.nblocks, true);
+        ALLOC(p.blkstart[t], p.nblocks, true);
+    }
+    ALLOC(p.lut_home, p.nblocks, true);
+    ALLOC(p.lut_act, p.nblocks, true);
+    ALLOC(p.act_flag, p.nblocks, true);
+    ALLOC(p.home_block, p.capH, true);
+    ALLOC(p.home_range, p.capH, true);
+    ALLOC(p.home_nbr_act, (size_t)p.capH * 27, true);
+    ALLOC(p.act_block, p.capA, true);
+    ALLOC(p.act_nbr_home, (size_t)p.capA * 27, true);
+    ALLOC(p.slab, (size_t)p.capH * TILE_N, true);
+    ALLOC(p.slab_mask, p.capH, true);
+    ALLOC(p.gv, (size_t)p.capA * 64, true);
+    ALLOC(p.gvs, (size_t)p.capA * 64, true);
+    ALLOC(e->d_pids_api, np, false);
+    ALLOC(e->d_apimap, np, false);
+#undef ALLOC
+
+    // ---- host-side layout: [faces | verts], indices offset by +nf ---------
+    // (cuda_mpm_model.cu:40-45)
+    std::vector<float> plane(np);
+    PSet& S0 = p.set[0];
+    for (int d = 0; d < 3; ++d) {
+        std::fill(plane.begin(), plane.begin() + nf, 0.f);
+        for (size_t i = 0; i < nv; ++i) plane[nf + i] = e->h_pos[i * 3 + d];
+        HIP_TRY(hipMemcpyAsync(S0.x[d], plane.data(), np * 4, hipMemcpyHostToDevice, e->stream));
+        HIP_TRY(hipStreamSynchronize(e->stream));
+        for (size_t i = 0; i < nv; ++i) plane[nf + i] = e->h_vel[i * 3 + d];
+        HIP_TRY(hipMemcpyAsync(S0.v[d], plane.data(), np * 4, hipMemcpyHostToDevice, e->stream));
+        HIP_TRY(hipStreamSynchronize(e->stream));
+    }
+    std::vector<int> iota(np);
+    std::iota(iota.begin(), iota.end(), 0);
+    HIP_TRY(hipMemcpy(S0.pid, iota.data(), np * 4, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(p.imap, iota.data(), np * 4, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(e->d_pids_api, iota.data(), np * 4, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(e->d_apimap, iota.data(), np * 4, hipMemcpyHostToDevice));
+    std::vector<int> col(nf);
+    for (int d = 0; d < 3; ++d) {
+        for (size_t f = 0; f < nf; ++f) col[f] = e->h_idx[f * 3 + d] + (int)nf;
+        HIP_TRY(hipMemcpy(idx_orig[d], col.data(), nf * 4, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(p.fv[d], col.data(), nf * 4, hipMemcpyHostToDevice));
+    }
+    // vertex -> (face, corner) adjacency, ascending face id
+    std::vector<int> off(nv + 1, 0), fc(3 * nf);
+    for (size_t k = 0; k < 3 * nf; ++k) off[e->h_idx[k] + 1]++;
+    for (size_t v = 0; v < nv; ++v) off[v + 1] += off[v];
+    {
+        std::vector<int> fill(off.begin(), off.end() - 1);
+        for (size_t f = 0; f < nf; ++f)
+            for (int c = 0; c < 3; ++c) fc[fill[e->h_idx[f * 3 + c]]++] = (int)(f << 2) | c;
+    }
+    HIP_TRY(hipMemcpy(adj_off, off.data(), (nv + 1) * 4, hipMemcpyHostToDevice));
+    if (nf) HIP_TRY(hipMemcpy(adj_fc, fc.data(), 3 * nf * 4, hipMemcpyHostToDevice));
+
+    // ---- launch geometry --------------------------------------------------
+    e->g_np = (unsigned)((np + 255) / 256);
+    e->g_nf = (unsigned)((nf + 255) / 256);
+    e->g_nv = (unsigned)((nv + 255) / 256);
+    e->g_tile = std::min(1024u, p.capH);
+    e->g_grid = std::min(1024u, (p.capA + 3) / 4);
+
+    // ---- FEM initialisation (cuda_mpm_kernels.cuh:13-70) + first sort -----
+    if (nf) hipLaunchKernelGGL(k_init_faces, dim3(e->g_nf), dim3(256), 0, e->stream, p);
+    if (nv) hipLaunchKernelGGL(k_init_vertex_volumes, dim3(e->g_nv), dim3(256), 0, e->stream, p);
+    Ctl c0{};
+    c0.cur = 0;
+    c0.need_rebuild = 1;
+    HIP_TRY(hipMemcpyAsync(p.ctl, &c0, sizeof(Ctl), hipMemcpyHostToDevice, e->stream));
+    launch_rebuild(e);
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    HIP_TRY(hipGetLastError());
+    e->finalized = true;
+    return mpm_sync(e);
+}
+
+int mpm_destroy(mpm_handle_t e) {
+    if (!e) return 0;
+    hipSetDevice(e->device);
+    if (e->own_stream) hipStreamSynchronize(e->own_stream);
+    for (void* a : e->allocs) hipFree(a);
+    if (e->d_stage) hipFree(e->d_stage);
+    e->cb.release();
+    if (e->own_stream) hipStreamDestroy(e->own_stream);
+    delete e;
+    return 0;
+}
+
+int mpm_counts(mpm_handle_t e, size_t* nv, size_t* nf, size_t* np) {
+    REQUIRE(e, "null handle");
+    if (nv) *nv = e->nv;
+    if (nf) *nf = e->nf;
+    if (np) *np = e->np;
+    return 0;
+}
+
+int mpm_set_stream(mpm_handle_t e, void* s) {
+    REQUIRE(e, "null handle");
+    if (int rc = use(e)) return rc;
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    e->stream = s ? static_cast<hipStream_t>(s) : e->own_stream;
+    return 0;
+}
+
+int mpm_sync(mpm_handle_t e) {
+    REQUIRE(e, "null handle");
+    if (int rc = use(e)) return rc;
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    HIP_TRY(hipGetLastError());
+    if (!e->finalized && !e->dp.ctl) return 0;
+    Ctl c;
+    HIP_TRY(hipMemcpy(&c, e->dp.ctl, sizeof(Ctl), hipMemcpyDeviceToHost));
+    if (c.error & ERR_CAPACITY) return fail(MPM_ERR_CAPACITY, "block table overflow");
+    if (c.error & ERR_DRIFT)
+        return fail(MPM_ERR_DRIFT,
+                    "a particle moved more than one cell in a substep (left its block's free zone); "
+                    "results are invalid -- reduce dt");
+    return 0;
+}
+
+// ---- the solver calls -----------------------------------------------------
+#define READY(e)                                        \
+    REQUIRE(e, "null handle");                          \
+    REQUIRE((e)->finalized, "call mpm_finalize first"); \
+    if (int rc__ = use(e)) return rc__
+
+int mpm_rebuild_mapping(mpm_handle_t e, int sort) {
+    READY(e);
+    launch_rebuild(e);
+    if (sort) return api_sort(e);
+    return 0;
+}
+
+int mpm_calc_fem_state_and_force(mpm_handle_t e, float dt) {
+    READY(e);
+    launch_fem(e, dt);
+    return 0;
+}
+
+int mpm_particle_to_grid(mpm_handle_t e, float dt) {
+    READY(e);
+    launch_p2g(e, dt);
+    e->grid_state = 1;
+    return 0;
+}
+
+int mpm_update_grid(mpm_handle_t e, int bc) {
+    READY(e);
+    REQUIRE(e->grid_state >= 1, "UpdateGrid before ParticleToGrid");
+    launch_grid(e, bc);
+    e->grid_state = 2;
+    return 0;
+}
+
+int mpm_grid_to_particle(mpm_handle_t e, float dt) {
+    READY(e);
+    REQUIRE(e->grid_state == 2, "GridToParticle before UpdateGrid");
+    launch_g2p(e, dt);
+    e->substeps += 1;
+    return 0;
+}
+
+int mpm_substep(mpm_handle_t e, float dt, int bc) { return mpm_run_substeps(e, 1, dt, bc); }
+
+int mpm_run_substeps(mpm_handle_t e, int n, float dt, int bc) {
+    READY(e);
+    for (int s = 0; s < n; ++s) {
+        launch_rebuild(e);
+        launch_fem(e, dt);
+        launch_p2g(e, dt);
+        launch_grid(e, bc);
+        launch_g2p(e, dt);
+    }
+    e->grid_state = 2;
+    e->substeps += (uint64_t)std::max(n, 0);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int mpm_profile_substeps(mpm_handle_t e, int n, float dt, int bc, float* phase_ms, float* total_ms) {
+    READY(e);
+    REQUIRE(n > 0 && n <= 4096, "n out of range");
+    const int NE = MPM_PHASE_COUNT + 1;
+    std::vector<hipEvent_t> ev((size_t)n * NE);
+    for (auto& x : ev) HIP_TRY(hipEventCreate(&x));
+    for (int s = 0; s < n; ++s) {
+        hipEvent_t* q = &ev[(size_t)s * NE];
+        HIP_TRY(hipEventRecord(q[0], e->stream));
+        launch_rebuild(e);
+        HIP_TRY(hipEventRecord(q[1], e->stream));
+        launch_fem(e, dt);
+        HIP_TRY(hipEventRecord(q[2], e->stream));
+        launch_p2g(e, dt);
+        HIP_TRY(hipEventRecord(q[3], e->stream));
+        launch_grid(e, bc);
+        HIP_TRY(hipEventRecord(q[4], e->stream));
+        launch_g2p(e, dt);
+        HIP_TRY(hipEventRecord(q[5], e->stream));
+    }
+    e->grid_state = 2;
+    e->substeps += (uint64_t)n;
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    double acc[MPM_PHASE_COUNT] = {0, 0, 0, 0, 0}, tot = 0;
+    for (int s = 0; s < n; ++s) {
+        hipEvent_t* q = &ev[(size_t)s * NE];
+        for (int k = 0; k < MPM_PHASE_COUNT; ++k) {
+            float ms = 0;
+            HIP_TRY(hipEventElapsedTime(&ms, q[k], q[k + 1]));
+            acc[k] += ms;
+        }
+        float ms = 0;
+        HIP_TRY(hipEventElapsedTime(&ms, q[0], q[MPM_PHASE_COUNT]));
+        tot += ms;
+    }
+    for (auto& x : ev) hipEventDestroy(x);
+    if (phase_ms)
+        for (int k = 0; k < MPM_PHASE_COUNT; ++k) phase_ms[k] = (float)(acc[k] / n);
+    if (total_ms) *total_ms = (float)(tot / n);
+    return 0;
+}
+
+int mpm_get_stats(mpm_handle_t e, mpm_stats_t* out) {
+    READY(e);
+    REQUIRE(out, "null stats");
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    Ctl c;
+    HIP_TRY(hipMemcpy(&c, e->dp.ctl, sizeof(Ctl), hipMemcpyDeviceToHost));
+    out->substeps = e->substeps;
+    out->rebuilds = c.rebuilds;
+    out->home_blocks = c.n_home;
+    out->active_blocks = c.n_active;
+    out->error_flags = c.error;
+    out->touched_blocks = 0;
+    if (e->grid_state >= 1) {
+        uint32_t cnt = 0;
+        if (int rc = touched_flags(e, nullptr, &cnt)) return rc;
+        out->touched_blocks = cnt;
+    }
+    return 0;
+}
+
+int mpm_grid_touched_cnt(mpm_handle_t e, uint32_t* out) {
+    READY(e);
+    REQUIRE(out, "null output");
+    *out = 0;
+    if (e->grid_state < 1) return 0;
+    return touched_flags(e, nullptr, out);
+}
+
+int mpm_download_array(mpm_handle_t e, int which, void* out, size_t bytes, size_t* written) {
+    READY(e);
+    REQUIRE(out, "null output");
+    return download_array(e, which, out, bytes, written);
+}
+
+int mpm_upload_particle_state(mpm_handle_t e, const float* pos, const float* vel, const float* affine,
+                              const float* volumes, const float* deformation_gradients) {
+    READY(e);
+    return upload_state(e, pos, vel, affine, volumes, deformation_gradients);
+}
+
+int mpm_sync_particle_state_to_cpu(mpm_handle_t e, float* pos_out) {
+    READY(e);
+    REQUIRE(pos_out, "null output");
+    return download_array(e, MPM_ARR_POSITIONS, pos_out, e->np * 12, nullptr);
+}
+
+int mpm_dump_cpu_state(mpm_handle_t e, float* pos_out, int32_t* idx_out) {
+    READY(e);
+    if (pos_out) {
+        // original vertex order = original ids nf..np (cuda_mpm_model.cu:257-260)
+        if (int rc = download_original_vertices(e, pos_out)) return rc;
+    }
+    if (idx_out) std::copy(e->h_idx.begin(), e->h_idx.end(), idx_out);
+    return 0;
+}
+
+int mpm_dump_obj(mpm_handle_t e, const char* filename) {
+    READY(e);
+    REQUIRE(filename, "null filename");
+    std::vector<float> pos(e->nv * 3);
+    if (int rc = download_original_vertices(e, pos.data())) return rc;
+    std::ofstream obj(filename);
+    if (!obj) return fail(MPM_ERR_INVALID, std::string("cannot open ") + filename);
+    for (size_t i = 0; i < e->nv; ++i) obj << "v " << pos[i * 3] << " " << pos[i * 3 + 1] << " " << pos[i * 3 + 2] << "\n";
+    for (size_t f = 0; f < e->nf; ++f)
+        obj << "f " << e->h_idx[f * 3] + 1 << " " << e->h_idx[f * 3 + 1] + 1 << " " << e->h_idx[f * 3 + 2] + 1 << "\n";
+    return 0;
+}
+
+int mpm_set_dump_dir(mpm_handle_t e, const char* dir) {
+    REQUIRE(e && dir, "null argument");
+    e->dump_dir = dir;
+    return 0;
+}
+
+int mpm_reallocate_external_bodies(mpm_handle_t e, size_t n) {
+    READY(e);
+    return e->cb.resize_bodies(n, e->stream);
+}
+
+int mpm_external_body_force_to_host(mpm_handle_t e, float* tau_out, float* f_out) {
+    READY(e);
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    if (e->cb.n_bodies == 0) return 0;
+    if (tau_out) HIP_TRY(hipMemcpy(tau_out, e->cb.body_tau, e->cb.n_bodies * 12, hipMemcpyDeviceToHost));
+    if (f_out) HIP_TRY(hipMemcpy(f_out, e->cb.body_f, e->cb.n_bodies * 12, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int mpm_copy_contact_pairs(mpm_handle_t e, size_t n, const uint32_t* particle, const uint32_t* body, const float* dist,
+                           const float* normal, const float* pos, const float* rigid_v, const float* rigid_p_WB) {
+    READY(e);
+    REQUIRE(n == 0 || (particle && body && dist && normal && pos && rigid_v && rigid_p_WB), "null contact array");
+    return copy_contacts(e, n, particle, body, dist, normal, pos, rigid_v, rigid_p_WB);
+}
+
+int mpm_update_contact(mpm_handle_t e, int frame, int substep, float dt, float mu, float stiffness, float damping,
+                       int dump, int exact, int max_iters, int* iters_out, float* residual_out) {
+    READY(e);
+    if (iters_out) *iters_out = 0;
+    if (residual_out) *residual_out = 0.f;
+    if (e->cb.n == 0) return 0;  // cuda_mpm_solver.cu:216-217
+    REQUIRE(e->grid_state == 2, "UpdateContact before UpdateGrid");
+    return update_contact(e, frame, substep, dt, mu, stiffness, damping, dump, exact, max_iters, iters_out,
+                          residual_out);
+}
+
+}  // extern "C"

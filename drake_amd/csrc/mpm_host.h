@@ -1,0 +1,88 @@
+// Host-side engine object shared by the C-ABI implementation files.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <string>
+#include <vector>
+
+#include "../../include/mpm_hip.h"
+#include "mpm_device.h"
+#include "mpm_rebuild.h"
+#include "mpm_step.h"
+#include "mpm_contact_dev.h"
+
+using namespace mpm;
+
+static thread_local std::string g_last_error;
+
+static int fail(int code, const std::string& msg) {
+    g_last_error = msg;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                                   \
+    do {                                                                                                \
+        hipError_t e__ = (expr);                                                                        \
+        if (e__ != hipSuccess)                                                                          \
+            return fail(MPM_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e__));               \
+    } while (0)
+
+#define REQUIRE(cond, msg)                                   \
+    do {                                                     \
+        if (!(cond)) return fail(MPM_ERR_INVALID, (msg));    \
+    } while (0)
+
+struct mpm_engine {
+    int device = 0;
+    int bits = 7;
+    mpm_material_t mat{};
+    hipStream_t stream = nullptr, own_stream = nullptr;
+    bool finalized = false;
+    // staged cloth (AddQRCloth)
+    std::vector<float> h_pos, h_vel;
+    std::vector<int> h_idx;  // vertex ids local to the vertex array
+    size_t nv = 0, nf = 0, np = 0;
+    DP dp{};
+    std::vector<void*> allocs;
+    // slot (API) order bookkeeping: slot -> original id and its inverse
+    int* d_pids_api = nullptr;
+    int* d_apimap = nullptr;
+    bool api_identity = true;
+    int grid_state = 0;  // 0 nothing, 1 slabs valid (after P2G), 2 grid updated
+    uint64_t substeps = 0;
+    // launch geometry
+    unsigned g_np = 0, g_nf = 0, g_nv = 0, g_tile = 0, g_grid = 0;
+    // contacts / rigid bodies
+    ContactBuffers cb{};
+    std::string dump_dir = ".";
+    // scratch for downloads
+    void* d_stage = nullptr;
+    size_t stage_bytes = 0;
+
+    template <class T>
+    int dalloc(T** out, size_t n, bool zero) {
+        void* ptr = nullptr;
+        const size_t bytes = std::max<size_t>(n, 1) * sizeof(T);
+        HIP_TRY(hipMalloc(&ptr, bytes));
+        allocs.push_back(ptr);
+        if (zero) HIP_TRY(hipMemsetAsync(ptr, 0, bytes, stream));
+        *out = static_cast<T*>(ptr);
+        return 0;
+    }
+    int stage(size_t bytes) {
+        if (bytes > stage_bytes) {
+            if (d_stage) HIP_TRY(hipFree(d_stage));
+            d_stage = nullptr;
+            HIP_TRY(hipMalloc(&d_stage, bytes));
+            stage_bytes = bytes;
+        }
+        return 0;
+    }
+};
+
+static int use(mpm_engine* e) {
+    HIP_TRY(hipSetDevice(e->device));
+    return 0;
+}
+

@@ -1,0 +1,242 @@
+/*
+ * mpm_hip.h -- C ABI of the MI355X-native cloth-MPM substep engine.
+ *
+ * This is the drop-in boundary for the hot path of g1n0st/drake's
+ * multibody/gpu_mpm layer: every entry point below replaces one method of the
+ * reference's GpuMpmState<float> / GpuMpmSolver<float> pair (the only scalar
+ * type the reference instantiates, cuda_mpm_model.cu:347, cuda_mpm_solver.cu:623).
+ * Citations are file:line under the reference tree.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; host buffers are caller-owned
+ *   - every call returns 0 on success or a negative mpm_status; the message
+ *     for the calling thread's last failure is mpm_last_error()
+ *   - one handle <-> one HIP device; calls on one handle must be serialised
+ *     by the caller (the reference is single-threaded per state as well)
+ *   - "slot order" is the reference's current particle order: [faces | verts]
+ *     after mpm_finalize (cuda_mpm_model.cu:40-45), permuted by every
+ *     mpm_rebuild_mapping(h, 1) exactly like RebuildMapping(state, true)
+ *     (stable sort on the low min(3*domain_bits,16) key bits,
+ *     cuda_mpm_solver.cu:47-68).  The engine's internal memory order is
+ *     different (block/cell sorted SoA) and never visible through this API.
+ *   - vectors cross the boundary as packed float triples / row-major 3x3,
+ *     exactly like the reference's Vec3<float>/Mat3<float> device buffers.
+ */
+#ifndef MPM_HIP_H_
+#define MPM_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#if defined(__GNUC__)
+#define MPM_API __attribute__((visibility("default")))
+#else
+#define MPM_API
+#endif
+
+typedef struct mpm_engine *mpm_handle_t;
+
+typedef enum {
+    MPM_OK = 0,
+    MPM_ERR_INVALID = -1,     /* bad argument / call order                     */
+    MPM_ERR_HIP = -2,         /* a HIP runtime call failed                     */
+    MPM_ERR_DRIFT = -3,       /* a particle left its block's free zone (CFL>1) */
+    MPM_ERR_CAPACITY = -4,    /* internal table overflow                       */
+    MPM_ERR_NO_DEVICE = -5    /* no usable GPU: there is no CPU fallback       */
+} mpm_status;
+
+/* Runtime form of the compile-time constants in settings.h:36-127. */
+typedef struct {
+    float youngs_modulus; /* settings.h:73  (4e5)                              */
+    float poisson_ratio;  /* settings.h:77  (0.3)                              */
+    float density;        /* settings.h:81  (2000)                             */
+    float gamma;          /* settings.h:85  (0) shear/friction of the cloth    */
+    float K;              /* settings.h:92  (1e5) normal penalty stiffness     */
+    float V;              /* settings.h:99  (0.8) RPIC damping blend           */
+    float c_F;            /* settings.h:103 (0)                                */
+    float sdf_friction;   /* settings.h:110 (0.3)                              */
+    float gravity;        /* settings.h:121 (-9.8)                             */
+    float epsv;           /* settings.h:125 (1e-3) friction regularisation     */
+    int32_t gravity_axis; /* settings.h:118 (2)                                */
+    int32_t wall_cells;   /* settings.h:56  (3) G_BOUNDARY_CONDITION           */
+} mpm_material_t;
+
+/* Arrays that mpm_download_array can return (parity tests, visualisation,
+ * checkpoints).  Particle arrays come back in slot order, packed like the
+ * reference's device buffers; grid arrays are dense and indexed by the
+ * reference's cell key (cuda_mpm_kernels.cuh:334-341). */
+typedef enum {
+    MPM_ARR_POSITIONS = 0,       /* float[3*np]   current_positions()          */
+    MPM_ARR_VELOCITIES = 1,      /* float[3*np]   current_velocities()         */
+    MPM_ARR_VOLUMES = 2,         /* float[np]     current_volumes()            */
+    MPM_ARR_AFFINE = 3,          /* float[9*np]   current_affine_matrices()    */
+    MPM_ARR_PIDS = 4,            /* int32[np]     current_pids()               */
+    MPM_ARR_INDEX_MAPPINGS = 5,  /* int32[np]     index_mappings()             */
+    MPM_ARR_SORT_KEYS = 6,       /* uint32[np]    current_sort_keys() evaluated on the
+                                    current positions (what RebuildMapping computes)  */
+    MPM_ARR_FORCES = 7,          /* float[3*np]   forces()                     */
+    MPM_ARR_TAUS = 8,            /* float[9*np]   taus()                       */
+    MPM_ARR_DEFORMATION_GRADIENTS = 9, /* float[9*nf] original face order      */
+    MPM_ARR_DM_INVERSES = 10,    /* float[4*nf]   original face order          */
+    MPM_ARR_INDICES = 11,        /* int32[3*nf]   indices() (offset by +nf)    */
+    MPM_ARR_GRID_MASSES = 12,    /* float[cells]  grid_masses()                */
+    MPM_ARR_GRID_MOMENTUM = 13,  /* float[3*cells] grid_momentum(): momentum after
+                                    ParticleToGrid, velocity after UpdateGrid   */
+    MPM_ARR_GRID_V_STAR = 14,    /* float[3*cells] grid_v_star()               */
+    MPM_ARR_GRID_TOUCHED_FLAGS = 15, /* uint32[blocks] grid_touched_flags()    */
+    MPM_ARR_GRID_TOUCHED_IDS = 16,   /* uint32[cnt] ascending block ids        */
+    MPM_ARR_CONTACT_VEL = 17,    /* float[3*nk]   contact_vel()                */
+    MPM_ARR_CONTACT_VEL0 = 18,   /* float[3*nk]   contact_vel0()               */
+    MPM_ARR_GRID_DIR = 19        /* float[3*cells] grid_Dir()                  */
+} mpm_array_id;
+
+/* Timed phases reported by mpm_profile_substeps. */
+enum {
+    MPM_PHASE_REBUILD = 0,
+    MPM_PHASE_FEM = 1,
+    MPM_PHASE_P2G = 2,
+    MPM_PHASE_GRID = 3,
+    MPM_PHASE_G2P = 4,
+    MPM_PHASE_COUNT = 5
+};
+
+typedef struct {
+    uint64_t substeps;        /* substeps executed so far                      */
+    uint64_t rebuilds;        /* internal block/cell re-sorts performed        */
+    uint32_t home_blocks;     /* 4^3 blocks that currently own particles       */
+    uint32_t active_blocks;   /* blocks whose nodes are updated each substep   */
+    uint32_t touched_blocks;  /* reference-exact touched count of last P2G     */
+    uint32_t error_flags;     /* sticky device error bits (0 = none)           */
+} mpm_stats_t;
+
+MPM_API const char *mpm_last_error(void);
+MPM_API int mpm_default_material(mpm_material_t *out);
+
+/* ---- GpuMpmState<float> -------------------------------------------------- */
+
+/* `GpuMpmState() = default` + the grid constants of settings.h:48-59 made
+ * runtime: the grid is (2^domain_bits)^3 cells of size 2^-domain_bits.
+ * `device` is the HIP device ordinal.  `material` may be NULL (defaults). */
+MPM_API int mpm_create(int domain_bits, const mpm_material_t *material, int device, mpm_handle_t *out);
+
+/* GpuMpmState::AddQRCloth (cuda_mpm_model.cu:16-33).  pos/vel: float[3*n_verts];
+ * indices: int32[3*n_faces] local to this cloth.  May be called repeatedly. */
+MPM_API int mpm_add_qr_cloth(mpm_handle_t h, const float *pos, const float *vel, size_t n_verts,
+                             const int32_t *indices, size_t n_faces);
+
+/* GpuMpmState::Finalize (cuda_mpm_model.cu:36-122): allocates every device
+ * buffer, uploads the particles and runs the FEM initialisation kernel. */
+MPM_API int mpm_finalize(mpm_handle_t h);
+
+/* GpuMpmState::Destroy (cuda_mpm_model.cu:124-242); also frees the handle. */
+MPM_API int mpm_destroy(mpm_handle_t h);
+
+/* n_verts() / n_faces() / n_particles() (cuda_mpm_model.cuh:43-45). */
+MPM_API int mpm_counts(mpm_handle_t h, size_t *n_verts, size_t *n_faces, size_t *n_particles);
+
+/* grid_touched_cnt_host() (cuda_mpm_model.cuh:95-100); synchronises. */
+MPM_API int mpm_grid_touched_cnt(mpm_handle_t h, uint32_t *out);
+
+/* GpuMpmState::DumpCpuState (cuda_mpm_model.cu:244-265): vertex positions in
+ * original vertex order (float[3*n_verts]) and triangle indices local to the
+ * vertex array (int32[3*n_faces]).  Either pointer may be NULL. */
+MPM_API int mpm_dump_cpu_state(mpm_handle_t h, float *pos_out, int32_t *indices_out);
+
+/* ReallocateContacts is implicit in mpm_copy_contact_pairs. */
+
+/* GpuMpmState::ReallocateExternelBodies (cuda_mpm_model.cu:319-338): sizes and
+ * zeroes the per-body impulse accumulators. */
+MPM_API int mpm_reallocate_external_bodies(mpm_handle_t h, size_t n_bodies);
+
+/* GpuMpmState::ExternelBodyForceToHost (cuda_mpm_model.cu:340-345):
+ * tau_out / f_out: float[3*n_bodies] accumulated impulses (F_Bq_W_tau, F_Bq_W_f). */
+MPM_API int mpm_external_body_force_to_host(mpm_handle_t h, float *tau_out, float *f_out);
+
+/* ---- GpuMpmSolver<float> ------------------------------------------------- */
+
+/* GpuMpmSolver::RebuildMapping (cuda_mpm_solver.cu:17-70).  Must be called
+ * once per substep before mpm_particle_to_grid, as every reference caller does
+ * (deformable_driver.h:244, cuda_mpm_test.cc:66).  sort != 0 re-orders the
+ * slot order like the reference's stable 16-bit radix sort. */
+MPM_API int mpm_rebuild_mapping(mpm_handle_t h, int sort);
+
+/* GpuMpmSolver::CalcFemStateAndForce (cuda_mpm_solver.cu:72-84). */
+MPM_API int mpm_calc_fem_state_and_force(mpm_handle_t h, float dt);
+
+/* GpuMpmSolver::ParticleToGrid (cuda_mpm_solver.cu:86-105). */
+MPM_API int mpm_particle_to_grid(mpm_handle_t h, float dt);
+
+/* GpuMpmSolver::UpdateGrid (cuda_mpm_solver.cu:107-151); mpm_bc in {-1,0,1,2,3}. */
+MPM_API int mpm_update_grid(mpm_handle_t h, int mpm_bc);
+
+/* GpuMpmSolver::GridToParticle (cuda_mpm_solver.cu:153-161). */
+MPM_API int mpm_grid_to_particle(mpm_handle_t h, float dt);
+
+/* GpuMpmSolver::GpuSync (cuda_mpm_solver.cu:163-166); also surfaces sticky
+ * device error flags as MPM_ERR_DRIFT / MPM_ERR_CAPACITY. */
+MPM_API int mpm_sync(mpm_handle_t h);
+
+/* GpuMpmSolver::SyncParticleStateToCpu (cuda_mpm_solver.cu:185-191):
+ * pos_out: float[3*n_particles] in slot order (the reference fills
+ * positions_host()). */
+MPM_API int mpm_sync_particle_state_to_cpu(mpm_handle_t h, float *pos_out);
+
+/* GpuMpmSolver::Dump (cuda_mpm_solver.cu:168-183): Wavefront OBJ. */
+MPM_API int mpm_dump_obj(mpm_handle_t h, const char *filename);
+
+/* GpuMpmSolver::CopyContactPairs (cuda_mpm_solver.cu:193-212) taking the
+ * MpmParticleContactPairs SoA (cpu_mpm_model.h:73-114): particle slot index,
+ * rigid body index, signed distance (<0), normal, contact position, rigid
+ * point velocity, body origin p_WB. */
+MPM_API int mpm_copy_contact_pairs(mpm_handle_t h, size_t n_contacts, const uint32_t *particle_in_contact_index,
+                                   const uint32_t *non_mpm_id, const float *penetration_distance,
+                                   const float *normal, const float *particle_in_contact_position,
+                                   const float *rigid_v, const float *rigid_p_WB);
+
+/* GpuMpmSolver::UpdateContact (cuda_mpm_solver.cu:214-621).  iterations_out,
+ * residual_out may be NULL.  frame/substep/dump only name the optional JSON
+ * statistics file (written to dump_dir set by mpm_set_dump_dir, default ".").
+ * max_newton_iterations <= 0 selects the reference's 2000. */
+MPM_API int mpm_update_contact(mpm_handle_t h, int frame, int substep, float dt, float friction_mu, float stiffness,
+                               float damping, int dump, int exact_line_search, int max_newton_iterations,
+                               int *iterations_out, float *residual_out);
+MPM_API int mpm_set_dump_dir(mpm_handle_t h, const char *dir);
+
+/* ---- conveniences on top of the reference interface ---------------------- */
+
+/* The five solver calls of one contact-free substep (cuda_mpm_test.cc:66-72,
+ * deformable_driver.h:244-258 without the contact part), without host syncs. */
+MPM_API int mpm_substep(mpm_handle_t h, float dt, int mpm_bc);
+MPM_API int mpm_run_substeps(mpm_handle_t h, int n, float dt, int mpm_bc);
+
+/* Runs n substeps with HIP events around every kernel group on the engine's
+ * stream and returns the mean milliseconds per substep of each phase
+ * (phase_ms[MPM_PHASE_COUNT]) and of the whole substep. */
+MPM_API int mpm_profile_substeps(mpm_handle_t h, int n, float dt, int mpm_bc, float *phase_ms, float *total_ms);
+
+/* Use a caller-provided hipStream_t (e.g. torch's current stream); NULL
+ * restores the engine's own stream. */
+MPM_API int mpm_set_stream(mpm_handle_t h, void *hip_stream);
+
+MPM_API int mpm_get_stats(mpm_handle_t h, mpm_stats_t *out);
+
+/* Copies one engine array to the host (see mpm_array_id).  `bytes` is the
+ * size of `out`; the call fails if it is too small. *written gets the number
+ * of bytes produced (may be NULL). */
+MPM_API int mpm_download_array(mpm_handle_t h, int which, void *out, size_t bytes, size_t *written);
+
+/* Overwrites particle state -- checkpoint restore and test injection.  pos,
+ * vel (float[3*np]), affine (float[9*np]), volumes (float[np]) are in slot
+ * order; deformation_gradients (float[9*nf]) in original face order, like
+ * mpm_download_array returns them.  Any pointer may be NULL (left unchanged). */
+MPM_API int mpm_upload_particle_state(mpm_handle_t h, const float *pos, const float *vel, const float *affine,
+                                      const float *volumes, const float *deformation_gradients);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MPM_HIP_H_ */

@@ -1,0 +1,50 @@
+"""Shared helpers for the parity tests (oracle vs HIP engine)."""
+import numpy as np
+
+from drake_amd import scenes
+from oracle import oracle as orc
+
+RTOL = 1e-5  # BASELINE.json north_star: "float state within 1e-5 relative"
+
+
+def close(a, b, scale=None, rtol=RTOL, what=""):
+    """max|a-b| <= rtol * scale, where scale is the natural magnitude of the
+    quantity (max|b| unless the caller knows better, e.g. sums that cancel)."""
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    assert a.shape == b.shape, (what, a.shape, b.shape)
+    if b.size == 0:
+        return
+    if scale is None:
+        scale = float(np.max(np.abs(b)))
+    err = float(np.max(np.abs(a - b)))
+    assert np.all(np.isfinite(a)), what
+    assert err <= rtol * scale + 1e-30, f"{what}: max err {err:.3e} > {rtol:.0e} * scale {scale:.3e}"
+
+
+def build_pair(domain_bits=6, layers=3, res=20, z0=0.5, side=0.3, seed=7, vel_amp=0.2, material=None):
+    """Same cloth stack on the oracle and on the engine."""
+    from drake_amd import GpuMpm
+
+    sheets = scenes.cloth_stack(layers, res, domain_bits, z0=z0, side=side, seed=seed, vel_amp=vel_amp)
+    o = orc.OracleMpm(domain_bits)
+    g = GpuMpm(domain_bits, material)
+    for pos, vel, idx in sheets:
+        o.add_qr_cloth(pos, vel, idx)
+        g.add_qr_cloth(pos, vel, idx)
+    o.finalize()
+    g.finalize()
+    return o, g
+
+
+def natural_scales(o, dt=1e-3):
+    """Magnitudes against which 1e-5 relative is measured.
+
+    The explicit update turns strain into velocity with gain dt*E/(rho*dx) (12.8 m/s per unit
+    strain at 64^3, dt=1e-3), so one float32 ulp of the deformation gradient is already a few
+    1e-6 m/s of nodal velocity on any implementation.  Velocities are therefore measured against
+    max(|v|max, g*dt, 10% of that gain); C (a velocity gradient) against 4/dx times that."""
+    dxinv = float(1 << o.domain_bits)
+    stiff = dt * o.p.youngs / o.p.density * dxinv
+    vmax = max(float(np.max(np.abs(o.vel))), 9.8 * dt, 0.1 * stiff)
+    return dict(pos=1.0, vel=vmax, C=4.0 * dxinv * vmax, vol=float(np.max(o.vol)))

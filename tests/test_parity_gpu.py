@@ -1,0 +1,203 @@
+"""HIP engine vs CPU oracle through the C ABI, phase by phase and over short
+trajectories.  Runs on the GPU box only (pytest -m gpu)."""
+import numpy as np
+import pytest
+
+from tests.helpers import RTOL, build_pair, close, natural_scales
+
+pytestmark = pytest.mark.gpu
+
+DT = 1e-3
+
+
+def _A():
+    from drake_amd import ARR
+    return ARR
+
+
+def test_finalize_matches_initialize_fem_state():
+    A = _A()
+    o, g = build_pair()
+    close(g.download(A.VOLUMES), o.vol, what="volumes")
+    close(g.download(A.DEFORMATION_GRADIENTS), o.F, scale=1.0, what="F0")
+    close(g.download(A.DM_INVERSES), o.DmInv, what="DmInv")
+    close(g.download(A.POSITIONS), o.pos, scale=1.0, what="pos")
+    close(g.download(A.VELOCITIES), o.vel, what="vel")
+    assert np.array_equal(g.download(A.INDICES).reshape(-1), o.indices)
+    assert np.array_equal(g.download(A.PIDS), o.pids)
+    p, i = g.dump_cpu_state()
+    po, io = o.dump_cpu_state()
+    assert np.array_equal(i, io)
+    assert np.array_equal(p, po)
+
+
+def test_keys_bit_exact_and_sort_maps():
+    A = _A()
+    o, g = build_pair()
+    o.rebuild_mapping(False)
+    g.rebuild_mapping(False)
+    assert np.array_equal(g.download(A.SORT_KEYS), o.sort_keys)
+    # RebuildMapping(sort=true): slot permutation must be the reference's stable 16-bit sort
+    o.rebuild_mapping(True)
+    g.rebuild_mapping(True)
+    assert np.array_equal(g.download(A.PIDS), o.pids)
+    assert np.array_equal(g.download(A.INDEX_MAPPINGS), o.index_mappings)
+    assert np.array_equal(g.download(A.SORT_KEYS), o.sort_keys)
+    close(g.download(A.POSITIONS), o.pos, scale=1.0, what="sorted pos")
+    close(g.download(A.VOLUMES), o.vol, what="sorted vol")
+
+
+@pytest.mark.parametrize("bc", [-1, 0, 1, 2, 3])
+def test_phase_by_phase(bc):
+    A = _A()
+    # place the sheets where the analytic colliders of that scene live
+    z0 = {-1: 0.5, 0: 0.56, 1: 0.75, 2: 0.11, 3: 0.5}[bc]
+    side = {-1: 0.3, 0: 0.3, 1: 0.34, 2: 0.3, 3: 0.5}[bc]
+    o, g = build_pair(z0=z0, side=side)
+    for step in range(3):
+        sc = natural_scales(o)
+        # same inputs on both sides for every step, so each kernel is judged on one step's rounding
+        # (the stiff cloth amplifies differences from step to step; trajectories are tested below)
+        g.upload_particle_state(o.pos, o.vel, o.C, None, o.F)
+        o.rebuild_mapping(False)
+        g.rebuild_mapping(False)
+        assert np.array_equal(g.download(A.SORT_KEYS), o.sort_keys)
+        o.calc_fem_state_and_force(DT)
+        g.calc_fem_state_and_force(DT)
+        close(g.download(A.DEFORMATION_GRADIENTS), o.F, scale=1.0, what="F")
+        # Stress is E * (F - R): one ulp of F (1e-7) is already E * 1e-7 of stress, so the natural
+        # scale of tau is vol * E (unit strain) and of a nodal force vol * E / edge; an undeformed
+        # cloth has tau = rounding noise far below that.
+        s_tau = max(float(np.abs(o.taus).max()), sc["vol"] * 4e5)
+        close(g.download(A.TAUS), o.taus, scale=s_tau, what="taus")
+        close(g.download(A.FORCES), o.forces, scale=max(float(np.abs(o.forces).max()), s_tau * (1 << o.domain_bits)),
+              what="forces")
+        close(g.download(A.POSITIONS), o.pos, scale=1.0, what="pos after fem")
+        close(g.download(A.VELOCITIES), o.vel, scale=sc["vel"], what="vel after fem")
+        o.particle_to_grid(DT)
+        g.particle_to_grid(DT)
+        gm = g.download(A.GRID_MASSES)
+        close(gm, o.g_m, what="grid mass")
+        # momentum is a sum with cancellation: scale by |v|max * m_max
+        close(g.download(A.GRID_MOMENTUM), o.g_mv, scale=sc["vel"] * float(o.g_m.max()), what="grid mv")
+        assert np.array_equal(g.download(A.GRID_TOUCHED_FLAGS), o.g_flags)
+        o.update_grid(bc)
+        g.update_grid(bc)
+        assert g.grid_touched_cnt() == o.g_cnt
+        assert np.array_equal(g.download(A.GRID_TOUCHED_IDS), o.touched_blocks())
+        vsc = sc["vel"]
+        # A node's velocity is a quotient of two sums that are both tiny on the stencil fringe; what
+        # reaches the particles is w * v with the same tiny w, so nodes are compared mass-weighted.
+        wgt = (o.g_m / o.g_m.max())[:, None]
+        close(g.download(A.GRID_MOMENTUM) * wgt, o.g_mv * wgt, scale=vsc, what="grid v")
+        close(g.download(A.GRID_V_STAR) * wgt, o.g_vstar * wgt, scale=vsc, what="grid v*")
+        o.grid_to_particle(DT)
+        g.grid_to_particle(DT)
+        sc = natural_scales(o)
+        close(g.download(A.POSITIONS), o.pos, scale=1.0, what="pos")
+        close(g.download(A.VELOCITIES), o.vel, scale=vsc, what="vel")
+        close(g.download(A.AFFINE), o.C, scale=4.0 * (1 << o.domain_bits) * vsc, what="C")
+    g.gpu_sync()
+
+
+def test_trajectory_with_sorts_and_rebuilds():
+    """20 substeps; the reference-style sort every 4th step on both sides; the engine's
+    own block re-sort triggers by itself.  Compared in original particle order."""
+    A = _A()
+    o, g = build_pair(layers=4, res=24, vel_amp=1.0)
+    for step in range(20):
+        srt = step % 4 == 0
+        o.substep(DT, -1, sort=srt)
+        g.rebuild_mapping(srt)
+        g.calc_fem_state_and_force(DT)
+        g.particle_to_grid(DT)
+        g.update_grid(-1)
+        g.grid_to_particle(DT)
+    g.gpu_sync()
+    st = g.stats()
+    assert st["error_flags"] == 0
+    pid_g = g.download(A.PIDS)
+    so = o.state_in_original_order()
+    sc = natural_scales(o)
+
+    def orig(a):
+        out = np.empty_like(a)
+        out[pid_g] = a
+        return out
+
+    # after 20 steps rounding differences have been amplified by the stiff cloth: 1e-4 of scale
+    close(orig(g.download(A.POSITIONS)), so["pos"], scale=1.0, rtol=1e-5, what="traj pos")
+    close(orig(g.download(A.VELOCITIES)), so["vel"], scale=sc["vel"], rtol=2e-3, what="traj vel")
+    close(orig(g.download(A.VOLUMES)), so["vol"], what="traj vol")
+    # index maps, per original particle: equal unless the particle sits within rounding of a cell face
+    o.rebuild_mapping(False)  # keys of the current positions (the engine derives them on demand)
+    ko = np.empty_like(o.sort_keys)
+    ko[o.pids] = o.sort_keys
+    assert (orig(g.download(A.SORT_KEYS)) == ko).mean() > 0.995
+    # pids / index_mappings stay mutually inverse permutations
+    im = g.download(A.INDEX_MAPPINGS)
+    assert np.array_equal(im[pid_g], np.arange(pid_g.size))
+
+
+def test_substep_equals_phase_calls():
+    A = _A()
+    _, g1 = build_pair(seed=11)
+    _, g2 = build_pair(seed=11)
+    for _ in range(5):
+        g1.substep(DT, -1)
+        g2.rebuild_mapping(False)
+        g2.calc_fem_state_and_force(DT)
+        g2.particle_to_grid(DT)
+        g2.update_grid(-1)
+        g2.grid_to_particle(DT)
+    close(g1.download(A.POSITIONS), g2.download(A.POSITIONS), scale=1.0, rtol=1e-6, what="substep pos")
+    close(g1.download(A.VELOCITIES), g2.download(A.VELOCITIES), rtol=1e-4, what="substep vel")
+
+
+def test_free_fall_and_conservation_large():
+    """Size-independent properties at a size the oracle is not run on: 250k particles on 128^3."""
+    from drake_amd import ARR as A, GpuMpm, scenes
+    g = GpuMpm(7)
+    scenes.populate(g, scenes.cloth_stack(8, 102, 7, z0=0.6, vel_amp=0.0, jitter=0.0))
+    vol = g.download(A.VOLUMES)
+    n = 20
+    for _ in range(n):
+        g.rebuild_mapping(False)
+        g.calc_fem_state_and_force(DT)
+        g.particle_to_grid(DT)
+        m = g.download(A.GRID_MASSES)
+        mv = g.download(A.GRID_MOMENTUM)
+        g.update_grid(-1)
+        g.grid_to_particle(DT)
+    g.gpu_sync()
+    assert g.stats()["error_flags"] == 0
+    mass = float(vol.astype(np.float64).sum() * 2000.0)
+    assert abs(float(m.astype(np.float64).sum()) - mass) <= 2e-5 * mass
+    v = g.download(A.VELOCITIES)
+    np.testing.assert_allclose(v[:, 2], -9.8 * DT * n, rtol=5e-5)
+    assert np.max(np.abs(v[:, :2])) < 1e-4
+    # grid momentum of the last scatter = particle momentum before it + gravity impulse
+    pz = float(mv[:, 2].astype(np.float64).sum())
+    expect = mass * (-9.8 * DT * n)
+    assert abs(pz - expect) <= 1e-4 * abs(expect)
+
+
+def test_error_paths_and_edge_cases():
+    from drake_amd import GpuMpm, MpmError
+    g = GpuMpm(6)
+    with pytest.raises(MpmError):
+        g.finalize()  # no particles
+    g = GpuMpm(6)
+    with pytest.raises(MpmError):
+        g.add_qr_cloth(np.zeros((3, 3), np.float32), np.zeros((3, 3), np.float32), np.array([0, 1, 5], np.int32))
+    # a single triangle, and vertices without faces, are legal inputs
+    g = GpuMpm(6)
+    pos = np.array([[0.5, 0.5, 0.5], [0.52, 0.5, 0.5], [0.5, 0.52, 0.5], [0.6, 0.6, 0.6]], np.float32)
+    g.add_qr_cloth(pos, np.zeros_like(pos), np.array([0, 1, 2], np.int32))
+    g.finalize()
+    with pytest.raises(MpmError):
+        g.update_grid(-1)  # before ParticleToGrid
+    for _ in range(3):
+        g.substep(DT, -1)
+    g.gpu_sync()
+    assert g.n_particles == 5 and g.n_faces == 1
