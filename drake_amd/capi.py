@@ -52,7 +52,7 @@ SYMBOLS = [
     "mpm_external_body_force_to_host", "mpm_rebuild_mapping", "mpm_calc_fem_state_and_force", "mpm_particle_to_grid",
     "mpm_update_grid", "mpm_grid_to_particle", "mpm_sync", "mpm_sync_particle_state_to_cpu", "mpm_dump_obj",
     "mpm_copy_contact_pairs", "mpm_update_contact", "mpm_set_dump_dir", "mpm_substep", "mpm_run_substeps",
-    "mpm_profile_substeps", "mpm_set_stream", "mpm_get_stats", "mpm_download_array", "mpm_upload_particle_state",
+    "mpm_profile_substeps", "mpm_set_stream", "mpm_get_stats", "mpm_debug_counters", "mpm_download_array", "mpm_upload_particle_state",
 ]
 
 
@@ -99,6 +99,7 @@ def load_library(build: bool = True):
         "mpm_profile_substeps": [vp, i, f, i, P(f), P(f)],
         "mpm_set_stream": [vp, vp],
         "mpm_get_stats": [vp, P(Stats)],
+        "mpm_debug_counters": [vp, P(C.c_uint64), i],
         "mpm_download_array": [vp, i, vp, sz, P(sz)],
         "mpm_upload_particle_state": [vp, vp, vp, vp, vp, vp],
     }
@@ -248,6 +249,11 @@ class GpuMpm:
 
     def set_stream(self, stream_handle: int | None):
         self._ck(self.lib.mpm_set_stream(self.h, C.c_void_p(stream_handle) if stream_handle else None))
+
+    def debug_counters(self, reset: bool = True):
+        out = (C.c_uint64 * 16)()
+        self._ck(self.lib.mpm_debug_counters(self.h, out, 1 if reset else 0))
+        return [int(x) for x in out]
 
     def stats(self) -> dict:
         s = Stats()

@@ -44,7 +44,9 @@ struct Ctl {
     unsigned n_active;     // blocks whose nodes are updated
     unsigned rebuilds;
     unsigned ticket;
-    unsigned pad;
+    unsigned q_p2g;        // work-queue heads of the tile kernels (each kernel re-arms the other's)
+    unsigned q_g2p;
+    unsigned pad[3];
 };
 
 struct DP {
@@ -53,9 +55,13 @@ struct DP {
     int nb;                // blocks per axis
     unsigned nblocks, ncells;
     unsigned capH, capA;
+    int dbg;               // MPM_DBG environment variable (kernel ablation switches, 0 in production)
     float dx, dxinv, Dinv;
+    // fixed-point scales of the LDS tile accumulators (powers of two), see k_p2g
+    double fix_m, fix_p, unfix_m, unfix_p;
     Material M;
     Ctl* ctl;
+    unsigned long long* dbgbuf;  // 16 diagnostic counters (only written when dbg & 4)
     PSet set[2];
     // per-substep scratch
     float* ab[6];          // faces: tau = a (x) b  (a = vol*P[:,2], b = F[:,2])
@@ -80,6 +86,7 @@ struct DP {
     uint32_t* home_block;  // home slot -> block id
     int4* home_range;      // (face begin, face end, vertex begin, vertex end) slots
     int* home_nbr_act;     // [home][27] active slot of block + offset, or -1
+    uint32_t* home_order;  // home slots, most particles first (work-queue order)
     uint32_t* act_block;
     int* act_nbr_home;     // [active][27] home slot of block + offset, or -1
     // grid

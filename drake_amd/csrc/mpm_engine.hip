@@ -6,6 +6,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <fstream>
 #include <numeric>
@@ -103,6 +104,27 @@ static void launch_g2p(mpm_engine* e, float dt) {
     hipLaunchKernelGGL(k_g2p, dim3(e->g_tile), dim3(512), 0, e->stream, e->dp, dt);
 }
 
+// The P2G tiles accumulate in 64-bit fixed point.  Scales are powers of two chosen from the
+// total particle mass M: a node can never hold more than M, and its momentum is allowed
+// |v| < 2^15 length units per time unit.  Resolution: M * 2^-61 (mass), M * 2^-47 (momentum).
+static int set_fixed_point_scales(mpm_engine* e) {
+    DP& p = e->dp;
+    std::vector<float> vol(e->np);
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    Ctl c;
+    HIP_TRY(hipMemcpy(&c, p.ctl, sizeof(Ctl), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(vol.data(), p.set[c.cur & 1].vol, e->np * 4, hipMemcpyDeviceToHost));
+    double mass = 0;
+    for (float v : vol) mass += (double)v * p.M.density;
+    if (!(mass > 0) || !std::isfinite(mass)) mass = 1.0;
+    const int k = 61 - (int)std::ceil(std::log2(mass));
+    p.fix_m = std::ldexp(1.0, k);
+    p.fix_p = std::ldexp(1.0, k - 14);
+    p.unfix_m = 1.0 / p.fix_m;
+    p.unfix_p = 1.0 / p.fix_p;
+    return 0;
+}
+
 int mpm_finalize(mpm_handle_t e) {
     REQUIRE(e, "null handle");
     REQUIRE(!e->finalized, "Finalize called twice");
@@ -113,6 +135,7 @@ int mpm_finalize(mpm_handle_t e) {
     DP& p = e->dp;
     p.Np = (int)np; p.Nf = (int)nf; p.Nv = (int)nv;
     p.bits = e->bits;
+    p.dbg = getenv("MPM_DBG") ? atoi(getenv("MPM_DBG")) : 0;
     p.nb = 1 << (e->bits - 2);
     p.ncells = 1u << (3 * e->bits);
     p.nblocks = p.ncells >> 6;
@@ -133,6 +156,7 @@ int mpm_finalize(mpm_handle_t e) {
 #define ALLOC(ptr, n, zero)                         \
     if ((rc = e->dalloc(&(ptr), (n), (zero)))) return rc
     ALLOC(p.ctl, 1, true);
+    ALLOC(p.dbgbuf, 16, true);
     for (int s = 0; s < 2; ++s) {
         PSet& S = p.set[s];
         for (int d = 0; d < 3; ++d) { ALLOC(S.x[d], np, true); ALLOC(S.v[d], np, true); }
@@ -164,6 +188,7 @@ int mpm_finalize(mpm_handle_t e) {
     ALLOC(p.home_block, p.capH, true);
     ALLOC(p.home_range, p.capH, true);
     ALLOC(p.home_nbr_act, (size_t)p.capH * 27, true);
+    ALLOC(p.home_order, p.capH, true);
     ALLOC(p.act_block, p.capA, true);
     ALLOC(p.act_nbr_home, (size_t)p.capA * 27, true);
     ALLOC(p.slab, (size_t)p.capH * TILE_N, true);
@@ -215,12 +240,13 @@ int mpm_finalize(mpm_handle_t e) {
     e->g_np = (unsigned)((np + 255) / 256);
     e->g_nf = (unsigned)((nf + 255) / 256);
     e->g_nv = (unsigned)((nv + 255) / 256);
-    e->g_tile = std::min(1024u, p.capH);
+    e->g_tile = std::min(512u, p.capH);  // 2 resident workgroups per CU pulling blocks from a queue
     e->g_grid = std::min(1024u, (p.capA + 3) / 4);
 
     // ---- FEM initialisation (cuda_mpm_kernels.cuh:13-70) + first sort -----
     if (nf) hipLaunchKernelGGL(k_init_faces, dim3(e->g_nf), dim3(256), 0, e->stream, p);
     if (nv) hipLaunchKernelGGL(k_init_vertex_volumes, dim3(e->g_nv), dim3(256), 0, e->stream, p);
+    if (int rc2 = set_fixed_point_scales(e)) return rc2;
     Ctl c0{};
     c0.cur = 0;
     c0.need_rebuild = 1;
@@ -414,7 +440,8 @@ int mpm_download_array(mpm_handle_t e, int which, void* out, size_t bytes, size_
 int mpm_upload_particle_state(mpm_handle_t e, const float* pos, const float* vel, const float* affine,
                               const float* volumes, const float* deformation_gradients) {
     READY(e);
-    return upload_state(e, pos, vel, affine, volumes, deformation_gradients);
+    if (int rc = upload_state(e, pos, vel, affine, volumes, deformation_gradients)) return rc;
+    return volumes ? set_fixed_point_scales(e) : 0;
 }
 
 int mpm_sync_particle_state_to_cpu(mpm_handle_t e, float* pos_out) {
@@ -443,6 +470,14 @@ int mpm_dump_obj(mpm_handle_t e, const char* filename) {
     for (size_t i = 0; i < e->nv; ++i) obj << "v " << pos[i * 3] << " " << pos[i * 3 + 1] << " " << pos[i * 3 + 2] << "\n";
     for (size_t f = 0; f < e->nf; ++f)
         obj << "f " << e->h_idx[f * 3] + 1 << " " << e->h_idx[f * 3 + 1] + 1 << " " << e->h_idx[f * 3 + 2] + 1 << "\n";
+    return 0;
+}
+
+int mpm_debug_counters(mpm_handle_t e, uint64_t* out16, int reset) {
+    READY(e);
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    if (out16) HIP_TRY(hipMemcpy(out16, e->dp.dbgbuf, 16 * 8, hipMemcpyDeviceToHost));
+    if (reset) HIP_TRY(hipMemset(e->dp.dbgbuf, 0, 16 * 8));
     return 0;
 }
 

@@ -1,5 +1,8 @@
 // Rebuild = the engine's particle sort: a counting sort of the particle set by
-// (type, block, cell) plus the block tables that the tile kernels use.
+// (type, block, cell) plus the block tables that the tile kernels use.  The
+// cell-level order only has to be approximately right: the transfer kernels
+// regroup each 512-particle chunk by its current base cell in LDS, a well
+// sorted chunk just spans fewer cells.
 // It replaces RebuildMapping's key + radix sort + compute_sorted_state
 // (cuda_mpm_solver.cu:17-70, radix_sort.cuh, cuda_mpm_kernels.cuh:365-416).
 //
@@ -12,24 +15,53 @@
 namespace mpm {
 
 // R1: cell key of every particle, its arrival rank inside the cell and the
-// per-block / per-cell histograms (integer atomics, resolved in L2).
+// per-block / per-cell histograms.  Consecutive slots mostly share a cell (the
+// previous order was cell sorted), so each wave first merges its lanes by
+// (cell, type) and issues one integer atomic per distinct cell and block
+// instead of one per particle (device-scope atomics are resolved at the
+// memory side and are expensive when thousands of them hit one address).
 __global__ __launch_bounds__(256) void k_rb_count(DP p) {
     if (!p.ctl->need_rebuild) return;
     const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= p.Np) return;
+    const bool valid = i < p.Np;
     const PSet& S = p.set[p.ctl->cur];
+    const int ii = valid ? i : p.Np - 1;
     const uint32_t hi = (uint32_t)((1 << p.bits) - 3);
-    uint32_t bx = base_cell(S.x[0][i], p.dxinv), by = base_cell(S.x[1][i], p.dxinv),
-             bz = base_cell(S.x[2][i], p.dxinv);
-    if (bx > hi || by > hi || bz > hi) {
-        atomicOr(&p.ctl->error, ERR_DOMAIN);
-        bx = min(bx, hi); by = min(by, hi); bz = min(bz, hi);
-    }
+    uint32_t bx = base_cell(S.x[0][ii], p.dxinv), by = base_cell(S.x[1][ii], p.dxinv),
+             bz = base_cell(S.x[2][ii], p.dxinv);
+    if (valid && (bx > hi || by > hi || bz > hi)) atomicOr(&p.ctl->error, ERR_DOMAIN);
+    bx = min(bx, hi); by = min(by, hi); bz = min(bz, hi);
+    const int t = ii >= p.Nf;
     const uint32_t key = cell_key(bx, by, bz);
-    const int t = i >= p.Nf;
-    p.pkey[i] = key;
-    p.prank[i] = (uint32_t)atomicAdd(&p.cellcnt[t][key], 1);
-    atomicAdd(&p.blkcnt[t][key >> 6], 1);
+    const int lane = threadIdx.x & 63;
+    // a wave never straddles more than two types; handle them one after the other
+    uint32_t rank = 0;
+    for (int ty = 0; ty < 2; ++ty) {
+        unsigned long long todo = __ballot(valid && t == ty);
+        while (todo) {
+            const int lead = __builtin_ctzll(todo);
+            const uint32_t lk = (uint32_t)__shfl((int)key, lead);
+            const unsigned long long same = __ballot(key == lk) & todo;
+            int base = 0;
+            if (lane == lead) base = atomicAdd(&p.cellcnt[ty][lk], (int)__popcll(same));
+            base = __shfl(base, lead);
+            if (same & (1ull << lane)) rank = (uint32_t)base + (uint32_t)__popcll(same & ((1ull << lane) - 1ull));
+            todo &= ~same;
+        }
+        // block histogram, merged per wave in the same way
+        todo = __ballot(valid && t == ty);
+        while (todo) {
+            const int lead = __builtin_ctzll(todo);
+            const uint32_t lb = (uint32_t)__shfl((int)(key >> 6), lead);
+            const unsigned long long same = __ballot((key >> 6) == lb) & todo;
+            if (lane == lead) atomicAdd(&p.blkcnt[ty][lb], (int)__popcll(same));
+            todo &= ~same;
+        }
+    }
+    if (valid) {
+        p.pkey[i] = key;
+        p.prank[i] = rank;
+    }
 }
 
 struct I3 {
@@ -157,6 +189,32 @@ __global__ __launch_bounds__(1024) void k_rb_tables(DP p) {
     if (n_active > p.capA) {
         if (tid == 0) atomicOr(&c->error, ERR_CAPACITY);
         n_active = p.capA;
+    }
+
+    // F: work-queue order, heaviest blocks first (longest-processing-time-first
+    // keeps the last workgroups short).  Counting sort on the chunk count.
+    {
+        __shared__ int s_bucket[64];
+        if (tid < 64) s_bucket[tid] = 0;
+        __syncthreads();
+        auto bucket_of = [&](unsigned h) {
+            const int4 rg = p.home_range[h];
+            const int chunks = ((rg.y - rg.x) + (rg.w - rg.z) + 255) >> 8;
+            return 63 - min(chunks, 63);  // descending
+        };
+        for (unsigned h = tid; h < n_home; h += 1024) atomicAdd(&s_bucket[bucket_of(h)], 1);
+        __syncthreads();
+        if (tid == 0) {
+            int run = 0;
+            for (int k = 0; k < 64; ++k) {
+                const int c = s_bucket[k];
+                s_bucket[k] = run;
+                run += c;
+            }
+        }
+        __syncthreads();
+        for (unsigned h = tid; h < n_home; h += 1024) p.home_order[atomicAdd(&s_bucket[bucket_of(h)], 1)] = h;
+        __syncthreads();
     }
 
     // E: neighbour tables

@@ -100,91 +100,51 @@ __global__ __launch_bounds__(256) void k_vforce(DP p) {
 
 // ---------------------------------------------------------------------------
 // P2G
+//
+// One workgroup per home block accumulates the block's (TILE_W)^3 node tile in
+// LDS and stores it as a slab.  Inside the block the transfer is organised per
+// base cell: all particles that share a base cell scatter to the same 27 nodes,
+//     node(n) += sum_p w_n(p) * (m_p, q_p + Bdx_p * (i,j,k)_n)
+// which is a small dense contraction  [27 x P] * [P x 13]  (13 = mass, 3
+// momentum terms, 9 affine terms).  It runs on the f32 matrix pipe
+// (v_mfma_f32_16x16x4_f32: exact f32 FMA chains, the VALU rate, but the sum over
+// particles needs no cross-lane shuffles and no per-particle LDS atomics).
+// Every wave works on its own 64-particle groups, without workgroup barriers:
+//   1. every lane loads one particle (coalesced SoA), finds its base cell in
+//      the tile and builds its 13-vector,
+//   2. the wave groups its 64 particles by base cell (ballot loop) and stages
+//      them in a wave-private LDS area,
+//   3. per cell: 4 particles per MFMA step, 2 MFMAs per step (node rows 0-15
+//      and 16-26), then 2 ds_add_f32 (64 distinct tile words each) per cell.
+// Replaces the warp-segmented scatter of cuda_mpm_kernels.cuh:418-543; the
+// order of particles inside a block is irrelevant.
 // ---------------------------------------------------------------------------
-template <int N>
-MPM_DEV float row_shl(float v) {
-    // lane i receives lane i+N of its 16-lane row; 0 past the row end
-    return __builtin_bit_cast(
-        float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x100 + N, 0xF, 0xF, true));
-}
-template <int N>
-MPM_DEV int row_shr_i(int v, int fill) {
-    // lane i receives lane i-N of its row; `fill` before the row start
-    return __builtin_amdgcn_update_dpp(fill, v, 0x110 + N, 0xF, 0xF, false);
-}
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-struct Seg {
-    float t1, t2, t4, t8;  // 1.0 where lane i+d continues this lane's run
-    bool leader;
-};
+constexpr int P2G_CHUNK = 512;
+constexpr int STG = 20;  // staged floats per particle: 16 columns of Y, fx, fy, fz, pad
 
-// Per-row (16 lanes) run structure of `key`: a run is a maximal sequence of
-// consecutive lanes with equal key.  Wave64 adaptation of the idea at
-// cuda_mpm_kernels.cuh:438-457, rebuilt for DPP row operations.
-MPM_DEV Seg make_segments(int key) {
-    const int lane = threadIdx.x & 63;
-    const int prev = row_shr_i<1>(key, ~key);
-    Seg s;
-    s.leader = prev != key;
-    const unsigned long long L = __ballot(s.leader);
-    const int in_row = lane & 15;
-    // leaders strictly above this lane, within the row
-    const unsigned m = (unsigned)(((L >> lane) >> 1) & ((1u << (15 - in_row)) - 1u));
-    const int interval = m ? __builtin_ctz(m) : (15 - in_row);
-    s.t1 = interval >= 1 ? 1.f : 0.f;
-    s.t2 = interval >= 2 ? 1.f : 0.f;
-    s.t4 = interval >= 4 ? 1.f : 0.f;
-    s.t8 = interval >= 8 ? 1.f : 0.f;
-    return s;
+template <int CTRL>
+MPM_DEV float quad_perm(float v) {
+    return __builtin_bit_cast(float,
+                              __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
 }
 
-// Sum of v over this lane's run, valid in the run's first lane.
-MPM_DEV float run_sum(float v, const Seg& s) {
-    v = fmaf(row_shl<1>(v), s.t1, v);
-    v = fmaf(row_shl<2>(v), s.t2, v);
-    v = fmaf(row_shl<4>(v), s.t4, v);
-    v = fmaf(row_shl<8>(v), s.t8, v);
-    return v;
+// LDS accumulation is done in 64-bit fixed point: on gfx950 a wave-wide ds_add_f32
+// costs ~190 LDS cycles per instruction (measured, scratch/lds_atomic_bench.hip)
+// against ~10 for ds_add_u64, and integer sums are exact and order independent.
+MPM_DEV void lds_add_fixed(long long* a, float v, double scale) {
+    const long long q = __double2ll_rn((double)v * scale);
+    __hip_atomic_fetch_add(reinterpret_cast<unsigned long long*>(a), (unsigned long long)q, __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
-MPM_DEV void lds_add(float* a, float v) { __hip_atomic_fetch_add(a, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
-
-// Scatter one particle's 27 stencil contributions into the LDS tile.
-// val(node) = w * (m, q + Bdx * (i,j,k)); all lanes of the wave must call this.
-MPM_DEV void scatter_tile(float4* tile, bool active, int rx, int ry, int rz, const float* wx, const float* wy,
-                          const float* wz, float m, const float* q, const float* Bdx) {
-    const int key = active ? ((rx * 8 + ry) * 8 + rz) : (0x1000 | (int)(threadIdx.x & 63));
-    const Seg seg = make_segments(key);
-    const bool emit = seg.leader && active;
-    float* base = reinterpret_cast<float*>(tile + ((rx * TILE_W + ry) * TILE_W + rz));
-#pragma unroll
-    for (int i = 0; i < 3; ++i) {
-        const float a0 = q[0] + Bdx[0] * (float)i, a1 = q[1] + Bdx[3] * (float)i, a2 = q[2] + Bdx[6] * (float)i;
-#pragma unroll
-        for (int j = 0; j < 3; ++j) {
-            const float wxy = wx[i] * wy[j];
-            const float b0 = a0 + Bdx[1] * (float)j, b1 = a1 + Bdx[4] * (float)j, b2 = a2 + Bdx[7] * (float)j;
-#pragma unroll
-            for (int k = 0; k < 3; ++k) {
-                const float w = wxy * wz[k];
-                float v0 = w * (b0 + Bdx[2] * (float)k);
-                float v1 = w * (b1 + Bdx[5] * (float)k);
-                float v2 = w * (b2 + Bdx[8] * (float)k);
-                float v3 = w * m;
-                v0 = run_sum(v0, seg);
-                v1 = run_sum(v1, seg);
-                v2 = run_sum(v2, seg);
-                v3 = run_sum(v3, seg);
-                if (emit) {
-                    float* n = base + 4 * ((i * TILE_W + j) * TILE_W + k);
-                    lds_add(n + 0, v0);
-                    lds_add(n + 1, v1);
-                    lds_add(n + 2, v2);
-                    lds_add(n + 3, v3);
-                }
-            }
-        }
-    }
+// coefficients (c0 + c1 f + c2 f^2) of the quadratic B-spline weight of stencil offset a
+MPM_DEV void bspline_coeff(int a, bool on, float& c0, float& c1, float& c2) {
+    c0 = a == 0 ? 1.125f : (a == 1 ? -.25f : .125f);
+    c1 = a == 0 ? -1.5f : (a == 1 ? 2.f : -.5f);
+    c2 = a == 1 ? -1.f : .5f;
+    if (!on) c0 = c1 = c2 = 0.f;
 }
 
 struct Stencil {
@@ -232,90 +192,251 @@ MPM_DEV Stencil make_stencil(const DP& p, float x, float y, float z, int ox, int
 }
 
 __global__ __launch_bounds__(512) void k_p2g(DP p, float dt) {
-    __shared__ float4 tile[TILE_N];
+    __shared__ long long tile[TILE_N * 4];  // (mvx, mvy, mvz, m) per node, fixed point
+    // wave-private staging: 64 particles (+8 slack rows touched by the operand prefetch)
+    __shared__ __attribute__((aligned(16))) float stage_all[8][(64 + 8) * STG];
     __shared__ unsigned s_mask;
+    __shared__ unsigned s_h;
     Ctl* ctl = p.ctl;
     const PSet& S = p.set[ctl->cur];
     const unsigned n_home = ctl->n_home;
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const float gdt = p.M.gravity * dt;
     const float sdt = -dt * p.Dinv;
-    for (unsigned h = blockIdx.x; h < n_home; h += gridDim.x) {
-        for (int n = tid; n < TILE_N; n += 512) tile[n] = make_float4(0.f, 0.f, 0.f, 0.f);
+    float* stage = stage_all[wv];
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
+
+    // ---- lane constants of the contraction ---------------------------------
+    const int j16 = lane & 15, g4 = lane >> 4, tt = lane & 3, dcomp = (lane >> 2) & 3;
+    float ax[2][3], ay[2][3], az[2][3];  // A operand: weight polynomials of node rows j16 and 16 + j16
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const int n = 16 * t + j16;
+        const bool on = n < 27;
+        bspline_coeff(n / 9, on, ax[t][0], ax[t][1], ax[t][2]);
+        bspline_coeff((n / 3) % 3, true, ay[t][0], ay[t][1], ay[t][2]);
+        bspline_coeff(n % 3, true, az[t][0], az[t][1], az[t][2]);
+    }
+    float fac[2][4];     // epilogue: (1, i, j, k)[tt] of node row 16 t + 4 g4 + r
+    int delta[2];        // float offset of this lane's node/component in the tile, -1 if none
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int n = 16 * t + 4 * g4 + r;
+            const int ni = n / 9, nj = (n / 3) % 3, nk = n % 3;
+            fac[t][r] = n >= 27 ? 0.f : (tt == 0 ? 1.f : (float)(tt == 1 ? ni : (tt == 2 ? nj : nk)));
+        }
+        const int n = 16 * t + 4 * g4 + tt;
+        delta[t] = n < 27 ? (((n / 9) * TILE_W + (n / 3) % 3) * TILE_W + n % 3) * 4 + dcomp : -1;
+    }
+    const double fscale = dcomp == 3 ? p.fix_m : p.fix_p;
+    // rows beyond the staged particles are read (and masked) by the last step: keep them finite
+    for (int k = lane; k < 8 * STG; k += 64) stage[64 * STG + k] = 0.f;
+
+    if (blockIdx.x == 0 && tid == 0) ctl->q_g2p = 0;  // re-arm the next tile kernel's queue
+    for (;;) {
+        __syncthreads();
+        if (tid == 0) s_h = atomicAdd(&ctl->q_p2g, 1u);
+        __syncthreads();
+        if (s_h >= n_home) break;
+        const unsigned h = p.home_order[s_h];
+        for (int n = tid; n < TILE_N * 4; n += 512) tile[n] = 0;
         if (tid == 0) s_mask = 0;
         __syncthreads();
         int bx, by, bz;
         block_coords(p.home_block[h], bx, by, bz);
         const int ox = bx * 4 - FREE_ZONE, oy = by * 4 - FREE_ZONE, oz = bz * 4 - FREE_ZONE;
         const int4 rg = p.home_range[h];
+        const int nfb = rg.y - rg.x, total = nfb + (rg.w - rg.z);
         unsigned mymask = 0;
         bool soft = false, hard = false;
-        // face particles: stress term, no force
-        for (int base = rg.x; base < rg.y; base += 512) {
-            const int i = base + tid;
-            const bool act = i < rg.y;
-            const int ii = act ? i : rg.y - 1;
+        // Every wave streams through its own groups of <= 64 particles; no workgroup barrier inside.
+        // Group g takes the g-th slice of the block's faces AND of its vertices: both ranges are
+        // sorted by cell, so a group's faces and vertices cover (nearly) the same few cells.
+        const int nvb = total - nfb;
+        const int ngroups = (total + 61) / 62;
+        for (int g = wv; g < ngroups; g += 8) {
+            // ---- 1. one particle per lane --------------------------------------
+            const int fa = (int)((long long)nfb * g / ngroups), fb = (int)((long long)nfb * (g + 1) / ngroups);
+            const int va = (int)((long long)nvb * g / ngroups), vb = (int)((long long)nvb * (g + 1) / ngroups);
+            const int gf = fb - fa, gn = gf + (vb - va);
+            const bool act = lane < gn;
+            const bool is_face = lane < gf;
+            const int ii = act ? (is_face ? rg.x + fa + lane : rg.z + va + (lane - gf)) : (nfb ? rg.x : rg.z);
             const Stencil st = make_stencil(p, S.x[0][ii], S.x[1][ii], S.x[2][ii], ox, oy, oz);
             const float m = S.vol[ii] * p.M.density;
-            float q[3], B[9];
-            const float a0 = p.ab[0][ii], a1 = p.ab[1][ii], a2 = p.ab[2][ii];
-            const float b0 = p.ab[3][ii], b1 = p.ab[4][ii], b2 = p.ab[5][ii];
-            const float av[3] = {a0, a1, a2}, bv[3] = {b0, b1, b2};
+            float Y[16];
+            {
+                float B[9];
+                float fext[3] = {0.f, 0.f, 0.f};
+                if (is_face) {
+                    const float av[3] = {p.ab[0][ii], p.ab[1][ii], p.ab[2][ii]};
+                    const float bv[3] = {p.ab[3][ii], p.ab[4][ii], p.ab[5][ii]};
 #pragma unroll
-            for (int r = 0; r < 3; ++r)
+                    for (int r = 0; r < 3; ++r)
 #pragma unroll
-                for (int c = 0; c < 3; ++c) B[r * 3 + c] = sdt * (av[r] * bv[c]) + S.C[r * 3 + c][ii] * m;
+                        for (int c = 0; c < 3; ++c) B[r * 3 + c] = sdt * (av[r] * bv[c]) + S.C[r * 3 + c][ii] * m;
+                } else {
 #pragma unroll
-            for (int r = 0; r < 3; ++r) {
-                float qq = S.v[r][ii] * m;
-                if (r == p.M.gravity_axis) qq += m * gdt;
-                qq -= (B[r * 3] * st.fx[0] + B[r * 3 + 1] * st.fx[1] + B[r * 3 + 2] * st.fx[2]) * p.dx;
-                q[r] = qq;
+                    for (int r = 0; r < 9; ++r) B[r] = S.C[r][ii] * m;
+#pragma unroll
+                    for (int r = 0; r < 3; ++r) fext[r] = p.f[r][ii] * dt;
+                }
+#pragma unroll
+                for (int r = 0; r < 3; ++r) {
+                    float qq = S.v[r][ii] * m;
+                    if (r == p.M.gravity_axis) qq += m * gdt;
+                    qq += fext[r];
+                    qq -= (B[r * 3] * st.fx[0] + B[r * 3 + 1] * st.fx[1] + B[r * 3 + 2] * st.fx[2]) * p.dx;
+                    Y[r * 4 + 0] = qq;
+                    Y[r * 4 + 1] = B[r * 3 + 0] * p.dx;
+                    Y[r * 4 + 2] = B[r * 3 + 1] * p.dx;
+                    Y[r * 4 + 3] = B[r * 3 + 2] * p.dx;
+                }
+                Y[12] = m; Y[13] = 0.f; Y[14] = 0.f; Y[15] = 0.f;
             }
-#pragma unroll
-            for (int r = 0; r < 9; ++r) B[r] *= p.dx;
             if (act) {
                 mymask |= st.mask27;
                 soft |= st.soft_out;
                 hard |= st.hard_out;
             }
-            scatter_tile(tile, act, st.rx, st.ry, st.rz, st.wx, st.wy, st.wz, m, q, B);
-        }
-        // vertex particles: force term, no stress
-        for (int base = rg.z; base < rg.w; base += 512) {
-            const int i = base + tid;
-            const bool act = i < rg.w;
-            const int ii = act ? i : rg.w - 1;
-            const Stencil st = make_stencil(p, S.x[0][ii], S.x[1][ii], S.x[2][ii], ox, oy, oz);
-            const float m = S.vol[ii] * p.M.density;
-            float q[3], B[9];
+            if (p.dbg & 2) {
+                float acc = 0.f;
 #pragma unroll
-            for (int r = 0; r < 9; ++r) B[r] = S.C[r][ii] * m;
-#pragma unroll
-            for (int r = 0; r < 3; ++r) {
-                float qq = S.v[r][ii] * m;
-                if (r == p.M.gravity_axis) qq += m * gdt;
-                qq += p.f[r][ii] * dt;
-                qq -= (B[r * 3] * st.fx[0] + B[r * 3 + 1] * st.fx[1] + B[r * 3 + 2] * st.fx[2]) * p.dx;
-                q[r] = qq;
+                for (int k = 0; k < 16; ++k) acc += Y[k];
+                if (acc == 1.2345e30f) tile[0] = (long long)acc;
+                continue;
             }
-#pragma unroll
-            for (int r = 0; r < 9; ++r) B[r] *= p.dx;
+            // ---- 2. group the wave's particles by base cell ---------------------
+            const int key = (st.rx * 8 + st.ry) * 8 + st.rz;
+            const unsigned long long actmask = __ballot(act);
+            int pos = 0;
+            {
+                unsigned long long todo = actmask;
+                int base = 0;
+                while (todo) {
+                    const int lk = __builtin_amdgcn_readlane(key, __builtin_ctzll(todo));
+                    const unsigned long long same = __ballot(key == lk) & todo;
+                    if ((same >> lane) & 1ull) pos = base + (int)__popcll(same & lt_mask);
+                    base += (int)__popcll(same);
+                    todo &= ~same;
+                }
+            }
+            // ---- 3. stage at the grouped position (wave-private LDS, in-order) --
             if (act) {
-                mymask |= st.mask27;
-                soft |= st.soft_out;
-                hard |= st.hard_out;
+                float4* sp = reinterpret_cast<float4*>(stage + pos * STG);
+                sp[0] = make_float4(Y[0], Y[1], Y[2], Y[3]);
+                sp[1] = make_float4(Y[4], Y[5], Y[6], Y[7]);
+                sp[2] = make_float4(Y[8], Y[9], Y[10], Y[11]);
+                sp[3] = make_float4(Y[12], Y[13], Y[14], Y[15]);
+                sp[4] = make_float4(st.fx[0], st.fx[1], st.fx[2], 0.f);
             }
-            scatter_tile(tile, act, st.rx, st.ry, st.rz, st.wx, st.wy, st.wz, m, q, B);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            if (p.dbg & 1) continue;
+            // ---- 4. per-cell contraction on the matrix pipe ----------------------
+            unsigned long long todo = actmask;
+            int s0 = 0;
+            float nfx, nfy, nfz, ny;
+            {
+                const float* sn = stage + g4 * STG;
+                nfx = sn[16]; nfy = sn[17]; nfz = sn[18]; ny = sn[j16];
+            }
+            const bool prof = (p.dbg & 4) != 0;
+            unsigned long long t_begin = 0, n_steps = 0, n_cells = 0;
+            if (prof) t_begin = __builtin_readcyclecounter();
+            while (todo) {
+                const int ckey = __builtin_amdgcn_readlane(key, __builtin_ctzll(todo));
+                const unsigned long long same = __ballot(key == ckey) & todo;
+                todo &= ~same;
+                const int s1 = s0 + (int)__popcll(same);
+                f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+                const bool stamp = (p.dbg & 32) && blockIdx.x == 7 && wv == 3 && g == wv && s0 == 0;
+                unsigned long long c0 = 0, c1 = 0, c2 = 0, c3 = 0;
+                if (stamp) c0 = __builtin_readcyclecounter();
+                if (prof) { n_cells += 1; n_steps += (unsigned)((s1 - s0 + 3) >> 2); }
+                // operands of a step are fetched one step ahead (the first step's during the previous
+                // cell's epilogue), so the LDS latency hides behind the MFMAs
+                for (int s = (p.dbg & 8) ? s1 : s0; s < s1; s += 4) {
+                    const bool ok = s + g4 < s1;
+                    const float fx = nfx, fy = nfy, fz = nfz;
+                    float y = ny;
+                    {
+                        const float* sn = stage + (s + 4 + g4) * STG;
+                        nfx = sn[16]; nfy = sn[17]; nfz = sn[18]; ny = sn[j16];
+                    }
+                    float w0 = fmaf(fmaf(ax[0][2], fx, ax[0][1]), fx, ax[0][0]) *
+                               fmaf(fmaf(ay[0][2], fy, ay[0][1]), fy, ay[0][0]) *
+                               fmaf(fmaf(az[0][2], fz, az[0][1]), fz, az[0][0]);
+                    float w1 = fmaf(fmaf(ax[1][2], fx, ax[1][1]), fx, ax[1][0]) *
+                               fmaf(fmaf(ay[1][2], fy, ay[1][1]), fy, ay[1][0]) *
+                               fmaf(fmaf(az[1][2], fz, az[1][1]), fz, az[1][0]);
+                    if (p.dbg & 128) { w0 = fx; w1 = fy; }
+                    if (!ok) { y = 0.f; w0 = 0.f; w1 = 0.f; }
+                    if (p.dbg & 64) {
+                        acc0[0] = fmaf(w0, y, acc0[0]);
+                        acc1[0] = fmaf(w1, y, acc1[0]);
+                    } else {
+                        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(w0, y, acc0, 0, 0, 0);
+                        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(w1, y, acc1, 0, 0, 0);
+                    }
+                }
+                // the loop leaves row block (last step + 4) preloaded; the next cell starts at s1
+                if (((s1 - s0) & 3) != 0 || (p.dbg & 8)) {
+                    const float* sn = stage + (s1 + g4) * STG;
+                    nfx = sn[16]; nfy = sn[17]; nfz = sn[18]; ny = sn[j16];
+                }
+                if (stamp) { asm volatile("" :: "v"(acc0), "v"(acc1)); c1 = __builtin_readcyclecounter(); p.dbgbuf[8] = (unsigned)(s1 - s0); }
+                s0 = s1;
+                // rows = nodes, columns = (component d, term tt): fold the 4 terms of each component
+                const int crx = ckey >> 6, cry = (ckey >> 3) & 7, crz = ckey & 7;
+                long long* tb = tile + ((crx * TILE_W + cry) * TILE_W + crz) * 4;
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    const f32x4 a = t ? acc1 : acc0;
+                    float v[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        float x = a[r] * fac[t][r];
+                        x += quad_perm<0xB1>(x);
+                        x += quad_perm<0x4E>(x);
+                        v[r] = x;
+                    }
+                    float val = v[0];
+                    val = tt == 1 ? v[1] : val;
+                    val = tt == 2 ? v[2] : val;
+                    val = tt == 3 ? v[3] : val;
+                    if (stamp && t == 1) { asm volatile("" :: "v"(val)); c2 = __builtin_readcyclecounter(); }
+                    if (delta[t] >= 0 && !(p.dbg & 16)) lds_add_fixed(tb + delta[t], val, fscale);
+                }
+                if (stamp) {
+                    c3 = __builtin_readcyclecounter();
+                    if (lane == 0) { p.dbgbuf[9] = c1 - c0; p.dbgbuf[10] = c2 - c1; p.dbgbuf[11] = c3 - c2; }
+                }
+            }
+            if (prof && lane == 0) {
+                atomicAdd(&p.dbgbuf[0], n_cells);
+                atomicAdd(&p.dbgbuf[1], n_steps);
+                atomicAdd(&p.dbgbuf[2], (unsigned long long)__builtin_readcyclecounter() - t_begin);
+                atomicAdd(&p.dbgbuf[3], 1ull);
+            }
+            // the next group's staging writes must not overtake this group's reads
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
         }
         if (mymask) atomicOr(&s_mask, mymask);
-        if (__ballot(soft) && (tid & 63) == 0) atomicOr(&ctl->need_rebuild, 1);
-        if (__ballot(hard) && (tid & 63) == 0) atomicOr(&ctl->error, ERR_DRIFT);
+        if (__ballot(soft) && lane == 0) atomicOr(&ctl->need_rebuild, 1);
+        if (__ballot(hard) && lane == 0) atomicOr(&ctl->error, ERR_DRIFT);
         __syncthreads();
         float4* out = p.slab + (size_t)h * TILE_N;
-        for (int n = tid; n < TILE_N; n += 512) out[n] = tile[n];
+        for (int n = tid; n < TILE_N; n += 512) {
+            const long long* q = tile + n * 4;
+            out[n] = make_float4((float)((double)q[0] * p.unfix_p), (float)((double)q[1] * p.unfix_p),
+                                 (float)((double)q[2] * p.unfix_p), (float)((double)q[3] * p.unfix_m));
+        }
         if (tid == 0) p.slab_mask[h] = s_mask;
-        __syncthreads();
     }
 }
 
@@ -470,9 +591,16 @@ __global__ __launch_bounds__(512) void k_g2p(DP p, float dt) {
     __shared__ float4 tile[TILE_N];
     const Ctl* ctl = p.ctl;
     const PSet& S = p.set[ctl->cur];
+    Ctl* ctlw = p.ctl;
     const unsigned n_home = ctl->n_home;
-    for (unsigned h = blockIdx.x; h < n_home; h += gridDim.x) {
+    __shared__ unsigned s_h;
+    if (blockIdx.x == 0 && threadIdx.x == 0) ctlw->q_p2g = 0;  // re-arm the P2G queue of the next substep
+    for (;;) {
         __syncthreads();
+        if (threadIdx.x == 0) s_h = atomicAdd(&ctlw->q_g2p, 1u);
+        __syncthreads();
+        if (s_h >= n_home) break;
+        const unsigned h = p.home_order[s_h];
         load_tile(p, h, tile, p.gv, 512);
         __syncthreads();
         int bx, by, bz;

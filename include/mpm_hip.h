@@ -224,6 +224,10 @@ MPM_API int mpm_set_stream(mpm_handle_t h, void *hip_stream);
 
 MPM_API int mpm_get_stats(mpm_handle_t h, mpm_stats_t *out);
 
+/* Diagnostic build support: 16 device counters that kernels fill only when the
+ * MPM_DBG environment variable has bit 2 set (see DESIGN.md "Diagnostics"). */
+MPM_API int mpm_debug_counters(mpm_handle_t h, uint64_t *out16, int reset);
+
 /* Copies one engine array to the host (see mpm_array_id).  `bytes` is the
  * size of `out`; the call fails if it is too small. *written gets the number
  * of bytes produced (may be NULL). */
