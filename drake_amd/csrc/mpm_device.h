@@ -81,7 +81,7 @@ struct DP {
     int* blkstart[2];
     int* lut_home;         // block id -> home slot or -1
     int* lut_act;          // block id -> active slot or -1
-    int* act_flag;
+    unsigned* home_bits;   // bitmap of non-empty blocks, filled by k_rb_count, cleared by k_rb_tables
     // tables
     uint32_t* home_block;  // home slot -> block id
     int4* home_range;      // (face begin, face end, vertex begin, vertex end) slots

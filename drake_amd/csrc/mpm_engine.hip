@@ -41,7 +41,7 @@ int mpm_default_material(mpm_material_t* m) {
 
 int mpm_create(int domain_bits, const mpm_material_t* material, int device, mpm_handle_t* out) {
     REQUIRE(out, "null handle pointer");
-    REQUIRE(domain_bits >= 4 && domain_bits <= 10, "domain_bits must be in [4,10]");
+    REQUIRE(domain_bits >= 4 && domain_bits <= 8, "domain_bits must be in [4,8] (16^3 .. 256^3 cells)");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
         return fail(MPM_ERR_NO_DEVICE, "no HIP device visible: the engine has no CPU fallback");
@@ -85,9 +85,9 @@ int mpm_add_qr_cloth(mpm_handle_t e, const float* pos, const float* vel, size_t 
 static void launch_rebuild(mpm_engine* e) {
     const DP& p = e->dp;
     hipLaunchKernelGGL(k_rb_count, dim3(e->g_np), dim3(256), 0, e->stream, p);
-    hipLaunchKernelGGL(k_rb_tables, dim3(1), dim3(1024), 0, e->stream, p);
+    hipLaunchKernelGGL(k_rb_tables, dim3(33), dim3(1024), 0, e->stream, p);
     hipLaunchKernelGGL(k_rb_scatter, dim3(e->g_np), dim3(256), 0, e->stream, p);
-    hipLaunchKernelGGL(k_rb_finish, dim3(e->g_np), dim3(256), 0, e->stream, p);
+    hipLaunchKernelGGL(k_rb_finish, dim3(std::min(e->g_np, 512u)), dim3(256), 0, e->stream, p);
 }
 static void launch_fem(mpm_engine* e, float dt) {
     const DP& p = e->dp;
@@ -182,9 +182,11 @@ int mpm_finalize(mpm_handle_t e) {
         ALLOC(p.blkcnt[t], p.nblocks, true);
         ALLOC(p.blkstart[t], p.nblocks, true);
     }
-    ALLOC(p.lut_home, p.nblocks, true);
-    ALLOC(p.lut_act, p.nblocks, true);
-    ALLOC(p.act_flag, p.nblocks, true);
+    ALLOC(p.lut_home, p.nblocks, false);
+    ALLOC(p.lut_act, p.nblocks, false);
+    HIP_TRY(hipMemsetAsync(p.lut_home, 0xFF, (size_t)p.nblocks * 4, e->stream));  // -1 = not a home block
+    HIP_TRY(hipMemsetAsync(p.lut_act, 0xFF, (size_t)p.nblocks * 4, e->stream));
+    ALLOC(p.home_bits, p.nblocks / 32 + 1, true);
     ALLOC(p.home_block, p.capH, true);
     ALLOC(p.home_range, p.capH, true);
     ALLOC(p.home_nbr_act, (size_t)p.capH * 27, true);

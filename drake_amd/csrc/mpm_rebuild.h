@@ -54,7 +54,12 @@ __global__ __launch_bounds__(256) void k_rb_count(DP p) {
             const int lead = __builtin_ctzll(todo);
             const uint32_t lb = (uint32_t)__shfl((int)(key >> 6), lead);
             const unsigned long long same = __ballot((key >> 6) == lb) & todo;
-            if (lane == lead) atomicAdd(&p.blkcnt[ty][lb], (int)__popcll(same));
+            if (lane == lead) {
+                // same-address device atomics serialise at ~30 ns each: only the first arrival
+                // of a (type, block) pair touches the non-empty bitmap
+                if (atomicAdd(&p.blkcnt[ty][lb], (int)__popcll(same)) == 0)
+                    atomicOr(&p.home_bits[lb >> 5], 1u << (lb & 31u));
+            }
             todo &= ~same;
         }
     }
@@ -64,139 +69,165 @@ __global__ __launch_bounds__(256) void k_rb_count(DP p) {
     }
 }
 
-struct I3 {
-    int a, b, c;
-};
-MPM_DEV I3 operator+(I3 l, I3 r) { return {l.a + r.a, l.b + r.b, l.c + r.c}; }
-
-// exclusive scan of one I3 per thread across a 1024-thread workgroup
-MPM_DEV I3 wg_scan_exclusive(I3 v, I3& total, I3 (*s_w)[1]) {
+// exclusive scan of one int per thread across a 1024-thread workgroup
+MPM_DEV int wg_scan_exclusive(int v, int& total, int* s_w) {
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    I3 inc = v;
+    int inc = v;
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) {
-        I3 t = {__shfl_up(inc.a, d), __shfl_up(inc.b, d), __shfl_up(inc.c, d)};
-        if (lane >= d) inc = inc + t;
+        const int t = __shfl_up(inc, d);
+        if (lane >= d) inc += t;
     }
     __syncthreads();
-    if (lane == 63) s_w[w][0] = inc;
+    if (lane == 63) s_w[w] = inc;
     __syncthreads();
-    I3 pre = {0, 0, 0}, tot = {0, 0, 0};
+    int pre = 0, tot = 0;
+#pragma unroll
     for (int k = 0; k < 16; ++k) {
-        const I3 t = s_w[k][0];
-        if (k < w) pre = pre + t;
-        tot = tot + t;
+        const int t = s_w[k];
+        pre += k < w ? t : 0;
+        tot += t;
     }
     total = tot;
-    return {pre.a + inc.a - v.a, pre.b + inc.b - v.b, pre.c + inc.c - v.c};
+    return pre + inc - v;
 }
 
+constexpr int MAX_BITMAP_WORDS = 8192;  // 2^18 blocks = 256^3 cells
+
 // R2: one workgroup turns the histograms into
-//   - the home-block list with its particle ranges and the scatter offsets,
+//   - the home-block list (ascending block id) with its particle ranges and scatter offsets,
 //   - the active-block list (27-neighbourhood of the home blocks),
-//   - both neighbour tables.
+//   - both neighbour tables and the heaviest-first work-queue order.
+// All work is proportional to the number of home blocks: non-empty blocks come from the bitmap
+// k_rb_count filled, the neighbourhood union is built in an LDS bitmap.
 __global__ __launch_bounds__(1024) void k_rb_tables(DP p) {
     Ctl* c = p.ctl;
     if (!c->need_rebuild) return;
-    __shared__ I3 s_w[16][1];
-    __shared__ I3 s_carry;
+    if (blockIdx.x > 0) {
+        // B (all other workgroups, concurrently with workgroup 0): per non-empty block and type,
+        // exclusive prefix of its 64 cell counters, in place.  16 lanes per row (one int4 each).
+        const unsigned nwords = p.nblocks >> 5;
+        const int sub = threadIdx.x & 15, rowl = threadIdx.x >> 4;  // 64 row slots per workgroup
+        for (unsigned w = blockIdx.x - 1; w < nwords; w += gridDim.x - 1) {
+            const unsigned bits = p.home_bits[w];
+            if (!bits) continue;
+            // row slot -> (k-th set bit of the word, type)
+            const int nrows = 2 * __popc(bits);
+            if (rowl >= nrows) continue;
+            unsigned rest = bits;
+            for (int k = 0; k < (rowl >> 1); ++k) rest &= rest - 1;
+            const unsigned b = (w << 5) + (unsigned)__builtin_ctz(rest);
+            int4* cc = reinterpret_cast<int4*>(p.cellcnt[rowl & 1] + (size_t)b * 64) + sub;
+            const int4 q = *cc;
+            const int tot = q.x + q.y + q.z + q.w;
+            int inc = tot;
+#pragma unroll
+            for (int d = 1; d < 16; d <<= 1) {
+                const int t = __shfl_up(inc, d, 16);
+                if (sub >= d) inc += t;
+            }
+            const int s0 = inc - tot;
+            *cc = make_int4(s0, s0 + q.x, s0 + q.x + q.y, s0 + q.x + q.y + q.z);
+        }
+        return;
+    }
+    __shared__ int s_w[16];
+    __shared__ unsigned s_bits[MAX_BITMAP_WORDS];
+    __shared__ int s_bucket[64];
     const int tid = threadIdx.x;
-    if (tid == 0) s_carry = {0, 0, 0};
+    const unsigned words = p.nblocks >> 5;
+    const unsigned wpt = (words + 1023u) / 1024u;          // bitmap words per thread
+    const unsigned w0 = min(tid * wpt, words), w1 = min(w0 + wpt, words);
+
+    // forget the previous tables
+    for (unsigned k = tid; k < c->n_home; k += 1024) p.lut_home[p.home_block[k]] = -1;
+    for (unsigned k = tid; k < c->n_active; k += 1024) p.lut_act[p.act_block[k]] = -1;
     __syncthreads();
 
-    // A: prefix sums over all blocks
-    for (unsigned base = 0; base < p.nblocks; base += 1024) {
-        const unsigned b = base + tid;
-        I3 v = {0, 0, 0};
-        if (b < p.nblocks) {
-            v.b = p.blkcnt[0][b];
-            v.c = p.blkcnt[1][b];
-            v.a = (v.b + v.c) > 0;
-        }
-        I3 tot;
-        const I3 ex = wg_scan_exclusive(v, tot, s_w);
-        const I3 carry = s_carry;
-        if (b < p.nblocks) {
-            const int f0 = carry.b + ex.b, v0 = carry.c + ex.c;
-            p.blkstart[0][b] = f0;
-            p.blkstart[1][b] = v0;
-            p.act_flag[b] = 0;
-            int slot = -1;
-            if (v.a) {
-                slot = carry.a + ex.a;
-                if ((unsigned)slot < p.capH) {
-                    p.home_block[slot] = b;
-                    p.home_range[slot] = make_int4(f0, f0 + v.b, p.Nf + v0, p.Nf + v0 + v.c);
-                } else {
-                    slot = -1;
-                }
+    // A: home list = set bits of the non-empty bitmap, in ascending order
+    int mine = 0;
+    for (unsigned w = w0; w < w1; ++w) mine += __popc(p.home_bits[w]);
+    int total_home = 0;
+    int slot = wg_scan_exclusive(mine, total_home, s_w);
+    for (unsigned w = w0; w < w1; ++w) {
+        unsigned bits = p.home_bits[w];
+        while (bits) {
+            const unsigned b = (w << 5) + (unsigned)__builtin_ctz(bits);
+            bits &= bits - 1;
+            if ((unsigned)slot < p.capH) {
+                p.home_block[slot] = b;
+                p.lut_home[b] = slot;
             }
-            p.lut_home[b] = slot;
+            ++slot;
         }
-        __syncthreads();
-        if (tid == 0) s_carry = carry + tot;
-        __syncthreads();
     }
-    unsigned n_home = (unsigned)s_carry.a;
+    unsigned n_home = (unsigned)total_home;
     if (n_home > p.capH) {
         if (tid == 0) atomicOr(&c->error, ERR_CAPACITY);
         n_home = p.capH;
     }
+    for (unsigned w = tid; w < words; w += 1024) s_bits[w] = 0;
+    __syncthreads();
 
-    // B: per home block, exclusive prefix of its 64 cell counters (in place)
-    for (unsigned w = tid; w < n_home * 2; w += 1024) {
-        const unsigned h = w >> 1, t = w & 1;
-        int4* cc = reinterpret_cast<int4*>(p.cellcnt[t] + (size_t)p.home_block[h] * 64);
-        int run = 0;
-#pragma unroll 4
-        for (int k = 0; k < 16; ++k) {
-            int4 q = cc[k];
-            const int s0 = run, s1 = s0 + q.x, s2 = s1 + q.y, s3 = s2 + q.z;
-            run = s3 + q.w;
-            cc[k] = make_int4(s0, s1, s2, s3);
+    // A2: particle ranges = prefix sums of the block counts over the home list
+    const unsigned hpt = (n_home + 1023u) / 1024u;
+    const unsigned h0 = min(tid * hpt, n_home), h1 = min(h0 + hpt, n_home);
+    {
+        int cf = 0, cv = 0;
+        for (unsigned h = h0; h < h1; ++h) {
+            const uint32_t b = p.home_block[h];
+            cf += p.blkcnt[0][b];
+            cv += p.blkcnt[1][b];
+        }
+        int tf = 0, tv = 0;
+        int rf = wg_scan_exclusive(cf, tf, s_w);
+        int rv = wg_scan_exclusive(cv, tv, s_w);
+        for (unsigned h = h0; h < h1; ++h) {
+            const uint32_t b = p.home_block[h];
+            const int nf = p.blkcnt[0][b], nv = p.blkcnt[1][b];
+            p.blkstart[0][b] = rf;
+            p.blkstart[1][b] = rv;
+            p.home_range[h] = make_int4(rf, rf + nf, p.Nf + rv, p.Nf + rv + nv);
+            rf += nf;
+            rv += nv;
         }
     }
-    // C: flag the 27-neighbourhood of every home block
+
+    // C: union of the 27-neighbourhoods in an LDS bitmap
     for (unsigned w = tid; w < n_home * 27; w += 1024) {
         const int nbid = neighbor_block(p.home_block[w / 27], (int)(w % 27), p.nb);
-        if (nbid >= 0) p.act_flag[nbid] = 1;
+        if (nbid >= 0) atomicOr(&s_bits[nbid >> 5], 1u << (nbid & 31));
     }
-    __syncthreads();
-    if (tid == 0) s_carry = {0, 0, 0};
     __syncthreads();
 
-    // D: compact the flags (ascending block id)
-    for (unsigned base = 0; base < p.nblocks; base += 1024) {
-        const unsigned b = base + tid;
-        I3 v = {0, 0, 0};
-        if (b < p.nblocks) v.a = p.act_flag[b];
-        I3 tot;
-        const I3 ex = wg_scan_exclusive(v, tot, s_w);
-        const I3 carry = s_carry;
-        if (b < p.nblocks) {
-            int slot = -1;
-            if (v.a) {
-                slot = carry.a + ex.a;
-                if ((unsigned)slot < p.capA) p.act_block[slot] = b; else slot = -1;
+    // D: active list = set bits, ascending
+    mine = 0;
+    for (unsigned w = w0; w < w1; ++w) mine += __popc(s_bits[w]);
+    int total_act = 0;
+    slot = wg_scan_exclusive(mine, total_act, s_w);
+    for (unsigned w = w0; w < w1; ++w) {
+        unsigned bits = s_bits[w];
+        while (bits) {
+            const unsigned b = (w << 5) + (unsigned)__builtin_ctz(bits);
+            bits &= bits - 1;
+            if ((unsigned)slot < p.capA) {
+                p.act_block[slot] = b;
+                p.lut_act[b] = slot;
             }
-            p.lut_act[b] = slot;
+            ++slot;
         }
-        __syncthreads();
-        if (tid == 0) s_carry = carry + tot;
-        __syncthreads();
     }
-    unsigned n_active = (unsigned)s_carry.a;
+    unsigned n_active = (unsigned)total_act;
     if (n_active > p.capA) {
         if (tid == 0) atomicOr(&c->error, ERR_CAPACITY);
         n_active = p.capA;
     }
+    if (tid < 64) s_bucket[tid] = 0;
+    __syncthreads();
 
-    // F: work-queue order, heaviest blocks first (longest-processing-time-first
-    // keeps the last workgroups short).  Counting sort on the chunk count.
+    // F: work-queue order, heaviest blocks first (longest-processing-time-first keeps the last
+    // workgroups short).  Counting sort on the particle count in units of 256.
     {
-        __shared__ int s_bucket[64];
-        if (tid < 64) s_bucket[tid] = 0;
-        __syncthreads();
         auto bucket_of = [&](unsigned h) {
             const int4 rg = p.home_range[h];
             const int chunks = ((rg.y - rg.x) + (rg.w - rg.z) + 255) >> 8;
@@ -207,25 +238,15 @@ __global__ __launch_bounds__(1024) void k_rb_tables(DP p) {
         if (tid == 0) {
             int run = 0;
             for (int k = 0; k < 64; ++k) {
-                const int c = s_bucket[k];
+                const int cnt = s_bucket[k];
                 s_bucket[k] = run;
-                run += c;
+                run += cnt;
             }
         }
         __syncthreads();
         for (unsigned h = tid; h < n_home; h += 1024) p.home_order[atomicAdd(&s_bucket[bucket_of(h)], 1)] = h;
-        __syncthreads();
     }
 
-    // E: neighbour tables
-    for (unsigned w = tid; w < n_home * 27; w += 1024) {
-        const int nbid = neighbor_block(p.home_block[w / 27], (int)(w % 27), p.nb);
-        p.home_nbr_act[w] = nbid >= 0 ? p.lut_act[nbid] : -1;
-    }
-    for (unsigned w = tid; w < n_active * 27; w += 1024) {
-        const int nbid = neighbor_block(p.act_block[w / 27], (int)(w % 27), p.nb);
-        p.act_nbr_home[w] = nbid >= 0 ? p.lut_home[nbid] : -1;
-    }
     if (tid == 0) {
         c->n_home = n_home;
         c->n_active = n_active;
@@ -236,6 +257,19 @@ __global__ __launch_bounds__(1024) void k_rb_tables(DP p) {
 __global__ __launch_bounds__(256) void k_rb_scatter(DP p) {
     if (!p.ctl->need_rebuild) return;
     const int i = blockIdx.x * 256 + threadIdx.x;
+    {
+        // neighbour tables (spread over the whole grid: one workgroup would be latency bound)
+        const unsigned n_home = p.ctl->n_home, n_active = p.ctl->n_active;
+        const unsigned gs = gridDim.x * 256u;
+        for (unsigned w = (unsigned)i; w < n_home * 27; w += gs) {
+            const int nbid = neighbor_block(p.home_block[w / 27], (int)(w % 27), p.nb);
+            p.home_nbr_act[w] = nbid >= 0 ? p.lut_act[nbid] : -1;
+        }
+        for (unsigned w = (unsigned)i; w < n_active * 27; w += gs) {
+            const int nbid = neighbor_block(p.act_block[w / 27], (int)(w % 27), p.nb);
+            p.act_nbr_home[w] = nbid >= 0 ? p.lut_home[nbid] : -1;
+        }
+    }
     if (i >= p.Np) return;
     const int cur = p.ctl->cur;
     const PSet& S = p.set[cur];
@@ -243,54 +277,72 @@ __global__ __launch_bounds__(256) void k_rb_scatter(DP p) {
     const uint32_t key = p.pkey[i];
     const int t = i >= p.Nf;
     const int dst = (t ? p.Nf : 0) + p.blkstart[t][key >> 6] + p.cellcnt[t][key] + (int)p.prank[i];
+    // all loads first, then all stores: the copies are independent, and issuing them as
+    // load/store pairs would serialise 42 memory round trips per thread
+    float a[16];
+    float fm[13];
 #pragma unroll
     for (int d = 0; d < 3; ++d) {
-        D.x[d][dst] = S.x[d][i];
-        D.v[d][dst] = S.v[d][i];
+        a[d] = S.x[d][i];
+        a[3 + d] = S.v[d][i];
     }
-    D.vol[dst] = S.vol[i];
+    a[6] = S.vol[i];
 #pragma unroll
-    for (int d = 0; d < 9; ++d) D.C[d][dst] = S.C[d][i];
+    for (int d = 0; d < 9; ++d) a[7 + d] = S.C[d][i];
     const int pid = S.pid[i];
+    if (!t) {
+#pragma unroll
+        for (int d = 0; d < 9; ++d) fm[d] = S.F[d][i];
+#pragma unroll
+        for (int d = 0; d < 4; ++d) fm[9 + d] = S.Dm[d][i];
+    }
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+        D.x[d][dst] = a[d];
+        D.v[d][dst] = a[3 + d];
+    }
+    D.vol[dst] = a[6];
+#pragma unroll
+    for (int d = 0; d < 9; ++d) D.C[d][dst] = a[7 + d];
     D.pid[dst] = pid;
     p.imap[pid] = dst;
     if (!t) {
 #pragma unroll
-        for (int d = 0; d < 9; ++d) D.F[d][dst] = S.F[d][i];
+        for (int d = 0; d < 9; ++d) D.F[d][dst] = fm[d];
 #pragma unroll
-        for (int d = 0; d < 4; ++d) D.Dm[d][dst] = S.Dm[d][i];
+        for (int d = 0; d < 4; ++d) D.Dm[d][dst] = fm[9 + d];
     }
 }
 
-// R4: refresh face -> vertex slots, re-zero the histograms, flip the sets.
+// R4: refresh face -> vertex slots, re-zero the histograms, flip the sets.  Launched with a
+// fixed, small number of workgroups (grid-stride) so that the closing ticket costs few atomics.
 __global__ __launch_bounds__(256) void k_rb_finish(DP p) {
     Ctl* c = p.ctl;
     if (!c->need_rebuild) return;
-    const int i = blockIdx.x * 256 + threadIdx.x;
+    const unsigned gs = gridDim.x * 256u, i0 = blockIdx.x * 256u + threadIdx.x;
     const PSet& D = p.set[c->cur ^ 1];
-    if (i < p.Nf) {
+    for (unsigned i = i0; i < (unsigned)p.Nf; i += gs) {
         const int pid = D.pid[i];
 #pragma unroll
         for (int k = 0; k < 3; ++k) p.fv[k][i] = p.imap[p.idx_orig[k][pid]];
     }
     // every cell row of a home block holds prefix values now: clear whole rows
     const unsigned n_home = c->n_home;
-    for (unsigned w = (unsigned)i; w < n_home * 32u; w += gridDim.x * 256u) {
+    for (unsigned w = i0; w < n_home * 32u; w += gs) {
         const unsigned h = w >> 5, t = (w >> 4) & 1u, k = w & 15u;
         const uint32_t b = p.home_block[h];
         reinterpret_cast<int4*>(p.cellcnt[t] + (size_t)b * 64)[k] = make_int4(0, 0, 0, 0);
         if (k == 0) p.blkcnt[t][b] = 0;
+        if (k == 1 && t == 0) p.home_bits[b >> 5] = 0;
     }
+    // The last workgroup to get here flips the particle sets.  Every thread has read `cur` and
+    // `need_rebuild` by now; the end of the kernel makes the flip visible to the next one.
     __syncthreads();
-    if (threadIdx.x == 0) {
-        __threadfence();
-        if (atomicAdd(&c->ticket, 1u) == gridDim.x - 1) {
-            c->ticket = 0;
-            c->cur ^= 1;
-            c->need_rebuild = 0;
-            c->rebuilds += 1;
-            __threadfence();
-        }
+    if (threadIdx.x == 0 && atomicAdd(&c->ticket, 1u) == gridDim.x - 1) {
+        c->ticket = 0;
+        c->cur ^= 1;
+        c->need_rebuild = 0;
+        c->rebuilds += 1;
     }
 }
 
