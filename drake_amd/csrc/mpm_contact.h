@@ -1,16 +1,231 @@
-// Host orchestration of the contact solve.
+// Host orchestration of the contact solve (CopyContactPairs / UpdateContact,
+// cuda_mpm_solver.cu:193-621).
 #pragma once
+#include <cmath>
+#include <fstream>
+#include <tuple>
+#include <vector>
+
 #include "mpm_host.h"
 
-static int copy_contacts(mpm_engine* e, size_t n, const uint32_t* particle, const uint32_t* body, const float* dist,
-                         const float* normal, const float* pos, const float* rigid_v, const float* p_WB) {
-    (void)particle; (void)body; (void)dist; (void)normal; (void)pos; (void)rigid_v; (void)p_WB;
-    e->cb.n = 0;
-    if (n == 0) return 0;
-    return fail(MPM_ERR_INVALID, "contact solve not built yet");
+template <class T>
+static int grow(T** ptr, size_t n) {
+    if (*ptr) HIP_TRY(hipFree(*ptr));
+    *ptr = nullptr;
+    HIP_TRY(hipMalloc((void**)ptr, std::max<size_t>(n, 1) * sizeof(T)));
+    return 0;
 }
 
-static int update_contact(mpm_engine* e, int, int, float, float, float, float, int, int, int, int*, float*) {
-    (void)e;
-    return fail(MPM_ERR_INVALID, "contact solve not built yet");
+// GpuMpmState::ReallocateContacts (cuda_mpm_model.cu:267-317) + the uploads of CopyContactPairs
+static int copy_contacts(mpm_engine* e, size_t n, const uint32_t* particle, const uint32_t* body, const float* dist,
+                         const float* normal, const float* pos, const float* rigid_v, const float* p_WB) {
+    ContactBuffers& b = e->cb;
+    b.n = n;
+    if (n == 0) return 0;
+    for (size_t k = 0; k < n; ++k) REQUIRE(particle[k] < e->np, "contact particle index out of range");
+    if (n > b.cap) {
+        const size_t cap = n + n / 4;
+        int rc;
+        if ((rc = grow(&b.slot, cap)) || (rc = grow(&b.body, cap)) || (rc = grow(&b.dist, cap)) ||
+            (rc = grow(&b.normal, 3 * cap)) || (rc = grow(&b.pos, 3 * cap)) || (rc = grow(&b.rigid_v, 3 * cap)) ||
+            (rc = grow(&b.p_WB, 3 * cap)) || (rc = grow(&b.vel, 3 * cap)) || (rc = grow(&b.vel0, 3 * cap)) ||
+            (rc = grow(&b.cnode, 27 * cap)) || (rc = grow(&b.cfx, 3 * cap)) || (rc = grow(&b.cmass, cap)) ||
+            (rc = grow(&b.cHG, 12 * cap)) || (rc = grow(&b.entries, 27 * cap)))
+            return rc;
+        b.cap = cap;
+    }
+    const size_t cells = (size_t)e->dp.capA * 64;
+    if (!b.node_start || b.cap_cells < cells) {
+        int rc;
+        if ((rc = grow(&b.node_start, cells + 1)) || (rc = grow(&b.node_fill, cells + 1)) || (rc = grow(&b.gD, cells)) ||
+            (rc = grow(&b.part, (size_t)3 * CT_MAX_WG * CT_PART)) || (rc = grow(&b.st, 1)))
+            return rc;
+        b.cap_cells = cells;
+    }
+    // the slot staging buffer doubles as the upload target for the API slot indices
+    if (int rc = e->stage(n * 4)) return rc;
+    HIP_TRY(hipMemcpyAsync(e->d_stage, particle, n * 4, hipMemcpyHostToDevice, e->stream));
+    HIP_TRY(hipMemcpyAsync(b.body, body, n * 4, hipMemcpyHostToDevice, e->stream));
+    HIP_TRY(hipMemcpyAsync(b.dist, dist, n * 4, hipMemcpyHostToDevice, e->stream));
+    HIP_TRY(hipMemcpyAsync(b.normal, normal, n * 12, hipMemcpyHostToDevice, e->stream));
+    HIP_TRY(hipMemcpyAsync(b.pos, pos, n * 12, hipMemcpyHostToDevice, e->stream));
+    HIP_TRY(hipMemcpyAsync(b.rigid_v, rigid_v, n * 12, hipMemcpyHostToDevice, e->stream));
+    HIP_TRY(hipMemcpyAsync(b.p_WB, p_WB, n * 12, hipMemcpyHostToDevice, e->stream));
+    const unsigned g = (unsigned)((n + 255) / 256);
+    hipLaunchKernelGGL(k_ct_slots, dim3(g), dim3(256), 0, e->stream, (int)n, (const uint32_t*)e->d_stage,
+                       e->d_pids_api, e->dp.imap, b.slot);
+    ContactDev c{};
+    c.n = (int)n;
+    c.slot = b.slot;
+    c.vel = b.vel;
+    hipLaunchKernelGGL(k_ct_init_vel, dim3(g), dim3(256), 0, e->stream, e->dp, c);
+    HIP_TRY(hipStreamSynchronize(e->stream));  // the host arrays may be released by the caller
+    return 0;
+}
+
+static ContactDev make_contact_dev(mpm_engine* e, float dt, float mu, float k, float d, int max_iters) {
+    ContactBuffers& b = e->cb;
+    ContactDev c{};
+    c.n = (int)b.n;
+    c.max_iters = max_iters;
+    c.dt = dt; c.mu = mu; c.k = k; c.d = d;
+    c.epsv = e->mat.epsv;
+    c.relax = 0.3f;   // jacobi_relax_coeff, cuda_mpm_solver.cu:239
+    c.tol = 1e-4f;    // kTol, cuda_mpm_solver.cu:236
+    c.slot = b.slot; c.body = b.body; c.dist = b.dist; c.normal = b.normal; c.pos = b.pos;
+    c.rigid_v = b.rigid_v; c.p_WB = b.p_WB; c.vel = b.vel; c.vel0 = b.vel0;
+    c.cnode = b.cnode; c.cfx = b.cfx; c.cmass = b.cmass; c.cHG = b.cHG;
+    c.node_start = b.node_start; c.node_fill = b.node_fill; c.entries = b.entries; c.gD = b.gD;
+    c.part = b.part; c.part_wg = CT_MAX_WG; c.st = b.st;
+    c.body_tau = b.body_tau; c.body_f = b.body_f;
+    return c;
+}
+
+static int update_contact(mpm_engine* e, int frame, int substep, float dt, float mu, float stiffness, float damping,
+                          int dump, int exact, int max_iters, int* iters_out, float* residual_out) {
+    ContactBuffers& b = e->cb;
+    const size_t n = b.n;
+    if (max_iters <= 0) max_iters = 2000;  // cuda_mpm_solver.cu:234
+    if (b.n_bodies == 0) {
+        // the reference requires ReallocateExternelBodies first; size the accumulators to the ids in use
+        return fail(MPM_ERR_INVALID, "call mpm_reallocate_external_bodies before mpm_update_contact");
+    }
+    ContactDev c = make_contact_dev(e, dt, mu, stiffness, damping, max_iters);
+    const DP& p = e->dp;
+    hipStream_t s = e->stream;
+    const unsigned gc = (unsigned)((n + 255) / 256);
+    const unsigned gcs = std::min(gc, (unsigned)CT_MAX_WG);   // grid-stride contact kernels
+    const unsigned gg = 512;                                   // grid-stride cell kernels
+    // ---- set-up: stencils and the node -> contacts adjacency ----------------------
+    HIP_TRY(hipMemsetAsync(b.node_fill, 0, ((size_t)p.capA * 64 + 1) * 4, s));
+    HIP_TRY(hipMemsetAsync(b.st, 0, sizeof(ContactState), s));
+    hipLaunchKernelGGL(k_ct_stencil, dim3(gc), dim3(256), 0, s, p, c);
+    hipLaunchKernelGGL(k_ct_scan, dim3(1), dim3(1024), 0, s, p, c);
+    hipLaunchKernelGGL(k_ct_fill, dim3(gc), dim3(256), 0, s, p, c);
+    hipLaunchKernelGGL(k_ct_sort_lists, dim3(gg), dim3(256), 0, s, p, c);
+    // pre-contact velocity at the contact points (cuda_mpm_solver.cu:267-272)
+    hipLaunchKernelGGL(k_ct_gather_vel, dim3(gc), dim3(256), 0, s, p, c, b.vel0, 0);
+
+    std::vector<float> s_res, s_energy;
+    std::vector<int> s_ls;
+    ContactState st{};
+    int iters = 0;
+    float residual = 1e10f;
+    if (!exact) {
+        // device-resident loop: iterations are launched in batches, kernels of an iteration
+        // that starts after convergence return immediately
+        const int batch = 8;
+        while (true) {
+            for (int q = 0; q < batch; ++q) {
+                const int first = (iters + q) == 0;
+                hipLaunchKernelGGL(k_ct_contact_grad, dim3(gc), dim3(256), 0, s, p, c, first);
+                hipLaunchKernelGGL(k_ct_node_dir, dim3(gg), dim3(CT_WG), 0, s, p, c);
+                hipLaunchKernelGGL(k_ct_ls_contact, dim3(gcs), dim3(CT_WG), 0, s, p, c, 0, 0.f);
+                hipLaunchKernelGGL(k_ct_ls_grid, dim3(gg), dim3(CT_WG), 0, s, p, c, 0, 0.f);
+                hipLaunchKernelGGL(k_ct_decide, dim3(1), dim3(64), 0, s, c, (int)gg, (int)gcs, (int)gg, 0);
+                hipLaunchKernelGGL(k_ct_apply, dim3(gg), dim3(CT_WG), 0, s, p, c);
+                hipLaunchKernelGGL(k_ct_latch, dim3(1), dim3(64), 0, s, c);
+            }
+            iters += batch;
+            HIP_TRY(hipMemcpyAsync(&st, b.st, sizeof(ContactState), hipMemcpyDeviceToHost, s));
+            HIP_TRY(hipStreamSynchronize(s));
+            if (st.done || st.iters >= max_iters) break;
+        }
+        iters = st.iters;
+        residual = st.residual;
+    } else {
+        // exact line search: Newton with bisection fallback on dE/dalpha, driven from the host
+        // exactly like cuda_mpm_solver.cu:383-471 (itself a clone of Drake's
+        // DoNewtonWithBisectionFallback)
+        auto probe = [&](float alpha, std::tuple<float, float, float>* out) -> int {
+            hipLaunchKernelGGL(k_ct_ls_contact, dim3(gcs), dim3(CT_WG), 0, s, p, c, 1, alpha);
+            hipLaunchKernelGGL(k_ct_ls_grid, dim3(gg), dim3(CT_WG), 0, s, p, c, 1, alpha);
+            hipLaunchKernelGGL(k_ct_decide, dim3(1), dim3(64), 0, s, c, (int)gg, (int)gcs, (int)gg, 1);
+            HIP_TRY(hipMemcpyAsync(&st, b.st, sizeof(ContactState), hipMemcpyDeviceToHost, s));
+            HIP_TRY(hipStreamSynchronize(s));
+            *out = std::make_tuple((float)st.scal[0], (float)st.scal[1], (float)st.scal[2]);
+            return 0;
+        };
+        auto sign = [](float v) { return v > 0 ? 1 : (v < 0 ? -1 : 0); };
+        const float f_tol = 1e-8f, x_tol = f_tol * c.relax;
+        while (residual > c.tol && iters < max_iters) {
+            hipLaunchKernelGGL(k_ct_contact_grad, dim3(gc), dim3(256), 0, s, p, c, iters == 0);
+            hipLaunchKernelGGL(k_ct_node_dir, dim3(gg), dim3(CT_WG), 0, s, p, c);
+            std::tuple<float, float, float> f_lo, f_hi, f_root;
+            int rc;
+            if ((rc = probe(0.f, &f_lo)) || (rc = probe(1.f, &f_hi))) return rc;
+            float x_lo = 0.f, x_hi = 1.f;
+            if (std::get<1>(f_lo) < 0.f && std::get<1>(f_hi) < 0.f) {
+                x_lo = 1.f;
+                f_lo = f_hi;
+            }
+            float root = x_hi, mdx = x_lo - x_hi, mdx_prev = mdx, alpha = 1.f, energy = 0.f;
+            int ls = 0;
+            bool ok = false;
+            while (!ok) {
+                if ((rc = probe(root, &f_root))) return rc;
+                if (sign(std::get<1>(f_root)) != sign(std::get<1>(f_hi))) {
+                    x_lo = root;
+                    f_lo = f_root;
+                } else {
+                    x_hi = root;
+                    f_hi = f_root;
+                }
+                if (std::fabs(std::get<1>(f_root)) < f_tol) ok = true;
+                const bool slow = 2.f * std::fabs(std::get<1>(f_root)) > std::fabs(mdx_prev * std::get<2>(f_root));
+                mdx_prev = mdx;
+                if (slow) {
+                    mdx = .5f * (x_lo - x_hi);
+                    root = x_lo - mdx;
+                } else {
+                    mdx = std::get<1>(f_root) / std::get<2>(f_root);
+                    const float x = root - mdx;
+                    if (x_lo <= x && x <= x_hi) {
+                        root = x;
+                    } else {
+                        mdx = .5f * (x_lo - x_hi);
+                        root = x_lo - mdx;
+                    }
+                }
+                if (std::fabs(mdx) < x_tol) ok = true;
+                if (ok) {
+                    energy = std::get<0>(f_root);
+                    alpha = root;
+                }
+                ls += 1;
+            }
+            HIP_TRY(hipMemcpyAsync(&b.st->alpha, &alpha, 4, hipMemcpyHostToDevice, s));
+            hipLaunchKernelGGL(k_ct_apply, dim3(gg), dim3(CT_WG), 0, s, p, c);
+            residual = std::sqrt(st.norm_dir_sq) / st.dofs;
+            iters += 1;
+            s_res.push_back(residual);
+            s_energy.push_back(energy);
+            s_ls.push_back(ls);
+        }
+    }
+    // contact velocities after the solve and the reaction on the rigid bodies
+    hipLaunchKernelGGL(k_ct_gather_vel, dim3(gc), dim3(256), 0, s, p, c, b.vel, 0);
+    hipLaunchKernelGGL(k_ct_impulse, dim3(gc), dim3(256), 0, s, c);
+    HIP_TRY(hipGetLastError());
+    if (iters_out) *iters_out = iters;
+    if (residual_out) *residual_out = residual;
+    if (dump) {
+        // per-substep statistics, same fields as cuda_mpm_solver.cu:587-612
+        const std::string fn = e->dump_dir + "/jacobi_iter_" + std::to_string(max_iters) + "_frame_" +
+                               std::to_string(frame) + "_substep_" + std::to_string(substep) + ".json";
+        std::ofstream f(fn);
+        if (!f) return fail(MPM_ERR_INVALID, "cannot write " + fn);
+        f << "[\n";
+        if (exact) {
+            for (size_t i = 0; i < s_res.size(); ++i)
+                f << "  {\n      \"residual\": " << s_res[i] << ",\n      \"line_search_cnt\": " << s_ls[i]
+                  << ",\n      \"energy\": " << s_energy[i] << "\n  }" << (i + 1 < s_res.size() ? "," : "") << "\n";
+        } else {
+            f << "  {\n      \"iterations\": " << iters << ",\n      \"residual\": " << residual
+              << ",\n      \"line_search_cnt\": " << (iters ? (double)st.ls_total / iters : 0.0)
+              << ",\n      \"energy\": " << st.energy << "\n  }\n";
+        }
+        f << "]\n";
+    }
+    return 0;
 }

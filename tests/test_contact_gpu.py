@@ -1,0 +1,89 @@
+"""Contact solve (CopyContactPairs + UpdateContact) on the GPU vs the oracle."""
+import numpy as np
+import pytest
+
+from tests.helpers import build_pair, close, natural_scales
+
+pytestmark = pytest.mark.gpu
+DT = 1e-3
+Z_FLOOR = 0.5
+
+
+def floor_contacts(pos_slot_order):
+    """Contact pairs against the half-space z < Z_FLOOR, built like CalcMpmContactPairs
+    (deformable_driver.h:120-194): one contact per penetrating particle, normal = -grad(phi)."""
+    z = pos_slot_order[:, 2]
+    idx = np.nonzero(z < Z_FLOOR)[0].astype(np.uint32)
+    n = idx.size
+    dist = (z[idx] - Z_FLOOR).astype(np.float32)
+    normal = np.tile(np.array([0, 0, -1], np.float32), (n, 1))
+    pos = pos_slot_order[idx].astype(np.float32)
+    zeros = np.zeros((n, 3), np.float32)
+    body = np.zeros(n, np.uint32)
+    return idx, body, dist, normal, pos, zeros, zeros.copy()
+
+
+@pytest.mark.parametrize("exact", [False, True])
+@pytest.mark.parametrize("mu", [0.0, 0.5])
+def test_update_contact_matches_oracle(exact, mu):
+    from drake_amd import ARR as A
+    from oracle import oracle as orc
+    # two sheets straddling the floor, moving down and sideways
+    o, g = build_pair(layers=2, res=20, z0=Z_FLOOR - 0.004, vel_amp=0.3)
+    o.vel[:, 2] -= 0.5
+    o.vel[:, 0] += 0.3
+    stiffness, damping = 1e5, 1e-3
+    for step in range(3):
+        g.upload_particle_state(o.pos, o.vel, o.C, None, o.F)
+        o.reallocate_external_bodies(1)
+        g.reallocate_external_bodies(1)
+        pos_g = g.sync_particle_state_to_cpu()
+        assert np.array_equal(pos_g, o.pos)
+        for s in (o, g):
+            s.rebuild_mapping(False)
+            s.calc_fem_state_and_force(DT)
+            s.particle_to_grid(DT)
+            s.update_grid(-1)
+        cp = floor_contacts(pos_g)
+        assert cp[0].size > 50
+        o.copy_contact_pairs(orc.ContactPairs(*cp))
+        g.copy_contact_pairs(*cp)
+        ro = o.update_contact(DT, mu, stiffness, damping, exact_line_search=exact)
+        rg = g.update_contact(DT, mu, stiffness, damping, exact_line_search=exact)
+        sc = natural_scales(o)
+        # same Newton trajectory: the iteration count may differ by rounding right at the tolerance
+        assert abs(rg["iterations"] - ro["iterations"]) <= max(2, ro["iterations"] // 10), (rg, ro)
+        assert rg["residual"] <= 1.5e-4
+        close(g.download(A.CONTACT_VEL0), o.c_vel0, scale=sc["vel"], what="contact vel0")
+        # the solve stops at residual 1e-4: velocities agree to the solver tolerance, not to rounding
+        close(g.download(A.CONTACT_VEL), o.c_vel, scale=sc["vel"], rtol=2e-3, what="contact vel")
+        wgt = (o.g_m / o.g_m.max())[:, None]
+        close(g.download(A.GRID_MOMENTUM) * wgt, o.g_mv * wgt, scale=sc["vel"], rtol=2e-3, what="grid v after contact")
+        tau_g, f_g = g.external_body_force_to_host()
+        fscale = float(np.abs(o.F_f).max())
+        close(f_g, o.F_f, scale=fscale, rtol=5e-3, what="body impulse")
+        close(tau_g, o.F_tau, scale=max(float(np.abs(o.F_tau).max()), fscale), rtol=5e-3, what="body angular impulse")
+        # the floor pushes up
+        assert f_g[0, 2] < 0  # impulse ON the body is downward
+        o.grid_to_particle(DT)
+        g.grid_to_particle(DT)
+        close(g.download(A.VELOCITIES), o.vel, scale=sc["vel"], rtol=2e-3, what="vel after contact step")
+    g.gpu_sync()
+
+
+def test_no_contacts_is_a_noop():
+    from drake_amd import ARR as A
+    o, g = build_pair(layers=2, res=12)
+    g.reallocate_external_bodies(2)
+    g.rebuild_mapping(False)
+    g.calc_fem_state_and_force(DT)
+    g.particle_to_grid(DT)
+    g.update_grid(-1)
+    before = g.download(A.GRID_MOMENTUM)
+    e = np.zeros((0, 3), np.float32)
+    g.copy_contact_pairs(np.zeros(0, np.uint32), np.zeros(0, np.uint32), np.zeros(0, np.float32), e, e, e, e)
+    r = g.update_contact(DT, 0.5, 1e5, 1e-3)
+    assert r["iterations"] == 0
+    assert np.array_equal(before, g.download(A.GRID_MOMENTUM))
+    tau, f = g.external_body_force_to_host()
+    assert not tau.any() and not f.any()
