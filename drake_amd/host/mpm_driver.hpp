@@ -1,0 +1,104 @@
+// Host-side driver that reproduces the substep loop of DeformableDriver::CalcAbstractStates
+// (multibody/plant/deformable_driver.h:221-271) on top of the facade, with analytic colliders
+// standing in for SceneGraph's signed-distance queries (deformable_driver.h:120-194).
+#pragma once
+#include <algorithm>
+#include <cmath>
+#include <vector>
+
+#include "../../include/gpu_mpm.hpp"
+
+namespace drake_amd {
+
+using drake::multibody::gmpm::GpuMpmSolver;
+using drake::multibody::gmpm::GpuMpmState;
+using drake::multibody::gmpm::MpmConfigParams;
+using drake::multibody::gmpm::MpmParticleContactPairs;
+using drake::multibody::gmpm::Vec3;
+
+// A rigid body with an analytic signed distance field.  phi < 0 inside.
+struct RigidBody {
+    enum Kind { kHalfSpace, kSphere } kind = kHalfSpace;
+    Vec3<float> origin{0, 0, 0};   // p_WB: a point on the plane / the sphere centre
+    Vec3<float> normal{0, 0, 1};   // half-space outward normal
+    float radius = 0.1f;
+    Vec3<float> v{0, 0, 0}, w{0, 0, 0};  // spatial velocity of the body frame
+    float distance(const Vec3<float>& p, Vec3<float>* grad) const {
+        if (kind == kHalfSpace) {
+            *grad = normal;
+            return (p[0] - origin[0]) * normal[0] + (p[1] - origin[1]) * normal[1] + (p[2] - origin[2]) * normal[2];
+        }
+        const float d[3] = {p[0] - origin[0], p[1] - origin[1], p[2] - origin[2]};
+        const float len = std::sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
+        *grad = {d[0] / len, d[1] / len, d[2] / len};
+        return len - radius;
+    }
+    Vec3<float> point_velocity(const Vec3<float>& p) const {
+        const float r[3] = {p[0] - origin[0], p[1] - origin[1], p[2] - origin[2]};
+        return {v[0] + w[1] * r[2] - w[2] * r[1], v[1] + w[2] * r[0] - w[0] * r[2], v[2] + w[0] * r[1] - w[1] * r[0]};
+    }
+};
+
+class MpmDriver {
+  public:
+    MpmDriver(GpuMpmState<float>* state, MpmConfigParams<float> config) : state_(state), config_(config) {}
+    std::vector<RigidBody>& bodies() { return bodies_; }
+
+    // CalcMpmContactPairs (deformable_driver.h:120-194): one contact per (particle, body) with phi < 0
+    void CalcMpmContactPairs(MpmParticleContactPairs<float>* result) const {
+        result->clear();
+        const auto& pos = state_->positions_host();
+        for (size_t p = 0; p < pos.size(); ++p)
+            for (size_t b = 0; b < bodies_.size(); ++b) {
+                Vec3<float> g;
+                const float phi = bodies_[b].distance(pos[p], &g);
+                if (phi < 0)
+                    result->push_back(uint32_t(p), uint32_t(b), phi, {-g[0], -g[1], -g[2]}, pos[p],
+                                      bodies_[b].point_velocity(pos[p]), bodies_[b].origin);
+            }
+    }
+
+    // One plant step of length dt: the loop of deformable_driver.h:240-261.
+    int CalcAbstractStates(float dt, int frame = 0) {
+        float dt_left = dt;
+        int substep = 0;
+        state_->ReallocateExternelBodies(std::max<size_t>(bodies_.size(), 1));  // InitalizeExternalContactForces
+        MpmParticleContactPairs<float> pairs;
+        while (dt_left > 0) {
+            const float ddt = std::min(dt_left, config_.substep_dt);
+            dt_left -= ddt;
+            solver_.SyncParticleStateToCpu(state_);
+            solver_.RebuildMapping(state_, false);
+            solver_.CalcFemStateAndForce(state_, ddt);
+            solver_.ParticleToGrid(state_, ddt);
+            solver_.UpdateGrid(state_, config_.mpm_bc);
+            CalcMpmContactPairs(&pairs);
+            solver_.CopyContactPairs(state_, pairs);
+            solver_.UpdateContact(state_, frame, substep, ddt, config_.contact_friction_mu, config_.contact_stiffness,
+                                  config_.contact_damping, config_.write_files, config_.exact_line_search);
+            solver_.GridToParticle(state_, ddt);
+            substep += 1;
+        }
+        // FinalizeExternalContactForces: impulses -> forces
+        state_->ExternelBodyForceToHost();
+        auto& f = state_->external_forces_host();
+        for (size_t i = 0; i < f.size(); ++i)
+            for (int d = 0; d < 3; ++d) {
+                f.p_BoBq_B[i][d] = 0;
+                f.F_Bq_W_tau[i][d] /= dt;
+                f.F_Bq_W_f[i][d] /= dt;
+            }
+        last_contacts_ = pairs.size();
+        return substep;
+    }
+    size_t last_contacts() const { return last_contacts_; }
+
+  private:
+    GpuMpmState<float>* state_;
+    MpmConfigParams<float> config_;
+    GpuMpmSolver<float> solver_;
+    std::vector<RigidBody> bodies_;
+    size_t last_contacts_ = 0;
+};
+
+}  // namespace drake_amd

@@ -1,0 +1,182 @@
+// gpu_mpm.hpp -- header-only C++ facade over the C ABI (mpm_hip.h) that re-creates the
+// reference's class interface, so that a caller written against
+//   multibody/gpu_mpm/cuda_mpm_model.cuh   (GpuMpmState<T>)
+//   multibody/gpu_mpm/cuda_mpm_solver.cuh  (GpuMpmSolver<T>)
+//   multibody/gpu_mpm/cpu_mpm_model.h      (MpmConfigParams, MpmParticleContactPairs, ...)
+// compiles against this engine by swapping the include.  Method names, argument order and
+// meaning are the reference's; only T = float exists (as in the reference, settings.h:37).
+//
+// Vec3<T> here is std::array<T,3>; Eigen::Vector3f has the same layout (three packed floats),
+// so inside Drake the arrays can be passed through reinterpret_cast or Eigen::Map.
+#pragma once
+#include <array>
+#include <cstdint>
+#include <stdexcept>
+#include <string>
+#include <tuple>
+#include <vector>
+
+#include "mpm_hip.h"
+
+namespace drake {
+namespace multibody {
+namespace gmpm {
+
+template <typename T> using Vec3 = std::array<T, 3>;
+namespace config { using GpuT = float; }
+
+inline void mpm_check(int rc) {
+    if (rc != 0) throw std::runtime_error(std::string("mpm_hip: ") + mpm_last_error());
+}
+
+// cpu_mpm_model.h:16-26
+template <typename T = config::GpuT>
+struct MpmConfigParams {
+    T substep_dt{static_cast<T>(1e-3)};
+    bool write_files{false};
+    T contact_stiffness{static_cast<T>(1e5)};
+    T contact_damping{static_cast<T>(0.0)};
+    T contact_friction_mu{static_cast<T>(0.0)};
+    int contact_query_frequency{1};
+    int mpm_bc{-1};
+    bool exact_line_search{false};
+};
+
+// cpu_mpm_model.h:32-40
+template <typename T>
+struct CpuMpmModel {
+    std::vector<Vec3<T>> cloth_pos;
+    std::vector<Vec3<T>> cloth_vel;
+    std::vector<int> cloth_indices;
+    MpmConfigParams<T> config;
+};
+
+// cpu_mpm_model.h:45-49
+template <typename T>
+struct MpmPortData {
+    std::vector<Vec3<T>> pos;
+    std::vector<int> indices;
+};
+
+// cpu_mpm_model.h:73-114
+template <typename T>
+struct MpmParticleContactPairs {
+    std::vector<uint32_t> particle_in_contact_index;
+    std::vector<uint32_t> non_mpm_id;
+    std::vector<T> penetration_distance;
+    std::vector<Vec3<T>> normal;
+    std::vector<Vec3<T>> particle_in_contact_position;
+    std::vector<Vec3<T>> rigid_v;
+    std::vector<Vec3<T>> rigid_p_WB;
+    void clear() {
+        particle_in_contact_index.clear(); non_mpm_id.clear(); penetration_distance.clear(); normal.clear();
+        particle_in_contact_position.clear(); rigid_v.clear(); rigid_p_WB.clear();
+    }
+    void push_back(uint32_t particle, uint32_t body, T dist, Vec3<T> n, Vec3<T> pos, Vec3<T> v, Vec3<T> p_WB) {
+        particle_in_contact_index.push_back(particle); non_mpm_id.push_back(body);
+        penetration_distance.push_back(dist); normal.push_back(n); particle_in_contact_position.push_back(pos);
+        rigid_v.push_back(v); rigid_p_WB.push_back(p_WB);
+    }
+    size_t size() const { return non_mpm_id.size(); }
+};
+
+// cuda_mpm_model.cuh:19-35
+template <typename T>
+struct ExternalSpatialForce {
+    std::vector<Vec3<T>> p_BoBq_B;
+    std::vector<Vec3<T>> F_Bq_W_tau;
+    std::vector<Vec3<T>> F_Bq_W_f;
+    size_t size() const { return p_BoBq_B.size(); }
+    void resize(size_t n) { p_BoBq_B.resize(n); F_Bq_W_tau.resize(n); F_Bq_W_f.resize(n); }
+};
+
+// cuda_mpm_model.cuh:37-260.  Copies alias the same engine handle, like the reference's
+// shallow-copied device pointers (deformable_model.cc:428); Destroy() is explicit.
+template <typename T>
+struct GpuMpmState {
+    static_assert(sizeof(T) == sizeof(float), "only float is instantiated, as in the reference");
+    explicit GpuMpmState(int domain_bits = 7, const mpm_material_t* material = nullptr, int device = 0) {
+        mpm_check(mpm_create(domain_bits, material, device, &h_));
+    }
+    mpm_handle_t handle() const { return h_; }
+
+    size_t n_verts() const { size_t a, b, c; mpm_check(mpm_counts(h_, &a, &b, &c)); return a; }
+    size_t n_faces() const { size_t a, b, c; mpm_check(mpm_counts(h_, &a, &b, &c)); return b; }
+    size_t n_particles() const { size_t a, b, c; mpm_check(mpm_counts(h_, &a, &b, &c)); return c; }
+
+    void AddQRCloth(const std::vector<Vec3<T>>& pos, const std::vector<Vec3<T>>& vel, const std::vector<int>& indices) {
+        mpm_check(mpm_add_qr_cloth(h_, reinterpret_cast<const float*>(pos.data()),
+                                   reinterpret_cast<const float*>(vel.data()), pos.size(), indices.data(),
+                                   indices.size() / 3));
+    }
+    void Finalize() { mpm_check(mpm_finalize(h_)); }
+    void Destroy() { mpm_check(mpm_destroy(h_)); h_ = nullptr; }
+
+    using DumpT = std::tuple<std::vector<Vec3<T>>, std::vector<int>>;
+    DumpT DumpCpuState() const {
+        std::vector<Vec3<T>> pos(n_verts());
+        std::vector<int> idx(n_faces() * 3);
+        mpm_check(mpm_dump_cpu_state(h_, reinterpret_cast<float*>(pos.data()), idx.data()));
+        return std::make_tuple(pos, idx);
+    }
+    void ReallocateContacts(size_t) {}  // implicit in CopyContactPairs
+    void ReallocateExternelBodies(size_t n) { mpm_check(mpm_reallocate_external_bodies(h_, n)); n_bodies_ = n; }
+    void ExternelBodyForceToHost() {
+        h_external_forces_.resize(n_bodies_);
+        mpm_check(mpm_external_body_force_to_host(h_, reinterpret_cast<float*>(h_external_forces_.F_Bq_W_tau.data()),
+                                                  reinterpret_cast<float*>(h_external_forces_.F_Bq_W_f.data())));
+    }
+    uint32_t grid_touched_cnt_host() const { uint32_t c = 0; mpm_check(mpm_grid_touched_cnt(h_, &c)); return c; }
+    std::vector<Vec3<T>>& positions_host() { return h_positions_; }
+    const std::vector<Vec3<T>>& positions_host() const { return h_positions_; }
+    ExternalSpatialForce<T>& external_forces_host() { return h_external_forces_; }
+    const ExternalSpatialForce<T>& external_forces_host() const { return h_external_forces_; }
+    size_t num_external_bodies() const { return n_bodies_; }
+    size_t num_contacts() const { return n_contacts_; }
+    int total_contact_iteration_count = 0;
+
+  private:
+    template <typename U> friend class GpuMpmSolver;
+    mpm_handle_t h_ = nullptr;
+    size_t n_bodies_ = 0, n_contacts_ = 0;
+    std::vector<Vec3<T>> h_positions_;
+    ExternalSpatialForce<T> h_external_forces_;
+};
+
+// cuda_mpm_solver.cuh:19-35 (stateless, all const)
+template <typename T>
+class GpuMpmSolver {
+  public:
+    void RebuildMapping(GpuMpmState<T>* s, bool sort) const { mpm_check(mpm_rebuild_mapping(s->h_, sort)); }
+    void CalcFemStateAndForce(GpuMpmState<T>* s, const T& dt) const { mpm_check(mpm_calc_fem_state_and_force(s->h_, dt)); }
+    void ParticleToGrid(GpuMpmState<T>* s, const T& dt) const { mpm_check(mpm_particle_to_grid(s->h_, dt)); }
+    void UpdateGrid(GpuMpmState<T>* s, int mpm_bc = -1) const { mpm_check(mpm_update_grid(s->h_, mpm_bc)); }
+    void GridToParticle(GpuMpmState<T>* s, const T& dt) const { mpm_check(mpm_grid_to_particle(s->h_, dt)); }
+    void GpuSync() const {}
+    void GpuSync(GpuMpmState<T>* s) const { mpm_check(mpm_sync(s->h_)); }
+    void SyncParticleStateToCpu(GpuMpmState<T>* s) const {
+        s->h_positions_.resize(s->n_particles());
+        mpm_check(mpm_sync_particle_state_to_cpu(s->h_, reinterpret_cast<float*>(s->h_positions_.data())));
+    }
+    void Dump(const GpuMpmState<T>& s, std::string filename) const { mpm_check(mpm_dump_obj(s.h_, filename.c_str())); }
+    void CopyContactPairs(GpuMpmState<T>* s, const MpmParticleContactPairs<T>& c) const {
+        s->n_contacts_ = c.size();
+        mpm_check(mpm_copy_contact_pairs(s->h_, c.size(), c.particle_in_contact_index.data(), c.non_mpm_id.data(),
+                                         c.penetration_distance.data(), reinterpret_cast<const float*>(c.normal.data()),
+                                         reinterpret_cast<const float*>(c.particle_in_contact_position.data()),
+                                         reinterpret_cast<const float*>(c.rigid_v.data()),
+                                         reinterpret_cast<const float*>(c.rigid_p_WB.data())));
+    }
+    void UpdateContact(GpuMpmState<T>* s, const int frame, const int substep, const T& dt, const T& friction_mu,
+                       const T& stiffness, const T& damping, const bool dump, const bool exact_line_search) const {
+        int it = 0;
+        float res = 0;
+        mpm_check(mpm_update_contact(s->h_, frame, substep, dt, friction_mu, stiffness, damping, dump,
+                                     exact_line_search, 0, &it, &res));
+        s->total_contact_iteration_count += it;
+    }
+};
+
+}  // namespace gmpm
+}  // namespace multibody
+}  // namespace drake
