@@ -65,7 +65,8 @@ struct DP {
     PSet set[2];
     // per-substep scratch
     float* ab[6];          // faces: tau = a (x) b  (a = vol*P[:,2], b = F[:,2])
-    float* G[9];           // faces: G[i*3+c] = force component i on corner c (negated when applied)
+    float4* G4;            // faces: G4[face slot * 3 + c] = force triple the face exerts on corner c (negated when applied)
+    int* vadj[8];          // vertex slot -> up to 8 (face slot * 3 + corner) records, -1 = none, -2 in [0] = use the CSR
     float* f[3];           // vertices: internal force
     // topology (original ids)
     const int* idx_orig[3];  // face -> original particle ids of its corners

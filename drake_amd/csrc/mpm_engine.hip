@@ -166,7 +166,8 @@ int mpm_finalize(mpm_handle_t e) {
         ALLOC(S.pid, np, true);
     }
     for (int d = 0; d < 6; ++d) ALLOC(p.ab[d], nf, true);
-    for (int d = 0; d < 9; ++d) ALLOC(p.G[d], nf, true);
+    ALLOC(p.G4, 3 * nf, true);
+    for (int d = 0; d < 8; ++d) ALLOC(p.vadj[d], nv, true);
     for (int d = 0; d < 3; ++d) ALLOC(p.f[d], np, true);
     int* idx_orig[3];
     int *adj_off, *adj_fc;

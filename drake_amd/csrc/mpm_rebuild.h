@@ -326,6 +326,24 @@ __global__ __launch_bounds__(256) void k_rb_finish(DP p) {
 #pragma unroll
         for (int k = 0; k < 3; ++k) p.fv[k][i] = p.imap[p.idx_orig[k][pid]];
     }
+    // per vertex slot, the (face slot, corner) records of its adjacent faces
+    for (unsigned k = i0; k < (unsigned)p.Nv; k += gs) {
+        const int vo = D.pid[p.Nf + k] - p.Nf;
+        const int e0 = p.adj_off[vo], e1 = p.adj_off[vo + 1];
+        if (e1 - e0 > 8) {
+            p.vadj[0][k] = -2;
+        } else {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                int rec = -1;
+                if (e0 + q < e1) {
+                    const int fc = p.adj_fc[e0 + q];
+                    rec = p.imap[fc >> 2] * 3 + (fc & 3);
+                }
+                p.vadj[q][k] = rec;
+            }
+        }
+    }
     // every cell row of a home block holds prefix values now: clear whole rows
     const unsigned n_home = c->n_home;
     for (unsigned w = i0; w < n_home * 32u; w += gs) {

@@ -66,32 +66,54 @@ __global__ __launch_bounds__(256) void k_fem(DP p, float dt) {
     // grad_N = Dm^-T [[-1,1,0],[-1,0,1]]  (:269-276)
     const float g00 = -Dm[0] - Dm[2], g01 = Dm[0], g02 = Dm[2];
     const float g10 = -Dm[1] - Dm[3], g11 = Dm[1], g12 = Dm[3];
+    float Gm[9];
 #pragma unroll
     for (int d = 0; d < 3; ++d) {
         const float a = P[d * 3 + 0], b = P[d * 3 + 1];
-        p.G[d * 3 + 0][i] = a * g00 + b * g10;
-        p.G[d * 3 + 1][i] = a * g01 + b * g11;
-        p.G[d * 3 + 2][i] = a * g02 + b * g12;
+        Gm[d * 3 + 0] = a * g00 + b * g10;
+        Gm[d * 3 + 1] = a * g01 + b * g11;
+        Gm[d * 3 + 2] = a * g02 + b * g12;
     }
+    // one 16-byte record per corner so that a vertex fetches its triple with a single load
+#pragma unroll
+    for (int c = 0; c < 3; ++c) p.G4[(size_t)i * 3 + c] = make_float4(Gm[c], Gm[3 + c], Gm[6 + c], 0.f);
 }
 
-// Vertex force = - sum over adjacent (face, corner) of G[:, corner], summed in
-// ascending original face id (the order sequential atomics would produce).
+// Vertex force = - sum over adjacent (face, corner) of that corner's force triple, summed in
+// ascending original face id (the order sequential atomics would produce).  The adjacency is
+// kept per vertex slot (refreshed at every rebuild) so that a vertex needs one coalesced index
+// load and one 16-byte gather per adjacent face.
 __global__ __launch_bounds__(256) void k_vforce(DP p) {
     const int k = blockIdx.x * 256 + threadIdx.x;
     if (k >= p.Nv) return;
     const int s = p.Nf + k;
-    const PSet& S = p.set[p.ctl->cur];
-    const int vo = S.pid[s] - p.Nf;
-    const int e0 = p.adj_off[vo], e1 = p.adj_off[vo + 1];
     float f0 = 0.f, f1 = 0.f, f2 = 0.f;
-    for (int e = e0; e < e1; ++e) {
-        const int fc = p.adj_fc[e];
-        const int fs = p.imap[fc >> 2];
-        const int c = fc & 3;
-        f0 += -p.G[0 + c][fs];
-        f1 += -p.G[3 + c][fs];
-        f2 += -p.G[6 + c][fs];
+    int rec[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) rec[q] = p.vadj[q][k];
+    if (rec[0] != -2) {
+        float4 g[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) g[q] = rec[q] >= 0 ? p.G4[rec[q]] : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            if (rec[q] >= 0) {
+                f0 += -g[q].x;
+                f1 += -g[q].y;
+                f2 += -g[q].z;
+            }
+        }
+    } else {
+        // more than 8 faces around this vertex: walk the original adjacency
+        const PSet& S = p.set[p.ctl->cur];
+        const int vo = S.pid[s] - p.Nf;
+        for (int e = p.adj_off[vo]; e < p.adj_off[vo + 1]; ++e) {
+            const int fc = p.adj_fc[e];
+            const float4 g = p.G4[(size_t)p.imap[fc >> 2] * 3 + (fc & 3)];
+            f0 += -g.x;
+            f1 += -g.y;
+            f2 += -g.z;
+        }
     }
     p.f[0][s] = f0;
     p.f[1][s] = f1;
@@ -256,36 +278,58 @@ __global__ __launch_bounds__(512) void k_p2g(DP p, float dt) {
         // sorted by cell, so a group's faces and vertices cover (nearly) the same few cells.
         const int nvb = total - nfb;
         const int ngroups = (total + 61) / 62;
-        for (int g = wv; g < ngroups; g += 8) {
-            // ---- 1. one particle per lane --------------------------------------
+        struct Raw {
+            float x[3], v[3], vol, C[9], aux[6];  // aux: tau factors a,b (faces) or force (vertices)
+            bool act, is_face;
+        };
+        auto load_raw = [&](int g) {
+            Raw r;
             const int fa = (int)((long long)nfb * g / ngroups), fb = (int)((long long)nfb * (g + 1) / ngroups);
             const int va = (int)((long long)nvb * g / ngroups), vb = (int)((long long)nvb * (g + 1) / ngroups);
             const int gf = fb - fa, gn = gf + (vb - va);
-            const bool act = lane < gn;
-            const bool is_face = lane < gf;
-            const int ii = act ? (is_face ? rg.x + fa + lane : rg.z + va + (lane - gf)) : (nfb ? rg.x : rg.z);
-            const Stencil st = make_stencil(p, S.x[0][ii], S.x[1][ii], S.x[2][ii], ox, oy, oz);
-            const float m = S.vol[ii] * p.M.density;
+            r.act = lane < gn;
+            r.is_face = lane < gf;
+            const int ii = r.act ? (r.is_face ? rg.x + fa + lane : rg.z + va + (lane - gf)) : (nfb ? rg.x : rg.z);
+#pragma unroll
+            for (int d = 0; d < 3; ++d) { r.x[d] = S.x[d][ii]; r.v[d] = S.v[d][ii]; }
+            r.vol = S.vol[ii];
+#pragma unroll
+            for (int d = 0; d < 9; ++d) r.C[d] = S.C[d][ii];
+            if (r.is_face) {
+#pragma unroll
+                for (int d = 0; d < 6; ++d) r.aux[d] = p.ab[d][ii];
+            } else {
+#pragma unroll
+                for (int d = 0; d < 3; ++d) r.aux[d] = p.f[d][ii];
+                r.aux[3] = r.aux[4] = r.aux[5] = 0.f;
+            }
+            return r;
+        };
+        Raw cur;
+        if (wv < ngroups) cur = load_raw(wv);
+        for (int g = wv; g < ngroups; g += 8) {
+            // ---- 1. one particle per lane (its raw state was prefetched) ----------
+            const bool act = cur.act, is_face = cur.is_face;
+            const Stencil st = make_stencil(p, cur.x[0], cur.x[1], cur.x[2], ox, oy, oz);
+            const float m = cur.vol * p.M.density;
             float Y[16];
             {
                 float B[9];
                 float fext[3] = {0.f, 0.f, 0.f};
                 if (is_face) {
-                    const float av[3] = {p.ab[0][ii], p.ab[1][ii], p.ab[2][ii]};
-                    const float bv[3] = {p.ab[3][ii], p.ab[4][ii], p.ab[5][ii]};
 #pragma unroll
                     for (int r = 0; r < 3; ++r)
 #pragma unroll
-                        for (int c = 0; c < 3; ++c) B[r * 3 + c] = sdt * (av[r] * bv[c]) + S.C[r * 3 + c][ii] * m;
+                        for (int c = 0; c < 3; ++c) B[r * 3 + c] = sdt * (cur.aux[r] * cur.aux[3 + c]) + cur.C[r * 3 + c] * m;
                 } else {
 #pragma unroll
-                    for (int r = 0; r < 9; ++r) B[r] = S.C[r][ii] * m;
+                    for (int r = 0; r < 9; ++r) B[r] = cur.C[r] * m;
 #pragma unroll
-                    for (int r = 0; r < 3; ++r) fext[r] = p.f[r][ii] * dt;
+                    for (int r = 0; r < 3; ++r) fext[r] = cur.aux[r] * dt;
                 }
 #pragma unroll
                 for (int r = 0; r < 3; ++r) {
-                    float qq = S.v[r][ii] * m;
+                    float qq = cur.v[r] * m;
                     if (r == p.M.gravity_axis) qq += m * gdt;
                     qq += fext[r];
                     qq -= (B[r * 3] * st.fx[0] + B[r * 3 + 1] * st.fx[1] + B[r * 3 + 2] * st.fx[2]) * p.dx;
@@ -296,6 +340,9 @@ __global__ __launch_bounds__(512) void k_p2g(DP p, float dt) {
                 }
                 Y[12] = m; Y[13] = 0.f; Y[14] = 0.f; Y[15] = 0.f;
             }
+            // the raw registers are dead now: start the next group's loads, they complete while this
+            // group goes through the LDS / matrix-pipe phases below (which never wait on vmcnt)
+            if (g + 8 < ngroups) cur = load_raw(g + 8);
             if (act) {
                 mymask |= st.mask27;
                 soft |= st.soft_out;

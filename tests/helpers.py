@@ -5,6 +5,7 @@ from drake_amd import scenes
 from oracle import oracle as orc
 
 RTOL = 1e-5  # BASELINE.json north_star: "float state within 1e-5 relative"
+MARGINS = []  # (error / allowed, what) of every comparison, reported at the end of the session
 
 
 def close(a, b, scale=None, rtol=RTOL, what=""):
@@ -18,6 +19,7 @@ def close(a, b, scale=None, rtol=RTOL, what=""):
     if scale is None:
         scale = float(np.max(np.abs(b)))
     err = float(np.max(np.abs(a - b)))
+    MARGINS.append((err / (rtol * scale + 1e-30), what))
     assert np.all(np.isfinite(a)), what
     assert err <= rtol * scale + 1e-30, f"{what}: max err {err:.3e} > {rtol:.0e} * scale {scale:.3e}"
 
