@@ -27,6 +27,9 @@ def _stale() -> bool:
 
 
 def build(force: bool = False, verbose: bool = False, extra=()) -> str:
+    if os.environ.get("MPM_DIAG_BUILD") == "1":
+        extra = tuple(extra) + ("-DMPM_DIAG=1",)
+        force = True
     if not force and not _stale():
         return LIB
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
@@ -40,5 +43,6 @@ def build(force: bool = False, verbose: bool = False, extra=()) -> str:
 
 
 if __name__ == "__main__":
-    build(force="--force" in sys.argv, verbose=True)
+    build(force="--force" in sys.argv or "--diag" in sys.argv, verbose=True,
+          extra=("-DMPM_DIAG=1",) if "--diag" in sys.argv else ())
     print(LIB)

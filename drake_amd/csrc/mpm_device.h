@@ -97,6 +97,13 @@ struct DP {
     float4* gvs;           // [active][64] v* (velocity after the explicit update, before contact)
 };
 
+// Kernel ablation / cycle-counter switches exist only in the diagnostic build (-DMPM_DIAG=1,
+// `python -m drake_amd._build --diag`); in the production build they fold to 0 and cost nothing.
+#ifndef MPM_DIAG
+#define MPM_DIAG 0
+#endif
+MPM_DEV int diag_flags(const DP& p) { return MPM_DIAG ? p.dbg : 0; }
+
 MPM_DEV int off_index(int ox, int oy, int oz) { return (ox + 1) * 9 + (oy + 1) * 3 + (oz + 1); }
 
 // id of the block at coords(b) + (ox,oy,oz), or -1 outside the grid

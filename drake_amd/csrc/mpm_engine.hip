@@ -94,14 +94,20 @@ static void launch_fem(mpm_engine* e, float dt) {
     if (e->nf) hipLaunchKernelGGL(k_fem, dim3(e->g_nf), dim3(256), 0, e->stream, p, dt);
     if (e->nv) hipLaunchKernelGGL(k_vforce, dim3(e->g_nv), dim3(256), 0, e->stream, p);
 }
+// The two tile kernels pull home blocks from device-side queues and each re-arms the other's
+// queue head; when the caller repeats one of them, the head is re-armed from the host.
 static void launch_p2g(mpm_engine* e, float dt) {
-    hipLaunchKernelGGL(k_p2g, dim3(e->g_tile), dim3(512), 0, e->stream, e->dp, dt);
+    if (e->last_tile_kernel == 1) (void)hipMemsetAsync(&e->dp.ctl->q_p2g, 0, 4, e->stream);
+    hipLaunchKernelGGL(k_p2g, dim3(getenv("MPM_P2G_WGS") ? atoi(getenv("MPM_P2G_WGS")) : e->g_tile), dim3(512), 0, e->stream, e->dp, dt);
+    e->last_tile_kernel = 1;
 }
 static void launch_grid(mpm_engine* e, int bc) {
     hipLaunchKernelGGL(k_grid<1>, dim3(e->g_grid), dim3(256), 0, e->stream, e->dp, bc);
 }
 static void launch_g2p(mpm_engine* e, float dt) {
-    hipLaunchKernelGGL(k_g2p, dim3(e->g_tile), dim3(512), 0, e->stream, e->dp, dt);
+    if (e->last_tile_kernel == 2) (void)hipMemsetAsync(&e->dp.ctl->q_g2p, 0, 4, e->stream);
+    hipLaunchKernelGGL(k_g2p, dim3(std::min(768u, e->dp.capH)), dim3(G2P_THREADS), 0, e->stream, e->dp, dt);
+    e->last_tile_kernel = 2;
 }
 
 // The P2G tiles accumulate in 64-bit fixed point.  Scales are powers of two chosen from the
@@ -257,6 +263,13 @@ int mpm_finalize(mpm_handle_t e) {
     launch_rebuild(e);
     HIP_TRY(hipStreamSynchronize(e->stream));
     HIP_TRY(hipGetLastError());
+    if (p.dbg) {
+        int a = 0, b = 0, c = 0;
+        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, k_p2g, 512, 0);
+        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, k_g2p, G2P_THREADS, 0);
+        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&c, k_fem, 256, 0);
+        std::fprintf(stderr, "[mpm_hip] resident workgroups per CU: p2g %d, g2p %d, fem %d\n", a, b, c);
+    }
     e->finalized = true;
     return mpm_sync(e);
 }

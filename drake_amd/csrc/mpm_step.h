@@ -14,10 +14,10 @@ namespace mpm {
 // FEM: one thread per face particle (slot order => coalesced face arrays).
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_fem(DP p, float dt) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= p.Nf) return;
+    const unsigned i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= (unsigned)p.Nf) return;
     const PSet& S = p.set[p.ctl->cur];
-    const int s0 = p.fv[0][i], s1 = p.fv[1][i], s2 = p.fv[2][i];
+    const unsigned s0 = (unsigned)p.fv[0][i], s1 = (unsigned)p.fv[1][i], s2 = (unsigned)p.fv[2][i];
     float x0[3], x1[3], x2[3];
 #pragma unroll
     for (int d = 0; d < 3; ++d) {
@@ -263,6 +263,7 @@ __global__ __launch_bounds__(512) void k_p2g(DP p, float dt) {
         __syncthreads();
         if (s_h >= n_home) break;
         const unsigned h = p.home_order[s_h];
+        const unsigned long long tb0 = (diag_flags(p) & 4) ? __builtin_readcyclecounter() : 0ull;
         for (int n = tid; n < TILE_N * 4; n += 512) tile[n] = 0;
         if (tid == 0) s_mask = 0;
         __syncthreads();
@@ -289,7 +290,8 @@ __global__ __launch_bounds__(512) void k_p2g(DP p, float dt) {
             const int gf = fb - fa, gn = gf + (vb - va);
             r.act = lane < gn;
             r.is_face = lane < gf;
-            const int ii = r.act ? (r.is_face ? rg.x + fa + lane : rg.z + va + (lane - gf)) : (nfb ? rg.x : rg.z);
+            // unsigned index: lets the loads use the scalar-base + 32-bit-offset addressing form
+            const unsigned ii = (unsigned)(r.act ? (r.is_face ? rg.x + fa + lane : rg.z + va + (lane - gf)) : (nfb ? rg.x : rg.z));
 #pragma unroll
             for (int d = 0; d < 3; ++d) { r.x[d] = S.x[d][ii]; r.v[d] = S.v[d][ii]; }
             r.vol = S.vol[ii];
@@ -307,8 +309,11 @@ __global__ __launch_bounds__(512) void k_p2g(DP p, float dt) {
         };
         Raw cur;
         if (wv < ngroups) cur = load_raw(wv);
+        const bool prof = (diag_flags(p) & 4) != 0 && wv == 0;
+        unsigned long long tq[3] = {0, 0, 0}, pc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         for (int g = wv; g < ngroups; g += 8) {
             // ---- 1. one particle per lane (its raw state was prefetched) ----------
+            if (prof) tq[0] = __builtin_readcyclecounter();
             const bool act = cur.act, is_face = cur.is_face;
             const Stencil st = make_stencil(p, cur.x[0], cur.x[1], cur.x[2], ox, oy, oz);
             const float m = cur.vol * p.M.density;
@@ -348,7 +353,7 @@ __global__ __launch_bounds__(512) void k_p2g(DP p, float dt) {
                 soft |= st.soft_out;
                 hard |= st.hard_out;
             }
-            if (p.dbg & 2) {
+            if (diag_flags(p) & 2) {
                 float acc = 0.f;
 #pragma unroll
                 for (int k = 0; k < 16; ++k) acc += Y[k];
@@ -382,7 +387,7 @@ __global__ __launch_bounds__(512) void k_p2g(DP p, float dt) {
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            if (p.dbg & 1) continue;
+            if (diag_flags(p) & 1) continue;
             // ---- 4. per-cell contraction on the matrix pipe ----------------------
             unsigned long long todo = actmask;
             int s0 = 0;
@@ -391,22 +396,17 @@ __global__ __launch_bounds__(512) void k_p2g(DP p, float dt) {
                 const float* sn = stage + g4 * STG;
                 nfx = sn[16]; nfy = sn[17]; nfz = sn[18]; ny = sn[j16];
             }
-            const bool prof = (p.dbg & 4) != 0;
-            unsigned long long t_begin = 0, n_steps = 0, n_cells = 0;
-            if (prof) t_begin = __builtin_readcyclecounter();
+            if (prof) tq[1] = __builtin_readcyclecounter();
             while (todo) {
                 const int ckey = __builtin_amdgcn_readlane(key, __builtin_ctzll(todo));
                 const unsigned long long same = __ballot(key == ckey) & todo;
                 todo &= ~same;
                 const int s1 = s0 + (int)__popcll(same);
                 f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-                const bool stamp = (p.dbg & 32) && blockIdx.x == 7 && wv == 3 && g == wv && s0 == 0;
-                unsigned long long c0 = 0, c1 = 0, c2 = 0, c3 = 0;
-                if (stamp) c0 = __builtin_readcyclecounter();
-                if (prof) { n_cells += 1; n_steps += (unsigned)((s1 - s0 + 3) >> 2); }
+                if (prof) { pc[4] += 1; pc[5] += (unsigned)((s1 - s0 + 3) >> 2); tq[2] = __builtin_readcyclecounter(); }
                 // operands of a step are fetched one step ahead (the first step's during the previous
                 // cell's epilogue), so the LDS latency hides behind the MFMAs
-                for (int s = (p.dbg & 8) ? s1 : s0; s < s1; s += 4) {
+                for (int s = (diag_flags(p) & 8) ? s1 : s0; s < s1; s += 4) {
                     const bool ok = s + g4 < s1;
                     const float fx = nfx, fy = nfy, fz = nfz;
                     float y = ny;
@@ -420,9 +420,9 @@ __global__ __launch_bounds__(512) void k_p2g(DP p, float dt) {
                     float w1 = fmaf(fmaf(ax[1][2], fx, ax[1][1]), fx, ax[1][0]) *
                                fmaf(fmaf(ay[1][2], fy, ay[1][1]), fy, ay[1][0]) *
                                fmaf(fmaf(az[1][2], fz, az[1][1]), fz, az[1][0]);
-                    if (p.dbg & 128) { w0 = fx; w1 = fy; }
+                    if (diag_flags(p) & 128) { w0 = fx; w1 = fy; }
                     if (!ok) { y = 0.f; w0 = 0.f; w1 = 0.f; }
-                    if (p.dbg & 64) {
+                    if (diag_flags(p) & 64) {
                         acc0[0] = fmaf(w0, y, acc0[0]);
                         acc1[0] = fmaf(w1, y, acc1[0]);
                     } else {
@@ -431,11 +431,11 @@ __global__ __launch_bounds__(512) void k_p2g(DP p, float dt) {
                     }
                 }
                 // the loop leaves row block (last step + 4) preloaded; the next cell starts at s1
-                if (((s1 - s0) & 3) != 0 || (p.dbg & 8)) {
+                if (((s1 - s0) & 3) != 0 || (diag_flags(p) & 8)) {
                     const float* sn = stage + (s1 + g4) * STG;
                     nfx = sn[16]; nfy = sn[17]; nfz = sn[18]; ny = sn[j16];
                 }
-                if (stamp) { asm volatile("" :: "v"(acc0), "v"(acc1)); c1 = __builtin_readcyclecounter(); p.dbgbuf[8] = (unsigned)(s1 - s0); }
+                if (prof) { asm volatile("" :: "v"(acc0), "v"(acc1)); const unsigned long long tm = __builtin_readcyclecounter(); pc[2] += tm - tq[2]; tq[2] = tm; }
                 s0 = s1;
                 // rows = nodes, columns = (component d, term tt): fold the 4 terms of each component
                 const int crx = ckey >> 6, cry = (ckey >> 3) & 7, crz = ckey & 7;
@@ -455,24 +455,23 @@ __global__ __launch_bounds__(512) void k_p2g(DP p, float dt) {
                     val = tt == 1 ? v[1] : val;
                     val = tt == 2 ? v[2] : val;
                     val = tt == 3 ? v[3] : val;
-                    if (stamp && t == 1) { asm volatile("" :: "v"(val)); c2 = __builtin_readcyclecounter(); }
-                    if (delta[t] >= 0 && !(p.dbg & 16)) lds_add_fixed(tb + delta[t], val, fscale);
+                    if (delta[t] >= 0 && !(diag_flags(p) & 16)) lds_add_fixed(tb + delta[t], val, fscale);
                 }
-                if (stamp) {
-                    c3 = __builtin_readcyclecounter();
-                    if (lane == 0) { p.dbgbuf[9] = c1 - c0; p.dbgbuf[10] = c2 - c1; p.dbgbuf[11] = c3 - c2; }
-                }
+                if (prof) pc[3] += __builtin_readcyclecounter() - tq[2];
             }
-            if (prof && lane == 0) {
-                atomicAdd(&p.dbgbuf[0], n_cells);
-                atomicAdd(&p.dbgbuf[1], n_steps);
-                atomicAdd(&p.dbgbuf[2], (unsigned long long)__builtin_readcyclecounter() - t_begin);
-                atomicAdd(&p.dbgbuf[3], 1ull);
+            if (prof) {
+                const unsigned long long te = __builtin_readcyclecounter();
+                pc[0] += tq[1] - tq[0];   // derive + group + stage
+                pc[1] += te - tq[1];      // contraction phase
+                pc[6] += 1;
             }
             // the next group's staging writes must not overtake this group's reads
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
         }
+        if (prof) pc[7] = __builtin_readcyclecounter() - tb0;  // whole block, before the final barrier + slab
+        if (prof && lane == 0)
+            for (int q = 0; q < 8; ++q) atomicAdd(&p.dbgbuf[q], pc[q]);
         if (mymask) atomicOr(&s_mask, mymask);
         if (__ballot(soft) && lane == 0) atomicOr(&ctl->need_rebuild, 1);
         if (__ballot(hard) && lane == 0) atomicOr(&ctl->error, ERR_DRIFT);
@@ -484,6 +483,10 @@ __global__ __launch_bounds__(512) void k_p2g(DP p, float dt) {
                                  (float)((double)q[2] * p.unfix_p), (float)((double)q[3] * p.unfix_m));
         }
         if (tid == 0) p.slab_mask[h] = s_mask;
+        if ((diag_flags(p) & 4) && tid == 0) {
+            atomicAdd(&p.dbgbuf[12], (unsigned long long)__builtin_readcyclecounter() - tb0);
+            atomicAdd(&p.dbgbuf[13], 1ull);
+        }
     }
 }
 
@@ -602,26 +605,39 @@ MPM_DEV void load_tile(const DP& p, unsigned h, float4* tile, const float4* fiel
     }
 }
 
-MPM_DEV void g2p_particle(const DP& p, const PSet& S, const float4* tile, int i, int ox, int oy, int oz, float dt) {
+MPM_DEV void g2p_particle(const DP& p, const PSet& S, const float4* tile, unsigned i, int ox, int oy, int oz, float dt) {
+    __builtin_assume(i < (1u << 28));  // 4 * i fits 32 bits: scalar base + 32-bit offset addressing
     const float x = S.x[0][i], y = S.x[1][i], z = S.x[2][i];
     const Stencil st = make_stencil(p, x, y, z, ox, oy, oz);
     float nv[3] = {0.f, 0.f, 0.f}, nC[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     const float4* base = tile + ((st.rx * TILE_W + st.ry) * TILE_W + st.rz);
+    // one z-row of the stencil (3 nodes) at a time: keeping all 27 node loads in flight costs
+    // ~200 VGPRs; the workgroup count per CU matters more than the load depth here
+#pragma unroll 1
+    for (int ab = (diag_flags(p) & 512) ? 8 : 0; ab < 9; ++ab) {
+        const int a = ab / 3, b = ab - 3 * a;
+        const float wa = a == 0 ? st.wx[0] : (a == 1 ? st.wx[1] : st.wx[2]);
+        const float wb = b == 0 ? st.wy[0] : (b == 1 ? st.wy[1] : st.wy[2]);
+        const float wab = wa * wb;
+        const float d0 = (float)a - st.fx[0], d1 = (float)b - st.fx[1];
+        const float4* row = base + (a * TILE_W + b) * TILE_W;
+        const float4 g0 = row[0], g1 = row[1], g2 = row[2];
+        const float4 gq[3] = {g0, g1, g2};
 #pragma unroll
-    for (int a = 0; a < 3; ++a)
-#pragma unroll
-        for (int b = 0; b < 3; ++b)
-#pragma unroll
-            for (int c = 0; c < 3; ++c) {
-                const float4 g = base[(a * TILE_W + b) * TILE_W + c];
-                const float w = st.wx[a] * st.wy[b] * st.wz[c];
-                const float d0 = (float)a - st.fx[0], d1 = (float)b - st.fx[1], d2 = (float)c - st.fx[2];
-                const float wv0 = w * g.x, wv1 = w * g.y, wv2 = w * g.z;
-                nv[0] += wv0; nv[1] += wv1; nv[2] += wv2;
-                nC[0] += wv0 * d0; nC[1] += wv0 * d1; nC[2] += wv0 * d2;
-                nC[3] += wv1 * d0; nC[4] += wv1 * d1; nC[5] += wv1 * d2;
-                nC[6] += wv2 * d0; nC[7] += wv2 * d1; nC[8] += wv2 * d2;
-            }
+        for (int c = 0; c < 3; ++c) {
+            const float w = wab * st.wz[c];
+            const float d2 = (float)c - st.fx[2];
+            const float wv0 = w * gq[c].x, wv1 = w * gq[c].y, wv2 = w * gq[c].z;
+            nv[0] += wv0; nv[1] += wv1; nv[2] += wv2;
+            nC[0] += wv0 * d0; nC[1] += wv0 * d1; nC[2] += wv0 * d2;
+            nC[3] += wv1 * d0; nC[4] += wv1 * d1; nC[5] += wv1 * d2;
+            nC[6] += wv2 * d0; nC[7] += wv2 * d1; nC[8] += wv2 * d2;
+        }
+    }
+    if (diag_flags(p) & 256) {  // ablation: no stores
+        if (nv[0] + nC[0] + nC[4] + nC[8] == 1.2345e30f) S.v[0][i] = nv[0];
+        return;
+    }
     const float sc = 4.f * p.dxinv;
     const float ca = (p.M.V + 1.f) * .5f, cb = (p.M.V - 1.f) * .5f;
 #pragma unroll
@@ -634,7 +650,8 @@ MPM_DEV void g2p_particle(const DP& p, const PSet& S, const float4* tile, int i,
     S.x[2][i] = z + nv[2] * dt;
 }
 
-__global__ __launch_bounds__(512) void k_g2p(DP p, float dt) {
+constexpr int G2P_THREADS = 512;
+__global__ __launch_bounds__(G2P_THREADS) void k_g2p(DP p, float dt) {
     __shared__ float4 tile[TILE_N];
     const Ctl* ctl = p.ctl;
     const PSet& S = p.set[ctl->cur];
@@ -648,14 +665,28 @@ __global__ __launch_bounds__(512) void k_g2p(DP p, float dt) {
         __syncthreads();
         if (s_h >= n_home) break;
         const unsigned h = p.home_order[s_h];
-        load_tile(p, h, tile, p.gv, 512);
+        const bool prof = (diag_flags(p) & 4) != 0;
+        unsigned long long t0 = 0, t1 = 0;
+        if (prof) t0 = __builtin_readcyclecounter();
+        load_tile(p, h, tile, p.gv, G2P_THREADS);
         __syncthreads();
+        if (prof) t1 = __builtin_readcyclecounter();
         int bx, by, bz;
         block_coords(p.home_block[h], bx, by, bz);
         const int ox = bx * 4 - FREE_ZONE, oy = by * 4 - FREE_ZONE, oz = bz * 4 - FREE_ZONE;
         const int4 rg = p.home_range[h];
-        for (int i = rg.x + (int)threadIdx.x; i < rg.y; i += 512) g2p_particle(p, S, tile, i, ox, oy, oz, dt);
-        for (int i = rg.z + (int)threadIdx.x; i < rg.w; i += 512) g2p_particle(p, S, tile, i, ox, oy, oz, dt);
+        // faces then vertices as one index space: a single copy of the (large) particle body
+        const int nfb = rg.y - rg.x, total = nfb + (rg.w - rg.z);
+#pragma unroll 1
+        for (int u = (int)threadIdx.x; u < total; u += G2P_THREADS)
+            g2p_particle(p, S, tile, (unsigned)(u < nfb ? rg.x + u : rg.z + (u - nfb)), ox, oy, oz, dt);
+        if (prof && (threadIdx.x & 63) == 0) {
+            const unsigned long long t2 = __builtin_readcyclecounter();
+            atomicAdd(&p.dbgbuf[8], t1 - t0);
+            atomicAdd(&p.dbgbuf[9], t2 - t1);
+            atomicAdd(&p.dbgbuf[10], (unsigned long long)((total + G2P_THREADS - 1) / G2P_THREADS));
+            atomicAdd(&p.dbgbuf[11], 1ull);
+        }
     }
 }
 

@@ -16,3 +16,4 @@ print("per substep: cells", c[0]/10, "steps", c[1]/10, "wave-phase cycles", c[2]
 print("cycles per wave-chunk", c[2]/max(c[3],1), "steps per wave-chunk", c[1]/max(c[3],1), "cells per wave-chunk", c[0]/max(c[3],1))
 
 print("stamps: particles", c[8], "steps-cycles", c[9], "epilogue-cycles", c[10], "atomics-cycles", c[11])
+print("g2p: tile-load cycles/wave-block", c[4]/max(c[7],1), "particle-loop cycles/wave-block", c[5]/max(c[7],1), "iterations/block", c[6]/max(c[7],1), "wave-blocks per substep", c[7]/10)
