@@ -83,23 +83,40 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     from drake_amd import GpuMpm, scenes
+    from drake_amd.dist import HaloChain
     bits, layers, res = scenes.CONFIGS[args.config]
     dt = 1e-3
     g = GpuMpm(bits, device=local_rank)
-    # every rank owns one full copy of the workload (weak scaling: per-GPU work is fixed)
+    # Weak scaling: every rank owns one 1M-particle cloth stack.  The ranks' patches sit side by
+    # side along x (rank r's local frame is shifted by r * 0.5), so neighbouring stacks share grid
+    # nodes around the cut and exchange them every substep (drake_amd/dist.py).
     scenes.populate(g, scenes.cloth_stack(layers, res, bits, seed=1234 + rank))
     nv, nf, npart = g.n_verts, g.n_faces, g.n_particles
+    nb = (1 << bits) // 4
+    chain = None
+    stream = torch.cuda.Stream()
+    if world > 1:
+        g.set_stream(stream.cuda_stream)  # kernels and RCCL transfers ordered on one stream
+        chain = HaloChain(g, rank, world, cut_lo_block=nb // 4, cut_hi_block=3 * nb // 4, pitch_blocks=nb // 2,
+                          zone_blocks=2, capacity_blocks=512, device=torch.device("cuda", local_rank))
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    g.run_substeps(args.warmup, dt, -1)
+    def run(n):
+        if chain is None:
+            g.run_substeps(n, dt, -1)
+        else:
+            with torch.cuda.stream(stream):
+                chain.run_substeps(n, dt, -1)
+
+    run(args.warmup)
     g.gpu_sync()
     barrier()
     t0 = time.perf_counter()
-    g.run_substeps(args.steps, dt, -1)
+    run(args.steps)
     g.gpu_sync()
     barrier()
     el = time.perf_counter() - t0
@@ -129,7 +146,7 @@ def main():
                    config=dict(workload=f"{args.config}: {npart} particles ({nf} faces + {nv} vertices), "
                                         f"{1 << bits}^3 grid, corotated cloth, no contact, dt={dt}",
                                particles_per_gpu=npart, grid=f"{1 << bits}^3", touched_blocks=st["touched_blocks"],
-                               rebuilds=st["rebuilds"], parallelism=f"replicated x{world}"),
+                               rebuilds=st["rebuilds"], parallelism=("single GPU" if world == 1 else f"{world} GPUs: x-tiled patches, 1 rank/GPU, RCCL halo of grid-block sums per substep")),
                    roofline=roofline)
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(bits, layers, res, dt, args.cpu_budget)

@@ -52,7 +52,9 @@ SYMBOLS = [
     "mpm_external_body_force_to_host", "mpm_rebuild_mapping", "mpm_calc_fem_state_and_force", "mpm_particle_to_grid",
     "mpm_update_grid", "mpm_grid_to_particle", "mpm_sync", "mpm_sync_particle_state_to_cpu", "mpm_dump_obj",
     "mpm_copy_contact_pairs", "mpm_update_contact", "mpm_set_dump_dir", "mpm_substep", "mpm_run_substeps",
-    "mpm_profile_substeps", "mpm_set_stream", "mpm_get_stats", "mpm_debug_counters", "mpm_download_array", "mpm_upload_particle_state",
+    "mpm_profile_substeps", "mpm_set_stream", "mpm_get_stats", "mpm_debug_counters", "mpm_grid_gather",
+    "mpm_halo_buffer_bytes", "mpm_halo_pack", "mpm_halo_add", "mpm_update_grid_from_sums", "mpm_substep_begin",
+    "mpm_substep_end", "mpm_download_array", "mpm_upload_particle_state",
 ]
 
 
@@ -99,6 +101,12 @@ def load_library(build: bool = True):
         "mpm_profile_substeps": [vp, i, f, i, P(f), P(f)],
         "mpm_set_stream": [vp, vp],
         "mpm_get_stats": [vp, P(Stats)],
+        "mpm_grid_gather": [vp],
+        "mpm_halo_pack": [vp, i, i, i, vp, sz],
+        "mpm_halo_add": [vp, vp, sz],
+        "mpm_update_grid_from_sums": [vp, i],
+        "mpm_substep_begin": [vp, f],
+        "mpm_substep_end": [vp, f, i],
         "mpm_debug_counters": [vp, P(C.c_uint64), i],
         "mpm_download_array": [vp, i, vp, sz, P(sz)],
         "mpm_upload_particle_state": [vp, vp, vp, vp, vp, vp],
@@ -107,6 +115,8 @@ def load_library(build: bool = True):
         fn = getattr(lib, name)
         fn.argtypes = args
         fn.restype = C.c_int
+    lib.mpm_halo_buffer_bytes.argtypes = [sz]
+    lib.mpm_halo_buffer_bytes.restype = sz
     _LIB = lib
     return lib
 
@@ -246,6 +256,28 @@ class GpuMpm:
         tot = C.c_float()
         self._ck(self.lib.mpm_profile_substeps(self.h, n, dt, mpm_bc, ph, C.byref(tot)))
         return {k: float(ph[i]) for i, k in enumerate(PHASES)}, float(tot.value)
+
+    # ---- multi-GPU halo (see drake_amd/dist.py) --------------------------------
+    def grid_gather(self):
+        self._ck(self.lib.mpm_grid_gather(self.h))
+
+    def halo_buffer_bytes(self, capacity_blocks: int) -> int:
+        return int(self.lib.mpm_halo_buffer_bytes(capacity_blocks))
+
+    def halo_pack(self, bx_lo: int, bx_hi: int, shift_bx: int, dev_ptr: int, capacity_blocks: int):
+        self._ck(self.lib.mpm_halo_pack(self.h, bx_lo, bx_hi, shift_bx, C.c_void_p(dev_ptr), capacity_blocks))
+
+    def halo_add(self, dev_ptr: int, capacity_blocks: int):
+        self._ck(self.lib.mpm_halo_add(self.h, C.c_void_p(dev_ptr), capacity_blocks))
+
+    def substep_begin(self, dt: float):
+        self._ck(self.lib.mpm_substep_begin(self.h, dt))
+
+    def substep_end(self, dt: float, mpm_bc: int = -1):
+        self._ck(self.lib.mpm_substep_end(self.h, dt, mpm_bc))
+
+    def update_grid_from_sums(self, mpm_bc: int = -1):
+        self._ck(self.lib.mpm_update_grid_from_sums(self.h, mpm_bc))
 
     def set_stream(self, stream_handle: int | None):
         self._ck(self.lib.mpm_set_stream(self.h, C.c_void_p(stream_handle) if stream_handle else None))

@@ -352,6 +352,62 @@ int mpm_update_grid(mpm_handle_t e, int bc) {
     return 0;
 }
 
+int mpm_grid_gather(mpm_handle_t e) {
+    READY(e);
+    REQUIRE(e->grid_state >= 1, "grid gather before ParticleToGrid");
+    hipLaunchKernelGGL(k_grid<0>, dim3(e->g_grid), dim3(256), 0, e->stream, e->dp, -1);
+    e->grid_state = 3;  // raw sums in gv
+    return 0;
+}
+
+size_t mpm_halo_buffer_bytes(size_t cap) { return (((4 + cap) * 4 + 15) / 16) * 16 + cap * 64 * 16; }
+
+int mpm_halo_pack(mpm_handle_t e, int bx_lo, int bx_hi, int shift_bx, void* dev_buf, size_t cap) {
+    READY(e);
+    REQUIRE(e->grid_state == 3, "halo pack needs mpm_grid_gather first");
+    REQUIRE(dev_buf && cap > 0 && cap < (1u << 24), "bad halo buffer");
+    HIP_TRY(hipMemsetAsync(dev_buf, 0, 16, e->stream));
+    hipLaunchKernelGGL(k_halo_pack, dim3(e->g_grid), dim3(256), 0, e->stream, e->dp, bx_lo, bx_hi, shift_bx,
+                       (unsigned)cap, (uint32_t*)dev_buf);
+    return 0;
+}
+
+int mpm_halo_add(mpm_handle_t e, const void* dev_buf, size_t cap) {
+    READY(e);
+    REQUIRE(e->grid_state == 3, "halo add needs mpm_grid_gather first");
+    REQUIRE(dev_buf && cap > 0, "bad halo buffer");
+    hipLaunchKernelGGL(k_halo_add, dim3(64), dim3(256), 0, e->stream, e->dp, (unsigned)cap, (const uint32_t*)dev_buf);
+    return 0;
+}
+
+int mpm_update_grid_from_sums(mpm_handle_t e, int bc) {
+    READY(e);
+    REQUIRE(e->grid_state == 3, "needs mpm_grid_gather first");
+    hipLaunchKernelGGL(k_grid<2>, dim3(e->g_grid), dim3(256), 0, e->stream, e->dp, bc);
+    e->grid_state = 2;
+    return 0;
+}
+
+int mpm_substep_begin(mpm_handle_t e, float dt) {
+    READY(e);
+    launch_rebuild(e);
+    launch_fem(e, dt);
+    launch_p2g(e, dt);
+    hipLaunchKernelGGL(k_grid<0>, dim3(e->g_grid), dim3(256), 0, e->stream, e->dp, -1);
+    e->grid_state = 3;
+    return 0;
+}
+
+int mpm_substep_end(mpm_handle_t e, float dt, int bc) {
+    READY(e);
+    REQUIRE(e->grid_state == 3, "mpm_substep_end without mpm_substep_begin");
+    hipLaunchKernelGGL(k_grid<2>, dim3(e->g_grid), dim3(256), 0, e->stream, e->dp, bc);
+    e->grid_state = 2;
+    launch_g2p(e, dt);
+    e->substeps += 1;
+    return 0;
+}
+
 int mpm_grid_to_particle(mpm_handle_t e, float dt) {
     READY(e);
     REQUIRE(e->grid_state == 2, "GridToParticle before UpdateGrid");

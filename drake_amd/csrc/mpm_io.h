@@ -219,6 +219,8 @@ static int download_grid(mpm_engine* e, int which, void* out, size_t bytes, size
     } else if (which == MPM_ARR_GRID_DIR) {
         REQUIRE(e->cb.n > 0 && e->grid_state == 2, "grid_Dir is only defined after UpdateContact");
         return fail(MPM_ERR_INVALID, "grid_Dir download not available");
+    } else if (e->grid_state == 3) {
+        // raw sums already gathered (multi-GPU path)
     } else if (e->grid_state == 1) {
         // state right after ParticleToGrid: raw sums (mass, momentum)
         hipLaunchKernelGGL(k_grid<0>, dim3(e->g_grid), dim3(256), 0, e->stream, p, -1);

@@ -493,9 +493,10 @@ __global__ __launch_bounds__(512) void k_p2g(DP p, float dt) {
 // ---------------------------------------------------------------------------
 // Grid: per active block, sum the overlapping tiles (fixed order => the grid is
 // a pure function of the slabs, no float atomics), then the explicit update.
-// MODE 0: store raw sums (mvx,mvy,mvz,m) -- only used to expose the state
-//         "after ParticleToGrid" to mpm_download_array.
-// MODE 1: v = mv/m, walls, analytic colliders per mpm_bc, store v and v*.
+// MODE 0: store raw sums (mvx,mvy,mvz,m): the state "after ParticleToGrid" (mpm_download_array)
+//         and the payload of the multi-GPU halo exchange.
+// MODE 1: gather + v = mv/m, walls, analytic colliders per mpm_bc, store v and v*.
+// MODE 2: like 1 but starting from the raw sums already in gv (after neighbours' sums were added).
 // ---------------------------------------------------------------------------
 MPM_DEV bool sphere_sdf(const float* pos, float cx, float cy, float cz, float r, float* n) {
     const float d0 = pos[0] - cx, d1 = pos[1] - cy, d2 = pos[2] - cz;
@@ -515,8 +516,9 @@ __global__ __launch_bounds__(256) void k_grid(DP p, int bc) {
     for (unsigned a = blockIdx.x * 4 + (tid >> 6); a < n_active; a += gridDim.x * 4) {
         const int* nbr = p.act_nbr_home + (size_t)a * 27;
         float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (MODE == 2) s = p.gv[(size_t)a * 64 + cell];
 #pragma unroll
-        for (int o = 0; o < 27; ++o) {
+        for (int o = 0; o < (MODE == 2 ? 0 : 27); ++o) {
             const int h = nbr[o];   // wave-uniform
             if (h < 0) continue;
             // this block seen from the home block is at offset -o
@@ -605,9 +607,8 @@ MPM_DEV void load_tile(const DP& p, unsigned h, float4* tile, const float4* fiel
     }
 }
 
-MPM_DEV void g2p_particle(const DP& p, const PSet& S, const float4* tile, unsigned i, int ox, int oy, int oz, float dt) {
-    __builtin_assume(i < (1u << 28));  // 4 * i fits 32 bits: scalar base + 32-bit offset addressing
-    const float x = S.x[0][i], y = S.x[1][i], z = S.x[2][i];
+MPM_DEV void g2p_particle(const DP& p, const PSet& S, const float4* tile, unsigned i, float x, float y, float z,
+                             int ox, int oy, int oz, float dt) {
     const Stencil st = make_stencil(p, x, y, z, ox, oy, oz);
     float nv[3] = {0.f, 0.f, 0.f}, nC[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     const float4* base = tile + ((st.rx * TILE_W + st.ry) * TILE_W + st.rz);
@@ -668,18 +669,32 @@ __global__ __launch_bounds__(G2P_THREADS) void k_g2p(DP p, float dt) {
         const bool prof = (diag_flags(p) & 4) != 0;
         unsigned long long t0 = 0, t1 = 0;
         if (prof) t0 = __builtin_readcyclecounter();
+        const int4 rg = p.home_range[h];
+        // faces then vertices as one index space: a single copy of the (large) particle body
+        const int nfb = rg.y - rg.x, total = nfb + (rg.w - rg.z);
+        auto slot_of = [&](int u) { return (unsigned)(u < nfb ? rg.x + u : rg.z + (u - nfb)); };
+        // the first positions are requested before the tile is staged, later ones one iteration
+        // ahead, so the HBM latency of the particle stream hides behind LDS work
+        int u = (int)threadIdx.x;
+        unsigned i = slot_of(u < total ? u : 0);
+        float px = S.x[0][i], py = S.x[1][i], pz = S.x[2][i];
         load_tile(p, h, tile, p.gv, G2P_THREADS);
         __syncthreads();
         if (prof) t1 = __builtin_readcyclecounter();
         int bx, by, bz;
         block_coords(p.home_block[h], bx, by, bz);
         const int ox = bx * 4 - FREE_ZONE, oy = by * 4 - FREE_ZONE, oz = bz * 4 - FREE_ZONE;
-        const int4 rg = p.home_range[h];
-        // faces then vertices as one index space: a single copy of the (large) particle body
-        const int nfb = rg.y - rg.x, total = nfb + (rg.w - rg.z);
 #pragma unroll 1
-        for (int u = (int)threadIdx.x; u < total; u += G2P_THREADS)
-            g2p_particle(p, S, tile, (unsigned)(u < nfb ? rg.x + u : rg.z + (u - nfb)), ox, oy, oz, dt);
+        for (; u < total; u += G2P_THREADS) {
+            const unsigned ci = i;
+            const float cx = px, cy = py, cz = pz;
+            const int un = u + G2P_THREADS;
+            if (un < total) {
+                i = slot_of(un);
+                px = S.x[0][i]; py = S.x[1][i]; pz = S.x[2][i];
+            }
+            g2p_particle(p, S, tile, ci, cx, cy, cz, ox, oy, oz, dt);
+        }
         if (prof && (threadIdx.x & 63) == 0) {
             const unsigned long long t2 = __builtin_readcyclecounter();
             atomicAdd(&p.dbgbuf[8], t1 - t0);
@@ -687,6 +702,54 @@ __global__ __launch_bounds__(G2P_THREADS) void k_g2p(DP p, float dt) {
             atomicAdd(&p.dbgbuf[10], (unsigned long long)((total + G2P_THREADS - 1) / G2P_THREADS));
             atomicAdd(&p.dbgbuf[11], 1ull);
         }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Multi-GPU halo: ranks tile the domain along x, each with its own engine and local grid.  After
+// the local gather (k_grid<0>) a rank packs the raw node sums of its active blocks in the layers
+// next to a cut, relabelled into the neighbour's block coordinates; the neighbour adds them to
+// its own sums (k_halo_add) and both then run the same grid update (k_grid<2>) on shared blocks.
+// Buffer: [0] count, [4..) block ids (cap), then cap * 64 float4.
+// ---------------------------------------------------------------------------
+MPM_DEV size_t halo_ids_offset() { return 4; }                       // in uint32 units
+MPM_DEV size_t halo_data_offset(unsigned cap) { return ((size_t)(4 + cap) * 4 + 15) / 16; }  // in float4 units
+
+__global__ __launch_bounds__(256) void k_halo_pack(DP p, int bx_lo, int bx_hi, int shift_bx, unsigned cap,
+                                                   uint32_t* buf) {
+    const unsigned n_active = p.ctl->n_active;
+    float4* data = reinterpret_cast<float4*>(buf) + halo_data_offset(cap);
+    for (unsigned a = blockIdx.x * 4 + (threadIdx.x >> 6); a < n_active; a += gridDim.x * 4) {
+        int bx, by, bz;
+        block_coords(p.act_block[a], bx, by, bz);
+        if (bx < bx_lo || bx > bx_hi) continue;   // wave-uniform
+        const int nbx = bx + shift_bx;
+        if (nbx < 0 || nbx >= p.nb) continue;
+        unsigned slot = 0;
+        if ((threadIdx.x & 63) == 0) slot = atomicAdd(&buf[0], 1u);
+        slot = __builtin_amdgcn_readfirstlane(slot);
+        if (slot >= cap) {
+            if ((threadIdx.x & 63) == 0) atomicOr(&p.ctl->error, ERR_CAPACITY);
+            continue;
+        }
+        if ((threadIdx.x & 63) == 0) buf[halo_ids_offset() + slot] = block_id((uint32_t)nbx, (uint32_t)by, (uint32_t)bz);
+        data[(size_t)slot * 64 + (threadIdx.x & 63)] = p.gv[(size_t)a * 64 + (threadIdx.x & 63)];
+    }
+}
+
+__global__ __launch_bounds__(256) void k_halo_add(DP p, unsigned cap, const uint32_t* buf) {
+    const unsigned n = min(buf[0], cap);
+    const float4* data = reinterpret_cast<const float4*>(buf) + halo_data_offset(cap);
+    for (unsigned e = blockIdx.x * 4 + (threadIdx.x >> 6); e < n; e += gridDim.x * 4) {
+        const uint32_t id = buf[halo_ids_offset() + e];
+        if (id >= p.nblocks) continue;
+        const int a = p.lut_act[id];
+        if (a < 0) continue;  // nothing of ours reaches that block
+        const size_t g = (size_t)a * 64 + (threadIdx.x & 63);
+        const float4 r = data[(size_t)e * 64 + (threadIdx.x & 63)];
+        float4 q = p.gv[g];
+        q.x += r.x; q.y += r.y; q.z += r.z; q.w += r.w;
+        p.gv[g] = q;
     }
 }
 

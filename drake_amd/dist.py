@@ -1,0 +1,99 @@
+"""Multi-GPU layer: ranks tile the domain along x.
+
+Every rank owns one engine (one GPU) with its own local grid.  Rank r's local block coordinate
+bx corresponds to bx - pitch_blocks on rank r+1: the patches are `pitch_blocks` apart, the local
+grids overlap around each cut.  Per substep the only exchange is the raw node sums (mass,
+momentum) of the active blocks in `zone_blocks` layers either side of a cut, sent to the
+neighbour in ITS block coordinates; both sides then run the same grid update on the shared
+blocks, so no second exchange is needed.
+
+Transport: torch.distributed point-to-point.  With the "nccl" backend (= RCCL over xGMI) the
+buffers are device tensors and the engine runs on torch's current stream, so nothing
+synchronises with the host.  With "gloo" (CPU tests, or two ranks sharing one GPU in the GPU
+test) the buffers are staged through host memory.
+
+Particles never change owner here: a scene must keep each rank's particles within
+`zone_blocks` layers of its own patch (true for the benchmark scenes, which move along z).
+"""
+from __future__ import annotations
+
+import torch
+import torch.distributed as dist
+
+
+class HaloChain:
+    def __init__(self, engine, rank: int, world: int, cut_lo_block: int, cut_hi_block: int, pitch_blocks: int,
+                 zone_blocks: int = 2, capacity_blocks: int = 512, device: torch.device | None = None,
+                 group=None):
+        """cut_lo_block / cut_hi_block: local x block index of the first block at/after the left /
+        right cut plane (e.g. patch x in [0.25, 0.75] on 128^3 -> 8 and 24)."""
+        self.e, self.rank, self.world, self.group = engine, rank, world, group
+        self.cap = capacity_blocks
+        self.left = rank - 1 if rank > 0 else None
+        self.right = rank + 1 if rank < world - 1 else None
+        self.zone_lo = (cut_lo_block - zone_blocks, cut_lo_block + zone_blocks - 1)
+        self.zone_hi = (cut_hi_block - zone_blocks, cut_hi_block + zone_blocks - 1)
+        self.pitch = pitch_blocks
+        backend = dist.get_backend(group) if world > 1 else "none"
+        self.staged = backend != "nccl"
+        self.device = device if device is not None else torch.device("cpu")
+        nbytes = engine.halo_buffer_bytes(capacity_blocks)
+        mk = lambda: torch.zeros(nbytes, dtype=torch.uint8, device=self.device)
+        self.send = {n: mk() for n in (self.left, self.right) if n is not None}
+        self.recv = {n: mk() for n in (self.left, self.right) if n is not None}
+        if self.staged:
+            self.h_send = {n: torch.zeros(nbytes, dtype=torch.uint8).pin_memory() if self.device.type == "cuda"
+                           else None for n in self.send}
+            self.h_recv = {n: torch.zeros(nbytes, dtype=torch.uint8) for n in self.recv}
+
+    # -- one exchange: pack -> send/recv -> add ------------------------------------
+    def exchange(self):
+        if self.world == 1:
+            return
+        e = self.e
+        if self.left is not None:   # my left zone, relabelled into the left neighbour's coordinates
+            e.halo_pack(self.zone_lo[0], self.zone_lo[1], +self.pitch, self.send[self.left].data_ptr(), self.cap)
+        if self.right is not None:
+            e.halo_pack(self.zone_hi[0], self.zone_hi[1], -self.pitch, self.send[self.right].data_ptr(), self.cap)
+        if self.staged:
+            self._exchange_staged()
+        else:
+            ops = []
+            for n in self.send:
+                ops.append(dist.P2POp(dist.isend, self.send[n], n, group=self.group))
+                ops.append(dist.P2POp(dist.irecv, self.recv[n], n, group=self.group))
+            for w in dist.batch_isend_irecv(ops):
+                w.wait()   # stream-ordered: the current stream waits, the host does not
+        for n in self.recv:
+            e.halo_add(self.recv[n].data_ptr(), self.cap)
+
+    def _exchange_staged(self):
+        cuda = self.device.type == "cuda"
+        if cuda:
+            torch.cuda.synchronize()
+        reqs = []
+        for n in self.send:
+            src = self.send[n].cpu() if cuda else self.send[n]
+            reqs.append(dist.isend(src, n, group=self.group))
+            reqs.append(dist.irecv(self.h_recv[n], n, group=self.group))
+        for r in reqs:
+            r.wait()
+        for n in self.recv:
+            self.recv[n].copy_(self.h_recv[n])
+        if cuda:
+            torch.cuda.synchronize()
+
+    # -- one substep of the whole chain ----------------------------------------------
+    def substep(self, dt: float, mpm_bc: int = -1):
+        self.e.substep_begin(dt)
+        self.exchange()
+        self.e.substep_end(dt, mpm_bc)
+
+    def run_substeps(self, n: int, dt: float, mpm_bc: int = -1):
+        for _ in range(n):
+            self.substep(dt, mpm_bc)
+
+
+def attach_engine_to_torch_stream(engine):
+    """Run the engine on torch's current stream so that RCCL transfers and kernels are ordered."""
+    engine.set_stream(torch.cuda.current_stream().cuda_stream)

@@ -44,7 +44,7 @@ def cloth_sheet(res: int, side: float, z: float, center=(0.5, 0.5)):
 
 
 def cloth_stack(layers: int, res: int, domain_bits: int, z0: float = 0.6, side: float = 0.5, seed: int = 1234,
-                jitter: float = 0.05, vel_amp: float = 0.01):
+                jitter: float = 0.05, vel_amp: float = 0.01, center=(0.5, 0.5)):
     """`layers` horizontal sheets of res x res vertices, sheet k at z0 + k*dx/2.
 
     Returns a list of (pos, vel, indices) tuples, one per sheet, ready for add_qr_cloth."""
@@ -52,7 +52,7 @@ def cloth_stack(layers: int, res: int, domain_bits: int, z0: float = 0.6, side: 
     spacing = side / res
     out = []
     for k in range(layers):
-        pos, idx = cloth_sheet(res, side, z0 + k * dx * 0.5)
+        pos, idx = cloth_sheet(res, side, z0 + k * dx * 0.5, center)
         n = pos.shape[0]
         j = np.stack([hash_uniform(seed, n, 6 * k + c) for c in range(3)], -1)
         v = np.stack([hash_uniform(seed, n, 6 * k + 3 + c) for c in range(3)], -1)

@@ -218,6 +218,30 @@ MPM_API int mpm_run_substeps(mpm_handle_t h, int n, float dt, int mpm_bc);
  * (phase_ms[MPM_PHASE_COUNT]) and of the whole substep. */
 MPM_API int mpm_profile_substeps(mpm_handle_t h, int n, float dt, int mpm_bc, float *phase_ms, float *total_ms);
 
+/* ---- multi-GPU: one engine per GPU, domains tiled along x ------------------
+ * Each rank runs its own engine on its own local grid; neighbouring ranks' grids overlap in a
+ * few block layers next to the cut.  Per substep, between mpm_particle_to_grid and the grid
+ * update:  mpm_grid_gather -> mpm_halo_pack (one buffer per neighbour) -> exchange the buffers
+ * (RCCL send/recv on the same stream, done by the caller) -> mpm_halo_add for every received
+ * buffer -> mpm_update_grid_from_sums.  Nothing here synchronises with the host.
+ * The reference has no multi-GPU path (settings.h:40 G_DEVICE_COUNT = 1); this is new surface. */
+
+/* Raw node sums (mass, momentum) of all active blocks, without the update. */
+MPM_API int mpm_grid_gather(mpm_handle_t h);
+/* Size in bytes of a halo buffer for `capacity_blocks` blocks. */
+MPM_API size_t mpm_halo_buffer_bytes(size_t capacity_blocks);
+/* Packs the sums of the active blocks whose x block coordinate is in [bx_lo, bx_hi] into
+ * dev_buf (device memory), relabelled by shift_bx blocks (the neighbour's local coordinates). */
+MPM_API int mpm_halo_pack(mpm_handle_t h, int bx_lo, int bx_hi, int shift_bx, void *dev_buf, size_t capacity_blocks);
+/* Adds a neighbour's packed sums to the local ones (blocks that are not active here are skipped). */
+MPM_API int mpm_halo_add(mpm_handle_t h, const void *dev_buf, size_t capacity_blocks);
+/* UpdateGrid (cuda_mpm_solver.cu:107-151) on sums that already include the neighbours'. */
+MPM_API int mpm_update_grid_from_sums(mpm_handle_t h, int mpm_bc);
+/* The two halves of a multi-GPU substep: RebuildMapping + CalcFemStateAndForce + ParticleToGrid +
+ * mpm_grid_gather, and mpm_update_grid_from_sums + GridToParticle. */
+MPM_API int mpm_substep_begin(mpm_handle_t h, float dt);
+MPM_API int mpm_substep_end(mpm_handle_t h, float dt, int mpm_bc);
+
 /* Use a caller-provided hipStream_t (e.g. torch's current stream); NULL
  * restores the engine's own stream. */
 MPM_API int mpm_set_stream(mpm_handle_t h, void *hip_stream);
