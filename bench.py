@@ -78,9 +78,18 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     assert torch.cuda.is_available(), "bench.py needs a GPU (the engine has no CPU fallback)"
+    # "nccl" is RCCL on ROCm.  MPM_BENCH_BACKEND=gloo exists only to rehearse the multi-rank code
+    # path on a one-GPU box (ranks share the GPU, halo staged through the host).
+    backend = os.environ.get("MPM_BENCH_BACKEND", "nccl")
+    ndev = torch.cuda.device_count()
+    if world > 1 and backend == "gloo":
+        local_rank = local_rank % ndev
     torch.cuda.set_device(local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
 
     from drake_amd import GpuMpm, scenes
     from drake_amd.dist import HaloChain
@@ -121,7 +130,7 @@ def main():
     barrier()
     el = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([el], device="cuda", dtype=torch.float64)
+        t = torch.tensor([el], device="cuda" if backend == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         el = float(t.item())
     st = g.stats()
