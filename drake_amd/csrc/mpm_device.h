@@ -13,9 +13,8 @@ namespace mpm {
 constexpr int FREE_ZONE = 2;
 constexpr int TILE_W = 4 + 2 * FREE_ZONE + 2;        // 10
 constexpr int TILE_N = TILE_W * TILE_W * TILE_W;     // 1000 nodes (16 KB of float4)
-// A particle may sit up to FREE_ZONE cells outside its home block (hard limit);
-// one that is more than SOFT_ZONE cells outside asks for a re-sort.
-constexpr int SOFT_ZONE = 1;
+// A particle may sit up to FREE_ZONE cells outside its home block (hard limit); it asks for a
+// re-sort when its next substep could take it past that (soft_zone_exit in mpm_step.h).
 
 constexpr unsigned ERR_DRIFT = 1u;      // particle outside the hard free zone
 constexpr unsigned ERR_CAPACITY = 2u;   // home/active table overflow
@@ -77,6 +76,7 @@ struct DP {
     // rebuild scratch
     uint32_t* pkey;
     uint32_t* prank;
+    uint32_t* src_of;      // sorted slot -> previous slot
     int* cellcnt[2];       // [type][cell key]; zero outside a rebuild
     int* blkcnt[2];        // [type][block id]; zero outside a rebuild
     int* blkstart[2];
@@ -88,6 +88,8 @@ struct DP {
     int4* home_range;      // (face begin, face end, vertex begin, vertex end) slots
     int* home_nbr_act;     // [home][27] active slot of block + offset, or -1
     uint32_t* home_order;  // home slots, most particles first (work-queue order)
+    int* home_ngroups;     // [home] number of P2G wave groups
+    int4* home_groups;     // pool of (face begin, face end, vertex begin, vertex end) slot ranges, <= 64 particles each
     uint32_t* act_block;
     int* act_nbr_home;     // [active][27] home slot of block + offset, or -1
     // grid
@@ -103,6 +105,12 @@ struct DP {
 #define MPM_DIAG 0
 #endif
 MPM_DEV int diag_flags(const DP& p) { return MPM_DIAG ? p.dbg : 0; }
+
+// A home block with n particles has ceil(n/64) wave groups; its list starts at this pool offset
+// (blocks are laid out in slot order, so the offsets never overlap).
+MPM_DEV size_t group_pool_offset(const DP& p, const int4& range, unsigned home) {
+    return (size_t)((range.x + (range.z - p.Nf)) >> 6) + home;
+}
 
 MPM_DEV int off_index(int ox, int oy, int oz) { return (ox + 1) * 9 + (oy + 1) * 3 + (oz + 1); }
 

@@ -87,7 +87,7 @@ static void launch_rebuild(mpm_engine* e) {
     hipLaunchKernelGGL(k_rb_count, dim3(e->g_np), dim3(256), 0, e->stream, p);
     hipLaunchKernelGGL(k_rb_tables, dim3(33), dim3(1024), 0, e->stream, p);
     hipLaunchKernelGGL(k_rb_scatter, dim3(e->g_np), dim3(256), 0, e->stream, p);
-    hipLaunchKernelGGL(k_rb_finish, dim3(std::min(e->g_np, 512u)), dim3(256), 0, e->stream, p);
+    hipLaunchKernelGGL(k_rb_finish, dim3(std::min(e->g_np, 1024u)), dim3(256), 0, e->stream, p);
 }
 static void launch_fem(mpm_engine* e, float dt) {
     const DP& p = e->dp;
@@ -184,6 +184,7 @@ int mpm_finalize(mpm_handle_t e) {
     ALLOC(p.imap, np, false);
     ALLOC(p.pkey, np, false);
     ALLOC(p.prank, np, false);
+    ALLOC(p.src_of, np, false);
     for (int t = 0; t < 2; ++t) {
         ALLOC(p.cellcnt[t], p.ncells, true);
         ALLOC(p.blkcnt[t], p.nblocks, true);
@@ -198,6 +199,8 @@ int mpm_finalize(mpm_handle_t e) {
     ALLOC(p.home_range, p.capH, true);
     ALLOC(p.home_nbr_act, (size_t)p.capH * 27, true);
     ALLOC(p.home_order, p.capH, true);
+    ALLOC(p.home_ngroups, p.capH, true);
+    ALLOC(p.home_groups, np / 64 + p.capH + 2, false);
     ALLOC(p.act_block, p.capA, true);
     ALLOC(p.act_nbr_home, (size_t)p.capA * 27, true);
     ALLOC(p.slab, (size_t)p.capH * TILE_N, true);

@@ -269,49 +269,54 @@ __global__ __launch_bounds__(256) void k_rb_scatter(DP p) {
             const int nbid = neighbor_block(p.act_block[w / 27], (int)(w % 27), p.nb);
             p.act_nbr_home[w] = nbid >= 0 ? p.lut_home[nbid] : -1;
         }
+        // P2G wave groups: per home block, consecutive 64-particle windows of the merged sequence
+        // (cell 0 faces, cell 0 vertices, cell 1 faces, ...), so a group holds faces and vertices of
+        // the same ~3 cells.  Window g starts at merged position 64 g; every boundary is found
+        // independently by a binary search over the block's 64 cell prefixes.  The groups stay valid
+        // until the next rebuild (they are slot ranges, not positions).
+        {
+            const unsigned lane = threadIdx.x & 63u;
+            const unsigned wave = (unsigned)i >> 6, nwaves = gs >> 6;
+            for (unsigned h = wave; h < n_home; h += nwaves) {
+                const uint32_t b = p.home_block[h];
+                const int4 rg = p.home_range[h];
+                const int* cf = p.cellcnt[0] + (size_t)b * 64;   // exclusive prefixes at this point
+                const int* cv = p.cellcnt[1] + (size_t)b * 64;
+                const int nf = rg.y - rg.x, nv = rg.w - rg.z, total = nf + nv;
+                const int ng = (total + 63) >> 6;
+                int4* out = p.home_groups + group_pool_offset(p, rg, h);
+                // split of merged position m into (faces before it, vertices before it)
+                auto split = [&](int m, int& f, int& v) {
+                    if (m >= total) { f = nf; v = nv; return; }
+                    int lo = 0, hi = 63;                       // last cell whose start is <= m
+                    while (lo < hi) {
+                        const int mid = (lo + hi + 1) >> 1;
+                        if (cf[mid] + cv[mid] <= m) lo = mid; else hi = mid - 1;
+                    }
+                    const int fs = cf[lo], vs = cv[lo];
+                    const int fe = lo < 63 ? cf[lo + 1] : nf;
+                    const int r = m - (fs + vs);
+                    if (r < fe - fs) { f = fs + r; v = vs; } else { f = fe; v = vs + (r - (fe - fs)); }
+                };
+                for (int g = (int)lane; g < ng; g += 64) {
+                    int f0, v0, f1, v1;
+                    split(g * 64, f0, v0);
+                    split(g * 64 + 64, f1, v1);
+                    out[g] = make_int4(rg.x + f0, rg.x + f1, rg.z + v0, rg.z + v1);
+                }
+                if (lane == 0) p.home_ngroups[h] = ng;
+            }
+        }
     }
     if (i >= p.Np) return;
-    const int cur = p.ctl->cur;
-    const PSet& S = p.set[cur];
-    const PSet& D = p.set[cur ^ 1];
+    const PSet& S = p.set[p.ctl->cur];
     const uint32_t key = p.pkey[i];
     const int t = i >= p.Nf;
     const int dst = (t ? p.Nf : 0) + p.blkstart[t][key >> 6] + p.cellcnt[t][key] + (int)p.prank[i];
-    // all loads first, then all stores: the copies are independent, and issuing them as
-    // load/store pairs would serialise 42 memory round trips per thread
-    float a[16];
-    float fm[13];
-#pragma unroll
-    for (int d = 0; d < 3; ++d) {
-        a[d] = S.x[d][i];
-        a[3 + d] = S.v[d][i];
-    }
-    a[6] = S.vol[i];
-#pragma unroll
-    for (int d = 0; d < 9; ++d) a[7 + d] = S.C[d][i];
-    const int pid = S.pid[i];
-    if (!t) {
-#pragma unroll
-        for (int d = 0; d < 9; ++d) fm[d] = S.F[d][i];
-#pragma unroll
-        for (int d = 0; d < 4; ++d) fm[9 + d] = S.Dm[d][i];
-    }
-#pragma unroll
-    for (int d = 0; d < 3; ++d) {
-        D.x[d][dst] = a[d];
-        D.v[d][dst] = a[3 + d];
-    }
-    D.vol[dst] = a[6];
-#pragma unroll
-    for (int d = 0; d < 9; ++d) D.C[d][dst] = a[7 + d];
-    D.pid[dst] = pid;
-    p.imap[pid] = dst;
-    if (!t) {
-#pragma unroll
-        for (int d = 0; d < 9; ++d) D.F[d][dst] = fm[d];
-#pragma unroll
-        for (int d = 0; d < 4; ++d) D.Dm[d][dst] = fm[9 + d];
-    }
+    // only the permutation is scattered (4 bytes per particle); the particle planes are moved by
+    // k_rb_finish as a gather, whose writes are fully coalesced
+    p.src_of[dst] = (uint32_t)i;
+    p.imap[S.pid[i]] = dst;
 }
 
 // R4: refresh face -> vertex slots, re-zero the histograms, flip the sets.  Launched with a
@@ -320,15 +325,53 @@ __global__ __launch_bounds__(256) void k_rb_finish(DP p) {
     Ctl* c = p.ctl;
     if (!c->need_rebuild) return;
     const unsigned gs = gridDim.x * 256u, i0 = blockIdx.x * 256u + threadIdx.x;
+    const PSet& S = p.set[c->cur];
     const PSet& D = p.set[c->cur ^ 1];
-    for (unsigned i = i0; i < (unsigned)p.Nf; i += gs) {
-        const int pid = D.pid[i];
+    // move the particle planes into their sorted slots: all loads first, then all stores
+    for (unsigned j = i0; j < (unsigned)p.Np; j += gs) {
+        const unsigned i = p.src_of[j];
+        float a[16];
 #pragma unroll
-        for (int k = 0; k < 3; ++k) p.fv[k][i] = p.imap[p.idx_orig[k][pid]];
+        for (int d = 0; d < 3; ++d) {
+            a[d] = S.x[d][i];
+            a[3 + d] = S.v[d][i];
+        }
+        a[6] = S.vol[i];
+#pragma unroll
+        for (int d = 0; d < 9; ++d) a[7 + d] = S.C[d][i];
+        const int pid = S.pid[i];
+        const bool face = j < (unsigned)p.Nf;
+        float fm[13];
+        int fvv[3] = {0, 0, 0};
+        if (face) {
+#pragma unroll
+            for (int d = 0; d < 9; ++d) fm[d] = S.F[d][i];
+#pragma unroll
+            for (int d = 0; d < 4; ++d) fm[9 + d] = S.Dm[d][i];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) fvv[k] = p.imap[p.idx_orig[k][pid]];
+        }
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            D.x[d][j] = a[d];
+            D.v[d][j] = a[3 + d];
+        }
+        D.vol[j] = a[6];
+#pragma unroll
+        for (int d = 0; d < 9; ++d) D.C[d][j] = a[7 + d];
+        D.pid[j] = pid;
+        if (face) {
+#pragma unroll
+            for (int d = 0; d < 9; ++d) D.F[d][j] = fm[d];
+#pragma unroll
+            for (int d = 0; d < 4; ++d) D.Dm[d][j] = fm[9 + d];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) p.fv[k][j] = fvv[k];
+        }
     }
     // per vertex slot, the (face slot, corner) records of its adjacent faces
     for (unsigned k = i0; k < (unsigned)p.Nv; k += gs) {
-        const int vo = D.pid[p.Nf + k] - p.Nf;
+        const int vo = S.pid[p.src_of[p.Nf + k]] - p.Nf;
         const int e0 = p.adj_off[vo], e1 = p.adj_off[vo + 1];
         if (e1 - e0 > 8) {
             p.vadj[0][k] = -2;

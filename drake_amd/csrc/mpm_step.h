@@ -155,9 +155,15 @@ MPM_DEV float quad_perm(float v) {
 // LDS accumulation is done in 64-bit fixed point: on gfx950 a wave-wide ds_add_f32
 // costs ~190 LDS cycles per instruction (measured, scratch/lds_atomic_bench.hip)
 // against ~10 for ds_add_u64, and integer sums are exact and order independent.
-MPM_DEV void lds_add_fixed(long long* a, float v, double scale) {
-    const long long q = __double2ll_rn((double)v * scale);
-    __hip_atomic_fetch_add(reinterpret_cast<unsigned long long*>(a), (unsigned long long)q, __ATOMIC_RELAXED,
+// float -> Q-format int64 with single-precision instructions only: v * scale is exact (power of
+// two), q = hi * 2^32 + lo with hi = floor(q / 2^32) (signed) and lo in [0, 2^32).
+MPM_DEV void lds_add_fixed(long long* a, float v, float scale) {
+    const float q = v * scale;
+    const float h = floorf(q * 0x1p-32f);
+    const int hi = (int)h;
+    const unsigned lo = (unsigned)fmaf(-h, 0x1p32f, q);
+    const unsigned long long fx = ((unsigned long long)(unsigned)hi << 32) | lo;
+    __hip_atomic_fetch_add(reinterpret_cast<unsigned long long*>(a), fx, __ATOMIC_RELAXED,
                            __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
@@ -167,6 +173,22 @@ MPM_DEV void bspline_coeff(int a, bool on, float& c0, float& c1, float& c2) {
     c1 = a == 0 ? -1.5f : (a == 1 ? 2.f : -.5f);
     c2 = a == 1 ? -1.f : .5f;
     if (!on) c0 = c1 = c2 = 0.f;
+}
+
+// A re-sort is requested while every particle can still take one more substep inside its tile:
+// t = position in cells relative to the tile origin must stay in [0, TILE_W - 2) for the base cell
+// to be valid; the margin is twice the particle's current displacement per substep, at least half
+// a cell (so slow particles use almost the whole free zone, fast ones ask early).
+MPM_DEV bool soft_zone_exit(const DP& p, const float* x, const float* v, float dt, int ox, int oy, int oz) {
+    const int o[3] = {ox, oy, oz};
+    bool out = false;
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+        const float t = x[d] * p.dxinv - .5f - (float)o[d];
+        const float margin = fmaxf(2.f * fabsf(v[d]) * dt * p.dxinv, .5f);
+        out |= (t - margin < 0.f) || (t + margin >= (float)(TILE_W - 2));
+    }
+    return out;
 }
 
 struct Stencil {
@@ -189,8 +211,7 @@ MPM_DEV Stencil make_stencil(const DP& p, float x, float y, float z, int ox, int
     bspline3(s.fx[1], s.wy);
     bspline3(s.fx[2], s.wz);
     int rx = (int)bx - ox, ry = (int)by - oy, rz = (int)bz - oz;
-    const int lo_s = FREE_ZONE - SOFT_ZONE, hi_s = FREE_ZONE + 3 + SOFT_ZONE;
-    s.soft_out = rx < lo_s || ry < lo_s || rz < lo_s || rx > hi_s || ry > hi_s || rz > hi_s;
+    s.soft_out = false;  // decided by the caller that knows the velocity (soft_zone_exit)
     const int hi_h = TILE_W - 3;
     s.hard_out = rx < 0 || ry < 0 || rz < 0 || rx > hi_h || ry > hi_h || rz > hi_h;
     rx = min(max(rx, 0), hi_h);
@@ -213,7 +234,7 @@ MPM_DEV Stencil make_stencil(const DP& p, float x, float y, float z, int ox, int
     return s;
 }
 
-__global__ __launch_bounds__(512) void k_p2g(DP p, float dt) {
+__global__ __launch_bounds__(512, 4) void k_p2g(DP p, float dt) {  // <= 128 VGPRs: two workgroups per CU
     __shared__ long long tile[TILE_N * 4];  // (mvx, mvy, mvz, m) per node, fixed point
     // wave-private staging: 64 particles (+8 slack rows touched by the operand prefetch)
     __shared__ __attribute__((aligned(16))) float stage_all[8][(64 + 8) * STG];
@@ -252,7 +273,7 @@ __global__ __launch_bounds__(512) void k_p2g(DP p, float dt) {
         const int n = 16 * t + 4 * g4 + tt;
         delta[t] = n < 27 ? (((n / 9) * TILE_W + (n / 3) % 3) * TILE_W + n % 3) * 4 + dcomp : -1;
     }
-    const double fscale = dcomp == 3 ? p.fix_m : p.fix_p;
+    const float fscale = (float)(dcomp == 3 ? p.fix_m : p.fix_p);
     // rows beyond the staged particles are read (and masked) by the last step: keep them finite
     for (int k = lane; k < 8 * STG; k += 64) stage[64 * STG + k] = 0.f;
 
@@ -275,23 +296,22 @@ __global__ __launch_bounds__(512) void k_p2g(DP p, float dt) {
         unsigned mymask = 0;
         bool soft = false, hard = false;
         // Every wave streams through its own groups of <= 64 particles; no workgroup barrier inside.
-        // Group g takes the g-th slice of the block's faces AND of its vertices: both ranges are
-        // sorted by cell, so a group's faces and vertices cover (nearly) the same few cells.
-        const int nvb = total - nfb;
-        const int ngroups = (total + 61) / 62;
+        // Groups are runs of whole cells (faces and vertices of the same cells together), laid out
+        // at the last rebuild: a group usually spans two base cells.
+        const int ngroups = p.home_ngroups[h];
+        const int4* groups = p.home_groups + group_pool_offset(p, rg, h);
         struct Raw {
             float x[3], v[3], vol, C[9], aux[6];  // aux: tau factors a,b (faces) or force (vertices)
             bool act, is_face;
         };
         auto load_raw = [&](int g) {
             Raw r;
-            const int fa = (int)((long long)nfb * g / ngroups), fb = (int)((long long)nfb * (g + 1) / ngroups);
-            const int va = (int)((long long)nvb * g / ngroups), vb = (int)((long long)nvb * (g + 1) / ngroups);
-            const int gf = fb - fa, gn = gf + (vb - va);
+            const int4 gr = groups[g];
+            const int gf = gr.y - gr.x, gn = gf + (gr.w - gr.z);
             r.act = lane < gn;
             r.is_face = lane < gf;
             // unsigned index: lets the loads use the scalar-base + 32-bit-offset addressing form
-            const unsigned ii = (unsigned)(r.act ? (r.is_face ? rg.x + fa + lane : rg.z + va + (lane - gf)) : (nfb ? rg.x : rg.z));
+            const unsigned ii = (unsigned)(r.act ? (r.is_face ? gr.x + lane : gr.z + (lane - gf)) : (nfb ? rg.x : rg.z));
 #pragma unroll
             for (int d = 0; d < 3; ++d) { r.x[d] = S.x[d][ii]; r.v[d] = S.v[d][ii]; }
             r.vol = S.vol[ii];
@@ -345,14 +365,14 @@ __global__ __launch_bounds__(512) void k_p2g(DP p, float dt) {
                 }
                 Y[12] = m; Y[13] = 0.f; Y[14] = 0.f; Y[15] = 0.f;
             }
+            if (act) {
+                mymask |= st.mask27;
+                soft |= soft_zone_exit(p, cur.x, cur.v, dt, ox, oy, oz);
+                hard |= st.hard_out;
+            }
             // the raw registers are dead now: start the next group's loads, they complete while this
             // group goes through the LDS / matrix-pipe phases below (which never wait on vmcnt)
             if (g + 8 < ngroups) cur = load_raw(g + 8);
-            if (act) {
-                mymask |= st.mask27;
-                soft |= st.soft_out;
-                hard |= st.hard_out;
-            }
             if (diag_flags(p) & 2) {
                 float acc = 0.f;
 #pragma unroll
