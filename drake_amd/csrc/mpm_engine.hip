@@ -94,10 +94,7 @@ static void launch_fem(mpm_engine* e, float dt) {
     if (e->nf) hipLaunchKernelGGL(k_fem, dim3(e->g_nf), dim3(256), 0, e->stream, p, dt);
     if (e->nv) hipLaunchKernelGGL(k_vforce, dim3(e->g_nv), dim3(256), 0, e->stream, p);
 }
-// The two tile kernels pull home blocks from device-side queues and each re-arms the other's
-// queue head; when the caller repeats one of them, the head is re-armed from the host.
 static void launch_p2g(mpm_engine* e, float dt) {
-    if (e->last_tile_kernel == 1) (void)hipMemsetAsync(&e->dp.ctl->q_p2g, 0, 4, e->stream);
     hipLaunchKernelGGL(k_p2g, dim3(getenv("MPM_P2G_WGS") ? atoi(getenv("MPM_P2G_WGS")) : e->g_tile), dim3(512), 0, e->stream, e->dp, dt);
     e->last_tile_kernel = 1;
 }
@@ -105,7 +102,6 @@ static void launch_grid(mpm_engine* e, int bc) {
     hipLaunchKernelGGL(k_grid<1>, dim3(e->g_grid), dim3(256), 0, e->stream, e->dp, bc);
 }
 static void launch_g2p(mpm_engine* e, float dt) {
-    if (e->last_tile_kernel == 2) (void)hipMemsetAsync(&e->dp.ctl->q_g2p, 0, 4, e->stream);
     hipLaunchKernelGGL(k_g2p, dim3(std::min(768u, e->dp.capH)), dim3(G2P_THREADS), 0, e->stream, e->dp, dt);
     e->last_tile_kernel = 2;
 }

@@ -239,7 +239,6 @@ __global__ __launch_bounds__(512, 4) void k_p2g(DP p, float dt) {  // <= 128 VGP
     // wave-private staging: 64 particles (+8 slack rows touched by the operand prefetch)
     __shared__ __attribute__((aligned(16))) float stage_all[8][(64 + 8) * STG];
     __shared__ unsigned s_mask;
-    __shared__ unsigned s_h;
     Ctl* ctl = p.ctl;
     const PSet& S = p.set[ctl->cur];
     const unsigned n_home = ctl->n_home;
@@ -277,13 +276,12 @@ __global__ __launch_bounds__(512, 4) void k_p2g(DP p, float dt) {  // <= 128 VGP
     // rows beyond the staged particles are read (and masked) by the last step: keep them finite
     for (int k = lane; k < 8 * STG; k += 64) stage[64 * STG + k] = 0.f;
 
-    if (blockIdx.x == 0 && tid == 0) ctl->q_g2p = 0;  // re-arm the next tile kernel's queue
-    for (;;) {
-        __syncthreads();
-        if (tid == 0) s_h = atomicAdd(&ctl->q_p2g, 1u);
-        __syncthreads();
-        if (s_h >= n_home) break;
-        const unsigned h = p.home_order[s_h];
+    // Home blocks are taken round-robin from the heaviest-first order: workgroup w processes
+    // entries w, w + G, ...; with G resident workgroups that is one heavy block each plus the
+    // light tail, and it needs neither a queue atomic nor extra barriers per block.
+    for (unsigned q = blockIdx.x; q < n_home; q += gridDim.x) {
+        __syncthreads();  // the previous block's slab has been written
+        const unsigned h = p.home_order[q];
         const unsigned long long tb0 = (diag_flags(p) & 4) ? __builtin_readcyclecounter() : 0ull;
         for (int n = tid; n < TILE_N * 4; n += 512) tile[n] = 0;
         if (tid == 0) s_mask = 0;
@@ -676,16 +674,10 @@ __global__ __launch_bounds__(G2P_THREADS) void k_g2p(DP p, float dt) {
     __shared__ float4 tile[TILE_N];
     const Ctl* ctl = p.ctl;
     const PSet& S = p.set[ctl->cur];
-    Ctl* ctlw = p.ctl;
     const unsigned n_home = ctl->n_home;
-    __shared__ unsigned s_h;
-    if (blockIdx.x == 0 && threadIdx.x == 0) ctlw->q_p2g = 0;  // re-arm the P2G queue of the next substep
-    for (;;) {
-        __syncthreads();
-        if (threadIdx.x == 0) s_h = atomicAdd(&ctlw->q_g2p, 1u);
-        __syncthreads();
-        if (s_h >= n_home) break;
-        const unsigned h = p.home_order[s_h];
+    for (unsigned q = blockIdx.x; q < n_home; q += gridDim.x) {
+        __syncthreads();  // everybody is done with the previous tile
+        const unsigned h = p.home_order[q];
         const bool prof = (diag_flags(p) & 4) != 0;
         unsigned long long t0 = 0, t1 = 0;
         if (prof) t0 = __builtin_readcyclecounter();
