@@ -131,9 +131,8 @@ __global__ __launch_bounds__(256) void k_ct_init_vel(DP p, ContactDev c) {
     const int k = blockIdx.x * 256 + threadIdx.x;
     if (k >= c.n) return;
     const PSet& S = p.set[p.ctl->cur];
-    const uint32_t s = c.slot[k];
-#pragma unroll
-    for (int d = 0; d < 3; ++d) c.vel[k * 3 + d] = S.v[d][s];
+    const float4 v = S.q[1][c.slot[k]];
+    c.vel[k * 3] = v.x; c.vel[k * 3 + 1] = v.y; c.vel[k * 3 + 2] = v.z;
 }
 
 // stencil of every contact: node indices into the compact grid, fx, particle mass
@@ -149,7 +148,7 @@ __global__ __launch_bounds__(256) void k_ct_stencil(DP p, ContactDev c) {
         b[d] = min(base_cell(x, p.dxinv), hi);
         c.cfx[d * c.n + k] = x * p.dxinv - (float)b[d];
     }
-    c.cmass[k] = S.vol[c.slot[k]] * p.M.density;
+    c.cmass[k] = S.q[0][c.slot[k]].w * p.M.density;
 #pragma unroll
     for (int i = 0; i < 3; ++i)
 #pragma unroll
@@ -245,9 +244,8 @@ MPM_DEV ContactFrame contact_frame(const DP& p, const ContactDev& c, int k) {
     const PSet& S = p.set[p.ctl->cur];
     const float nh[3] = {-c.normal[k * 3], -c.normal[k * 3 + 1], -c.normal[k * 3 + 2]};
     frame_from_normal(nh, f.R);
-    const uint32_t s = c.slot[k];
-    const float v0r[3] = {S.v[0][s] - c.rigid_v[k * 3], S.v[1][s] - c.rigid_v[k * 3 + 1],
-                          S.v[2][s] - c.rigid_v[k * 3 + 2]};
+    const float4 pv = S.q[1][c.slot[k]];
+    const float v0r[3] = {pv.x - c.rigid_v[k * 3], pv.y - c.rigid_v[k * 3 + 1], pv.z - c.rigid_v[k * 3 + 2]};
     mulv3(f.R, v0r, f.v0);
     f.phi0 = -c.dist[k];
     f.mass = c.cmass[k];

@@ -20,18 +20,25 @@ constexpr unsigned ERR_DRIFT = 1u;      // particle outside the hard free zone
 constexpr unsigned ERR_CAPACITY = 2u;   // home/active table overflow
 constexpr unsigned ERR_DOMAIN = 4u;     // particle base cell outside the grid
 
-// One of the two ping-pong particle sets.  Structure of arrays: one plane per
-// component, slots [0,Nf) are face particles, [Nf,Np) vertex particles, each
-// range sorted by cell key at the last rebuild.
+// One of the two ping-pong particle sets.  Every particle is four 16-byte records in four
+// planes (one coalesced dwordx4 access per plane and wave), slots [0,Nf) are face particles,
+// [Nf,Np) vertex particles, each range sorted by cell key at the last rebuild:
+//   q[0] = (x, y, z, vol)      q[1] = (vx, vy, vz, C8)
+//   q[2] = (C0, C1, C2, C3)    q[3] = (C4, C5, C6, C7)          C row-major, as in the reference
+// Face particles carry four more records, indexed by face slot:
+//   fq[0] = (F0..F3)  fq[1] = (F4..F7)  fq[2] = (F8, Dm0, Dm1, Dm2)
+//   fq[3] = (Dm3, v0, v1, v2)   v* = slots of the three corner vertices (int bits)
 struct PSet {
-    float* x[3];
-    float* v[3];
-    float* vol;
-    float* C[9];
+    float4* q[4];
     int* pid;      // slot -> original particle id ([faces | verts] order of Finalize)
-    float* F[9];   // face slots only
-    float* Dm[4];  // face slots only
+    float4* fq[4];
 };
+
+MPM_DEV void unpack_C(const float4& q1, const float4& q2, const float4& q3, float* C) {
+    C[0] = q2.x; C[1] = q2.y; C[2] = q2.z; C[3] = q2.w;
+    C[4] = q3.x; C[5] = q3.y; C[6] = q3.z; C[7] = q3.w;
+    C[8] = q1.w;
+}
 
 // Device-resident control block; everything the host would otherwise have to
 // read back between kernels.
@@ -63,7 +70,8 @@ struct DP {
     unsigned long long* dbgbuf;  // 16 diagnostic counters (only written when dbg & 4)
     PSet set[2];
     // per-substep scratch
-    float* ab[6];          // faces: tau = a (x) b  (a = vol*P[:,2], b = F[:,2])
+    float4* ab0;           // faces: tau = a (x) b with a = vol*P[:,2], b = F[:,2]: (a0, a1, a2, b0)
+    float2* ab1;           //        (b1, b2)
     float4* G4;            // faces: G4[face slot * 3 + c] = force triple the face exerts on corner c (negated when applied)
     int* vadj[8];          // vertex slot -> up to 8 (face slot * 3 + corner) records, -1 = none, -2 in [0] = use the CSR
     float* f[3];           // vertices: internal force
@@ -72,7 +80,6 @@ struct DP {
     const int* adj_off;      // vertex (original, 0-based) -> range in adj_fc
     const int* adj_fc;       // (original face id << 2) | corner
     int* imap;               // original particle id -> slot
-    int* fv[3];              // face slot -> slots of its corner vertices
     // rebuild scratch
     uint32_t* pkey;
     uint32_t* prank;

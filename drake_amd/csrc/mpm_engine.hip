@@ -111,13 +111,13 @@ static void launch_g2p(mpm_engine* e, float dt) {
 // |v| < 2^15 length units per time unit.  Resolution: M * 2^-61 (mass), M * 2^-47 (momentum).
 static int set_fixed_point_scales(mpm_engine* e) {
     DP& p = e->dp;
-    std::vector<float> vol(e->np);
+    std::vector<float> q0(e->np * 4);
     HIP_TRY(hipStreamSynchronize(e->stream));
     Ctl c;
     HIP_TRY(hipMemcpy(&c, p.ctl, sizeof(Ctl), hipMemcpyDeviceToHost));
-    HIP_TRY(hipMemcpy(vol.data(), p.set[c.cur & 1].vol, e->np * 4, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(q0.data(), p.set[c.cur & 1].q[0], e->np * 16, hipMemcpyDeviceToHost));
     double mass = 0;
-    for (float v : vol) mass += (double)v * p.M.density;
+    for (size_t i = 0; i < e->np; ++i) mass += (double)q0[i * 4 + 3] * p.M.density;
     if (!(mass > 0) || !std::isfinite(mass)) mass = 1.0;
     const int k = 61 - (int)std::ceil(std::log2(mass));
     p.fix_m = std::ldexp(1.0, k);
@@ -161,19 +161,17 @@ int mpm_finalize(mpm_handle_t e) {
     ALLOC(p.dbgbuf, 16, true);
     for (int s = 0; s < 2; ++s) {
         PSet& S = p.set[s];
-        for (int d = 0; d < 3; ++d) { ALLOC(S.x[d], np, true); ALLOC(S.v[d], np, true); }
-        ALLOC(S.vol, np, true);
-        for (int d = 0; d < 9; ++d) { ALLOC(S.C[d], np, true); ALLOC(S.F[d], nf, true); }
-        for (int d = 0; d < 4; ++d) ALLOC(S.Dm[d], nf, true);
+        for (int d = 0; d < 4; ++d) { ALLOC(S.q[d], np, true); ALLOC(S.fq[d], nf, true); }
         ALLOC(S.pid, np, true);
     }
-    for (int d = 0; d < 6; ++d) ALLOC(p.ab[d], nf, true);
+    ALLOC(p.ab0, nf, true);
+    ALLOC(p.ab1, nf, true);
     ALLOC(p.G4, 3 * nf, true);
     for (int d = 0; d < 8; ++d) ALLOC(p.vadj[d], nv, true);
     for (int d = 0; d < 3; ++d) ALLOC(p.f[d], np, true);
     int* idx_orig[3];
     int *adj_off, *adj_fc;
-    for (int d = 0; d < 3; ++d) { ALLOC(idx_orig[d], nf, false); p.idx_orig[d] = idx_orig[d]; ALLOC(p.fv[d], nf, false); }
+    for (int d = 0; d < 3; ++d) { ALLOC(idx_orig[d], nf, false); p.idx_orig[d] = idx_orig[d]; }
     ALLOC(adj_off, nv + 1, false);
     ALLOC(adj_fc, 3 * nf, false);
     p.adj_off = adj_off; p.adj_fc = adj_fc;
@@ -209,16 +207,16 @@ int mpm_finalize(mpm_handle_t e) {
 
     // ---- host-side layout: [faces | verts], indices offset by +nf ---------
     // (cuda_mpm_model.cu:40-45)
-    std::vector<float> plane(np);
     PSet& S0 = p.set[0];
-    for (int d = 0; d < 3; ++d) {
-        std::fill(plane.begin(), plane.begin() + nf, 0.f);
-        for (size_t i = 0; i < nv; ++i) plane[nf + i] = e->h_pos[i * 3 + d];
-        HIP_TRY(hipMemcpyAsync(S0.x[d], plane.data(), np * 4, hipMemcpyHostToDevice, e->stream));
-        HIP_TRY(hipStreamSynchronize(e->stream));
-        for (size_t i = 0; i < nv; ++i) plane[nf + i] = e->h_vel[i * 3 + d];
-        HIP_TRY(hipMemcpyAsync(S0.v[d], plane.data(), np * 4, hipMemcpyHostToDevice, e->stream));
-        HIP_TRY(hipStreamSynchronize(e->stream));
+    {
+        std::vector<float> q0(np * 4, 0.f), q1(np * 4, 0.f);   // (x,y,z,vol) and (vx,vy,vz,C8); faces are filled on the device
+        for (size_t i = 0; i < nv; ++i)
+            for (int d = 0; d < 3; ++d) {
+                q0[(nf + i) * 4 + d] = e->h_pos[i * 3 + d];
+                q1[(nf + i) * 4 + d] = e->h_vel[i * 3 + d];
+            }
+        HIP_TRY(hipMemcpy(S0.q[0], q0.data(), np * 16, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(S0.q[1], q1.data(), np * 16, hipMemcpyHostToDevice));
     }
     std::vector<int> iota(np);
     std::iota(iota.begin(), iota.end(), 0);
@@ -230,7 +228,13 @@ int mpm_finalize(mpm_handle_t e) {
     for (int d = 0; d < 3; ++d) {
         for (size_t f = 0; f < nf; ++f) col[f] = e->h_idx[f * 3 + d] + (int)nf;
         HIP_TRY(hipMemcpy(idx_orig[d], col.data(), nf * 4, hipMemcpyHostToDevice));
-        HIP_TRY(hipMemcpy(p.fv[d], col.data(), nf * 4, hipMemcpyHostToDevice));
+    }
+    if (nf) {
+        // corner vertex slots ride in fq[3].yzw (slot == original id before the first sort)
+        std::vector<int> f3(nf * 4, 0);
+        for (size_t f = 0; f < nf; ++f)
+            for (int d = 0; d < 3; ++d) f3[f * 4 + 1 + d] = e->h_idx[f * 3 + d] + (int)nf;
+        HIP_TRY(hipMemcpy(S0.fq[3], f3.data(), nf * 16, hipMemcpyHostToDevice));
     }
     // vertex -> (face, corner) adjacency, ascending face id
     std::vector<int> off(nv + 1, 0), fc(3 * nf);

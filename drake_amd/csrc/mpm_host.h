@@ -48,6 +48,7 @@ struct mpm_engine {
     // slot (API) order bookkeeping: slot -> original id and its inverse
     int* d_pids_api = nullptr;
     int* d_apimap = nullptr;
+    int* d_iota = nullptr;     // identity map, created on first use (views in original order)
     bool api_identity = true;
     int grid_state = 0;  // 0 nothing, 1 slabs valid (after P2G), 2 grid updated
     uint64_t substeps = 0;

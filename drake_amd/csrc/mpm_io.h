@@ -11,37 +11,34 @@ namespace mpm {
 
 // initialize_fem_state_kernel (cuda_mpm_kernels.cuh:13-70), faces in original
 // order (slot == original id at this point).  The per-face quarter volume is
-// parked in ab[0] for k_init_vertex_volumes.
+// parked in G4[face].x for k_init_vertex_volumes.
 __global__ __launch_bounds__(256) void k_init_faces(DP p) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= p.Nf) return;
     const PSet& S = p.set[0];
-    const int s0 = p.fv[0][i], s1 = p.fv[1][i], s2 = p.fv[2][i];
-    float D0[3], D1[3];
-#pragma unroll
-    for (int d = 0; d < 3; ++d) {
-        const float a = S.x[d][s0], b = S.x[d][s1], c = S.x[d][s2];
-        S.x[d][i] = (a + b + c) / 3.f;
-        S.v[d][i] = (S.v[d][s0] + S.v[d][s1] + S.v[d][s2]) / 3.f;
-        D0[d] = b - a;
-        D1[d] = c - a;
-    }
+    const float4 f3 = S.fq[3][i];
+    const int s0 = __float_as_int(f3.y), s1 = __float_as_int(f3.z), s2 = __float_as_int(f3.w);
+    const float4 xa = S.q[0][s0], xb = S.q[0][s1], xc = S.q[0][s2];
+    const float4 va = S.q[1][s0], vb = S.q[1][s1], vc = S.q[1][s2];
+    const float D0[3] = {xb.x - xa.x, xb.y - xa.y, xb.z - xa.z};
+    const float D1[3] = {xc.x - xa.x, xc.y - xa.y, xc.z - xa.z};
     const float Ds[6] = {D0[0], D1[0], D0[1], D1[1], D0[2], D1[2]};
     float Q[9], R[6];
     givens_qr3<2>(Ds, Q, R);
     const float Dmat[4] = {R[0], R[1], 0.f, R[3]};
     float Di[4];
     inv2(Dmat, Di);
-#pragma unroll
-    for (int d = 0; d < 4; ++d) S.Dm[d][i] = Di[d];
-#pragma unroll
-    for (int d = 0; d < 9; ++d) S.F[d][i] = Q[d];
     const float cx = D0[1] * D1[2] - D1[1] * D0[2];
     const float cy = D0[2] * D1[0] - D1[2] * D0[0];
     const float cz = D0[0] * D1[1] - D1[0] * D0[1];
     const float v4 = sqrtf(cx * cx + cy * cy + cz * cz) / 8.f * p.dx;
-    S.vol[i] = v4;
-    p.ab[0][i] = v4;
+    S.q[0][i] = make_float4((xa.x + xb.x + xc.x) / 3.f, (xa.y + xb.y + xc.y) / 3.f, (xa.z + xb.z + xc.z) / 3.f, v4);
+    S.q[1][i] = make_float4((va.x + vb.x + vc.x) / 3.f, (va.y + vb.y + vc.y) / 3.f, (va.z + vb.z + vc.z) / 3.f, 0.f);
+    S.fq[0][i] = make_float4(Q[0], Q[1], Q[2], Q[3]);
+    S.fq[1][i] = make_float4(Q[4], Q[5], Q[6], Q[7]);
+    S.fq[2][i] = make_float4(Q[8], Di[0], Di[1], Di[2]);
+    S.fq[3][i] = make_float4(Di[3], f3.y, f3.z, f3.w);
+    p.G4[(size_t)i * 3].x = v4;
 }
 
 // vertex volume = sum of the quarter volumes of its faces (ascending face id)
@@ -49,38 +46,85 @@ __global__ __launch_bounds__(256) void k_init_vertex_volumes(DP p) {
     const int k = blockIdx.x * 256 + threadIdx.x;
     if (k >= p.Nv) return;
     float v = 0.f;
-    for (int e = p.adj_off[k]; e < p.adj_off[k + 1]; ++e) v += p.ab[0][p.adj_fc[e] >> 2];
-    p.set[0].vol[p.Nf + k] = v;
+    for (int e = p.adj_off[k]; e < p.adj_off[k + 1]; ++e) v += p.G4[(size_t)(p.adj_fc[e] >> 2) * 3].x;
+    p.set[0].q[0][p.Nf + k].w = v;
 }
 
 // ---- slot-order views -------------------------------------------------------
-struct Planes {
-    const float* q[9];
-};
-struct PlanesW {
-    float* q[9];
-};
+enum Field { F_POS, F_VEL, F_VOL, F_AFFINE, F_FORCE, F_DEFGRAD, F_DMINV };
 
-// out[s*NC + c] = plane[c][ imap[ pids_api[s] ] ]; zero where the slot is outside [lo, hi)
-template <int NC>
-__global__ __launch_bounds__(256) void k_gather_slots(Planes pl, float* out, int n, const int* pids_api,
-                                                      const int* imap, int lo, int hi) {
-    const int s = blockIdx.x * 256 + threadIdx.x;
-    if (s >= n) return;
-    const int j = imap[pids_api[s]];
-    const bool ok = j >= lo && j < hi;
-#pragma unroll
-    for (int c = 0; c < NC; ++c) out[(size_t)s * NC + c] = ok ? pl.q[c][j] : 0.f;
+template <int FIELD>
+struct FieldInfo;
+template <> struct FieldInfo<F_POS> { static constexpr int N = 3; };
+template <> struct FieldInfo<F_VEL> { static constexpr int N = 3; };
+template <> struct FieldInfo<F_VOL> { static constexpr int N = 1; };
+template <> struct FieldInfo<F_AFFINE> { static constexpr int N = 9; };
+template <> struct FieldInfo<F_FORCE> { static constexpr int N = 3; };
+template <> struct FieldInfo<F_DEFGRAD> { static constexpr int N = 9; };
+template <> struct FieldInfo<F_DMINV> { static constexpr int N = 4; };
+
+template <int FIELD>
+MPM_DEV void read_field(const DP& p, const PSet& S, int j, float* o) {
+    if (FIELD == F_POS) { const float4 q = S.q[0][j]; o[0] = q.x; o[1] = q.y; o[2] = q.z; }
+    if (FIELD == F_VEL) { const float4 q = S.q[1][j]; o[0] = q.x; o[1] = q.y; o[2] = q.z; }
+    if (FIELD == F_VOL) o[0] = S.q[0][j].w;
+    if (FIELD == F_AFFINE) unpack_C(S.q[1][j], S.q[2][j], S.q[3][j], o);
+    if (FIELD == F_FORCE) {
+        const bool v = j >= p.Nf;
+        o[0] = v ? p.f[0][j] : 0.f; o[1] = v ? p.f[1][j] : 0.f; o[2] = v ? p.f[2][j] : 0.f;
+    }
+    if (FIELD == F_DEFGRAD) {
+        const float4 a = S.fq[0][j], b = S.fq[1][j];
+        o[0] = a.x; o[1] = a.y; o[2] = a.z; o[3] = a.w; o[4] = b.x; o[5] = b.y; o[6] = b.z; o[7] = b.w;
+        o[8] = S.fq[2][j].x;
+    }
+    if (FIELD == F_DMINV) {
+        const float4 c = S.fq[2][j];
+        o[0] = c.y; o[1] = c.z; o[2] = c.w; o[3] = S.fq[3][j].x;
+    }
 }
 
-template <int NC>
-__global__ __launch_bounds__(256) void k_scatter_slots(PlanesW pl, const float* in, int n, const int* pids_api,
-                                                       const int* imap) {
+template <int FIELD>
+MPM_DEV void write_field(const PSet& S, int j, const float* v) {
+    if (FIELD == F_POS) { float4 q = S.q[0][j]; q.x = v[0]; q.y = v[1]; q.z = v[2]; S.q[0][j] = q; }
+    if (FIELD == F_VEL) { float4 q = S.q[1][j]; q.x = v[0]; q.y = v[1]; q.z = v[2]; S.q[1][j] = q; }
+    if (FIELD == F_VOL) S.q[0][j].w = v[0];
+    if (FIELD == F_AFFINE) {
+        S.q[2][j] = make_float4(v[0], v[1], v[2], v[3]);
+        S.q[3][j] = make_float4(v[4], v[5], v[6], v[7]);
+        S.q[1][j].w = v[8];
+    }
+    if (FIELD == F_DEFGRAD) {
+        S.fq[0][j] = make_float4(v[0], v[1], v[2], v[3]);
+        S.fq[1][j] = make_float4(v[4], v[5], v[6], v[7]);
+        S.fq[2][j].x = v[8];
+    }
+}
+
+// out[s*N .. ] = field of the particle in slot s; `order` maps slot -> original id (the API slot
+// order, or the identity for views in original order)
+template <int FIELD>
+__global__ __launch_bounds__(256) void k_gather_field(DP p, float* out, int n, const int* order) {
+    constexpr int N = FieldInfo<FIELD>::N;
     const int s = blockIdx.x * 256 + threadIdx.x;
     if (s >= n) return;
-    const int j = imap[pids_api[s]];
+    const PSet& S = p.set[p.ctl->cur];
+    float v[9];
+    read_field<FIELD>(p, S, p.imap[order[s]], v);
 #pragma unroll
-    for (int c = 0; c < NC; ++c) pl.q[c][j] = in[(size_t)s * NC + c];
+    for (int c = 0; c < N; ++c) out[(size_t)s * N + c] = v[c];
+}
+
+template <int FIELD>
+__global__ __launch_bounds__(256) void k_scatter_field(DP p, const float* in, int n, const int* order) {
+    constexpr int N = FieldInfo<FIELD>::N;
+    const int s = blockIdx.x * 256 + threadIdx.x;
+    if (s >= n) return;
+    const PSet& S = p.set[p.ctl->cur];
+    float v[9];
+#pragma unroll
+    for (int c = 0; c < N; ++c) v[c] = in[(size_t)s * N + c];
+    write_field<FIELD>(S, p.imap[order[s]], v);
 }
 
 // taus()[slot] = a (x) b for face particles, zero for vertices
@@ -90,11 +134,10 @@ __global__ __launch_bounds__(256) void k_gather_taus(DP p, float* out, const int
     const int j = p.imap[pids_api[s]];
     float a[3] = {0.f, 0.f, 0.f}, b[3] = {0.f, 0.f, 0.f};
     if (j < p.Nf) {
-#pragma unroll
-        for (int d = 0; d < 3; ++d) {
-            a[d] = p.ab[d][j];
-            b[d] = p.ab[3 + d][j];
-        }
+        const float4 q = p.ab0[j];
+        const float2 r = p.ab1[j];
+        a[0] = q.x; a[1] = q.y; a[2] = q.z;
+        b[0] = q.w; b[1] = r.x; b[2] = r.y;
     }
 #pragma unroll
     for (int r = 0; r < 3; ++r)
@@ -108,8 +151,8 @@ __global__ __launch_bounds__(256) void k_slot_keys(DP p, uint32_t* out, const in
     const int s = blockIdx.x * 256 + threadIdx.x;
     if (s >= p.Np) return;
     const PSet& S = p.set[p.ctl->cur];
-    const int j = p.imap[pids_api[s]];
-    out[s] = cell_key(base_cell(S.x[0][j], p.dxinv), base_cell(S.x[1][j], p.dxinv), base_cell(S.x[2][j], p.dxinv));
+    const float4 x = S.q[0][p.imap[pids_api[s]]];
+    out[s] = cell_key(base_cell(x.x, p.dxinv), base_cell(x.y, p.dxinv), base_cell(x.z, p.dxinv));
 }
 
 // dense views of the compact grid: out_m[key], out_v[3*key]
@@ -141,46 +184,48 @@ __global__ __launch_bounds__(256) void k_touched_flags(DP p, uint32_t* flags) {
 
 }  // namespace mpm
 
-static PSet current_set(mpm_engine* e, int* rc) {
-    Ctl c{};
-    hipError_t err = hipStreamSynchronize(e->stream);
-    if (err == hipSuccess) err = hipMemcpy(&c, e->dp.ctl, sizeof(Ctl), hipMemcpyDeviceToHost);
-    *rc = err == hipSuccess ? 0 : fail(MPM_ERR_HIP, std::string("read control block: ") + hipGetErrorString(err));
-    return e->dp.set[c.cur & 1];
+// identity "slot -> original id" map on the device (views in original order)
+static int device_iota(mpm_engine* e, int** out) {
+    if (!e->d_iota) {
+        std::vector<int> iota(e->np);
+        std::iota(iota.begin(), iota.end(), 0);
+        HIP_TRY(hipMalloc((void**)&e->d_iota, e->np * 4));
+        e->allocs.push_back(e->d_iota);
+        HIP_TRY(hipMemcpy(e->d_iota, iota.data(), e->np * 4, hipMemcpyHostToDevice));
+    }
+    *out = e->d_iota;
+    return 0;
 }
 
-template <int NC>
-static int gather_to_host(mpm_engine* e, const float* const* planes, float* out, int lo, int hi) {
-    const size_t n = e->np;
-    if (int rc = e->stage(n * NC * 4)) return rc;
-    Planes pl{};
-    for (int c = 0; c < NC; ++c) pl.q[c] = planes[c];
-    hipLaunchKernelGGL(k_gather_slots<NC>, dim3(e->g_np), dim3(256), 0, e->stream, pl, (float*)e->d_stage, (int)n,
-                       e->d_pids_api, e->dp.imap, lo, hi);
-    HIP_TRY(hipMemcpyAsync(out, e->d_stage, n * NC * 4, hipMemcpyDeviceToHost, e->stream));
+template <int FIELD>
+static int gather_to_host(mpm_engine* e, float* out, size_t n, const int* order) {
+    constexpr int N = FieldInfo<FIELD>::N;
+    if (n == 0) return 0;
+    if (int rc = e->stage(n * N * 4)) return rc;
+    hipLaunchKernelGGL(k_gather_field<FIELD>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, e->stream, e->dp,
+                       (float*)e->d_stage, (int)n, order);
+    HIP_TRY(hipMemcpyAsync(out, e->d_stage, n * N * 4, hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    return 0;
+}
+
+template <int FIELD>
+static int scatter_from_host(mpm_engine* e, const float* in, size_t n, const int* order) {
+    constexpr int N = FieldInfo<FIELD>::N;
+    if (n == 0) return 0;
+    if (int rc = e->stage(n * N * 4)) return rc;
+    HIP_TRY(hipMemcpyAsync(e->d_stage, in, n * N * 4, hipMemcpyHostToDevice, e->stream));
+    hipLaunchKernelGGL(k_scatter_field<FIELD>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, e->stream, e->dp,
+                       (const float*)e->d_stage, (int)n, order);
     HIP_TRY(hipStreamSynchronize(e->stream));
     return 0;
 }
 
 // Vertex positions in original vertex order (DumpCpuState, cuda_mpm_model.cu:244-265)
 static int download_original_vertices(mpm_engine* e, float* out) {
-    int rc = 0;
-    const PSet S = current_set(e, &rc);
-    if (rc) return rc;
-    std::vector<int> iota(e->np);
-    std::iota(iota.begin(), iota.end(), 0);
-    // gather in original order = identity "slot -> original id" map
-    if ((rc = e->stage(e->np * 12 + e->np * 4))) return rc;
-    int* d_iota = reinterpret_cast<int*>(static_cast<char*>(e->d_stage) + e->np * 12);
-    HIP_TRY(hipMemcpy(d_iota, iota.data(), e->np * 4, hipMemcpyHostToDevice));
-    Planes pl{};
-    for (int c = 0; c < 3; ++c) pl.q[c] = S.x[c];
-    hipLaunchKernelGGL(k_gather_slots<3>, dim3(e->g_np), dim3(256), 0, e->stream, pl, (float*)e->d_stage, (int)e->np,
-                       d_iota, e->dp.imap, 0, (int)e->np);
-    HIP_TRY(hipMemcpyAsync(out, static_cast<char*>(e->d_stage) + e->nf * 12, e->nv * 12, hipMemcpyDeviceToHost,
-                           e->stream));
-    HIP_TRY(hipStreamSynchronize(e->stream));
-    return 0;
+    int* iota = nullptr;
+    if (int rc = device_iota(e, &iota)) return rc;
+    return gather_to_host<F_POS>(e, out, e->nv, iota + e->nf);
 }
 
 // flags_out (nblocks uint32, may be null) and the touched count
@@ -246,29 +291,17 @@ static int download_array(mpm_engine* e, int which, void* out, size_t bytes, siz
     };
     switch (which) {
         case MPM_ARR_POSITIONS:
-        case MPM_ARR_VELOCITIES: {
             if ((rc = need(np * 12))) return rc;
-            const PSet S = current_set(e, &rc);
-            if (rc) return rc;
-            const float* pl[3];
-            for (int d = 0; d < 3; ++d) pl[d] = which == MPM_ARR_POSITIONS ? S.x[d] : S.v[d];
-            return gather_to_host<3>(e, pl, (float*)out, 0, (int)np);
-        }
-        case MPM_ARR_VOLUMES: {
+            return gather_to_host<F_POS>(e, (float*)out, np, e->d_pids_api);
+        case MPM_ARR_VELOCITIES:
+            if ((rc = need(np * 12))) return rc;
+            return gather_to_host<F_VEL>(e, (float*)out, np, e->d_pids_api);
+        case MPM_ARR_VOLUMES:
             if ((rc = need(np * 4))) return rc;
-            const PSet S = current_set(e, &rc);
-            if (rc) return rc;
-            const float* pl[1] = {S.vol};
-            return gather_to_host<1>(e, pl, (float*)out, 0, (int)np);
-        }
-        case MPM_ARR_AFFINE: {
+            return gather_to_host<F_VOL>(e, (float*)out, np, e->d_pids_api);
+        case MPM_ARR_AFFINE:
             if ((rc = need(np * 36))) return rc;
-            const PSet S = current_set(e, &rc);
-            if (rc) return rc;
-            const float* pl[9];
-            for (int d = 0; d < 9; ++d) pl[d] = S.C[d];
-            return gather_to_host<9>(e, pl, (float*)out, 0, (int)np);
-        }
+            return gather_to_host<F_AFFINE>(e, (float*)out, np, e->d_pids_api);
         case MPM_ARR_PIDS:
         case MPM_ARR_INDEX_MAPPINGS: {
             if ((rc = need(np * 4))) return rc;
@@ -285,11 +318,9 @@ static int download_array(mpm_engine* e, int which, void* out, size_t bytes, siz
             HIP_TRY(hipStreamSynchronize(e->stream));
             return 0;
         }
-        case MPM_ARR_FORCES: {
+        case MPM_ARR_FORCES:
             if ((rc = need(np * 12))) return rc;
-            const float* pl[3] = {p.f[0], p.f[1], p.f[2]};
-            return gather_to_host<3>(e, pl, (float*)out, (int)nf, (int)np);
-        }
+            return gather_to_host<F_FORCE>(e, (float*)out, np, e->d_pids_api);
         case MPM_ARR_TAUS: {
             if ((rc = need(np * 36))) return rc;
             if ((rc = e->stage(np * 36))) return rc;
@@ -304,25 +335,10 @@ static int download_array(mpm_engine* e, int which, void* out, size_t bytes, siz
             // face arrays stay in original face order in the reference
             const int nc = which == MPM_ARR_DM_INVERSES ? 4 : 9;
             if ((rc = need(nf * nc * 4))) return rc;
-            const PSet S = current_set(e, &rc);
-            if (rc) return rc;
-            std::vector<int> iota(np);
-            std::iota(iota.begin(), iota.end(), 0);
-            if ((rc = e->stage(np * 36 + np * 4))) return rc;
-            int* d_iota = reinterpret_cast<int*>(static_cast<char*>(e->d_stage) + np * 36);
-            HIP_TRY(hipMemcpy(d_iota, iota.data(), np * 4, hipMemcpyHostToDevice));
-            Planes pl{};
-            for (int c = 0; c < nc; ++c) pl.q[c] = nc == 4 ? S.Dm[c] : S.F[c];
-            if (nf == 0) return 0;
-            if (nc == 4)
-                hipLaunchKernelGGL(k_gather_slots<4>, dim3(e->g_nf), dim3(256), 0, e->stream, pl, (float*)e->d_stage,
-                                   (int)nf, d_iota, p.imap, 0, (int)nf);
-            else
-                hipLaunchKernelGGL(k_gather_slots<9>, dim3(e->g_nf), dim3(256), 0, e->stream, pl, (float*)e->d_stage,
-                                   (int)nf, d_iota, p.imap, 0, (int)nf);
-            HIP_TRY(hipMemcpyAsync(out, e->d_stage, nf * nc * 4, hipMemcpyDeviceToHost, e->stream));
-            HIP_TRY(hipStreamSynchronize(e->stream));
-            return 0;
+            int* iota = nullptr;
+            if ((rc = device_iota(e, &iota))) return rc;
+            return nc == 4 ? gather_to_host<F_DMINV>(e, (float*)out, nf, iota)
+                           : gather_to_host<F_DEFGRAD>(e, (float*)out, nf, iota);
         }
         case MPM_ARR_INDICES: {
             if ((rc = need(nf * 12))) return rc;
@@ -368,60 +384,20 @@ static int download_array(mpm_engine* e, int which, void* out, size_t bytes, siz
 static int upload_state(mpm_engine* e, const float* pos, const float* vel, const float* affine, const float* volumes,
                         const float* Fdef) {
     int rc = 0;
-    const PSet S = current_set(e, &rc);
-    if (rc) return rc;
     const size_t np = e->np;
-    auto put = [&](const float* src, int nc, float* const* planes) -> int {
-        if (int r = e->stage(np * nc * 4)) return r;
-        HIP_TRY(hipMemcpyAsync(e->d_stage, src, np * nc * 4, hipMemcpyHostToDevice, e->stream));
-        PlanesW pl{};
-        for (int c = 0; c < nc; ++c) pl.q[c] = planes[c];
-        if (nc == 3)
-            hipLaunchKernelGGL(k_scatter_slots<3>, dim3(e->g_np), dim3(256), 0, e->stream, pl, (const float*)e->d_stage,
-                               (int)np, e->d_pids_api, e->dp.imap);
-        else if (nc == 9)
-            hipLaunchKernelGGL(k_scatter_slots<9>, dim3(e->g_np), dim3(256), 0, e->stream, pl, (const float*)e->d_stage,
-                               (int)np, e->d_pids_api, e->dp.imap);
-        else
-            hipLaunchKernelGGL(k_scatter_slots<1>, dim3(e->g_np), dim3(256), 0, e->stream, pl, (const float*)e->d_stage,
-                               (int)np, e->d_pids_api, e->dp.imap);
-        HIP_TRY(hipStreamSynchronize(e->stream));
-        return 0;
-    };
     if (pos) {
-        float* pl[3] = {S.x[0], S.x[1], S.x[2]};
-        if ((rc = put(pos, 3, pl))) return rc;
+        if ((rc = scatter_from_host<F_POS>(e, pos, np, e->d_pids_api))) return rc;
         // positions changed arbitrarily: force a re-sort before the next transfer
         int one = 1;
         HIP_TRY(hipMemcpy(&e->dp.ctl->need_rebuild, &one, sizeof(int), hipMemcpyHostToDevice));
     }
-    if (vel) {
-        float* pl[3] = {S.v[0], S.v[1], S.v[2]};
-        if ((rc = put(vel, 3, pl))) return rc;
-    }
-    if (affine) {
-        float* pl[9];
-        for (int d = 0; d < 9; ++d) pl[d] = S.C[d];
-        if ((rc = put(affine, 9, pl))) return rc;
-    }
-    if (volumes) {
-        float* pl[1] = {S.vol};
-        if ((rc = put(volumes, 1, pl))) return rc;
-    }
+    if (vel && (rc = scatter_from_host<F_VEL>(e, vel, np, e->d_pids_api))) return rc;
+    if (affine && (rc = scatter_from_host<F_AFFINE>(e, affine, np, e->d_pids_api))) return rc;
+    if (volumes && (rc = scatter_from_host<F_VOL>(e, volumes, np, e->d_pids_api))) return rc;
     if (Fdef && e->nf) {
-        // original face order: "slot -> original id" is the identity for this view
-        const size_t nf = e->nf;
-        std::vector<int> iota(nf);
-        std::iota(iota.begin(), iota.end(), 0);
-        if ((rc = e->stage(nf * 36 + nf * 4))) return rc;
-        int* d_iota = reinterpret_cast<int*>(static_cast<char*>(e->d_stage) + nf * 36);
-        HIP_TRY(hipMemcpy(d_iota, iota.data(), nf * 4, hipMemcpyHostToDevice));
-        HIP_TRY(hipMemcpyAsync(e->d_stage, Fdef, nf * 36, hipMemcpyHostToDevice, e->stream));
-        PlanesW pl{};
-        for (int c = 0; c < 9; ++c) pl.q[c] = S.F[c];
-        hipLaunchKernelGGL(k_scatter_slots<9>, dim3(e->g_nf), dim3(256), 0, e->stream, pl, (const float*)e->d_stage,
-                           (int)nf, d_iota, e->dp.imap);
-        HIP_TRY(hipStreamSynchronize(e->stream));
+        int* iota = nullptr;
+        if ((rc = device_iota(e, &iota))) return rc;
+        if ((rc = scatter_from_host<F_DEFGRAD>(e, Fdef, e->nf, iota))) return rc;
     }
     return 0;
 }

@@ -27,8 +27,8 @@ __global__ __launch_bounds__(256) void k_rb_count(DP p) {
     const PSet& S = p.set[p.ctl->cur];
     const int ii = valid ? i : p.Np - 1;
     const uint32_t hi = (uint32_t)((1 << p.bits) - 3);
-    uint32_t bx = base_cell(S.x[0][ii], p.dxinv), by = base_cell(S.x[1][ii], p.dxinv),
-             bz = base_cell(S.x[2][ii], p.dxinv);
+    const float4 xq = S.q[0][ii];
+    uint32_t bx = base_cell(xq.x, p.dxinv), by = base_cell(xq.y, p.dxinv), bz = base_cell(xq.z, p.dxinv);
     if (valid && (bx > hi || by > hi || bz > hi)) atomicOr(&p.ctl->error, ERR_DOMAIN);
     bx = min(bx, hi); by = min(by, hi); bz = min(bz, hi);
     const int t = ii >= p.Nf;
@@ -327,46 +327,24 @@ __global__ __launch_bounds__(256) void k_rb_finish(DP p) {
     const unsigned gs = gridDim.x * 256u, i0 = blockIdx.x * 256u + threadIdx.x;
     const PSet& S = p.set[c->cur];
     const PSet& D = p.set[c->cur ^ 1];
-    // move the particle planes into their sorted slots: all loads first, then all stores
+    // move the particle records into their sorted slots (16-byte gathers, coalesced 16-byte stores)
     for (unsigned j = i0; j < (unsigned)p.Np; j += gs) {
         const unsigned i = p.src_of[j];
-        float a[16];
-#pragma unroll
-        for (int d = 0; d < 3; ++d) {
-            a[d] = S.x[d][i];
-            a[3 + d] = S.v[d][i];
-        }
-        a[6] = S.vol[i];
-#pragma unroll
-        for (int d = 0; d < 9; ++d) a[7 + d] = S.C[d][i];
+        const float4 a0 = S.q[0][i], a1 = S.q[1][i], a2 = S.q[2][i], a3 = S.q[3][i];
         const int pid = S.pid[i];
         const bool face = j < (unsigned)p.Nf;
-        float fm[13];
-        int fvv[3] = {0, 0, 0};
+        float4 b0, b1, b2, b3;
         if (face) {
-#pragma unroll
-            for (int d = 0; d < 9; ++d) fm[d] = S.F[d][i];
-#pragma unroll
-            for (int d = 0; d < 4; ++d) fm[9 + d] = S.Dm[d][i];
-#pragma unroll
-            for (int k = 0; k < 3; ++k) fvv[k] = p.imap[p.idx_orig[k][pid]];
+            b0 = S.fq[0][i]; b1 = S.fq[1][i]; b2 = S.fq[2][i]; b3 = S.fq[3][i];
+            // corner vertices keep their original ids; their slots have just changed
+            b3.y = __int_as_float(p.imap[p.idx_orig[0][pid]]);
+            b3.z = __int_as_float(p.imap[p.idx_orig[1][pid]]);
+            b3.w = __int_as_float(p.imap[p.idx_orig[2][pid]]);
         }
-#pragma unroll
-        for (int d = 0; d < 3; ++d) {
-            D.x[d][j] = a[d];
-            D.v[d][j] = a[3 + d];
-        }
-        D.vol[j] = a[6];
-#pragma unroll
-        for (int d = 0; d < 9; ++d) D.C[d][j] = a[7 + d];
+        D.q[0][j] = a0; D.q[1][j] = a1; D.q[2][j] = a2; D.q[3][j] = a3;
         D.pid[j] = pid;
         if (face) {
-#pragma unroll
-            for (int d = 0; d < 9; ++d) D.F[d][j] = fm[d];
-#pragma unroll
-            for (int d = 0; d < 4; ++d) D.Dm[d][j] = fm[9 + d];
-#pragma unroll
-            for (int k = 0; k < 3; ++k) p.fv[k][j] = fvv[k];
+            D.fq[0][j] = b0; D.fq[1][j] = b1; D.fq[2][j] = b2; D.fq[3][j] = b3;
         }
     }
     // per vertex slot, the (face slot, corner) records of its adjacent faces

@@ -17,25 +17,25 @@ __global__ __launch_bounds__(256) void k_fem(DP p, float dt) {
     const unsigned i = blockIdx.x * 256 + threadIdx.x;
     if (i >= (unsigned)p.Nf) return;
     const PSet& S = p.set[p.ctl->cur];
-    const unsigned s0 = (unsigned)p.fv[0][i], s1 = (unsigned)p.fv[1][i], s2 = (unsigned)p.fv[2][i];
-    float x0[3], x1[3], x2[3];
-#pragma unroll
-    for (int d = 0; d < 3; ++d) {
-        x0[d] = S.x[d][s0];
-        x1[d] = S.x[d][s1];
-        x2[d] = S.x[d][s2];
-        S.x[d][i] = (x0[d] + x1[d] + x2[d]) / 3.f;
-        S.v[d][i] = (S.v[d][s0] + S.v[d][s1] + S.v[d][s2]) / 3.f;
-    }
-    float F[9], C[9], Dm[4];
-#pragma unroll
-    for (int d = 0; d < 9; ++d) {
-        F[d] = S.F[d][i];
-        C[d] = S.C[d][i];
-    }
-#pragma unroll
-    for (int d = 0; d < 4; ++d) Dm[d] = S.Dm[d][i];
-    const float vol = S.vol[i];
+    const float4 f0 = S.fq[0][i], f1 = S.fq[1][i], f2 = S.fq[2][i], f3 = S.fq[3][i];
+    const unsigned s0 = (unsigned)__float_as_int(f3.y), s1 = (unsigned)__float_as_int(f3.z),
+                   s2 = (unsigned)__float_as_int(f3.w);
+    const float4 xa = S.q[0][s0], xb = S.q[0][s1], xc = S.q[0][s2];
+    const float4 va = S.q[1][s0], vb = S.q[1][s1], vc = S.q[1][s2];
+    float4 q0 = S.q[0][i], q1 = S.q[1][i];
+    const float4 q2 = S.q[2][i], q3 = S.q[3][i];
+    const float x0[3] = {xa.x, xa.y, xa.z}, x1[3] = {xb.x, xb.y, xb.z}, x2[3] = {xc.x, xc.y, xc.z};
+    // the face particle sits at the centroid and moves with the mean velocity (:203-207);
+    // vol (q0.w) and C8 (q1.w) ride along unchanged
+    q0.x = (xa.x + xb.x + xc.x) / 3.f; q0.y = (xa.y + xb.y + xc.y) / 3.f; q0.z = (xa.z + xb.z + xc.z) / 3.f;
+    q1.x = (va.x + vb.x + vc.x) / 3.f; q1.y = (va.y + vb.y + vc.y) / 3.f; q1.z = (va.z + vb.z + vc.z) / 3.f;
+    S.q[0][i] = q0;
+    S.q[1][i] = q1;
+    const float F[9] = {f0.x, f0.y, f0.z, f0.w, f1.x, f1.y, f1.z, f1.w, f2.x};
+    const float Dm[4] = {f2.y, f2.z, f2.w, f3.x};
+    float C[9];
+    unpack_C(q1, q2, q3, C);
+    const float vol = q0.w;
 
     // normal column evolves with the affine velocity field (:216-226)
     float cF[9];
@@ -53,16 +53,17 @@ __global__ __launch_bounds__(256) void k_fem(DP p, float dt) {
         cF[d * 3 + 0] = e0 * Dm[0] + e1 * Dm[2];
         cF[d * 3 + 1] = e0 * Dm[1] + e1 * Dm[3];
     }
-#pragma unroll
-    for (int d = 0; d < 9; ++d) S.F[d][i] = cF[d];
+    S.fq[0][i] = make_float4(cF[0], cF[1], cF[2], cF[3]);
+    S.fq[1][i] = make_float4(cF[4], cF[5], cF[6], cF[7]);
+    S.fq[2][i] = make_float4(cF[8], Dm[0], Dm[1], Dm[2]);
 
     float P[9];
     cloth_dphi_dF(p.M, cF, P);
 #pragma unroll
     for (int d = 0; d < 9; ++d) P[d] *= vol;
     // tau = (V P[:,2]) (x) F[:,2]  (:265-267), kept factored
-    p.ab[0][i] = P[2]; p.ab[1][i] = P[5]; p.ab[2][i] = P[8];
-    p.ab[3][i] = cF[2]; p.ab[4][i] = cF[5]; p.ab[5][i] = cF[8];
+    p.ab0[i] = make_float4(P[2], P[5], P[8], cF[2]);
+    p.ab1[i] = make_float2(cF[5], cF[8]);
     // grad_N = Dm^-T [[-1,1,0],[-1,0,1]]  (:269-276)
     const float g00 = -Dm[0] - Dm[2], g01 = Dm[0], g02 = Dm[2];
     const float g10 = -Dm[1] - Dm[3], g11 = Dm[1], g12 = Dm[3];
@@ -310,14 +311,14 @@ __global__ __launch_bounds__(512, 4) void k_p2g(DP p, float dt) {  // <= 128 VGP
             r.is_face = lane < gf;
             // unsigned index: lets the loads use the scalar-base + 32-bit-offset addressing form
             const unsigned ii = (unsigned)(r.act ? (r.is_face ? gr.x + lane : gr.z + (lane - gf)) : (nfb ? rg.x : rg.z));
-#pragma unroll
-            for (int d = 0; d < 3; ++d) { r.x[d] = S.x[d][ii]; r.v[d] = S.v[d][ii]; }
-            r.vol = S.vol[ii];
-#pragma unroll
-            for (int d = 0; d < 9; ++d) r.C[d] = S.C[d][ii];
+            const float4 q0 = S.q[0][ii], q1 = S.q[1][ii], q2 = S.q[2][ii], q3 = S.q[3][ii];
+            r.x[0] = q0.x; r.x[1] = q0.y; r.x[2] = q0.z; r.vol = q0.w;
+            r.v[0] = q1.x; r.v[1] = q1.y; r.v[2] = q1.z;
+            unpack_C(q1, q2, q3, r.C);
             if (r.is_face) {
-#pragma unroll
-                for (int d = 0; d < 6; ++d) r.aux[d] = p.ab[d][ii];
+                const float4 a = p.ab0[ii];
+                const float2 b = p.ab1[ii];
+                r.aux[0] = a.x; r.aux[1] = a.y; r.aux[2] = a.z; r.aux[3] = a.w; r.aux[4] = b.x; r.aux[5] = b.y;
             } else {
 #pragma unroll
                 for (int d = 0; d < 3; ++d) r.aux[d] = p.f[d][ii];
@@ -626,7 +627,7 @@ MPM_DEV void load_tile(const DP& p, unsigned h, float4* tile, const float4* fiel
 }
 
 MPM_DEV void g2p_particle(const DP& p, const PSet& S, const float4* tile, unsigned i, float x, float y, float z,
-                             int ox, int oy, int oz, float dt) {
+                             float vol, int ox, int oy, int oz, float dt) {
     const Stencil st = make_stencil(p, x, y, z, ox, oy, oz);
     float nv[3] = {0.f, 0.f, 0.f}, nC[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     const float4* base = tile + ((st.rx * TILE_W + st.ry) * TILE_W + st.rz);
@@ -654,19 +655,21 @@ MPM_DEV void g2p_particle(const DP& p, const PSet& S, const float4* tile, unsign
         }
     }
     if (diag_flags(p) & 256) {  // ablation: no stores
-        if (nv[0] + nC[0] + nC[4] + nC[8] == 1.2345e30f) S.v[0][i] = nv[0];
+        if (nv[0] + nC[0] + nC[4] + nC[8] == 1.2345e30f) S.q[1][i].x = nv[0];
         return;
     }
     const float sc = 4.f * p.dxinv;
     const float ca = (p.M.V + 1.f) * .5f, cb = (p.M.V - 1.f) * .5f;
+    float Cn[9];
 #pragma unroll
     for (int r = 0; r < 3; ++r)
 #pragma unroll
-        for (int c = 0; c < 3; ++c) S.C[r * 3 + c][i] = ca * (sc * nC[r * 3 + c]) + cb * (sc * nC[c * 3 + r]);
-    S.v[0][i] = nv[0]; S.v[1][i] = nv[1]; S.v[2][i] = nv[2];
-    S.x[0][i] = x + nv[0] * dt;
-    S.x[1][i] = y + nv[1] * dt;
-    S.x[2][i] = z + nv[2] * dt;
+        for (int c = 0; c < 3; ++c) Cn[r * 3 + c] = ca * (sc * nC[r * 3 + c]) + cb * (sc * nC[c * 3 + r]);
+    // four 16-byte stores per particle
+    S.q[0][i] = make_float4(x + nv[0] * dt, y + nv[1] * dt, z + nv[2] * dt, vol);
+    S.q[1][i] = make_float4(nv[0], nv[1], nv[2], Cn[8]);
+    S.q[2][i] = make_float4(Cn[0], Cn[1], Cn[2], Cn[3]);
+    S.q[3][i] = make_float4(Cn[4], Cn[5], Cn[6], Cn[7]);
 }
 
 constexpr int G2P_THREADS = 512;
@@ -689,7 +692,7 @@ __global__ __launch_bounds__(G2P_THREADS) void k_g2p(DP p, float dt) {
         // ahead, so the HBM latency of the particle stream hides behind LDS work
         int u = (int)threadIdx.x;
         unsigned i = slot_of(u < total ? u : 0);
-        float px = S.x[0][i], py = S.x[1][i], pz = S.x[2][i];
+        float4 pq = S.q[0][i];
         load_tile(p, h, tile, p.gv, G2P_THREADS);
         __syncthreads();
         if (prof) t1 = __builtin_readcyclecounter();
@@ -699,13 +702,13 @@ __global__ __launch_bounds__(G2P_THREADS) void k_g2p(DP p, float dt) {
 #pragma unroll 1
         for (; u < total; u += G2P_THREADS) {
             const unsigned ci = i;
-            const float cx = px, cy = py, cz = pz;
+            const float4 c = pq;
             const int un = u + G2P_THREADS;
             if (un < total) {
                 i = slot_of(un);
-                px = S.x[0][i]; py = S.x[1][i]; pz = S.x[2][i];
+                pq = S.q[0][i];
             }
-            g2p_particle(p, S, tile, ci, cx, cy, cz, ox, oy, oz, dt);
+            g2p_particle(p, S, tile, ci, c.x, c.y, c.z, c.w, ox, oy, oz, dt);
         }
         if (prof && (threadIdx.x & 63) == 0) {
             const unsigned long long t2 = __builtin_readcyclecounter();
