@@ -40,6 +40,7 @@ def cpu_baseline(domain_bits, layers, res, dt, budget_s=20.0):
     threads = orc.max_threads()
     orc.set_threads(threads)
     o = orc.OracleMpm(domain_bits)
+    o.fast_scatter = True  # atomics-free multi-core scatter (same arithmetic, see oracle/mpm_oracle.c)
     # sample: fewer layers of the same sheets (same particle density per cell column)
     sl = max(2, layers // 4)
     for pos, vel, idx in scenes.cloth_stack(sl, res, domain_bits):

@@ -613,6 +613,94 @@ ORC_API void orc_particle_to_grid(const orc_params *p, size_t n, const float *po
     }
 }
 
+
+/* ------------------------------------------------------------------ */
+/* CPU-baseline variant of the scatter                                 */
+/* ------------------------------------------------------------------ */
+/* Same arithmetic as orc_particle_to_grid, organised for many host cores: particles are
+ * bucketed by the 4^3 block of their base cell and the blocks are processed in 8 colours
+ * (parity of the block coordinates).  A stencil reaches at most into the next block, so two
+ * blocks of one colour never write the same node and no atomics are needed.  Used only by the
+ * cpu_baseline leg of bench.py (the "reference CPU path timed beside" the GPU); the parity tests
+ * use the plain function above.  Sums per node are accumulated in a different order, so results
+ * agree with orc_particle_to_grid to rounding, not bitwise (checked in tests/test_oracle_kat.py). */
+ORC_API void orc_particle_to_grid_colored(const orc_params *p, size_t n, const float *pos,
+                                          const float *vel, const float *vol, const float *Caff,
+                                          const float *forces, const float *taus, uint32_t *flags,
+                                          float *gm, float *gmv, float dt) {
+    const float dxinv = p_dxinv(p), dx = p_dx(p), dinv = p_dinv(p);
+    const int gax = p->gravity_axis;
+    const uint32_t nblocks = 1u << (3 * (p->domain_bits - 2));
+    uint32_t *blk = (uint32_t *)malloc(n * sizeof(uint32_t));
+    uint32_t *start = (uint32_t *)calloc(nblocks + 1, sizeof(uint32_t));
+    uint32_t *order = (uint32_t *)malloc(n * sizeof(uint32_t));
+#pragma omp parallel for schedule(static)
+    for (long q = 0; q < (long)n; ++q) {
+        const uint32_t bx = f2u(pos[q * 3] * dxinv - .5f), by = f2u(pos[q * 3 + 1] * dxinv - .5f),
+                       bz = f2u(pos[q * 3 + 2] * dxinv - .5f);
+        blk[q] = orc_morton_code(bx >> 2, by >> 2, bz >> 2);
+    }
+    for (size_t q = 0; q < n; ++q) start[blk[q] + 1]++;
+    for (uint32_t b = 0; b < nblocks; ++b) start[b + 1] += start[b];
+    {
+        uint32_t *fill = (uint32_t *)malloc(nblocks * sizeof(uint32_t));
+        memcpy(fill, start, nblocks * sizeof(uint32_t));
+        for (size_t q = 0; q < n; ++q) order[fill[blk[q]]++] = (uint32_t)q;
+        free(fill);
+    }
+    for (int colour = 0; colour < 8; ++colour) {
+#pragma omp parallel for schedule(dynamic, 4)
+        for (long b = 0; b < (long)nblocks; ++b) {
+            if (start[b + 1] == start[b]) continue;
+            /* colour = parity bits of the block coordinates; Morton code has x,y,z in bits 2,1,0 */
+            if ((int)(b & 7) != colour) continue;
+            for (uint32_t k = start[b]; k < start[b + 1]; ++k) {
+                const size_t q = order[k];
+                uint32_t base[3];
+                float fx[3], w[3][3];
+                for (int d = 0; d < 3; ++d) {
+                    base[d] = f2u(pos[q * 3 + d] * dxinv - .5f);
+                    fx[d] = pos[q * 3 + d] * dxinv - (float)base[d];
+                    bspline(fx[d], &w[0][d], &w[1][d], &w[2][d]);
+                }
+                const float mass = vol[q] * p->density;
+                const float *v = &vel[q * 3];
+                float B[9];
+                for (int i = 0; i < 9; ++i) B[i] = (-dt * dinv) * taus[q * 9 + i] + Caff[q * 9 + i] * mass;
+                const float *frc = &forces[q * 3];
+                for (int i = 0; i < 3; ++i)
+                    for (int j = 0; j < 3; ++j)
+                        for (int kk = 0; kk < 3; ++kk) {
+                            const float xr[3] = {((float)i - fx[0]) * dx, ((float)j - fx[1]) * dx,
+                                                 ((float)kk - fx[2]) * dx};
+                            const float wt = w[i][0] * w[j][1] * w[kk][2];
+                            float val[4];
+                            val[0] = mass * wt;
+                            val[1] = v[0] * val[0];
+                            val[2] = v[1] * val[0];
+                            val[3] = v[2] * val[0];
+                            val[gax + 1] += val[0] * p->gravity * dt;
+                            val[1] += (B[0] * xr[0] + B[1] * xr[1] + B[2] * xr[2]) * wt;
+                            val[2] += (B[3] * xr[0] + B[4] * xr[1] + B[5] * xr[2]) * wt;
+                            val[3] += (B[6] * xr[0] + B[7] * xr[1] + B[8] * xr[2]) * wt;
+                            val[1] += frc[0] * dt * wt;
+                            val[2] += frc[1] * dt * wt;
+                            val[3] += frc[2] * dt * wt;
+                            const uint32_t c = orc_cell_index(base[0] + i, base[1] + j, base[2] + kk);
+                            flags[c >> 6] = 1;
+                            gm[c] += val[0];
+                            gmv[c * 3 + 0] += val[1];
+                            gmv[c * 3 + 1] += val[2];
+                            gmv[c * 3 + 2] += val[3];
+                        }
+            }
+        }
+    }
+    free(blk);
+    free(start);
+    free(order);
+}
+
 /* gather_touched_grid_kernel (:545-583): the reference compacts flagged blocks
  * in a nondeterministic order; the restatement emits them in ascending id. */
 ORC_API uint32_t orc_gather_touched(uint32_t n_blocks, const uint32_t *flags, uint32_t *ids) {

@@ -225,11 +225,14 @@ class OracleMpm:
                                             _cf(dt))
 
     # -- GpuMpmSolver::ParticleToGrid (cuda_mpm_solver.cu:86-105)
+    fast_scatter = False  # True: the multi-core variant (cpu_baseline only)
+
     def particle_to_grid(self, dt: float):
         if self.g_cnt > 0:
             self.L.orc_clean_grid(C.c_uint32(self.g_cnt * 64), _u(self.g_ids), _u(self.g_flags), _f(self.g_m),
                                   _f(self.g_mv))
-        self.L.orc_particle_to_grid(C.byref(self.p), C.c_size_t(self.n_particles), _f(self.pos), _f(self.vel),
+        fn = self.L.orc_particle_to_grid_colored if self.fast_scatter else self.L.orc_particle_to_grid
+        fn(C.byref(self.p), C.c_size_t(self.n_particles), _f(self.pos), _f(self.vel),
                                     _f(self.vol), _f(self.C), _f(self.forces), _f(self.taus), _u(self.g_flags),
                                     _f(self.g_m), _f(self.g_mv), _cf(dt))
 

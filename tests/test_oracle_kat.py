@@ -244,3 +244,19 @@ def test_dump_cpu_state_unpermutes():
     p1, i1 = o.dump_cpu_state()
     assert np.array_equal(p0, p1) and np.array_equal(i0, i1)
     assert not np.array_equal(o.pids, np.arange(o.n_particles))
+
+
+def test_colored_scatter_matches_plain_scatter():
+    """The multi-core scatter used for the CPU baseline is the same function up to summation order."""
+    a = orc.OracleMpm(6)
+    b = orc.OracleMpm(6)
+    _small_cloth(a)
+    _small_cloth(b)
+    b.fast_scatter = True
+    for _ in range(3):
+        a.substep(1e-3, -1)
+        b.substep(1e-3, -1)
+    assert np.array_equal(a.g_flags, b.g_flags)
+    assert np.max(np.abs(a.g_m - b.g_m)) <= 2e-6 * a.g_m.max()
+    assert np.max(np.abs(a.pos - b.pos)) <= 1e-6
+    assert np.max(np.abs(a.vel - b.vel)) <= 1e-5 * max(np.abs(a.vel).max(), 1e-2)
