@@ -32,6 +32,7 @@ struct PSet {
     float4* q[4];
     int* pid;      // slot -> original particle id ([faces | verts] order of Finalize)
     float4* fq[4];
+    int4* va[2];   // vertex (slot - Nf) -> up to 8 (face slot * 3 + corner) records, -1 = none, -2 in [0].x = use the CSR
 };
 
 MPM_DEV void unpack_C(const float4& q1, const float4& q2, const float4& q3, float* C) {
@@ -44,7 +45,7 @@ MPM_DEV void unpack_C(const float4& q1, const float4& q2, const float4& q3, floa
 // read back between kernels.
 struct Ctl {
     int cur;               // index of the current PSet
-    int need_rebuild;      // raised by P2G when a particle leaves the soft zone
+    int need_rebuild;      // raised by G2P when an advected particle no longer fits its block tile
     unsigned error;        // sticky ERR_* bits
     unsigned n_home;       // blocks owning particles (tiles)
     unsigned n_active;     // blocks whose nodes are updated
@@ -73,7 +74,6 @@ struct DP {
     float4* ab0;           // faces: tau = a (x) b with a = vol*P[:,2], b = F[:,2]: (a0, a1, a2, b0)
     float2* ab1;           //        (b1, b2)
     float4* G4;            // faces: G4[face slot * 3 + c] = force triple the face exerts on corner c (negated when applied)
-    int* vadj[8];          // vertex slot -> up to 8 (face slot * 3 + corner) records, -1 = none, -2 in [0] = use the CSR
     float* f[3];           // vertices: internal force
     // topology (original ids)
     const int* idx_orig[3];  // face -> original particle ids of its corners
@@ -84,6 +84,8 @@ struct DP {
     uint32_t* pkey;
     uint32_t* prank;
     uint32_t* src_of;      // sorted slot -> previous slot
+    int* dst_of;           // previous slot -> sorted slot
+    unsigned* tickets;     // 32 arrival counters, 128 bytes apart (k_rb_finish)
     int* cellcnt[2];       // [type][cell key]; zero outside a rebuild
     int* blkcnt[2];        // [type][block id]; zero outside a rebuild
     int* blkstart[2];
@@ -134,6 +136,12 @@ MPM_DEV int neighbor_block(uint32_t b, int o, int nb) {
 
 // base cell of a position (float -> uint conversion saturates at 0 like the
 // reference's CUDA cast, cuda_mpm_kernels.cuh:372-374)
+// Workgroups are dealt to the 8 XCDs round robin (blockIdx % 8), each XCD with its own L2.  The
+// streaming kernels gather mesh neighbours, which sit in nearby slots: give every XCD one
+// contiguous eighth of the index range so that shared lines are fetched into one L2, not eight.
+// Launch with a grid rounded up to a multiple of 8; chunks past the end are empty.
+MPM_DEV unsigned xcd_chunk(unsigned b, unsigned grid) { return (b & 7u) * (grid >> 3) + (b >> 3); }
+
 MPM_DEV uint32_t base_cell(float x, float dxinv) {
     const float t = x * dxinv - .5f;
     return t > 0.f ? (uint32_t)t : 0u;

@@ -87,12 +87,17 @@ static void launch_rebuild(mpm_engine* e) {
     hipLaunchKernelGGL(k_rb_count, dim3(e->g_np), dim3(256), 0, e->stream, p);
     hipLaunchKernelGGL(k_rb_tables, dim3(33), dim3(1024), 0, e->stream, p);
     hipLaunchKernelGGL(k_rb_scatter, dim3(e->g_np), dim3(256), 0, e->stream, p);
-    hipLaunchKernelGGL(k_rb_finish, dim3(std::min(e->g_np, 1024u)), dim3(256), 0, e->stream, p);
+    hipLaunchKernelGGL(k_rb_finish, dim3((std::min(e->g_np, 2048u) + 7u) & ~7u), dim3(256), 0, e->stream, p);
 }
+static void drop_step_graph(mpm_engine* e) {
+    if (e->step_graph) (void)hipGraphExecDestroy(e->step_graph);
+    e->step_graph = nullptr;
+}
+
 static void launch_fem(mpm_engine* e, float dt) {
     const DP& p = e->dp;
-    if (e->nf) hipLaunchKernelGGL(k_fem, dim3(e->g_nf), dim3(256), 0, e->stream, p, dt);
-    if (e->nv) hipLaunchKernelGGL(k_vforce, dim3(e->g_nv), dim3(256), 0, e->stream, p);
+    if (e->nf) hipLaunchKernelGGL(k_fem, dim3((e->g_nf + 7u) & ~7u), dim3(256), 0, e->stream, p, dt);
+    if (e->nv) hipLaunchKernelGGL(k_vforce, dim3((e->g_nv + 7u) & ~7u), dim3(256), 0, e->stream, p);
 }
 static void launch_p2g(mpm_engine* e, float dt) {
     hipLaunchKernelGGL(k_p2g, dim3(getenv("MPM_P2G_WGS") ? atoi(getenv("MPM_P2G_WGS")) : e->g_tile), dim3(512), 0, e->stream, e->dp, dt);
@@ -163,11 +168,11 @@ int mpm_finalize(mpm_handle_t e) {
         PSet& S = p.set[s];
         for (int d = 0; d < 4; ++d) { ALLOC(S.q[d], np, true); ALLOC(S.fq[d], nf, true); }
         ALLOC(S.pid, np, true);
+        for (int d = 0; d < 2; ++d) ALLOC(S.va[d], nv, true);
     }
     ALLOC(p.ab0, nf, true);
     ALLOC(p.ab1, nf, true);
     ALLOC(p.G4, 3 * nf, true);
-    for (int d = 0; d < 8; ++d) ALLOC(p.vadj[d], nv, true);
     for (int d = 0; d < 3; ++d) ALLOC(p.f[d], np, true);
     int* idx_orig[3];
     int *adj_off, *adj_fc;
@@ -179,6 +184,8 @@ int mpm_finalize(mpm_handle_t e) {
     ALLOC(p.pkey, np, false);
     ALLOC(p.prank, np, false);
     ALLOC(p.src_of, np, false);
+    ALLOC(p.dst_of, np, false);
+    ALLOC(p.tickets, 32 * 32, true);
     for (int t = 0; t < 2; ++t) {
         ALLOC(p.cellcnt[t], p.ncells, true);
         ALLOC(p.blkcnt[t], p.nblocks, true);
@@ -257,6 +264,7 @@ int mpm_finalize(mpm_handle_t e) {
 
     // ---- FEM initialisation (cuda_mpm_kernels.cuh:13-70) + first sort -----
     if (nf) hipLaunchKernelGGL(k_init_faces, dim3(e->g_nf), dim3(256), 0, e->stream, p);
+    if (nv) hipLaunchKernelGGL(k_init_vertex_adjacency, dim3(e->g_nv), dim3(256), 0, e->stream, p);
     if (nv) hipLaunchKernelGGL(k_init_vertex_volumes, dim3(e->g_nv), dim3(256), 0, e->stream, p);
     if (int rc2 = set_fixed_point_scales(e)) return rc2;
     Ctl c0{};
@@ -281,6 +289,7 @@ int mpm_destroy(mpm_handle_t e) {
     if (!e) return 0;
     hipSetDevice(e->device);
     if (e->own_stream) hipStreamSynchronize(e->own_stream);
+    drop_step_graph(e);
     for (void* a : e->allocs) hipFree(a);
     if (e->d_stage) hipFree(e->d_stage);
     e->cb.release();
@@ -421,15 +430,46 @@ int mpm_grid_to_particle(mpm_handle_t e, float dt) {
 
 int mpm_substep(mpm_handle_t e, float dt, int bc) { return mpm_run_substeps(e, 1, dt, bc); }
 
+static void launch_substep(mpm_engine* e, float dt, int bc) {
+    launch_rebuild(e);
+    launch_fem(e, dt);
+    launch_p2g(e, dt);
+    launch_grid(e, bc);
+    launch_g2p(e, dt);
+}
+
+// A substep is nine dependent kernels with constant arguments and no host decisions (the re-sort
+// is decided on the device), so a batch of substeps replays one captured graph: the graph's
+// kernel-to-kernel hand-over is cheaper than nine stream dispatches.
+static int step_graph_for(mpm_engine* e, float dt, int bc) {
+    if (e->step_graph && e->step_graph_dt == dt && e->step_graph_bc == bc && e->step_graph_stream == e->stream)
+        return 0;
+    drop_step_graph(e);
+    hipGraph_t g = nullptr;
+    HIP_TRY(hipStreamBeginCapture(e->stream, hipStreamCaptureModeThreadLocal));
+    for (int k = 0; k < e->step_graph_len; ++k) launch_substep(e, dt, bc);
+    HIP_TRY(hipStreamEndCapture(e->stream, &g));
+    const hipError_t err = hipGraphInstantiate(&e->step_graph, g, nullptr, nullptr, 0);
+    (void)hipGraphDestroy(g);
+    HIP_TRY(err);
+    e->step_graph_dt = dt;
+    e->step_graph_bc = bc;
+    e->step_graph_stream = e->stream;
+    return 0;
+}
+
 int mpm_run_substeps(mpm_handle_t e, int n, float dt, int bc) {
     READY(e);
-    for (int s = 0; s < n; ++s) {
-        launch_rebuild(e);
-        launch_fem(e, dt);
-        launch_p2g(e, dt);
-        launch_grid(e, bc);
-        launch_g2p(e, dt);
+    // MPM_GRAPH=<substeps per graph> replays captured graphs; measured slower than plain stream
+    // dispatch on ROCm 7.2, hence opt-in
+    static const int graph_len = getenv("MPM_GRAPH") ? atoi(getenv("MPM_GRAPH")) : 0;
+    int s = 0;
+    if (graph_len > 0 && n >= graph_len) {
+        e->step_graph_len = graph_len;
+        if (int rc = step_graph_for(e, dt, bc)) return rc;
+        for (; s + graph_len <= n; s += graph_len) HIP_TRY(hipGraphLaunch(e->step_graph, e->stream));
     }
+    for (; s < n; ++s) launch_substep(e, dt, bc);
     e->grid_state = 2;
     e->substeps += (uint64_t)std::max(n, 0);
     HIP_TRY(hipGetLastError());

@@ -52,6 +52,12 @@ struct mpm_engine {
     bool api_identity = true;
     int grid_state = 0;  // 0 nothing, 1 slabs valid (after P2G), 2 grid updated
     uint64_t substeps = 0;
+    // one captured substep (run_substeps replays it): launch arguments are all by-value constants
+    hipGraphExec_t step_graph = nullptr;
+    float step_graph_dt = 0.f;
+    int step_graph_bc = 0;
+    int step_graph_len = 1;
+    hipStream_t step_graph_stream = nullptr;
     int last_tile_kernel = 0;  // 1 = P2G, 2 = G2P (see launch_p2g)
     // launch geometry
     unsigned g_np = 0, g_nf = 0, g_nv = 0, g_tile = 0, g_grid = 0;

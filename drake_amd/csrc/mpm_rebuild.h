@@ -34,18 +34,23 @@ __global__ __launch_bounds__(256) void k_rb_count(DP p) {
     const int t = ii >= p.Nf;
     const uint32_t key = cell_key(bx, by, bz);
     const int lane = threadIdx.x & 63;
-    // a wave never straddles more than two types; handle them one after the other
-    uint32_t rank = 0;
+    // A wave straddles at most two types; handle them one after the other.  The atomics of all
+    // groups are issued back to back and their results are collected once, after the loops, so a
+    // wave pays one memory round trip instead of one per distinct cell.
+    int ret_cell = 0, ret_blk = 1, my_lead = lane;
+    unsigned long long my_same = 0ull;
+    bool blk_lead = false;
     for (int ty = 0; ty < 2; ++ty) {
         unsigned long long todo = __ballot(valid && t == ty);
         while (todo) {
             const int lead = __builtin_ctzll(todo);
             const uint32_t lk = (uint32_t)__shfl((int)key, lead);
             const unsigned long long same = __ballot(key == lk) & todo;
-            int base = 0;
-            if (lane == lead) base = atomicAdd(&p.cellcnt[ty][lk], (int)__popcll(same));
-            base = __shfl(base, lead);
-            if (same & (1ull << lane)) rank = (uint32_t)base + (uint32_t)__popcll(same & ((1ull << lane) - 1ull));
+            if (lane == lead) ret_cell = atomicAdd(&p.cellcnt[ty][lk], (int)__popcll(same));
+            if (same & (1ull << lane)) {
+                my_lead = lead;
+                my_same = same;
+            }
             todo &= ~same;
         }
         // block histogram, merged per wave in the same way
@@ -55,14 +60,16 @@ __global__ __launch_bounds__(256) void k_rb_count(DP p) {
             const uint32_t lb = (uint32_t)__shfl((int)(key >> 6), lead);
             const unsigned long long same = __ballot((key >> 6) == lb) & todo;
             if (lane == lead) {
-                // same-address device atomics serialise at ~30 ns each: only the first arrival
-                // of a (type, block) pair touches the non-empty bitmap
-                if (atomicAdd(&p.blkcnt[ty][lb], (int)__popcll(same)) == 0)
-                    atomicOr(&p.home_bits[lb >> 5], 1u << (lb & 31u));
+                ret_blk = atomicAdd(&p.blkcnt[ty][lb], (int)__popcll(same));
+                blk_lead = true;
             }
             todo &= ~same;
         }
     }
+    // same-address device atomics serialise at ~30 ns each: only the first arrival of a
+    // (type, block) pair touches the non-empty bitmap
+    if (blk_lead && ret_blk == 0) atomicOr(&p.home_bits[key >> 11], 1u << ((key >> 6) & 31u));
+    const uint32_t rank = (uint32_t)__shfl(ret_cell, my_lead) + (uint32_t)__popcll(my_same & ((1ull << lane) - 1ull));
     if (valid) {
         p.pkey[i] = key;
         p.prank[i] = rank;
@@ -316,6 +323,7 @@ __global__ __launch_bounds__(256) void k_rb_scatter(DP p) {
     // only the permutation is scattered (4 bytes per particle); the particle planes are moved by
     // k_rb_finish as a gather, whose writes are fully coalesced
     p.src_of[dst] = (uint32_t)i;
+    p.dst_of[i] = dst;
     p.imap[S.pid[i]] = dst;
 }
 
@@ -324,45 +332,35 @@ __global__ __launch_bounds__(256) void k_rb_scatter(DP p) {
 __global__ __launch_bounds__(256) void k_rb_finish(DP p) {
     Ctl* c = p.ctl;
     if (!c->need_rebuild) return;
-    const unsigned gs = gridDim.x * 256u, i0 = blockIdx.x * 256u + threadIdx.x;
+    const unsigned gs = gridDim.x * 256u, i0 = xcd_chunk(blockIdx.x, gridDim.x) * 256u + threadIdx.x;
     const PSet& S = p.set[c->cur];
     const PSet& D = p.set[c->cur ^ 1];
-    // move the particle records into their sorted slots (16-byte gathers, coalesced 16-byte stores)
+    // move the particle records into their sorted slots (16-byte gathers, coalesced 16-byte stores);
+    // every slot reference inside a record (face -> corner vertices, vertex -> adjacent face
+    // corners) is translated through dst_of, whose accesses stay local because mesh neighbours
+    // were neighbours in the old order too
+    auto moved = [&](int rec) { return rec < 0 ? rec : p.dst_of[(unsigned)rec / 3u] * 3 + (int)((unsigned)rec % 3u); };
     for (unsigned j = i0; j < (unsigned)p.Np; j += gs) {
         const unsigned i = p.src_of[j];
         const float4 a0 = S.q[0][i], a1 = S.q[1][i], a2 = S.q[2][i], a3 = S.q[3][i];
         const int pid = S.pid[i];
-        const bool face = j < (unsigned)p.Nf;
-        float4 b0, b1, b2, b3;
-        if (face) {
-            b0 = S.fq[0][i]; b1 = S.fq[1][i]; b2 = S.fq[2][i]; b3 = S.fq[3][i];
-            // corner vertices keep their original ids; their slots have just changed
-            b3.y = __int_as_float(p.imap[p.idx_orig[0][pid]]);
-            b3.z = __int_as_float(p.imap[p.idx_orig[1][pid]]);
-            b3.w = __int_as_float(p.imap[p.idx_orig[2][pid]]);
-        }
         D.q[0][j] = a0; D.q[1][j] = a1; D.q[2][j] = a2; D.q[3][j] = a3;
         D.pid[j] = pid;
-        if (face) {
+        if (j < (unsigned)p.Nf) {
+            const float4 b0 = S.fq[0][i], b1 = S.fq[1][i], b2 = S.fq[2][i];
+            float4 b3 = S.fq[3][i];
+            b3.y = __int_as_float(p.dst_of[__float_as_int(b3.y)]);
+            b3.z = __int_as_float(p.dst_of[__float_as_int(b3.z)]);
+            b3.w = __int_as_float(p.dst_of[__float_as_int(b3.w)]);
             D.fq[0][j] = b0; D.fq[1][j] = b1; D.fq[2][j] = b2; D.fq[3][j] = b3;
-        }
-    }
-    // per vertex slot, the (face slot, corner) records of its adjacent faces
-    for (unsigned k = i0; k < (unsigned)p.Nv; k += gs) {
-        const int vo = S.pid[p.src_of[p.Nf + k]] - p.Nf;
-        const int e0 = p.adj_off[vo], e1 = p.adj_off[vo + 1];
-        if (e1 - e0 > 8) {
-            p.vadj[0][k] = -2;
         } else {
-#pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                int rec = -1;
-                if (e0 + q < e1) {
-                    const int fc = p.adj_fc[e0 + q];
-                    rec = p.imap[fc >> 2] * 3 + (fc & 3);
-                }
-                p.vadj[q][k] = rec;
+            int4 r0 = S.va[0][i - p.Nf], r1 = S.va[1][i - p.Nf];
+            if (r0.x != -2) {
+                r0 = make_int4(moved(r0.x), moved(r0.y), moved(r0.z), moved(r0.w));
+                r1 = make_int4(moved(r1.x), moved(r1.y), moved(r1.z), moved(r1.w));
             }
+            D.va[0][j - p.Nf] = r0;
+            D.va[1][j - p.Nf] = r1;
         }
     }
     // every cell row of a home block holds prefix values now: clear whole rows
@@ -376,12 +374,22 @@ __global__ __launch_bounds__(256) void k_rb_finish(DP p) {
     }
     // The last workgroup to get here flips the particle sets.  Every thread has read `cur` and
     // `need_rebuild` by now; the end of the kernel makes the flip visible to the next one.
+    // All workgroups arrive within a few microseconds of each other and same-address device
+    // atomics serialise at ~60 ns each, so the count is taken in two levels: 32 counters (one
+    // cache line each) and a final one.
     __syncthreads();
-    if (threadIdx.x == 0 && atomicAdd(&c->ticket, 1u) == gridDim.x - 1) {
-        c->ticket = 0;
-        c->cur ^= 1;
-        c->need_rebuild = 0;
-        c->rebuilds += 1;
+    if (threadIdx.x == 0) {
+        const unsigned lanes = min(gridDim.x, 32u), grp = blockIdx.x & 31u;
+        const unsigned members = (gridDim.x - grp + 31u) / 32u;
+        if (atomicAdd(&p.tickets[grp * 32u], 1u) == members - 1u) {
+            p.tickets[grp * 32u] = 0;
+            if (atomicAdd(&c->ticket, 1u) == lanes - 1u) {
+                c->ticket = 0;
+                c->cur ^= 1;
+                c->need_rebuild = 0;
+                c->rebuilds += 1;
+            }
+        }
     }
 }
 

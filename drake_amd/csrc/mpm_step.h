@@ -14,7 +14,7 @@ namespace mpm {
 // FEM: one thread per face particle (slot order => coalesced face arrays).
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_fem(DP p, float dt) {
-    const unsigned i = blockIdx.x * 256 + threadIdx.x;
+    const unsigned i = xcd_chunk(blockIdx.x, gridDim.x) * 256 + threadIdx.x;
     if (i >= (unsigned)p.Nf) return;
     const PSet& S = p.set[p.ctl->cur];
     const float4 f0 = S.fq[0][i], f1 = S.fq[1][i], f2 = S.fq[2][i], f3 = S.fq[3][i];
@@ -85,13 +85,13 @@ __global__ __launch_bounds__(256) void k_fem(DP p, float dt) {
 // kept per vertex slot (refreshed at every rebuild) so that a vertex needs one coalesced index
 // load and one 16-byte gather per adjacent face.
 __global__ __launch_bounds__(256) void k_vforce(DP p) {
-    const int k = blockIdx.x * 256 + threadIdx.x;
+    const int k = (int)(xcd_chunk(blockIdx.x, gridDim.x) * 256 + threadIdx.x);
     if (k >= p.Nv) return;
     const int s = p.Nf + k;
     float f0 = 0.f, f1 = 0.f, f2 = 0.f;
-    int rec[8];
-#pragma unroll
-    for (int q = 0; q < 8; ++q) rec[q] = p.vadj[q][k];
+    const PSet& S = p.set[p.ctl->cur];
+    const int4 r0 = S.va[0][k], r1 = S.va[1][k];
+    const int rec[8] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w};
     if (rec[0] != -2) {
         float4 g[8];
 #pragma unroll
@@ -106,7 +106,6 @@ __global__ __launch_bounds__(256) void k_vforce(DP p) {
         }
     } else {
         // more than 8 faces around this vertex: walk the original adjacency
-        const PSet& S = p.set[p.ctl->cur];
         const int vo = S.pid[s] - p.Nf;
         for (int e = p.adj_off[vo]; e < p.adj_off[vo + 1]; ++e) {
             const int fc = p.adj_fc[e];
@@ -174,22 +173,6 @@ MPM_DEV void bspline_coeff(int a, bool on, float& c0, float& c1, float& c2) {
     c1 = a == 0 ? -1.5f : (a == 1 ? 2.f : -.5f);
     c2 = a == 1 ? -1.f : .5f;
     if (!on) c0 = c1 = c2 = 0.f;
-}
-
-// A re-sort is requested while every particle can still take one more substep inside its tile:
-// t = position in cells relative to the tile origin must stay in [0, TILE_W - 2) for the base cell
-// to be valid; the margin is twice the particle's current displacement per substep, at least half
-// a cell (so slow particles use almost the whole free zone, fast ones ask early).
-MPM_DEV bool soft_zone_exit(const DP& p, const float* x, const float* v, float dt, int ox, int oy, int oz) {
-    const int o[3] = {ox, oy, oz};
-    bool out = false;
-#pragma unroll
-    for (int d = 0; d < 3; ++d) {
-        const float t = x[d] * p.dxinv - .5f - (float)o[d];
-        const float margin = fmaxf(2.f * fabsf(v[d]) * dt * p.dxinv, .5f);
-        out |= (t - margin < 0.f) || (t + margin >= (float)(TILE_W - 2));
-    }
-    return out;
 }
 
 struct Stencil {
@@ -291,9 +274,9 @@ __global__ __launch_bounds__(512, 4) void k_p2g(DP p, float dt) {  // <= 128 VGP
         block_coords(p.home_block[h], bx, by, bz);
         const int ox = bx * 4 - FREE_ZONE, oy = by * 4 - FREE_ZONE, oz = bz * 4 - FREE_ZONE;
         const int4 rg = p.home_range[h];
-        const int nfb = rg.y - rg.x, total = nfb + (rg.w - rg.z);
+        const int nfb = rg.y - rg.x;
         unsigned mymask = 0;
-        bool soft = false, hard = false;
+        bool hard = false;
         // Every wave streams through its own groups of <= 64 particles; no workgroup barrier inside.
         // Groups are runs of whole cells (faces and vertices of the same cells together), laid out
         // at the last rebuild: a group usually spans two base cells.
@@ -366,7 +349,6 @@ __global__ __launch_bounds__(512, 4) void k_p2g(DP p, float dt) {  // <= 128 VGP
             }
             if (act) {
                 mymask |= st.mask27;
-                soft |= soft_zone_exit(p, cur.x, cur.v, dt, ox, oy, oz);
                 hard |= st.hard_out;
             }
             // the raw registers are dead now: start the next group's loads, they complete while this
@@ -492,7 +474,6 @@ __global__ __launch_bounds__(512, 4) void k_p2g(DP p, float dt) {  // <= 128 VGP
         if (prof && lane == 0)
             for (int q = 0; q < 8; ++q) atomicAdd(&p.dbgbuf[q], pc[q]);
         if (mymask) atomicOr(&s_mask, mymask);
-        if (__ballot(soft) && lane == 0) atomicOr(&ctl->need_rebuild, 1);
         if (__ballot(hard) && lane == 0) atomicOr(&ctl->error, ERR_DRIFT);
         __syncthreads();
         float4* out = p.slab + (size_t)h * TILE_N;
@@ -626,7 +607,7 @@ MPM_DEV void load_tile(const DP& p, unsigned h, float4* tile, const float4* fiel
     }
 }
 
-MPM_DEV void g2p_particle(const DP& p, const PSet& S, const float4* tile, unsigned i, float x, float y, float z,
+MPM_DEV bool g2p_particle(const DP& p, const PSet& S, const float4* tile, unsigned i, float x, float y, float z,
                              float vol, int ox, int oy, int oz, float dt) {
     const Stencil st = make_stencil(p, x, y, z, ox, oy, oz);
     float nv[3] = {0.f, 0.f, 0.f}, nC[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -656,7 +637,7 @@ MPM_DEV void g2p_particle(const DP& p, const PSet& S, const float4* tile, unsign
     }
     if (diag_flags(p) & 256) {  // ablation: no stores
         if (nv[0] + nC[0] + nC[4] + nC[8] == 1.2345e30f) S.q[1][i].x = nv[0];
-        return;
+        return false;
     }
     const float sc = 4.f * p.dxinv;
     const float ca = (p.M.V + 1.f) * .5f, cb = (p.M.V - 1.f) * .5f;
@@ -666,10 +647,18 @@ MPM_DEV void g2p_particle(const DP& p, const PSet& S, const float4* tile, unsign
 #pragma unroll
         for (int c = 0; c < 3; ++c) Cn[r * 3 + c] = ca * (sc * nC[r * 3 + c]) + cb * (sc * nC[c * 3 + r]);
     // four 16-byte stores per particle
-    S.q[0][i] = make_float4(x + nv[0] * dt, y + nv[1] * dt, z + nv[2] * dt, vol);
+    const float xn = x + nv[0] * dt, yn = y + nv[1] * dt, zn = z + nv[2] * dt;
+    S.q[0][i] = make_float4(xn, yn, zn, vol);
     S.q[1][i] = make_float4(nv[0], nv[1], nv[2], Cn[8]);
     S.q[2][i] = make_float4(Cn[0], Cn[1], Cn[2], Cn[3]);
     S.q[3][i] = make_float4(Cn[4], Cn[5], Cn[6], Cn[7]);
+    // Does the advected particle still fit this block's tile?  Vertices are tested where the next
+    // P2G will find them; a face is re-centred on its corners by the FEM kernel first, which moves
+    // it by O(dt * velocity spread inside the face), hence the 1/8-cell guard band.
+    const float guard = .125f, top = (float)(TILE_W - 2) - guard;
+    const float tx = xn * p.dxinv - .5f - (float)ox, ty = yn * p.dxinv - .5f - (float)oy,
+                tz = zn * p.dxinv - .5f - (float)oz;
+    return !(tx >= guard && tx < top && ty >= guard && ty < top && tz >= guard && tz < top);
 }
 
 constexpr int G2P_THREADS = 512;
@@ -691,6 +680,7 @@ __global__ __launch_bounds__(G2P_THREADS) void k_g2p(DP p, float dt) {
         // the first positions are requested before the tile is staged, later ones one iteration
         // ahead, so the HBM latency of the particle stream hides behind LDS work
         int u = (int)threadIdx.x;
+        bool left = false;
         unsigned i = slot_of(u < total ? u : 0);
         float4 pq = S.q[0][i];
         load_tile(p, h, tile, p.gv, G2P_THREADS);
@@ -708,8 +698,11 @@ __global__ __launch_bounds__(G2P_THREADS) void k_g2p(DP p, float dt) {
                 i = slot_of(un);
                 pq = S.q[0][i];
             }
-            g2p_particle(p, S, tile, ci, c.x, c.y, c.z, c.w, ox, oy, oz, dt);
+            left |= g2p_particle(p, S, tile, ci, c.x, c.y, c.z, c.w, ox, oy, oz, dt);
         }
+        // a plain store: the flag only ever goes 0 -> 1 inside this kernel (same-address atomics
+        // from thousands of waves would serialise at the memory side)
+        if (__ballot(left) && (threadIdx.x & 63) == 0) p.ctl->need_rebuild = 1;
         if (prof && (threadIdx.x & 63) == 0) {
             const unsigned long long t2 = __builtin_readcyclecounter();
             atomicAdd(&p.dbgbuf[8], t1 - t0);
