@@ -23,13 +23,34 @@ import numpy as np  # noqa: E402
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
+# kernel names as rocprofv3 prints them, per phase of mpm_profile_substeps
+KERNEL_OF = dict(fem="mpm::k_fem", vforce="mpm::k_vforce", p2g="mpm::k_p2g", grid="mpm::k_grid<1>", g2p="mpm::k_g2p")
+
+
 def algorithmic_bytes(np_, nf, nv, ncells):
-    """bytes one substep has to move, fp32, one pass per phase."""
-    fem = 200 * nf + 36 * nv
+    """bytes one substep has to move, fp32, one pass per phase.
+    The reference's FEM kernel (200 B/face + 36 B/vertex) is two kernels here."""
+    fem = 200 * nf
+    vforce = 36 * nv
     p2g = 116 * np_ + 16 * ncells
     grid = 40 * ncells
     g2p = 72 * np_ + 12 * ncells
-    return dict(fem=fem, p2g=p2g, grid=grid, g2p=g2p, total=fem + p2g + grid + g2p)
+    return dict(fem=fem, vforce=vforce, p2g=p2g, grid=grid, g2p=g2p, total=fem + vforce + p2g + grid + g2p)
+
+
+def measured_traffic(kernel, config):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes of this same
+    command (profiles/pmc_traffic.json, written by scripts/pmc_summary.py: FETCH_SIZE doubled per
+    MI355X_MICROARCH.md's gfx950 correction + WRITE_SIZE, KiB -> bytes), or None."""
+    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    try:
+        with open(path) as f:
+            t = json.load(f)
+        if t.get("config") != config:
+            return None
+        return float(t["kernels"][kernel]["hbm_bytes_per_launch"])
+    except (OSError, KeyError, ValueError):
+        return None
 
 
 def cpu_baseline(domain_bits, layers, res, dt, budget_s=20.0):
@@ -65,8 +86,8 @@ def cpu_baseline(domain_bits, layers, res, dt, budget_s=20.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=400)
-    ap.add_argument("--warmup", type=int, default=40)
+    ap.add_argument("--steps", type=int, default=200)   # 200 substeps ...
+    ap.add_argument("--warmup", type=int, default=20)  # ... after 20 warm-up
     ap.add_argument("--config", default="cloth_1m")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=20.0)
@@ -137,15 +158,26 @@ def main():
     st = g.stats()
     assert st["error_flags"] == 0, st
 
-    # per-kernel timing with HIP events on the engine's stream (separate, un-timed pass)
-    phases, tot_ms = g.profile_substeps(min(args.steps, 200), dt, -1)
+    # per-kernel timing with HIP events on the engine's stream: a separate, un-timed pass over the
+    # SAME substeps (fresh engine, same scene, same warm-up), so that the kernel durations describe
+    # the timed region and not whatever the cloth does after it
+    if world == 1:
+        g.destroy()
+        g = GpuMpm(bits, device=local_rank)
+        scenes.populate(g, scenes.cloth_stack(layers, res, bits, seed=1234 + rank))
+        g.run_substeps(args.warmup, dt, -1)
+        g.gpu_sync()
+    phases, tot_ms = g.profile_substeps(min(args.steps, 4096), dt, -1)
     g.gpu_sync()
+    st = g.stats()
+    assert st["error_flags"] == 0, st
     ncells = 64 * st["touched_blocks"]
     ab = algorithmic_bytes(npart, nf, nv, ncells)
-    dom = max(("fem", "p2g", "grid", "g2p"), key=lambda k: phases[k])
+    dom = max(KERNEL_OF, key=lambda k: phases[k])
     ach = ab[dom] / (phases[dom] * 1e-3) / 1e9
-    roofline = dict(bound="hbm", kernel=dom, achieved=ach, peak=HBM_PEAK_GBS, unit="GB/s", frac=ach / HBM_PEAK_GBS,
-                    traffic=None, algorithmic_bytes_per_launch=ab[dom], kernel_ms=phases[dom],
+    roofline = dict(bound="hbm", kernel=KERNEL_OF[dom], achieved=ach, peak=HBM_PEAK_GBS, unit="GB/s",
+                    frac=ach / HBM_PEAK_GBS, traffic=measured_traffic(KERNEL_OF[dom], args.config),
+                    algorithmic_bytes_per_launch=ab[dom], kernel_ms=phases[dom],
                     substep_achieved=ab["total"] / (el / args.steps) / 1e9,
                     substep_frac=ab["total"] / (el / args.steps) / 1e9 / HBM_PEAK_GBS, phase_ms=phases)
 

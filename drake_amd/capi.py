@@ -43,7 +43,7 @@ class ARR:
     GRID_TOUCHED_FLAGS, GRID_TOUCHED_IDS, CONTACT_VEL, CONTACT_VEL0, GRID_DIR = range(15, 20)
 
 
-PHASES = ("rebuild", "fem", "p2g", "grid", "g2p")
+PHASES = ("rebuild", "fem", "vforce", "p2g", "grid", "g2p")
 
 # every symbol include/mpm_hip.h declares (checked by tests/test_capi_symbols.py)
 SYMBOLS = [

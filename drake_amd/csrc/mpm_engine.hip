@@ -94,10 +94,15 @@ static void drop_step_graph(mpm_engine* e) {
     e->step_graph = nullptr;
 }
 
+static void launch_fem_faces(mpm_engine* e, float dt) {
+    if (e->nf) hipLaunchKernelGGL(k_fem, dim3((e->g_nf + 7u) & ~7u), dim3(256), 0, e->stream, e->dp, dt);
+}
+static void launch_fem_vertices(mpm_engine* e) {
+    if (e->nv) hipLaunchKernelGGL(k_vforce, dim3((e->g_nv + 7u) & ~7u), dim3(256), 0, e->stream, e->dp);
+}
 static void launch_fem(mpm_engine* e, float dt) {
-    const DP& p = e->dp;
-    if (e->nf) hipLaunchKernelGGL(k_fem, dim3((e->g_nf + 7u) & ~7u), dim3(256), 0, e->stream, p, dt);
-    if (e->nv) hipLaunchKernelGGL(k_vforce, dim3((e->g_nv + 7u) & ~7u), dim3(256), 0, e->stream, p);
+    launch_fem_faces(e, dt);
+    launch_fem_vertices(e);
 }
 static void launch_p2g(mpm_engine* e, float dt) {
     hipLaunchKernelGGL(k_p2g, dim3(getenv("MPM_P2G_WGS") ? atoi(getenv("MPM_P2G_WGS")) : e->g_tile), dim3(512), 0, e->stream, e->dp, dt);
@@ -487,19 +492,21 @@ int mpm_profile_substeps(mpm_handle_t e, int n, float dt, int bc, float* phase_m
         HIP_TRY(hipEventRecord(q[0], e->stream));
         launch_rebuild(e);
         HIP_TRY(hipEventRecord(q[1], e->stream));
-        launch_fem(e, dt);
+        launch_fem_faces(e, dt);
         HIP_TRY(hipEventRecord(q[2], e->stream));
-        launch_p2g(e, dt);
+        launch_fem_vertices(e);
         HIP_TRY(hipEventRecord(q[3], e->stream));
-        launch_grid(e, bc);
+        launch_p2g(e, dt);
         HIP_TRY(hipEventRecord(q[4], e->stream));
-        launch_g2p(e, dt);
+        launch_grid(e, bc);
         HIP_TRY(hipEventRecord(q[5], e->stream));
+        launch_g2p(e, dt);
+        HIP_TRY(hipEventRecord(q[6], e->stream));
     }
     e->grid_state = 2;
     e->substeps += (uint64_t)n;
     HIP_TRY(hipStreamSynchronize(e->stream));
-    double acc[MPM_PHASE_COUNT] = {0, 0, 0, 0, 0}, tot = 0;
+    double acc[MPM_PHASE_COUNT] = {}, tot = 0;
     for (int s = 0; s < n; ++s) {
         hipEvent_t* q = &ev[(size_t)s * NE];
         for (int k = 0; k < MPM_PHASE_COUNT; ++k) {

@@ -29,7 +29,11 @@ __global__ __launch_bounds__(256) void k_rb_count(DP p) {
     const uint32_t hi = (uint32_t)((1 << p.bits) - 3);
     const float4 xq = S.q[0][ii];
     uint32_t bx = base_cell(xq.x, p.dxinv), by = base_cell(xq.y, p.dxinv), bz = base_cell(xq.z, p.dxinv);
-    if (valid && (bx > hi || by > hi || bz > hi)) atomicOr(&p.ctl->error, ERR_DOMAIN);
+    // (a negative coordinate saturates to cell 0 in the conversion, so test the float)
+    const float lim = (float)(hi + 1u);
+    auto inside = [&](float x) { const float t = x * p.dxinv - .5f; return t >= 0.f && t < lim; };
+    if (valid && !(inside(xq.x) && inside(xq.y) && inside(xq.z)) && !(p.ctl->error & ERR_DOMAIN))
+        atomicOr(&p.ctl->error, ERR_DOMAIN);
     bx = min(bx, hi); by = min(by, hi); bz = min(bz, hi);
     const int t = ii >= p.Nf;
     const uint32_t key = cell_key(bx, by, bz);

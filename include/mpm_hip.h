@@ -97,11 +97,12 @@ typedef enum {
 /* Timed phases reported by mpm_profile_substeps. */
 enum {
     MPM_PHASE_REBUILD = 0,
-    MPM_PHASE_FEM = 1,
-    MPM_PHASE_P2G = 2,
-    MPM_PHASE_GRID = 3,
-    MPM_PHASE_G2P = 4,
-    MPM_PHASE_COUNT = 5
+    MPM_PHASE_FEM = 1,     /* per-face kernel of CalcFemStateAndForce */
+    MPM_PHASE_VFORCE = 2,  /* its per-vertex force gather */
+    MPM_PHASE_P2G = 3,
+    MPM_PHASE_GRID = 4,
+    MPM_PHASE_G2P = 5,
+    MPM_PHASE_COUNT = 6
 };
 
 typedef struct {
