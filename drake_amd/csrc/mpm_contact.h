@@ -7,12 +7,14 @@
 #include <vector>
 
 #include "mpm_host.h"
+#include "mpm_sort.h"
 
 template <class T>
 static int grow(T** ptr, size_t n) {
     if (*ptr) HIP_TRY(hipFree(*ptr));
     *ptr = nullptr;
     HIP_TRY(hipMalloc((void**)ptr, std::max<size_t>(n, 1) * sizeof(T)));
+    if (mpm_engine::poison()) HIP_TRY(hipMemset(*ptr, 0xFF, std::max<size_t>(n, 1) * sizeof(T)));
     return 0;
 }
 
@@ -23,22 +25,34 @@ static int copy_contacts(mpm_engine* e, size_t n, const uint32_t* particle, cons
     b.n = n;
     if (n == 0) return 0;
     for (size_t k = 0; k < n; ++k) REQUIRE(particle[k] < e->np, "contact particle index out of range");
+    for (size_t k = 0; k < n; ++k) REQUIRE(body[k] < std::max<size_t>(b.n_bodies, 1), "contact body index out of range");
     if (n > b.cap) {
         const size_t cap = n + n / 4;
         int rc;
         if ((rc = grow(&b.slot, cap)) || (rc = grow(&b.body, cap)) || (rc = grow(&b.dist, cap)) ||
             (rc = grow(&b.normal, 3 * cap)) || (rc = grow(&b.pos, 3 * cap)) || (rc = grow(&b.rigid_v, 3 * cap)) ||
             (rc = grow(&b.p_WB, 3 * cap)) || (rc = grow(&b.vel, 3 * cap)) || (rc = grow(&b.vel0, 3 * cap)) ||
-            (rc = grow(&b.cnode, 27 * cap)) || (rc = grow(&b.cfx, 3 * cap)) || (rc = grow(&b.cmass, cap)) ||
-            (rc = grow(&b.cHG, 12 * cap)) || (rc = grow(&b.entries, 27 * cap)))
+            (rc = grow(&b.key, cap)) || (rc = grow(&b.order, cap)) || (rc = grow(&b.key2, cap)) ||
+            (rc = grow(&b.order2, cap)) || (rc = grow(&b.cnode, 27 * cap)) || (rc = grow(&b.cfx, 3 * cap)) ||
+            (rc = grow(&b.cmass, cap)) || (rc = grow(&b.cphi0, cap)) || (rc = grow(&b.cR, 9 * cap)) ||
+            (rc = grow(&b.cv0, 3 * cap)) || (rc = grow(&b.crv, 3 * cap)) || (rc = grow(&b.cvel, 3 * cap)) ||
+            (rc = grow(&b.cHG, 12 * cap)))
             return rc;
         b.cap = cap;
     }
+    {
+        const int items = sort_items_for(n);
+        const size_t tiles = (n + (size_t)64 * items - 1) / ((size_t)64 * items);
+        if (256 * tiles > b.cap_hist) {
+            if (int rc = grow(&b.sort_hist, 256 * tiles + 256)) return rc;
+            b.cap_hist = 256 * tiles + 256;
+        }
+    }
     const size_t cells = (size_t)e->dp.capA * 64;
-    if (!b.node_start || b.cap_cells < cells) {
+    if (!b.run || b.cap_cells < cells) {
         int rc;
-        if ((rc = grow(&b.node_start, cells + 1)) || (rc = grow(&b.node_fill, cells + 1)) || (rc = grow(&b.gD, cells)) ||
-            (rc = grow(&b.part, (size_t)3 * CT_MAX_WG * CT_PART)) || (rc = grow(&b.st, 1)))
+        if ((rc = grow(&b.run, cells)) || (rc = grow(&b.node_flag, cells)) || (rc = grow(&b.node_list, cells)) ||
+            (rc = grow(&b.gD, cells)) || (rc = grow(&b.part, (size_t)3 * CT_ROWS * CT_PART)) || (rc = grow(&b.st, 1)))
             return rc;
         b.cap_cells = cells;
     }
@@ -74,10 +88,12 @@ static ContactDev make_contact_dev(mpm_engine* e, float dt, float mu, float k, f
     c.tol = 1e-4f;    // kTol, cuda_mpm_solver.cu:236
     c.slot = b.slot; c.body = b.body; c.dist = b.dist; c.normal = b.normal; c.pos = b.pos;
     c.rigid_v = b.rigid_v; c.p_WB = b.p_WB; c.vel = b.vel; c.vel0 = b.vel0;
-    c.cnode = b.cnode; c.cfx = b.cfx; c.cmass = b.cmass; c.cHG = b.cHG;
-    c.node_start = b.node_start; c.node_fill = b.node_fill; c.entries = b.entries; c.gD = b.gD;
-    c.part = b.part; c.part_wg = CT_MAX_WG; c.st = b.st;
-    c.body_tau = b.body_tau; c.body_f = b.body_f;
+    c.key = b.key; c.order = b.order;
+    c.cnode = b.cnode; c.cfx = b.cfx; c.cmass = b.cmass; c.cphi0 = b.cphi0; c.cR = b.cR; c.cv0 = b.cv0;
+    c.crv = b.crv; c.cvel = b.cvel; c.cHG = b.cHG;
+    c.run = b.run; c.node_flag = b.node_flag; c.node_list = b.node_list; c.gD = b.gD;
+    c.part = b.part; c.st = b.st;
+    c.body_tau = b.body_tau; c.body_f = b.body_f; c.n_bodies = (int)b.n_bodies;
     return c;
 }
 
@@ -94,17 +110,24 @@ static int update_contact(mpm_engine* e, int frame, int substep, float dt, float
     const DP& p = e->dp;
     hipStream_t s = e->stream;
     const unsigned gc = (unsigned)((n + 255) / 256);
-    const unsigned gcs = std::min(gc, (unsigned)CT_MAX_WG);   // grid-stride contact kernels
-    const unsigned gg = 512;                                   // grid-stride cell kernels
-    // ---- set-up: stencils and the node -> contacts adjacency ----------------------
-    HIP_TRY(hipMemsetAsync(b.node_fill, 0, ((size_t)p.capA * 64 + 1) * 4, s));
+    const int n_con_wg = (int)std::min(gc, (unsigned)CT_ROWS);  // grid-stride contact part of k_ct_ls
+    const int n_grid_wg = CT_ROWS;                               // grid-stride cell part
+    const int n_dir_wg = CT_ROWS;
+    // ---- set-up: contacts in base-cell order, per-cell runs, nodes that see contacts ---------
     HIP_TRY(hipMemsetAsync(b.st, 0, sizeof(ContactState), s));
-    hipLaunchKernelGGL(k_ct_stencil, dim3(gc), dim3(256), 0, s, p, c);
-    hipLaunchKernelGGL(k_ct_scan, dim3(1), dim3(1024), 0, s, p, c);
-    hipLaunchKernelGGL(k_ct_fill, dim3(gc), dim3(256), 0, s, p, c);
-    hipLaunchKernelGGL(k_ct_sort_lists, dim3(gg), dim3(256), 0, s, p, c);
+    hipLaunchKernelGGL(k_ct_keys, dim3(1024), dim3(256), 0, s, p, c);
+    {
+        int bits = 1;
+        while (((size_t)1 << bits) < (size_t)p.capA * 64) ++bits;
+        // CT_NO_CELL has all those bits set and more: it sorts behind every real cell as long as
+        // one more bit takes part
+        if (radix_sort_pairs(s, b.key, b.order, b.key2, b.order2, b.sort_hist, n, std::min(bits + 1, 31)))
+            return fail(MPM_ERR_HIP, "contact sort failed");
+    }
+    hipLaunchKernelGGL(k_ct_prepare, dim3(gc), dim3(256), 0, s, p, c);
+    hipLaunchKernelGGL(k_ct_node_list, dim3(1), dim3(1024), 0, s, p, c);
     // pre-contact velocity at the contact points (cuda_mpm_solver.cu:267-272)
-    hipLaunchKernelGGL(k_ct_gather_vel, dim3(gc), dim3(256), 0, s, p, c, b.vel0, 0);
+    hipLaunchKernelGGL(k_ct_gather_vel, dim3(gc), dim3(256), 0, s, p, c, b.vel0);
 
     std::vector<float> s_res, s_energy;
     std::vector<int> s_ls;
@@ -119,12 +142,10 @@ static int update_contact(mpm_engine* e, int frame, int substep, float dt, float
             for (int q = 0; q < batch; ++q) {
                 const int first = (iters + q) == 0;
                 hipLaunchKernelGGL(k_ct_contact_grad, dim3(gc), dim3(256), 0, s, p, c, first);
-                hipLaunchKernelGGL(k_ct_node_dir, dim3(gg), dim3(CT_WG), 0, s, p, c);
-                hipLaunchKernelGGL(k_ct_ls_contact, dim3(gcs), dim3(CT_WG), 0, s, p, c, 0, 0.f);
-                hipLaunchKernelGGL(k_ct_ls_grid, dim3(gg), dim3(CT_WG), 0, s, p, c, 0, 0.f);
-                hipLaunchKernelGGL(k_ct_decide, dim3(1), dim3(64), 0, s, c, (int)gg, (int)gcs, (int)gg, 0);
-                hipLaunchKernelGGL(k_ct_apply, dim3(gg), dim3(CT_WG), 0, s, p, c);
-                hipLaunchKernelGGL(k_ct_latch, dim3(1), dim3(64), 0, s, c);
+                hipLaunchKernelGGL(k_ct_node_dir, dim3(n_dir_wg), dim3(CT_WG), 0, s, p, c);
+                hipLaunchKernelGGL(k_ct_ls, dim3(n_con_wg + n_grid_wg), dim3(CT_WG), 0, s, p, c, n_con_wg, 0, 0.f);
+                hipLaunchKernelGGL(k_ct_decide, dim3(1), dim3(1024), 0, s, c, n_dir_wg, n_con_wg, n_grid_wg, 0);
+                hipLaunchKernelGGL(k_ct_apply, dim3(n_dir_wg), dim3(CT_WG), 0, s, p, c);
             }
             iters += batch;
             HIP_TRY(hipMemcpyAsync(&st, b.st, sizeof(ContactState), hipMemcpyDeviceToHost, s));
@@ -138,9 +159,8 @@ static int update_contact(mpm_engine* e, int frame, int substep, float dt, float
         // exactly like cuda_mpm_solver.cu:383-471 (itself a clone of Drake's
         // DoNewtonWithBisectionFallback)
         auto probe = [&](float alpha, std::tuple<float, float, float>* out) -> int {
-            hipLaunchKernelGGL(k_ct_ls_contact, dim3(gcs), dim3(CT_WG), 0, s, p, c, 1, alpha);
-            hipLaunchKernelGGL(k_ct_ls_grid, dim3(gg), dim3(CT_WG), 0, s, p, c, 1, alpha);
-            hipLaunchKernelGGL(k_ct_decide, dim3(1), dim3(64), 0, s, c, (int)gg, (int)gcs, (int)gg, 1);
+            hipLaunchKernelGGL(k_ct_ls, dim3(n_con_wg + n_grid_wg), dim3(CT_WG), 0, s, p, c, n_con_wg, 1, alpha);
+            hipLaunchKernelGGL(k_ct_decide, dim3(1), dim3(1024), 0, s, c, n_dir_wg, n_con_wg, n_grid_wg, 1);
             HIP_TRY(hipMemcpyAsync(&st, b.st, sizeof(ContactState), hipMemcpyDeviceToHost, s));
             HIP_TRY(hipStreamSynchronize(s));
             *out = std::make_tuple((float)st.scal[0], (float)st.scal[1], (float)st.scal[2]);
@@ -150,7 +170,7 @@ static int update_contact(mpm_engine* e, int frame, int substep, float dt, float
         const float f_tol = 1e-8f, x_tol = f_tol * c.relax;
         while (residual > c.tol && iters < max_iters) {
             hipLaunchKernelGGL(k_ct_contact_grad, dim3(gc), dim3(256), 0, s, p, c, iters == 0);
-            hipLaunchKernelGGL(k_ct_node_dir, dim3(gg), dim3(CT_WG), 0, s, p, c);
+            hipLaunchKernelGGL(k_ct_node_dir, dim3(n_dir_wg), dim3(CT_WG), 0, s, p, c);
             std::tuple<float, float, float> f_lo, f_hi, f_root;
             int rc;
             if ((rc = probe(0.f, &f_lo)) || (rc = probe(1.f, &f_hi))) return rc;
@@ -195,7 +215,7 @@ static int update_contact(mpm_engine* e, int frame, int substep, float dt, float
                 ls += 1;
             }
             HIP_TRY(hipMemcpyAsync(&b.st->alpha, &alpha, 4, hipMemcpyHostToDevice, s));
-            hipLaunchKernelGGL(k_ct_apply, dim3(gg), dim3(CT_WG), 0, s, p, c);
+            hipLaunchKernelGGL(k_ct_apply, dim3(n_dir_wg), dim3(CT_WG), 0, s, p, c);
             residual = std::sqrt(st.norm_dir_sq) / st.dofs;
             iters += 1;
             s_res.push_back(residual);
@@ -204,8 +224,8 @@ static int update_contact(mpm_engine* e, int frame, int substep, float dt, float
         }
     }
     // contact velocities after the solve and the reaction on the rigid bodies
-    hipLaunchKernelGGL(k_ct_gather_vel, dim3(gc), dim3(256), 0, s, p, c, b.vel, 0);
-    hipLaunchKernelGGL(k_ct_impulse, dim3(gc), dim3(256), 0, s, c);
+    hipLaunchKernelGGL(k_ct_gather_vel, dim3(gc), dim3(256), 0, s, p, c, b.vel);
+    hipLaunchKernelGGL(k_ct_impulse, dim3(std::min(gc, 256u)), dim3(256), 0, s, c);
     HIP_TRY(hipGetLastError());
     if (iters_out) *iters_out = iters;
     if (residual_out) *residual_out = residual;

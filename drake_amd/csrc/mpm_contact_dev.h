@@ -5,9 +5,13 @@
 // Differences in organisation from the reference (same arithmetic):
 //   - the contact -> node scatter of Hessians/gradients (12 float atomics x 27
 //     nodes per contact per iteration, cuda_mpm_kernels.cuh:1184-1212) is a
-//     gather: contact positions are fixed during the solve, so a node -> contacts
-//     adjacency (CSR) is built once per UpdateContact and every Newton iteration
-//     sums each node's list in a fixed order;
+//     gather.  Contact positions are fixed during the solve, so once per
+//     UpdateContact the contacts are sorted by the cell of their stencil base
+//     (stable radix sort, mpm_sort.h).  A node then finds all its contacts as
+//     the contiguous runs of its 27 neighbour cells and sums them in that fixed
+//     order, 16 lanes per node; the weights are recomputed from the contact's
+//     fractional position, so there is no per-(node, contact) adjacency in memory;
+//   - all per-contact work arrays live in that sorted order (coalesced);
 //   - the backtracking line search evaluates all 28 step lengths 1, 1/2, ...,
 //     2^-27 in one pass and picks the first acceptable one on the device, so an
 //     iteration needs no host round trip (the reference syncs >= 3 times);
@@ -22,12 +26,15 @@ namespace mpm {
 
 constexpr int LS_CAND = 28;          // alpha = 2^-j, j = 0..27 (alpha < 1e-8 is accepted as is)
 constexpr int CT_PART = LS_CAND + 4; // partial record: E1[28], E0, norm_dir, dofs, pad
+constexpr int CT_WG = 256;           // threads per workgroup of the contact kernels
+constexpr int CT_ROWS = 256;         // partial-sum records per kind (= max workgroups of the reducing kernels)
+constexpr uint32_t CT_NO_CELL = 0x7FFFFFFFu;  // sort key of a contact whose base cell is outside the active grid
 
 struct ContactState {       // device-resident solver state
-    int done;               // converged or iteration cap reached
+    int done;               // 0 running, 2 finish after this update, 1 finished
     int iters;
     int ls_total;           // accumulated line-search evaluations (statistics)
-    int pad;
+    int n_nodes;            // nodes that see at least one contact
     float alpha;            // step accepted in the current iteration
     float residual;         // sqrt(sum |Dir|^2) / DoFs
     float energy;
@@ -42,23 +49,32 @@ struct ContactDev {
     int n;                  // contacts
     int max_iters;
     float dt, mu, k, d, epsv, relax, tol;
+    // as handed over by CopyContactPairs (contact order of the caller)
     const uint32_t* slot;   // internal particle slot
     const uint32_t* body;
     const float *dist, *normal, *pos, *rigid_v, *p_WB;
-    float *vel, *vel0;
-    int* cnode;             // [27][n] compact grid index (active slot * 64 + cell) or -1
+    float *vel, *vel0;      // contact_vel / contact_vel0, caller's order
+    // sorted by base cell (position j <-> caller's contact order[j])
+    uint32_t* key;          // [n] compact base cell (active slot * 64 + cell) or CT_NO_CELL
+    uint32_t* order;        // [n]
+    int* cnode;             // [27][n] compact grid index of the stencil nodes or -1
     float* cfx;             // [3][n]
     float* cmass;           // [n]
+    float* cphi0;           // [n]
+    float* cR;              // [9][n] world -> contact frame
+    float* cv0;             // [3][n] lagged relative velocity, contact frame
+    float* crv;             // [3][n] rigid velocity at the contact point
+    float* cvel;            // [3][n] contact velocity (sorted order)
     float* cHG;             // [12][n] world-frame mass-weighted Hessian (9) and gradient (3)
-    int* node_start;        // [cells + 1] CSR over compact grid cells
-    int* node_fill;
-    int2* entries;          // (contact, weight bits)
+    int2* run;              // [cells] (begin, end) of the contacts whose base cell this is
+    int* node_flag;         // [cells] 1 if some contact's stencil reaches the node
+    int* node_list;         // [<= cells] those nodes
     float4* gD;             // [cells] search direction (relaxed)
-    double* part;           // [workgroups][CT_PART]
-    int part_wg;            // number of partial records of one kind
+    double* part;           // [3][CT_ROWS][CT_PART]
     ContactState* st;
     float* body_tau;
     float* body_f;
+    int n_bodies;
 };
 
 struct ContactBuffers {
@@ -75,13 +91,15 @@ struct ContactBuffers {
     float* p_WB = nullptr;
     float* vel = nullptr;       // contact_vel
     float* vel0 = nullptr;      // contact_vel0
+    uint32_t *key = nullptr, *order = nullptr, *key2 = nullptr, *order2 = nullptr;
+    int* sort_hist = nullptr;
+    size_t cap_hist = 0;
     int* cnode = nullptr;
-    float* cfx = nullptr;
-    float* cmass = nullptr;
-    float* cHG = nullptr;
-    int2* entries = nullptr;
-    int* node_start = nullptr;
-    int* node_fill = nullptr;
+    float *cfx = nullptr, *cmass = nullptr, *cphi0 = nullptr, *cR = nullptr, *cv0 = nullptr, *crv = nullptr,
+          *cvel = nullptr, *cHG = nullptr;
+    int2* run = nullptr;
+    int* node_flag = nullptr;
+    int* node_list = nullptr;
     float4* gD = nullptr;
     double* part = nullptr;
     ContactState* st = nullptr;
@@ -89,8 +107,9 @@ struct ContactBuffers {
     float* body_f = nullptr;    // F_Bq_W_f
 
     void release() {
-        void* ptrs[] = {slot, body, dist, normal, pos, rigid_v, p_WB, vel, vel0, cnode, cfx, cmass, cHG,
-                        entries, node_start, node_fill, gD, part, st, body_tau, body_f};
+        void* ptrs[] = {slot, body, dist, normal, pos, rigid_v, p_WB, vel, vel0, key, order, key2, order2, sort_hist,
+                        cnode, cfx, cmass, cphi0, cR, cv0, crv, cvel, cHG, run, node_flag, node_list, gD, part, st,
+                        body_tau, body_f};
         for (void* q : ptrs)
             if (q) (void)hipFree(q);
         *this = ContactBuffers();
@@ -114,10 +133,7 @@ struct ContactBuffers {
     }
 };
 
-constexpr int CT_WG = 256;       // threads per workgroup of the contact kernels
-constexpr int CT_MAX_WG = 1024;  // partial-sum records per kind
-
-// ---- set-up (once per UpdateContact) -----------------------------------------
+// ---- CopyContactPairs ----------------------------------------------------------
 
 // API slot -> internal slot of the particle each contact refers to
 __global__ __launch_bounds__(256) void k_ct_slots(int n, const uint32_t* api_slot, const int* pids_api,
@@ -135,46 +151,106 @@ __global__ __launch_bounds__(256) void k_ct_init_vel(DP p, ContactDev c) {
     c.vel[k * 3] = v.x; c.vel[k * 3 + 1] = v.y; c.vel[k * 3 + 2] = v.z;
 }
 
-// stencil of every contact: node indices into the compact grid, fx, particle mass
-__global__ __launch_bounds__(256) void k_ct_stencil(DP p, ContactDev c) {
-    const int k = blockIdx.x * 256 + threadIdx.x;
-    if (k >= c.n) return;
-    const PSet& S = p.set[p.ctl->cur];
-    uint32_t b[3];
+// ---- set-up (once per UpdateContact) -----------------------------------------
+
+MPM_DEV int compact_cell(const DP& p, uint32_t x, uint32_t y, uint32_t z) {
+    const int a = p.lut_act[block_id(x >> 2, y >> 2, z >> 2)];
+    return a < 0 ? -1 : a * 64 + (int)(((x & 3u) << 4) | ((y & 3u) << 2) | (z & 3u));
+}
+
+MPM_DEV void contact_base(const DP& p, const float* pos, uint32_t* b) {
     const uint32_t hi = (uint32_t)((1 << p.bits) - 3);
 #pragma unroll
-    for (int d = 0; d < 3; ++d) {
-        const float x = c.pos[k * 3 + d];
-        b[d] = min(base_cell(x, p.dxinv), hi);
-        c.cfx[d * c.n + k] = x * p.dxinv - (float)b[d];
+    for (int d = 0; d < 3; ++d) b[d] = min(base_cell(pos[d], p.dxinv), hi);
+}
+
+// S1: sort key = compact index of the stencil's base cell; clears the per-cell tables
+__global__ __launch_bounds__(256) void k_ct_keys(DP p, ContactDev c) {
+    const int gs = gridDim.x * 256, i0 = blockIdx.x * 256 + threadIdx.x;
+    const int ncell = (int)p.ctl->n_active * 64;
+    for (int g = i0; g < ncell; g += gs) {
+        c.run[g] = make_int2(0, 0);
+        c.node_flag[g] = 0;
+        c.gD[g] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
-    c.cmass[k] = S.q[0][c.slot[k]].w * p.M.density;
+    for (int k = i0; k < c.n; k += gs) {
+        uint32_t b[3];
+        contact_base(p, c.pos + (size_t)k * 3, b);
+        const int cc = compact_cell(p, b[0], b[1], b[2]);
+        c.key[k] = cc < 0 ? CT_NO_CELL : (uint32_t)cc;
+        c.order[k] = (uint32_t)k;
+    }
+}
+
+// S2 (after the sort): everything that stays fixed during the solve, in sorted order
+// (stencil, fx, mass, contact frame, lagged velocity: cuda_mpm_kernels.cuh:1107-1139)
+__global__ __launch_bounds__(256) void k_ct_prepare(DP p, ContactDev c) {
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= c.n) return;
+    const int k = (int)c.order[j];
+    const PSet& S = p.set[p.ctl->cur];
+    const uint32_t key = c.key[j];
+    // runs of equal keys
+    if (key != CT_NO_CELL) {
+        if (j == 0 || c.key[j - 1] != key) c.run[key].x = j;
+        if (j == c.n - 1 || c.key[j + 1] != key) c.run[key].y = j + 1;
+    }
+    uint32_t b[3];
+    contact_base(p, c.pos + (size_t)k * 3, b);
+#pragma unroll
+    for (int d = 0; d < 3; ++d) c.cfx[d * c.n + j] = c.pos[k * 3 + d] * p.dxinv - (float)b[d];
+    const uint32_t slot = c.slot[k];
+    c.cmass[j] = S.q[0][slot].w * p.M.density;
 #pragma unroll
     for (int i = 0; i < 3; ++i)
 #pragma unroll
-        for (int j = 0; j < 3; ++j)
+        for (int jj = 0; jj < 3; ++jj)
 #pragma unroll
             for (int l = 0; l < 3; ++l) {
-                const uint32_t x = b[0] + i, y = b[1] + j, z = b[2] + l;
-                const int a = p.lut_act[block_id(x >> 2, y >> 2, z >> 2)];
-                const int g = a < 0 ? -1 : a * 64 + (int)(((x & 3u) << 4) | ((y & 3u) << 2) | (z & 3u));
-                c.cnode[(i * 9 + j * 3 + l) * c.n + k] = g;
-                if (g >= 0) atomicAdd(&c.node_fill[g], 1);
+                // (a contact whose base cell lies outside the active grid cannot be found by the
+                // nodes' run lookup: it is left out of the solve altogether; contact points at
+                // particle positions, which is what the driver produces, never are)
+                const int g = key != CT_NO_CELL ? compact_cell(p, b[0] + i, b[1] + jj, b[2] + l) : -1;
+                c.cnode[(i * 9 + jj * 3 + l) * c.n + j] = g;
+                if (g >= 0) c.node_flag[g] = 1;
             }
+    const float nh[3] = {-c.normal[k * 3], -c.normal[k * 3 + 1], -c.normal[k * 3 + 2]};
+    float R[9];
+    frame_from_normal(nh, R);
+    const float4 pv = S.q[1][slot];
+    const float rv[3] = {c.rigid_v[k * 3], c.rigid_v[k * 3 + 1], c.rigid_v[k * 3 + 2]};
+    const float v0r[3] = {pv.x - rv[0], pv.y - rv[1], pv.z - rv[2]};
+    float v0[3];
+    mulv3(R, v0r, v0);
+#pragma unroll
+    for (int t = 0; t < 9; ++t) c.cR[t * c.n + j] = R[t];
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+        c.cv0[t * c.n + j] = v0[t];
+        c.crv[t * c.n + j] = rv[t];
+        c.cvel[t * c.n + j] = c.vel[k * 3 + t];   // contact_vel of CopyContactPairs (first iteration)
+    }
+    c.cphi0[j] = -c.dist[k];
 }
 
-// exclusive scan of node_fill -> node_start over all compact cells (single workgroup)
-__global__ __launch_bounds__(1024) void k_ct_scan(DP p, ContactDev c) {
+// S3: list of the nodes that see a contact (ascending), one workgroup
+__global__ __launch_bounds__(1024) void k_ct_node_list(DP p, ContactDev c) {
     __shared__ int s_w[16];
     __shared__ int s_carry;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int ncell = (int)p.ctl->n_active * 64;
     if (tid == 0) s_carry = 0;
     __syncthreads();
-    for (int base = 0; base < ncell; base += 1024) {
-        const int g = base + tid;
-        const int v = g < ncell ? c.node_fill[g] : 0;
-        int inc = v;
+    const int per = 8;
+    for (int base = 0; base < ncell; base += 1024 * per) {
+        int f[per], sum = 0;
+#pragma unroll
+        for (int q = 0; q < per; ++q) {
+            const int g = base + tid * per + q;
+            f[q] = g < ncell ? c.node_flag[g] : 0;
+            sum += f[q];
+        }
+        int inc = sum;
 #pragma unroll
         for (int d = 1; d < 64; d <<= 1) {
             const int t = __shfl_up(inc, d);
@@ -184,85 +260,32 @@ __global__ __launch_bounds__(1024) void k_ct_scan(DP p, ContactDev c) {
         __syncthreads();
         int pre = s_carry;
         for (int q = 0; q < w; ++q) pre += s_w[q];
-        if (g < ncell) {
-            c.node_start[g] = pre + inc - v;
-            c.node_fill[g] = 0;
-        }
+        int at = pre + inc - sum;
+#pragma unroll
+        for (int q = 0; q < per; ++q)
+            if (f[q]) c.node_list[at++] = base + tid * per + q;
         __syncthreads();
         if (tid == 1023) s_carry = pre + inc;
         __syncthreads();
     }
-    if (tid == 0) c.node_start[ncell] = s_carry;
+    if (tid == 0) c.st->n_nodes = s_carry;
 }
 
 MPM_DEV float stencil_weight(const float* wx, const float* wy, const float* wz, int n) {
     return wx[n / 9] * wy[(n / 3) % 3] * wz[n % 3];
 }
 
-__global__ __launch_bounds__(256) void k_ct_fill(DP p, ContactDev c) {
-    const int k = blockIdx.x * 256 + threadIdx.x;
-    if (k >= c.n) return;
-    float wx[3], wy[3], wz[3];
-    bspline3(c.cfx[k], wx);
-    bspline3(c.cfx[c.n + k], wy);
-    bspline3(c.cfx[2 * c.n + k], wz);
-#pragma unroll
-    for (int n = 0; n < 27; ++n) {
-        const int g = c.cnode[n * c.n + k];
-        if (g < 0) continue;
-        const int at = c.node_start[g] + atomicAdd(&c.node_fill[g], 1);
-        c.entries[at] = make_int2(k, __float_as_int(stencil_weight(wx, wy, wz, n)));
-    }
-}
-
-// order every node's list by contact id so that the per-node sums are reproducible
-__global__ __launch_bounds__(256) void k_ct_sort_lists(DP p, ContactDev c) {
-    const int ncell = (int)p.ctl->n_active * 64;
-    for (int g = blockIdx.x * 256 + threadIdx.x; g < ncell; g += gridDim.x * 256) {
-        const int a = c.node_start[g], b = c.node_start[g + 1];
-        for (int i = a + 1; i < b; ++i) {
-            const int2 e = c.entries[i];
-            int j = i - 1;
-            while (j >= a && c.entries[j].x > e.x) {
-                c.entries[j + 1] = c.entries[j];
-                --j;
-            }
-            c.entries[j + 1] = e;
-        }
-    }
-}
-
-// ---- per contact helpers -----------------------------------------------------
-struct ContactFrame {
-    float R[9];     // rows: tangent 1, tangent 2, normal (world -> contact)
-    float v0[3];    // lagged particle velocity relative to the body, contact frame
-    float phi0, mass;
-};
-
-MPM_DEV ContactFrame contact_frame(const DP& p, const ContactDev& c, int k) {
-    ContactFrame f;
-    const PSet& S = p.set[p.ctl->cur];
-    const float nh[3] = {-c.normal[k * 3], -c.normal[k * 3 + 1], -c.normal[k * 3 + 2]};
-    frame_from_normal(nh, f.R);
-    const float4 pv = S.q[1][c.slot[k]];
-    const float v0r[3] = {pv.x - c.rigid_v[k * 3], pv.y - c.rigid_v[k * 3 + 1], pv.z - c.rigid_v[k * 3 + 2]};
-    mulv3(f.R, v0r, f.v0);
-    f.phi0 = -c.dist[k];
-    f.mass = c.cmass[k];
-    return f;
-}
-
 // grid_to_particle_kernel<CONTACT_TRANSFER=true> (cuda_mpm_kernels.cuh:860-866, 891-894):
 // velocity at the contact point from nodes with m > 1e-7
-MPM_DEV void gather_contact_velocity(const DP& p, const ContactDev& c, int k, float* v) {
+MPM_DEV void gather_contact_velocity(const DP& p, const ContactDev& c, int j, float* v) {
     float wx[3], wy[3], wz[3];
-    bspline3(c.cfx[k], wx);
-    bspline3(c.cfx[c.n + k], wy);
-    bspline3(c.cfx[2 * c.n + k], wz);
+    bspline3(c.cfx[j], wx);
+    bspline3(c.cfx[c.n + j], wy);
+    bspline3(c.cfx[2 * c.n + j], wz);
     v[0] = v[1] = v[2] = 0.f;
 #pragma unroll
     for (int n = 0; n < 27; ++n) {
-        const int g = c.cnode[n * c.n + k];
+        const int g = c.cnode[n * c.n + j];
         if (g < 0) continue;
         const float4 q = p.gv[g];
         if (q.w > 1e-7f) {
@@ -274,12 +297,13 @@ MPM_DEV void gather_contact_velocity(const DP& p, const ContactDev& c, int k, fl
     }
 }
 
-__global__ __launch_bounds__(256) void k_ct_gather_vel(DP p, ContactDev c, float* out, int check_done) {
-    const int k = blockIdx.x * 256 + threadIdx.x;
-    if (k >= c.n) return;
-    if (check_done && c.st->done) return;
+// contact velocities in the caller's order (contact_vel0 before the solve, contact_vel after)
+__global__ __launch_bounds__(256) void k_ct_gather_vel(DP p, ContactDev c, float* out) {
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= c.n) return;
     float v[3];
-    gather_contact_velocity(p, c, k, v);
+    gather_contact_velocity(p, c, j, v);
+    const int k = (int)c.order[j];
     out[k * 3] = v[0];
     out[k * 3 + 1] = v[1];
     out[k * 3 + 2] = v[2];
@@ -290,35 +314,40 @@ __global__ __launch_bounds__(256) void k_ct_gather_vel(DP p, ContactDev c, float
 // C1: refresh contact_vel (from the 2nd iteration on) and evaluate the contact Hessian and
 // gradient in the world frame (cuda_mpm_kernels.cuh:1107-1154)
 __global__ __launch_bounds__(256) void k_ct_contact_grad(DP p, ContactDev c, int first) {
-    const int k = blockIdx.x * 256 + threadIdx.x;
-    if (k >= c.n || c.st->done) return;
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= c.n || c.st->done) return;
     float v[3];
     if (first) {
-        v[0] = c.vel[k * 3]; v[1] = c.vel[k * 3 + 1]; v[2] = c.vel[k * 3 + 2];
+        v[0] = c.cvel[j]; v[1] = c.cvel[c.n + j]; v[2] = c.cvel[2 * c.n + j];
     } else {
-        gather_contact_velocity(p, c, k, v);
-        c.vel[k * 3] = v[0]; c.vel[k * 3 + 1] = v[1]; c.vel[k * 3 + 2] = v[2];
+        gather_contact_velocity(p, c, j, v);
+        c.cvel[j] = v[0]; c.cvel[c.n + j] = v[1]; c.cvel[2 * c.n + j] = v[2];
     }
-    const ContactFrame f = contact_frame(p, c, k);
-    const float vr[3] = {v[0] - c.rigid_v[k * 3], v[1] - c.rigid_v[k * 3 + 1], v[2] - c.rigid_v[k * 3 + 2]};
+    float R[9], v0[3];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) R[t] = c.cR[t * c.n + j];
+#pragma unroll
+    for (int t = 0; t < 3; ++t) v0[t] = c.cv0[t * c.n + j];
+    const float vr[3] = {v[0] - c.crv[j], v[1] - c.crv[c.n + j], v[2] - c.crv[2 * c.n + j]};
     float vl[3];
-    mulv3(f.R, vr, vl);
+    mulv3(R, vr, vl);
     const ContactParams cp = {c.dt, c.mu, c.k, c.d, c.epsv};
     float CH[9], CG[3];
-    contact_grad_hess(cp, f.phi0, f.v0, vl, CH, CG);
+    contact_grad_hess(cp, c.cphi0[j], v0, vl, CH, CG);
     // world frame: R^T G, R^T H R
     float RT[9], tmp[9], WH[9], WG[3];
 #pragma unroll
     for (int i = 0; i < 3; ++i)
 #pragma unroll
-        for (int j = 0; j < 3; ++j) RT[j * 3 + i] = f.R[i * 3 + j];
+        for (int jj = 0; jj < 3; ++jj) RT[jj * 3 + i] = R[i * 3 + jj];
     mulv3(RT, CG, WG);
     mul33(RT, CH, tmp);
-    mul33(tmp, f.R, WH);
+    mul33(tmp, R, WH);
+    const float mass = c.cmass[j];
 #pragma unroll
-    for (int a = 0; a < 9; ++a) c.cHG[a * c.n + k] = f.mass * WH[a];
+    for (int a = 0; a < 9; ++a) c.cHG[a * c.n + j] = mass * WH[a];
 #pragma unroll
-    for (int a = 0; a < 3; ++a) c.cHG[(9 + a) * c.n + k] = f.mass * WG[a];
+    for (int a = 0; a < 3; ++a) c.cHG[(9 + a) * c.n + j] = mass * WG[a];
 }
 
 MPM_DEV void wg_reduce_store(double* vals, int count, double* out) {
@@ -340,26 +369,60 @@ MPM_DEV void wg_reduce_store(double* vals, int count, double* out) {
     __syncthreads();
 }
 
-// G1: per node, gather the Hessian/gradient of its contacts, add the inertia term and solve for
-// the Newton direction (cuda_mpm_kernels.cuh:1217-1274)
+// G1: per node that sees contacts, gather the Hessian/gradient of those contacts, add the inertia
+// term and solve for the Newton direction (cuda_mpm_kernels.cuh:1217-1274).  16 lanes per node:
+// the node's contacts are the runs of its 27 neighbour base cells; lane s takes every 16th
+// contact of a run, the 16 partial sums are folded in a fixed butterfly.
 __global__ __launch_bounds__(CT_WG) void k_ct_node_dir(DP p, ContactDev c) {
-    const int ncell = (int)p.ctl->n_active * 64;
     double acc[2] = {0, 0};
+    const int sub = threadIdx.x & 15;
     if (!c.st->done) {
-        for (int g = blockIdx.x * CT_WG + threadIdx.x; g < ncell; g += gridDim.x * CT_WG) {
-            float4 D = make_float4(0.f, 0.f, 0.f, 0.f);
-            const float4 q = p.gv[g];
-            const int a = c.node_start[g], b = c.node_start[g + 1];
-            if (q.w > 0.f && b > a) {
-                float H[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, G[3] = {0.f, 0.f, 0.f};
-                for (int e = a; e < b; ++e) {
-                    const int2 en = c.entries[e];
-                    const float w = __int_as_float(en.y);
+        const int n_nodes = c.st->n_nodes;
+        const int stride = (gridDim.x * CT_WG) >> 4;
+        for (int q = (blockIdx.x * CT_WG + threadIdx.x) >> 4; q < ((n_nodes + 3) & ~3); q += stride) {
+            // (a wave holds 4 nodes; all 64 lanes stay in the loop for the shuffles below)
+            const bool live = q < n_nodes;
+            const int g = live ? c.node_list[q] : 0;
+            float H[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, G[3] = {0.f, 0.f, 0.f};
+            const float4 gq = p.gv[g];
+            if (live && gq.w > 0.f) {
+                const int a = g >> 6, cell = g & 63;
+                int bx, by, bz;
+                block_coords(p.act_block[a], bx, by, bz);
+                const int gx = bx * 4 + (cell >> 4), gy = by * 4 + ((cell >> 2) & 3), gz = bz * 4 + (cell & 3);
+#pragma unroll 1
+                for (int o = 0; o < 27; ++o) {
+                    // contacts whose base cell is node - (i, j, l) reach this node with weight N_i N_j N_l
+                    const int i = o / 9, jj = (o / 3) % 3, l = o % 3;
+                    const int x = gx - i, y = gy - jj, z = gz - l;
+                    if (x < 0 || y < 0 || z < 0) continue;
+                    const int cc = compact_cell(p, (uint32_t)x, (uint32_t)y, (uint32_t)z);
+                    if (cc < 0) continue;
+                    const int2 r = c.run[cc];
+                    for (int k = r.x + sub; k < r.y; k += 16) {
+                        float wx[3], wy[3], wz[3];
+                        bspline3(c.cfx[k], wx);
+                        bspline3(c.cfx[c.n + k], wy);
+                        bspline3(c.cfx[2 * c.n + k], wz);
+                        const float w = wx[i] * wy[jj] * wz[l];
 #pragma unroll
-                    for (int t = 0; t < 9; ++t) H[t] += w * w * c.cHG[t * c.n + en.x];
+                        for (int t = 0; t < 9; ++t) H[t] += w * w * c.cHG[t * c.n + k];
 #pragma unroll
-                    for (int t = 0; t < 3; ++t) G[t] += w * c.cHG[(9 + t) * c.n + en.x];
+                        for (int t = 0; t < 3; ++t) G[t] += w * c.cHG[(9 + t) * c.n + k];
+                    }
                 }
+            }
+            // fold the 16 lanes of the node (xor butterfly inside a row of 16)
+#pragma unroll
+            for (int d = 8; d >= 1; d >>= 1) {
+#pragma unroll
+                for (int t = 0; t < 9; ++t) H[t] += __shfl_xor(H[t], d, 16);
+#pragma unroll
+                for (int t = 0; t < 3; ++t) G[t] += __shfl_xor(G[t], d, 16);
+            }
+            if (!live || sub != 0) continue;
+            float4 D = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (gq.w > 0.f) {
                 float hn = 0.f, gn = 0.f;
 #pragma unroll
                 for (int t = 0; t < 9; ++t) hn += H[t] * H[t];
@@ -367,10 +430,10 @@ __global__ __launch_bounds__(CT_WG) void k_ct_node_dir(DP p, ContactDev c) {
                 for (int t = 0; t < 3; ++t) gn += G[t] * G[t];
                 if ((double)sqrtf(hn) > 1e-7 || (double)sqrtf(gn) > 1e-7) {
                     const float4 vs = p.gvs[g];
-                    H[0] -= q.w; H[4] -= q.w; H[8] -= q.w;
-                    G[0] -= q.w * (q.x - vs.x);
-                    G[1] -= q.w * (q.y - vs.y);
-                    G[2] -= q.w * (q.z - vs.z);
+                    H[0] -= gq.w; H[4] -= gq.w; H[8] -= gq.w;
+                    G[0] -= gq.w * (gq.x - vs.x);
+                    G[1] -= gq.w * (gq.y - vs.y);
+                    G[2] -= gq.w * (gq.z - vs.z);
                     float Hi[9], d[3];
                     inv33(H, Hi);
                     mulv3(Hi, G, d);
@@ -385,121 +448,135 @@ __global__ __launch_bounds__(CT_WG) void k_ct_node_dir(DP p, ContactDev c) {
     wg_reduce_store(acc, 2, c.part + (size_t)blockIdx.x * CT_PART + LS_CAND + 1);
 }
 
-// C2: contact part of the line-search energies for every candidate step
-// (cuda_mpm_kernels.cuh:1276-1473 with global_line_search = true)
-__global__ __launch_bounds__(CT_WG) void k_ct_ls_contact(DP p, ContactDev c, int exact, float alpha_probe) {
+// C2 + G2: line-search energies for every candidate step: contact part
+// (cuda_mpm_kernels.cuh:1276-1473 with global_line_search = true) in workgroups [0, n_con_wg),
+// inertia part (cuda_mpm_kernels.cuh:1536-1589) in the rest
+__global__ __launch_bounds__(CT_WG) void k_ct_ls(DP p, ContactDev c, int n_con_wg, int exact, float alpha_probe) {
     double acc[CT_PART];
 #pragma unroll
     for (int q = 0; q < CT_PART; ++q) acc[q] = 0;
     const bool live = !c.st->done;
-    for (int k = blockIdx.x * CT_WG + threadIdx.x; live && k < c.n; k += gridDim.x * CT_WG) {
-        float wx[3], wy[3], wz[3];
-        bspline3(c.cfx[k], wx);
-        bspline3(c.cfx[c.n + k], wy);
-        bspline3(c.cfx[2 * c.n + k], wz);
-        float ov[3] = {0.f, 0.f, 0.f}, dd[3] = {0.f, 0.f, 0.f};
+    if ((int)blockIdx.x < n_con_wg) {
+        for (int j = blockIdx.x * CT_WG + threadIdx.x; live && j < c.n; j += n_con_wg * CT_WG) {
+            float wx[3], wy[3], wz[3];
+            bspline3(c.cfx[j], wx);
+            bspline3(c.cfx[c.n + j], wy);
+            bspline3(c.cfx[2 * c.n + j], wz);
+            float ov[3] = {0.f, 0.f, 0.f}, dd[3] = {0.f, 0.f, 0.f};
 #pragma unroll
-        for (int n = 0; n < 27; ++n) {
-            const int g = c.cnode[n * c.n + k];
-            if (g < 0) continue;
-            const float w = stencil_weight(wx, wy, wz, n);
-            const float4 q = p.gv[g], D = c.gD[g];
-            ov[0] += w * q.x; ov[1] += w * q.y; ov[2] += w * q.z;
-            dd[0] += w * D.x; dd[1] += w * D.y; dd[2] += w * D.z;
-        }
-        const ContactFrame f = contact_frame(p, c, k);
-        const ContactParams cp = {c.dt, c.mu, c.k, c.d, c.epsv};
-        const float rv[3] = {c.rigid_v[k * 3], c.rigid_v[k * 3 + 1], c.rigid_v[k * 3 + 2]};
-        float ovl[3], ddl[3];
-        {
-            const float t[3] = {ov[0] - rv[0], ov[1] - rv[1], ov[2] - rv[2]};
-            mulv3(f.R, t, ovl);
-            mulv3(f.R, dd, ddl);
-        }
-        if (!exact) {
-            acc[LS_CAND] += (double)(f.mass * contact_cost(cp, f.phi0, f.v0, ovl));
-            float al = 1.f;
-#pragma unroll 4
-            for (int j = 0; j < LS_CAND; ++j) {
-                const float nv[3] = {ovl[0] - al * ddl[0], ovl[1] - al * ddl[1], ovl[2] - al * ddl[2]};
-                acc[j] += (double)(f.mass * contact_cost(cp, f.phi0, f.v0, nv));
-                al *= .5f;
+            for (int n = 0; n < 27; ++n) {
+                const int g = c.cnode[n * c.n + j];
+                if (g < 0) continue;
+                const float w = stencil_weight(wx, wy, wz, n);
+                const float4 q = p.gv[g], D = c.gD[g];
+                ov[0] += w * q.x; ov[1] += w * q.y; ov[2] += w * q.z;
+                dd[0] += w * D.x; dd[1] += w * D.y; dd[2] += w * D.z;
             }
-        } else {
-            const float al = alpha_probe;
-            const float nv[3] = {ovl[0] - al * ddl[0], ovl[1] - al * ddl[1], ovl[2] - al * ddl[2]};
-            float CH[9], CG[3];
-            contact_grad_hess(cp, f.phi0, f.v0, nv, CH, CG);
-            float t[3];
+            const ContactParams cp = {c.dt, c.mu, c.k, c.d, c.epsv};
+            float R[9], v0[3];
 #pragma unroll
-            for (int a = 0; a < 3; ++a) t[a] = ddl[0] * CH[a] + ddl[1] * CH[3 + a] + ddl[2] * CH[6 + a];
-            acc[0] += (double)(f.mass * contact_cost(cp, f.phi0, f.v0, nv));
-            acc[1] += (double)(f.mass * dot3(CG, ddl));
-            acc[2] += (double)(f.mass * dot3(t, ddl));
-        }
-    }
-    wg_reduce_store(acc, LS_CAND + 1, c.part + (size_t)(c.part_wg + blockIdx.x) * CT_PART);
-}
-
-// G2: inertia part of the line-search energies (cuda_mpm_kernels.cuh:1536-1589)
-__global__ __launch_bounds__(CT_WG) void k_ct_ls_grid(DP p, ContactDev c, int exact, float alpha_probe) {
-    double acc[CT_PART];
+            for (int t = 0; t < 9; ++t) R[t] = c.cR[t * c.n + j];
 #pragma unroll
-    for (int q = 0; q < CT_PART; ++q) acc[q] = 0;
-    const int ncell = (int)p.ctl->n_active * 64;
-    if (!c.st->done) {
-        for (int g = blockIdx.x * CT_WG + threadIdx.x; g < ncell; g += gridDim.x * CT_WG) {
-            const float4 q = p.gv[g];
-            if (!(q.w > 0.f)) continue;
-            const float4 vs = p.gvs[g], D = c.gD[g];
-            const float o[3] = {q.x - vs.x, q.y - vs.y, q.z - vs.z};
+            for (int t = 0; t < 3; ++t) v0[t] = c.cv0[t * c.n + j];
+            const float phi0 = c.cphi0[j], mass = c.cmass[j];
+            float ovl[3], ddl[3];
+            {
+                const float t[3] = {ov[0] - c.crv[j], ov[1] - c.crv[c.n + j], ov[2] - c.crv[2 * c.n + j]};
+                mulv3(R, t, ovl);
+                mulv3(R, dd, ddl);
+            }
             if (!exact) {
-                acc[LS_CAND] += (double)(.5f * q.w * (o[0] * o[0] + o[1] * o[1] + o[2] * o[2]));
+                acc[LS_CAND] += (double)(mass * contact_cost(cp, phi0, v0, ovl));
                 float al = 1.f;
 #pragma unroll 4
-                for (int j = 0; j < LS_CAND; ++j) {
-                    const float n0 = o[0] - al * D.x, n1 = o[1] - al * D.y, n2 = o[2] - al * D.z;
-                    acc[j] += (double)(.5f * q.w * (n0 * n0 + n1 * n1 + n2 * n2));
+                for (int q = 0; q < LS_CAND; ++q) {
+                    const float nv[3] = {ovl[0] - al * ddl[0], ovl[1] - al * ddl[1], ovl[2] - al * ddl[2]};
+                    acc[q] += (double)(mass * contact_cost(cp, phi0, v0, nv));
                     al *= .5f;
                 }
             } else {
                 const float al = alpha_probe;
-                const float n0 = o[0] - al * D.x, n1 = o[1] - al * D.y, n2 = o[2] - al * D.z;
-                acc[0] += (double)(.5f * q.w * (n0 * n0 + n1 * n1 + n2 * n2));
-                acc[1] += (double)(-q.w * (n0 * D.x + n1 * D.y + n2 * D.z));
-                acc[2] += (double)(q.w * (D.x * D.x + D.y * D.y + D.z * D.z));
+                const float nv[3] = {ovl[0] - al * ddl[0], ovl[1] - al * ddl[1], ovl[2] - al * ddl[2]};
+                float CH[9], CG[3];
+                contact_grad_hess(cp, phi0, v0, nv, CH, CG);
+                float t[3];
+#pragma unroll
+                for (int a = 0; a < 3; ++a) t[a] = ddl[0] * CH[a] + ddl[1] * CH[3 + a] + ddl[2] * CH[6 + a];
+                acc[0] += (double)(mass * contact_cost(cp, phi0, v0, nv));
+                acc[1] += (double)(mass * dot3(CG, ddl));
+                acc[2] += (double)(mass * dot3(t, ddl));
             }
         }
+        wg_reduce_store(acc, LS_CAND + 1, c.part + (size_t)(CT_ROWS + blockIdx.x) * CT_PART);
+        return;
     }
-    wg_reduce_store(acc, LS_CAND + 1, c.part + (size_t)(2 * c.part_wg + blockIdx.x) * CT_PART);
+    const int ncell = (int)p.ctl->n_active * 64;
+    const int b = (int)blockIdx.x - n_con_wg, nb = (int)gridDim.x - n_con_wg;
+    for (int g = b * CT_WG + threadIdx.x; live && g < ncell; g += nb * CT_WG) {
+        const float4 q = p.gv[g];
+        if (!(q.w > 0.f)) continue;
+        const float4 vs = p.gvs[g], D = c.gD[g];
+        const float o[3] = {q.x - vs.x, q.y - vs.y, q.z - vs.z};
+        if (!exact) {
+            acc[LS_CAND] += (double)(.5f * q.w * (o[0] * o[0] + o[1] * o[1] + o[2] * o[2]));
+            float al = 1.f;
+#pragma unroll 4
+            for (int k = 0; k < LS_CAND; ++k) {
+                const float n0 = o[0] - al * D.x, n1 = o[1] - al * D.y, n2 = o[2] - al * D.z;
+                acc[k] += (double)(.5f * q.w * (n0 * n0 + n1 * n1 + n2 * n2));
+                al *= .5f;
+            }
+        } else {
+            const float al = alpha_probe;
+            const float n0 = o[0] - al * D.x, n1 = o[1] - al * D.y, n2 = o[2] - al * D.z;
+            acc[0] += (double)(.5f * q.w * (n0 * n0 + n1 * n1 + n2 * n2));
+            acc[1] += (double)(-q.w * (n0 * D.x + n1 * D.y + n2 * D.z));
+            acc[2] += (double)(q.w * (D.x * D.x + D.y * D.y + D.z * D.z));
+        }
+    }
+    wg_reduce_store(acc, LS_CAND + 1, c.part + (size_t)(2 * CT_ROWS + b) * CT_PART);
 }
 
 // S: fixed-order sum of the partial records, choice of the step, convergence test
-// (cuda_mpm_solver.cu:472-528, 567-570)
-__global__ __launch_bounds__(64) void k_ct_decide(ContactDev c, int n_dir_wg, int n_con_wg, int n_grid_wg, int exact) {
+// (cuda_mpm_solver.cu:472-528, 567-570).  1024 threads: thread (r, e) sums entry e of the rows
+// r, r + 32, ... of every kind; wave 0 adds the 32 row groups in order and decides.
+__global__ __launch_bounds__(1024) void k_ct_decide(ContactDev c, int n_dir_wg, int n_con_wg, int n_grid_wg, int exact) {
+    __shared__ double s_sum[32][CT_PART];
     ContactState* st = c.st;
-    if (st->done) return;
-    const int lane = threadIdx.x;
-    // lanes 0..28: energies; lane 29: norm_dir; lane 30: dofs
-    double v = 0;
-    if (lane <= LS_CAND) {
-        for (int w = 0; w < n_con_wg; ++w) v += c.part[(size_t)(c.part_wg + w) * CT_PART + lane];
-        for (int w = 0; w < n_grid_wg; ++w) v += c.part[(size_t)(2 * c.part_wg + w) * CT_PART + lane];
-    } else if (lane <= LS_CAND + 2) {
-        for (int w = 0; w < n_dir_wg; ++w) v += c.part[(size_t)w * CT_PART + lane];
+    if (st->done) {
+        // "finish after this update" becomes "finished" once that update (k_ct_apply of the
+        // previous iteration) has run
+        if (threadIdx.x == 0 && st->done == 2) st->done = 1;
+        return;
     }
+    const int e = threadIdx.x & 31, r = threadIdx.x >> 5;
+    // entries 0..28: energies; 29: norm_dir; 30: dofs
+    double v = 0;
+    if (e <= LS_CAND) {
+        for (int w = r; w < n_con_wg; w += 32) v += c.part[(size_t)(CT_ROWS + w) * CT_PART + e];
+        for (int w = r; w < n_grid_wg; w += 32) v += c.part[(size_t)(2 * CT_ROWS + w) * CT_PART + e];
+    } else if (e <= LS_CAND + 2) {
+        for (int w = r; w < n_dir_wg; w += 32) v += c.part[(size_t)w * CT_PART + e];
+    }
+    s_sum[r][e] = v;
+    __syncthreads();
+    if (threadIdx.x >= 64) return;
+    const int lane = threadIdx.x;
+    v = 0;
+    if (lane < CT_PART)
+        for (int q = 0; q < 32; ++q) v += s_sum[q][lane];
     if (lane == LS_CAND + 1) st->norm_dir_sq = (float)v;
     if (lane == LS_CAND + 2) st->dofs = (float)v;
     if (exact) {
         if (lane < 3) st->scal[lane] = v;
         return;
     }
-    const float e = (float)v;
-    const float E0 = __shfl(e, LS_CAND);
-    const unsigned long long ok = __ballot(lane < LS_CAND && e <= E0);
+    const float en = (float)v;
+    const float E0 = __shfl(en, LS_CAND);
+    const unsigned long long ok = __ballot(lane < LS_CAND && en <= E0);
     int j = ok ? __builtin_ctzll(ok) : LS_CAND - 1;  // "Tiny Alpha": accept 2^-27 anyway
-    const float Ej = __shfl(e, j);
-    const float nd = __shfl(e, LS_CAND + 1), dofs = __shfl(e, LS_CAND + 2);
+    const float Ej = __shfl(en, j);
+    const float nd = __shfl(en, LS_CAND + 1), dofs = __shfl(en, LS_CAND + 2);
     if (lane == 0) {
         st->alpha = ldexpf(1.f, -j);
         st->energy = Ej;
@@ -511,43 +588,60 @@ __global__ __launch_bounds__(64) void k_ct_decide(ContactDev c, int n_dir_wg, in
     }
 }
 
-// G3: v -= alpha Dir (cuda_mpm_kernels.cuh:1591-1614)
+// G3: v -= alpha Dir (cuda_mpm_kernels.cuh:1591-1614); only nodes that see contacts have a direction
 __global__ __launch_bounds__(CT_WG) void k_ct_apply(DP p, ContactDev c) {
     ContactState* st = c.st;
     if (st->done == 1) return;
     const float al = st->alpha;
-    const int ncell = (int)p.ctl->n_active * 64;
-    for (int g = blockIdx.x * CT_WG + threadIdx.x; g < ncell; g += gridDim.x * CT_WG) {
-        float4 q = p.gv[g];
-        if (!(q.w > 0.f)) continue;
+    const int n_nodes = st->n_nodes;
+    for (int q = blockIdx.x * CT_WG + threadIdx.x; q < n_nodes; q += gridDim.x * CT_WG) {
+        const int g = c.node_list[q];
+        float4 v = p.gv[g];
+        if (!(v.w > 0.f)) continue;
         const float4 D = c.gD[g];
-        q.x -= al * D.x; q.y -= al * D.y; q.z -= al * D.z;
-        p.gv[g] = q;
+        v.x -= al * D.x; v.y -= al * D.y; v.z -= al * D.z;
+        p.gv[g] = v;
     }
 }
 
-// turns "finish after this update" (2) into "finished" (1) once the update has been applied
-__global__ void k_ct_latch(ContactDev c) {
-    if (threadIdx.x == 0 && c.st->done == 2) c.st->done = 1;
-}
-
-// apply_contact_impulse_to_rigid_bodies (cuda_mpm_kernels.cuh:1616-1658)
+// apply_contact_impulse_to_rigid_bodies (cuda_mpm_kernels.cuh:1616-1658).  Impulses are summed
+// per workgroup in LDS (bodies 0..31) before they touch the per-body accumulators: thousands of
+// float atomics on one address serialise at the memory side.
+constexpr int CT_LDS_BODIES = 32;
 __global__ __launch_bounds__(256) void k_ct_impulse(ContactDev c) {
-    const int k = blockIdx.x * 256 + threadIdx.x;
-    if (k >= c.n) return;
-    const float m = c.cmass[k];
-    float l[3], r[3];
+    __shared__ float s_acc[CT_LDS_BODIES][6];
+    for (int q = threadIdx.x; q < CT_LDS_BODIES * 6; q += 256) (&s_acc[0][0])[q] = 0.f;
+    __syncthreads();
+    for (int j = blockIdx.x * 256 + threadIdx.x; j < c.n; j += gridDim.x * 256) {
+        const int k = (int)c.order[j];   // sorted position j is the caller's contact k
+        const float m = c.cmass[j];
+        float l[3], r[3];
 #pragma unroll
-    for (int a = 0; a < 3; ++a) {
-        l[a] = m * -(c.vel[k * 3 + a] - c.vel0[k * 3 + a]);
-        r[a] = c.pos[k * 3 + a] - c.p_WB[k * 3 + a];
+        for (int a = 0; a < 3; ++a) {
+            l[a] = m * -(c.vel[k * 3 + a] - c.vel0[k * 3 + a]);
+            r[a] = c.pos[k * 3 + a] - c.p_WB[k * 3 + a];
+        }
+        const float h[3] = {r[1] * l[2] - l[1] * r[2], r[2] * l[0] - l[2] * r[0], r[0] * l[1] - l[0] * r[1]};
+        const uint32_t b = c.body[k];
+        if (b < (uint32_t)CT_LDS_BODIES) {
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+                atomicAdd(&s_acc[b][a], h[a]);
+                atomicAdd(&s_acc[b][3 + a], l[a]);
+            }
+        } else if (b < (uint32_t)c.n_bodies) {
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+                atomicAdd(&c.body_tau[b * 3 + a], h[a]);
+                atomicAdd(&c.body_f[b * 3 + a], l[a]);
+            }
+        }
     }
-    const float h[3] = {r[1] * l[2] - l[1] * r[2], r[2] * l[0] - l[2] * r[0], r[0] * l[1] - l[0] * r[1]};
-    const uint32_t b = c.body[k];
-#pragma unroll
-    for (int a = 0; a < 3; ++a) {
-        atomicAdd(&c.body_tau[b * 3 + a], h[a]);
-        atomicAdd(&c.body_f[b * 3 + a], l[a]);
+    __syncthreads();
+    for (int q = threadIdx.x; q < min(c.n_bodies, CT_LDS_BODIES) * 6; q += 256) {
+        const int b = q / 6, a = q % 6;
+        const float v = s_acc[b][a];
+        if (v != 0.f) atomicAdd(a < 3 ? &c.body_tau[b * 3 + a] : &c.body_f[b * 3 + a - 3], v);
     }
 }
 

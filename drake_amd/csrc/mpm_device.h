@@ -49,11 +49,12 @@ struct Ctl {
     unsigned error;        // sticky ERR_* bits
     unsigned n_home;       // blocks owning particles (tiles)
     unsigned n_active;     // blocks whose nodes are updated
+    unsigned n_items;      // work items of the tile kernels (home blocks, heavy ones split)
     unsigned rebuilds;
     unsigned ticket;
     unsigned q_p2g;        // work-queue heads of the tile kernels (each kernel re-arms the other's)
     unsigned q_g2p;
-    unsigned pad[3];
+    unsigned pad[2];
 };
 
 struct DP {
@@ -61,7 +62,8 @@ struct DP {
     int bits;              // grid is (1<<bits)^3 cells
     int nb;                // blocks per axis
     unsigned nblocks, ncells;
-    unsigned capH, capA;
+    unsigned capH, capA, capI;
+    int item_groups;       // a work item holds at most this many 64-particle wave groups
     int dbg;               // MPM_DBG environment variable (kernel ablation switches, 0 in production)
     float dx, dxinv, Dinv;
     // fixed-point scales of the LDS tile accumulators (powers of two), see k_p2g
@@ -96,14 +98,19 @@ struct DP {
     uint32_t* home_block;  // home slot -> block id
     int4* home_range;      // (face begin, face end, vertex begin, vertex end) slots
     int* home_nbr_act;     // [home][27] active slot of block + offset, or -1
-    uint32_t* home_order;  // home slots, most particles first (work-queue order)
+    // Work items of the tile kernels (P2G, G2P): a home block, or a contiguous run of the wave
+    // groups of a heavy one.  Every item has its own slab; k_grid sums all slabs of a block.
+    int4* item_desc;       // [item] (home, first group, end group, 0)
+    uint32_t* item_order;  // items, most groups first (static round-robin order)
+    int2* home_items;      // [home] (first item, item count)
+    int* act_nbr_items;    // [active][27] first item | count << 24 of the neighbour home block, or -1
     int* home_ngroups;     // [home] number of P2G wave groups
     int4* home_groups;     // pool of (face begin, face end, vertex begin, vertex end) slot ranges, <= 64 particles each
     uint32_t* act_block;
     int* act_nbr_home;     // [active][27] home slot of block + offset, or -1
     // grid
     float4* slab;          // [home][TILE_N] (mvx, mvy, mvz, m) partial sums of one tile
-    uint32_t* slab_mask;   // [home] 27-bit set of neighbour blocks reached by a stencil
+    uint32_t* slab_mask;   // [item] 27-bit set of neighbour blocks reached by a stencil
     float4* gv;            // [active][64] (vx, vy, vz, m)  (momentum before the grid update)
     float4* gvs;           // [active][64] v* (velocity after the explicit update, before contact)
 };

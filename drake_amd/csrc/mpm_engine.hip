@@ -112,7 +112,7 @@ static void launch_grid(mpm_engine* e, int bc) {
     hipLaunchKernelGGL(k_grid<1>, dim3(e->g_grid), dim3(256), 0, e->stream, e->dp, bc);
 }
 static void launch_g2p(mpm_engine* e, float dt) {
-    hipLaunchKernelGGL(k_g2p, dim3(std::min(768u, e->dp.capH)), dim3(G2P_THREADS), 0, e->stream, e->dp, dt);
+    hipLaunchKernelGGL(k_g2p, dim3(std::min(768u, e->dp.capI)), dim3(G2P_THREADS), 0, e->stream, e->dp, dt);
     e->last_tile_kernel = 2;
 }
 
@@ -153,6 +153,8 @@ int mpm_finalize(mpm_handle_t e) {
     p.nblocks = p.ncells >> 6;
     p.capH = (unsigned)std::min<size_t>(p.nblocks, np);
     p.capA = (unsigned)std::min<size_t>(p.nblocks, (size_t)27 * p.capH);
+    p.item_groups = getenv("MPM_ITEM_GROUPS") ? std::max(1, atoi(getenv("MPM_ITEM_GROUPS"))) : 48;
+    p.capI = p.capH + (unsigned)(np / (64 * (size_t)p.item_groups)) + 16u;
     p.dxinv = (float)(1 << e->bits);
     p.dx = 1.f / p.dxinv;
     p.Dinv = 4.f * p.dxinv * p.dxinv;
@@ -204,13 +206,16 @@ int mpm_finalize(mpm_handle_t e) {
     ALLOC(p.home_block, p.capH, true);
     ALLOC(p.home_range, p.capH, true);
     ALLOC(p.home_nbr_act, (size_t)p.capH * 27, true);
-    ALLOC(p.home_order, p.capH, true);
+    ALLOC(p.item_desc, p.capI, true);
+    ALLOC(p.item_order, p.capI, true);
+    ALLOC(p.home_items, p.capH, true);
+    ALLOC(p.act_nbr_items, (size_t)p.capA * 27, true);
     ALLOC(p.home_ngroups, p.capH, true);
     ALLOC(p.home_groups, np / 64 + p.capH + 2, false);
     ALLOC(p.act_block, p.capA, true);
     ALLOC(p.act_nbr_home, (size_t)p.capA * 27, true);
-    ALLOC(p.slab, (size_t)p.capH * TILE_N, true);
-    ALLOC(p.slab_mask, p.capH, true);
+    ALLOC(p.slab, (size_t)p.capI * TILE_N, true);
+    ALLOC(p.slab_mask, p.capI, true);
     ALLOC(p.gv, (size_t)p.capA * 64, true);
     ALLOC(p.gvs, (size_t)p.capA * 64, true);
     ALLOC(e->d_pids_api, np, false);
@@ -264,7 +269,7 @@ int mpm_finalize(mpm_handle_t e) {
     e->g_np = (unsigned)((np + 255) / 256);
     e->g_nf = (unsigned)((nf + 255) / 256);
     e->g_nv = (unsigned)((nv + 255) / 256);
-    e->g_tile = std::min(512u, p.capH);  // 2 resident workgroups per CU pulling blocks from a queue
+    e->g_tile = std::min(512u, p.capI);  // 2 resident workgroups per CU pulling blocks from a queue
     e->g_grid = std::min(1024u, (p.capA + 3) / 4);
 
     // ---- FEM initialisation (cuda_mpm_kernels.cuh:13-70) + first sort -----

@@ -68,6 +68,12 @@ struct mpm_engine {
     void* d_stage = nullptr;
     size_t stage_bytes = 0;
 
+    // MPM_POISON=1 (tests): buffers that are not zero-initialised start as 0xFF bytes (NaN floats,
+    // -1 ints), so that a read of something never written shows up on every box
+    static bool poison() {
+        static const bool on = getenv("MPM_POISON") != nullptr;
+        return on;
+    }
     template <class T>
     int dalloc(T** out, size_t n, bool zero) {
         void* ptr = nullptr;
@@ -75,6 +81,7 @@ struct mpm_engine {
         HIP_TRY(hipMalloc(&ptr, bytes));
         allocs.push_back(ptr);
         if (zero) HIP_TRY(hipMemsetAsync(ptr, 0, bytes, stream));
+        else if (poison()) HIP_TRY(hipMemsetAsync(ptr, 0xFF, bytes, stream));
         *out = static_cast<T*>(ptr);
         return 0;
     }
@@ -83,6 +90,7 @@ struct mpm_engine {
             if (d_stage) HIP_TRY(hipFree(d_stage));
             d_stage = nullptr;
             HIP_TRY(hipMalloc(&d_stage, bytes));
+            if (poison()) HIP_TRY(hipMemset(d_stage, 0xFF, bytes));
             stage_bytes = bytes;
         }
         return 0;

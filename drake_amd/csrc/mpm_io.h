@@ -192,11 +192,11 @@ __global__ __launch_bounds__(256) void k_densify(DP p, const float4* field, floa
 
 // grid_touched_flags(): blocks reached by any particle stencil in the last P2G
 __global__ __launch_bounds__(256) void k_touched_flags(DP p, uint32_t* flags) {
-    const unsigned n = p.ctl->n_home * 27u;
+    const unsigned n = p.ctl->n_items * 27u;
     for (unsigned w = blockIdx.x * 256 + threadIdx.x; w < n; w += gridDim.x * 256) {
-        const unsigned h = w / 27, o = w % 27;
-        if ((p.slab_mask[h] >> o) & 1u) {
-            const int nb = neighbor_block(p.home_block[h], (int)o, p.nb);
+        const unsigned item = w / 27, o = w % 27;
+        if ((p.slab_mask[item] >> o) & 1u) {
+            const int nb = neighbor_block(p.home_block[p.item_desc[item].x], (int)o, p.nb);
             if (nb >= 0) flags[nb] = 1u;
         }
     }

@@ -236,15 +236,40 @@ __global__ __launch_bounds__(1024) void k_rb_tables(DP p) {
     if (tid < 64) s_bucket[tid] = 0;
     __syncthreads();
 
-    // F: work-queue order, heaviest blocks first (longest-processing-time-first keeps the last
-    // workgroups short).  Counting sort on the particle count in units of 256.
+    // F: work items.  A home block with more than item_groups wave groups is split evenly into
+    // several items (so a dense pile still spreads over the CUs); the static round-robin order is
+    // heaviest first (longest-processing-time-first keeps the last workgroups short).
+    unsigned n_items;
     {
-        auto bucket_of = [&](unsigned h) {
+        int mine_items = 0;
+        for (unsigned h = h0; h < h1; ++h) {
             const int4 rg = p.home_range[h];
-            const int chunks = ((rg.y - rg.x) + (rg.w - rg.z) + 255) >> 8;
-            return 63 - min(chunks, 63);  // descending
+            const int ng = ((rg.y - rg.x) + (rg.w - rg.z) + 63) >> 6;
+            mine_items += (ng + p.item_groups - 1) / p.item_groups;
+        }
+        int total_items = 0;
+        int it = wg_scan_exclusive(mine_items, total_items, s_w);
+        for (unsigned h = h0; h < h1; ++h) {
+            const int4 rg = p.home_range[h];
+            const int ng = ((rg.y - rg.x) + (rg.w - rg.z) + 63) >> 6;
+            const int ni = (ng + p.item_groups - 1) / p.item_groups;
+            p.home_items[h] = make_int2(it, ni);
+            for (int k = 0; k < ni; ++k)
+                if ((unsigned)(it + k) < p.capI)
+                    p.item_desc[it + k] = make_int4((int)h, (int)((long long)k * ng / ni), (int)((long long)(k + 1) * ng / ni), 0);
+            it += ni;
+        }
+        n_items = (unsigned)total_items;
+        if (n_items > p.capI) {
+            if (tid == 0) atomicOr(&c->error, ERR_CAPACITY);
+            n_items = p.capI;
+        }
+        __syncthreads();
+        auto bucket_of = [&](unsigned w) {
+            const int4 d = p.item_desc[w];
+            return 63 - min(d.z - d.y, 63);  // descending group count
         };
-        for (unsigned h = tid; h < n_home; h += 1024) atomicAdd(&s_bucket[bucket_of(h)], 1);
+        for (unsigned w = tid; w < n_items; w += 1024) atomicAdd(&s_bucket[bucket_of(w)], 1);
         __syncthreads();
         if (tid == 0) {
             int run = 0;
@@ -255,12 +280,13 @@ __global__ __launch_bounds__(1024) void k_rb_tables(DP p) {
             }
         }
         __syncthreads();
-        for (unsigned h = tid; h < n_home; h += 1024) p.home_order[atomicAdd(&s_bucket[bucket_of(h)], 1)] = h;
+        for (unsigned w = tid; w < n_items; w += 1024) p.item_order[atomicAdd(&s_bucket[bucket_of(w)], 1)] = w;
     }
 
     if (tid == 0) {
         c->n_home = n_home;
         c->n_active = n_active;
+        c->n_items = n_items;
     }
 }
 
@@ -278,7 +304,14 @@ __global__ __launch_bounds__(256) void k_rb_scatter(DP p) {
         }
         for (unsigned w = (unsigned)i; w < n_active * 27; w += gs) {
             const int nbid = neighbor_block(p.act_block[w / 27], (int)(w % 27), p.nb);
-            p.act_nbr_home[w] = nbid >= 0 ? p.lut_home[nbid] : -1;
+            const int hn = nbid >= 0 ? p.lut_home[nbid] : -1;
+            p.act_nbr_home[w] = hn;
+            int packed = -1;
+            if (hn >= 0) {
+                const int2 it = p.home_items[hn];
+                packed = it.x | (it.y << 24);
+            }
+            p.act_nbr_items[w] = packed;
         }
         // P2G wave groups: per home block, consecutive 64-particle windows of the merged sequence
         // (cell 0 faces, cell 0 vertices, cell 1 faces, ...), so a group holds faces and vertices of

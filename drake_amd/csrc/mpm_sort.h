@@ -1,0 +1,152 @@
+// Stable LSD radix sort of (key, value) pairs on the device, 8 bits per pass.
+//
+// Used where an order has to be *stable* and reproducible: the slot order of
+// RebuildMapping(sort = true) (the reference's 16-bit radix sort,
+// radix_sort.cuh / cuda_mpm_solver.cu:47-68) and the cell order of the contact
+// pairs in UpdateContact.  The engine's own particle order does not use it (see
+// mpm_rebuild.h: that one is a counting sort fused with the block tables).
+//
+// One wave per workgroup owns a tile of 64 * items consecutive pairs:
+//   k_sort_hist    digit histogram of the tile                -> hist[digit][tile]
+//   k_sort_scan    exclusive scan of hist in (digit, tile) order (one workgroup)
+//   k_sort_scatter ranks the tile's pairs chunk by chunk with wave ballots (lanes in order,
+//                  chunks in order => stable) and writes them to their final position
+// No barriers and no global atomics; LDS holds the 256 running offsets of the tile.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "mpm_device.h"
+
+namespace mpm {
+
+__global__ __launch_bounds__(64) void k_sort_hist(const uint32_t* keys, int n, int shift, int items, int* hist,
+                                                  int ntiles) {
+    __shared__ int s_cnt[256];
+    const int lane = threadIdx.x, tile = blockIdx.x;
+    for (int d = lane; d < 256; d += 64) s_cnt[d] = 0;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    const int begin = tile * 64 * items;
+    for (int it = 0; it < items; ++it) {
+        const int i = begin + it * 64 + lane;
+        if (i < n) atomicAdd(&s_cnt[(keys[i] >> shift) & 255u], 1);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    for (int d = lane; d < 256; d += 64) hist[(size_t)d * ntiles + tile] = s_cnt[d];
+}
+
+// exclusive scan of `total` ints in place, one 1024-thread workgroup
+__global__ __launch_bounds__(1024) void k_sort_scan(int* a, int total) {
+    __shared__ int s_w[16];
+    __shared__ int s_carry;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    if (tid == 0) s_carry = 0;
+    __syncthreads();
+    // every thread owns `per` consecutive entries of each 1024 * per block
+    const int per = 8;
+    for (int base = 0; base < total; base += 1024 * per) {
+        int v[per], sum = 0;
+#pragma unroll
+        for (int q = 0; q < per; ++q) {
+            const int i = base + tid * per + q;
+            v[q] = i < total ? a[i] : 0;
+            sum += v[q];
+        }
+        int inc = sum;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int t = __shfl_up(inc, d);
+            if (lane >= d) inc += t;
+        }
+        if (lane == 63) s_w[w] = inc;
+        __syncthreads();
+        int pre = s_carry;
+        for (int q = 0; q < w; ++q) pre += s_w[q];
+        int run = pre + inc - sum;
+#pragma unroll
+        for (int q = 0; q < per; ++q) {
+            const int i = base + tid * per + q;
+            if (i < total) a[i] = run;
+            run += v[q];
+        }
+        __syncthreads();
+        if (tid == 1023) s_carry = pre + inc;
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(64) void k_sort_scatter(const uint32_t* keys, const uint32_t* vals, uint32_t* keys_out,
+                                                     uint32_t* vals_out, int n, int shift, int items, const int* hist,
+                                                     int ntiles) {
+    __shared__ int s_off[256];
+    const int lane = threadIdx.x, tile = blockIdx.x;
+    for (int d = lane; d < 256; d += 64) s_off[d] = hist[(size_t)d * ntiles + tile];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    const int begin = tile * 64 * items;
+    for (int it = 0; it < items; ++it) {
+        const int i = begin + it * 64 + lane;
+        const bool valid = i < n;
+        const uint32_t key = valid ? keys[i] : 0u;
+        const uint32_t val = valid ? vals[i] : 0u;
+        const uint32_t digit = (key >> shift) & 255u;
+        // lanes of this chunk with the same digit
+        unsigned long long same = __ballot(valid);
+#pragma unroll
+        for (int b = 0; b < 8; ++b) {
+            const unsigned long long m = __ballot((digit >> b) & 1u);
+            same &= ((digit >> b) & 1u) ? m : ~m;
+        }
+        int dst = 0;
+        if (valid) dst = s_off[digit] + (int)__popcll(same & lt);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        // the last lane of every digit group moves the running offset on
+        if (valid && (same >> lane) == 1ull) s_off[digit] = dst + 1;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if (valid) {
+            keys_out[dst] = key;
+            vals_out[dst] = val;
+        }
+    }
+}
+
+}  // namespace mpm
+
+// Sorts n pairs by the key bits [0, bits) (stable).  `a` holds the input and receives the result;
+// `b` and `hist` are scratch (hist: 256 * ceil(n / (64 * items)) ints).
+struct SortScratch {
+    uint32_t *kb = nullptr, *vb = nullptr;
+    int* hist = nullptr;
+    size_t cap = 0, cap_hist = 0;
+};
+
+static inline int sort_items_for(size_t n) { return n > (1u << 18) ? 64 : 16; }
+
+static int radix_sort_pairs(hipStream_t s, uint32_t* ka, uint32_t* va, uint32_t* kb, uint32_t* vb, int* hist, size_t n,
+                            int bits) {
+    using namespace mpm;
+    if (n < 2 || bits <= 0) return 0;
+    const int items = sort_items_for(n);
+    const int ntiles = (int)((n + (size_t)64 * items - 1) / ((size_t)64 * items));
+    const int passes = (bits + 7) / 8;
+    uint32_t *ki = ka, *vi = va, *ko = kb, *vo = vb;
+    for (int pass = 0; pass < passes; ++pass) {
+        hipLaunchKernelGGL(k_sort_hist, dim3(ntiles), dim3(64), 0, s, (const uint32_t*)ki, (int)n, pass * 8, items, hist,
+                           ntiles);
+        hipLaunchKernelGGL(k_sort_scan, dim3(1), dim3(1024), 0, s, hist, 256 * ntiles);
+        hipLaunchKernelGGL(k_sort_scatter, dim3(ntiles), dim3(64), 0, s, (const uint32_t*)ki, (const uint32_t*)vi, ko, vo,
+                           (int)n, pass * 8, items, (const int*)hist, ntiles);
+        std::swap(ki, ko);
+        std::swap(vi, vo);
+    }
+    if (ki != ka) {  // odd number of passes: the result sits in the scratch pair
+        if (hipMemcpyAsync(ka, ki, n * 4, hipMemcpyDeviceToDevice, s) != hipSuccess) return -1;
+        if (hipMemcpyAsync(va, vi, n * 4, hipMemcpyDeviceToDevice, s) != hipSuccess) return -1;
+    }
+    return 0;
+}

@@ -225,7 +225,6 @@ __global__ __launch_bounds__(512, 4) void k_p2g(DP p, float dt) {  // <= 128 VGP
     __shared__ unsigned s_mask;
     Ctl* ctl = p.ctl;
     const PSet& S = p.set[ctl->cur];
-    const unsigned n_home = ctl->n_home;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const float gdt = p.M.gravity * dt;
     const float sdt = -dt * p.Dinv;
@@ -260,12 +259,16 @@ __global__ __launch_bounds__(512, 4) void k_p2g(DP p, float dt) {  // <= 128 VGP
     // rows beyond the staged particles are read (and masked) by the last step: keep them finite
     for (int k = lane; k < 8 * STG; k += 64) stage[64 * STG + k] = 0.f;
 
-    // Home blocks are taken round-robin from the heaviest-first order: workgroup w processes
-    // entries w, w + G, ...; with G resident workgroups that is one heavy block each plus the
-    // light tail, and it needs neither a queue atomic nor extra barriers per block.
-    for (unsigned q = blockIdx.x; q < n_home; q += gridDim.x) {
-        __syncthreads();  // the previous block's slab has been written
-        const unsigned h = p.home_order[q];
+    // Work items (a home block, or a run of the wave groups of a heavy one) are taken round-robin
+    // from the heaviest-first order: workgroup w processes entries w, w + G, ...; with G resident
+    // workgroups that is one heavy item each plus the light tail, and it needs neither a queue
+    // atomic nor extra barriers per item.
+    const unsigned n_items = ctl->n_items;
+    for (unsigned q = blockIdx.x; q < n_items; q += gridDim.x) {
+        __syncthreads();  // the previous item's slab has been written
+        const unsigned item = p.item_order[q];
+        const int4 idesc = p.item_desc[item];
+        const unsigned h = (unsigned)idesc.x;
         const unsigned long long tb0 = (diag_flags(p) & 4) ? __builtin_readcyclecounter() : 0ull;
         for (int n = tid; n < TILE_N * 4; n += 512) tile[n] = 0;
         if (tid == 0) s_mask = 0;
@@ -280,8 +283,8 @@ __global__ __launch_bounds__(512, 4) void k_p2g(DP p, float dt) {  // <= 128 VGP
         // Every wave streams through its own groups of <= 64 particles; no workgroup barrier inside.
         // Groups are runs of whole cells (faces and vertices of the same cells together), laid out
         // at the last rebuild: a group usually spans two base cells.
-        const int ngroups = p.home_ngroups[h];
-        const int4* groups = p.home_groups + group_pool_offset(p, rg, h);
+        const int ngroups = idesc.z - idesc.y;
+        const int4* groups = p.home_groups + group_pool_offset(p, rg, h) + idesc.y;
         struct Raw {
             float x[3], v[3], vol, C[9], aux[6];  // aux: tau factors a,b (faces) or force (vertices)
             bool act, is_face;
@@ -476,13 +479,13 @@ __global__ __launch_bounds__(512, 4) void k_p2g(DP p, float dt) {  // <= 128 VGP
         if (mymask) atomicOr(&s_mask, mymask);
         if (__ballot(hard) && lane == 0) atomicOr(&ctl->error, ERR_DRIFT);
         __syncthreads();
-        float4* out = p.slab + (size_t)h * TILE_N;
+        float4* out = p.slab + (size_t)item * TILE_N;
         for (int n = tid; n < TILE_N; n += 512) {
             const long long* q = tile + n * 4;
             out[n] = make_float4((float)((double)q[0] * p.unfix_p), (float)((double)q[1] * p.unfix_p),
                                  (float)((double)q[2] * p.unfix_p), (float)((double)q[3] * p.unfix_m));
         }
-        if (tid == 0) p.slab_mask[h] = s_mask;
+        if (tid == 0) p.slab_mask[item] = s_mask;
         if ((diag_flags(p) & 4) && tid == 0) {
             atomicAdd(&p.dbgbuf[12], (unsigned long long)__builtin_readcyclecounter() - tb0);
             atomicAdd(&p.dbgbuf[13], 1ull);
@@ -514,21 +517,24 @@ __global__ __launch_bounds__(256) void k_grid(DP p, int bc) {
     const int cell = tid & 63;
     const int cx = cell >> 4, cy = (cell >> 2) & 3, cz = cell & 3;
     for (unsigned a = blockIdx.x * 4 + (tid >> 6); a < n_active; a += gridDim.x * 4) {
-        const int* nbr = p.act_nbr_home + (size_t)a * 27;
+        const int* nbr = p.act_nbr_items + (size_t)a * 27;
         float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
         if (MODE == 2) s = p.gv[(size_t)a * 64 + cell];
 #pragma unroll
         for (int o = 0; o < (MODE == 2 ? 0 : 27); ++o) {
-            const int h = nbr[o];   // wave-uniform
-            if (h < 0) continue;
-            // this block seen from the home block is at offset -o
-            if (!((p.slab_mask[h] >> (26 - o)) & 1u)) continue;
+            const int packed = nbr[o];   // wave-uniform: first item | count << 24 of that home block
+            if (packed < 0) continue;
             const int tx = cx - 4 * (o / 9 - 1) + FREE_ZONE;
             const int ty = cy - 4 * ((o / 3) % 3 - 1) + FREE_ZONE;
             const int tz = cz - 4 * (o % 3 - 1) + FREE_ZONE;
-            if (tx < 0 || ty < 0 || tz < 0 || tx >= TILE_W || ty >= TILE_W || tz >= TILE_W) continue;
-            const float4 t = p.slab[(size_t)h * TILE_N + (tx * TILE_W + ty) * TILE_W + tz];
-            s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w;
+            const bool in_tile = !(tx < 0 || ty < 0 || tz < 0 || tx >= TILE_W || ty >= TILE_W || tz >= TILE_W);
+            const int it0 = packed & 0xFFFFFF, it1 = it0 + (packed >> 24);
+            for (int it = it0; it < it1; ++it) {
+                // this block seen from the home block is at offset -o
+                if (!((p.slab_mask[it] >> (26 - o)) & 1u) || !in_tile) continue;
+                const float4 t = p.slab[(size_t)it * TILE_N + (tx * TILE_W + ty) * TILE_W + tz];
+                s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w;
+            }
         }
         const size_t gi = (size_t)a * 64 + cell;
         if (MODE == 0) {
@@ -666,14 +672,22 @@ __global__ __launch_bounds__(G2P_THREADS) void k_g2p(DP p, float dt) {
     __shared__ float4 tile[TILE_N];
     const Ctl* ctl = p.ctl;
     const PSet& S = p.set[ctl->cur];
-    const unsigned n_home = ctl->n_home;
-    for (unsigned q = blockIdx.x; q < n_home; q += gridDim.x) {
+    const unsigned n_items = ctl->n_items;
+    for (unsigned q = blockIdx.x; q < n_items; q += gridDim.x) {
         __syncthreads();  // everybody is done with the previous tile
-        const unsigned h = p.home_order[q];
+        const int4 idesc = p.item_desc[p.item_order[q]];
+        const unsigned h = (unsigned)idesc.x;
         const bool prof = (diag_flags(p) & 4) != 0;
         unsigned long long t0 = 0, t1 = 0;
         if (prof) t0 = __builtin_readcyclecounter();
-        const int4 rg = p.home_range[h];
+        int4 rg;
+        {
+            // the item's particles: from the first slot of its first wave group to the end of its last
+            const int4 hr = p.home_range[h];
+            const int4* groups = p.home_groups + group_pool_offset(p, hr, h);
+            const int4 ga = groups[idesc.y], gb = groups[idesc.z - 1];
+            rg = make_int4(ga.x, gb.y, ga.z, gb.w);
+        }
         // faces then vertices as one index space: a single copy of the (large) particle body
         const int nfb = rg.y - rg.x, total = nfb + (rg.w - rg.z);
         auto slot_of = [&](int u) { return (unsigned)(u < nfb ? rg.x + u : rg.z + (u - nfb)); };
