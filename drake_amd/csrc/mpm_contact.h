@@ -14,7 +14,11 @@ static int grow(T** ptr, size_t n) {
     if (*ptr) HIP_TRY(hipFree(*ptr));
     *ptr = nullptr;
     HIP_TRY(hipMalloc((void**)ptr, std::max<size_t>(n, 1) * sizeof(T)));
-    if (mpm_engine::poison()) HIP_TRY(hipMemset(*ptr, 0xFF, std::max<size_t>(n, 1) * sizeof(T)));
+    if (mpm_engine::poison()) {  // debugging aid only: full device syncs around a null-stream fill
+        HIP_TRY(hipDeviceSynchronize());
+        HIP_TRY(hipMemset(*ptr, 0xFF, std::max<size_t>(n, 1) * sizeof(T)));
+        HIP_TRY(hipDeviceSynchronize());
+    }
     return 0;
 }
 
@@ -52,7 +56,9 @@ static int copy_contacts(mpm_engine* e, size_t n, const uint32_t* particle, cons
     if (!b.run || b.cap_cells < cells) {
         int rc;
         if ((rc = grow(&b.run, cells)) || (rc = grow(&b.node_flag, cells)) || (rc = grow(&b.node_list, cells)) ||
-            (rc = grow(&b.gD, cells)) || (rc = grow(&b.part, (size_t)3 * CT_ROWS * CT_PART)) || (rc = grow(&b.st, 1)))
+            (rc = grow(&b.node_runs, 27 * cells)) || (rc = grow(&b.gD, cells)) ||
+            (rc = grow(&b.part, (size_t)2 * CT_ROWS * CT_PART)) || (rc = grow(&b.part_dir, (size_t)2 * CT_DIR_WG)) ||
+            (rc = grow(&b.st, 1)))
             return rc;
         b.cap_cells = cells;
     }
@@ -91,8 +97,9 @@ static ContactDev make_contact_dev(mpm_engine* e, float dt, float mu, float k, f
     c.key = b.key; c.order = b.order;
     c.cnode = b.cnode; c.cfx = b.cfx; c.cmass = b.cmass; c.cphi0 = b.cphi0; c.cR = b.cR; c.cv0 = b.cv0;
     c.crv = b.crv; c.cvel = b.cvel; c.cHG = b.cHG;
-    c.run = b.run; c.node_flag = b.node_flag; c.node_list = b.node_list; c.gD = b.gD;
-    c.part = b.part; c.st = b.st;
+    c.run = b.run; c.node_flag = b.node_flag; c.node_list = b.node_list; c.node_runs = b.node_runs;
+    c.cap_nodes = (int)b.cap_cells; c.gD = b.gD;
+    c.part = b.part; c.part_dir = b.part_dir; c.st = b.st;
     c.body_tau = b.body_tau; c.body_f = b.body_f; c.n_bodies = (int)b.n_bodies;
     return c;
 }
@@ -112,7 +119,7 @@ static int update_contact(mpm_engine* e, int frame, int substep, float dt, float
     const unsigned gc = (unsigned)((n + 255) / 256);
     const int n_con_wg = (int)std::min(gc, (unsigned)CT_ROWS);  // grid-stride contact part of k_ct_ls
     const int n_grid_wg = CT_ROWS;                               // grid-stride cell part
-    const int n_dir_wg = CT_ROWS;
+    const int n_dir_wg = CT_DIR_WG;
     // ---- set-up: contacts in base-cell order, per-cell runs, nodes that see contacts ---------
     HIP_TRY(hipMemsetAsync(b.st, 0, sizeof(ContactState), s));
     hipLaunchKernelGGL(k_ct_keys, dim3(1024), dim3(256), 0, s, p, c);
@@ -126,6 +133,7 @@ static int update_contact(mpm_engine* e, int frame, int substep, float dt, float
     }
     hipLaunchKernelGGL(k_ct_prepare, dim3(gc), dim3(256), 0, s, p, c);
     hipLaunchKernelGGL(k_ct_node_list, dim3(1), dim3(1024), 0, s, p, c);
+    hipLaunchKernelGGL(k_ct_node_runs, dim3(1024), dim3(256), 0, s, p, c);
     // pre-contact velocity at the contact points (cuda_mpm_solver.cu:267-272)
     hipLaunchKernelGGL(k_ct_gather_vel, dim3(gc), dim3(256), 0, s, p, c, b.vel0);
 
@@ -145,7 +153,7 @@ static int update_contact(mpm_engine* e, int frame, int substep, float dt, float
                 hipLaunchKernelGGL(k_ct_node_dir, dim3(n_dir_wg), dim3(CT_WG), 0, s, p, c);
                 hipLaunchKernelGGL(k_ct_ls, dim3(n_con_wg + n_grid_wg), dim3(CT_WG), 0, s, p, c, n_con_wg, 0, 0.f);
                 hipLaunchKernelGGL(k_ct_decide, dim3(1), dim3(1024), 0, s, c, n_dir_wg, n_con_wg, n_grid_wg, 0);
-                hipLaunchKernelGGL(k_ct_apply, dim3(n_dir_wg), dim3(CT_WG), 0, s, p, c);
+                hipLaunchKernelGGL(k_ct_apply, dim3(CT_ROWS), dim3(CT_WG), 0, s, p, c);
             }
             iters += batch;
             HIP_TRY(hipMemcpyAsync(&st, b.st, sizeof(ContactState), hipMemcpyDeviceToHost, s));
@@ -215,7 +223,7 @@ static int update_contact(mpm_engine* e, int frame, int substep, float dt, float
                 ls += 1;
             }
             HIP_TRY(hipMemcpyAsync(&b.st->alpha, &alpha, 4, hipMemcpyHostToDevice, s));
-            hipLaunchKernelGGL(k_ct_apply, dim3(n_dir_wg), dim3(CT_WG), 0, s, p, c);
+            hipLaunchKernelGGL(k_ct_apply, dim3(CT_ROWS), dim3(CT_WG), 0, s, p, c);
             residual = std::sqrt(st.norm_dir_sq) / st.dofs;
             iters += 1;
             s_res.push_back(residual);

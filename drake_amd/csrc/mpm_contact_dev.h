@@ -21,12 +21,14 @@
 #include <stdint.h>
 
 #include "mpm_device.h"
+#include "mpm_sort.h"
 
 namespace mpm {
 
 constexpr int LS_CAND = 28;          // alpha = 2^-j, j = 0..27 (alpha < 1e-8 is accepted as is)
 constexpr int CT_PART = LS_CAND + 4; // partial record: E1[28], E0, norm_dir, dofs, pad
 constexpr int CT_WG = 256;           // threads per workgroup of the contact kernels
+constexpr int CT_DIR_WG = 2048;      // workgroups of k_ct_node_dir (16 lanes per node)
 constexpr int CT_ROWS = 256;         // partial-sum records per kind (= max workgroups of the reducing kernels)
 constexpr uint32_t CT_NO_CELL = 0x7FFFFFFFu;  // sort key of a contact whose base cell is outside the active grid
 
@@ -69,8 +71,11 @@ struct ContactDev {
     int2* run;              // [cells] (begin, end) of the contacts whose base cell this is
     int* node_flag;         // [cells] 1 if some contact's stencil reaches the node
     int* node_list;         // [<= cells] those nodes
+    int2* node_runs;        // [27][cap_nodes] contact runs per listed node and stencil offset
+    int cap_nodes;
     float4* gD;             // [cells] search direction (relaxed)
-    double* part;           // [3][CT_ROWS][CT_PART]
+    double* part;           // [2][CT_ROWS][CT_PART] line-search partial sums (contacts, cells)
+    double* part_dir;       // [CT_DIR_WG][2] (|Dir|^2, DoFs) per workgroup of k_ct_node_dir
     ContactState* st;
     float* body_tau;
     float* body_f;
@@ -100,15 +105,17 @@ struct ContactBuffers {
     int2* run = nullptr;
     int* node_flag = nullptr;
     int* node_list = nullptr;
+    int2* node_runs = nullptr;
     float4* gD = nullptr;
     double* part = nullptr;
+    double* part_dir = nullptr;
     ContactState* st = nullptr;
     float* body_tau = nullptr;  // F_Bq_W_tau
     float* body_f = nullptr;    // F_Bq_W_f
 
     void release() {
         void* ptrs[] = {slot, body, dist, normal, pos, rigid_v, p_WB, vel, vel0, key, order, key2, order2, sort_hist,
-                        cnode, cfx, cmass, cphi0, cR, cv0, crv, cvel, cHG, run, node_flag, node_list, gD, part, st,
+                        cnode, cfx, cmass, cphi0, cR, cv0, crv, cvel, cHG, run, node_flag, node_list, node_runs, gD, part, part_dir, st,
                         body_tau, body_f};
         for (void* q : ptrs)
             if (q) (void)hipFree(q);
@@ -233,42 +240,56 @@ __global__ __launch_bounds__(256) void k_ct_prepare(DP p, ContactDev c) {
     c.cphi0[j] = -c.dist[k];
 }
 
-// S3: list of the nodes that see a contact (ascending), one workgroup
+// S3: list of the nodes that see a contact (ascending), one workgroup; 16 cells per thread and
+// block (the cell count is a multiple of 64)
 __global__ __launch_bounds__(1024) void k_ct_node_list(DP p, ContactDev c) {
     __shared__ int s_w[16];
-    __shared__ int s_carry;
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int tid = threadIdx.x;
     const int ncell = (int)p.ctl->n_active * 64;
-    if (tid == 0) s_carry = 0;
-    __syncthreads();
-    const int per = 8;
-    for (int base = 0; base < ncell; base += 1024 * per) {
-        int f[per], sum = 0;
+    int carry = 0;
+    for (int base = 0; base < ncell; base += 16384) {
+        int4 f[4];
+        int sum = 0;
 #pragma unroll
-        for (int q = 0; q < per; ++q) {
-            const int g = base + tid * per + q;
-            f[q] = g < ncell ? c.node_flag[g] : 0;
-            sum += f[q];
+        for (int q = 0; q < 4; ++q) {
+            const int g = base + tid * 16 + q * 4;
+            f[q] = g < ncell ? *reinterpret_cast<const int4*>(c.node_flag + g) : make_int4(0, 0, 0, 0);
+            sum += f[q].x + f[q].y + f[q].z + f[q].w;
         }
-        int inc = sum;
+        int block_total;
+        int at = carry + wg1024_exclusive(sum, block_total, s_w);
 #pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const int t = __shfl_up(inc, d);
-            if (lane >= d) inc += t;
+        for (int q = 0; q < 4; ++q) {
+            const int g = base + tid * 16 + q * 4;
+            if (f[q].x) c.node_list[at++] = g;
+            if (f[q].y) c.node_list[at++] = g + 1;
+            if (f[q].z) c.node_list[at++] = g + 2;
+            if (f[q].w) c.node_list[at++] = g + 3;
         }
-        if (lane == 63) s_w[w] = inc;
-        __syncthreads();
-        int pre = s_carry;
-        for (int q = 0; q < w; ++q) pre += s_w[q];
-        int at = pre + inc - sum;
-#pragma unroll
-        for (int q = 0; q < per; ++q)
-            if (f[q]) c.node_list[at++] = base + tid * per + q;
-        __syncthreads();
-        if (tid == 1023) s_carry = pre + inc;
-        __syncthreads();
+        carry += block_total;
     }
-    if (tid == 0) c.st->n_nodes = s_carry;
+    if (tid == 0) c.st->n_nodes = carry;
+}
+
+// S4: per listed node, the contact runs of the 27 base cells whose stencil reaches it
+// (base = node - (i, j, l)), so that the Newton iterations do not repeat the table walks
+__global__ __launch_bounds__(256) void k_ct_node_runs(DP p, ContactDev c) {
+    const int n_nodes = c.st->n_nodes;
+    for (int t = blockIdx.x * 256 + threadIdx.x; t < n_nodes * 27; t += gridDim.x * 256) {
+        const int q = t / 27, o = t % 27;
+        const int g = c.node_list[q];
+        const int a = g >> 6, cell = g & 63;
+        int bx, by, bz;
+        block_coords(p.act_block[a], bx, by, bz);
+        const int x = bx * 4 + (cell >> 4) - o / 9, y = by * 4 + ((cell >> 2) & 3) - (o / 3) % 3,
+                  z = bz * 4 + (cell & 3) - o % 3;
+        int2 r = make_int2(0, 0);
+        if (x >= 0 && y >= 0 && z >= 0) {
+            const int cc = compact_cell(p, (uint32_t)x, (uint32_t)y, (uint32_t)z);
+            if (cc >= 0) r = c.run[cc];
+        }
+        c.node_runs[(size_t)o * c.cap_nodes + q] = r;
+    }
 }
 
 MPM_DEV float stencil_weight(const float* wx, const float* wy, const float* wz, int n) {
@@ -386,19 +407,11 @@ __global__ __launch_bounds__(CT_WG) void k_ct_node_dir(DP p, ContactDev c) {
             float H[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, G[3] = {0.f, 0.f, 0.f};
             const float4 gq = p.gv[g];
             if (live && gq.w > 0.f) {
-                const int a = g >> 6, cell = g & 63;
-                int bx, by, bz;
-                block_coords(p.act_block[a], bx, by, bz);
-                const int gx = bx * 4 + (cell >> 4), gy = by * 4 + ((cell >> 2) & 3), gz = bz * 4 + (cell & 3);
-#pragma unroll 1
+#pragma unroll 3
                 for (int o = 0; o < 27; ++o) {
                     // contacts whose base cell is node - (i, j, l) reach this node with weight N_i N_j N_l
                     const int i = o / 9, jj = (o / 3) % 3, l = o % 3;
-                    const int x = gx - i, y = gy - jj, z = gz - l;
-                    if (x < 0 || y < 0 || z < 0) continue;
-                    const int cc = compact_cell(p, (uint32_t)x, (uint32_t)y, (uint32_t)z);
-                    if (cc < 0) continue;
-                    const int2 r = c.run[cc];
+                    const int2 r = c.node_runs[(size_t)o * c.cap_nodes + q];
                     for (int k = r.x + sub; k < r.y; k += 16) {
                         float wx[3], wy[3], wz[3];
                         bspline3(c.cfx[k], wx);
@@ -445,7 +458,7 @@ __global__ __launch_bounds__(CT_WG) void k_ct_node_dir(DP p, ContactDev c) {
             c.gD[g] = D;
         }
     }
-    wg_reduce_store(acc, 2, c.part + (size_t)blockIdx.x * CT_PART + LS_CAND + 1);
+    wg_reduce_store(acc, 2, c.part_dir + (size_t)blockIdx.x * 2);
 }
 
 // C2 + G2: line-search energies for every candidate step: contact part
@@ -507,7 +520,7 @@ __global__ __launch_bounds__(CT_WG) void k_ct_ls(DP p, ContactDev c, int n_con_w
                 acc[2] += (double)(mass * dot3(t, ddl));
             }
         }
-        wg_reduce_store(acc, LS_CAND + 1, c.part + (size_t)(CT_ROWS + blockIdx.x) * CT_PART);
+        wg_reduce_store(acc, LS_CAND + 1, c.part + (size_t)blockIdx.x * CT_PART);
         return;
     }
     const int ncell = (int)p.ctl->n_active * 64;
@@ -534,7 +547,7 @@ __global__ __launch_bounds__(CT_WG) void k_ct_ls(DP p, ContactDev c, int n_con_w
             acc[2] += (double)(q.w * (D.x * D.x + D.y * D.y + D.z * D.z));
         }
     }
-    wg_reduce_store(acc, LS_CAND + 1, c.part + (size_t)(2 * CT_ROWS + b) * CT_PART);
+    wg_reduce_store(acc, LS_CAND + 1, c.part + (size_t)(CT_ROWS + b) * CT_PART);
 }
 
 // S: fixed-order sum of the partial records, choice of the step, convergence test
@@ -553,10 +566,10 @@ __global__ __launch_bounds__(1024) void k_ct_decide(ContactDev c, int n_dir_wg, 
     // entries 0..28: energies; 29: norm_dir; 30: dofs
     double v = 0;
     if (e <= LS_CAND) {
-        for (int w = r; w < n_con_wg; w += 32) v += c.part[(size_t)(CT_ROWS + w) * CT_PART + e];
-        for (int w = r; w < n_grid_wg; w += 32) v += c.part[(size_t)(2 * CT_ROWS + w) * CT_PART + e];
+        for (int w = r; w < n_con_wg; w += 32) v += c.part[(size_t)w * CT_PART + e];
+        for (int w = r; w < n_grid_wg; w += 32) v += c.part[(size_t)(CT_ROWS + w) * CT_PART + e];
     } else if (e <= LS_CAND + 2) {
-        for (int w = r; w < n_dir_wg; w += 32) v += c.part[(size_t)w * CT_PART + e];
+        for (int w = r; w < n_dir_wg; w += 32) v += c.part_dir[(size_t)w * 2 + (e - LS_CAND - 1)];
     }
     s_sum[r][e] = v;
     __syncthreads();

@@ -124,8 +124,8 @@ static int set_fixed_point_scales(mpm_engine* e) {
     std::vector<float> q0(e->np * 4);
     HIP_TRY(hipStreamSynchronize(e->stream));
     Ctl c;
-    HIP_TRY(hipMemcpy(&c, p.ctl, sizeof(Ctl), hipMemcpyDeviceToHost));
-    HIP_TRY(hipMemcpy(q0.data(), p.set[c.cur & 1].q[0], e->np * 16, hipMemcpyDeviceToHost));
+    D2H(e, &c, p.ctl, sizeof(Ctl));
+    D2H(e, q0.data(), p.set[c.cur & 1].q[0], e->np * 16);
     double mass = 0;
     for (size_t i = 0; i < e->np; ++i) mass += (double)q0[i * 4 + 3] * p.M.density;
     if (!(mass > 0) || !std::isfinite(mass)) mass = 1.0;
@@ -232,26 +232,26 @@ int mpm_finalize(mpm_handle_t e) {
                 q0[(nf + i) * 4 + d] = e->h_pos[i * 3 + d];
                 q1[(nf + i) * 4 + d] = e->h_vel[i * 3 + d];
             }
-        HIP_TRY(hipMemcpy(S0.q[0], q0.data(), np * 16, hipMemcpyHostToDevice));
-        HIP_TRY(hipMemcpy(S0.q[1], q1.data(), np * 16, hipMemcpyHostToDevice));
+        H2D(e, S0.q[0], q0.data(), np * 16);
+        H2D(e, S0.q[1], q1.data(), np * 16);
     }
     std::vector<int> iota(np);
     std::iota(iota.begin(), iota.end(), 0);
-    HIP_TRY(hipMemcpy(S0.pid, iota.data(), np * 4, hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(p.imap, iota.data(), np * 4, hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(e->d_pids_api, iota.data(), np * 4, hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(e->d_apimap, iota.data(), np * 4, hipMemcpyHostToDevice));
+    H2D(e, S0.pid, iota.data(), np * 4);
+    H2D(e, p.imap, iota.data(), np * 4);
+    H2D(e, e->d_pids_api, iota.data(), np * 4);
+    H2D(e, e->d_apimap, iota.data(), np * 4);
     std::vector<int> col(nf);
     for (int d = 0; d < 3; ++d) {
         for (size_t f = 0; f < nf; ++f) col[f] = e->h_idx[f * 3 + d] + (int)nf;
-        HIP_TRY(hipMemcpy(idx_orig[d], col.data(), nf * 4, hipMemcpyHostToDevice));
+        H2D(e, idx_orig[d], col.data(), nf * 4);
     }
     if (nf) {
         // corner vertex slots ride in fq[3].yzw (slot == original id before the first sort)
         std::vector<int> f3(nf * 4, 0);
         for (size_t f = 0; f < nf; ++f)
             for (int d = 0; d < 3; ++d) f3[f * 4 + 1 + d] = e->h_idx[f * 3 + d] + (int)nf;
-        HIP_TRY(hipMemcpy(S0.fq[3], f3.data(), nf * 16, hipMemcpyHostToDevice));
+        H2D(e, S0.fq[3], f3.data(), nf * 16);
     }
     // vertex -> (face, corner) adjacency, ascending face id
     std::vector<int> off(nv + 1, 0), fc(3 * nf);
@@ -262,8 +262,8 @@ int mpm_finalize(mpm_handle_t e) {
         for (size_t f = 0; f < nf; ++f)
             for (int c = 0; c < 3; ++c) fc[fill[e->h_idx[f * 3 + c]]++] = (int)(f << 2) | c;
     }
-    HIP_TRY(hipMemcpy(adj_off, off.data(), (nv + 1) * 4, hipMemcpyHostToDevice));
-    if (nf) HIP_TRY(hipMemcpy(adj_fc, fc.data(), 3 * nf * 4, hipMemcpyHostToDevice));
+    H2D(e, adj_off, off.data(), (nv + 1) * 4);
+    if (nf) H2D(e, adj_fc, fc.data(), 3 * nf * 4);
 
     // ---- launch geometry --------------------------------------------------
     e->g_np = (unsigned)((np + 255) / 256);
@@ -331,7 +331,7 @@ int mpm_sync(mpm_handle_t e) {
     HIP_TRY(hipGetLastError());
     if (!e->finalized && !e->dp.ctl) return 0;
     Ctl c;
-    HIP_TRY(hipMemcpy(&c, e->dp.ctl, sizeof(Ctl), hipMemcpyDeviceToHost));
+    D2H(e, &c, e->dp.ctl, sizeof(Ctl));
     if (c.error & ERR_CAPACITY) return fail(MPM_ERR_CAPACITY, "block table overflow");
     if (c.error & ERR_DRIFT)
         return fail(MPM_ERR_DRIFT,
@@ -535,7 +535,7 @@ int mpm_get_stats(mpm_handle_t e, mpm_stats_t* out) {
     REQUIRE(out, "null stats");
     HIP_TRY(hipStreamSynchronize(e->stream));
     Ctl c;
-    HIP_TRY(hipMemcpy(&c, e->dp.ctl, sizeof(Ctl), hipMemcpyDeviceToHost));
+    D2H(e, &c, e->dp.ctl, sizeof(Ctl));
     out->substeps = e->substeps;
     out->rebuilds = c.rebuilds;
     out->home_blocks = c.n_home;
@@ -603,8 +603,9 @@ int mpm_dump_obj(mpm_handle_t e, const char* filename) {
 int mpm_debug_counters(mpm_handle_t e, uint64_t* out16, int reset) {
     READY(e);
     HIP_TRY(hipStreamSynchronize(e->stream));
-    if (out16) HIP_TRY(hipMemcpy(out16, e->dp.dbgbuf, 16 * 8, hipMemcpyDeviceToHost));
-    if (reset) HIP_TRY(hipMemset(e->dp.dbgbuf, 0, 16 * 8));
+    if (out16) D2H(e, out16, e->dp.dbgbuf, 16 * 8);
+    if (reset) HIP_TRY(hipMemsetAsync(e->dp.dbgbuf, 0, 16 * 8, e->stream));
+    HIP_TRY(hipStreamSynchronize(e->stream));
     return 0;
 }
 
@@ -623,8 +624,8 @@ int mpm_external_body_force_to_host(mpm_handle_t e, float* tau_out, float* f_out
     READY(e);
     HIP_TRY(hipStreamSynchronize(e->stream));
     if (e->cb.n_bodies == 0) return 0;
-    if (tau_out) HIP_TRY(hipMemcpy(tau_out, e->cb.body_tau, e->cb.n_bodies * 12, hipMemcpyDeviceToHost));
-    if (f_out) HIP_TRY(hipMemcpy(f_out, e->cb.body_f, e->cb.n_bodies * 12, hipMemcpyDeviceToHost));
+    if (tau_out) D2H(e, tau_out, e->cb.body_tau, e->cb.n_bodies * 12);
+    if (f_out) D2H(e, f_out, e->cb.body_f, e->cb.n_bodies * 12);
     return 0;
 }
 

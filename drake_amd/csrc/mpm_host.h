@@ -90,12 +90,27 @@ struct mpm_engine {
             if (d_stage) HIP_TRY(hipFree(d_stage));
             d_stage = nullptr;
             HIP_TRY(hipMalloc(&d_stage, bytes));
-            if (poison()) HIP_TRY(hipMemset(d_stage, 0xFF, bytes));
+            if (poison()) HIP_TRY(hipMemsetAsync(d_stage, 0xFF, bytes, stream));
             stage_bytes = bytes;
         }
         return 0;
     }
 };
+
+// Blocking copies ORDERED ON THE ENGINE'S STREAM.  That stream is non-blocking: the legacy null
+// stream behind plain hipMemcpy/hipMemset does not wait for it and is not waited for by it, so
+// a plain hipMemcpy can overtake a queued hipMemsetAsync or kernel (seen as rare garbage in
+// freshly finalised engines).  Nothing in the engine may use the synchronous calls.
+#define H2D(e, dst, src, bytes)                                                                    \
+    do {                                                                                           \
+        HIP_TRY(hipMemcpyAsync((dst), (src), (bytes), hipMemcpyHostToDevice, (e)->stream));        \
+        HIP_TRY(hipStreamSynchronize((e)->stream));                                                \
+    } while (0)
+#define D2H(e, dst, src, bytes)                                                                    \
+    do {                                                                                           \
+        HIP_TRY(hipMemcpyAsync((dst), (src), (bytes), hipMemcpyDeviceToHost, (e)->stream));        \
+        HIP_TRY(hipStreamSynchronize((e)->stream));                                                \
+    } while (0)
 
 static int use(mpm_engine* e) {
     HIP_TRY(hipSetDevice(e->device));

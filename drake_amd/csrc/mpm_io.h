@@ -211,7 +211,7 @@ static int device_iota(mpm_engine* e, int** out) {
         std::iota(iota.begin(), iota.end(), 0);
         HIP_TRY(hipMalloc((void**)&e->d_iota, e->np * 4));
         e->allocs.push_back(e->d_iota);
-        HIP_TRY(hipMemcpy(e->d_iota, iota.data(), e->np * 4, hipMemcpyHostToDevice));
+        H2D(e, e->d_iota, iota.data(), e->np * 4);
     }
     *out = e->d_iota;
     return 0;
@@ -326,7 +326,7 @@ static int download_array(mpm_engine* e, int which, void* out, size_t bytes, siz
         case MPM_ARR_INDEX_MAPPINGS: {
             if ((rc = need(np * 4))) return rc;
             HIP_TRY(hipStreamSynchronize(e->stream));
-            HIP_TRY(hipMemcpy(out, which == MPM_ARR_PIDS ? e->d_pids_api : e->d_apimap, np * 4, hipMemcpyDeviceToHost));
+            D2H(e, out, which == MPM_ARR_PIDS ? e->d_pids_api : e->d_apimap, np * 4);
             return 0;
         }
         case MPM_ARR_SORT_KEYS: {
@@ -392,8 +392,7 @@ static int download_array(mpm_engine* e, int which, void* out, size_t bytes, siz
             if ((rc = need(e->cb.n * 12))) return rc;
             HIP_TRY(hipStreamSynchronize(e->stream));
             if (e->cb.n)
-                HIP_TRY(hipMemcpy(out, which == MPM_ARR_CONTACT_VEL ? e->cb.vel : e->cb.vel0, e->cb.n * 12,
-                                  hipMemcpyDeviceToHost));
+                D2H(e, out, which == MPM_ARR_CONTACT_VEL ? e->cb.vel : e->cb.vel0, e->cb.n * 12);
             return 0;
         }
         default:
@@ -409,7 +408,7 @@ static int upload_state(mpm_engine* e, const float* pos, const float* vel, const
         if ((rc = scatter_from_host<F_POS>(e, pos, np, e->d_pids_api))) return rc;
         // positions changed arbitrarily: force a re-sort before the next transfer
         int one = 1;
-        HIP_TRY(hipMemcpy(&e->dp.ctl->need_rebuild, &one, sizeof(int), hipMemcpyHostToDevice));
+        H2D(e, &e->dp.ctl->need_rebuild, &one, sizeof(int));
     }
     if (vel && (rc = scatter_from_host<F_VEL>(e, vel, np, e->d_pids_api))) return rc;
     if (affine && (rc = scatter_from_host<F_AFFINE>(e, affine, np, e->d_pids_api))) return rc;
@@ -431,7 +430,7 @@ static int api_sort(mpm_engine* e) {
     std::vector<uint32_t> keys(np);
     std::vector<int> pids(np);
     if (int rc = download_array(e, MPM_ARR_SORT_KEYS, keys.data(), np * 4, nullptr)) return rc;
-    HIP_TRY(hipMemcpy(pids.data(), e->d_pids_api, np * 4, hipMemcpyDeviceToHost));
+    D2H(e, pids.data(), e->d_pids_api, np * 4);
     const int nbits = std::min(3 * e->bits, 16);
     const uint32_t mask = nbits >= 32 ? 0xFFFFFFFFu : ((1u << nbits) - 1u);
     std::vector<uint32_t> order(np);
@@ -443,8 +442,8 @@ static int api_sort(mpm_engine* e) {
         npids[s] = pids[order[s]];
         nmap[npids[s]] = (int)s;
     }
-    HIP_TRY(hipMemcpy(e->d_pids_api, npids.data(), np * 4, hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(e->d_apimap, nmap.data(), np * 4, hipMemcpyHostToDevice));
+    H2D(e, e->d_pids_api, npids.data(), np * 4);
+    H2D(e, e->d_apimap, nmap.data(), np * 4);
     e->api_identity = false;
     return 0;
 }

@@ -16,6 +16,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <utility>
+
 #include "mpm_device.h"
 
 namespace mpm {
@@ -37,43 +39,67 @@ __global__ __launch_bounds__(64) void k_sort_hist(const uint32_t* keys, int n, i
     for (int d = lane; d < 256; d += 64) hist[(size_t)d * ntiles + tile] = s_cnt[d];
 }
 
-// exclusive scan of `total` ints in place, one 1024-thread workgroup
+// Exclusive scan of one int per thread across a 1024-thread workgroup (shared by the scans below).
+MPM_DEV int wg1024_exclusive(int v, int& total, int* s_w) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    int inc = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int t = __shfl_up(inc, d);
+        if (lane >= d) inc += t;
+    }
+    __syncthreads();   // s_w may still be read from the previous call
+    if (lane == 63) s_w[w] = inc;
+    __syncthreads();
+    int pre = 0, tot = 0;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        const int t = s_w[k];
+        pre += k < w ? t : 0;
+        tot += t;
+    }
+    total = tot;
+    return pre + inc - v;
+}
+
+// exclusive scan of `total` ints in place, one 1024-thread workgroup; every thread owns 16
+// consecutive entries (four 16-byte loads) of each 16384-entry block.  `a` must be 16-byte
+// aligned and padded to a multiple of 4 entries.
 __global__ __launch_bounds__(1024) void k_sort_scan(int* a, int total) {
     __shared__ int s_w[16];
-    __shared__ int s_carry;
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    if (tid == 0) s_carry = 0;
-    __syncthreads();
-    // every thread owns `per` consecutive entries of each 1024 * per block
-    const int per = 8;
-    for (int base = 0; base < total; base += 1024 * per) {
-        int v[per], sum = 0;
+    const int tid = threadIdx.x;
+    int carry = 0;
+    for (int base = 0; base < total; base += 16384) {
+        int4 v[4];
+        int sum = 0;
 #pragma unroll
-        for (int q = 0; q < per; ++q) {
-            const int i = base + tid * per + q;
-            v[q] = i < total ? a[i] : 0;
-            sum += v[q];
+        for (int q = 0; q < 4; ++q) {
+            const int i = base + tid * 16 + q * 4;
+            v[q] = i < total ? *reinterpret_cast<const int4*>(a + i) : make_int4(0, 0, 0, 0);
+            if (i + 1 >= total) v[q].y = 0;
+            if (i + 2 >= total) v[q].z = 0;
+            if (i + 3 >= total) v[q].w = 0;
+            sum += v[q].x + v[q].y + v[q].z + v[q].w;
         }
-        int inc = sum;
+        int block_total;
+        int run = carry + wg1024_exclusive(sum, block_total, s_w);
 #pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const int t = __shfl_up(inc, d);
-            if (lane >= d) inc += t;
+        for (int q = 0; q < 4; ++q) {
+            const int i = base + tid * 16 + q * 4;
+            int4 o;
+            o.x = run; run += v[q].x;
+            o.y = run; run += v[q].y;
+            o.z = run; run += v[q].z;
+            o.w = run; run += v[q].w;
+            if (i + 3 < total) {
+                *reinterpret_cast<int4*>(a + i) = o;
+            } else {
+                if (i < total) a[i] = o.x;
+                if (i + 1 < total) a[i + 1] = o.y;
+                if (i + 2 < total) a[i + 2] = o.z;
+            }
         }
-        if (lane == 63) s_w[w] = inc;
-        __syncthreads();
-        int pre = s_carry;
-        for (int q = 0; q < w; ++q) pre += s_w[q];
-        int run = pre + inc - sum;
-#pragma unroll
-        for (int q = 0; q < per; ++q) {
-            const int i = base + tid * per + q;
-            if (i < total) a[i] = run;
-            run += v[q];
-        }
-        __syncthreads();
-        if (tid == 1023) s_carry = pre + inc;
-        __syncthreads();
+        carry += block_total;
     }
 }
 
@@ -119,12 +145,6 @@ __global__ __launch_bounds__(64) void k_sort_scatter(const uint32_t* keys, const
 
 // Sorts n pairs by the key bits [0, bits) (stable).  `a` holds the input and receives the result;
 // `b` and `hist` are scratch (hist: 256 * ceil(n / (64 * items)) ints).
-struct SortScratch {
-    uint32_t *kb = nullptr, *vb = nullptr;
-    int* hist = nullptr;
-    size_t cap = 0, cap_hist = 0;
-};
-
 static inline int sort_items_for(size_t n) { return n > (1u << 18) ? 64 : 16; }
 
 static int radix_sort_pairs(hipStream_t s, uint32_t* ka, uint32_t* va, uint32_t* kb, uint32_t* vb, int* hist, size_t n,
