@@ -40,7 +40,7 @@ static int copy_contacts(mpm_engine* e, size_t n, const uint32_t* particle, cons
             (rc = grow(&b.order2, cap)) || (rc = grow(&b.cnode, 27 * cap)) || (rc = grow(&b.cfx, 3 * cap)) ||
             (rc = grow(&b.cmass, cap)) || (rc = grow(&b.cphi0, cap)) || (rc = grow(&b.cR, 9 * cap)) ||
             (rc = grow(&b.cv0, 3 * cap)) || (rc = grow(&b.crv, 3 * cap)) || (rc = grow(&b.cvel, 3 * cap)) ||
-            (rc = grow(&b.cHG, 12 * cap)))
+            (rc = grow(&b.crec, 4 * cap)))
             return rc;
         b.cap = cap;
     }
@@ -96,7 +96,7 @@ static ContactDev make_contact_dev(mpm_engine* e, float dt, float mu, float k, f
     c.rigid_v = b.rigid_v; c.p_WB = b.p_WB; c.vel = b.vel; c.vel0 = b.vel0;
     c.key = b.key; c.order = b.order;
     c.cnode = b.cnode; c.cfx = b.cfx; c.cmass = b.cmass; c.cphi0 = b.cphi0; c.cR = b.cR; c.cv0 = b.cv0;
-    c.crv = b.crv; c.cvel = b.cvel; c.cHG = b.cHG;
+    c.crv = b.crv; c.cvel = b.cvel; c.crec = b.crec;
     c.run = b.run; c.node_flag = b.node_flag; c.node_list = b.node_list; c.node_runs = b.node_runs;
     c.cap_nodes = (int)b.cap_cells; c.gD = b.gD;
     c.part = b.part; c.part_dir = b.part_dir; c.st = b.st;

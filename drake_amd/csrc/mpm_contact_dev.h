@@ -67,7 +67,8 @@ struct ContactDev {
     float* cv0;             // [3][n] lagged relative velocity, contact frame
     float* crv;             // [3][n] rigid velocity at the contact point
     float* cvel;            // [3][n] contact velocity (sorted order)
-    float* cHG;             // [12][n] world-frame mass-weighted Hessian (9) and gradient (3)
+    float4* crec;           // [n][4] per contact: world-frame mass-weighted Hessian (9), gradient (3), fx (3), pad --
+                            // one 64-byte line, read by the 27 nodes of the stencil every iteration
     int2* run;              // [cells] (begin, end) of the contacts whose base cell this is
     int* node_flag;         // [cells] 1 if some contact's stencil reaches the node
     int* node_list;         // [<= cells] those nodes
@@ -101,7 +102,8 @@ struct ContactBuffers {
     size_t cap_hist = 0;
     int* cnode = nullptr;
     float *cfx = nullptr, *cmass = nullptr, *cphi0 = nullptr, *cR = nullptr, *cv0 = nullptr, *crv = nullptr,
-          *cvel = nullptr, *cHG = nullptr;
+          *cvel = nullptr;
+    float4* crec = nullptr;
     int2* run = nullptr;
     int* node_flag = nullptr;
     int* node_list = nullptr;
@@ -115,7 +117,7 @@ struct ContactBuffers {
 
     void release() {
         void* ptrs[] = {slot, body, dist, normal, pos, rigid_v, p_WB, vel, vel0, key, order, key2, order2, sort_hist,
-                        cnode, cfx, cmass, cphi0, cR, cv0, crv, cvel, cHG, run, node_flag, node_list, node_runs, gD, part, part_dir, st,
+                        cnode, cfx, cmass, cphi0, cR, cv0, crv, cvel, crec, run, node_flag, node_list, node_runs, gD, part, part_dir, st,
                         body_tau, body_f};
         for (void* q : ptrs)
             if (q) (void)hipFree(q);
@@ -365,16 +367,20 @@ __global__ __launch_bounds__(256) void k_ct_contact_grad(DP p, ContactDev c, int
     mul33(RT, CH, tmp);
     mul33(tmp, R, WH);
     const float mass = c.cmass[j];
-#pragma unroll
-    for (int a = 0; a < 9; ++a) c.cHG[a * c.n + j] = mass * WH[a];
-#pragma unroll
-    for (int a = 0; a < 3; ++a) c.cHG[(9 + a) * c.n + j] = mass * WG[a];
+    float4* rec = c.crec + (size_t)j * 4;
+    rec[0] = make_float4(mass * WH[0], mass * WH[1], mass * WH[2], mass * WH[3]);
+    rec[1] = make_float4(mass * WH[4], mass * WH[5], mass * WH[6], mass * WH[7]);
+    rec[2] = make_float4(mass * WH[8], mass * WG[0], mass * WG[1], mass * WG[2]);
+    if (first) rec[3] = make_float4(c.cfx[j], c.cfx[c.n + j], c.cfx[2 * c.n + j], 0.f);
 }
 
-MPM_DEV void wg_reduce_store(double* vals, int count, double* out) {
-    // vals: per-thread values; reduces over the workgroup (CT_WG threads) into out[count]
+template <int count>
+MPM_DEV void wg_reduce_store(double* vals, double* out) {
+    // vals: per-thread values; reduces over the workgroup (CT_WG threads) into out[count].  Fully
+    // unrolled: `vals` has to stay in registers
     __shared__ double s_red[CT_WG / 64][CT_PART];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+#pragma unroll
     for (int q = 0; q < count; ++q) {
         double v = vals[q];
 #pragma unroll
@@ -395,9 +401,10 @@ MPM_DEV void wg_reduce_store(double* vals, int count, double* out) {
 // the node's contacts are the runs of its 27 neighbour base cells; lane s takes every 16th
 // contact of a run, the 16 partial sums are folded in a fixed butterfly.
 __global__ __launch_bounds__(CT_WG) void k_ct_node_dir(DP p, ContactDev c) {
+    if (c.st->done) return;   // k_ct_decide does not read the records of a finished solve
     double acc[2] = {0, 0};
     const int sub = threadIdx.x & 15;
-    if (!c.st->done) {
+    {
         const int n_nodes = c.st->n_nodes;
         const int stride = (gridDim.x * CT_WG) >> 4;
         for (int q = (blockIdx.x * CT_WG + threadIdx.x) >> 4; q < ((n_nodes + 3) & ~3); q += stride) {
@@ -407,21 +414,32 @@ __global__ __launch_bounds__(CT_WG) void k_ct_node_dir(DP p, ContactDev c) {
             float H[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, G[3] = {0.f, 0.f, 0.f};
             const float4 gq = p.gv[g];
             if (live && gq.w > 0.f) {
-#pragma unroll 3
-                for (int o = 0; o < 27; ++o) {
+                // lane s owns the runs of stencil offsets s and s + 16 (27 offsets over 16 lanes): the
+                // table walks and the contact loads of different offsets overlap across the lanes, the
+                // loop over a run's contacts is a plain stream
+#pragma unroll
+                for (int half = 0; half < 2; ++half) {
+                    const int o = sub + 16 * half;
+                    if (o >= 27) break;
                     // contacts whose base cell is node - (i, j, l) reach this node with weight N_i N_j N_l
                     const int i = o / 9, jj = (o / 3) % 3, l = o % 3;
                     const int2 r = c.node_runs[(size_t)o * c.cap_nodes + q];
-                    for (int k = r.x + sub; k < r.y; k += 16) {
+#pragma unroll 2
+                    for (int k = r.x; k < r.y; ++k) {
+                        const float4* rec = c.crec + (size_t)k * 4;
+                        const float4 r0 = rec[0], r1 = rec[1], r2 = rec[2], r3 = rec[3];
                         float wx[3], wy[3], wz[3];
-                        bspline3(c.cfx[k], wx);
-                        bspline3(c.cfx[c.n + k], wy);
-                        bspline3(c.cfx[2 * c.n + k], wz);
-                        const float w = wx[i] * wy[jj] * wz[l];
-#pragma unroll
-                        for (int t = 0; t < 9; ++t) H[t] += w * w * c.cHG[t * c.n + k];
-#pragma unroll
-                        for (int t = 0; t < 3; ++t) G[t] += w * c.cHG[(9 + t) * c.n + k];
+                        bspline3(r3.x, wx);
+                        bspline3(r3.y, wy);
+                        bspline3(r3.z, wz);
+                        const float w = (i == 0 ? wx[0] : (i == 1 ? wx[1] : wx[2])) *
+                                        (jj == 0 ? wy[0] : (jj == 1 ? wy[1] : wy[2])) *
+                                        (l == 0 ? wz[0] : (l == 1 ? wz[1] : wz[2]));
+                        const float w2 = w * w;
+                        H[0] += w2 * r0.x; H[1] += w2 * r0.y; H[2] += w2 * r0.z; H[3] += w2 * r0.w;
+                        H[4] += w2 * r1.x; H[5] += w2 * r1.y; H[6] += w2 * r1.z; H[7] += w2 * r1.w;
+                        H[8] += w2 * r2.x;
+                        G[0] += w * r2.y; G[1] += w * r2.z; G[2] += w * r2.w;
                     }
                 }
             }
@@ -458,17 +476,18 @@ __global__ __launch_bounds__(CT_WG) void k_ct_node_dir(DP p, ContactDev c) {
             c.gD[g] = D;
         }
     }
-    wg_reduce_store(acc, 2, c.part_dir + (size_t)blockIdx.x * 2);
+    wg_reduce_store<2>(acc, c.part_dir + (size_t)blockIdx.x * 2);
 }
 
 // C2 + G2: line-search energies for every candidate step: contact part
 // (cuda_mpm_kernels.cuh:1276-1473 with global_line_search = true) in workgroups [0, n_con_wg),
 // inertia part (cuda_mpm_kernels.cuh:1536-1589) in the rest
 __global__ __launch_bounds__(CT_WG) void k_ct_ls(DP p, ContactDev c, int n_con_wg, int exact, float alpha_probe) {
+    if (c.st->done) return;   // k_ct_decide does not read the records of a finished solve
     double acc[CT_PART];
 #pragma unroll
     for (int q = 0; q < CT_PART; ++q) acc[q] = 0;
-    const bool live = !c.st->done;
+    const bool live = true;
     if ((int)blockIdx.x < n_con_wg) {
         for (int j = blockIdx.x * CT_WG + threadIdx.x; live && j < c.n; j += n_con_wg * CT_WG) {
             float wx[3], wy[3], wz[3];
@@ -501,7 +520,7 @@ __global__ __launch_bounds__(CT_WG) void k_ct_ls(DP p, ContactDev c, int n_con_w
             if (!exact) {
                 acc[LS_CAND] += (double)(mass * contact_cost(cp, phi0, v0, ovl));
                 float al = 1.f;
-#pragma unroll 4
+#pragma unroll
                 for (int q = 0; q < LS_CAND; ++q) {
                     const float nv[3] = {ovl[0] - al * ddl[0], ovl[1] - al * ddl[1], ovl[2] - al * ddl[2]};
                     acc[q] += (double)(mass * contact_cost(cp, phi0, v0, nv));
@@ -520,7 +539,7 @@ __global__ __launch_bounds__(CT_WG) void k_ct_ls(DP p, ContactDev c, int n_con_w
                 acc[2] += (double)(mass * dot3(t, ddl));
             }
         }
-        wg_reduce_store(acc, LS_CAND + 1, c.part + (size_t)blockIdx.x * CT_PART);
+        wg_reduce_store<LS_CAND + 1>(acc, c.part + (size_t)blockIdx.x * CT_PART);
         return;
     }
     const int ncell = (int)p.ctl->n_active * 64;
@@ -533,7 +552,7 @@ __global__ __launch_bounds__(CT_WG) void k_ct_ls(DP p, ContactDev c, int n_con_w
         if (!exact) {
             acc[LS_CAND] += (double)(.5f * q.w * (o[0] * o[0] + o[1] * o[1] + o[2] * o[2]));
             float al = 1.f;
-#pragma unroll 4
+#pragma unroll
             for (int k = 0; k < LS_CAND; ++k) {
                 const float n0 = o[0] - al * D.x, n1 = o[1] - al * D.y, n2 = o[2] - al * D.z;
                 acc[k] += (double)(.5f * q.w * (n0 * n0 + n1 * n1 + n2 * n2));
@@ -547,7 +566,7 @@ __global__ __launch_bounds__(CT_WG) void k_ct_ls(DP p, ContactDev c, int n_con_w
             acc[2] += (double)(q.w * (D.x * D.x + D.y * D.y + D.z * D.z));
         }
     }
-    wg_reduce_store(acc, LS_CAND + 1, c.part + (size_t)(CT_ROWS + b) * CT_PART);
+    wg_reduce_store<LS_CAND + 1>(acc, c.part + (size_t)(CT_ROWS + b) * CT_PART);
 }
 
 // S: fixed-order sum of the partial records, choice of the step, convergence test
@@ -555,6 +574,7 @@ __global__ __launch_bounds__(CT_WG) void k_ct_ls(DP p, ContactDev c, int n_con_w
 // r, r + 32, ... of every kind; wave 0 adds the 32 row groups in order and decides.
 __global__ __launch_bounds__(1024) void k_ct_decide(ContactDev c, int n_dir_wg, int n_con_wg, int n_grid_wg, int exact) {
     __shared__ double s_sum[32][CT_PART];
+    __shared__ double s_dir[16][2];
     ContactState* st = c.st;
     if (st->done) {
         // "finish after this update" becomes "finished" once that update (k_ct_apply of the
@@ -568,16 +588,34 @@ __global__ __launch_bounds__(1024) void k_ct_decide(ContactDev c, int n_dir_wg, 
     if (e <= LS_CAND) {
         for (int w = r; w < n_con_wg; w += 32) v += c.part[(size_t)w * CT_PART + e];
         for (int w = r; w < n_grid_wg; w += 32) v += c.part[(size_t)(CT_ROWS + w) * CT_PART + e];
-    } else if (e <= LS_CAND + 2) {
-        for (int w = r; w < n_dir_wg; w += 32) v += c.part_dir[(size_t)w * 2 + (e - LS_CAND - 1)];
     }
     s_sum[r][e] = v;
+    // the (|Dir|^2, DoFs) records of k_ct_node_dir: thread t adds records t, t + 1024, ..., then a
+    // fixed tree over the workgroup
+    {
+        double d0 = 0, d1 = 0;
+        for (int w = threadIdx.x; w < n_dir_wg; w += 1024) {
+            d0 += c.part_dir[(size_t)w * 2];
+            d1 += c.part_dir[(size_t)w * 2 + 1];
+        }
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) {
+            d0 += __shfl_down(d0, d);
+            d1 += __shfl_down(d1, d);
+        }
+        if ((threadIdx.x & 63) == 0) {
+            s_dir[threadIdx.x >> 6][0] = d0;
+            s_dir[threadIdx.x >> 6][1] = d1;
+        }
+    }
     __syncthreads();
     if (threadIdx.x >= 64) return;
     const int lane = threadIdx.x;
     v = 0;
-    if (lane < CT_PART)
+    if (lane <= LS_CAND)
         for (int q = 0; q < 32; ++q) v += s_sum[q][lane];
+    else if (lane <= LS_CAND + 2)
+        for (int q = 0; q < 16; ++q) v += s_dir[q][lane - LS_CAND - 1];
     if (lane == LS_CAND + 1) st->norm_dir_sq = (float)v;
     if (lane == LS_CAND + 2) st->dofs = (float)v;
     if (exact) {
