@@ -48,6 +48,10 @@ struct mpm_engine {
     // slot (API) order bookkeeping: slot -> original id and its inverse
     int* d_pids_api = nullptr;
     int* d_apimap = nullptr;
+    // RebuildMapping(sort = true): scratch of the device radix sort, second pids buffer
+    uint32_t *d_sort_keys = nullptr, *d_sort_vals = nullptr, *d_sort_keys2 = nullptr, *d_sort_vals2 = nullptr;
+    int* d_sort_hist = nullptr;
+    int* d_pids_api2 = nullptr;
     int* d_iota = nullptr;     // identity map, created on first use (views in original order)
     bool api_identity = true;
     int grid_state = 0;  // 0 nothing, 1 slabs valid (after P2G), 2 grid updated

@@ -6,6 +6,7 @@
 #include <vector>
 
 #include "mpm_host.h"
+#include "mpm_sort.h"
 
 namespace mpm {
 
@@ -425,25 +426,51 @@ static int upload_state(mpm_engine* e, const float* pos, const float* vel, const
 // the low min(3*bits,16) bits of the key (cuda_mpm_solver.cu:47-68).  Slot order
 // is pure bookkeeping for this engine (pids/index_mappings), the particle data
 // itself does not move.
+namespace mpm {
+// sort input: the masked key of every slot and the slot itself
+__global__ __launch_bounds__(256) void k_api_sort_keys(DP p, const int* pids_api, uint32_t mask, uint32_t* keys,
+                                                       uint32_t* vals) {
+    const int s = blockIdx.x * 256 + threadIdx.x;
+    if (s >= p.Np) return;
+    const PSet& S = p.set[p.ctl->cur];
+    const float4 x = S.q[0][p.imap[pids_api[s]]];
+    keys[s] = cell_key(base_cell(x.x, p.dxinv), base_cell(x.y, p.dxinv), base_cell(x.z, p.dxinv)) & mask;
+    vals[s] = (uint32_t)s;
+}
+// new slot s holds the particle of old slot order[s]
+__global__ __launch_bounds__(256) void k_api_relabel(int n, const uint32_t* order, const int* pids_old, int* pids_new,
+                                                     int* apimap) {
+    const int s = blockIdx.x * 256 + threadIdx.x;
+    if (s >= n) return;
+    const int pid = pids_old[order[s]];
+    pids_new[s] = pid;
+    apimap[pid] = s;
+}
+}  // namespace mpm
+
 static int api_sort(mpm_engine* e) {
+    using namespace mpm;
     const size_t np = e->np;
-    std::vector<uint32_t> keys(np);
-    std::vector<int> pids(np);
-    if (int rc = download_array(e, MPM_ARR_SORT_KEYS, keys.data(), np * 4, nullptr)) return rc;
-    D2H(e, pids.data(), e->d_pids_api, np * 4);
-    const int nbits = std::min(3 * e->bits, 16);
-    const uint32_t mask = nbits >= 32 ? 0xFFFFFFFFu : ((1u << nbits) - 1u);
-    std::vector<uint32_t> order(np);
-    std::iota(order.begin(), order.end(), 0u);
-    std::stable_sort(order.begin(), order.end(),
-                     [&](uint32_t a, uint32_t b) { return (keys[a] & mask) < (keys[b] & mask); });
-    std::vector<int> npids(np), nmap(np);
-    for (size_t s = 0; s < np; ++s) {
-        npids[s] = pids[order[s]];
-        nmap[npids[s]] = (int)s;
+    if (!e->d_sort_keys) {
+        int rc = 0;
+        const int items = sort_items_for(np);
+        const size_t tiles = (np + (size_t)64 * items - 1) / ((size_t)64 * items);
+        if ((rc = e->dalloc(&e->d_sort_keys, np, false)) || (rc = e->dalloc(&e->d_sort_vals, np, false)) ||
+            (rc = e->dalloc(&e->d_sort_keys2, np, false)) || (rc = e->dalloc(&e->d_sort_vals2, np, false)) ||
+            (rc = e->dalloc(&e->d_sort_hist, 256 * tiles + 256, false)) || (rc = e->dalloc(&e->d_pids_api2, np, false)))
+            return rc;
     }
-    H2D(e, e->d_pids_api, npids.data(), np * 4);
-    H2D(e, e->d_apimap, nmap.data(), np * 4);
+    const int nbits = std::min(3 * e->bits, 16);
+    const uint32_t mask = (1u << nbits) - 1u;
+    hipLaunchKernelGGL(k_api_sort_keys, dim3(e->g_np), dim3(256), 0, e->stream, e->dp, (const int*)e->d_pids_api, mask,
+                       e->d_sort_keys, e->d_sort_vals);
+    if (radix_sort_pairs(e->stream, e->d_sort_keys, e->d_sort_vals, e->d_sort_keys2, e->d_sort_vals2, e->d_sort_hist, np,
+                         nbits))
+        return fail(MPM_ERR_HIP, "slot sort failed");
+    hipLaunchKernelGGL(k_api_relabel, dim3(e->g_np), dim3(256), 0, e->stream, (int)np, (const uint32_t*)e->d_sort_vals,
+                       (const int*)e->d_pids_api, e->d_pids_api2, e->d_apimap);
+    std::swap(e->d_pids_api, e->d_pids_api2);
     e->api_identity = false;
+    HIP_TRY(hipGetLastError());
     return 0;
 }

@@ -182,6 +182,31 @@ def test_free_fall_and_conservation_large():
     assert abs(pz - expect) <= 1e-4 * abs(expect)
 
 
+def test_slot_sort_is_the_stable_16_bit_sort_at_full_size():
+    """RebuildMapping(sort=true) at the benchmark size (1M particles): the slot permutation must be
+    the stable sort on the low 16 key bits (cuda_mpm_solver.cu:47-68), applied twice (a second sort
+    permutes an already permuted slot order)."""
+    from drake_amd import ARR as A, GpuMpm, scenes
+    bits, layers, res = scenes.CONFIGS["cloth_1m"]
+    g = GpuMpm(bits)
+    scenes.populate(g, scenes.cloth_stack(layers, res, bits))
+    pids = np.arange(g.n_particles, dtype=np.int32)
+    for rounds in range(2):
+        g.run_substeps(7, DT, -1)
+        g.rebuild_mapping(False)
+        keys = g.download(A.SORT_KEYS)          # key of the particle in each slot, before the sort
+        assert np.array_equal(g.download(A.PIDS), pids)
+        order = np.argsort(keys & np.uint32(0xFFFF), kind="stable")
+        g.rebuild_mapping(True)
+        pids = pids[order]
+        assert np.array_equal(g.download(A.PIDS), pids)
+        imap = np.empty_like(pids)
+        imap[pids] = np.arange(pids.size, dtype=np.int32)
+        assert np.array_equal(g.download(A.INDEX_MAPPINGS), imap)
+        assert np.array_equal(g.download(A.SORT_KEYS), keys[order])
+    assert g.stats()["error_flags"] == 0
+
+
 def test_error_paths_and_edge_cases():
     from drake_amd import GpuMpm, MpmError
     g = GpuMpm(6)
