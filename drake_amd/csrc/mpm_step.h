@@ -286,7 +286,10 @@ __global__ __launch_bounds__(512, 4) void k_p2g(DP p, float dt) {  // <= 128 VGP
         const int ngroups = idesc.z - idesc.y;
         const int4* groups = p.home_groups + group_pool_offset(p, rg, h) + idesc.y;
         struct Raw {
-            float x[3], v[3], vol, C[9], aux[6];  // aux: tau factors a,b (faces) or force (vertices)
+            float x[3], v[3], vol, C[9];
+            // tau factors a, b (faces) and force (vertices) in separate registers: merging them
+            // into one array makes the compiler route the prefetch through scratch memory
+            float ta[3], tb[3], frc[3];
             bool act, is_face;
         };
         auto load_raw = [&](int g) {
@@ -301,14 +304,15 @@ __global__ __launch_bounds__(512, 4) void k_p2g(DP p, float dt) {  // <= 128 VGP
             r.x[0] = q0.x; r.x[1] = q0.y; r.x[2] = q0.z; r.vol = q0.w;
             r.v[0] = q1.x; r.v[1] = q1.y; r.v[2] = q1.z;
             unpack_C(q1, q2, q3, r.C);
+            r.ta[0] = r.ta[1] = r.ta[2] = r.tb[0] = r.tb[1] = r.tb[2] = 0.f;
+            r.frc[0] = r.frc[1] = r.frc[2] = 0.f;
             if (r.is_face) {
                 const float4 a = p.ab0[ii];
                 const float2 b = p.ab1[ii];
-                r.aux[0] = a.x; r.aux[1] = a.y; r.aux[2] = a.z; r.aux[3] = a.w; r.aux[4] = b.x; r.aux[5] = b.y;
+                r.ta[0] = a.x; r.ta[1] = a.y; r.ta[2] = a.z; r.tb[0] = a.w; r.tb[1] = b.x; r.tb[2] = b.y;
             } else {
 #pragma unroll
-                for (int d = 0; d < 3; ++d) r.aux[d] = p.f[d][ii];
-                r.aux[3] = r.aux[4] = r.aux[5] = 0.f;
+                for (int d = 0; d < 3; ++d) r.frc[d] = p.f[d][ii];
             }
             return r;
         };
@@ -330,12 +334,12 @@ __global__ __launch_bounds__(512, 4) void k_p2g(DP p, float dt) {  // <= 128 VGP
 #pragma unroll
                     for (int r = 0; r < 3; ++r)
 #pragma unroll
-                        for (int c = 0; c < 3; ++c) B[r * 3 + c] = sdt * (cur.aux[r] * cur.aux[3 + c]) + cur.C[r * 3 + c] * m;
+                        for (int c = 0; c < 3; ++c) B[r * 3 + c] = sdt * (cur.ta[r] * cur.tb[c]) + cur.C[r * 3 + c] * m;
                 } else {
 #pragma unroll
                     for (int r = 0; r < 9; ++r) B[r] = cur.C[r] * m;
 #pragma unroll
-                    for (int r = 0; r < 3; ++r) fext[r] = cur.aux[r] * dt;
+                    for (int r = 0; r < 3; ++r) fext[r] = cur.frc[r] * dt;
                 }
 #pragma unroll
                 for (int r = 0; r < 3; ++r) {
