@@ -513,8 +513,16 @@ MPM_DEV bool sphere_sdf(const float* pos, float cx, float cy, float cz, float r,
     return len - r < 0.f;
 }
 
+constexpr int GRID_LIST = 160;   // slabs over one block: 27 neighbours x splits
+MPM_DEV int __reduce_max_sync_i32(int v) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v = max(v, __shfl_xor(v, d));
+    return v;
+}
+
 template <int MODE>
 __global__ __launch_bounds__(256) void k_grid(DP p, int bc) {
+    __shared__ int2 s_list[4][GRID_LIST];   // (item, offset index)
     const Ctl* ctl = p.ctl;
     const unsigned n_active = ctl->n_active;
     const int tid = threadIdx.x;
@@ -524,21 +532,46 @@ __global__ __launch_bounds__(256) void k_grid(DP p, int bc) {
         const int* nbr = p.act_nbr_items + (size_t)a * 27;
         float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
         if (MODE == 2) s = p.gv[(size_t)a * 64 + cell];
-#pragma unroll
-        for (int o = 0; o < (MODE == 2 ? 0 : 27); ++o) {
-            const int packed = nbr[o];   // wave-uniform: first item | count << 24 of that home block
-            if (packed < 0) continue;
-            const int tx = cx - 4 * (o / 9 - 1) + FREE_ZONE;
-            const int ty = cy - 4 * ((o / 3) % 3 - 1) + FREE_ZONE;
-            const int tz = cz - 4 * (o % 3 - 1) + FREE_ZONE;
-            const bool in_tile = !(tx < 0 || ty < 0 || tz < 0 || tx >= TILE_W || ty >= TILE_W || tz >= TILE_W);
-            const int it0 = packed & 0xFFFFFF, it1 = it0 + (packed >> 24);
-            for (int it = it0; it < it1; ++it) {
+        if (MODE != 2) {
+            // Phase 1: lanes 0..26 look at one neighbour home block each and list the slabs (one per
+            // work item of that block) whose stencils reached this block, in a fixed order
+            // (split index, then offset).  Phase 2 streams through the list: all table walks are
+            // done, the slab reads are independent and overlap.
+            int2* list = s_list[tid >> 6];
+            const int packed = cell < 27 ? nbr[cell] : -1;
+            const int it0 = packed & 0xFFFFFF, ni = packed < 0 ? 0 : (packed >> 24);
+            int cnt = 0;
+            const int nimax = __reduce_max_sync_i32(ni);
+            for (int k = 0; k < nimax; ++k) {
                 // this block seen from the home block is at offset -o
-                if (!((p.slab_mask[it] >> (26 - o)) & 1u) || !in_tile) continue;
-                const float4 t = p.slab[(size_t)it * TILE_N + (tx * TILE_W + ty) * TILE_W + tz];
-                s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w;
+                const bool hit = k < ni && ((p.slab_mask[it0 + k] >> (26 - cell)) & 1u);
+                const unsigned long long m = __ballot(hit);
+                if (hit) {
+                    const int at = cnt + (int)__popcll(m & ((1ull << cell) - 1ull));
+                    if (at < GRID_LIST) list[at] = make_int2(it0 + k, cell);
+                }
+                cnt += (int)__popcll(m);
             }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            cnt = min(cnt, GRID_LIST);   // (more than GRID_LIST slabs over one block: see k_rb_tables, ERR_CAPACITY)
+#pragma unroll 4
+            for (int e = 0; e < cnt; ++e) {
+                const int2 en = list[e];
+                const int it = en.x, o = en.y;
+                const int tx = cx - 4 * (o / 9 - 1) + FREE_ZONE;
+                const int ty = cy - 4 * ((o / 3) % 3 - 1) + FREE_ZONE;
+                const int tz = cz - 4 * (o % 3 - 1) + FREE_ZONE;
+                // branch-free so that the unrolled loads are issued back to back: lanes outside the
+                // slab read its node 0 and add nothing
+                const bool in_tile = !(tx < 0 || ty < 0 || tz < 0 || tx >= TILE_W || ty >= TILE_W || tz >= TILE_W);
+                const int node = in_tile ? (tx * TILE_W + ty) * TILE_W + tz : 0;
+                const float4 t = p.slab[(size_t)it * TILE_N + node];
+                s.x += in_tile ? t.x : 0.f; s.y += in_tile ? t.y : 0.f;
+                s.z += in_tile ? t.z : 0.f; s.w += in_tile ? t.w : 0.f;
+            }
+            __builtin_amdgcn_wave_barrier();   // the list is reused by the wave's next block
         }
         const size_t gi = (size_t)a * 64 + cell;
         if (MODE == 0) {
