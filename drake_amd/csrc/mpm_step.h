@@ -639,14 +639,24 @@ __global__ __launch_bounds__(256) void k_grid(DP p, int bc) {
 // Stage the (TILE_W)^3 node velocities around a home block into LDS.
 MPM_DEV void load_tile(const DP& p, unsigned h, float4* tile, const float4* field, int nthreads) {
     const int* nbr = p.home_nbr_act + (size_t)h * 27;
-    for (int n = threadIdx.x; n < TILE_N; n += nthreads) {
+    // two nodes per thread (TILE_N <= 2 * nthreads), branch-free and in three sweeps so that the
+    // table loads and then the node loads of both are in flight together
+    int a[2], cell[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int n = min((int)threadIdx.x + q * nthreads, TILE_N - 1);
         const int tx = n / (TILE_W * TILE_W), ty = (n / TILE_W) % TILE_W, tz = n % TILE_W;
         const int qx = tx - FREE_ZONE + 4, qy = ty - FREE_ZONE + 4, qz = tz - FREE_ZONE + 4;  // >= 2
-        const int o = (qx >> 2) * 9 + (qy >> 2) * 3 + (qz >> 2);
-        const int a = nbr[o];
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (a >= 0) v = field[(size_t)a * 64 + ((qx & 3) << 4) + ((qy & 3) << 2) + (qz & 3)];
-        tile[n] = v;
+        a[q] = nbr[(qx >> 2) * 9 + (qy >> 2) * 3 + (qz >> 2)];
+        cell[q] = ((qx & 3) << 4) + ((qy & 3) << 2) + (qz & 3);
+    }
+    float4 v[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) v[q] = field[(size_t)max(a[q], 0) * 64 + cell[q]];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int n = (int)threadIdx.x + q * nthreads;
+        if (n < TILE_N) tile[n] = a[q] >= 0 ? v[q] : make_float4(0.f, 0.f, 0.f, 0.f);
     }
 }
 
