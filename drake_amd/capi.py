@@ -54,7 +54,7 @@ SYMBOLS = [
     "mpm_copy_contact_pairs", "mpm_update_contact", "mpm_set_dump_dir", "mpm_substep", "mpm_run_substeps",
     "mpm_profile_substeps", "mpm_set_stream", "mpm_get_stats", "mpm_debug_counters", "mpm_grid_gather",
     "mpm_halo_buffer_bytes", "mpm_halo_pack", "mpm_halo_add", "mpm_update_grid_from_sums", "mpm_substep_begin",
-    "mpm_substep_end", "mpm_download_array", "mpm_upload_particle_state",
+    "mpm_substep_end", "mpm_substep_begin_halo", "mpm_substep_end_halo", "mpm_download_array", "mpm_upload_particle_state",
 ]
 
 
@@ -107,6 +107,8 @@ def load_library(build: bool = True):
         "mpm_update_grid_from_sums": [vp, i],
         "mpm_substep_begin": [vp, f],
         "mpm_substep_end": [vp, f, i],
+        "mpm_substep_begin_halo": [vp, f, i, P(C.c_int), P(C.c_int), P(C.c_int), P(C.c_void_p), sz],
+        "mpm_substep_end_halo": [vp, f, i, i, P(C.c_void_p), sz],
         "mpm_debug_counters": [vp, P(C.c_uint64), i],
         "mpm_download_array": [vp, i, vp, sz, P(sz)],
         "mpm_upload_particle_state": [vp, vp, vp, vp, vp, vp],
@@ -275,6 +277,26 @@ class GpuMpm:
 
     def substep_end(self, dt: float, mpm_bc: int = -1):
         self._ck(self.lib.mpm_substep_end(self.h, dt, mpm_bc))
+
+    @staticmethod
+    def halo_zone_args(zones, send_ptrs):
+        """ctypes argument pack for substep_begin_halo: zones = [(bx_lo, bx_hi, shift_bx)], built once."""
+        n = len(zones)
+        arr = lambda vals: (C.c_int * max(n, 1))(*vals)
+        return (n, arr([z[0] for z in zones]), arr([z[1] for z in zones]), arr([z[2] for z in zones]),
+                (C.c_void_p * max(n, 1))(*send_ptrs))
+
+    @staticmethod
+    def halo_buffer_args(ptrs):
+        return (len(ptrs), (C.c_void_p * max(len(ptrs), 1))(*ptrs))
+
+    def substep_begin_halo(self, dt: float, zone_args, capacity_blocks: int):
+        n, lo, hi, sh, bufs = zone_args
+        self._ck(self.lib.mpm_substep_begin_halo(self.h, dt, n, lo, hi, sh, bufs, capacity_blocks))
+
+    def substep_end_halo(self, dt: float, mpm_bc: int, buffer_args, capacity_blocks: int):
+        n, bufs = buffer_args
+        self._ck(self.lib.mpm_substep_end_halo(self.h, dt, mpm_bc, n, bufs, capacity_blocks))
 
     def update_grid_from_sums(self, mpm_bc: int = -1):
         self._ck(self.lib.mpm_update_grid_from_sums(self.h, mpm_bc))

@@ -430,6 +430,22 @@ int mpm_substep_end(mpm_handle_t e, float dt, int bc) {
     return 0;
 }
 
+int mpm_substep_begin_halo(mpm_handle_t e, float dt, int n, const int* bx_lo, const int* bx_hi, const int* shift_bx,
+                           void* const* send_bufs, size_t cap) {
+    REQUIRE(n >= 0 && n <= 8 && (n == 0 || (bx_lo && bx_hi && shift_bx && send_bufs)), "bad halo zone list");
+    if (int rc = mpm_substep_begin(e, dt)) return rc;
+    for (int i = 0; i < n; ++i)
+        if (int rc = mpm_halo_pack(e, bx_lo[i], bx_hi[i], shift_bx[i], send_bufs[i], cap)) return rc;
+    return 0;
+}
+
+int mpm_substep_end_halo(mpm_handle_t e, float dt, int bc, int n, const void* const* recv_bufs, size_t cap) {
+    REQUIRE(n >= 0 && n <= 8 && (n == 0 || recv_bufs), "bad halo buffer list");
+    for (int i = 0; i < n; ++i)
+        if (int rc = mpm_halo_add(e, recv_bufs[i], cap)) return rc;
+    return mpm_substep_end(e, dt, bc);
+}
+
 int mpm_grid_to_particle(mpm_handle_t e, float dt) {
     READY(e);
     REQUIRE(e->grid_state == 2, "GridToParticle before UpdateGrid");

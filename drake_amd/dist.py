@@ -34,6 +34,7 @@ class HaloChain:
         self.zone_lo = (cut_lo_block - zone_blocks, cut_lo_block + zone_blocks - 1)
         self.zone_hi = (cut_hi_block - zone_blocks, cut_hi_block + zone_blocks - 1)
         self.pitch = pitch_blocks
+        self._fast_args = None
         backend = dist.get_backend(group) if world > 1 else "none"
         self.staged = backend != "nccl"
         self.device = device if device is not None else torch.device("cpu")
@@ -47,23 +48,32 @@ class HaloChain:
             self.h_recv = {n: torch.zeros(nbytes, dtype=torch.uint8) for n in self.recv}
 
     # -- one exchange: pack -> send/recv -> add ------------------------------------
+    def _zones(self):
+        z = []
+        if self.left is not None:   # my left zone, relabelled into the left neighbour's coordinates
+            z.append((self.zone_lo[0], self.zone_lo[1], +self.pitch, self.left))
+        if self.right is not None:
+            z.append((self.zone_hi[0], self.zone_hi[1], -self.pitch, self.right))
+        return z
+
+    def _transfer(self):
+        if self.staged:
+            self._exchange_staged()
+            return
+        ops = []
+        for n in self.send:
+            ops.append(dist.P2POp(dist.isend, self.send[n], n, group=self.group))
+            ops.append(dist.P2POp(dist.irecv, self.recv[n], n, group=self.group))
+        for w in dist.batch_isend_irecv(ops):
+            w.wait()   # stream-ordered: the current stream waits, the host does not
+
     def exchange(self):
         if self.world == 1:
             return
         e = self.e
-        if self.left is not None:   # my left zone, relabelled into the left neighbour's coordinates
-            e.halo_pack(self.zone_lo[0], self.zone_lo[1], +self.pitch, self.send[self.left].data_ptr(), self.cap)
-        if self.right is not None:
-            e.halo_pack(self.zone_hi[0], self.zone_hi[1], -self.pitch, self.send[self.right].data_ptr(), self.cap)
-        if self.staged:
-            self._exchange_staged()
-        else:
-            ops = []
-            for n in self.send:
-                ops.append(dist.P2POp(dist.isend, self.send[n], n, group=self.group))
-                ops.append(dist.P2POp(dist.irecv, self.recv[n], n, group=self.group))
-            for w in dist.batch_isend_irecv(ops):
-                w.wait()   # stream-ordered: the current stream waits, the host does not
+        for lo, hi, shift, n in self._zones():
+            e.halo_pack(lo, hi, shift, self.send[n].data_ptr(), self.cap)
+        self._transfer()
         for n in self.recv:
             e.halo_add(self.recv[n].data_ptr(), self.cap)
 
@@ -85,9 +95,20 @@ class HaloChain:
 
     # -- one substep of the whole chain ----------------------------------------------
     def substep(self, dt: float, mpm_bc: int = -1):
-        self.e.substep_begin(dt)
+        e = self.e
+        if self.world > 1 and hasattr(e, "substep_begin_halo"):
+            # two host calls per substep: (re-sort, FEM, P2G, gather, packs) | exchange | (adds, update, G2P)
+            if self._fast_args is None:
+                zones = self._zones()
+                self._fast_args = (e.halo_zone_args([z[:3] for z in zones], [self.send[z[3]].data_ptr() for z in zones]),
+                                   e.halo_buffer_args([self.recv[n].data_ptr() for n in self.recv]))
+            e.substep_begin_halo(dt, self._fast_args[0], self.cap)
+            self._transfer()
+            e.substep_end_halo(dt, mpm_bc, self._fast_args[1], self.cap)
+            return
+        e.substep_begin(dt)
         self.exchange()
-        self.e.substep_end(dt, mpm_bc)
+        e.substep_end(dt, mpm_bc)
 
     def run_substeps(self, n: int, dt: float, mpm_bc: int = -1):
         for _ in range(n):
