@@ -22,6 +22,22 @@ class MpmError(RuntimeError):
         self.code = code
 
 
+class Collider(C.Structure):
+    """mpm_collider_t: kind 0 half-space (z_B <= 0 inside), 1 sphere, 2 box (half extents), 3 capsule (z_B)."""
+    _fields_ = [("kind", C.c_int32), ("body", C.c_uint32), ("p_WB", C.c_float * 3), ("R_WB", C.c_float * 9),
+                ("dims", C.c_float * 3), ("v", C.c_float * 3), ("w", C.c_float * 3)]
+
+    def __init__(self, kind, body=0, p_WB=(0, 0, 0), R_WB=None, dims=(0, 0, 0), v=(0, 0, 0), w=(0, 0, 0)):
+        super().__init__()
+        self.kind, self.body = int(kind), int(body)
+        R = np.eye(3, dtype=np.float32) if R_WB is None else np.asarray(R_WB, np.float32).reshape(3, 3)
+        self.p_WB[:] = [float(x) for x in p_WB]
+        self.R_WB[:] = [float(x) for x in R.reshape(-1)]
+        self.dims[:] = [float(x) for x in dims]
+        self.v[:] = [float(x) for x in v]
+        self.w[:] = [float(x) for x in w]
+
+
 class Material(C.Structure):
     _fields_ = [
         ("youngs_modulus", C.c_float), ("poisson_ratio", C.c_float), ("density", C.c_float), ("gamma", C.c_float),
@@ -51,7 +67,7 @@ SYMBOLS = [
     "mpm_counts", "mpm_grid_touched_cnt", "mpm_dump_cpu_state", "mpm_reallocate_external_bodies",
     "mpm_external_body_force_to_host", "mpm_rebuild_mapping", "mpm_calc_fem_state_and_force", "mpm_particle_to_grid",
     "mpm_update_grid", "mpm_grid_to_particle", "mpm_sync", "mpm_sync_particle_state_to_cpu", "mpm_dump_obj",
-    "mpm_copy_contact_pairs", "mpm_update_contact", "mpm_set_dump_dir", "mpm_substep", "mpm_run_substeps",
+    "mpm_copy_contact_pairs", "mpm_generate_contact_pairs", "mpm_download_contact_pairs", "mpm_update_contact", "mpm_set_dump_dir", "mpm_substep", "mpm_run_substeps",
     "mpm_profile_substeps", "mpm_set_stream", "mpm_get_stats", "mpm_debug_counters", "mpm_grid_gather",
     "mpm_halo_buffer_bytes", "mpm_halo_pack", "mpm_halo_add", "mpm_update_grid_from_sums", "mpm_substep_begin",
     "mpm_substep_end", "mpm_substep_begin_halo", "mpm_substep_end_halo", "mpm_download_array", "mpm_upload_particle_state",
@@ -107,6 +123,8 @@ def load_library(build: bool = True):
         "mpm_update_grid_from_sums": [vp, i],
         "mpm_substep_begin": [vp, f],
         "mpm_substep_end": [vp, f, i],
+        "mpm_generate_contact_pairs": [vp, sz, vp, P(sz)],
+        "mpm_download_contact_pairs": [vp, vp, vp, vp, vp, vp, vp, vp],
         "mpm_substep_begin_halo": [vp, f, i, P(C.c_int), P(C.c_int), P(C.c_int), P(C.c_void_p), sz],
         "mpm_substep_end_halo": [vp, f, i, i, P(C.c_void_p), sz],
         "mpm_debug_counters": [vp, P(C.c_uint64), i],
@@ -236,6 +254,24 @@ class GpuMpm:
         arrs = [_f32(dist), _f32(normal, (-1, 3)), _f32(pos, (-1, 3)), _f32(rigid_v, (-1, 3)), _f32(rigid_p_WB, (-1, 3))]
         self._ck(self.lib.mpm_copy_contact_pairs(self.h, n, _ptr(particle), _ptr(body), *[_ptr(a) for a in arrs]))
         self._n_contacts = n
+
+    def generate_contact_pairs(self, colliders) -> int:
+        """Device-side CalcMpmContactPairs + CopyContactPairs for analytic colliders; returns the pair count."""
+        arr = (Collider * max(len(colliders), 1))(*colliders)
+        n = C.c_size_t()
+        self._ck(self.lib.mpm_generate_contact_pairs(self.h, len(colliders), arr, C.byref(n)))
+        self._n_contacts = int(n.value)
+        return self._n_contacts
+
+    def download_contact_pairs(self):
+        """(particle, body, dist, normal, pos, rigid_v, rigid_p_WB) of the pairs currently in the engine."""
+        n = getattr(self, "_n_contacts", 0)
+        particle, body = np.zeros(n, np.uint32), np.zeros(n, np.uint32)
+        dist = np.zeros(n, np.float32)
+        v3 = [np.zeros((n, 3), np.float32) for _ in range(4)]
+        self._ck(self.lib.mpm_download_contact_pairs(self.h, _ptr(particle), _ptr(body), _ptr(dist),
+                                                     *[_ptr(a) for a in v3]))
+        return (particle, body, dist, *v3)
 
     def update_contact(self, dt, friction_mu, stiffness, damping, exact_line_search=False, frame=0, substep=0,
                        dump=False, max_newton_iterations=0):

@@ -6,6 +6,7 @@
 #include <tuple>
 #include <vector>
 
+#include "../../include/mpm_hip.h"
 #include "mpm_host.h"
 #include "mpm_sort.h"
 
@@ -23,17 +24,13 @@ static int grow(T** ptr, size_t n) {
 }
 
 // GpuMpmState::ReallocateContacts (cuda_mpm_model.cu:267-317) + the uploads of CopyContactPairs
-static int copy_contacts(mpm_engine* e, size_t n, const uint32_t* particle, const uint32_t* body, const float* dist,
-                         const float* normal, const float* pos, const float* rigid_v, const float* p_WB) {
+static int ensure_contact_capacity(mpm_engine* e, size_t n) {
     ContactBuffers& b = e->cb;
-    b.n = n;
-    if (n == 0) return 0;
-    for (size_t k = 0; k < n; ++k) REQUIRE(particle[k] < e->np, "contact particle index out of range");
-    for (size_t k = 0; k < n; ++k) REQUIRE(body[k] < std::max<size_t>(b.n_bodies, 1), "contact body index out of range");
     if (n > b.cap) {
         const size_t cap = n + n / 4;
         int rc;
-        if ((rc = grow(&b.slot, cap)) || (rc = grow(&b.body, cap)) || (rc = grow(&b.dist, cap)) ||
+        if ((rc = grow(&b.api_idx, cap)) || (rc = grow(&b.slot, cap)) || (rc = grow(&b.body, cap)) ||
+            (rc = grow(&b.dist, cap)) ||
             (rc = grow(&b.normal, 3 * cap)) || (rc = grow(&b.pos, 3 * cap)) || (rc = grow(&b.rigid_v, 3 * cap)) ||
             (rc = grow(&b.p_WB, 3 * cap)) || (rc = grow(&b.vel, 3 * cap)) || (rc = grow(&b.vel0, 3 * cap)) ||
             (rc = grow(&b.key, cap)) || (rc = grow(&b.order, cap)) || (rc = grow(&b.key2, cap)) ||
@@ -62,9 +59,19 @@ static int copy_contacts(mpm_engine* e, size_t n, const uint32_t* particle, cons
             return rc;
         b.cap_cells = cells;
     }
-    // the slot staging buffer doubles as the upload target for the API slot indices
-    if (int rc = e->stage(n * 4)) return rc;
-    HIP_TRY(hipMemcpyAsync(e->d_stage, particle, n * 4, hipMemcpyHostToDevice, e->stream));
+    return 0;
+}
+
+// GpuMpmState::ReallocateContacts (cuda_mpm_model.cu:267-317) + the uploads of CopyContactPairs
+static int copy_contacts(mpm_engine* e, size_t n, const uint32_t* particle, const uint32_t* body, const float* dist,
+                         const float* normal, const float* pos, const float* rigid_v, const float* p_WB) {
+    ContactBuffers& b = e->cb;
+    b.n = n;
+    if (n == 0) return 0;
+    for (size_t k = 0; k < n; ++k) REQUIRE(particle[k] < e->np, "contact particle index out of range");
+    for (size_t k = 0; k < n; ++k) REQUIRE(body[k] < std::max<size_t>(b.n_bodies, 1), "contact body index out of range");
+    if (int rc = ensure_contact_capacity(e, n)) return rc;
+    HIP_TRY(hipMemcpyAsync(b.api_idx, particle, n * 4, hipMemcpyHostToDevice, e->stream));
     HIP_TRY(hipMemcpyAsync(b.body, body, n * 4, hipMemcpyHostToDevice, e->stream));
     HIP_TRY(hipMemcpyAsync(b.dist, dist, n * 4, hipMemcpyHostToDevice, e->stream));
     HIP_TRY(hipMemcpyAsync(b.normal, normal, n * 12, hipMemcpyHostToDevice, e->stream));
@@ -72,7 +79,7 @@ static int copy_contacts(mpm_engine* e, size_t n, const uint32_t* particle, cons
     HIP_TRY(hipMemcpyAsync(b.rigid_v, rigid_v, n * 12, hipMemcpyHostToDevice, e->stream));
     HIP_TRY(hipMemcpyAsync(b.p_WB, p_WB, n * 12, hipMemcpyHostToDevice, e->stream));
     const unsigned g = (unsigned)((n + 255) / 256);
-    hipLaunchKernelGGL(k_ct_slots, dim3(g), dim3(256), 0, e->stream, (int)n, (const uint32_t*)e->d_stage,
+    hipLaunchKernelGGL(k_ct_slots, dim3(g), dim3(256), 0, e->stream, (int)n, (const uint32_t*)b.api_idx,
                        e->d_pids_api, e->dp.imap, b.slot);
     ContactDev c{};
     c.n = (int)n;
@@ -80,6 +87,64 @@ static int copy_contacts(mpm_engine* e, size_t n, const uint32_t* particle, cons
     c.vel = b.vel;
     hipLaunchKernelGGL(k_ct_init_vel, dim3(g), dim3(256), 0, e->stream, e->dp, c);
     HIP_TRY(hipStreamSynchronize(e->stream));  // the host arrays may be released by the caller
+    return 0;
+}
+
+// Device-side CalcMpmContactPairs + CopyContactPairs for analytic colliders (include/mpm_hip.h)
+static int generate_contacts(mpm_engine* e, size_t n_col, const mpm_collider_t* cols, size_t* n_out) {
+    static_assert(sizeof(Collider) == sizeof(mpm_collider_t), "collider layouts differ");
+    ContactBuffers& b = e->cb;
+    const DP& p = e->dp;
+    hipStream_t s = e->stream;
+    b.n = 0;
+    if (n_out) *n_out = 0;
+    if (n_col == 0) return 0;
+    for (size_t j = 0; j < n_col; ++j) {
+        REQUIRE(cols[j].kind >= 0 && cols[j].kind <= 3, "unknown collider kind");
+        REQUIRE(cols[j].body < std::max<size_t>(b.n_bodies, 1), "collider body index out of range");
+    }
+    if (n_col > b.cap_colliders) {
+        if (int rc = grow(&b.colliders, n_col)) return rc;
+        b.cap_colliders = n_col;
+    }
+    const size_t np = e->np, padded = ((np + 1 + 4095) / 4096) * 4096;
+    if (!b.gen_cnt) {
+        int rc;
+        if ((rc = grow(&b.gen_cnt, padded)) || (rc = grow(&b.gen_sums, padded / 4096 + 8))) return rc;
+    }
+    H2D(e, b.colliders, cols, n_col * sizeof(Collider));
+    HIP_TRY(hipMemsetAsync(b.gen_cnt, 0, padded * 4, s));
+    hipLaunchKernelGGL(k_ct_gen_count, dim3(e->g_np), dim3(256), 0, s, p, (const int*)e->d_pids_api, (int)n_col,
+                       (const Collider*)b.colliders, b.gen_cnt);
+    if (device_exclusive_scan(s, b.gen_cnt, np + 1, b.gen_sums)) return fail(MPM_ERR_HIP, "contact scan failed");
+    int total = 0;
+    D2H(e, &total, b.gen_cnt + np, 4);   // the one number the host needs: how many pairs
+    if (total <= 0) return 0;
+    if (int rc = ensure_contact_capacity(e, (size_t)total)) return rc;
+    ContactDev c{};
+    c.n = total;
+    c.slot = b.slot; c.body = b.body; c.dist = b.dist; c.normal = b.normal; c.pos = b.pos;
+    c.rigid_v = b.rigid_v; c.p_WB = b.p_WB; c.vel = b.vel;
+    hipLaunchKernelGGL(k_ct_gen_write, dim3(e->g_np), dim3(256), 0, s, p, (const int*)e->d_pids_api, (int)n_col,
+                       (const Collider*)b.colliders, (const int*)b.gen_cnt, total, b.api_idx, c);
+    HIP_TRY(hipGetLastError());
+    b.n = (size_t)total;
+    if (n_out) *n_out = (size_t)total;
+    return 0;
+}
+
+static int download_contacts(mpm_engine* e, uint32_t* particle, uint32_t* body, float* dist, float* normal, float* pos,
+                             float* rigid_v, float* p_WB) {
+    const ContactBuffers& b = e->cb;
+    const size_t n = b.n;
+    if (n == 0) return 0;
+    if (particle) D2H(e, particle, b.api_idx, n * 4);
+    if (body) D2H(e, body, b.body, n * 4);
+    if (dist) D2H(e, dist, b.dist, n * 4);
+    if (normal) D2H(e, normal, b.normal, n * 12);
+    if (pos) D2H(e, pos, b.pos, n * 12);
+    if (rigid_v) D2H(e, rigid_v, b.rigid_v, n * 12);
+    if (p_WB) D2H(e, p_WB, b.p_WB, n * 12);
     return 0;
 }
 

@@ -83,6 +83,12 @@ struct ContactDev {
     int n_bodies;
 };
 
+struct Collider {        // mirrors mpm_collider_t (include/mpm_hip.h)
+    int kind;
+    uint32_t body;
+    float p[3], R[9], dims[3], v[3], w[3];
+};
+
 struct ContactBuffers {
     size_t n = 0, cap = 0;
     size_t n_bodies = 0, cap_bodies = 0;
@@ -97,6 +103,10 @@ struct ContactBuffers {
     float* p_WB = nullptr;
     float* vel = nullptr;       // contact_vel
     float* vel0 = nullptr;      // contact_vel0
+    uint32_t* api_idx = nullptr;  // particle_in_contact_index (caller's slot), kept for downloads
+    Collider* colliders = nullptr;
+    size_t cap_colliders = 0;
+    int *gen_cnt = nullptr, *gen_sums = nullptr;
     uint32_t *key = nullptr, *order = nullptr, *key2 = nullptr, *order2 = nullptr;
     int* sort_hist = nullptr;
     size_t cap_hist = 0;
@@ -116,7 +126,7 @@ struct ContactBuffers {
     float* body_f = nullptr;    // F_Bq_W_f
 
     void release() {
-        void* ptrs[] = {slot, body, dist, normal, pos, rigid_v, p_WB, vel, vel0, key, order, key2, order2, sort_hist,
+        void* ptrs[] = {api_idx, colliders, gen_cnt, gen_sums, slot, body, dist, normal, pos, rigid_v, p_WB, vel, vel0, key, order, key2, order2, sort_hist,
                         cnode, cfx, cmass, cphi0, cR, cv0, crv, cvel, crec, run, node_flag, node_list, node_runs, gD, part, part_dir, st,
                         body_tau, body_f};
         for (void* q : ptrs)
@@ -158,6 +168,96 @@ __global__ __launch_bounds__(256) void k_ct_init_vel(DP p, ContactDev c) {
     const PSet& S = p.set[p.ctl->cur];
     const float4 v = S.q[1][c.slot[k]];
     c.vel[k * 3] = v.x; c.vel[k * 3 + 1] = v.y; c.vel[k * 3 + 2] = v.z;
+}
+
+// ---- device-side CalcMpmContactPairs (deformable_driver.h:120-194) ---------------------------
+// signed distance of the world point x to collider c and its unit gradient in the world
+MPM_DEV float collider_sdf(const Collider& c, const float* x, float* grad) {
+    const float d[3] = {x[0] - c.p[0], x[1] - c.p[1], x[2] - c.p[2]};
+    // body frame: xb = R^T d
+    const float xb[3] = {c.R[0] * d[0] + c.R[3] * d[1] + c.R[6] * d[2], c.R[1] * d[0] + c.R[4] * d[1] + c.R[7] * d[2],
+                         c.R[2] * d[0] + c.R[5] * d[1] + c.R[8] * d[2]};
+    float gb[3] = {0.f, 0.f, 1.f}, phi;
+    if (c.kind == 0) {            // half-space z_B <= 0
+        phi = xb[2];
+    } else if (c.kind == 1) {     // sphere
+        const float len = sqrtf(xb[0] * xb[0] + xb[1] * xb[1] + xb[2] * xb[2]);
+        phi = len - c.dims[0];
+        if (len > 0.f) { gb[0] = xb[0] / len; gb[1] = xb[1] / len; gb[2] = xb[2] / len; }
+    } else if (c.kind == 2) {     // box with half extents dims
+        const float q[3] = {fabsf(xb[0]) - c.dims[0], fabsf(xb[1]) - c.dims[1], fabsf(xb[2]) - c.dims[2]};
+        const float sg[3] = {xb[0] < 0.f ? -1.f : 1.f, xb[1] < 0.f ? -1.f : 1.f, xb[2] < 0.f ? -1.f : 1.f};
+        const float m = fmaxf(q[0], fmaxf(q[1], q[2]));
+        if (m <= 0.f) {           // inside: distance to the nearest face
+            const int a = (q[0] >= q[1] && q[0] >= q[2]) ? 0 : (q[1] >= q[2] ? 1 : 2);
+            phi = m;
+            gb[0] = a == 0 ? sg[0] : 0.f; gb[1] = a == 1 ? sg[1] : 0.f; gb[2] = a == 2 ? sg[2] : 0.f;
+        } else {
+            const float o[3] = {fmaxf(q[0], 0.f), fmaxf(q[1], 0.f), fmaxf(q[2], 0.f)};
+            phi = sqrtf(o[0] * o[0] + o[1] * o[1] + o[2] * o[2]);
+            gb[0] = sg[0] * o[0] / phi; gb[1] = sg[1] * o[1] / phi; gb[2] = sg[2] * o[2] / phi;
+        }
+    } else {                      // capsule along z_B
+        const float zc = fminf(fmaxf(xb[2], -c.dims[1]), c.dims[1]);
+        const float r[3] = {xb[0], xb[1], xb[2] - zc};
+        const float len = sqrtf(r[0] * r[0] + r[1] * r[1] + r[2] * r[2]);
+        phi = len - c.dims[0];
+        if (len > 0.f) { gb[0] = r[0] / len; gb[1] = r[1] / len; gb[2] = r[2] / len; }
+    }
+    mulv3(c.R, gb, grad);         // world = R gb
+    return phi;
+}
+
+// P1: number of penetrated colliders per particle slot (the caller's slot order)
+__global__ __launch_bounds__(256) void k_ct_gen_count(DP p, const int* pids_api, int n_col, const Collider* cols,
+                                                      int* cnt) {
+    const int s = blockIdx.x * 256 + threadIdx.x;
+    if (s >= p.Np) return;
+    const PSet& S = p.set[p.ctl->cur];
+    const float4 q = S.q[0][p.imap[pids_api[s]]];
+    const float x[3] = {q.x, q.y, q.z};
+    int n = 0;
+    for (int j = 0; j < n_col; ++j) {
+        float g[3];
+        n += collider_sdf(cols[j], x, g) < 0.f ? 1 : 0;
+    }
+    cnt[s] = n;
+}
+
+// P2: the pairs, at the scanned offsets: ascending (slot, collider)
+__global__ __launch_bounds__(256) void k_ct_gen_write(DP p, const int* pids_api, int n_col, const Collider* cols,
+                                                      const int* offs, int cap, uint32_t* api_idx, ContactDev c) {
+    const int s = blockIdx.x * 256 + threadIdx.x;
+    if (s >= p.Np) return;
+    int at = offs[s];
+    if (offs[s + 1] == at) return;
+    const PSet& S = p.set[p.ctl->cur];
+    const uint32_t slot = (uint32_t)p.imap[pids_api[s]];
+    const float4 q = S.q[0][slot], vq = S.q[1][slot];
+    const float x[3] = {q.x, q.y, q.z};
+    for (int j = 0; j < n_col; ++j) {
+        const Collider& cl = cols[j];
+        float g[3];
+        const float phi = collider_sdf(cl, x, g);
+        if (!(phi < 0.f) || at >= cap) continue;
+        api_idx[at] = (uint32_t)s;
+        const_cast<uint32_t*>(c.slot)[at] = slot;
+        const_cast<uint32_t*>(c.body)[at] = cl.body;
+        const_cast<float*>(c.dist)[at] = phi;
+        const float r[3] = {x[0] - cl.p[0], x[1] - cl.p[1], x[2] - cl.p[2]};
+        const float rv[3] = {cl.v[0] + cl.w[1] * r[2] - cl.w[2] * r[1], cl.v[1] + cl.w[2] * r[0] - cl.w[0] * r[2],
+                             cl.v[2] + cl.w[0] * r[1] - cl.w[1] * r[0]};
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            const_cast<float*>(c.normal)[at * 3 + d] = -g[d];
+            const_cast<float*>(c.pos)[at * 3 + d] = x[d];
+            const_cast<float*>(c.rigid_v)[at * 3 + d] = rv[d];
+            const_cast<float*>(c.p_WB)[at * 3 + d] = cl.p[d];
+        }
+        // initialize_contact_velocities (cuda_mpm_kernels.cuh:926-938)
+        c.vel[at * 3] = vq.x; c.vel[at * 3 + 1] = vq.y; c.vel[at * 3 + 2] = vq.z;
+        ++at;
+    }
 }
 
 // ---- set-up (once per UpdateContact) -----------------------------------------

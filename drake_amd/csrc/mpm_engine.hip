@@ -652,6 +652,19 @@ int mpm_copy_contact_pairs(mpm_handle_t e, size_t n, const uint32_t* particle, c
     return copy_contacts(e, n, particle, body, dist, normal, pos, rigid_v, rigid_p_WB);
 }
 
+int mpm_generate_contact_pairs(mpm_handle_t e, size_t n_colliders, const mpm_collider_t* colliders, size_t* n_out) {
+    READY(e);
+    REQUIRE(n_colliders == 0 || colliders, "null collider array");
+    REQUIRE(n_colliders <= 1024, "too many colliders");
+    return generate_contacts(e, n_colliders, colliders, n_out);
+}
+
+int mpm_download_contact_pairs(mpm_handle_t e, uint32_t* particle, uint32_t* body, float* dist, float* normal,
+                               float* pos, float* rigid_v, float* p_WB) {
+    READY(e);
+    return download_contacts(e, particle, body, dist, normal, pos, rigid_v, p_WB);
+}
+
 int mpm_update_contact(mpm_handle_t e, int frame, int substep, float dt, float mu, float stiffness, float damping,
                        int dump, int exact, int max_iters, int* iters_out, float* residual_out) {
     READY(e);

@@ -103,6 +103,57 @@ __global__ __launch_bounds__(1024) void k_sort_scan(int* a, int total) {
     }
 }
 
+// Large exclusive scan: k_scan_blocks scans 4096-entry blocks in place and records their totals,
+// k_sort_scan scans the totals, k_scan_add adds them back.  `n` entries, padded storage to a
+// multiple of 4096.
+__global__ __launch_bounds__(256) void k_scan_blocks(int* a, int n, int* sums) {
+    __shared__ int s_w[4];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int base = blockIdx.x * 4096 + tid * 16;
+    int4 v[4];
+    int sum = 0;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int i = base + q * 4;
+        v[q] = *reinterpret_cast<const int4*>(a + i);
+        if (i >= n) v[q].x = 0;
+        if (i + 1 >= n) v[q].y = 0;
+        if (i + 2 >= n) v[q].z = 0;
+        if (i + 3 >= n) v[q].w = 0;
+        sum += v[q].x + v[q].y + v[q].z + v[q].w;
+    }
+    int inc = sum;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int t = __shfl_up(inc, d);
+        if (lane >= d) inc += t;
+    }
+    if (lane == 63) s_w[w] = inc;
+    __syncthreads();
+    int run = inc - sum;
+    for (int k = 0; k < w; ++k) run += s_w[k];
+    if (tid == 255) sums[blockIdx.x] = run + sum;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        int4 o;
+        o.x = run; run += v[q].x;
+        o.y = run; run += v[q].y;
+        o.z = run; run += v[q].z;
+        o.w = run; run += v[q].w;
+        *reinterpret_cast<int4*>(a + base + q * 4) = o;
+    }
+}
+__global__ __launch_bounds__(256) void k_scan_add(int* a, const int* sums) {
+    const int off = sums[blockIdx.x];
+    int4* q = reinterpret_cast<int4*>(a + blockIdx.x * 4096) + threadIdx.x;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        int4 v = q[k * 256];
+        v.x += off; v.y += off; v.z += off; v.w += off;
+        q[k * 256] = v;
+    }
+}
+
 __global__ __launch_bounds__(64) void k_sort_scatter(const uint32_t* keys, const uint32_t* vals, uint32_t* keys_out,
                                                      uint32_t* vals_out, int n, int shift, int items, const int* hist,
                                                      int ntiles) {
@@ -145,6 +196,18 @@ __global__ __launch_bounds__(64) void k_sort_scatter(const uint32_t* keys, const
 
 // Sorts n pairs by the key bits [0, bits) (stable).  `a` holds the input and receives the result;
 // `b` and `hist` are scratch (hist: 256 * ceil(n / (64 * items)) ints).
+// In-place exclusive scan of n ints (storage padded to a multiple of 4096); sums: n/4096 + 2 ints,
+// sums[nblocks] receives the grand total.
+static int device_exclusive_scan(hipStream_t s, int* a, size_t n, int* sums) {
+    using namespace mpm;
+    const int nb = (int)((n + 4095) / 4096);
+    if (hipMemsetAsync(sums + nb, 0, 4, s) != hipSuccess) return -1;
+    hipLaunchKernelGGL(k_scan_blocks, dim3(nb), dim3(256), 0, s, a, (int)n, sums);
+    hipLaunchKernelGGL(k_sort_scan, dim3(1), dim3(1024), 0, s, sums, nb + 1);
+    hipLaunchKernelGGL(k_scan_add, dim3(nb), dim3(256), 0, s, a, (const int*)sums);
+    return 0;
+}
+
 static inline int sort_items_for(size_t n) { return n > (1u << 18) ? 64 : 16; }
 
 static int radix_sort_pairs(hipStream_t s, uint32_t* ka, uint32_t* va, uint32_t* kb, uint32_t* vb, int* hist, size_t n,

@@ -68,8 +68,9 @@ int main(int argc, char** argv) {
         solver.Dump(state, "/tmp/mpm_cloth_test.obj");
         state.Destroy();
     }
-    {
-        // cloth dropped on a rigid floor at z = 0.4 (config 3 in miniature)
+    for (int device_pairs = 0; device_pairs < 2; ++device_pairs) {
+        // cloth dropped on a rigid floor at z = 0.4 (config 3 in miniature): once with the contact pairs
+        // made on the host like DeformableDriver does, once with mpm_generate_contact_pairs
         GpuMpmState<T> state;
         std::vector<Vec3<T>> pos, vel;
         std::vector<int> idx;
@@ -82,6 +83,7 @@ int main(int argc, char** argv) {
         cfg.contact_damping = T(1e-5);
         cfg.contact_friction_mu = T(1.0);
         drake_amd::MpmDriver driver(&state, cfg);
+        driver.device_contact_pairs = device_pairs != 0;
         drake_amd::RigidBody floor;
         floor.origin = {0, 0, T(0.4)};
         driver.bodies().push_back(floor);
@@ -95,8 +97,8 @@ int main(int argc, char** argv) {
         auto dumped = state.DumpCpuState();
         double zmin = 1, zmax = 0;
         for (const auto& q : std::get<0>(dumped)) { zmin = std::min<double>(zmin, q[2]); zmax = std::max<double>(zmax, q[2]); }
-        std::printf("floor drop: z in [%.4f, %.4f], max contacts=%zu, peak force on floor z=%.4g, newton iterations=%d\n",
-                    zmin, zmax, max_contacts, fz, state.total_contact_iteration_count);
+        std::printf("floor drop (%s pairs): z in [%.4f, %.4f], max contacts=%zu, peak force on floor z=%.4g, newton iterations=%d\n",
+                    device_pairs ? "device" : "host", zmin, zmax, max_contacts, fz, state.total_contact_iteration_count);
         CHECK(zmin > 0.39 && zmax < 0.42);   // caught by the floor, not tunnelling
         CHECK(max_contacts > 0);
         CHECK(fz < 0);                        // the cloth pushed the floor down

@@ -33,6 +33,24 @@ struct RigidBody {
         *grad = {d[0] / len, d[1] / len, d[2] / len};
         return len - radius;
     }
+    // the same body for the device-side pair generation (mpm_generate_contact_pairs)
+    mpm_collider_t collider(uint32_t body) const {
+        mpm_collider_t c{};
+        c.kind = kind == kHalfSpace ? 0 : 1;
+        c.body = body;
+        for (int d = 0; d < 3; ++d) { c.p_WB[d] = origin[d]; c.v[d] = v[d]; c.w[d] = w[d]; }
+        // body z axis = the half-space normal; any orthonormal completion
+        float z[3] = {normal[0], normal[1], normal[2]};
+        if (kind != kHalfSpace) { z[0] = 0; z[1] = 0; z[2] = 1; }
+        const float a[3] = {std::fabs(z[0]) < .9f ? 1.f : 0.f, std::fabs(z[0]) < .9f ? 0.f : 1.f, 0.f};
+        float x[3] = {a[1] * z[2] - a[2] * z[1], a[2] * z[0] - a[0] * z[2], a[0] * z[1] - a[1] * z[0]};
+        const float xl = std::sqrt(x[0] * x[0] + x[1] * x[1] + x[2] * x[2]);
+        for (float& q : x) q /= xl;
+        const float y[3] = {z[1] * x[2] - z[2] * x[1], z[2] * x[0] - z[0] * x[2], z[0] * x[1] - z[1] * x[0]};
+        for (int r = 0; r < 3; ++r) { c.R_WB[r * 3] = x[r]; c.R_WB[r * 3 + 1] = y[r]; c.R_WB[r * 3 + 2] = z[r]; }
+        c.dims[0] = radius;
+        return c;
+    }
     Vec3<float> point_velocity(const Vec3<float>& p) const {
         const float r[3] = {p[0] - origin[0], p[1] - origin[1], p[2] - origin[2]};
         return {v[0] + w[1] * r[2] - w[2] * r[1], v[1] + w[2] * r[0] - w[0] * r[2], v[2] + w[0] * r[1] - w[1] * r[0]};
@@ -67,16 +85,26 @@ class MpmDriver {
         while (dt_left > 0) {
             const float ddt = std::min(dt_left, config_.substep_dt);
             dt_left -= ddt;
-            solver_.SyncParticleStateToCpu(state_);
+            if (!device_contact_pairs) solver_.SyncParticleStateToCpu(state_);
             solver_.RebuildMapping(state_, false);
             solver_.CalcFemStateAndForce(state_, ddt);
             solver_.ParticleToGrid(state_, ddt);
             solver_.UpdateGrid(state_, config_.mpm_bc);
-            CalcMpmContactPairs(&pairs);
-            solver_.CopyContactPairs(state_, pairs);
+            size_t n_pairs = 0;
+            if (device_contact_pairs) {
+                // no positions to the host, no pairs back
+                std::vector<mpm_collider_t> cols;
+                for (size_t b = 0; b < bodies_.size(); ++b) cols.push_back(bodies_[b].collider(uint32_t(b)));
+                n_pairs = solver_.GenerateContactPairs(state_, cols);
+            } else {
+                CalcMpmContactPairs(&pairs);
+                solver_.CopyContactPairs(state_, pairs);
+                n_pairs = pairs.size();
+            }
             solver_.UpdateContact(state_, frame, substep, ddt, config_.contact_friction_mu, config_.contact_stiffness,
                                   config_.contact_damping, config_.write_files, config_.exact_line_search);
             solver_.GridToParticle(state_, ddt);
+            n_pairs_last_ = n_pairs;
             substep += 1;
         }
         // FinalizeExternalContactForces: impulses -> forces
@@ -88,17 +116,18 @@ class MpmDriver {
                 f.F_Bq_W_tau[i][d] /= dt;
                 f.F_Bq_W_f[i][d] /= dt;
             }
-        last_contacts_ = pairs.size();
+        last_contacts_ = n_pairs_last_;
         return substep;
     }
     size_t last_contacts() const { return last_contacts_; }
+    bool device_contact_pairs = false;  // true: mpm_generate_contact_pairs instead of the host loop
 
   private:
     GpuMpmState<float>* state_;
     MpmConfigParams<float> config_;
     GpuMpmSolver<float> solver_;
     std::vector<RigidBody> bodies_;
-    size_t last_contacts_ = 0;
+    size_t last_contacts_ = 0, n_pairs_last_ = 0;
 };
 
 }  // namespace drake_amd

@@ -167,6 +167,24 @@ class GpuMpmSolver {
                                          reinterpret_cast<const float*>(c.rigid_v.data()),
                                          reinterpret_cast<const float*>(c.rigid_p_WB.data())));
     }
+    // Extension: CalcMpmContactPairs + CopyContactPairs on the device for bodies with
+    // analytic signed distance fields; nothing travels to the host but the pair count.
+    size_t GenerateContactPairs(GpuMpmState<T>* s, const std::vector<mpm_collider_t>& colliders) const {
+        size_t n = 0;
+        mpm_check(mpm_generate_contact_pairs(s->h_, colliders.size(), colliders.data(), &n));
+        s->n_contacts_ = n;
+        return n;
+    }
+    void DownloadContactPairs(const GpuMpmState<T>& s, MpmParticleContactPairs<T>* c) const {
+        const size_t n = s.n_contacts_;
+        c->particle_in_contact_index.resize(n); c->non_mpm_id.resize(n); c->penetration_distance.resize(n);
+        c->normal.resize(n); c->particle_in_contact_position.resize(n); c->rigid_v.resize(n); c->rigid_p_WB.resize(n);
+        mpm_check(mpm_download_contact_pairs(s.h_, c->particle_in_contact_index.data(), c->non_mpm_id.data(),
+                                             c->penetration_distance.data(), reinterpret_cast<float*>(c->normal.data()),
+                                             reinterpret_cast<float*>(c->particle_in_contact_position.data()),
+                                             reinterpret_cast<float*>(c->rigid_v.data()),
+                                             reinterpret_cast<float*>(c->rigid_p_WB.data())));
+    }
     void UpdateContact(GpuMpmState<T>* s, const int frame, const int substep, const T& dt, const T& friction_mu,
                        const T& stiffness, const T& damping, const bool dump, const bool exact_line_search) const {
         int it = 0;

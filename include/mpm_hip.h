@@ -198,6 +198,33 @@ MPM_API int mpm_copy_contact_pairs(mpm_handle_t h, size_t n_contacts, const uint
                                    const float *normal, const float *particle_in_contact_position,
                                    const float *rigid_v, const float *rigid_p_WB);
 
+/* Device-side replacement of DeformableDriver::CalcMpmContactPairs (deformable_driver.h:120-194)
+ * followed by CopyContactPairs, for rigid bodies with analytic signed distance fields: no particle
+ * positions travel to the host.  For every particle slot s (ascending) and collider j (ascending)
+ * with phi_j(x_s) < 0 one contact is produced with exactly the fields of MpmParticleContactPairs
+ * (cpu_mpm_model.h:73-114; deformable_driver.h:181-187): particle_in_contact_index = s,
+ * non_mpm_id = body, penetration_distance = phi, normal = -grad(phi)/|grad(phi)|,
+ * position = x_s, rigid_v = v + w x (x_s - p_WB), rigid_p_WB = p_WB.
+ *   kind 0 half-space: inside is z_B <= 0 (Drake's HalfSpace), plane through p_WB, normal = R_WB[:,2]
+ *   kind 1 sphere:     radius dims[0], centre p_WB
+ *   kind 2 box:        half extents dims[0..2] in the body frame
+ *   kind 3 capsule:    radius dims[0], half length dims[1] along z_B
+ * The pairs are left in the engine as if mpm_copy_contact_pairs had been called;
+ * mpm_download_contact_pairs returns them (any pointer may be NULL). */
+typedef struct mpm_collider {
+    int32_t kind;
+    uint32_t body;      /* index into the external-body accumulators */
+    float p_WB[3];      /* body origin in the world */
+    float R_WB[9];      /* rotation body -> world, row major */
+    float dims[3];
+    float v[3], w[3];   /* spatial velocity of the body frame, world */
+} mpm_collider_t;
+MPM_API int mpm_generate_contact_pairs(mpm_handle_t h, size_t n_colliders, const mpm_collider_t *colliders,
+                                       size_t *n_contacts_out);
+MPM_API int mpm_download_contact_pairs(mpm_handle_t h, uint32_t *particle_in_contact_index, uint32_t *non_mpm_id,
+                                       float *penetration_distance, float *normal, float *position, float *rigid_v,
+                                       float *rigid_p_WB);
+
 /* GpuMpmSolver::UpdateContact (cuda_mpm_solver.cu:214-621).  iterations_out,
  * residual_out may be NULL.  frame/substep/dump only name the optional JSON
  * statistics file (written to dump_dir set by mpm_set_dump_dir, default ".").

@@ -28,10 +28,20 @@ def main():
     ap.add_argument("--config", default="cloth_1m")
     ap.add_argument("--mu", type=float, default=0.5)
     ap.add_argument("--floor", type=float, default=0.5)
+    ap.add_argument("--dt", type=float, default=1e-3)
+    ap.add_argument("--stiffness", type=float, default=1e5)
+    ap.add_argument("--damping", type=float, default=1e-3)
+    ap.add_argument("--survey-config3", action="store_true",
+                    help="SURVEY.md 8(d) config 3: floor z<0.25, k=1e6, d=1e-5, mu=1, dt=2e-4")
+    ap.add_argument("--device-pairs", action="store_true",
+                    help="contact pairs from mpm_generate_contact_pairs instead of the host round trip")
     args = ap.parse_args()
-    from drake_amd import GpuMpm, scenes
+    if args.survey_config3:
+        args.floor, args.stiffness, args.damping, args.mu, args.dt = 0.25, 1e6, 1e-5, 1.0, 2e-4
+    from drake_amd import Collider, GpuMpm, scenes
     bits, layers, res = scenes.CONFIGS[args.config]
-    dt, stiffness, damping = 1e-3, 1e5, 1e-3
+    dt, stiffness, damping = args.dt, args.stiffness, args.damping
+    floor = [Collider(0, body=0, p_WB=(0.5, 0.5, args.floor))]
     g = GpuMpm(bits)
     # the stack starts with its lowest sheets already touching the floor and moves down at 0.5 m/s
     sheets = scenes.cloth_stack(layers, res, bits, z0=args.floor - 0.004)
@@ -50,19 +60,24 @@ def main():
         g.update_grid(-1)
         g.gpu_sync()
         t1 = time.perf_counter()
-        pos = g.sync_particle_state_to_cpu()
-        t2 = time.perf_counter()
-        z = pos[:, 2]
-        idx = np.nonzero(z < args.floor)[0].astype(np.uint32)
-        n = idx.size
-        dist = (z[idx] - args.floor).astype(np.float32)
-        normal = np.tile(np.array([0, 0, -1], np.float32), (n, 1))
-        cpos = pos[idx]
-        zeros = np.zeros((n, 3), np.float32)
-        body = np.zeros(n, np.uint32)
-        t3 = time.perf_counter()
-        g.copy_contact_pairs(idx, body, dist, normal, cpos, zeros, zeros)
-        t4 = time.perf_counter()
+        if args.device_pairs:
+            t2 = t3 = time.perf_counter()
+            n = g.generate_contact_pairs(floor)
+            t4 = time.perf_counter()
+        else:
+            pos = g.sync_particle_state_to_cpu()
+            t2 = time.perf_counter()
+            z = pos[:, 2]
+            idx = np.nonzero(z < args.floor)[0].astype(np.uint32)
+            n = idx.size
+            dist = (z[idx] - args.floor).astype(np.float32)
+            normal = np.tile(np.array([0, 0, -1], np.float32), (n, 1))
+            cpos = pos[idx]
+            zeros = np.zeros((n, 3), np.float32)
+            body = np.zeros(n, np.uint32)
+            t3 = time.perf_counter()
+            g.copy_contact_pairs(idx, body, dist, normal, cpos, zeros, zeros)
+            t4 = time.perf_counter()
         r = g.update_contact(dt, args.mu, stiffness, damping)
         g.gpu_sync()
         t5 = time.perf_counter()
@@ -78,7 +93,8 @@ def main():
             iters.append(r["iterations"])
             ncontacts.append(n)
     k = args.steps
-    out = dict(config=args.config, particles=g.n_particles, steps=k, mu=args.mu,
+    out = dict(config=args.config, particles=g.n_particles, steps=k, mu=args.mu, dt=dt, stiffness=stiffness,
+               damping=damping, floor=args.floor, pairs="device" if args.device_pairs else "host",
                contacts_mean=float(np.mean(ncontacts)), contacts_max=int(np.max(ncontacts)),
                newton_iterations_mean=float(np.mean(iters)), newton_iterations_max=int(np.max(iters)),
                ms_per_substep={a: 1e3 * b / k for a, b in T.items()},
