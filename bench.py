@@ -102,6 +102,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)  # ... after 20 warm-up
     ap.add_argument("--config", default="cloth_1m")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--sort-every", type=int, default=0,
+                    help="also call RebuildMapping(sort=true) every N substeps (SURVEY 8d config 2 variants; "
+                         "0 = never, the reference's Drake behaviour and the reported metric)")
     ap.add_argument("--cpu-budget", type=float, default=20.0)
     args = ap.parse_args()
 
@@ -149,7 +152,14 @@ def main():
         torch.cuda.synchronize()
 
     def run(n):
-        if chain is None:
+        if chain is None and args.sort_every > 0:
+            done = 0
+            while done < n:
+                g.rebuild_mapping(True)   # slot-order sort (device radix sort); particle data does not move
+                k = min(args.sort_every, n - done)
+                g.run_substeps(k, dt, -1)
+                done += k
+        elif chain is None:
             g.run_substeps(n, dt, -1)
         else:
             with torch.cuda.stream(stream):
@@ -200,7 +210,7 @@ def main():
                    config=dict(workload=f"{args.config}: {npart} particles ({nf} faces + {nv} vertices), "
                                         f"{1 << bits}^3 grid, corotated cloth, no contact, dt={dt}",
                                particles_per_gpu=npart, grid=f"{1 << bits}^3", touched_blocks=st["touched_blocks"],
-                               rebuilds=st["rebuilds"], parallelism=("single GPU" if world == 1 else f"{world} GPUs: x-tiled patches, 1 rank/GPU, RCCL halo of grid-block sums per substep")),
+                               rebuilds=st["rebuilds"], slot_sort_every=args.sort_every, parallelism=("single GPU" if world == 1 else f"{world} GPUs: x-tiled patches, 1 rank/GPU, RCCL halo of grid-block sums per substep")),
                    roofline=roofline)
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(bits, layers, res, dt, args.cpu_budget)
