@@ -101,6 +101,7 @@ def main():
     ap.add_argument("--steps", type=int, default=200)   # 200 substeps ...
     ap.add_argument("--warmup", type=int, default=20)  # ... after 20 warm-up
     ap.add_argument("--config", default="cloth_1m")
+    ap.add_argument("--dt", type=float, default=1e-3, help="substep length (SURVEY 8d: 1e-3 for config 2)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--sort-every", type=int, default=0,
                     help="also call RebuildMapping(sort=true) every N substeps (SURVEY 8d config 2 variants; "
@@ -131,7 +132,7 @@ def main():
     from drake_amd import GpuMpm, scenes
     from drake_amd.dist import HaloChain
     bits, layers, res = scenes.CONFIGS[args.config]
-    dt = 1e-3
+    dt = args.dt
     g = GpuMpm(bits, device=local_rank)
     # Weak scaling: every rank owns one 1M-particle cloth stack.  The ranks' patches sit side by
     # side along x (rank r's local frame is shifted by r * 0.5), so neighbouring stacks share grid
