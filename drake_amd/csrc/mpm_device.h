@@ -88,6 +88,7 @@ struct DP {
     uint32_t* src_of;      // sorted slot -> previous slot
     int* dst_of;           // previous slot -> sorted slot
     unsigned* tickets;     // 32 arrival counters, 128 bytes apart (k_rb_finish)
+    uint32_t* halo_hdr[2]; // per launch: halo send buffers whose entry counters k_grid<0> resets (or null)
     int* cellcnt[2];       // [type][cell key]; zero outside a rebuild
     int* blkcnt[2];        // [type][block id]; zero outside a rebuild
     int* blkstart[2];

@@ -432,17 +432,39 @@ int mpm_substep_end(mpm_handle_t e, float dt, int bc) {
 
 int mpm_substep_begin_halo(mpm_handle_t e, float dt, int n, const int* bx_lo, const int* bx_hi, const int* shift_bx,
                            void* const* send_bufs, size_t cap) {
-    REQUIRE(n >= 0 && n <= 8 && (n == 0 || (bx_lo && bx_hi && shift_bx && send_bufs)), "bad halo zone list");
-    if (int rc = mpm_substep_begin(e, dt)) return rc;
-    for (int i = 0; i < n; ++i)
-        if (int rc = mpm_halo_pack(e, bx_lo[i], bx_hi[i], shift_bx[i], send_bufs[i], cap)) return rc;
+    READY(e);
+    REQUIRE(n >= 0 && n <= 2 && (n == 0 || (bx_lo && bx_hi && shift_bx && send_bufs)), "bad halo zone list");
+    REQUIRE(n == 0 || (cap > 0 && cap < (1u << 24)), "bad halo buffer");
+    launch_rebuild(e);
+    launch_fem(e, dt);
+    launch_p2g(e, dt);
+    DP p = e->dp;   // per-launch copy: k_grid<0> resets the entry counters of the send buffers
+    HaloZones z{};
+    for (int i = 0; i < n; ++i) {
+        REQUIRE(send_bufs[i], "null halo buffer");
+        p.halo_hdr[i] = static_cast<uint32_t*>(send_bufs[i]);
+        z.lo[i] = bx_lo[i]; z.hi[i] = bx_hi[i]; z.shift[i] = shift_bx[i];
+        z.buf[i] = static_cast<uint32_t*>(send_bufs[i]);
+    }
+    hipLaunchKernelGGL(k_grid<0>, dim3(e->g_grid), dim3(256), 0, e->stream, p, -1);
+    e->grid_state = 3;
+    if (n > 0)
+        hipLaunchKernelGGL(k_halo_pack2, dim3(e->g_grid, n), dim3(256), 0, e->stream, e->dp, z, (unsigned)cap);
     return 0;
 }
 
 int mpm_substep_end_halo(mpm_handle_t e, float dt, int bc, int n, const void* const* recv_bufs, size_t cap) {
-    REQUIRE(n >= 0 && n <= 8 && (n == 0 || recv_bufs), "bad halo buffer list");
-    for (int i = 0; i < n; ++i)
-        if (int rc = mpm_halo_add(e, recv_bufs[i], cap)) return rc;
+    READY(e);
+    REQUIRE(n >= 0 && n <= 2 && (n == 0 || recv_bufs), "bad halo buffer list");
+    REQUIRE(e->grid_state == 3, "mpm_substep_end_halo without mpm_substep_begin_halo");
+    if (n > 0) {
+        HaloBufs b{};
+        for (int i = 0; i < n; ++i) {
+            REQUIRE(recv_bufs[i], "null halo buffer");
+            b.buf[i] = static_cast<const uint32_t*>(recv_bufs[i]);
+        }
+        hipLaunchKernelGGL(k_halo_add2, dim3(64, n), dim3(256), 0, e->stream, e->dp, b, (unsigned)cap);
+    }
     return mpm_substep_end(e, dt, bc);
 }
 

@@ -528,6 +528,8 @@ __global__ __launch_bounds__(256) void k_grid(DP p, int bc) {
     const int tid = threadIdx.x;
     const int cell = tid & 63;
     const int cx = cell >> 4, cy = (cell >> 2) & 3, cz = cell & 3;
+    // the multi-GPU path packs halo buffers right after this kernel: reset their entry counters here
+    if (MODE == 0 && blockIdx.x == 0 && tid < 2 && p.halo_hdr[tid]) p.halo_hdr[tid][0] = 0u;
     for (unsigned a = blockIdx.x * 4 + (tid >> 6); a < n_active; a += gridDim.x * 4) {
         const int* nbr = p.act_nbr_items + (size_t)a * 27;
         float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -807,6 +809,55 @@ __global__ __launch_bounds__(256) void k_halo_pack(DP p, int bx_lo, int bx_hi, i
 }
 
 __global__ __launch_bounds__(256) void k_halo_add(DP p, unsigned cap, const uint32_t* buf) {
+    const unsigned n = min(buf[0], cap);
+    const float4* data = reinterpret_cast<const float4*>(buf) + halo_data_offset(cap);
+    for (unsigned e = blockIdx.x * 4 + (threadIdx.x >> 6); e < n; e += gridDim.x * 4) {
+        const uint32_t id = buf[halo_ids_offset() + e];
+        if (id >= p.nblocks) continue;
+        const int a = p.lut_act[id];
+        if (a < 0) continue;  // nothing of ours reaches that block
+        const size_t g = (size_t)a * 64 + (threadIdx.x & 63);
+        const float4 r = data[(size_t)e * 64 + (threadIdx.x & 63)];
+        float4 q = p.gv[g];
+        q.x += r.x; q.y += r.y; q.z += r.z; q.w += r.w;
+        p.gv[g] = q;
+    }
+}
+
+// both zones / both received buffers of a chain rank in one launch each (blockIdx.y selects)
+struct HaloZones {
+    int lo[2], hi[2], shift[2];
+    uint32_t* buf[2];
+};
+__global__ __launch_bounds__(256) void k_halo_pack2(DP p, HaloZones z, unsigned cap) {
+    const int k = blockIdx.y;
+    uint32_t* buf = z.buf[k];
+    const int bx_lo = z.lo[k], bx_hi = z.hi[k], shift_bx = z.shift[k];
+    const unsigned n_active = p.ctl->n_active;
+    float4* data = reinterpret_cast<float4*>(buf) + halo_data_offset(cap);
+    for (unsigned a = blockIdx.x * 4 + (threadIdx.x >> 6); a < n_active; a += gridDim.x * 4) {
+        int bx, by, bz;
+        block_coords(p.act_block[a], bx, by, bz);
+        if (bx < bx_lo || bx > bx_hi) continue;   // wave-uniform
+        const int nbx = bx + shift_bx;
+        if (nbx < 0 || nbx >= p.nb) continue;
+        unsigned slot = 0;
+        if ((threadIdx.x & 63) == 0) slot = atomicAdd(&buf[0], 1u);
+        slot = __builtin_amdgcn_readfirstlane(slot);
+        if (slot >= cap) {
+            if ((threadIdx.x & 63) == 0) atomicOr(&p.ctl->error, ERR_CAPACITY);
+            continue;
+        }
+        if ((threadIdx.x & 63) == 0) buf[halo_ids_offset() + slot] = block_id((uint32_t)nbx, (uint32_t)by, (uint32_t)bz);
+        data[(size_t)slot * 64 + (threadIdx.x & 63)] = p.gv[(size_t)a * 64 + (threadIdx.x & 63)];
+    }
+}
+struct HaloBufs {
+    const uint32_t* buf[2];
+};
+// (a block lies in one zone only, so the two buffers of a launch touch disjoint cells)
+__global__ __launch_bounds__(256) void k_halo_add2(DP p, HaloBufs b, unsigned cap) {
+    const uint32_t* buf = b.buf[blockIdx.y];
     const unsigned n = min(buf[0], cap);
     const float4* data = reinterpret_cast<const float4*>(buf) + halo_data_offset(cap);
     for (unsigned e = blockIdx.x * 4 + (threadIdx.x >> 6); e < n; e += gridDim.x * 4) {

@@ -35,6 +35,7 @@ class HaloChain:
         self.zone_hi = (cut_hi_block - zone_blocks, cut_hi_block + zone_blocks - 1)
         self.pitch = pitch_blocks
         self._fast_args = None
+        self._ops = None
         backend = dist.get_backend(group) if world > 1 else "none"
         self.staged = backend != "nccl"
         self.device = device if device is not None else torch.device("cpu")
@@ -60,11 +61,12 @@ class HaloChain:
         if self.staged:
             self._exchange_staged()
             return
-        ops = []
-        for n in self.send:
-            ops.append(dist.P2POp(dist.isend, self.send[n], n, group=self.group))
-            ops.append(dist.P2POp(dist.irecv, self.recv[n], n, group=self.group))
-        for w in dist.batch_isend_irecv(ops):
+        if self._ops is None:   # the buffers never change: build the op list once
+            self._ops = []
+            for n in self.send:
+                self._ops.append(dist.P2POp(dist.isend, self.send[n], n, group=self.group))
+                self._ops.append(dist.P2POp(dist.irecv, self.recv[n], n, group=self.group))
+        for w in dist.batch_isend_irecv(self._ops):
             w.wait()   # stream-ordered: the current stream waits, the host does not
 
     def exchange(self):

@@ -270,7 +270,7 @@ MPM_API int mpm_update_grid_from_sums(mpm_handle_t h, int mpm_bc);
 MPM_API int mpm_substep_begin(mpm_handle_t h, float dt);
 MPM_API int mpm_substep_end(mpm_handle_t h, float dt, int mpm_bc);
 /* The same with the halo kernels folded in (one host call either side of the exchange):
- * begin + mpm_halo_pack for each of the n_zones (bx_lo[i], bx_hi[i], shift_bx[i]) -> send_bufs[i];
+ * begin + mpm_halo_pack for each of the n_zones <= 2 (bx_lo[i], bx_hi[i], shift_bx[i]) -> send_bufs[i];
  * mpm_halo_add for each of the n_bufs received buffers + end. */
 MPM_API int mpm_substep_begin_halo(mpm_handle_t h, float dt, int n_zones, const int *bx_lo, const int *bx_hi,
                                    const int *shift_bx, void *const *send_bufs, size_t capacity_blocks);
