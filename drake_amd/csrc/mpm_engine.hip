@@ -335,8 +335,10 @@ int mpm_sync(mpm_handle_t e) {
     if (c.error & ERR_CAPACITY) return fail(MPM_ERR_CAPACITY, "block table overflow");
     if (c.error & ERR_DRIFT)
         return fail(MPM_ERR_DRIFT,
-                    "a particle moved more than one cell in a substep (left its block's free zone); "
-                    "results are invalid -- reduce dt");
+                    "a face particle was re-centred on its corners out of its block's tile: the corner "
+                    "velocities differ by cells per substep, the state is diverging -- reduce dt");
+    if (c.error & ERR_DOMAIN)
+        return fail(MPM_ERR_DOMAIN, "a particle left the grid; results are invalid");
     return 0;
 }
 

@@ -557,7 +557,10 @@ __global__ __launch_bounds__(256) void k_grid(DP p, int bc) {
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            cnt = min(cnt, GRID_LIST);   // (more than GRID_LIST slabs over one block: see k_rb_tables, ERR_CAPACITY)
+            if (cnt > GRID_LIST) {   // > 160 slabs over one block (dozens of split, very heavy neighbours)
+                if (cell == 0) atomicOr(&p.ctl->error, ERR_CAPACITY);
+                cnt = GRID_LIST;
+            }
 #pragma unroll 4
             for (int e = 0; e < cnt; ++e) {
                 const int2 en = list[e];

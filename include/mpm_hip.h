@@ -44,9 +44,10 @@ typedef enum {
     MPM_OK = 0,
     MPM_ERR_INVALID = -1,     /* bad argument / call order                     */
     MPM_ERR_HIP = -2,         /* a HIP runtime call failed                     */
-    MPM_ERR_DRIFT = -3,       /* a particle left its block's free zone (CFL>1) */
+    MPM_ERR_DRIFT = -3,       /* a face particle was re-centred out of its block's tile (diverging state) */
     MPM_ERR_CAPACITY = -4,    /* internal table overflow                       */
-    MPM_ERR_NO_DEVICE = -5    /* no usable GPU: there is no CPU fallback       */
+    MPM_ERR_NO_DEVICE = -5,   /* no usable GPU: there is no CPU fallback       */
+    MPM_ERR_DOMAIN = -6       /* a particle left the grid (the reference: undefined behaviour) */
 } mpm_status;
 
 /* Runtime form of the compile-time constants in settings.h:36-127. */
@@ -178,7 +179,7 @@ MPM_API int mpm_update_grid(mpm_handle_t h, int mpm_bc);
 MPM_API int mpm_grid_to_particle(mpm_handle_t h, float dt);
 
 /* GpuMpmSolver::GpuSync (cuda_mpm_solver.cu:163-166); also surfaces sticky
- * device error flags as MPM_ERR_DRIFT / MPM_ERR_CAPACITY. */
+ * device error flags as MPM_ERR_DRIFT / MPM_ERR_CAPACITY / MPM_ERR_DOMAIN. */
 MPM_API int mpm_sync(mpm_handle_t h);
 
 /* GpuMpmSolver::SyncParticleStateToCpu (cuda_mpm_solver.cu:185-191):

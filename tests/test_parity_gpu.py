@@ -226,3 +226,37 @@ def test_error_paths_and_edge_cases():
         g.substep(DT, -1)
     g.gpu_sync()
     assert g.n_particles == 5 and g.n_faces == 1
+
+
+def test_domain_error_and_fast_particles():
+    """A particle outside the grid (undefined behaviour in the reference) is reported at the next
+    sync as MPM_ERR_DOMAIN; fast particles are not an error."""
+    from drake_amd import GpuMpm, MpmError, scenes
+
+    def small():
+        g = GpuMpm(6)
+        scenes.populate(g, scenes.cloth_stack(2, 12, 6, z0=0.5))
+        return g
+
+    g = small()
+    pos = g.sync_particle_state_to_cpu()
+    bad = pos.copy()
+    bad[5, 2] = -0.25                       # below the grid
+    g.upload_particle_state(bad)
+    g.rebuild_mapping(False)
+    with pytest.raises(MpmError) as ei:
+        g.gpu_sync()
+    assert ei.value.code == -6
+    # fast motion is legal: the re-sort is requested by G2P for exactly the particles that left their
+    # tile and runs before the next transfer, so 3.8 cells per substep is as good as 0.1
+    g = small()
+    vel = np.zeros((g.n_particles, 3), np.float32)
+    vel[:, 2] = -60.0                       # 60 m/s * 1e-3 s = 3.8 cells of 1/64 per substep
+    g.upload_particle_state(None, vel)
+    z0 = g.sync_particle_state_to_cpu()[:, 2].copy()
+    for _ in range(3):
+        g.substep(DT, -1)
+    g.gpu_sync()
+    assert g.stats()["error_flags"] == 0 and g.stats()["rebuilds"] >= 3
+    dz = g.sync_particle_state_to_cpu()[:, 2] - z0
+    np.testing.assert_allclose(dz, -(60.0 * 3 * DT + 9.8 * DT * DT * 6), rtol=1e-3)
