@@ -670,27 +670,43 @@ MPM_DEV bool g2p_particle(const DP& p, const PSet& S, const float4* tile, unsign
     const Stencil st = make_stencil(p, x, y, z, ox, oy, oz);
     float nv[3] = {0.f, 0.f, 0.f}, nC[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     const float4* base = tile + ((st.rx * TILE_W + st.ry) * TILE_W + st.rz);
-    // one z-row of the stencil (3 nodes) at a time: keeping all 27 node loads in flight costs
-    // ~200 VGPRs; the workgroup count per CU matters more than the load depth here
+    // The stencil weight is a product w_i(x) w_j(y) w_k(z), so the 27-node sums
+    //     v   = sum w v_n,      C[r][c] = sum w v_n[r] (n - fx)[c]
+    // factorise: contract z along each row of 3 nodes, then y over the 3 rows of a plane, then x
+    // over the 3 planes (279 multiply-adds instead of 27 x 14).  One z-row is loaded at a time:
+    // keeping all 27 node loads in flight costs ~200 VGPRs.
+    const float ez[3] = {st.wz[0] * (0.f - st.fx[2]), st.wz[1] * (1.f - st.fx[2]), st.wz[2] * (2.f - st.fx[2])};
+    const float ey[3] = {st.wy[0] * (0.f - st.fx[1]), st.wy[1] * (1.f - st.fx[1]), st.wy[2] * (2.f - st.fx[1])};
+    float B[3] = {0.f, 0.f, 0.f}, By[3] = {0.f, 0.f, 0.f}, Bz[3] = {0.f, 0.f, 0.f};
 #pragma unroll 1
     for (int ab = (diag_flags(p) & 512) ? 8 : 0; ab < 9; ++ab) {
         const int a = ab / 3, b = ab - 3 * a;
-        const float wa = a == 0 ? st.wx[0] : (a == 1 ? st.wx[1] : st.wx[2]);
-        const float wb = b == 0 ? st.wy[0] : (b == 1 ? st.wy[1] : st.wy[2]);
-        const float wab = wa * wb;
-        const float d0 = (float)a - st.fx[0], d1 = (float)b - st.fx[1];
         const float4* row = base + (a * TILE_W + b) * TILE_W;
         const float4 g0 = row[0], g1 = row[1], g2 = row[2];
-        const float4 gq[3] = {g0, g1, g2};
+        const float wb = b == 0 ? st.wy[0] : (b == 1 ? st.wy[1] : st.wy[2]);
+        const float eb = b == 0 ? ey[0] : (b == 1 ? ey[1] : ey[2]);
+        const float A[3] = {st.wz[0] * g0.x + st.wz[1] * g1.x + st.wz[2] * g2.x,
+                            st.wz[0] * g0.y + st.wz[1] * g1.y + st.wz[2] * g2.y,
+                            st.wz[0] * g0.z + st.wz[1] * g1.z + st.wz[2] * g2.z};
+        const float Az[3] = {ez[0] * g0.x + ez[1] * g1.x + ez[2] * g2.x, ez[0] * g0.y + ez[1] * g1.y + ez[2] * g2.y,
+                             ez[0] * g0.z + ez[1] * g1.z + ez[2] * g2.z};
 #pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            const float w = wab * st.wz[c];
-            const float d2 = (float)c - st.fx[2];
-            const float wv0 = w * gq[c].x, wv1 = w * gq[c].y, wv2 = w * gq[c].z;
-            nv[0] += wv0; nv[1] += wv1; nv[2] += wv2;
-            nC[0] += wv0 * d0; nC[1] += wv0 * d1; nC[2] += wv0 * d2;
-            nC[3] += wv1 * d0; nC[4] += wv1 * d1; nC[5] += wv1 * d2;
-            nC[6] += wv2 * d0; nC[7] += wv2 * d1; nC[8] += wv2 * d2;
+        for (int r = 0; r < 3; ++r) {
+            B[r] += wb * A[r];
+            By[r] += eb * A[r];
+            Bz[r] += wb * Az[r];
+        }
+        if (b == 2) {   // plane a is complete
+            const float wa = a == 0 ? st.wx[0] : (a == 1 ? st.wx[1] : st.wx[2]);
+            const float ea = wa * ((float)a - st.fx[0]);
+#pragma unroll
+            for (int r = 0; r < 3; ++r) {
+                nv[r] += wa * B[r];
+                nC[r * 3 + 0] += ea * B[r];
+                nC[r * 3 + 1] += wa * By[r];
+                nC[r * 3 + 2] += wa * Bz[r];
+                B[r] = By[r] = Bz[r] = 0.f;
+            }
         }
     }
     if (diag_flags(p) & 256) {  // ablation: no stores
