@@ -84,9 +84,9 @@ int mpm_add_qr_cloth(mpm_handle_t e, const float* pos, const float* vel, size_t 
 
 static void launch_rebuild(mpm_engine* e) {
     const DP& p = e->dp;
-    hipLaunchKernelGGL(k_rb_count, dim3(e->g_np), dim3(256), 0, e->stream, p);
+    hipLaunchKernelGGL(k_rb_count, dim3(std::min(e->g_np, e->g_rb)), dim3(256), 0, e->stream, p);
     hipLaunchKernelGGL(k_rb_tables, dim3(33), dim3(1024), 0, e->stream, p);
-    hipLaunchKernelGGL(k_rb_scatter, dim3(e->g_np), dim3(256), 0, e->stream, p);
+    hipLaunchKernelGGL(k_rb_scatter, dim3(std::min(e->g_np, e->g_rb)), dim3(256), 0, e->stream, p);
     hipLaunchKernelGGL(k_rb_finish, dim3((std::min(e->g_np, 2048u) + 7u) & ~7u), dim3(256), 0, e->stream, p);
 }
 static void drop_step_graph(mpm_engine* e) {
@@ -271,6 +271,7 @@ int mpm_finalize(mpm_handle_t e) {
     e->g_nv = (unsigned)((nv + 255) / 256);
     e->g_tile = std::min(512u, p.capI);  // 2 resident workgroups per CU pulling blocks from a queue
     e->g_grid = std::min(1024u, (p.capA + 3) / 4);
+    e->g_rb = getenv("MPM_RB_WGS") ? (unsigned)atoi(getenv("MPM_RB_WGS")) : 2048u;
 
     // ---- FEM initialisation (cuda_mpm_kernels.cuh:13-70) + first sort -----
     if (nf) hipLaunchKernelGGL(k_init_faces, dim3(e->g_nf), dim3(256), 0, e->stream, p);

@@ -22,9 +22,11 @@ namespace mpm {
 // memory side and are expensive when thousands of them hit one address).
 __global__ __launch_bounds__(256) void k_rb_count(DP p) {
     if (!p.ctl->need_rebuild) return;
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    const bool valid = i < p.Np;
     const PSet& S = p.set[p.ctl->cur];
+    // grid-stride over 256-particle chunks: a small fixed grid keeps the idle launches cheap
+    for (int base = blockIdx.x * 256; base < p.Np; base += gridDim.x * 256) {
+    const int i = base + threadIdx.x;
+    const bool valid = i < p.Np;
     const int ii = valid ? i : p.Np - 1;
     const uint32_t hi = (uint32_t)((1 << p.bits) - 3);
     const float4 xq = S.q[0][ii];
@@ -77,6 +79,7 @@ __global__ __launch_bounds__(256) void k_rb_count(DP p) {
     if (valid) {
         p.pkey[i] = key;
         p.prank[i] = rank;
+    }
     }
 }
 
@@ -352,16 +355,17 @@ __global__ __launch_bounds__(256) void k_rb_scatter(DP p) {
             }
         }
     }
-    if (i >= p.Np) return;
     const PSet& S = p.set[p.ctl->cur];
-    const uint32_t key = p.pkey[i];
-    const int t = i >= p.Nf;
-    const int dst = (t ? p.Nf : 0) + p.blkstart[t][key >> 6] + p.cellcnt[t][key] + (int)p.prank[i];
-    // only the permutation is scattered (4 bytes per particle); the particle planes are moved by
-    // k_rb_finish as a gather, whose writes are fully coalesced
-    p.src_of[dst] = (uint32_t)i;
-    p.dst_of[i] = dst;
-    p.imap[S.pid[i]] = dst;
+    for (int j = i; j < p.Np; j += (int)(gridDim.x * 256u)) {
+        const uint32_t key = p.pkey[j];
+        const int t = j >= p.Nf;
+        const int dst = (t ? p.Nf : 0) + p.blkstart[t][key >> 6] + p.cellcnt[t][key] + (int)p.prank[j];
+        // only the permutation is scattered (4 bytes per particle); the particle planes are moved by
+        // k_rb_finish as a gather, whose writes are fully coalesced
+        p.src_of[dst] = (uint32_t)j;
+        p.dst_of[j] = dst;
+        p.imap[S.pid[j]] = dst;
+    }
 }
 
 // R4: refresh face -> vertex slots, re-zero the histograms, flip the sets.  Launched with a
