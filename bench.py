@@ -142,10 +142,33 @@ def main():
     nb = (1 << bits) // 4
     chain = None
     stream = torch.cuda.Stream()
+    transport = "RCCL"
     if world > 1:
         g.set_stream(stream.cuda_stream)  # kernels and RCCL transfers ordered on one stream
-        chain = HaloChain(g, rank, world, cut_lo_block=nb // 4, cut_hi_block=3 * nb // 4, pitch_blocks=nb // 2,
-                          zone_blocks=2, capacity_blocks=512, device=torch.device("cuda", local_rank))
+        mk = lambda group: HaloChain(g, rank, world, cut_lo_block=nb // 4, cut_hi_block=3 * nb // 4,
+                                     pitch_blocks=nb // 2, zone_blocks=2, capacity_blocks=512,
+                                     device=torch.device("cuda", local_rank), group=group)
+        chain = mk(None)
+        if backend == "nccl":
+            # The RCCL point-to-point path cannot be exercised on the one-GPU development boxes.  If its
+            # first exchange raises, say so and fall back to the host-staged transport (tested) instead of
+            # dying without a number; the JSON line names the transport that was measured.
+            staged_group = dist.new_group(backend="gloo")
+            ok = torch.ones(1, device="cuda")
+            try:
+                with torch.cuda.stream(stream):
+                    chain.run_substeps(1, dt, -1)
+                torch.cuda.synchronize()
+            except Exception as exc:  # noqa: BLE001
+                print(f"[bench] rank {rank}: RCCL halo exchange failed ({exc!r}); using the host-staged transport",
+                      file=sys.stderr)
+                ok.zero_()
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)   # every rank takes the same decision
+            if float(ok.item()) == 0.0:
+                chain = mk(staged_group)
+                transport = "host-staged (gloo)"
+        else:
+            transport = "host-staged (gloo)"
 
     def barrier():
         if world > 1:
@@ -211,7 +234,7 @@ def main():
                    config=dict(workload=f"{args.config}: {npart} particles ({nf} faces + {nv} vertices), "
                                         f"{1 << bits}^3 grid, corotated cloth, no contact, dt={dt}",
                                particles_per_gpu=npart, grid=f"{1 << bits}^3", touched_blocks=st["touched_blocks"],
-                               rebuilds=st["rebuilds"], slot_sort_every=args.sort_every, parallelism=("single GPU" if world == 1 else f"{world} GPUs: x-tiled patches, 1 rank/GPU, RCCL halo of grid-block sums per substep")),
+                               rebuilds=st["rebuilds"], slot_sort_every=args.sort_every, parallelism=("single GPU" if world == 1 else f"{world} GPUs: x-tiled patches, 1 rank/GPU, {transport} halo of grid-block sums per substep")),
                    roofline=roofline)
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(bits, layers, res, dt, args.cpu_budget)
