@@ -9,6 +9,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <fstream>
+#include <functional>
 #include <numeric>
 #include <string>
 #include <vector>
@@ -301,6 +302,8 @@ int mpm_destroy(mpm_handle_t e) {
     hipSetDevice(e->device);
     if (e->own_stream) hipStreamSynchronize(e->own_stream);
     drop_step_graph(e);
+    for (auto& kg : e->halo_graph)
+        if (kg.exec) (void)hipGraphExecDestroy(kg.exec);
     for (void* a : e->allocs) hipFree(a);
     if (e->d_stage) hipFree(e->d_stage);
     e->cb.release();
@@ -433,26 +436,60 @@ int mpm_substep_end(mpm_handle_t e, float dt, int bc) {
     return 0;
 }
 
+// Replays `body` (a sequence of launches on e->stream) from a graph cached under `key`.
+static int replay_keyed(mpm_engine* e, mpm_engine::KeyedGraph& kg, const std::vector<uint64_t>& key,
+                        const std::function<void()>& body) {
+    if (!kg.exec || kg.key != key) {
+        if (kg.exec) (void)hipGraphExecDestroy(kg.exec);
+        kg.exec = nullptr;
+        hipGraph_t g = nullptr;
+        HIP_TRY(hipStreamBeginCapture(e->stream, hipStreamCaptureModeThreadLocal));
+        body();
+        HIP_TRY(hipStreamEndCapture(e->stream, &g));
+        const hipError_t err = hipGraphInstantiate(&kg.exec, g, nullptr, nullptr, 0);
+        (void)hipGraphDestroy(g);
+        HIP_TRY(err);
+        kg.key = key;
+    }
+    HIP_TRY(hipGraphLaunch(kg.exec, e->stream));
+    return 0;
+}
+static bool halo_graphs() {
+    static const bool on = getenv("MPM_HALO_GRAPH") != nullptr && atoi(getenv("MPM_HALO_GRAPH")) != 0;
+    return on;
+}
+static uint64_t bits_of(float f) { uint32_t u; std::memcpy(&u, &f, 4); return u; }
+
 int mpm_substep_begin_halo(mpm_handle_t e, float dt, int n, const int* bx_lo, const int* bx_hi, const int* shift_bx,
                            void* const* send_bufs, size_t cap) {
     READY(e);
     REQUIRE(n >= 0 && n <= 2 && (n == 0 || (bx_lo && bx_hi && shift_bx && send_bufs)), "bad halo zone list");
     REQUIRE(n == 0 || (cap > 0 && cap < (1u << 24)), "bad halo buffer");
-    launch_rebuild(e);
-    launch_fem(e, dt);
-    launch_p2g(e, dt);
     DP p = e->dp;   // per-launch copy: k_grid<0> resets the entry counters of the send buffers
     HaloZones z{};
+    std::vector<uint64_t> key = {1, bits_of(dt), (uint64_t)n, (uint64_t)cap, (uint64_t)(uintptr_t)e->stream};
     for (int i = 0; i < n; ++i) {
         REQUIRE(send_bufs[i], "null halo buffer");
         p.halo_hdr[i] = static_cast<uint32_t*>(send_bufs[i]);
         z.lo[i] = bx_lo[i]; z.hi[i] = bx_hi[i]; z.shift[i] = shift_bx[i];
         z.buf[i] = static_cast<uint32_t*>(send_bufs[i]);
+        key.insert(key.end(), {(uint64_t)(uint32_t)bx_lo[i], (uint64_t)(uint32_t)bx_hi[i], (uint64_t)(uint32_t)shift_bx[i],
+                               (uint64_t)(uintptr_t)send_bufs[i]});
     }
-    hipLaunchKernelGGL(k_grid<0>, dim3(e->g_grid), dim3(256), 0, e->stream, p, -1);
+    auto body = [&]() {
+        launch_rebuild(e);
+        launch_fem(e, dt);
+        launch_p2g(e, dt);
+        hipLaunchKernelGGL(k_grid<0>, dim3(e->g_grid), dim3(256), 0, e->stream, p, -1);
+        if (n > 0)
+            hipLaunchKernelGGL(k_halo_pack2, dim3(e->g_grid, n), dim3(256), 0, e->stream, e->dp, z, (unsigned)cap);
+    };
+    if (halo_graphs()) {
+        if (int rc = replay_keyed(e, e->halo_graph[0], key, body)) return rc;
+    } else {
+        body();
+    }
     e->grid_state = 3;
-    if (n > 0)
-        hipLaunchKernelGGL(k_halo_pack2, dim3(e->g_grid, n), dim3(256), 0, e->stream, e->dp, z, (unsigned)cap);
     return 0;
 }
 
@@ -460,15 +497,28 @@ int mpm_substep_end_halo(mpm_handle_t e, float dt, int bc, int n, const void* co
     READY(e);
     REQUIRE(n >= 0 && n <= 2 && (n == 0 || recv_bufs), "bad halo buffer list");
     REQUIRE(e->grid_state == 3, "mpm_substep_end_halo without mpm_substep_begin_halo");
-    if (n > 0) {
-        HaloBufs b{};
-        for (int i = 0; i < n; ++i) {
-            REQUIRE(recv_bufs[i], "null halo buffer");
-            b.buf[i] = static_cast<const uint32_t*>(recv_bufs[i]);
-        }
-        hipLaunchKernelGGL(k_halo_add2, dim3(64, n), dim3(256), 0, e->stream, e->dp, b, (unsigned)cap);
+    HaloBufs b{};
+    std::vector<uint64_t> key = {2, bits_of(dt), (uint64_t)(uint32_t)bc, (uint64_t)n, (uint64_t)cap,
+                                 (uint64_t)(uintptr_t)e->stream};
+    for (int i = 0; i < n; ++i) {
+        REQUIRE(recv_bufs[i], "null halo buffer");
+        b.buf[i] = static_cast<const uint32_t*>(recv_bufs[i]);
+        key.push_back((uint64_t)(uintptr_t)recv_bufs[i]);
     }
-    return mpm_substep_end(e, dt, bc);
+    auto body = [&]() {
+        if (n > 0)
+            hipLaunchKernelGGL(k_halo_add2, dim3(64, n), dim3(256), 0, e->stream, e->dp, b, (unsigned)cap);
+        hipLaunchKernelGGL(k_grid<2>, dim3(e->g_grid), dim3(256), 0, e->stream, e->dp, bc);
+        launch_g2p(e, dt);
+    };
+    if (halo_graphs()) {
+        if (int rc = replay_keyed(e, e->halo_graph[1], key, body)) return rc;
+    } else {
+        body();
+    }
+    e->grid_state = 2;
+    e->substeps += 1;
+    return 0;
 }
 
 int mpm_grid_to_particle(mpm_handle_t e, float dt) {

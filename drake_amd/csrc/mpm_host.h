@@ -63,6 +63,11 @@ struct mpm_engine {
     int step_graph_bc = 0;
     int step_graph_len = 1;
     hipStream_t step_graph_stream = nullptr;
+    // the two halves of the multi-GPU substep as replayable graphs (host enqueue time matters there)
+    struct KeyedGraph {
+        hipGraphExec_t exec = nullptr;
+        std::vector<uint64_t> key;
+    } halo_graph[2];
     int last_tile_kernel = 0;  // 1 = P2G, 2 = G2P (see launch_p2g)
     // launch geometry
     unsigned g_np = 0, g_nf = 0, g_nv = 0, g_tile = 0, g_grid = 0;
