@@ -68,7 +68,7 @@ SYMBOLS = [
     "mpm_external_body_force_to_host", "mpm_rebuild_mapping", "mpm_calc_fem_state_and_force", "mpm_particle_to_grid",
     "mpm_update_grid", "mpm_grid_to_particle", "mpm_sync", "mpm_sync_particle_state_to_cpu", "mpm_dump_obj",
     "mpm_copy_contact_pairs", "mpm_generate_contact_pairs", "mpm_download_contact_pairs", "mpm_update_contact", "mpm_set_dump_dir", "mpm_substep", "mpm_run_substeps",
-    "mpm_profile_substeps", "mpm_set_stream", "mpm_get_stats", "mpm_debug_counters", "mpm_grid_gather",
+    "mpm_profile_substeps", "mpm_set_stream", "mpm_set_deterministic", "mpm_get_stats", "mpm_debug_counters", "mpm_grid_gather",
     "mpm_halo_buffer_bytes", "mpm_halo_pack", "mpm_halo_add", "mpm_update_grid_from_sums", "mpm_substep_begin",
     "mpm_substep_end", "mpm_substep_begin_halo", "mpm_substep_end_halo", "mpm_download_array", "mpm_upload_particle_state",
 ]
@@ -125,6 +125,7 @@ def load_library(build: bool = True):
         "mpm_substep_end": [vp, f, i],
         "mpm_generate_contact_pairs": [vp, sz, vp, P(sz)],
         "mpm_download_contact_pairs": [vp, vp, vp, vp, vp, vp, vp, vp],
+        "mpm_set_deterministic": [vp, i],
         "mpm_substep_begin_halo": [vp, f, i, P(C.c_int), P(C.c_int), P(C.c_int), P(C.c_void_p), sz],
         "mpm_substep_end_halo": [vp, f, i, i, P(C.c_void_p), sz],
         "mpm_debug_counters": [vp, P(C.c_uint64), i],
@@ -336,6 +337,9 @@ class GpuMpm:
 
     def update_grid_from_sums(self, mpm_bc: int = -1):
         self._ck(self.lib.mpm_update_grid_from_sums(self.h, mpm_bc))
+
+    def set_deterministic(self, on: bool = True):
+        self._ck(self.lib.mpm_set_deterministic(self.h, 1 if on else 0))
 
     def set_stream(self, stream_handle: int | None):
         self._ck(self.lib.mpm_set_stream(self.h, C.c_void_p(stream_handle) if stream_handle else None))

@@ -88,6 +88,7 @@ static void launch_rebuild(mpm_engine* e) {
     hipLaunchKernelGGL(k_rb_count, dim3(std::min(e->g_np, e->g_rb)), dim3(256), 0, e->stream, p);
     hipLaunchKernelGGL(k_rb_tables, dim3(33), dim3(1024), 0, e->stream, p);
     hipLaunchKernelGGL(k_rb_scatter, dim3(std::min(e->g_np, e->g_rb)), dim3(256), 0, e->stream, p);
+    if (e->deterministic) hipLaunchKernelGGL(k_rb_canon, dim3(512), dim3(256), 0, e->stream, p);
     hipLaunchKernelGGL(k_rb_finish, dim3((std::min(e->g_np, 2048u) + 7u) & ~7u), dim3(256), 0, e->stream, p);
 }
 static void drop_step_graph(mpm_engine* e) {
@@ -317,6 +318,13 @@ int mpm_counts(mpm_handle_t e, size_t* nv, size_t* nf, size_t* np) {
     if (nv) *nv = e->nv;
     if (nf) *nf = e->nf;
     if (np) *np = e->np;
+    return 0;
+}
+
+int mpm_set_deterministic(mpm_handle_t e, int on) {
+    REQUIRE(e, "null handle");
+    if (e->deterministic != (on != 0)) drop_step_graph(e);   // the captured substep has one kernel more or less
+    e->deterministic = on != 0;
     return 0;
 }
 

@@ -54,6 +54,7 @@ struct mpm_engine {
     int* d_pids_api2 = nullptr;
     int* d_iota = nullptr;     // identity map, created on first use (views in original order)
     bool api_identity = true;
+    bool deterministic = getenv("MPM_DETERMINISTIC") != nullptr;  // see mpm_set_deterministic
     unsigned g_rb = 2048;  // workgroups of the particle-parallel re-sort kernels
     int grid_state = 0;  // 0 nothing, 1 slabs valid (after P2G), 2 grid updated
     uint64_t substeps = 0;

@@ -368,6 +368,41 @@ __global__ __launch_bounds__(256) void k_rb_scatter(DP p) {
     }
 }
 
+// R3b (optional, mpm_set_deterministic): the counting sort places the particles of one (type, cell)
+// segment in the arrival order of their atomics, which differs from run to run.  Sorting every
+// segment by the previous slot makes the new order a pure function of the old one, hence the whole
+// trajectory bitwise reproducible.  One thread per (home block, type, cell); segments are short
+// (tens of particles) and sit in L2.
+__global__ __launch_bounds__(256) void k_rb_canon(DP p) {
+    Ctl* c = p.ctl;
+    if (!c->need_rebuild) return;
+    const PSet& S = p.set[c->cur];
+    const unsigned n = c->n_home * 128u;
+    for (unsigned w = blockIdx.x * 256 + threadIdx.x; w < n; w += gridDim.x * 256) {
+        const unsigned h = w >> 7, t = (w >> 6) & 1u, cell = w & 63u;
+        const uint32_t b = p.home_block[h];
+        const int4 rg = p.home_range[h];
+        const int* pre = p.cellcnt[t] + (size_t)b * 64;      // exclusive prefixes at this point
+        const int lo = (t ? rg.z : rg.x) + pre[cell];
+        const int hi = cell < 63u ? (t ? rg.z : rg.x) + pre[cell + 1] : (t ? rg.w : rg.y);
+        // insertion sort of src_of[lo, hi)
+        for (int j = lo + 1; j < hi; ++j) {
+            const uint32_t v = p.src_of[j];
+            int k = j - 1;
+            while (k >= lo && p.src_of[k] > v) {
+                p.src_of[k + 1] = p.src_of[k];
+                --k;
+            }
+            p.src_of[k + 1] = v;
+        }
+        for (int j = lo; j < hi; ++j) {
+            const uint32_t src = p.src_of[j];
+            p.dst_of[src] = j;
+            p.imap[S.pid[src]] = j;
+        }
+    }
+}
+
 // R4: refresh face -> vertex slots, re-zero the histograms, flip the sets.  Launched with a
 // fixed, small number of workgroups (grid-stride) so that the closing ticket costs few atomics.
 __global__ __launch_bounds__(256) void k_rb_finish(DP p) {

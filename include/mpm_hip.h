@@ -182,6 +182,13 @@ MPM_API int mpm_grid_to_particle(mpm_handle_t h, float dt);
  * device error flags as MPM_ERR_DRIFT / MPM_ERR_CAPACITY / MPM_ERR_DOMAIN. */
 MPM_API int mpm_sync(mpm_handle_t h);
 
+/* Bitwise reproducibility from run to run (off by default; the environment variable
+ * MPM_DETERMINISTIC=1 turns it on at mpm_create).  A substep never uses float atomics, but the
+ * engine's re-sort orders the particles inside a cell by the arrival of integer atomics; with
+ * this switch every re-sort additionally sorts each cell's particles by their previous slot
+ * (one more kernel per substep, ~2 us when idle, ~15 us per re-sort at 1M particles). */
+MPM_API int mpm_set_deterministic(mpm_handle_t h, int on);
+
 /* GpuMpmSolver::SyncParticleStateToCpu (cuda_mpm_solver.cu:185-191):
  * pos_out: float[3*n_particles] in slot order (the reference fills
  * positions_host()). */
