@@ -120,6 +120,8 @@ struct GpuMpmState {
         return std::make_tuple(pos, idx);
     }
     void ReallocateContacts(size_t) {}  // implicit in CopyContactPairs
+    // extension: bitwise run-to-run reproducibility (see mpm_set_deterministic)
+    void SetDeterministic(bool on) { mpm_check(mpm_set_deterministic(h_, on ? 1 : 0)); }
     void ReallocateExternelBodies(size_t n) { mpm_check(mpm_reallocate_external_bodies(h_, n)); n_bodies_ = n; }
     void ExternelBodyForceToHost() {
         h_external_forces_.resize(n_bodies_);
