@@ -17,7 +17,8 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB_PATH = os.path.join(_HERE, "libmpm_oracle.so")
+# MPM_ORACLE_LIB: load another build of the same source (e.g. `make -C oracle asan`)
+_LIB_PATH = os.environ.get("MPM_ORACLE_LIB") or os.path.join(_HERE, "libmpm_oracle.so")
 _lib = None
 
 
@@ -42,6 +43,8 @@ class Params(C.Structure):
 def build(force: bool = False) -> str:
     """Compile the oracle with gcc (a few seconds)."""
     src = os.path.join(_HERE, "mpm_oracle.c")
+    if os.environ.get("MPM_ORACLE_LIB"):
+        return _LIB_PATH
     if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < os.path.getmtime(src):
         subprocess.check_call(["make", "-C", _HERE, "-s", "-B", "libmpm_oracle.so"])
     return _LIB_PATH
