@@ -52,8 +52,7 @@ struct Ctl {
     unsigned n_items;      // work items of the tile kernels (home blocks, heavy ones split)
     unsigned rebuilds;
     unsigned ticket;
-    unsigned q_p2g;        // work-queue heads of the tile kernels (each kernel re-arms the other's)
-    unsigned q_g2p;
+    unsigned reserved[2];
     unsigned pad[2];
 };
 

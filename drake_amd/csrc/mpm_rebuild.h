@@ -1,13 +1,13 @@
 // Rebuild = the engine's particle sort: a counting sort of the particle set by
 // (type, block, cell) plus the block tables that the tile kernels use.  The
-// cell-level order only has to be approximately right: the transfer kernels
-// regroup each 512-particle chunk by its current base cell in LDS, a well
-// sorted chunk just spans fewer cells.
+// cell-level order only has to be approximately right: P2G regroups each
+// 64-particle wave group by its current base cell with ballots, a well sorted
+// group just spans fewer cells.
 // It replaces RebuildMapping's key + radix sort + compute_sorted_state
 // (cuda_mpm_solver.cu:17-70, radix_sort.cuh, cuda_mpm_kernels.cuh:365-416).
 //
 // All four kernels are launched every substep and return immediately unless
-// Ctl::need_rebuild is set (raised on the device by the P2G kernel), so the
+// Ctl::need_rebuild is set (raised on the device by the G2P kernel), so the
 // decision never costs a host round trip.
 #pragma once
 #include "mpm_device.h"
@@ -111,7 +111,7 @@ constexpr int MAX_BITMAP_WORDS = 8192;  // 2^18 blocks = 256^3 cells
 // R2: one workgroup turns the histograms into
 //   - the home-block list (ascending block id) with its particle ranges and scatter offsets,
 //   - the active-block list (27-neighbourhood of the home blocks),
-//   - both neighbour tables and the heaviest-first work-queue order.
+//   - the work items of the tile kernels in heaviest-first order.
 // All work is proportional to the number of home blocks: non-empty blocks come from the bitmap
 // k_rb_count filled, the neighbourhood union is built in an LDS bitmap.
 __global__ __launch_bounds__(1024) void k_rb_tables(DP p) {

@@ -180,7 +180,7 @@ struct Stencil {
     float fx[3];
     float wx[3], wy[3], wz[3];
     unsigned mask27;     // neighbour blocks reached by the 3^3 stencil
-    bool soft_out, hard_out;
+    bool hard_out;       // base cell outside the tile (clamped): see MPM_ERR_DRIFT
 };
 
 MPM_DEV Stencil make_stencil(const DP& p, float x, float y, float z, int ox, int oy, int oz) {
@@ -195,7 +195,6 @@ MPM_DEV Stencil make_stencil(const DP& p, float x, float y, float z, int ox, int
     bspline3(s.fx[1], s.wy);
     bspline3(s.fx[2], s.wz);
     int rx = (int)bx - ox, ry = (int)by - oy, rz = (int)bz - oz;
-    s.soft_out = false;  // decided by the caller that knows the velocity (soft_zone_exit)
     const int hi_h = TILE_W - 3;
     s.hard_out = rx < 0 || ry < 0 || rz < 0 || rx > hi_h || ry > hi_h || rz > hi_h;
     rx = min(max(rx, 0), hi_h);
