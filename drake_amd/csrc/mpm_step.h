@@ -123,8 +123,9 @@ __global__ __launch_bounds__(256) void k_vforce(DP p) {
 // ---------------------------------------------------------------------------
 // P2G
 //
-// One workgroup per home block accumulates the block's (TILE_W)^3 node tile in
-// LDS and stores it as a slab.  Inside the block the transfer is organised per
+// One workgroup per work item (a home block, or a run of the wave groups of a
+// heavy one) accumulates the block's (TILE_W)^3 node tile in LDS and stores it
+// as a slab.  Inside the item the transfer is organised per
 // base cell: all particles that share a base cell scatter to the same 27 nodes,
 //     node(n) += sum_p w_n(p) * (m_p, q_p + Bdx_p * (i,j,k)_n)
 // which is a small dense contraction  [27 x P] * [P x 13]  (13 = mass, 3
@@ -132,18 +133,19 @@ __global__ __launch_bounds__(256) void k_vforce(DP p) {
 // (v_mfma_f32_16x16x4_f32: exact f32 FMA chains, the VALU rate, but the sum over
 // particles needs no cross-lane shuffles and no per-particle LDS atomics).
 // Every wave works on its own 64-particle groups, without workgroup barriers:
-//   1. every lane loads one particle (coalesced SoA), finds its base cell in
-//      the tile and builds its 13-vector,
+//   1. every lane loads one particle (four 16-byte records, prefetched one group
+//      ahead), finds its base cell in the tile and builds its 13-vector,
 //   2. the wave groups its 64 particles by base cell (ballot loop) and stages
 //      them in a wave-private LDS area,
 //   3. per cell: 4 particles per MFMA step, 2 MFMAs per step (node rows 0-15
-//      and 16-26), then 2 ds_add_f32 (64 distinct tile words each) per cell.
+//      and 16-26), then the 4 terms of every (node, component) are folded with
+//      DPP and added to the tile: 2 ds_add_u64 (64 distinct words each) per cell,
+//      in 64-bit fixed point (exact, order independent).
 // Replaces the warp-segmented scatter of cuda_mpm_kernels.cuh:418-543; the
 // order of particles inside a block is irrelevant.
 // ---------------------------------------------------------------------------
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int P2G_CHUNK = 512;
 constexpr int STG = 20;  // staged floats per particle: 16 columns of Y, fx, fy, fz, pad
 
 template <int CTRL>
