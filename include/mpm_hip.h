@@ -18,7 +18,7 @@
  *     mpm_rebuild_mapping(h, 1) exactly like RebuildMapping(state, true)
  *     (stable sort on the low min(3*domain_bits,16) key bits,
  *     cuda_mpm_solver.cu:47-68).  The engine's internal memory order is
- *     different (block/cell sorted SoA) and never visible through this API.
+ *     different (block/cell sorted 16-byte records) and never visible through this API.
  *   - vectors cross the boundary as packed float triples / row-major 3x3,
  *     exactly like the reference's Vec3<float>/Mat3<float> device buffers.
  */
