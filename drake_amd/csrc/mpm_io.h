@@ -283,8 +283,9 @@ static int download_grid(mpm_engine* e, int which, void* out, size_t bytes, size
         REQUIRE(e->grid_state == 2, "grid_v_star is undefined before UpdateGrid");
         field = p.gvs;
     } else if (which == MPM_ARR_GRID_DIR) {
-        REQUIRE(e->cb.n > 0 && e->grid_state == 2, "grid_Dir is only defined after UpdateContact");
-        return fail(MPM_ERR_INVALID, "grid_Dir download not available");
+        // the relaxed Newton direction of the last UpdateContact iteration (nodes without contacts: 0)
+        REQUIRE(e->cb.n > 0 && e->cb.gD && e->grid_state == 2, "grid_Dir is only defined after UpdateContact");
+        field = e->cb.gD;
     } else if (e->grid_state == 3) {
         // raw sums already gathered (multi-GPU path)
     } else if (e->grid_state == 1) {

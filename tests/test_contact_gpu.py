@@ -75,6 +75,10 @@ def test_update_contact_matches_oracle(exact, mu):
         close(g.download(A.CONTACT_VEL), o.c_vel, scale=sc["vel"], rtol=2e-3, what="contact vel")
         wgt = (o.g_m / o.g_m.max())[:, None]
         close(g.download(A.GRID_MOMENTUM) * wgt, o.g_mv * wgt, scale=sc["vel"], rtol=2e-3, what="grid v after contact")
+        # grid_Dir accessor: the last relaxed Newton direction, non-zero only on nodes that see contacts
+        gdir = g.download(A.GRID_DIR)
+        assert gdir.shape == (g.n_cells, 3) and np.isfinite(gdir).all() and np.abs(gdir).max() > 0
+        assert np.count_nonzero(np.abs(gdir).max(1)) < 0.05 * g.n_cells
         tau_g, f_g = g.external_body_force_to_host()
         fscale = float(np.abs(o.F_f).max())
         close(f_g, o.F_f, scale=fscale, rtol=5e-3, what="body impulse")
