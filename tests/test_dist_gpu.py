@@ -1,5 +1,6 @@
-"""Two ranks (two processes sharing the one GPU of the test box, gloo transport staged through
-host memory) against a single engine that holds both cloth patches in one grid."""
+"""Two and three ranks (processes sharing the one GPU of the test box, gloo transport staged
+through host memory) against a single engine that holds all cloth patches in one grid.  With three
+ranks the middle one has two neighbours: both zones packed / both buffers added in one launch."""
 import os
 import sys
 
@@ -16,6 +17,10 @@ def _patch(rank, center_x):
     return scenes.cloth_stack(LAYERS, RES, BITS, z0=0.5, side=SIDE, seed=40 + rank, vel_amp=0.5, center=(center_x, 0.5))
 
 
+def _centre(rank, world):
+    return 0.5 - 0.125 * (world - 1) + 0.25 * rank
+
+
 def _worker(rank, world, port, q):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -27,7 +32,7 @@ def _worker(rank, world, port, q):
     from drake_amd.dist import HaloChain
     g = GpuMpm(BITS)
     # same patch as the reference's, translated to the rank's local frame (centre x = 0.5)
-    gx = 0.375 + 0.25 * rank
+    gx = _centre(rank, world)
     sheets = [(p + np.array([0.5 - gx, 0, 0], np.float32), v, i) for p, v, i in _patch(rank, gx)]
     scenes.populate(g, sheets)
     chain = HaloChain(g, rank, world, cut_lo_block=6, cut_hi_block=10, pitch_blocks=4, zone_blocks=2,
@@ -42,47 +47,51 @@ def _worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
-def test_two_rank_chain_matches_single_engine():
+@pytest.mark.parametrize("world", [2, 3])
+def test_chain_matches_single_engine(world):
     import torch.multiprocessing as mp
     from drake_amd import ARR, GpuMpm, scenes
     from tests.helpers import close
-    # reference: both patches in one grid
+    # reference: all patches in one grid
     ref = GpuMpm(BITS)
-    a, b = _patch(0, 0.375), _patch(1, 0.625)
-    scenes.populate(ref, a + b)
+    patches = [_patch(r, _centre(r, world)) for r in range(world)]
+    scenes.populate(ref, [s for pt in patches for s in pt])
     for _ in range(STEPS):
         ref.substep(DT, -1)
     ref.gpu_sync()
     rp, rv = ref.download(ARR.POSITIONS), ref.download(ARR.VELOCITIES)
     # Finalize order is [faces | verts] over the concatenated cloths: split it back per patch
-    nv1 = sum(s[0].shape[0] for s in a)
-    nf1 = sum(s[2].size // 3 for s in a)
     nf = ref.n_faces
-    idx_a = np.r_[0:nf1, nf:nf + nv1]
-    idx_b = np.r_[nf1:nf, nf + nv1:ref.n_particles]
+    idx, f0, v0 = [], 0, 0
+    for pt in patches:
+        nfp = sum(s[2].size // 3 for s in pt)
+        nvp = sum(s[0].shape[0] for s in pt)
+        idx.append(np.r_[f0:f0 + nfp, nf + v0:nf + v0 + nvp])
+        f0 += nfp
+        v0 += nvp
 
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29650 + (os.getpid() % 200)
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    port = 29650 + (os.getpid() % 200) + 7 * world
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
     got = {}
-    for _ in range(2):
+    for _ in range(world):
         r, pos, vel, err = q.get(timeout=300)
         got[r] = (pos, vel, err)
     for p in procs:
         p.join(timeout=120)
         assert p.exitcode == 0
     vs = max(float(np.abs(rv).max()), 1.0)
-    for r, idx in ((0, idx_a), (1, idx_b)):
+    for r in range(world):
         pos, vel, err = got[r]
         assert err == 0
-        close(pos, rp[idx], scale=1.0, rtol=1e-5, what=f"rank {r} positions vs single engine")
-        close(vel, rv[idx], scale=vs, rtol=2e-3, what=f"rank {r} velocities vs single engine")
+        close(pos, rp[idx[r]], scale=1.0, rtol=1e-5, what=f"rank {r}/{world} positions vs single engine")
+        close(vel, rv[idx[r]], scale=vs, rtol=2e-3, what=f"rank {r}/{world} velocities vs single engine")
     # the patches do interact through the shared nodes: without the exchange the result differs
     solo = GpuMpm(BITS)
-    scenes.populate(solo, a)
+    scenes.populate(solo, patches[0])
     for _ in range(STEPS):
         solo.substep(DT, -1)
-    assert np.abs(solo.download(ARR.VELOCITIES) - rv[idx_a]).max() > 1e-3 * vs
+    assert np.abs(solo.download(ARR.VELOCITIES) - rv[idx[0]]).max() > 1e-3 * vs
