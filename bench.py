@@ -116,18 +116,19 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     assert torch.cuda.is_available(), "bench.py needs a GPU (the engine has no CPU fallback)"
-    # "nccl" is RCCL on ROCm.  MPM_BENCH_BACKEND=gloo exists only to rehearse the multi-rank code
-    # path on a one-GPU box (ranks share the GPU, halo staged through the host).
-    backend = os.environ.get("MPM_BENCH_BACKEND", "nccl")
+    # Multi-GPU transports, tried in this order (the JSON line names the one that was measured):
+    #   1. the library's own chain: RCCL send/recv on the engine's stream (mpm_chain_*),
+    #   2. torch.distributed point-to-point over RCCL ("nccl" backend, drake_amd/dist.py),
+    #   3. host-staged gloo (what the one-GPU tests exercise).
+    # The process group itself is gloo: it only carries the rendezvous, barriers and the timing
+    # reduction.  MPM_BENCH_BACKEND=gloo forces 3 (ranks may then share one GPU: a rehearsal).
+    backend = os.environ.get("MPM_BENCH_BACKEND", "rccl")
     ndev = torch.cuda.device_count()
-    if world > 1 and backend == "gloo":
-        local_rank = local_rank % ndev
+    if world > 1 and (backend == "gloo" or os.environ.get("MPM_BENCH_SHARE_GPU")):
+        local_rank = local_rank % ndev   # rehearsal on a box with fewer GPUs than ranks
     torch.cuda.set_device(local_rank)
     if world > 1:
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-        else:
-            dist.init_process_group(backend)
+        dist.init_process_group("gloo")
 
     from drake_amd import GpuMpm, scenes
     from drake_amd.dist import HaloChain
@@ -141,34 +142,60 @@ def main():
     nv, nf, npart = g.n_verts, g.n_faces, g.n_particles
     nb = (1 << bits) // 4
     chain = None
+    native = False
     stream = torch.cuda.Stream()
-    transport = "RCCL"
-    if world > 1:
-        g.set_stream(stream.cuda_stream)  # kernels and RCCL transfers ordered on one stream
-        mk = lambda group: HaloChain(g, rank, world, cut_lo_block=nb // 4, cut_hi_block=3 * nb // 4,
-                                     pitch_blocks=nb // 2, zone_blocks=2, capacity_blocks=512,
-                                     device=torch.device("cuda", local_rank), group=group)
-        chain = mk(None)
-        if backend == "nccl":
-            # The RCCL point-to-point path cannot be exercised on the one-GPU development boxes.  If its
-            # first exchange raises, say so and fall back to the host-staged transport (tested) instead of
-            # dying without a number; the JSON line names the transport that was measured.
-            staged_group = dist.new_group(backend="gloo")
-            ok = torch.ones(1, device="cuda")
+    transport = "none"
+    cuts = dict(cut_lo_block=nb // 4, cut_hi_block=3 * nb // 4, pitch_blocks=nb // 2, zone_blocks=2, capacity_blocks=512)
+
+    def all_ok(flag):   # every rank takes the same decision
+        t = torch.tensor([1.0 if flag else 0.0])
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        return float(t.item()) == 1.0
+
+    if world > 1 and backend != "gloo":
+        # 1. native chain
+        box = [None]
+        try:
+            if rank == 0:
+                box[0] = GpuMpm.chain_unique_id()
+        except Exception as exc:  # noqa: BLE001
+            print(f"[bench] rank 0: no RCCL id ({exc!r})", file=sys.stderr)
+        dist.broadcast_object_list(box, src=0)
+        ok = box[0] is not None
+        if ok:
             try:
+                g.chain_init(box[0], rank, world, **cuts)
+                g.chain_substeps(1, dt, -1)
+                g.gpu_sync()
+            except Exception as exc:  # noqa: BLE001
+                print(f"[bench] rank {rank}: native RCCL chain failed ({exc!r})", file=sys.stderr)
+                ok = False
+        native = all_ok(ok)
+        if native:
+            transport = "RCCL send/recv on the engine stream (mpm_chain)"
+        else:
+            # 2. torch.distributed over RCCL
+            ok = True
+            try:
+                g.chain_destroy()
+                g.set_stream(stream.cuda_stream)  # kernels and RCCL transfers ordered through one stream
+                chain = HaloChain(g, rank, world, device=torch.device("cuda", local_rank),
+                                  group=dist.new_group(backend="nccl"), **cuts)
                 with torch.cuda.stream(stream):
                     chain.run_substeps(1, dt, -1)
                 torch.cuda.synchronize()
             except Exception as exc:  # noqa: BLE001
-                print(f"[bench] rank {rank}: RCCL halo exchange failed ({exc!r}); using the host-staged transport",
-                      file=sys.stderr)
-                ok.zero_()
-            dist.all_reduce(ok, op=dist.ReduceOp.MIN)   # every rank takes the same decision
-            if float(ok.item()) == 0.0:
-                chain = mk(staged_group)
-                transport = "host-staged (gloo)"
-        else:
-            transport = "host-staged (gloo)"
+                print(f"[bench] rank {rank}: torch RCCL halo exchange failed ({exc!r})", file=sys.stderr)
+                ok = False
+            if all_ok(ok):
+                transport = "RCCL via torch.distributed point-to-point"
+            else:
+                chain = None
+    if world > 1 and not native and chain is None:
+        # 3. host-staged
+        g.set_stream(stream.cuda_stream)
+        chain = HaloChain(g, rank, world, device=torch.device("cuda", local_rank), group=None, **cuts)
+        transport = "host-staged (gloo)"
 
     def barrier():
         if world > 1:
@@ -176,7 +203,9 @@ def main():
         torch.cuda.synchronize()
 
     def run(n):
-        if chain is None and args.sort_every > 0:
+        if native:
+            g.chain_substeps(n, dt, -1)
+        elif chain is None and args.sort_every > 0:
             done = 0
             while done < n:
                 g.rebuild_mapping(True)   # slot-order sort (device radix sort); particle data does not move
@@ -198,7 +227,7 @@ def main():
     barrier()
     el = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([el], device="cuda" if backend == "nccl" else "cpu", dtype=torch.float64)
+        t = torch.tensor([el], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         el = float(t.item())
     st = g.stats()

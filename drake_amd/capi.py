@@ -70,7 +70,8 @@ SYMBOLS = [
     "mpm_copy_contact_pairs", "mpm_generate_contact_pairs", "mpm_download_contact_pairs", "mpm_update_contact", "mpm_set_dump_dir", "mpm_substep", "mpm_run_substeps",
     "mpm_profile_substeps", "mpm_set_stream", "mpm_set_deterministic", "mpm_get_stats", "mpm_debug_counters", "mpm_grid_gather",
     "mpm_halo_buffer_bytes", "mpm_halo_pack", "mpm_halo_add", "mpm_update_grid_from_sums", "mpm_substep_begin",
-    "mpm_substep_end", "mpm_substep_begin_halo", "mpm_substep_end_halo", "mpm_download_array", "mpm_upload_particle_state",
+    "mpm_substep_end", "mpm_substep_begin_halo", "mpm_substep_mid_halo", "mpm_substep_end_halo", "mpm_chain_unique_id",
+    "mpm_chain_init", "mpm_chain_substeps", "mpm_chain_destroy", "mpm_download_array", "mpm_upload_particle_state",
 ]
 
 
@@ -128,6 +129,11 @@ def load_library(build: bool = True):
         "mpm_set_deterministic": [vp, i],
         "mpm_substep_begin_halo": [vp, f, i, P(C.c_int), P(C.c_int), P(C.c_int), P(C.c_void_p), sz],
         "mpm_substep_end_halo": [vp, f, i, i, P(C.c_void_p), sz],
+        "mpm_substep_mid_halo": [vp, f, i],
+        "mpm_chain_unique_id": [vp],
+        "mpm_chain_init": [vp, vp, i, i, i, i, i, i, sz, i],
+        "mpm_chain_substeps": [vp, i, f, i],
+        "mpm_chain_destroy": [vp],
         "mpm_debug_counters": [vp, P(C.c_uint64), i],
         "mpm_download_array": [vp, i, vp, sz, P(sz)],
         "mpm_upload_particle_state": [vp, vp, vp, vp, vp, vp],
@@ -330,6 +336,31 @@ class GpuMpm:
     def substep_begin_halo(self, dt: float, zone_args, capacity_blocks: int):
         n, lo, hi, sh, bufs = zone_args
         self._ck(self.lib.mpm_substep_begin_halo(self.h, dt, n, lo, hi, sh, bufs, capacity_blocks))
+
+    # ---- native chain: RCCL point-to-point on the engine's stream (mpm_chain_*) -----
+    @staticmethod
+    def chain_unique_id() -> bytes:
+        buf = C.create_string_buffer(128)
+        lib = load_library()
+        rc = lib.mpm_chain_unique_id(buf)
+        if rc != 0:
+            raise MpmError(rc, (lib.mpm_last_error() or b"").decode())
+        return buf.raw
+
+    def chain_init(self, unique_id: bytes, rank: int, world: int, cut_lo_block: int, cut_hi_block: int,
+                   pitch_blocks: int, zone_blocks: int = 2, capacity_blocks: int = 512, periodic: bool = False):
+        assert len(unique_id) == 128
+        self._ck(self.lib.mpm_chain_init(self.h, C.c_char_p(unique_id), rank, world, cut_lo_block, cut_hi_block,
+                                         pitch_blocks, zone_blocks, capacity_blocks, 1 if periodic else 0))
+
+    def chain_substeps(self, n: int, dt: float, mpm_bc: int = -1):
+        self._ck(self.lib.mpm_chain_substeps(self.h, n, dt, mpm_bc))
+
+    def chain_destroy(self):
+        self._ck(self.lib.mpm_chain_destroy(self.h))
+
+    def substep_mid_halo(self, dt: float, mpm_bc: int = -1):
+        self._ck(self.lib.mpm_substep_mid_halo(self.h, dt, mpm_bc))
 
     def substep_end_halo(self, dt: float, mpm_bc: int, buffer_args, capacity_blocks: int):
         n, bufs = buffer_args

@@ -88,6 +88,9 @@ struct DP {
     int* dst_of;           // previous slot -> sorted slot
     unsigned* tickets;     // 32 arrival counters, 128 bytes apart (k_rb_finish)
     uint32_t* halo_hdr[2]; // per launch: halo send buffers whose entry counters k_grid<0> resets (or null)
+    // per launch: restrict k_grid<2> / k_g2p to the part of the grid that does (1) or does not (0)
+    // depend on the halo exchange; -1 = everything.  Zones are x-block ranges [lo, hi].
+    int halo_cls, halo_nz, halo_zlo[2], halo_zhi[2];
     int* cellcnt[2];       // [type][cell key]; zero outside a rebuild
     int* blkcnt[2];        // [type][block id]; zero outside a rebuild
     int* blkstart[2];
@@ -148,6 +151,18 @@ MPM_DEV int neighbor_block(uint32_t b, int o, int nb) {
 // contiguous eighth of the index range so that shared lines are fetched into one L2, not eight.
 // Launch with a grid rounded up to a multiple of 8; chunks past the end are empty.
 MPM_DEV unsigned xcd_chunk(unsigned b, unsigned grid) { return (b & 7u) * (grid >> 3) + (b >> 3); }
+
+MPM_DEV bool in_halo_zone(const DP& p, int bx) {
+    bool z = false;
+    for (int k = 0; k < p.halo_nz; ++k) z |= bx >= p.halo_zlo[k] && bx <= p.halo_zhi[k];
+    return z;
+}
+// a grid block is "boundary" if neighbours' sums are added to it; a work item if its tile (blocks
+// bx-1 .. bx+1) touches such a block
+MPM_DEV bool halo_block_selected(const DP& p, int bx) { return p.halo_cls < 0 || (int)in_halo_zone(p, bx) == p.halo_cls; }
+MPM_DEV bool halo_item_selected(const DP& p, int bx) {
+    return p.halo_cls < 0 || (int)(in_halo_zone(p, bx - 1) || in_halo_zone(p, bx) || in_halo_zone(p, bx + 1)) == p.halo_cls;
+}
 
 MPM_DEV uint32_t base_cell(float x, float dxinv) {
     const float t = x * dxinv - .5f;

@@ -18,6 +18,7 @@
 #include "mpm_host.h"
 #include "mpm_io.h"
 #include "mpm_contact.h"
+#include "mpm_chain.h"
 
 extern "C" {
 
@@ -155,6 +156,7 @@ int mpm_finalize(mpm_handle_t e) {
     p.nblocks = p.ncells >> 6;
     p.capH = (unsigned)std::min<size_t>(p.nblocks, np);
     p.capA = (unsigned)std::min<size_t>(p.nblocks, (size_t)27 * p.capH);
+    p.halo_cls = -1;
     p.item_groups = getenv("MPM_ITEM_GROUPS") ? std::max(1, atoi(getenv("MPM_ITEM_GROUPS"))) : 48;
     p.capI = p.capH + (unsigned)(np / (64 * (size_t)p.item_groups)) + 16u;
     p.dxinv = (float)(1 << e->bits);
@@ -302,6 +304,7 @@ int mpm_destroy(mpm_handle_t e) {
     if (!e) return 0;
     hipSetDevice(e->device);
     if (e->own_stream) hipStreamSynchronize(e->own_stream);
+    (void)mpm_chain_destroy(e);
     drop_step_graph(e);
     for (auto& kg : e->halo_graph)
         if (kg.exec) (void)hipGraphExecDestroy(kg.exec);
@@ -498,6 +501,24 @@ int mpm_substep_begin_halo(mpm_handle_t e, float dt, int n, const int* bx_lo, co
         body();
     }
     e->grid_state = 3;
+    e->halo_mid_done = false;
+    e->halo_nz = n;
+    for (int i = 0; i < n; ++i) { e->halo_zlo[i] = bx_lo[i]; e->halo_zhi[i] = bx_hi[i]; }
+    return 0;
+}
+
+// Between begin and end: the part of the grid update and of G2P that does not depend on the
+// neighbours' sums, to be overlapped with the exchange.  Zones = the ranges given to begin.
+int mpm_substep_mid_halo(mpm_handle_t e, float dt, int bc) {
+    READY(e);
+    REQUIRE(e->grid_state == 3 && !e->halo_mid_done, "mpm_substep_mid_halo needs mpm_substep_begin_halo first");
+    DP p = e->dp;
+    p.halo_cls = 0;
+    p.halo_nz = e->halo_nz;
+    for (int i = 0; i < e->halo_nz; ++i) { p.halo_zlo[i] = e->halo_zlo[i]; p.halo_zhi[i] = e->halo_zhi[i]; }
+    hipLaunchKernelGGL(k_grid<2>, dim3(e->g_grid), dim3(256), 0, e->stream, p, bc);
+    hipLaunchKernelGGL(k_g2p, dim3(std::min(768u, p.capI)), dim3(G2P_THREADS), 0, e->stream, p, dt);
+    e->halo_mid_done = true;
     return 0;
 }
 
@@ -513,19 +534,104 @@ int mpm_substep_end_halo(mpm_handle_t e, float dt, int bc, int n, const void* co
         b.buf[i] = static_cast<const uint32_t*>(recv_bufs[i]);
         key.push_back((uint64_t)(uintptr_t)recv_bufs[i]);
     }
+    const bool split = e->halo_mid_done;
+    DP p = e->dp;
+    if (split) {   // the interior is done: only what the received sums touch is left
+        p.halo_cls = 1;
+        p.halo_nz = e->halo_nz;
+        for (int i = 0; i < e->halo_nz; ++i) { p.halo_zlo[i] = e->halo_zlo[i]; p.halo_zhi[i] = e->halo_zhi[i]; }
+    }
     auto body = [&]() {
-        if (n > 0)
-            hipLaunchKernelGGL(k_halo_add2, dim3(64, n), dim3(256), 0, e->stream, e->dp, b, (unsigned)cap);
-        hipLaunchKernelGGL(k_grid<2>, dim3(e->g_grid), dim3(256), 0, e->stream, e->dp, bc);
-        launch_g2p(e, dt);
+        if (n > 0) hipLaunchKernelGGL(k_halo_add2, dim3(64, n), dim3(256), 0, e->stream, p, b, (unsigned)cap);
+        hipLaunchKernelGGL(k_grid<2>, dim3(e->g_grid), dim3(256), 0, e->stream, p, bc);
+        hipLaunchKernelGGL(k_g2p, dim3(std::min(768u, p.capI)), dim3(G2P_THREADS), 0, e->stream, p, dt);
     };
-    if (halo_graphs()) {
+    if (halo_graphs() && !split) {
         if (int rc = replay_keyed(e, e->halo_graph[1], key, body)) return rc;
     } else {
         body();
     }
+    e->halo_mid_done = false;
     e->grid_state = 2;
     e->substeps += 1;
+    return 0;
+}
+
+int mpm_chain_unique_id(char id_out[128]) {
+    REQUIRE(id_out, "null argument");
+    const rccl_rt::Api* a = rccl_rt::api();
+    if (!a) return fail(MPM_ERR_HIP, "RCCL (librccl.so) is not available in this process");
+    rccl_rt::UniqueId id;
+    RCCL_TRY(a->get_unique_id(&id));
+    std::memcpy(id_out, id.internal, rccl_rt::kIdBytes);
+    return 0;
+}
+
+int mpm_chain_destroy(mpm_handle_t e) {
+    REQUIRE(e, "null handle");
+    mpm_engine::Chain& c = e->chain;
+    if (int rc = use(e)) return rc;
+    (void)hipStreamSynchronize(e->stream);
+    const rccl_rt::Api* a = rccl_rt::api();
+    if (c.comm && a) (void)a->comm_destroy(c.comm);
+    for (void* q : {c.send_l, c.send_r, c.recv_l, c.recv_r})
+        if (q) (void)hipFree(q);
+    c = mpm_engine::Chain();
+    return 0;
+}
+
+int mpm_chain_init(mpm_handle_t e, const char id[128], int rank, int world, int cut_lo_block, int cut_hi_block,
+                   int pitch_blocks, int zone_blocks, size_t capacity_blocks, int periodic) {
+    READY(e);
+    REQUIRE(id && world >= 1 && rank >= 0 && rank < world, "bad rank / world");
+    REQUIRE(zone_blocks >= 1 && capacity_blocks > 0 && capacity_blocks < (1u << 24), "bad halo geometry");
+    const rccl_rt::Api* a = rccl_rt::api();
+    if (!a) return fail(MPM_ERR_HIP, "RCCL (librccl.so) is not available in this process");
+    if (int rc = mpm_chain_destroy(e)) return rc;
+    mpm_engine::Chain& c = e->chain;
+    c.rank = rank; c.world = world; c.pitch = pitch_blocks; c.cap = capacity_blocks;
+    c.left = rank > 0 ? rank - 1 : (periodic ? world - 1 : -1);
+    c.right = rank < world - 1 ? rank + 1 : (periodic ? 0 : -1);
+    c.zone_lo[0] = cut_lo_block - zone_blocks; c.zone_hi[0] = cut_lo_block + zone_blocks - 1;
+    c.zone_lo[1] = cut_hi_block - zone_blocks; c.zone_hi[1] = cut_hi_block + zone_blocks - 1;
+    c.bytes = mpm_halo_buffer_bytes(capacity_blocks);
+    for (void** q : {&c.send_l, &c.send_r, &c.recv_l, &c.recv_r}) {
+        HIP_TRY(hipMalloc(q, c.bytes));
+        HIP_TRY(hipMemsetAsync(*q, 0, c.bytes, e->stream));
+    }
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    rccl_rt::UniqueId uid;
+    std::memcpy(uid.internal, id, rccl_rt::kIdBytes);
+    RCCL_TRY(a->comm_init_rank(&c.comm, world, uid, rank));
+    return 0;
+}
+
+int mpm_chain_substeps(mpm_handle_t e, int n, float dt, int bc) {
+    READY(e);
+    mpm_engine::Chain& c = e->chain;
+    REQUIRE(c.comm, "mpm_chain_init first");
+    const rccl_rt::Api* a = rccl_rt::api();
+    // zones / buffers in the order (left, right), leaving out a missing neighbour
+    int lo[2], hi[2], sh[2], nz = 0;
+    void *sb[2], *rb[2];
+    if (c.left >= 0) { lo[nz] = c.zone_lo[0]; hi[nz] = c.zone_hi[0]; sh[nz] = +c.pitch; sb[nz] = c.send_l; rb[nz] = c.recv_l; ++nz; }
+    if (c.right >= 0) { lo[nz] = c.zone_lo[1]; hi[nz] = c.zone_hi[1]; sh[nz] = -c.pitch; sb[nz] = c.send_r; rb[nz] = c.recv_r; ++nz; }
+    for (int s = 0; s < n; ++s) {
+        if (int rc = mpm_substep_begin_halo(e, dt, nz, lo, hi, sh, sb, c.cap)) return rc;
+        if (nz > 0) {
+            RCCL_TRY(a->group_start());
+            // what goes to the left arrives "from the right" over there: when both neighbours are the
+            // same rank (ring of one or two) the k-th send pairs with the k-th receive, so the receives
+            // are posted right-then-left against sends left-then-right
+            if (c.left >= 0) RCCL_TRY(a->send(c.send_l, c.bytes, 0 /* ncclChar */, c.left, c.comm, e->stream));
+            if (c.right >= 0) RCCL_TRY(a->send(c.send_r, c.bytes, 0, c.right, c.comm, e->stream));
+            if (c.right >= 0) RCCL_TRY(a->recv(c.recv_r, c.bytes, 0, c.right, c.comm, e->stream));
+            if (c.left >= 0) RCCL_TRY(a->recv(c.recv_l, c.bytes, 0, c.left, c.comm, e->stream));
+            RCCL_TRY(a->group_end());
+        }
+        if (int rc = mpm_substep_end_halo(e, dt, bc, nz, rb, c.cap)) return rc;
+    }
+    HIP_TRY(hipGetLastError());
     return 0;
 }
 

@@ -55,6 +55,16 @@ struct mpm_engine {
     int* d_iota = nullptr;     // identity map, created on first use (views in original order)
     bool api_identity = true;
     bool deterministic = getenv("MPM_DETERMINISTIC") != nullptr;  // see mpm_set_deterministic
+    // native chain (mpm_chain_*): communicator, neighbours, device buffers
+    struct Chain {
+        void* comm = nullptr;
+        int rank = 0, world = 1, left = -1, right = -1;
+        int zone_lo[2] = {0, 0}, zone_hi[2] = {0, 0}, pitch = 0;
+        size_t cap = 0, bytes = 0;
+        void *send_l = nullptr, *send_r = nullptr, *recv_l = nullptr, *recv_r = nullptr;
+    } chain;
+    bool halo_mid_done = false;   // mpm_substep_mid_halo ran in this substep
+    int halo_nz = 0, halo_zlo[2] = {0, 0}, halo_zhi[2] = {0, 0};
     unsigned g_rb = 2048;  // workgroups of the particle-parallel re-sort kernels
     int grid_state = 0;  // 0 nothing, 1 slabs valid (after P2G), 2 grid updated
     uint64_t substeps = 0;

@@ -532,6 +532,11 @@ __global__ __launch_bounds__(256) void k_grid(DP p, int bc) {
     // the multi-GPU path packs halo buffers right after this kernel: reset their entry counters here
     if (MODE == 0 && blockIdx.x == 0 && tid < 2 && p.halo_hdr[tid]) p.halo_hdr[tid][0] = 0u;
     for (unsigned a = blockIdx.x * 4 + (tid >> 6); a < n_active; a += gridDim.x * 4) {
+        if (MODE == 2 && p.halo_cls >= 0) {   // split update around the halo exchange (wave-uniform)
+            int hx, hy, hz;
+            block_coords(p.act_block[a], hx, hy, hz);
+            if (!halo_block_selected(p, hx)) continue;
+        }
         const int* nbr = p.act_nbr_items + (size_t)a * 27;
         float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
         if (MODE == 2) s = p.gv[(size_t)a * 64 + cell];
@@ -746,6 +751,11 @@ __global__ __launch_bounds__(G2P_THREADS) void k_g2p(DP p, float dt) {
         __syncthreads();  // everybody is done with the previous tile
         const int4 idesc = p.item_desc[p.item_order[q]];
         const unsigned h = (unsigned)idesc.x;
+        if (p.halo_cls >= 0) {   // split gather around the halo exchange (uniform over the workgroup)
+            int hx, hy, hz;
+            block_coords(p.home_block[h], hx, hy, hz);
+            if (!halo_item_selected(p, hx)) continue;
+        }
         const bool prof = (diag_flags(p) & 4) != 0;
         unsigned long long t0 = 0, t1 = 0;
         if (prof) t0 = __builtin_readcyclecounter();
@@ -836,6 +846,14 @@ __global__ __launch_bounds__(256) void k_halo_add(DP p, unsigned cap, const uint
         if (id >= p.nblocks) continue;
         const int a = p.lut_act[id];
         if (a < 0) continue;  // nothing of ours reaches that block
+        if (p.halo_nz > 0) {  // with a split update only zone blocks are still raw sums
+            int hx, hy, hz;
+            block_coords(id, hx, hy, hz);
+            if (!in_halo_zone(p, hx)) {
+                if ((threadIdx.x & 63) == 0) atomicOr(&p.ctl->error, ERR_CAPACITY);
+                continue;
+            }
+        }
         const size_t g = (size_t)a * 64 + (threadIdx.x & 63);
         const float4 r = data[(size_t)e * 64 + (threadIdx.x & 63)];
         float4 q = p.gv[g];
@@ -885,6 +903,14 @@ __global__ __launch_bounds__(256) void k_halo_add2(DP p, HaloBufs b, unsigned ca
         if (id >= p.nblocks) continue;
         const int a = p.lut_act[id];
         if (a < 0) continue;  // nothing of ours reaches that block
+        if (p.halo_nz > 0) {  // with a split update only zone blocks are still raw sums
+            int hx, hy, hz;
+            block_coords(id, hx, hy, hz);
+            if (!in_halo_zone(p, hx)) {
+                if ((threadIdx.x & 63) == 0) atomicOr(&p.ctl->error, ERR_CAPACITY);
+                continue;
+            }
+        }
         const size_t g = (size_t)a * 64 + (threadIdx.x & 63);
         const float4 r = data[(size_t)e * 64 + (threadIdx.x & 63)];
         float4 q = p.gv[g];

@@ -24,7 +24,7 @@ import torch.distributed as dist
 class HaloChain:
     def __init__(self, engine, rank: int, world: int, cut_lo_block: int, cut_hi_block: int, pitch_blocks: int,
                  zone_blocks: int = 2, capacity_blocks: int = 512, device: torch.device | None = None,
-                 group=None):
+                 group=None, split: bool | None = None):
         """cut_lo_block / cut_hi_block: local x block index of the first block at/after the left /
         right cut plane (e.g. patch x in [0.25, 0.75] on 128^3 -> 8 and 24)."""
         self.e, self.rank, self.world, self.group = engine, rank, world, group
@@ -38,6 +38,10 @@ class HaloChain:
         self._ops = None
         backend = dist.get_backend(group) if world > 1 else "none"
         self.staged = backend != "nccl"
+        # split = update and gather what does not depend on the neighbours while the exchange is in
+        # flight (mpm_substep_mid_halo).  Pays with an asynchronous transport (RCCL); with the staged
+        # one it only exercises the code path.
+        self.split = (not self.staged) if split is None else split
         self.device = device if device is not None else torch.device("cpu")
         nbytes = engine.halo_buffer_bytes(capacity_blocks)
         mk = lambda: torch.zeros(nbytes, dtype=torch.uint8, device=self.device)
@@ -57,16 +61,21 @@ class HaloChain:
             z.append((self.zone_hi[0], self.zone_hi[1], -self.pitch, self.right))
         return z
 
-    def _transfer(self):
+    def _start_transfer(self):
+        """Posts the exchange; returns the handles to wait for (none for the staged transport,
+        which is synchronous)."""
         if self.staged:
             self._exchange_staged()
-            return
+            return []
         if self._ops is None:   # the buffers never change: build the op list once
             self._ops = []
             for n in self.send:
                 self._ops.append(dist.P2POp(dist.isend, self.send[n], n, group=self.group))
                 self._ops.append(dist.P2POp(dist.irecv, self.recv[n], n, group=self.group))
-        for w in dist.batch_isend_irecv(self._ops):
+        return dist.batch_isend_irecv(self._ops)
+
+    def _transfer(self):
+        for w in self._start_transfer():
             w.wait()   # stream-ordered: the current stream waits, the host does not
 
     def exchange(self):
@@ -105,7 +114,12 @@ class HaloChain:
                 self._fast_args = (e.halo_zone_args([z[:3] for z in zones], [self.send[z[3]].data_ptr() for z in zones]),
                                    e.halo_buffer_args([self.recv[n].data_ptr() for n in self.recv]))
             e.substep_begin_halo(dt, self._fast_args[0], self.cap)
-            self._transfer()
+            works = self._start_transfer()
+            if self.split:
+                # runs on the engine's stream while RCCL moves the buffers on its own
+                e.substep_mid_halo(dt, mpm_bc)
+            for w in works:
+                w.wait()
             e.substep_end_halo(dt, mpm_bc, self._fast_args[1], self.cap)
             return
         e.substep_begin(dt)

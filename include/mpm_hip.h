@@ -282,6 +282,24 @@ MPM_API int mpm_substep_end(mpm_handle_t h, float dt, int mpm_bc);
  * mpm_halo_add for each of the n_bufs received buffers + end. */
 MPM_API int mpm_substep_begin_halo(mpm_handle_t h, float dt, int n_zones, const int *bx_lo, const int *bx_hi,
                                    const int *shift_bx, void *const *send_bufs, size_t capacity_blocks);
+/* The same chain driven by the library itself: RCCL point-to-point on the engine's stream (no
+ * event between pack, transfer and add; a cross-stream dependency costs ~20 us on this stack) and
+ * one host call for a batch of substeps.  Rank 0 makes the id (mpm_chain_unique_id), the caller
+ * distributes its 128 bytes by any means, every rank calls mpm_chain_init with its own handle.
+ * Rank r's local frame is shifted by r * pitch_blocks blocks along x; cut_lo / cut_hi are the local
+ * x block indices of the left / right cut planes, zone_blocks the halo depth either side of a cut.
+ * periodic != 0 closes the chain into a ring (rank world-1's right neighbour is rank 0): used to
+ * exercise the transport with a single rank, whose neighbours are then itself. */
+MPM_API int mpm_chain_unique_id(char id_out[128]);
+MPM_API int mpm_chain_init(mpm_handle_t h, const char id[128], int rank, int world, int cut_lo_block, int cut_hi_block,
+                           int pitch_blocks, int zone_blocks, size_t capacity_blocks, int periodic);
+MPM_API int mpm_chain_substeps(mpm_handle_t h, int n_substeps, float dt, int mpm_bc);
+MPM_API int mpm_chain_destroy(mpm_handle_t h);
+
+/* Optional, between the two: the part of UpdateGrid and GridToParticle that does not depend on the
+ * neighbours' sums (blocks outside the zones given to begin, work items whose tiles do not touch a
+ * zone), to be enqueued while the exchange is in flight; mpm_substep_end_halo then only does the rest. */
+MPM_API int mpm_substep_mid_halo(mpm_handle_t h, float dt, int mpm_bc);
 MPM_API int mpm_substep_end_halo(mpm_handle_t h, float dt, int mpm_bc, int n_bufs, const void *const *recv_bufs,
                                  size_t capacity_blocks);
 

@@ -21,7 +21,7 @@ def _centre(rank, world):
     return 0.5 - 0.125 * (world - 1) + 0.25 * rank
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, split):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -36,7 +36,7 @@ def _worker(rank, world, port, q):
     sheets = [(p + np.array([0.5 - gx, 0, 0], np.float32), v, i) for p, v, i in _patch(rank, gx)]
     scenes.populate(g, sheets)
     chain = HaloChain(g, rank, world, cut_lo_block=6, cut_hi_block=10, pitch_blocks=4, zone_blocks=2,
-                      capacity_blocks=256, device=torch.device("cuda", 0))
+                      capacity_blocks=256, device=torch.device("cuda", 0), split=split)
     for _ in range(STEPS):
         chain.substep(DT, -1)
     g.gpu_sync()
@@ -47,8 +47,8 @@ def _worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 3])
-def test_chain_matches_single_engine(world):
+@pytest.mark.parametrize("world,split", [(2, False), (3, False), (3, True)])
+def test_chain_matches_single_engine(world, split):
     import torch.multiprocessing as mp
     from drake_amd import ARR, GpuMpm, scenes
     from tests.helpers import close
@@ -72,8 +72,8 @@ def test_chain_matches_single_engine(world):
 
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29650 + (os.getpid() % 200) + 7 * world
-    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    port = 29650 + (os.getpid() % 200) + 7 * world + (3 if split else 0)
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, split)) for r in range(world)]
     for p in procs:
         p.start()
     got = {}
@@ -87,8 +87,8 @@ def test_chain_matches_single_engine(world):
     for r in range(world):
         pos, vel, err = got[r]
         assert err == 0
-        close(pos, rp[idx[r]], scale=1.0, rtol=1e-5, what=f"rank {r}/{world} positions vs single engine")
-        close(vel, rv[idx[r]], scale=vs, rtol=2e-3, what=f"rank {r}/{world} velocities vs single engine")
+        close(pos, rp[idx[r]], scale=1.0, rtol=1e-5, what=f"rank {r}/{world}{' split' if split else ''} positions vs single engine")
+        close(vel, rv[idx[r]], scale=vs, rtol=2e-3, what=f"rank {r}/{world}{' split' if split else ''} velocities vs single engine")
     # the patches do interact through the shared nodes: without the exchange the result differs
     solo = GpuMpm(BITS)
     scenes.populate(solo, patches[0])
