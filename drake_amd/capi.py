@@ -251,6 +251,10 @@ class GpuMpm:
         self._ck(self.lib.mpm_sync_particle_state_to_cpu(self.h, _ptr(pos)))
         return pos
 
+    def set_dump_dir(self, path: str):
+        """Directory of the solver-statistics JSON written by update_contact(dump=True)."""
+        self._ck(self.lib.mpm_set_dump_dir(self.h, path.encode()))
+
     def dump(self, filename: str):
         self._ck(self.lib.mpm_dump_obj(self.h, filename.encode()))
 
