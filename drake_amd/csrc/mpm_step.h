@@ -181,7 +181,6 @@ struct Stencil {
     int rx, ry, rz;      // base cell relative to the tile origin (block origin - FREE_ZONE)
     float fx[3];
     float wx[3], wy[3], wz[3];
-    unsigned mask27;     // neighbour blocks reached by the 3^3 stencil
     bool hard_out;       // base cell outside the tile (clamped): see MPM_ERR_DRIFT
 };
 
@@ -203,6 +202,11 @@ MPM_DEV Stencil make_stencil(const DP& p, float x, float y, float z, int ox, int
     ry = min(max(ry, 0), hi_h);
     rz = min(max(rz, 0), hi_h);
     s.rx = rx; s.ry = ry; s.rz = rz;
+    return s;
+}
+
+// neighbour blocks (27-bit set) reached by the 3^3 stencil of base cell (rx, ry, rz) of a tile
+MPM_DEV unsigned tile_reach_mask(int rx, int ry, int rz) {
     // block offset (-1,0,1) of the first and last stencil node per axis, as bit sets
     auto bits = [](int r) -> unsigned {
         const int lo = (r - FREE_ZONE + 4) >> 2, hi2 = (r + 2 - FREE_ZONE + 4) >> 2;  // 0..2
@@ -215,8 +219,7 @@ MPM_DEV Stencil make_stencil(const DP& p, float x, float y, float z, int ox, int
 #pragma unroll
         for (int b = 0; b < 3; ++b)
             if (((mx >> a) & 1u) && ((my >> b) & 1u)) m27 |= mz << (a * 9 + b * 3);
-    s.mask27 = m27;
-    return s;
+    return m27;
 }
 
 __global__ __launch_bounds__(512, 4) void k_p2g(DP p, float dt) {  // <= 128 VGPRs: two workgroups per CU
@@ -257,8 +260,9 @@ __global__ __launch_bounds__(512, 4) void k_p2g(DP p, float dt) {  // <= 128 VGP
         delta[t] = n < 27 ? (((n / 9) * TILE_W + (n / 3) % 3) * TILE_W + n % 3) * 4 + dcomp : -1;
     }
     const float fscale = (float)(dcomp == 3 ? p.fix_m : p.fix_p);
-    // rows beyond the staged particles are read (and masked) by the last step: keep them finite
-    for (int k = lane; k < 8 * STG; k += 64) stage[64 * STG + k] = 0.f;
+    // A step reads 4 staged rows; rows that do not belong to the cell (the next cell's particles,
+    // rows never written) are masked in the B operand only, so every row must hold finite numbers
+    for (int k = lane; k < (64 + 8) * STG; k += 64) stage[k] = 0.f;
 
     // Work items (a home block, or a run of the wave groups of a heavy one) are taken round-robin
     // from the heaviest-first order: workgroup w processes entries w, w + G, ...; with G resident
@@ -355,10 +359,7 @@ __global__ __launch_bounds__(512, 4) void k_p2g(DP p, float dt) {  // <= 128 VGP
                 }
                 Y[12] = m; Y[13] = 0.f; Y[14] = 0.f; Y[15] = 0.f;
             }
-            if (act) {
-                mymask |= st.mask27;
-                hard |= st.hard_out;
-            }
+            if (act) hard |= st.hard_out;
             // the raw registers are dead now: start the next group's loads, they complete while this
             // group goes through the LDS / matrix-pipe phases below (which never wait on vmcnt)
             if (g + 8 < ngroups) cur = load_raw(g + 8);
@@ -430,7 +431,7 @@ __global__ __launch_bounds__(512, 4) void k_p2g(DP p, float dt) {  // <= 128 VGP
                                fmaf(fmaf(ay[1][2], fy, ay[1][1]), fy, ay[1][0]) *
                                fmaf(fmaf(az[1][2], fz, az[1][1]), fz, az[1][0]);
                     if (diag_flags(p) & 128) { w0 = fx; w1 = fy; }
-                    if (!ok) { y = 0.f; w0 = 0.f; w1 = 0.f; }
+                    if (!ok) y = 0.f;   // (weights of foreign rows are finite: 0 * w = 0)
                     if (diag_flags(p) & 64) {
                         acc0[0] = fmaf(w0, y, acc0[0]);
                         acc1[0] = fmaf(w1, y, acc1[0]);
@@ -448,6 +449,7 @@ __global__ __launch_bounds__(512, 4) void k_p2g(DP p, float dt) {  // <= 128 VGP
                 s0 = s1;
                 // rows = nodes, columns = (component d, term tt): fold the 4 terms of each component
                 const int crx = ckey >> 6, cry = (ckey >> 3) & 7, crz = ckey & 7;
+                mymask |= tile_reach_mask(crx, cry, crz);   // wave-uniform: scalar unit
                 long long* tb = tile + ((crx * TILE_W + cry) * TILE_W + crz) * 4;
 #pragma unroll
                 for (int t = 0; t < 2; ++t) {
@@ -481,7 +483,7 @@ __global__ __launch_bounds__(512, 4) void k_p2g(DP p, float dt) {  // <= 128 VGP
         if (prof) pc[7] = __builtin_readcyclecounter() - tb0;  // whole block, before the final barrier + slab
         if (prof && lane == 0)
             for (int q = 0; q < 8; ++q) atomicAdd(&p.dbgbuf[q], pc[q]);
-        if (mymask) atomicOr(&s_mask, mymask);
+        if (mymask && lane == 0) atomicOr(&s_mask, mymask);
         if (__ballot(hard) && lane == 0) atomicOr(&ctl->error, ERR_DRIFT);
         __syncthreads();
         float4* out = p.slab + (size_t)item * TILE_N;
