@@ -145,7 +145,7 @@ def main():
     native = False
     stream = torch.cuda.Stream()
     transport = "none"
-    cuts = dict(cut_lo_block=nb // 4, cut_hi_block=3 * nb // 4, pitch_blocks=nb // 2, zone_blocks=2, capacity_blocks=512)
+    cuts = dict(cut_lo_block=nb // 4, cut_hi_block=3 * nb // 4, pitch_blocks=nb // 2, zone_blocks=2, capacity_blocks=1024)
 
     def all_ok(flag):   # every rank takes the same decision
         t = torch.tensor([1.0 if flag else 0.0])
