@@ -14,6 +14,9 @@ import os
 import sys
 import time
 
+# the host driver of this pool only supports dmabuf IPC: RCCL / cross-process device memory needs it
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
