@@ -9,6 +9,7 @@
 #include "../../include/mpm_hip.h"
 #include "mpm_host.h"
 #include "mpm_sort.h"
+#include "mpm_rootfind.h"
 
 template <class T>
 static int grow(T** ptr, size_t n) {
@@ -239,54 +240,31 @@ static int update_contact(mpm_engine* e, int frame, int substep, float dt, float
             *out = std::make_tuple((float)st.scal[0], (float)st.scal[1], (float)st.scal[2]);
             return 0;
         };
-        auto sign = [](float v) { return v > 0 ? 1 : (v < 0 ? -1 : 0); };
-        const float f_tol = 1e-8f, x_tol = f_tol * c.relax;
+        const float f_tol = 1e-8f, x_tol = f_tol * c.relax;   // cuda_mpm_solver.cu:383-385
         while (residual > c.tol && iters < max_iters) {
             hipLaunchKernelGGL(k_ct_contact_grad, dim3(gc), dim3(256), 0, s, p, c, iters == 0);
             hipLaunchKernelGGL(k_ct_node_dir, dim3(n_dir_wg), dim3(CT_WG), 0, s, p, c);
             std::tuple<float, float, float> f_lo, f_hi, f_root;
             int rc;
             if ((rc = probe(0.f, &f_lo)) || (rc = probe(1.f, &f_hi))) return rc;
-            float x_lo = 0.f, x_hi = 1.f;
-            if (std::get<1>(f_lo) < 0.f && std::get<1>(f_hi) < 0.f) {
+            float x_lo = 0.f;
+            if (std::get<1>(f_lo) < 0.f && std::get<1>(f_hi) < 0.f) {   // :395-398
                 x_lo = 1.f;
                 f_lo = f_hi;
             }
-            float root = x_hi, mdx = x_lo - x_hi, mdx_prev = mdx, alpha = 1.f, energy = 0.f;
-            int ls = 0;
-            bool ok = false;
-            while (!ok) {
-                if ((rc = probe(root, &f_root))) return rc;
-                if (sign(std::get<1>(f_root)) != sign(std::get<1>(f_hi))) {
-                    x_lo = root;
-                    f_lo = f_root;
-                } else {
-                    x_hi = root;
-                    f_hi = f_root;
-                }
-                if (std::fabs(std::get<1>(f_root)) < f_tol) ok = true;
-                const bool slow = 2.f * std::fabs(std::get<1>(f_root)) > std::fabs(mdx_prev * std::get<2>(f_root));
-                mdx_prev = mdx;
-                if (slow) {
-                    mdx = .5f * (x_lo - x_hi);
-                    root = x_lo - mdx;
-                } else {
-                    mdx = std::get<1>(f_root) / std::get<2>(f_root);
-                    const float x = root - mdx;
-                    if (x_lo <= x && x <= x_hi) {
-                        root = x;
-                    } else {
-                        mdx = .5f * (x_lo - x_hi);
-                        root = x_lo - mdx;
-                    }
-                }
-                if (std::fabs(mdx) < x_tol) ok = true;
-                if (ok) {
-                    energy = std::get<0>(f_root);
-                    alpha = root;
-                }
-                ls += 1;
+            // Newton with bisection fallback on dE/dalpha, starting at the upper end (:399), with the
+            // clone's three deviations from Drake's routine (mpm_rootfind.h)
+            RootFinder<float> rf;
+            rf.start(x_lo, std::get<1>(f_lo), 1.f, std::get<1>(f_hi), 1.f, x_tol, f_tol, 200,
+                     RF_SIGN3 | RF_NO_ENDS | RF_STEP_LAST);
+            float energy = 0.f;
+            while (rf.status == 0) {
+                if ((rc = probe(rf.root, &f_root))) return rc;
+                energy = std::get<0>(f_root);
+                rf.feed(std::get<1>(f_root), std::get<2>(f_root));
             }
+            const float alpha = rf.root;
+            const int ls = rf.evals;
             HIP_TRY(hipMemcpyAsync(&b.st->alpha, &alpha, 4, hipMemcpyHostToDevice, s));
             hipLaunchKernelGGL(k_ct_apply, dim3(CT_ROWS), dim3(CT_WG), 0, s, p, c);
             residual = std::sqrt(st.norm_dir_sq) / st.dofs;

@@ -865,4 +865,44 @@ int mpm_update_contact(mpm_handle_t e, int frame, int substep, float dt, float m
                           residual_out);
 }
 
+// The root finder of the exact line search behind a C callback, for the known-answer tests
+// (host code only: no device is touched).
+int mpm_newton_bisect_f64(mpm_rootfind_fn fn, void* user, double x_lo, double x_hi, double guess, double x_tol,
+                          double f_tol, int max_evals, int flags, double* root_out, int* evals_out) {
+    REQUIRE(fn && root_out && evals_out, "null argument");
+    REQUIRE(x_lo < x_hi && x_lo <= guess && guess <= x_hi && x_tol > 0 && f_tol > 0, "bad bracket / tolerances");
+    double f_lo, f_hi, d;
+    fn(user, x_lo, &f_lo, &d);
+    fn(user, x_hi, &f_hi, &d);
+    RootFinder<double> rf;
+    rf.start(x_lo, f_lo, x_hi, f_hi, guess, x_tol, f_tol, max_evals, flags);
+    while (rf.status == 0) {
+        double f, df;
+        fn(user, rf.root, &f, &df);
+        rf.feed(f, df);
+    }
+    *root_out = rf.root;
+    *evals_out = rf.evals;
+    return rf.status == 1 ? 0 : 1;
+}
+
+int mpm_newton_bisect_f32(mpm_rootfind_fn fn, void* user, float x_lo, float x_hi, float guess, float x_tol,
+                          float f_tol, int max_evals, int flags, float* root_out, int* evals_out) {
+    REQUIRE(fn && root_out && evals_out, "null argument");
+    REQUIRE(x_lo < x_hi && x_lo <= guess && guess <= x_hi && x_tol > 0 && f_tol > 0, "bad bracket / tolerances");
+    double f_lo, f_hi, d;
+    fn(user, (double)x_lo, &f_lo, &d);
+    fn(user, (double)x_hi, &f_hi, &d);
+    RootFinder<float> rf;
+    rf.start(x_lo, (float)f_lo, x_hi, (float)f_hi, guess, x_tol, f_tol, max_evals, flags);
+    while (rf.status == 0) {
+        double f, df;
+        fn(user, (double)rf.root, &f, &df);
+        rf.feed((float)f, (float)df);
+    }
+    *root_out = rf.root;
+    *evals_out = rf.evals;
+    return rf.status == 1 ? 0 : 1;
+}
+
 }  // extern "C"

@@ -1129,7 +1129,121 @@ static ls_eval ls_full(const ls_ctx *c, float alpha) {
     ls_eval r = {E1, dE, d2E};
     return r;
 }
-static int sgn(float v) { return v > 0.f ? 1 : (v < 0.f ? -1 : 0); }
+/* ------------------------------------------------------------------ */
+/* Newton-Raphson with bisection fallback on a bracketed root.
+ *
+ * One body, two instantiations:
+ *   - double, Drake semantics: DoNewtonWithBisectionFallback,
+ *     multibody/contact_solvers/newton_with_bisection.cc:14-119 with Bracket
+ *     (newton_with_bisection.h:21-60: signbit comparison).  This is what the
+ *     reference's own test vectors exercise
+ *     (multibody/contact_solvers/test/newton_with_bisection_test.cc:55-225).
+ *   - float, the clone inside UpdateContact's exact line search
+ *     (cuda_mpm_solver.cu:383-471), which differs from the original in three
+ *     ways, selected by `flags`:
+ *       ORC_RF_SIGN3     bracket update compares a three-way sign (:367-369,
+ *                        :431) instead of signbit,
+ *       ORC_RF_NO_ENDS   no early return when an end of the bracket already
+ *                        satisfies f_tol (Drake :28-32),
+ *       ORC_RF_STEP_LAST when |f(root)| < f_tol the clone still takes the
+ *                        Newton/bisection step and returns the UPDATED root
+ *                        (:437-468), the original returns the evaluated one.
+ * The clone has no iteration limit; max_evals bounds it here (the caller
+ * passes a large number) so a bracket of two adjacent floats cannot spin.
+ * fn(ctx, x, out): out[0] = carried value (energy; unused by Drake's cases),
+ * out[1] = f(x), out[2] = f'(x).
+ * Returns 0 on convergence, 1 when max_evals ran out (Drake throws there). */
+#define ORC_RF_SIGN3 1
+#define ORC_RF_NO_ENDS 2
+#define ORC_RF_STEP_LAST 4
+#define ORC_DEFINE_ROOTFIND(NAME, T, FABS, HALF, TWO)                                            \
+    static int NAME(void (*fn)(void *, T, T *), void *ctx, T x_lo, T f_lo, T x_hi, T f_hi,       \
+                    T guess, T x_tol, T f_tol, int max_evals, int flags, T *root_out,            \
+                    int *evals_out, T *last3) {                                                  \
+        *evals_out = 0;                                                                          \
+        if (!(flags & ORC_RF_NO_ENDS)) {                                                         \
+            if (FABS(f_lo) < f_tol) { *root_out = x_lo; return 0; }                              \
+            if (FABS(f_hi) < f_tol) { *root_out = x_hi; return 0; }                              \
+        }                                                                                        \
+        T root = guess, mdx = x_lo - x_hi, mdx_prev = mdx;                                       \
+        T e[3] = {0, 0, 0};                                                                      \
+        for (int n = 1; n <= max_evals; ++n) {                                                   \
+            fn(ctx, root, e);                                                                    \
+            *evals_out = n;                                                                      \
+            if (last3) { last3[0] = e[0]; last3[1] = e[1]; last3[2] = e[2]; }                    \
+            const T f = e[1], df = e[2];                                                         \
+            int differ;                                                                          \
+            if (flags & ORC_RF_SIGN3)                                                            \
+                differ = ((f > 0) - (f < 0)) != ((f_hi > 0) - (f_hi < 0));                       \
+            else                                                                                 \
+                differ = (signbit(f) != 0) != (signbit(f_hi) != 0);                              \
+            if (differ) { x_lo = root; f_lo = f; } else { x_hi = root; f_hi = f; }               \
+            int done = 0;                                                                        \
+            if (FABS(f) < f_tol) {                                                               \
+                if (!(flags & ORC_RF_STEP_LAST)) { *root_out = root; return 0; }                 \
+                done = 1;                                                                        \
+            }                                                                                    \
+            const int slow = TWO * FABS(f) > FABS(mdx_prev * df);                                \
+            mdx_prev = mdx;                                                                      \
+            if (slow) {                                                                          \
+                mdx = HALF * (x_lo - x_hi);                                                      \
+                root = x_lo - mdx;                                                               \
+            } else {                                                                             \
+                mdx = f / df;                                                                    \
+                const T x = root - mdx;                                                          \
+                if (x_lo <= x && x <= x_hi) {                                                    \
+                    root = x;                                                                    \
+                } else {                                                                         \
+                    mdx = HALF * (x_lo - x_hi);                                                  \
+                    root = x_lo - mdx;                                                           \
+                }                                                                                \
+            }                                                                                    \
+            if (FABS(mdx) < x_tol) done = 1;                                                     \
+            if (done) { *root_out = root; return 0; }                                            \
+        }                                                                                        \
+        *root_out = root;                                                                        \
+        return 1;                                                                                \
+    }
+ORC_DEFINE_ROOTFIND(rootfind_f32, float, fabsf, .5f, 2.f)
+ORC_DEFINE_ROOTFIND(rootfind_f64, double, fabs, .5, 2.0)
+
+/* test entry: the double instantiation behind a C callback (f, f') = fn(x) */
+typedef void (*orc_fn64)(double x, double *f, double *df);
+static void rf64_thunk(void *ctx, double x, double *out) {
+    out[0] = 0;
+    (*(orc_fn64 *)ctx)(x, &out[1], &out[2]);
+}
+ORC_API int orc_newton_bisect_f64(orc_fn64 fn, double x_lo, double x_hi, double guess, double x_tol,
+                                  double f_tol, int max_evals, int flags, double *root,
+                                  int *evals) {
+    double f_lo, f_hi, d;
+    fn(x_lo, &f_lo, &d);
+    fn(x_hi, &f_hi, &d);
+    return rootfind_f64(rf64_thunk, &fn, x_lo, f_lo, x_hi, f_hi, guess, x_tol, f_tol, max_evals,
+                        flags, root, evals, NULL);
+}
+/* the float instantiation with the clone's flags, same callback type (values are rounded to
+ * float on the way in and out): lets the tests run the reference's cases through the very code
+ * path orc_update_contact uses */
+static void rf32_thunk(void *ctx, float x, float *out) {
+    double f, df;
+    (*(orc_fn64 *)ctx)((double)x, &f, &df);
+    out[0] = 0.f; out[1] = (float)f; out[2] = (float)df;
+}
+ORC_API int orc_newton_bisect_f32(orc_fn64 fn, float x_lo, float x_hi, float guess, float x_tol,
+                                  float f_tol, int max_evals, int flags, float *root, int *evals) {
+    double f_lo, f_hi, d;
+    fn((double)x_lo, &f_lo, &d);
+    fn((double)x_hi, &f_hi, &d);
+    return rootfind_f32(rf32_thunk, &fn, x_lo, (float)f_lo, x_hi, (float)f_hi, guess, x_tol, f_tol,
+                        max_evals, flags, root, evals, NULL);
+}
+
+static void ls_thunk(void *ctx, float alpha, float *out) {
+    const ls_eval r = ls_full((const ls_ctx *)ctx, alpha);
+    out[0] = r.E; out[1] = r.dE; out[2] = r.d2E;
+}
+
 
 /* GpuMpmSolver::UpdateContact (cuda_mpm_solver.cu:214-621), Jacobi branch.
  * Grid arrays are dense, indexed by cell key.  On exit gv holds the post
@@ -1173,48 +1287,18 @@ ORC_API int orc_update_contact(const orc_params *p, size_t nk, const float *cpos
         if (exact_line_search) {                                 /* :383-471 */
             const float f_tol = 1e-8f;
             const float x_tol = f_tol * relax;
-            float x_lo = 0.f, x_hi = 1.f, root;
-            ls_eval f_lo = ls_full(&ctx, 0.f), f_hi = ls_full(&ctx, 1.f), f_root = {0, 0, 0};
-            if (f_lo.dE < 0.f && f_hi.dE < 0.f) {
+            float x_lo = 0.f, x_hi = 1.f, root = 1.f;
+            ls_eval f_lo = ls_full(&ctx, 0.f), f_hi = ls_full(&ctx, 1.f);
+            if (f_lo.dE < 0.f && f_hi.dE < 0.f) {                /* :395-398 */
                 x_lo = 1.f;
                 f_lo = f_hi;
             }
-            (void)f_lo;
-            root = x_hi;
-            float mdx = x_lo - x_hi, mdx_prev = mdx;
-            int done = 0;
-            while (!done) {
-                f_root = ls_full(&ctx, root);
-                if (sgn(f_root.dE) != sgn(f_hi.dE)) {
-                    x_lo = root;
-                    f_lo = f_root;
-                } else {
-                    x_hi = root;
-                    f_hi = f_root;
-                }
-                if (fabsf(f_root.dE) < f_tol) done = 1;
-                const int slow = 2.f * fabsf(f_root.dE) > fabsf(mdx_prev * f_root.d2E);
-                mdx_prev = mdx;
-                if (slow) {
-                    mdx = .5f * (x_lo - x_hi);
-                    root = x_lo - mdx;
-                } else {
-                    mdx = f_root.dE / f_root.d2E;
-                    const float x = root - mdx;
-                    if (x_lo <= x && x <= x_hi) {
-                        root = x;
-                    } else {
-                        mdx = .5f * (x_lo - x_hi);
-                        root = x_lo - mdx;
-                    }
-                }
-                if (fabsf(mdx) < x_tol) done = 1;
-                if (done) {
-                    E1 = f_root.E;
-                    alpha = root;
-                }
-                ls_cnt += 1;
-            }
+            float last[3] = {0.f, 0.f, 0.f};
+            /* guess = x_upper (:399); the clone's three deviations from Drake's routine */
+            rootfind_f32(ls_thunk, &ctx, x_lo, f_lo.dE, x_hi, f_hi.dE, x_hi, x_tol, f_tol, 200,
+                         ORC_RF_SIGN3 | ORC_RF_NO_ENDS | ORC_RF_STEP_LAST, &root, &ls_cnt, last);
+            E1 = last[0];
+            alpha = root;
         } else {                                                 /* :472-528 */
             int done = 0;
             while (!done) {
