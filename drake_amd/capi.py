@@ -72,7 +72,10 @@ SYMBOLS = [
     "mpm_halo_buffer_bytes", "mpm_halo_pack", "mpm_halo_add", "mpm_update_grid_from_sums", "mpm_substep_begin",
     "mpm_substep_end", "mpm_substep_begin_halo", "mpm_substep_mid_halo", "mpm_substep_end_halo", "mpm_chain_unique_id",
     "mpm_chain_init", "mpm_chain_substeps", "mpm_chain_destroy", "mpm_download_array", "mpm_upload_particle_state",
+    "mpm_newton_bisect_f64", "mpm_newton_bisect_f32",
 ]
+
+ROOTFIND_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_double, C.POINTER(C.c_double), C.POINTER(C.c_double))
 
 
 def library_path() -> str:
@@ -142,6 +145,11 @@ def load_library(build: bool = True):
         fn = getattr(lib, name)
         fn.argtypes = args
         fn.restype = C.c_int
+    d = C.c_double
+    lib.mpm_newton_bisect_f64.argtypes = [ROOTFIND_FN, vp, d, d, d, d, d, i, i, P(d), P(i)]
+    lib.mpm_newton_bisect_f64.restype = i
+    lib.mpm_newton_bisect_f32.argtypes = [ROOTFIND_FN, vp, f, f, f, f, f, i, i, P(f), P(i)]
+    lib.mpm_newton_bisect_f32.restype = i
     lib.mpm_halo_buffer_bytes.argtypes = [sz]
     lib.mpm_halo_buffer_bytes.restype = sz
     _LIB = lib

@@ -39,7 +39,6 @@ with open(os.path.join(ROOT, "tests", "golden", "newton_with_bisection_cases.jso
     CASES = json.load(_f)["cases"]
 
 ORC_FN = C.CFUNCTYPE(None, C.c_double, C.POINTER(C.c_double), C.POINTER(C.c_double))
-ENG_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_double, C.POINTER(C.c_double), C.POINTER(C.c_double))
 
 
 def run_oracle(case, flags=0, f32=False):
@@ -68,8 +67,9 @@ def run_oracle(case, flags=0, f32=False):
 
 
 def run_engine(case, flags=0, f32=False):
-    import drake_amd
-    L = drake_amd.load_library()
+    from drake_amd import capi
+    L = capi.load_library()
+    ENG_FN = capi.ROOTFIND_FN
     fn = FUNCTIONS[case["fn"]]
     trace = []
 
@@ -81,18 +81,12 @@ def run_engine(case, flags=0, f32=False):
     ev = C.c_int(0)
     if f32:
         root = C.c_float(0)
-        f = L.mpm_newton_bisect_f32
-        f.restype = C.c_int
-        rc = f(ENG_FN(cb), None, C.c_float(case["a"]), C.c_float(case["b"]), C.c_float(case["guess"]),
-               C.c_float(case["x_tol32"]), C.c_float(case["f_tol32"]), C.c_int(200), C.c_int(flags), C.byref(root),
-               C.byref(ev))
+        rc = L.mpm_newton_bisect_f32(ENG_FN(cb), None, case["a"], case["b"], case["guess"], case["x_tol32"],
+                                     case["f_tol32"], 200, flags, C.byref(root), C.byref(ev))
     else:
         root = C.c_double(0)
-        f = L.mpm_newton_bisect_f64
-        f.restype = C.c_int
-        rc = f(ENG_FN(cb), None, C.c_double(case["a"]), C.c_double(case["b"]), C.c_double(case["guess"]),
-               C.c_double(case["x_tolerance"]), C.c_double(case["f_tolerance"]), C.c_int(case["max_iterations"]),
-               C.c_int(flags), C.byref(root), C.byref(ev))
+        rc = L.mpm_newton_bisect_f64(ENG_FN(cb), None, case["a"], case["b"], case["guess"], case["x_tolerance"],
+                                     case["f_tolerance"], case["max_iterations"], flags, C.byref(root), C.byref(ev))
     return rc, root.value, ev.value, trace[2:]
 
 
