@@ -6,5 +6,6 @@ include/mpm_hip.h).  This package only holds the build recipe, a ctypes binding
 used by the tests and bench.py, and synthetic scene generators.  There is no
 CPU fallback: every compute call goes to the HIP library or raises.
 """
-from .capi import MpmError, GpuMpm, load_library, library_path, Material, Collider, ARR, PHASES  # noqa: F401
+from .capi import (MpmError, GpuMpm, load_library, library_path, Material, Collider, GridCollider, BC_TABLE,  # noqa: F401
+                   grid_collider_preset, ARR, PHASES)
 from . import scenes  # noqa: F401

@@ -38,6 +38,33 @@ class Collider(C.Structure):
         self.w[:] = [float(x) for x in w]
 
 
+class GridCollider(C.Structure):
+    """mpm_grid_collider_t: shape 0 sphere / 1 half-space; mode 0 fixed / 1 slip while approaching / 2 slip."""
+    _fields_ = [("shape", C.c_int32), ("mode", C.c_int32), ("p", C.c_float * 3), ("n", C.c_float * 3),
+                ("radius", C.c_float), ("v", C.c_float * 3), ("friction", C.c_float)]
+
+    def __init__(self, shape=0, mode=0, p=(0, 0, 0), n=(0, 0, 1), radius=0.0, v=(0, 0, 0), friction=-1.0):
+        super().__init__()
+        self.shape, self.mode, self.radius, self.friction = int(shape), int(mode), float(radius), float(friction)
+        self.p[:] = [float(x) for x in p]
+        self.n[:] = [float(x) for x in n]
+        self.v[:] = [float(x) for x in v]
+
+
+BC_TABLE = 4   # mpm_bc value that selects the table of set_grid_colliders
+
+
+def grid_collider_preset(mpm_bc: int, sdf_friction: float = 0.3):
+    """The collider table that reproduces the reference's scene mpm_bc (cuda_mpm_kernels.cuh:673-774)."""
+    lib = load_library()
+    arr = (GridCollider * 16)()
+    n = C.c_size_t()
+    rc = lib.mpm_grid_collider_preset(mpm_bc, C.c_float(sdf_friction), arr, 16, C.byref(n))
+    if rc:
+        raise MpmError(rc, (lib.mpm_last_error() or b"").decode())
+    return [arr[k] for k in range(n.value)]
+
+
 class Material(C.Structure):
     _fields_ = [
         ("youngs_modulus", C.c_float), ("poisson_ratio", C.c_float), ("density", C.c_float), ("gamma", C.c_float),
@@ -72,7 +99,9 @@ SYMBOLS = [
     "mpm_halo_buffer_bytes", "mpm_halo_pack", "mpm_halo_add", "mpm_update_grid_from_sums", "mpm_substep_begin",
     "mpm_substep_end", "mpm_substep_begin_halo", "mpm_substep_mid_halo", "mpm_substep_end_halo", "mpm_chain_unique_id",
     "mpm_chain_init", "mpm_chain_substeps", "mpm_chain_destroy", "mpm_download_array", "mpm_upload_particle_state",
-    "mpm_newton_bisect_f64", "mpm_newton_bisect_f32",
+    "mpm_newton_bisect_f64", "mpm_newton_bisect_f32", "mpm_finalize_external_contact_forces",
+    "mpm_spatial_force_shift", "mpm_external_forces_at_body_origin", "mpm_set_grid_colliders",
+    "mpm_grid_collider_preset",
 ]
 
 ROOTFIND_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_double, C.POINTER(C.c_double), C.POINTER(C.c_double))
@@ -140,6 +169,11 @@ def load_library(build: bool = True):
         "mpm_debug_counters": [vp, P(C.c_uint64), i],
         "mpm_download_array": [vp, i, vp, sz, P(sz)],
         "mpm_upload_particle_state": [vp, vp, vp, vp, vp, vp],
+        "mpm_finalize_external_contact_forces": [vp, f, vp, vp],
+        "mpm_spatial_force_shift": [sz, vp, vp, vp, vp],
+        "mpm_set_grid_colliders": [vp, sz, vp],
+        "mpm_grid_collider_preset": [i, f, vp, sz, P(sz)],
+        "mpm_external_forces_at_body_origin": [sz, vp, vp, vp, vp, vp],
     }
     for name, args in sigs.items():
         fn = getattr(lib, name)
@@ -154,6 +188,29 @@ def load_library(build: bool = True):
     lib.mpm_halo_buffer_bytes.restype = sz
     _LIB = lib
     return lib
+
+
+def spatial_force_shift(tau, f, offset):
+    """SpatialForce::Shift for n forces (spatial_force.h:91-93): tau - offset x f."""
+    tau, f, offset = (_f32(a, (-1, 3)) for a in (tau, f, offset))
+    out = np.zeros_like(tau)
+    lib = load_library()
+    rc = lib.mpm_spatial_force_shift(tau.shape[0], _ptr(tau), _ptr(f), _ptr(offset), _ptr(out))
+    if rc:
+        raise MpmError(rc, (lib.mpm_last_error() or b"").decode())
+    return out
+
+
+def external_forces_at_body_origin(R_WB, p_BoBq_B, tau, f):
+    """AddAppliedExternalSpatialForces (multibody_plant.cc:2385-2407): torque shifted to the body origin."""
+    R = _f32(R_WB, (-1, 9))
+    p, tau, f = (_f32(a, (-1, 3)) for a in (p_BoBq_B, tau, f))
+    out = np.zeros_like(tau)
+    lib = load_library()
+    rc = lib.mpm_external_forces_at_body_origin(tau.shape[0], _ptr(R), _ptr(p), _ptr(tau), _ptr(f), _ptr(out))
+    if rc:
+        raise MpmError(rc, (lib.mpm_last_error() or b"").decode())
+    return out
 
 
 def _ptr(a):
@@ -235,6 +292,14 @@ class GpuMpm:
         self._ck(self.lib.mpm_external_body_force_to_host(self.h, _ptr(tau), _ptr(frc)))
         return tau, frc
 
+    def finalize_external_contact_forces(self, dt: float):
+        """FinalizeExternalContactForces (deformable_driver.h:210-219): (tau, f) forces of the plant step dt."""
+        n = getattr(self, "_n_bodies", 0)
+        tau = np.zeros((n, 3), np.float32)
+        frc = np.zeros((n, 3), np.float32)
+        self._ck(self.lib.mpm_finalize_external_contact_forces(self.h, dt, _ptr(tau), _ptr(frc)))
+        return tau, frc
+
     # ---- GpuMpmSolver -------------------------------------------------------
     def rebuild_mapping(self, sort: bool = False):
         self._ck(self.lib.mpm_rebuild_mapping(self.h, 1 if sort else 0))
@@ -247,6 +312,11 @@ class GpuMpm:
 
     def update_grid(self, mpm_bc: int = -1):
         self._ck(self.lib.mpm_update_grid(self.h, mpm_bc))
+
+    def set_grid_colliders(self, colliders):
+        """Table of analytic grid colliders used by mpm_bc = BC_TABLE (list of GridCollider)."""
+        arr = (GridCollider * max(len(colliders), 1))(*colliders)
+        self._ck(self.lib.mpm_set_grid_colliders(self.h, len(colliders), arr))
 
     def grid_to_particle(self, dt: float):
         self._ck(self.lib.mpm_grid_to_particle(self.h, dt))

@@ -19,6 +19,7 @@
 #include "mpm_io.h"
 #include "mpm_contact.h"
 #include "mpm_chain.h"
+#include "mpm_feedback.h"
 
 extern "C" {
 
@@ -84,6 +85,52 @@ int mpm_add_qr_cloth(mpm_handle_t e, const float* pos, const float* vel, size_t 
     return 0;
 }
 
+// ---- analytic colliders of the grid update ---------------------------------------------------
+// The reference's compile-time scenes (cuda_mpm_kernels.cuh:673-774) as tables; MPM_BC_TABLE selects
+// the table set with mpm_set_grid_colliders.
+static GridCollider gc_sphere(float x, float y, float z, float r, int mode, float friction) {
+    GridCollider c{};
+    c.shape = 0; c.mode = mode;
+    c.p[0] = x; c.p[1] = y; c.p[2] = z;
+    c.radius = r; c.friction = friction;
+    return c;
+}
+static int grid_collider_preset(int bc, float sdf_friction, GridColliders* out) {
+    out->n = 0;
+    switch (bc) {
+        case -1: return 0;
+        case 0:   // one sphere, slip, active while approaching (:673-692)
+            out->c[out->n++] = gc_sphere(.5f, .5f, .5f, .08f, 1, sdf_friction);
+            return 0;
+        case 1:   // two fixed spheres (:694-734)
+            out->c[out->n++] = gc_sphere(.38f, .38f, .75f, .04f, 0, sdf_friction);
+            out->c[out->n++] = gc_sphere(.38f, .62f, .75f, .04f, 0, sdf_friction);
+            return 0;
+        case 2: { // plane z < 0.11, slip, active whenever inside (:737-749)
+            GridCollider c{};
+            c.shape = 1; c.mode = 2;
+            c.p[2] = .11f; c.n[2] = 1.f; c.friction = sdf_friction;
+            out->c[out->n++] = c;
+            return 0;
+        }
+        case 3: { // four pin spheres (:752-774)
+            const float span[2] = {.3f, .7f};
+            for (int k = 0; k < 4; ++k) out->c[out->n++] = gc_sphere(span[k % 2], span[k / 2], .5f, .02f, 0, sdf_friction);
+            return 0;
+        }
+        default: return -1;
+    }
+}
+static int grid_colliders_for(mpm_engine* e, int bc, GridColliders* out) {
+    if (bc == MPM_BC_TABLE) {
+        *out = e->grid_colliders;
+        return 0;
+    }
+    if (grid_collider_preset(bc, e->mat.sdf_friction, out))
+        return fail(MPM_ERR_INVALID, "mpm_bc must be -1, 0, 1, 2, 3 or MPM_BC_TABLE");
+    return 0;
+}
+
 static void launch_rebuild(mpm_engine* e) {
     const DP& p = e->dp;
     hipLaunchKernelGGL(k_rb_count, dim3(std::min(e->g_np, e->g_rb)), dim3(256), 0, e->stream, p);
@@ -111,8 +158,8 @@ static void launch_p2g(mpm_engine* e, float dt) {
     hipLaunchKernelGGL(k_p2g, dim3(getenv("MPM_P2G_WGS") ? atoi(getenv("MPM_P2G_WGS")) : e->g_tile), dim3(512), 0, e->stream, e->dp, dt);
     e->last_tile_kernel = 1;
 }
-static void launch_grid(mpm_engine* e, int bc) {
-    hipLaunchKernelGGL(k_grid<1>, dim3(e->g_grid), dim3(256), 0, e->stream, e->dp, bc);
+static void launch_grid(mpm_engine* e, const GridColliders& gc) {
+    hipLaunchKernelGGL(k_grid<1>, dim3(e->g_grid), dim3(256), 0, e->stream, e->dp, gc);
 }
 static void launch_g2p(mpm_engine* e, float dt) {
     hipLaunchKernelGGL(k_g2p, dim3(std::min(768u, e->dp.capI)), dim3(G2P_THREADS), 0, e->stream, e->dp, dt);
@@ -386,7 +433,9 @@ int mpm_particle_to_grid(mpm_handle_t e, float dt) {
 int mpm_update_grid(mpm_handle_t e, int bc) {
     READY(e);
     REQUIRE(e->grid_state >= 1, "UpdateGrid before ParticleToGrid");
-    launch_grid(e, bc);
+    GridColliders gc;
+    if (int rc = grid_colliders_for(e, bc, &gc)) return rc;
+    launch_grid(e, gc);
     e->grid_state = 2;
     return 0;
 }
@@ -394,7 +443,7 @@ int mpm_update_grid(mpm_handle_t e, int bc) {
 int mpm_grid_gather(mpm_handle_t e) {
     READY(e);
     REQUIRE(e->grid_state >= 1, "grid gather before ParticleToGrid");
-    hipLaunchKernelGGL(k_grid<0>, dim3(e->g_grid), dim3(256), 0, e->stream, e->dp, -1);
+    hipLaunchKernelGGL(k_grid<0>, dim3(e->g_grid), dim3(256), 0, e->stream, e->dp, GridColliders{});
     e->grid_state = 3;  // raw sums in gv
     return 0;
 }
@@ -422,7 +471,9 @@ int mpm_halo_add(mpm_handle_t e, const void* dev_buf, size_t cap) {
 int mpm_update_grid_from_sums(mpm_handle_t e, int bc) {
     READY(e);
     REQUIRE(e->grid_state == 3, "needs mpm_grid_gather first");
-    hipLaunchKernelGGL(k_grid<2>, dim3(e->g_grid), dim3(256), 0, e->stream, e->dp, bc);
+    GridColliders gc;
+    if (int rc = grid_colliders_for(e, bc, &gc)) return rc;
+    hipLaunchKernelGGL(k_grid<2>, dim3(e->g_grid), dim3(256), 0, e->stream, e->dp, gc);
     e->grid_state = 2;
     return 0;
 }
@@ -432,7 +483,7 @@ int mpm_substep_begin(mpm_handle_t e, float dt) {
     launch_rebuild(e);
     launch_fem(e, dt);
     launch_p2g(e, dt);
-    hipLaunchKernelGGL(k_grid<0>, dim3(e->g_grid), dim3(256), 0, e->stream, e->dp, -1);
+    hipLaunchKernelGGL(k_grid<0>, dim3(e->g_grid), dim3(256), 0, e->stream, e->dp, GridColliders{});
     e->grid_state = 3;
     return 0;
 }
@@ -440,7 +491,9 @@ int mpm_substep_begin(mpm_handle_t e, float dt) {
 int mpm_substep_end(mpm_handle_t e, float dt, int bc) {
     READY(e);
     REQUIRE(e->grid_state == 3, "mpm_substep_end without mpm_substep_begin");
-    hipLaunchKernelGGL(k_grid<2>, dim3(e->g_grid), dim3(256), 0, e->stream, e->dp, bc);
+    GridColliders gc;
+    if (int rc = grid_colliders_for(e, bc, &gc)) return rc;
+    hipLaunchKernelGGL(k_grid<2>, dim3(e->g_grid), dim3(256), 0, e->stream, e->dp, gc);
     e->grid_state = 2;
     launch_g2p(e, dt);
     e->substeps += 1;
@@ -491,7 +544,7 @@ int mpm_substep_begin_halo(mpm_handle_t e, float dt, int n, const int* bx_lo, co
         launch_rebuild(e);
         launch_fem(e, dt);
         launch_p2g(e, dt);
-        hipLaunchKernelGGL(k_grid<0>, dim3(e->g_grid), dim3(256), 0, e->stream, p, -1);
+        hipLaunchKernelGGL(k_grid<0>, dim3(e->g_grid), dim3(256), 0, e->stream, p, GridColliders{});
         if (n > 0)
             hipLaunchKernelGGL(k_halo_pack2, dim3(e->g_grid, n), dim3(256), 0, e->stream, e->dp, z, (unsigned)cap);
     };
@@ -512,11 +565,13 @@ int mpm_substep_begin_halo(mpm_handle_t e, float dt, int n, const int* bx_lo, co
 int mpm_substep_mid_halo(mpm_handle_t e, float dt, int bc) {
     READY(e);
     REQUIRE(e->grid_state == 3 && !e->halo_mid_done, "mpm_substep_mid_halo needs mpm_substep_begin_halo first");
+    GridColliders gc;
+    if (int rc = grid_colliders_for(e, bc, &gc)) return rc;
     DP p = e->dp;
     p.halo_cls = 0;
     p.halo_nz = e->halo_nz;
     for (int i = 0; i < e->halo_nz; ++i) { p.halo_zlo[i] = e->halo_zlo[i]; p.halo_zhi[i] = e->halo_zhi[i]; }
-    hipLaunchKernelGGL(k_grid<2>, dim3(e->g_grid), dim3(256), 0, e->stream, p, bc);
+    hipLaunchKernelGGL(k_grid<2>, dim3(e->g_grid), dim3(256), 0, e->stream, p, gc);
     hipLaunchKernelGGL(k_g2p, dim3(std::min(768u, p.capI)), dim3(G2P_THREADS), 0, e->stream, p, dt);
     e->halo_mid_done = true;
     return 0;
@@ -526,9 +581,11 @@ int mpm_substep_end_halo(mpm_handle_t e, float dt, int bc, int n, const void* co
     READY(e);
     REQUIRE(n >= 0 && n <= 2 && (n == 0 || recv_bufs), "bad halo buffer list");
     REQUIRE(e->grid_state == 3, "mpm_substep_end_halo without mpm_substep_begin_halo");
+    GridColliders gc;
+    if (int rc = grid_colliders_for(e, bc, &gc)) return rc;
     HaloBufs b{};
     std::vector<uint64_t> key = {2, bits_of(dt), (uint64_t)(uint32_t)bc, (uint64_t)n, (uint64_t)cap,
-                                 (uint64_t)(uintptr_t)e->stream};
+                                 (uint64_t)(uintptr_t)e->stream, e->grid_colliders_version};
     for (int i = 0; i < n; ++i) {
         REQUIRE(recv_bufs[i], "null halo buffer");
         b.buf[i] = static_cast<const uint32_t*>(recv_bufs[i]);
@@ -543,7 +600,7 @@ int mpm_substep_end_halo(mpm_handle_t e, float dt, int bc, int n, const void* co
     }
     auto body = [&]() {
         if (n > 0) hipLaunchKernelGGL(k_halo_add2, dim3(64, n), dim3(256), 0, e->stream, p, b, (unsigned)cap);
-        hipLaunchKernelGGL(k_grid<2>, dim3(e->g_grid), dim3(256), 0, e->stream, p, bc);
+        hipLaunchKernelGGL(k_grid<2>, dim3(e->g_grid), dim3(256), 0, e->stream, p, gc);
         hipLaunchKernelGGL(k_g2p, dim3(std::min(768u, p.capI)), dim3(G2P_THREADS), 0, e->stream, p, dt);
     };
     if (halo_graphs() && !split) {
@@ -645,30 +702,32 @@ int mpm_grid_to_particle(mpm_handle_t e, float dt) {
 
 int mpm_substep(mpm_handle_t e, float dt, int bc) { return mpm_run_substeps(e, 1, dt, bc); }
 
-static void launch_substep(mpm_engine* e, float dt, int bc) {
+static void launch_substep(mpm_engine* e, float dt, const GridColliders& gc) {
     launch_rebuild(e);
     launch_fem(e, dt);
     launch_p2g(e, dt);
-    launch_grid(e, bc);
+    launch_grid(e, gc);
     launch_g2p(e, dt);
 }
 
 // A substep is nine dependent kernels with constant arguments and no host decisions (the re-sort
 // is decided on the device), so a batch of substeps replays one captured graph: the graph's
 // kernel-to-kernel hand-over is cheaper than nine stream dispatches.
-static int step_graph_for(mpm_engine* e, float dt, int bc) {
-    if (e->step_graph && e->step_graph_dt == dt && e->step_graph_bc == bc && e->step_graph_stream == e->stream)
+static int step_graph_for(mpm_engine* e, float dt, int bc, const GridColliders& gc) {
+    if (e->step_graph && e->step_graph_dt == dt && e->step_graph_bc == bc && e->step_graph_stream == e->stream &&
+        e->step_graph_gcv == e->grid_colliders_version)
         return 0;
     drop_step_graph(e);
     hipGraph_t g = nullptr;
     HIP_TRY(hipStreamBeginCapture(e->stream, hipStreamCaptureModeThreadLocal));
-    for (int k = 0; k < e->step_graph_len; ++k) launch_substep(e, dt, bc);
+    for (int k = 0; k < e->step_graph_len; ++k) launch_substep(e, dt, gc);
     HIP_TRY(hipStreamEndCapture(e->stream, &g));
     const hipError_t err = hipGraphInstantiate(&e->step_graph, g, nullptr, nullptr, 0);
     (void)hipGraphDestroy(g);
     HIP_TRY(err);
     e->step_graph_dt = dt;
     e->step_graph_bc = bc;
+    e->step_graph_gcv = e->grid_colliders_version;
     e->step_graph_stream = e->stream;
     return 0;
 }
@@ -678,13 +737,15 @@ int mpm_run_substeps(mpm_handle_t e, int n, float dt, int bc) {
     // MPM_GRAPH=<substeps per graph> replays captured graphs; measured slower than plain stream
     // dispatch on ROCm 7.2, hence opt-in
     static const int graph_len = getenv("MPM_GRAPH") ? atoi(getenv("MPM_GRAPH")) : 0;
+    GridColliders gc;
+    if (int rc = grid_colliders_for(e, bc, &gc)) return rc;
     int s = 0;
     if (graph_len > 0 && n >= graph_len) {
         e->step_graph_len = graph_len;
-        if (int rc = step_graph_for(e, dt, bc)) return rc;
+        if (int rc = step_graph_for(e, dt, bc, gc)) return rc;
         for (; s + graph_len <= n; s += graph_len) HIP_TRY(hipGraphLaunch(e->step_graph, e->stream));
     }
-    for (; s < n; ++s) launch_substep(e, dt, bc);
+    for (; s < n; ++s) launch_substep(e, dt, gc);
     e->grid_state = 2;
     e->substeps += (uint64_t)std::max(n, 0);
     HIP_TRY(hipGetLastError());
@@ -694,6 +755,8 @@ int mpm_run_substeps(mpm_handle_t e, int n, float dt, int bc) {
 int mpm_profile_substeps(mpm_handle_t e, int n, float dt, int bc, float* phase_ms, float* total_ms) {
     READY(e);
     REQUIRE(n > 0 && n <= 4096, "n out of range");
+    GridColliders gc;
+    if (int rc = grid_colliders_for(e, bc, &gc)) return rc;
     const int NE = MPM_PHASE_COUNT + 1;
     std::vector<hipEvent_t> ev((size_t)n * NE);
     for (auto& x : ev) HIP_TRY(hipEventCreate(&x));
@@ -708,7 +771,7 @@ int mpm_profile_substeps(mpm_handle_t e, int n, float dt, int bc, float* phase_m
         HIP_TRY(hipEventRecord(q[3], e->stream));
         launch_p2g(e, dt);
         HIP_TRY(hipEventRecord(q[4], e->stream));
-        launch_grid(e, bc);
+        launch_grid(e, gc);
         HIP_TRY(hipEventRecord(q[5], e->stream));
         launch_g2p(e, dt);
         HIP_TRY(hipEventRecord(q[6], e->stream));
@@ -831,6 +894,65 @@ int mpm_external_body_force_to_host(mpm_handle_t e, float* tau_out, float* f_out
     if (e->cb.n_bodies == 0) return 0;
     if (tau_out) D2H(e, tau_out, e->cb.body_tau, e->cb.n_bodies * 12);
     if (f_out) D2H(e, f_out, e->cb.body_f, e->cb.n_bodies * 12);
+    return 0;
+}
+
+int mpm_set_grid_colliders(mpm_handle_t e, size_t n, const mpm_grid_collider_t* colliders) {
+    static_assert(sizeof(GridCollider) == sizeof(mpm_grid_collider_t), "grid collider layouts differ");
+    REQUIRE(e, "null handle");
+    REQUIRE(n <= (size_t)MAX_GRID_COLLIDERS, "too many grid colliders (at most 16)");
+    REQUIRE(n == 0 || colliders, "null collider array");
+    GridColliders gc{};
+    for (size_t k = 0; k < n; ++k) {
+        const mpm_grid_collider_t& c = colliders[k];
+        REQUIRE(c.shape == MPM_GC_SPHERE || c.shape == MPM_GC_HALF_SPACE, "unknown grid collider shape");
+        REQUIRE(c.mode >= MPM_GC_FIXED && c.mode <= MPM_GC_SLIP, "unknown grid collider mode");
+        if (c.shape == MPM_GC_SPHERE) REQUIRE(c.radius > 0.f, "sphere radius must be positive");
+        if (c.shape == MPM_GC_HALF_SPACE) {
+            const float l = c.n[0] * c.n[0] + c.n[1] * c.n[1] + c.n[2] * c.n[2];
+            REQUIRE(std::fabs(l - 1.f) < 1e-4f, "half-space normal must be a unit vector");
+        }
+        std::memcpy(&gc.c[k], &c, sizeof(GridCollider));
+        if (c.friction < 0.f) gc.c[k].friction = e->mat.sdf_friction;
+    }
+    gc.n = (int)n;
+    e->grid_colliders = gc;
+    e->grid_colliders_version += 1;
+    return 0;
+}
+
+int mpm_grid_collider_preset(int mpm_bc, float sdf_friction, mpm_grid_collider_t* out, size_t capacity, size_t* n_out) {
+    REQUIRE(n_out, "null argument");
+    GridColliders gc{};
+    if (grid_collider_preset(mpm_bc, sdf_friction, &gc)) return fail(MPM_ERR_INVALID, "mpm_bc must be -1, 0, 1, 2 or 3");
+    *n_out = (size_t)gc.n;
+    REQUIRE((size_t)gc.n <= capacity && (gc.n == 0 || out), "output array too small");
+    for (int k = 0; k < gc.n; ++k) std::memcpy(&out[k], &gc.c[k], sizeof(GridCollider));
+    return 0;
+}
+
+int mpm_finalize_external_contact_forces(mpm_handle_t e, float dt, float* tau_out, float* f_out) {
+    READY(e);
+    REQUIRE(dt > 0.f, "dt must be positive");
+    if (int rc = mpm_external_body_force_to_host(e, tau_out, f_out)) return rc;
+    // impulses accumulated over the substeps of one plant step -> forces (deformable_driver.h:214-217)
+    for (size_t i = 0; i < e->cb.n_bodies * 3; ++i) {
+        if (tau_out) tau_out[i] /= dt;
+        if (f_out) f_out[i] /= dt;
+    }
+    return 0;
+}
+
+int mpm_spatial_force_shift(size_t n, const float* tau, const float* f, const float* offset, float* tau_out) {
+    REQUIRE(n == 0 || (tau && f && offset && tau_out), "null argument");
+    spatial_force_shift(n, tau, f, offset, tau_out);
+    return 0;
+}
+
+int mpm_external_forces_at_body_origin(size_t n, const float* R_WB, const float* p_BoBq_B, const float* tau,
+                                       const float* f, float* tau_Bo_out) {
+    REQUIRE(n == 0 || (R_WB && p_BoBq_B && tau && f && tau_Bo_out), "null argument");
+    forces_at_body_origin(n, R_WB, p_BoBq_B, tau, f, tau_Bo_out);
     return 0;
 }
 

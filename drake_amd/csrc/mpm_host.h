@@ -72,6 +72,10 @@ struct mpm_engine {
     hipGraphExec_t step_graph = nullptr;
     float step_graph_dt = 0.f;
     int step_graph_bc = 0;
+    uint64_t step_graph_gcv = 0;
+    // analytic colliders of the grid update selected by mpm_bc = MPM_BC_TABLE (mpm_set_grid_colliders)
+    GridColliders grid_colliders{};
+    uint64_t grid_colliders_version = 0;
     int step_graph_len = 1;
     hipStream_t step_graph_stream = nullptr;
     // the two halves of the multi-GPU substep as replayable graphs (host enqueue time matters there)

@@ -290,7 +290,7 @@ static int download_grid(mpm_engine* e, int which, void* out, size_t bytes, size
         // raw sums already gathered (multi-GPU path)
     } else if (e->grid_state == 1) {
         // state right after ParticleToGrid: raw sums (mass, momentum)
-        hipLaunchKernelGGL(k_grid<0>, dim3(e->g_grid), dim3(256), 0, e->stream, p, -1);
+        hipLaunchKernelGGL(k_grid<0>, dim3(e->g_grid), dim3(256), 0, e->stream, p, GridColliders{});
     }
     if (int rc = e->stage(need)) return rc;
     HIP_TRY(hipMemsetAsync(e->d_stage, 0, need, e->stream));

@@ -508,13 +508,20 @@ __global__ __launch_bounds__(512, 4) void k_p2g(DP p, float dt) {  // <= 128 VGP
 // MODE 1: gather + v = mv/m, walls, analytic colliders per mpm_bc, store v and v*.
 // MODE 2: like 1 but starting from the raw sums already in gv (after neighbours' sums were added).
 // ---------------------------------------------------------------------------
-MPM_DEV bool sphere_sdf(const float* pos, float cx, float cy, float cz, float r, float* n) {
-    const float d0 = pos[0] - cx, d1 = pos[1] - cy, d2 = pos[2] - cz;
-    const float len = sqrtf(d0 * d0 + d1 * d1 + d2 * d2);
-    const float inv = 1.f / len;
-    n[0] = d0 * inv; n[1] = d1 * inv; n[2] = d2 * inv;
-    return len - r < 0.f;
-}
+// Analytic colliders of the grid update: a runtime table in place of the reference's compile-time
+// scenes (update_grid_kernel<T, MPM_BOUNDARY_CONDITION>, cuda_mpm_kernels.cuh:660-789).  The first
+// collider of the list whose region contains the node decides (the reference's `else` / `break`
+// chains, :694-734, :752-774).
+struct GridCollider {       // mirrors mpm_grid_collider_t (include/mpm_hip.h)
+    int shape;              // 0 sphere (centre p, radius), 1 half-space (inside: n . (x - p) < 0)
+    int mode;               // 0 fixed, 1 slip while approaching (scene 0), 2 slip whenever inside (scene 2)
+    float p[3], n[3], radius, v[3], friction;
+};
+constexpr int MAX_GRID_COLLIDERS = 16;
+struct GridColliders {
+    int n;
+    GridCollider c[MAX_GRID_COLLIDERS];
+};
 
 constexpr int GRID_LIST = 160;   // slabs over one block: 27 neighbours x splits
 MPM_DEV int __reduce_max_sync_i32(int v) {
@@ -524,7 +531,7 @@ MPM_DEV int __reduce_max_sync_i32(int v) {
 }
 
 template <int MODE>
-__global__ __launch_bounds__(256) void k_grid(DP p, int bc) {
+__global__ __launch_bounds__(256) void k_grid(DP p, GridColliders gc) {
     __shared__ int2 s_list[4][GRID_LIST];   // (item, offset index)
     const Ctl* ctl = p.ctl;
     const unsigned n_active = ctl->n_active;
@@ -604,38 +611,36 @@ __global__ __launch_bounds__(256) void k_grid(DP p, int bc) {
             if (gy >= N - wl && v[1] > 0.f) v[1] = 0.f;
             if (gz < wl && v[2] < 0.f) v[2] = 0.f;
             if (gz >= N - wl && v[2] > 0.f) v[2] = 0.f;
-            if (bc >= 0) {
+            if (gc.n > 0) {
                 const float pos[3] = {((float)gx + .5f) * p.dx, ((float)gy + .5f) * p.dx, ((float)gz + .5f) * p.dx};
-                bool fixed = false, inside = false;
-                float n[3] = {0.f, 0.f, 0.f};
-                if (bc == 0) {
-                    if (sphere_sdf(pos, .5f, .5f, .5f, .08f, n)) {
-                        const float dn = -(n[0] * v[0] + n[1] * v[1] + n[2] * v[2]);
-                        inside = dn > 0.f;
-                    }
-                } else if (bc == 1) {
-                    fixed = true;
-                    inside = sphere_sdf(pos, .38f, .38f, .75f, .04f, n) || sphere_sdf(pos, .38f, .62f, .75f, .04f, n);
-                } else if (bc == 2) {
-                    n[2] = 1.f;
-                    inside = pos[2] - .11f < 0.f;
-                } else if (bc == 3) {
-                    fixed = true;
-                    inside = sphere_sdf(pos, .3f, .3f, .5f, .02f, n) || sphere_sdf(pos, .7f, .3f, .5f, .02f, n) ||
-                             sphere_sdf(pos, .3f, .7f, .5f, .02f, n) || sphere_sdf(pos, .7f, .7f, .5f, .02f, n);
-                }
-                if (inside) {
-                    if (fixed) {
-                        v[0] = v[1] = v[2] = 0.f;  // v += (v_collider - v), collider at rest
+                for (int k = 0; k < gc.n; ++k) {      // (uniform trip count: the table is a kernel argument)
+                    const GridCollider& cl = gc.c[k];
+                    float n[3], dist;
+                    if (cl.shape == 0) {
+                        const float d0 = pos[0] - cl.p[0], d1 = pos[1] - cl.p[1], d2 = pos[2] - cl.p[2];
+                        const float len = sqrtf(d0 * d0 + d1 * d1 + d2 * d2);
+                        const float inv = 1.f / len;
+                        n[0] = d0 * inv; n[1] = d1 * inv; n[2] = d2 * inv;
+                        dist = len - cl.radius;
                     } else {
-                        const float dv[3] = {-v[0], -v[1], -v[2]};
-                        const float dn = n[0] * dv[0] + n[1] * dv[1] + n[2] * dv[2];
-                        const float fr = p.M.sdf_friction;
-                        const float frac = dn * (1.f - fr);
+                        n[0] = cl.n[0]; n[1] = cl.n[1]; n[2] = cl.n[2];
+                        dist = n[0] * (pos[0] - cl.p[0]) + n[1] * (pos[1] - cl.p[1]) + n[2] * (pos[2] - cl.p[2]);
+                    }
+                    if (!(dist < 0.f)) continue;
+                    // diff_vel = v_collider - v, dotnv = n . diff_vel  (:683-687)
+                    const float dv[3] = {cl.v[0] - v[0], cl.v[1] - v[1], cl.v[2] - v[2]};
+                    const float dn = n[0] * dv[0] + n[1] * dv[1] + n[2] * dv[2];
+                    if (cl.mode == 0) {
+                        v[0] += dv[0]; v[1] += dv[1]; v[2] += dv[2];          // :778-781
+                    } else if (cl.mode == 2 || dn > 0.f) {
+                        // :783-786; `dotnv * (1. - SDF_FRICTION)` is a double product in the reference
+                        const float fr = cl.friction;
+                        const float frac = (float)((double)dn * (1.0 - (double)fr));
                         v[0] += dv[0] * fr + n[0] * frac;
                         v[1] += dv[1] * fr + n[1] * frac;
                         v[2] += dv[2] * fr + n[2] * frac;
                     }
+                    break;
                 }
             }
             s.x = v[0]; s.y = v[1]; s.z = v[2];

@@ -80,7 +80,12 @@ class MpmDriver {
     int CalcAbstractStates(float dt, int frame = 0) {
         float dt_left = dt;
         int substep = 0;
-        state_->ReallocateExternelBodies(std::max<size_t>(bodies_.size(), 1));  // InitalizeExternalContactForces
+        {
+            std::vector<Vec3<float>> origins;
+            for (const auto& b : bodies_) origins.push_back(b.origin);
+            if (origins.empty()) origins.push_back({0, 0, 0});
+            drake::multibody::gmpm::InitalizeExternalContactForces(state_, origins);
+        }
         MpmParticleContactPairs<float> pairs;
         while (dt_left > 0) {
             const float ddt = std::min(dt_left, config_.substep_dt);
@@ -107,15 +112,7 @@ class MpmDriver {
             n_pairs_last_ = n_pairs;
             substep += 1;
         }
-        // FinalizeExternalContactForces: impulses -> forces
-        state_->ExternelBodyForceToHost();
-        auto& f = state_->external_forces_host();
-        for (size_t i = 0; i < f.size(); ++i)
-            for (int d = 0; d < 3; ++d) {
-                f.p_BoBq_B[i][d] = 0;
-                f.F_Bq_W_tau[i][d] /= dt;
-                f.F_Bq_W_f[i][d] /= dt;
-            }
+        drake::multibody::gmpm::FinalizeExternalContactForces(state_, dt);   // impulses -> forces
         last_contacts_ = n_pairs_last_;
         return substep;
     }

@@ -197,6 +197,57 @@ class GpuMpmSolver {
     }
 };
 
+// ---- rigid feedback wire format: the three steps either side of the substep loop --------------
+
+// DeformableDriver::InitalizeExternalContactForces (multibody/plant/deformable_driver.h:196-208):
+// size and zero the per-body accumulators; p_BoBq_B temporarily carries the body origins in the
+// world (the reference stores EvalBodyPoseInWorld(...).translation() there for the contact-pair
+// generator and clears it again in Finalize).
+template <typename T>
+inline void InitalizeExternalContactForces(GpuMpmState<T>* s, const std::vector<Vec3<T>>& body_origins_W) {
+    s->ReallocateExternelBodies(body_origins_W.size());
+    auto& F = s->external_forces_host();
+    F.resize(body_origins_W.size());
+    for (size_t i = 0; i < F.size(); ++i) {
+        F.p_BoBq_B[i] = body_origins_W[i];
+        F.F_Bq_W_tau[i] = {0, 0, 0};
+        F.F_Bq_W_f[i] = {0, 0, 0};
+    }
+}
+
+// DeformableDriver::FinalizeExternalContactForces (deformable_driver.h:210-219): impulses of the
+// plant step dt -> forces, p_BoBq_B reset to zero (the torques are already about the body origins).
+template <typename T>
+inline void FinalizeExternalContactForces(GpuMpmState<T>* s, const T& dt) {
+    auto& F = s->external_forces_host();
+    F.resize(s->num_external_bodies());
+    mpm_check(mpm_finalize_external_contact_forces(s->handle(), dt, reinterpret_cast<float*>(F.F_Bq_W_tau.data()),
+                                                   reinterpret_cast<float*>(F.F_Bq_W_f.data())));
+    for (auto& p : F.p_BoBq_B) p = {0, 0, 0};
+}
+
+// The MPM block of MultibodyPlant::AddAppliedExternalSpatialForces (multibody_plant.cc:2385-2407):
+// F_BBo_W_array[i] += SpatialForce(tau_i, f_i).Shift(-(R_WB_i * p_BoBq_B_i)).  R_WB row major.
+template <typename T>
+inline void AddAppliedExternalSpatialForces(const GpuMpmState<T>& s, const std::vector<std::array<T, 9>>& R_WB,
+                                            std::vector<Vec3<T>>* tau_BBo_W, std::vector<Vec3<T>>* f_BBo_W) {
+    const auto& F = s.external_forces_host();
+    const size_t n = F.size();
+    if (R_WB.size() != n || tau_BBo_W->size() != n || f_BBo_W->size() != n)
+        throw std::logic_error("AddAppliedExternalSpatialForces: one pose and one spatial force slot per body");
+    std::vector<Vec3<T>> shifted(n);
+    mpm_check(mpm_external_forces_at_body_origin(n, reinterpret_cast<const float*>(R_WB.data()),
+                                                 reinterpret_cast<const float*>(F.p_BoBq_B.data()),
+                                                 reinterpret_cast<const float*>(F.F_Bq_W_tau.data()),
+                                                 reinterpret_cast<const float*>(F.F_Bq_W_f.data()),
+                                                 reinterpret_cast<float*>(shifted.data())));
+    for (size_t i = 0; i < n; ++i)
+        for (int d = 0; d < 3; ++d) {
+            (*tau_BBo_W)[i][d] += shifted[i][d];
+            (*f_BBo_W)[i][d] += F.F_Bq_W_f[i][d];
+        }
+}
+
 }  // namespace gmpm
 }  // namespace multibody
 }  // namespace drake

@@ -158,6 +158,25 @@ MPM_API int mpm_reallocate_external_bodies(mpm_handle_t h, size_t n_bodies);
  * tau_out / f_out: float[3*n_bodies] accumulated impulses (F_Bq_W_tau, F_Bq_W_f). */
 MPM_API int mpm_external_body_force_to_host(mpm_handle_t h, float *tau_out, float *f_out);
 
+/* ---- rigid feedback wire format (consumers of the accumulators above) ----- */
+
+/* DeformableDriver::FinalizeExternalContactForces (multibody/plant/deformable_driver.h:210-219):
+ * ExternelBodyForceToHost, then impulse / dt -> force for every body.  `dt` is the PLANT step
+ * (the accumulators collect the impulses of all its substeps).  tau_out / f_out: float[3*n_bodies],
+ * torque about the body origin p_WB handed in with the contact pairs, and force, in the world frame. */
+MPM_API int mpm_finalize_external_contact_forces(mpm_handle_t h, float dt, float *tau_out, float *f_out);
+
+/* SpatialForce::Shift (multibody/math/spatial_force.h:91-93, 151-155) for n forces:
+ * tau_out[i] = tau[i] - offset[i] x f[i]; f is unchanged.  Host arithmetic, needs no GPU. */
+MPM_API int mpm_spatial_force_shift(size_t n, const float *tau, const float *f, const float *offset, float *tau_out);
+
+/* What MultibodyPlant::AddAppliedExternalSpatialForces does with external_forces_host()
+ * (multibody/plant/multibody_plant.cc:2385-2407): p_BoBq_W = R_WB * p_BoBq_B,
+ * F_BBo_W = SpatialForce(tau, f).Shift(-p_BoBq_W), i.e. tau_Bo = tau + p_BoBq_W x f.
+ * R_WB: float[9*n] row major; the rest float[3*n].  Host arithmetic, needs no GPU. */
+MPM_API int mpm_external_forces_at_body_origin(size_t n_bodies, const float *R_WB, const float *p_BoBq_B,
+                                               const float *tau, const float *f, float *tau_Bo_out);
+
 /* ---- GpuMpmSolver<float> ------------------------------------------------- */
 
 /* GpuMpmSolver::RebuildMapping (cuda_mpm_solver.cu:17-70).  Must be called
@@ -172,8 +191,37 @@ MPM_API int mpm_calc_fem_state_and_force(mpm_handle_t h, float dt);
 /* GpuMpmSolver::ParticleToGrid (cuda_mpm_solver.cu:86-105). */
 MPM_API int mpm_particle_to_grid(mpm_handle_t h, float dt);
 
-/* GpuMpmSolver::UpdateGrid (cuda_mpm_solver.cu:107-151); mpm_bc in {-1,0,1,2,3}. */
+/* GpuMpmSolver::UpdateGrid (cuda_mpm_solver.cu:107-151).  mpm_bc in {-1,0,1,2,3} are the
+ * reference's scenes (update_grid_kernel<T, BC>, cuda_mpm_kernels.cuh:673-774); MPM_BC_TABLE
+ * uses the colliders set with mpm_set_grid_colliders.  The same values are accepted wherever an
+ * entry point takes mpm_bc. */
+#define MPM_BC_TABLE 4
 MPM_API int mpm_update_grid(mpm_handle_t h, int mpm_bc);
+
+/* Runtime form of the analytic colliders that the reference hard-codes per scene in
+ * update_grid_kernel (cuda_mpm_kernels.cuh:660-789).  For a node at x = (idx + 0.5) dx (:661-665)
+ * the FIRST collider of the list with phi(x) < 0 decides (the reference's else/break chains):
+ *   MPM_GC_FIXED             v <- v + (v_c - v)                                   (:778-781)
+ *   MPM_GC_SLIP_APPROACHING  only if n.(v_c - v) > 0 (scene 0, :684-690), then
+ *   MPM_GC_SLIP              v += mu (v_c - v) + (1 - mu) n (n.(v_c - v))          (:783-786)
+ * with n = grad(phi) and mu = friction (SDF_FRICTION, settings.h:110; a negative value selects the
+ * engine's material.sdf_friction).  Shapes: sphere (centre p, radius), half-space (inside where
+ * n.(x - p) < 0, n a unit vector).  At most 16 colliders. */
+enum { MPM_GC_SPHERE = 0, MPM_GC_HALF_SPACE = 1 };
+enum { MPM_GC_FIXED = 0, MPM_GC_SLIP_APPROACHING = 1, MPM_GC_SLIP = 2 };
+typedef struct mpm_grid_collider {
+    int32_t shape;
+    int32_t mode;
+    float p[3];
+    float n[3];
+    float radius;
+    float v[3];        /* collider velocity (0 in every reference scene) */
+    float friction;
+} mpm_grid_collider_t;
+MPM_API int mpm_set_grid_colliders(mpm_handle_t h, size_t n, const mpm_grid_collider_t *colliders);
+/* The table that reproduces scene mpm_bc in {-1,0,1,2,3} (what mpm_update_grid(h, mpm_bc) runs). */
+MPM_API int mpm_grid_collider_preset(int mpm_bc, float sdf_friction, mpm_grid_collider_t *out, size_t capacity,
+                                     size_t *n_out);
 
 /* GpuMpmSolver::GridToParticle (cuda_mpm_solver.cu:153-161). */
 MPM_API int mpm_grid_to_particle(mpm_handle_t h, float dt);

@@ -797,6 +797,67 @@ ORC_API void orc_update_grid(const orc_params *p, int bc, uint32_t touched_cells
     }
 }
 
+/* The same update with the colliders as a runtime table: checker for the
+ * engine's mpm_set_grid_colliders.  Layout and semantics of mpm_grid_collider_t (include/mpm_hip.h):
+ * the first collider whose region contains the node decides; mode 0 fixed (:778-781), 1 slip while
+ * approaching (:684-690), 2 slip whenever inside (:737-749); response :783-786.  With the preset
+ * tables it must reproduce orc_update_grid(bc) bit for bit (tests/test_oracle_kat.py). */
+typedef struct {
+    int32_t shape, mode;
+    float p[3], n[3], radius, v[3], friction;
+} orc_grid_collider;
+
+ORC_API void orc_update_grid_table(const orc_params *p, int n_col, const orc_grid_collider *cols,
+                                   uint32_t touched_cells, const uint32_t *ids, const float *gm,
+                                   float *gmv, float *gvs) {
+    const int N = 1 << p->domain_bits, wall = p->wall;
+    const float dx = p_dx(p);
+#pragma omp parallel for schedule(static)
+    for (long t = 0; t < (long)touched_cells; ++t) {
+        const uint32_t c = (ids[t >> 6] << 6) | ((uint32_t)t & 63u);
+        if (!(gm[c] > 0.f)) continue;
+        float *gv = &gmv[c * 3];
+        gv[0] /= gm[c];
+        gv[1] /= gm[c];
+        gv[2] /= gm[c];
+        uint32_t xyz[3];
+        orc_inverse_cell_index(c, xyz);
+        for (int d = 0; d < 3; ++d) {
+            if ((int)xyz[d] < wall && gv[d] < 0.f) gv[d] = 0.f;
+            if ((int)xyz[d] >= N - wall && gv[d] > 0.f) gv[d] = 0.f;
+        }
+        const float pos[3] = {((float)xyz[0] + .5f) * dx, ((float)xyz[1] + .5f) * dx,
+                              ((float)xyz[2] + .5f) * dx};
+        for (int k = 0; k < n_col; ++k) {
+            const orc_grid_collider *cl = &cols[k];
+            float nrm[3], dist;
+            if (cl->shape == 0) {
+                sphere_hit(pos, cl->p[0], cl->p[1], cl->p[2], cl->radius, nrm, &dist);
+            } else {
+                nrm[0] = cl->n[0]; nrm[1] = cl->n[1]; nrm[2] = cl->n[2];
+                dist = nrm[0] * (pos[0] - cl->p[0]) + nrm[1] * (pos[1] - cl->p[1]) +
+                       nrm[2] * (pos[2] - cl->p[2]);
+            }
+            if (!(dist < 0.f)) continue;
+            const float dv[3] = {cl->v[0] - gv[0], cl->v[1] - gv[1], cl->v[2] - gv[2]};
+            const float dotnv = dotn(3, nrm, dv);
+            if (cl->mode == 0) {
+                gv[0] += dv[0]; gv[1] += dv[1]; gv[2] += dv[2];
+            } else if (cl->mode == 2 || dotnv > 0.f) {
+                const float fr = cl->friction;
+                const float frac = (float)((double)dotnv * (1.0 - (double)fr));
+                gv[0] += dv[0] * fr + nrm[0] * frac;
+                gv[1] += dv[1] * fr + nrm[1] * frac;
+                gv[2] += dv[2] * fr + nrm[2] * frac;
+            }
+            break;
+        }
+        gvs[c * 3 + 0] = gv[0];
+        gvs[c * 3 + 1] = gv[1];
+        gvs[c * 3 + 2] = gv[2];
+    }
+}
+
 /* grid_to_particle_kernel<T,BLOCK,CONTACT_TRANSFER> (:798-924) */
 ORC_API void orc_grid_to_particle(const orc_params *p, size_t n, float *pos, float *vel,
                                   float *Caff, const float *gm, const float *gv, float dt,

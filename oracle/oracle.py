@@ -40,6 +40,12 @@ class Params(C.Structure):
     ]
 
 
+class GridCollider(C.Structure):
+    """Runtime grid collider, same layout as mpm_grid_collider_t (include/mpm_hip.h)."""
+    _fields_ = [("shape", C.c_int32), ("mode", C.c_int32), ("p", C.c_float * 3), ("n", C.c_float * 3),
+                ("radius", C.c_float), ("v", C.c_float * 3), ("friction", C.c_float)]
+
+
 def build(force: bool = False) -> str:
     """Compile the oracle with gcc (a few seconds)."""
     src = os.path.join(_HERE, "mpm_oracle.c")
@@ -244,6 +250,13 @@ class OracleMpm:
         self.g_cnt = int(self.L.orc_gather_touched(C.c_uint32(self.n_blocks), _u(self.g_flags), _u(self.g_ids)))
         self.L.orc_update_grid(C.byref(self.p), C.c_int(mpm_bc), C.c_uint32(self.g_cnt * 64), _u(self.g_ids),
                                _f(self.g_m), _f(self.g_mv), _f(self.g_vstar))
+
+    def update_grid_table(self, colliders):
+        """UpdateGrid with a runtime collider table (list of GridCollider)."""
+        self.g_cnt = int(self.L.orc_gather_touched(C.c_uint32(self.n_blocks), _u(self.g_flags), _u(self.g_ids)))
+        arr = (GridCollider * max(len(colliders), 1))(*colliders)
+        self.L.orc_update_grid_table(C.byref(self.p), C.c_int(len(colliders)), arr, C.c_uint32(self.g_cnt * 64),
+                                     _u(self.g_ids), _f(self.g_m), _f(self.g_mv), _f(self.g_vstar))
 
     # -- GpuMpmSolver::GridToParticle (cuda_mpm_solver.cu:153-161)
     def grid_to_particle(self, dt: float):

@@ -24,13 +24,29 @@ def close(a, b, scale=None, rtol=RTOL, what=""):
     assert err <= rtol * scale + 1e-30, f"{what}: max err {err:.3e} > {rtol:.0e} * scale {scale:.3e}"
 
 
-def build_pair(domain_bits=6, layers=3, res=20, z0=0.5, side=0.3, seed=7, vel_amp=0.2, material=None):
-    """Same cloth stack on the oracle and on the engine."""
+# material fields: (engine name, oracle name)
+_MATERIAL_FIELDS = dict(youngs_modulus="youngs", poisson_ratio="poisson", density="density", gamma="gamma", K="K", V="V",
+                        c_F="cF", sdf_friction="sdf_friction", gravity="gravity", epsv="epsv")
+
+# the bagging demo's variants of the settings.h constants (settings.h:88-111: K = 4e5, V = 0.2, SDF_FRICTION = 1.0)
+BAGGING_MATERIAL = dict(K=4e5, V=0.2, sdf_friction=1.0)
+
+
+def build_pair(domain_bits=6, layers=3, res=20, z0=0.5, side=0.3, seed=7, vel_amp=0.2, material=None, sheets=None):
+    """Same cloth stack on the oracle and on the engine.  `material`: dict of mpm_material_t fields
+    applied to both sides."""
     from drake_amd import GpuMpm
 
-    sheets = scenes.cloth_stack(layers, res, domain_bits, z0=z0, side=side, seed=seed, vel_amp=vel_amp)
+    if sheets is None:
+        sheets = scenes.cloth_stack(layers, res, domain_bits, z0=z0, side=side, seed=seed, vel_amp=vel_amp)
     o = orc.OracleMpm(domain_bits)
-    g = GpuMpm(domain_bits, material)
+    gm = None
+    if material:
+        gm = GpuMpm.default_material()
+        for k, v in material.items():
+            setattr(gm, k, v)
+            setattr(o.p, _MATERIAL_FIELDS[k], v)
+    g = GpuMpm(domain_bits, gm)
     for pos, vel, idx in sheets:
         o.add_qr_cloth(pos, vel, idx)
         g.add_qr_cloth(pos, vel, idx)

@@ -260,3 +260,43 @@ def test_colored_scatter_matches_plain_scatter():
     assert np.max(np.abs(a.g_m - b.g_m)) <= 2e-6 * a.g_m.max()
     assert np.max(np.abs(a.pos - b.pos)) <= 1e-6
     assert np.max(np.abs(a.vel - b.vel)) <= 1e-5 * max(np.abs(a.vel).max(), 1e-2)
+
+
+@pytest.mark.parametrize("bc", [-1, 0, 1, 2, 3])
+def test_collider_table_presets_reproduce_the_scenes(bc):
+    """orc_update_grid_table fed with the preset table of scene bc (the engine's
+    mpm_grid_collider_preset: host code, no GPU) equals orc_update_grid(bc), the line-by-line
+    restatement of update_grid_kernel<bc> (cuda_mpm_kernels.cuh:632-796), bit for bit."""
+    from drake_amd import grid_collider_preset, scenes
+    z0 = {-1: 0.5, 0: 0.56, 1: 0.75, 2: 0.11, 3: 0.5}[bc]
+    side = {-1: 0.3, 0: 0.3, 1: 0.34, 2: 0.3, 3: 0.5}[bc]
+
+    def scattered():
+        o = orc.OracleMpm(6)
+        for pos, vel, idx in scenes.cloth_stack(3, 20, 6, z0=z0, side=side, seed=7, vel_amp=0.5):
+            vel[:, 2] -= 0.4
+            o.add_qr_cloth(pos, vel, idx)
+        o.finalize()
+        o.rebuild_mapping(False)
+        o.calc_fem_state_and_force(1e-3)
+        o.particle_to_grid(1e-3)
+        return o
+
+    a = scattered()
+    mv0 = a.g_mv.copy()
+    a.update_grid(bc)
+    want_mv, want_vs = a.g_mv.copy(), a.g_vstar.copy()
+    table = []
+    for c in grid_collider_preset(bc, a.p.sdf_friction):
+        t = orc.GridCollider()
+        C.memmove(C.byref(t), C.byref(c), C.sizeof(t))
+        table.append(t)
+    assert len(table) == {-1: 0, 0: 1, 1: 2, 2: 1, 3: 4}[bc]
+    a.g_mv[:] = mv0
+    a.g_vstar[:] = 0
+    a.update_grid_table(table)
+    assert np.array_equal(a.g_mv, want_mv) and np.array_equal(a.g_vstar, want_vs)
+    if bc >= 0:   # the scene does something
+        a.g_mv[:] = mv0
+        a.update_grid(-1)
+        assert not np.array_equal(a.g_mv, want_mv)
