@@ -73,6 +73,12 @@ class Material(C.Structure):
     ]
 
 
+class ContactStats(C.Structure):
+    _fields_ = [("iterations", C.c_int32), ("line_search_evals", C.c_int32), ("contacts", C.c_uint32),
+                ("nodes", C.c_uint32), ("residual", C.c_float), ("alpha", C.c_float), ("energy", C.c_float),
+                ("E0", C.c_float), ("norm_dir_sq", C.c_float), ("dofs", C.c_float)]
+
+
 class Stats(C.Structure):
     _fields_ = [
         ("substeps", C.c_uint64), ("rebuilds", C.c_uint64), ("home_blocks", C.c_uint32), ("active_blocks", C.c_uint32),
@@ -101,7 +107,7 @@ SYMBOLS = [
     "mpm_chain_init", "mpm_chain_substeps", "mpm_chain_destroy", "mpm_download_array", "mpm_upload_particle_state",
     "mpm_newton_bisect_f64", "mpm_newton_bisect_f32", "mpm_finalize_external_contact_forces",
     "mpm_spatial_force_shift", "mpm_external_forces_at_body_origin", "mpm_set_grid_colliders",
-    "mpm_grid_collider_preset",
+    "mpm_grid_collider_preset", "mpm_get_contact_stats",
 ]
 
 ROOTFIND_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_double, C.POINTER(C.c_double), C.POINTER(C.c_double))
@@ -172,6 +178,7 @@ def load_library(build: bool = True):
         "mpm_finalize_external_contact_forces": [vp, f, vp, vp],
         "mpm_spatial_force_shift": [sz, vp, vp, vp, vp],
         "mpm_set_grid_colliders": [vp, sz, vp],
+        "mpm_get_contact_stats": [vp, P(ContactStats)],
         "mpm_grid_collider_preset": [i, f, vp, sz, P(sz)],
         "mpm_external_forces_at_body_origin": [sz, vp, vp, vp, vp, vp],
     }
@@ -370,6 +377,11 @@ class GpuMpm:
                                              1 if dump else 0, 1 if exact_line_search else 0, max_newton_iterations,
                                              C.byref(it), C.byref(res)))
         return dict(iterations=int(it.value), residual=float(res.value))
+
+    def contact_stats(self) -> dict:
+        s = ContactStats()
+        self._ck(self.lib.mpm_get_contact_stats(self.h, C.byref(s)))
+        return {k: getattr(s, k) for k, _ in ContactStats._fields_}
 
     # ---- conveniences -------------------------------------------------------
     def substep(self, dt: float, mpm_bc: int = -1):

@@ -205,6 +205,7 @@ static int update_contact(mpm_engine* e, int frame, int substep, float dt, float
 
     std::vector<float> s_res, s_energy;
     std::vector<int> s_ls;
+    float s_alpha_last = 0.f, s_E0_last = 0.f;
     ContactState st{};
     int iters = 0;
     float residual = 1e10f;
@@ -247,6 +248,7 @@ static int update_contact(mpm_engine* e, int frame, int substep, float dt, float
             std::tuple<float, float, float> f_lo, f_hi, f_root;
             int rc;
             if ((rc = probe(0.f, &f_lo)) || (rc = probe(1.f, &f_hi))) return rc;
+            s_E0_last = std::get<0>(f_lo);   // E(alpha = 0)
             float x_lo = 0.f;
             if (std::get<1>(f_lo) < 0.f && std::get<1>(f_hi) < 0.f) {   // :395-398
                 x_lo = 1.f;
@@ -265,6 +267,7 @@ static int update_contact(mpm_engine* e, int frame, int substep, float dt, float
             }
             const float alpha = rf.root;
             const int ls = rf.evals;
+            s_alpha_last = alpha;
             HIP_TRY(hipMemcpyAsync(&b.st->alpha, &alpha, 4, hipMemcpyHostToDevice, s));
             hipLaunchKernelGGL(k_ct_apply, dim3(CT_ROWS), dim3(CT_WG), 0, s, p, c);
             residual = std::sqrt(st.norm_dir_sq) / st.dofs;
@@ -280,6 +283,28 @@ static int update_contact(mpm_engine* e, int frame, int substep, float dt, float
     HIP_TRY(hipGetLastError());
     if (iters_out) *iters_out = iters;
     if (residual_out) *residual_out = residual;
+    {
+        // what the reference prints / dumps per substep (cuda_mpm_solver.cu:577-612), kept for mpm_get_contact_stats
+        mpm_contact_stats_t& cs = e->last_contact;
+        cs.iterations = iters;
+        cs.contacts = (uint32_t)n;
+        cs.nodes = (uint32_t)st.n_nodes;
+        cs.residual = residual;
+        cs.norm_dir_sq = st.norm_dir_sq;
+        cs.dofs = st.dofs;
+        if (exact) {
+            cs.line_search_evals = 0;
+            for (int v : s_ls) cs.line_search_evals += v;
+            cs.alpha = s_alpha_last;
+            cs.energy = s_energy.empty() ? 0.f : s_energy.back();
+            cs.E0 = s_E0_last;
+        } else {
+            cs.line_search_evals = st.ls_total;
+            cs.alpha = st.alpha;
+            cs.energy = st.energy;
+            cs.E0 = st.E0;
+        }
+    }
     if (dump) {
         // per-substep statistics, same fields as cuda_mpm_solver.cu:587-612
         const std::string fn = e->dump_dir + "/jacobi_iter_" + std::to_string(max_iters) + "_frame_" +

@@ -976,11 +976,19 @@ int mpm_download_contact_pairs(mpm_handle_t e, uint32_t* particle, uint32_t* bod
     return download_contacts(e, particle, body, dist, normal, pos, rigid_v, p_WB);
 }
 
+int mpm_get_contact_stats(mpm_handle_t e, mpm_contact_stats_t* out) {
+    READY(e);
+    REQUIRE(out, "null stats");
+    *out = e->last_contact;
+    return 0;
+}
+
 int mpm_update_contact(mpm_handle_t e, int frame, int substep, float dt, float mu, float stiffness, float damping,
                        int dump, int exact, int max_iters, int* iters_out, float* residual_out) {
     READY(e);
     if (iters_out) *iters_out = 0;
     if (residual_out) *residual_out = 0.f;
+    e->last_contact = mpm_contact_stats_t{};
     if (e->cb.n == 0) return 0;  // cuda_mpm_solver.cu:216-217
     REQUIRE(e->grid_state == 2, "UpdateContact before UpdateGrid");
     return update_contact(e, frame, substep, dt, mu, stiffness, damping, dump, exact, max_iters, iters_out,

@@ -88,6 +88,7 @@ struct mpm_engine {
     unsigned g_np = 0, g_nf = 0, g_nv = 0, g_tile = 0, g_grid = 0;
     // contacts / rigid bodies
     ContactBuffers cb{};
+    mpm_contact_stats_t last_contact{};   // of the last mpm_update_contact
     std::string dump_dir = ".";
     // scratch for downloads
     void* d_stage = nullptr;

@@ -290,6 +290,25 @@ MPM_API int mpm_update_contact(mpm_handle_t h, int frame, int substep, float dt,
                                int *iterations_out, float *residual_out);
 MPM_API int mpm_set_dump_dir(mpm_handle_t h, const char *dir);
 
+/* The numbers the reference prints and dumps per UpdateContact call (cuda_mpm_solver.cu:577-612:
+ * iteration count, residual, line-search count, energy), plus the step and energies of the LAST
+ * Newton iteration so that a single iteration (max_newton_iterations = 1) can be compared:
+ * alpha = accepted step, energy = E(alpha) as the line search evaluated it, E0 = E(0),
+ * norm_dir_sq / dofs = sum |Dir|^2 before relaxation and the DoF count (cuda_mpm_solver.cu:567-570). */
+typedef struct {
+    int32_t iterations;
+    int32_t line_search_evals;   /* summed over the iterations */
+    uint32_t contacts;
+    uint32_t nodes;              /* grid nodes reached by a contact stencil */
+    float residual;
+    float alpha;
+    float energy;
+    float E0;
+    float norm_dir_sq;
+    float dofs;
+} mpm_contact_stats_t;
+MPM_API int mpm_get_contact_stats(mpm_handle_t h, mpm_contact_stats_t *out);
+
 /* ---- conveniences on top of the reference interface ---------------------- */
 
 /* The five solver calls of one contact-free substep (cuda_mpm_test.cc:66-72,

@@ -1306,6 +1306,11 @@ static void ls_thunk(void *ctx, float alpha, float *out) {
 }
 
 
+/* diagnostics of the last Newton iteration of the last orc_update_contact call (single-threaded
+ * test use): accepted alpha, E(0), E(alpha), sum |Dir|^2, DoFs, line-search evaluations */
+static float g_last_diag[6];
+ORC_API void orc_last_contact_diag(float *out6) { memcpy(out6, g_last_diag, sizeof(g_last_diag)); }
+
 /* GpuMpmSolver::UpdateContact (cuda_mpm_solver.cu:214-621), Jacobi branch.
  * Grid arrays are dense, indexed by cell key.  On exit gv holds the post
  * contact grid velocities, cvel/cvel0 the contact velocities, tau/frc the
@@ -1350,6 +1355,7 @@ ORC_API int orc_update_contact(const orc_params *p, size_t nk, const float *cpos
             const float x_tol = f_tol * relax;
             float x_lo = 0.f, x_hi = 1.f, root = 1.f;
             ls_eval f_lo = ls_full(&ctx, 0.f), f_hi = ls_full(&ctx, 1.f);
+            E0 = f_lo.E;
             if (f_lo.dE < 0.f && f_hi.dE < 0.f) {                /* :395-398 */
                 x_lo = 1.f;
                 f_lo = f_hi;
@@ -1381,6 +1387,8 @@ ORC_API int orc_update_contact(const orc_params *p, size_t nk, const float *cpos
         }
         ls_total += ls_cnt;
         last_energy = E1;
+        g_last_diag[0] = alpha; g_last_diag[1] = E0; g_last_diag[2] = E1; g_last_diag[3] = nd;
+        g_last_diag[4] = (float)dofs; g_last_diag[5] = (float)ls_cnt;
         orc_contact_apply_alpha(tc, ids, gm, gv, gD, alpha);     /* :532-539 */
         memcpy(pos_tmp, cpos, n3 * sizeof(float));
         orc_grid_to_particle(p, nk, pos_tmp, cvel, NULL, gm, gv, dt, 1); /* :557-562 */

@@ -305,8 +305,11 @@ class OracleMpm:
             _f(self.g_G), _f(self.g_D), _f(self.g_alpha), _f(self.g_E0), _f(self.g_E1), _f(self.F_tau), _f(self.F_f),
             _cf(dt), _cf(friction_mu), _cf(stiffness), _cf(damping), C.c_int(1 if exact_line_search else 0),
             C.c_int(max_iters), C.byref(res), C.byref(lsa), C.byref(en))
+        diag = np.zeros(6, np.float32)
+        self.L.orc_last_contact_diag(_f(diag))
         return dict(iterations=int(it), residual=float(res.value), line_search_avg=float(lsa.value),
-                    energy=float(en.value))
+                    energy=float(en.value), alpha=float(diag[0]), E0=float(diag[1]), E1=float(diag[2]),
+                    norm_dir_sq=float(diag[3]), dofs=float(diag[4]), ls_last=int(diag[5]))
 
     # -- GpuMpmState::DumpCpuState (cuda_mpm_model.cu:244-265)
     def dump_cpu_state(self):

@@ -29,8 +29,20 @@ def pytest_terminal_summary(terminalreporter):
     if not MARGINS:
         return
     worst = {}
-    for ratio, what in MARGINS:
-        worst[what] = max(worst.get(what, 0.0), ratio)
-    terminalreporter.write_line("parity margins (max error / allowed):")
-    for what, ratio in sorted(worst.items(), key=lambda kv: -kv[1])[:12]:
-        terminalreporter.write_line(f"  {ratio:6.3f}  {what}")
+    for ratio, what, rtol, rel_scale, rel_plain in MARGINS:
+        w = worst.get(what)
+        if w is None:
+            worst[what] = [ratio, rtol, rel_scale, rel_plain]
+        else:
+            w[0] = max(w[0], ratio); w[1] = max(w[1], rtol); w[2] = max(w[2], rel_scale); w[3] = max(w[3], rel_plain)
+    lines = ["parity margins, worst case per quantity: error/allowed | tolerance | error rel. to the test's scale | "
+             "error rel. to plain max|ref|"]
+    for what, (ratio, rtol, rs, rp) in sorted(worst.items(), key=lambda kv: -kv[1][0]):
+        lines.append(f"  {ratio:6.3f}  {rtol:8.1e}  {rs:9.2e}  {rp:9.2e}  {what}")
+    for ln in lines[:16]:
+        terminalreporter.write_line(ln)
+    # the full table goes to a file next to the GPU logs when that directory exists
+    out = os.path.join(ROOT, "gpurun_out")
+    if os.path.isdir(out):
+        with open(os.path.join(out, "parity_margins.txt"), "w") as f:
+            f.write("\n".join(lines) + "\n")

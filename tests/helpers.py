@@ -19,7 +19,9 @@ def close(a, b, scale=None, rtol=RTOL, what=""):
     if scale is None:
         scale = float(np.max(np.abs(b)))
     err = float(np.max(np.abs(a - b)))
-    MARGINS.append((err / (rtol * scale + 1e-30), what))
+    plain = float(np.max(np.abs(b)))
+    # (error / allowed, what, tolerance, error relative to the test's scale, error relative to plain max|ref|)
+    MARGINS.append((err / (rtol * scale + 1e-30), what, rtol, err / (scale + 1e-300), err / (plain + 1e-300)))
     assert np.all(np.isfinite(a)), what
     assert err <= rtol * scale + 1e-30, f"{what}: max err {err:.3e} > {rtol:.0e} * scale {scale:.3e}"
 

@@ -38,16 +38,21 @@ def _diagnose(g, o):
     return out
 
 
+# (stiffness, damping, dt, friction): the first test's historical values, and SURVEY.md 8(d) config 3 =
+# the bagging demo's parameters (examples/multibody/deformable/mpm_bagging.cc:9,15-17)
+CONTACT_PARAMS = {"soft": (1e5, 1e-3, 1e-3), "config3": (1e6, 1e-5, 2e-4)}
+
+
 @pytest.mark.parametrize("exact", [False, True])
-@pytest.mark.parametrize("mu", [0.0, 0.5])
-def test_update_contact_matches_oracle(exact, mu):
+@pytest.mark.parametrize("params,mu", [("soft", 0.0), ("soft", 0.5), ("config3", 1.0)])
+def test_update_contact_matches_oracle(exact, params, mu):
     from drake_amd import ARR as A
     from oracle import oracle as orc
+    stiffness, damping, DT = CONTACT_PARAMS[params]
     # two sheets straddling the floor, moving down and sideways
     o, g = build_pair(layers=2, res=20, z0=Z_FLOOR - 0.004, vel_amp=0.3)
     o.vel[:, 2] -= 0.5
     o.vel[:, 0] += 0.3
-    stiffness, damping = 1e5, 1e-3
     for step in range(3):
         g.upload_particle_state(o.pos, o.vel, o.C, None, o.F)
         o.reallocate_external_bodies(1)
@@ -65,7 +70,7 @@ def test_update_contact_matches_oracle(exact, mu):
         g.copy_contact_pairs(*cp)
         ro = o.update_contact(DT, mu, stiffness, damping, exact_line_search=exact)
         rg = g.update_contact(DT, mu, stiffness, damping, exact_line_search=exact)
-        sc = natural_scales(o)
+        sc = natural_scales(o, DT)
         # same Newton trajectory: the iteration count differs when rounding moves an iterate across the
         # 1e-4 stopping tolerance or (exact search) across the 1e-8 slope tolerance evaluated in float
         assert abs(rg["iterations"] - ro["iterations"]) <= max(3, ro["iterations"] // 4), (rg, ro, step, _diagnose(g, o))
@@ -107,3 +112,56 @@ def test_no_contacts_is_a_noop():
     assert np.array_equal(before, g.download(A.GRID_MOMENTUM))
     tau, f = g.external_body_force_to_host()
     assert not tau.any() and not f.any()
+
+
+@pytest.mark.parametrize("exact", [False, True])
+@pytest.mark.parametrize("params,mu", [("soft", 0.5), ("config3", 1.0)])
+def test_single_newton_iteration_matches_oracle(exact, params, mu):
+    """max_newton_iterations = 1 ("one full Newton iteration's Dir / norm_dir"): the
+    solver tolerance plays no role, so the direction (cuda_mpm_kernels.cuh:1217-1274), its norm, the
+    line-search energies and the chosen step (cuda_mpm_solver.cu:383-528) are compared at rounding level."""
+    from drake_amd import ARR as A
+    from oracle import oracle as orc
+    stiffness, damping, DT = CONTACT_PARAMS[params]
+    o, g = build_pair(layers=2, res=24, z0=Z_FLOOR - 0.004, vel_amp=0.3)
+    o.vel[:, 2] -= 0.5
+    o.vel[:, 0] += 0.3
+    g.upload_particle_state(o.pos, o.vel, o.C, None, o.F)
+    for s in (o, g):
+        s.reallocate_external_bodies(1)
+        s.rebuild_mapping(False)
+        s.calc_fem_state_and_force(DT)
+        s.particle_to_grid(DT)
+        s.update_grid(-1)
+    cp = floor_contacts(g.sync_particle_state_to_cpu())
+    assert cp[0].size > 100
+    o.copy_contact_pairs(orc.ContactPairs(*cp))
+    g.copy_contact_pairs(*cp)
+    ro = o.update_contact(DT, mu, stiffness, damping, exact_line_search=exact, max_iters=1)
+    rg = g.update_contact(DT, mu, stiffness, damping, exact_line_search=exact, max_newton_iterations=1)
+    cs = g.contact_stats()
+    assert ro["iterations"] == rg["iterations"] == cs["iterations"] == 1
+    assert cs["contacts"] == cp[0].size
+    # Newton direction (relaxed by 0.3) on every node, its norm and the DoF count
+    gdir = g.download(A.GRID_DIR)
+    close(gdir, o.g_D, what="1-iteration Dir")
+    assert cs["dofs"] == ro["dofs"] > 0
+    assert np.count_nonzero(np.abs(o.g_D).max(1)) == int(ro["dofs"])
+    close([cs["norm_dir_sq"]], [ro["norm_dir_sq"]], what="1-iteration |Dir|^2")
+    close([rg["residual"]], [ro["residual"]], what="1-iteration residual")
+    # line search: energies and the step.  The energies are sums of ~1e3 float terms that the oracle adds
+    # in float in contact order (the reference: float atomics) and the engine in double: 1e-5 relative.
+    close([cs["E0"]], [ro["E0"]], what="1-iteration E(0)")
+    close([cs["energy"]], [ro["E1"]], scale=abs(ro["E0"]), what="1-iteration E(alpha)")
+    if exact:
+        close([cs["alpha"]], [ro["alpha"]], scale=1.0, rtol=1e-4, what="1-iteration alpha (exact search)")
+    else:
+        assert cs["alpha"] == ro["alpha"]
+        assert cs["line_search_evals"] == ro["ls_last"]
+    sc = natural_scales(o, DT)
+    rt = 1e-4 if exact else 1e-5     # (the exact search's alpha itself is converged to 1e-8 * 0.3 in float)
+    wgt = (o.g_m / o.g_m.max())[:, None]
+    close(g.download(A.GRID_MOMENTUM) * wgt, o.g_mv * wgt, scale=sc["vel"], rtol=rt, what="1-iteration grid v")
+    close(g.download(A.CONTACT_VEL), o.c_vel, scale=sc["vel"], rtol=rt, what="1-iteration contact vel")
+    tau_g, f_g = g.external_body_force_to_host()
+    close(f_g, o.F_f, scale=float(np.abs(o.F_f).max()), rtol=10 * rt, what="1-iteration body impulse")
