@@ -56,30 +56,71 @@ def measured_traffic(kernel, config):
         return None
 
 
+def host_description():
+    """CPU model and the cores this process may use (north_star: "core count stated")."""
+    model, sockets, cores_per_socket, threads_per_core = "unknown", None, None, None
+    try:
+        import subprocess
+        for ln in subprocess.run(["lscpu"], capture_output=True, text=True, timeout=10).stdout.splitlines():
+            k, _, v = ln.partition(":")
+            k, v = k.strip(), v.strip()
+            if k == "Model name":
+                model = v
+            elif k == "Socket(s)":
+                sockets = int(v)
+            elif k == "Core(s) per socket":
+                cores_per_socket = int(v)
+            elif k == "Thread(s) per core":
+                threads_per_core = int(v)
+    except Exception:  # noqa: BLE001
+        pass
+    try:
+        allowed = len(os.sched_getaffinity(0))
+    except AttributeError:
+        allowed = os.cpu_count() or 1
+    # a container may also be limited by a CPU quota rather than by affinity
+    quota = None
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            q, per = f.read().split()
+            if q != "max":
+                quota = float(q) / float(per)
+    except Exception:  # noqa: BLE001
+        pass
+    tpc = threads_per_core or 1
+    return dict(model=model, logical_cpus_of_host=os.cpu_count(), logical_cpus_allowed=allowed,
+                physical_cores_allowed=max(1, allowed // tpc), threads_per_core=tpc,
+                sockets=sockets, cores_per_socket=cores_per_socket, cgroup_cpu_quota=quota)
+
+
 def cpu_baseline(domain_bits, layers, res, dt, budget_s=20.0):
-    """The oracle (a port, OpenMP) timed on the host cores on a bounded sample: the same
-    cloth-stack recipe at a size that keeps the run near `budget_s`, scaled per particle."""
+    """The oracle (a port of the reference's kernels to plain C + OpenMP; the reference has no CPU
+    path of its own) timed on the host cores on the FULL workload (same scene, grid and dt as the
+    GPU leg), for a bounded number of substeps.  Reported: the rate at the thread count that is
+    fastest on this box (`cores` = that thread count), the 1-thread rate, and the host's CPU."""
     from drake_amd import scenes
     from oracle import oracle as orc
+    host = host_description()
     o = orc.OracleMpm(domain_bits)
     o.fast_scatter = True  # atomics-free multi-core scatter (same arithmetic, see oracle/mpm_oracle.c)
-    # sample: fewer layers of the same sheets (same particle density per cell column)
-    sl = max(2, layers // 4)
-    for pos, vel, idx in scenes.cloth_stack(sl, res, domain_bits):
+    for pos, vel, idx in scenes.cloth_stack(layers, res, domain_bits):
         o.add_qr_cloth(pos, vel, idx)
     o.finalize()
-    o.substep(dt, -1)  # warm-up
-    # the port does not scale to every core of a big host (short loops, dense grid sweeps): use the
-    # thread count that is fastest on this box and report it
+    t_begin = time.perf_counter()
+    # thread counts: the cores this process is allowed to use, and fractions / multiples of that
+    # (the port has short loops and dense-grid sweeps: it does not scale to every core of a big host)
+    allowed = host["logical_cpus_allowed"]
+    phys = host["physical_cores_allowed"]
+    cand = sorted({max(1, min(orc.max_threads(), c)) for c in (phys // 2, phys, allowed, 8, 16, 32)})
     best, threads = None, 1
-    cand = sorted({min(orc.max_threads(), c) for c in (8, 16, 32, 64, 128, 256)})
+    orc.set_threads(cand[-1])
+    o.substep(dt, -1)  # warm-up (page in the dense grid arrays)
     for c in cand:
         orc.set_threads(c)
-        o.substep(dt, -1)
         t0 = time.perf_counter()
         o.substep(dt, -1)
         o.substep(dt, -1)
-        el = time.perf_counter() - t0
+        el = (time.perf_counter() - t0) / 2
         if best is None or el < best:
             best, threads = el, c
     orc.set_threads(threads)
@@ -88,14 +129,52 @@ def cpu_baseline(domain_bits, layers, res, dt, budget_s=20.0):
         o.substep(dt, -1)
         n += 1
         el = time.perf_counter() - t0
-        if el > budget_s or n >= 50:
+        if el > budget_s * 0.6 or n >= 50:
             break
-    per_particle_step = el / n / o.n_particles
-    nv, nf, npart = scenes.particle_count(layers, res)
-    sps = 1.0 / (per_particle_step * npart)
+    sps = n / el
+    # the scalar figure: a few substeps on one thread, plain (non-coloured) scatter
+    orc.set_threads(1)
+    o.fast_scatter = False
+    n1, t0 = 0, time.perf_counter()
+    while True:
+        o.substep(dt, -1)
+        n1 += 1
+        el1 = time.perf_counter() - t0
+        if el1 > budget_s * 0.25 or n1 >= 5:
+            break
     return dict(value=sps, unit="substeps/s", cores=threads, kind="port",
-                sample=f"{n} substeps of a {sl}-layer slice ({o.n_particles} particles, same sheets and grid), "
-                       f"scaled per particle to {npart}; OpenMP oracle, {threads} threads")
+                sample=f"{n} substeps of the full workload ({o.n_particles} particles, {1 << domain_bits}^3 grid, "
+                       f"dt={dt}); OpenMP oracle with {threads} threads (fastest of {cand}); "
+                       f"1 thread: {n1} substeps",
+                one_thread_value=n1 / el1, threads_tried=cand, host=host,
+                wall_s=time.perf_counter() - t_begin)
+
+
+def launch_ranks(n, argv):
+    """`python bench.py --gpus N` without torchrun: start N rank processes of this same script
+    (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in their environment, rendezvous on 127.0.0.1) and
+    exit with the worst of their codes.  The parent never initialises the GPU and never exec()s."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port))
+        # only rank 0 prints the JSON line; the other ranks' stdout goes to our stderr
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__), *argv], env=env,
+                                      stdout=None if r == 0 else sys.stderr))
+    rc = 0
+    for p in procs:
+        try:
+            code = p.wait(timeout=3000)
+        except subprocess.TimeoutExpired:
+            p.kill()
+            code = 124
+        rc = max(rc, abs(code))
+    return rc
 
 
 def main():
@@ -110,7 +189,13 @@ def main():
                     help="also call RebuildMapping(sort=true) every N substeps (SURVEY 8d config 2 variants; "
                          "0 = never, the reference's Drake behaviour and the reported metric)")
     ap.add_argument("--cpu-budget", type=float, default=20.0)
+    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
+                    help="weak: every rank owns one copy of the workload; strong: the ranks share ONE copy")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # plain `python bench.py --gpus N`: become the launcher.  Nothing has touched the GPU yet.
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
 
     import torch
     import torch.distributed as dist
@@ -118,6 +203,7 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    assert world == max(args.gpus, 1) or "WORLD_SIZE" in os.environ, (world, args.gpus)
     assert torch.cuda.is_available(), "bench.py needs a GPU (the engine has no CPU fallback)"
     # Multi-GPU transports, tried in this order (the JSON line names the one that was measured):
     #   1. the library's own chain: RCCL send/recv on the engine's stream (mpm_chain_*),
@@ -129,6 +215,9 @@ def main():
     ndev = torch.cuda.device_count()
     if world > 1 and (backend == "gloo" or os.environ.get("MPM_BENCH_SHARE_GPU")):
         local_rank = local_rank % ndev   # rehearsal on a box with fewer GPUs than ranks
+    elif local_rank >= ndev:
+        raise SystemExit(f"bench.py: rank {rank} needs GPU {local_rank} but only {ndev} are visible "
+                         "(set MPM_BENCH_SHARE_GPU=1 to rehearse several ranks on one GPU)")
     torch.cuda.set_device(local_rank)
     if world > 1:
         dist.init_process_group("gloo")

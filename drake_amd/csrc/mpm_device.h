@@ -19,6 +19,7 @@ constexpr int TILE_N = TILE_W * TILE_W * TILE_W;     // 1000 nodes (16 KB of flo
 constexpr unsigned ERR_DRIFT = 1u;      // particle outside the hard free zone
 constexpr unsigned ERR_CAPACITY = 2u;   // home/active table overflow
 constexpr unsigned ERR_DOMAIN = 4u;     // particle base cell outside the grid
+constexpr unsigned ERR_RANGE = 8u;      // a P2G node sum left the range of the fixed-point tile (or was NaN)
 
 // One of the two ping-pong particle sets.  Every particle is four 16-byte records in four
 // planes (one coalesced dwordx4 access per plane and wave), slots [0,Nf) are face particles,

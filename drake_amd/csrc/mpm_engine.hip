@@ -401,6 +401,10 @@ int mpm_sync(mpm_handle_t e) {
                     "velocities differ by cells per substep, the state is diverging -- reduce dt");
     if (c.error & ERR_DOMAIN)
         return fail(MPM_ERR_DOMAIN, "a particle left the grid; results are invalid");
+    if (c.error & ERR_RANGE)
+        return fail(MPM_ERR_RANGE,
+                    "a node sum of ParticleToGrid was not finite or exceeded the fixed-point range "
+                    "(|node momentum| >= total mass * 2^15 length units per time unit): the state has diverged");
     return 0;
 }
 

@@ -157,16 +157,22 @@ MPM_DEV float quad_perm(float v) {
 // LDS accumulation is done in 64-bit fixed point: on gfx950 a wave-wide ds_add_f32
 // costs ~190 LDS cycles per instruction (measured, scratch/lds_atomic_bench.hip)
 // against ~10 for ds_add_u64, and integer sums are exact and order independent.
-// float -> Q-format int64 with single-precision instructions only: v * scale is exact (power of
-// two), q = hi * 2^32 + lo with hi = floor(q / 2^32) (signed) and lo in [0, 2^32).
-MPM_DEV void lds_add_fixed(long long* a, float v, float scale) {
+// float -> Q-format int64 with single-precision instructions only: q = v * scale is exact (power
+// of two); |q| = hi * 2^32 + lo with hi = floor(|q| / 2^32) and lo = |q| - hi * 2^32 in [0, 2^32),
+// both exact because they are parts of the same 24-bit mantissa (doing this on the SIGNED value
+// would form 2^32 - |q| for small negative q, which does not fit a float: +-128 quanta of noise).
+// Below 2^24 quanta q has fractional bits: they are rounded to nearest even, so the conversion is
+// unbiased whatever the particle count.  Returns false when |q| does not fit 62 bits.
+MPM_DEV bool lds_add_fixed(long long* a, float v, float scale) {
     const float q = v * scale;
-    const float h = floorf(q * 0x1p-32f);
-    const int hi = (int)h;
-    const unsigned lo = (unsigned)fmaf(-h, 0x1p32f, q);
-    const unsigned long long fx = ((unsigned long long)(unsigned)hi << 32) | lo;
+    const float aq = fabsf(q);
+    const float h = floorf(aq * 0x1p-32f);
+    const unsigned lo = (unsigned)rintf(fmaf(-h, 0x1p32f, aq));
+    const unsigned long long mag = ((unsigned long long)(unsigned)h << 32) | lo;
+    const unsigned long long fx = q < 0.f ? 0ull - mag : mag;
     __hip_atomic_fetch_add(reinterpret_cast<unsigned long long*>(a), fx, __ATOMIC_RELAXED,
                            __HIP_MEMORY_SCOPE_WORKGROUP);
+    return aq < 0x1p62f;   // (false for NaN too)
 }
 
 // coefficients (c0 + c1 f + c2 f^2) of the quadratic B-spline weight of stencil offset a
@@ -284,7 +290,7 @@ __global__ __launch_bounds__(512, 4) void k_p2g(DP p, float dt) {  // <= 128 VGP
         const int4 rg = p.home_range[h];
         const int nfb = rg.y - rg.x;
         unsigned mymask = 0;
-        bool hard = false;
+        bool hard = false, in_range = true;
         // Every wave streams through its own groups of <= 64 particles; no workgroup barrier inside.
         // Groups are runs of whole cells (faces and vertices of the same cells together), laid out
         // at the last rebuild: a group usually spans two base cells.
@@ -466,7 +472,7 @@ __global__ __launch_bounds__(512, 4) void k_p2g(DP p, float dt) {  // <= 128 VGP
                     val = tt == 1 ? v[1] : val;
                     val = tt == 2 ? v[2] : val;
                     val = tt == 3 ? v[3] : val;
-                    if (delta[t] >= 0 && !(diag_flags(p) & 16)) lds_add_fixed(tb + delta[t], val, fscale);
+                    if (delta[t] >= 0 && !(diag_flags(p) & 16)) in_range &= lds_add_fixed(tb + delta[t], val, fscale);
                 }
                 if (prof) pc[3] += __builtin_readcyclecounter() - tq[2];
             }
@@ -485,6 +491,7 @@ __global__ __launch_bounds__(512, 4) void k_p2g(DP p, float dt) {  // <= 128 VGP
             for (int q = 0; q < 8; ++q) atomicAdd(&p.dbgbuf[q], pc[q]);
         if (mymask && lane == 0) atomicOr(&s_mask, mymask);
         if (__ballot(hard) && lane == 0) atomicOr(&ctl->error, ERR_DRIFT);
+        if (__ballot(!in_range) && lane == 0) atomicOr(&ctl->error, ERR_RANGE);
         __syncthreads();
         float4* out = p.slab + (size_t)item * TILE_N;
         for (int n = tid; n < TILE_N; n += 512) {

@@ -47,7 +47,8 @@ typedef enum {
     MPM_ERR_DRIFT = -3,       /* a face particle was re-centred out of its block's tile (diverging state) */
     MPM_ERR_CAPACITY = -4,    /* internal table overflow                       */
     MPM_ERR_NO_DEVICE = -5,   /* no usable GPU: there is no CPU fallback       */
-    MPM_ERR_DOMAIN = -6       /* a particle left the grid (the reference: undefined behaviour) */
+    MPM_ERR_DOMAIN = -6,      /* a particle left the grid (the reference: undefined behaviour) */
+    MPM_ERR_RANGE = -7        /* a ParticleToGrid node sum was not finite / out of the accumulators' range */
 } mpm_status;
 
 /* Runtime form of the compile-time constants in settings.h:36-127. */

@@ -68,3 +68,11 @@ def natural_scales(o, dt=1e-3):
     stiff = dt * o.p.youngs / o.p.density * dxinv
     vmax = max(float(np.max(np.abs(o.vel))), 9.8 * dt, 0.1 * stiff)
     return dict(pos=1.0, vel=vmax, C=4.0 * dxinv * vmax, vol=float(np.max(o.vol)))
+
+
+def solve_tolerance(dofs, k_tol=1e-4):
+    """Velocity tolerance (m/s, absolute) for comparing two CONVERGED contact solves.  UpdateContact
+    stops when sqrt(sum_nodes |Dir|^2) / DoFs <= kTol = 1e-4 (cuda_mpm_solver.cu:236, 567-570), i.e. at
+    an RMS remaining Newton step of kTol * sqrt(DoFs) per node: two solvers that stop one iteration
+    apart differ by about that much.  (Rounding-level agreement is tested on a single iteration.)"""
+    return k_tol * float(np.sqrt(max(float(dofs), 1.0)))

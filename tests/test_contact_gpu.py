@@ -2,7 +2,7 @@
 import numpy as np
 import pytest
 
-from tests.helpers import build_pair, close, natural_scales
+from tests.helpers import build_pair, close, natural_scales, solve_tolerance
 
 pytestmark = pytest.mark.gpu
 DT = 1e-3
@@ -76,23 +76,25 @@ def test_update_contact_matches_oracle(exact, params, mu):
         assert abs(rg["iterations"] - ro["iterations"]) <= max(3, ro["iterations"] // 4), (rg, ro, step, _diagnose(g, o))
         assert rg["residual"] <= 1.5e-4
         close(g.download(A.CONTACT_VEL0), o.c_vel0, scale=sc["vel"], what="contact vel0")
-        # the solve stops at residual 1e-4: velocities agree to the solver tolerance, not to rounding
-        close(g.download(A.CONTACT_VEL), o.c_vel, scale=sc["vel"], rtol=2e-3, what="contact vel")
+        # converged solves agree to the solver's stopping tolerance (rounding-level agreement: the
+        # single-iteration test below)
+        tol = solve_tolerance(g.contact_stats()["dofs"])
+        close(g.download(A.CONTACT_VEL), o.c_vel, scale=1.0, rtol=tol, what="contact vel")
         wgt = (o.g_m / o.g_m.max())[:, None]
-        close(g.download(A.GRID_MOMENTUM) * wgt, o.g_mv * wgt, scale=sc["vel"], rtol=2e-3, what="grid v after contact")
+        close(g.download(A.GRID_MOMENTUM) * wgt, o.g_mv * wgt, scale=1.0, rtol=tol, what="grid v after contact")
         # grid_Dir accessor: the last relaxed Newton direction, non-zero only on nodes that see contacts
         gdir = g.download(A.GRID_DIR)
         assert gdir.shape == (g.n_cells, 3) and np.isfinite(gdir).all() and np.abs(gdir).max() > 0
         assert np.count_nonzero(np.abs(gdir).max(1)) < 0.05 * g.n_cells
         tau_g, f_g = g.external_body_force_to_host()
         fscale = float(np.abs(o.F_f).max())
-        close(f_g, o.F_f, scale=fscale, rtol=5e-3, what="body impulse")
-        close(tau_g, o.F_tau, scale=max(float(np.abs(o.F_tau).max()), fscale), rtol=5e-3, what="body angular impulse")
+        close(f_g, o.F_f, scale=fscale, rtol=1e-3, what="body impulse")
+        close(tau_g, o.F_tau, scale=max(float(np.abs(o.F_tau).max()), fscale), rtol=1e-3, what="body angular impulse")
         # the floor pushes up
         assert f_g[0, 2] < 0  # impulse ON the body is downward
         o.grid_to_particle(DT)
         g.grid_to_particle(DT)
-        close(g.download(A.VELOCITIES), o.vel, scale=sc["vel"], rtol=2e-3, what="vel after contact step")
+        close(g.download(A.VELOCITIES), o.vel, scale=1.0, rtol=tol, what="vel after contact step")
     g.gpu_sync()
 
 
