@@ -88,9 +88,12 @@ def host_description():
     except Exception:  # noqa: BLE001
         pass
     tpc = threads_per_core or 1
+    phys = max(1, allowed // tpc)
+    # what this process can actually run on: the affinity mask capped by the container's CPU quota
+    avail = phys if quota is None else max(1, min(phys, int(round(quota))))
     return dict(model=model, logical_cpus_of_host=os.cpu_count(), logical_cpus_allowed=allowed,
-                physical_cores_allowed=max(1, allowed // tpc), threads_per_core=tpc,
-                sockets=sockets, cores_per_socket=cores_per_socket, cgroup_cpu_quota=quota)
+                physical_cores_of_host=phys, threads_per_core=tpc, sockets=sockets, cores_per_socket=cores_per_socket,
+                cgroup_cpu_quota=quota, cores_available=avail)
 
 
 def cpu_baseline(domain_bits, layers, res, dt, budget_s=20.0):
@@ -109,9 +112,8 @@ def cpu_baseline(domain_bits, layers, res, dt, budget_s=20.0):
     t_begin = time.perf_counter()
     # thread counts: the cores this process is allowed to use, and fractions / multiples of that
     # (the port has short loops and dense-grid sweeps: it does not scale to every core of a big host)
-    allowed = host["logical_cpus_allowed"]
-    phys = host["physical_cores_allowed"]
-    cand = sorted({max(1, min(orc.max_threads(), c)) for c in (phys // 2, phys, allowed, 8, 16, 32)})
+    avail = host["cores_available"]
+    cand = sorted({max(1, min(orc.max_threads(), c)) for c in (avail // 2, avail, 2 * avail)})
     best, threads = None, 1
     orc.set_threads(cand[-1])
     o.substep(dt, -1)  # warm-up (page in the dense grid arrays)
@@ -144,7 +146,8 @@ def cpu_baseline(domain_bits, layers, res, dt, budget_s=20.0):
             break
     return dict(value=sps, unit="substeps/s", cores=threads, kind="port",
                 sample=f"{n} substeps of the full workload ({o.n_particles} particles, {1 << domain_bits}^3 grid, "
-                       f"dt={dt}); OpenMP oracle with {threads} threads (fastest of {cand}); "
+                       f"dt={dt}); OpenMP oracle with {threads} threads (fastest of {cand}; {host['cores_available']} cores "
+                       f"available to this process on a {host['model']}); "
                        f"1 thread: {n1} substeps",
                 one_thread_value=n1 / el1, threads_tried=cand, host=host,
                 wall_s=time.perf_counter() - t_begin)

@@ -71,10 +71,16 @@ def test_update_contact_matches_oracle(exact, params, mu):
         ro = o.update_contact(DT, mu, stiffness, damping, exact_line_search=exact)
         rg = g.update_contact(DT, mu, stiffness, damping, exact_line_search=exact)
         sc = natural_scales(o, DT)
-        # same Newton trajectory: the iteration count differs when rounding moves an iterate across the
-        # 1e-4 stopping tolerance or (exact search) across the 1e-8 slope tolerance evaluated in float
-        assert abs(rg["iterations"] - ro["iterations"]) <= max(3, ro["iterations"] // 4), (rg, ro, step, _diagnose(g, o))
-        assert rg["residual"] <= 1.5e-4
+        # Both solves must converge.  Iteration counts: the line search accepts a step on `E1 <= E0`
+        # (cuda_mpm_solver.cu:518), two sums that agree to ~7 digits near convergence.  The reference (and
+        # the oracle) add them in float, so rounding noise rejects good steps and the count depends on
+        # the summation order; the engine adds in double and is never slower.
+        # The first iteration, where noise plays no role, is compared exactly in the test below.
+        slack = max(3, ro["iterations"] // 4)
+        assert rg["iterations"] <= ro["iterations"] + slack, (rg, ro, step, _diagnose(g, o))
+        if params == "soft":
+            assert abs(rg["iterations"] - ro["iterations"]) <= slack, (rg, ro, step)
+        assert rg["residual"] <= 1e-4 and ro["residual"] <= 1e-4
         close(g.download(A.CONTACT_VEL0), o.c_vel0, scale=sc["vel"], what="contact vel0")
         # converged solves agree to the solver's stopping tolerance (rounding-level agreement: the
         # single-iteration test below)
