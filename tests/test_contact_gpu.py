@@ -2,6 +2,8 @@
 import numpy as np
 import pytest
 
+from tests.helpers import IMPULSE_RTOL
+
 from tests.helpers import build_pair, close, natural_scales, solve_tolerance
 
 pytestmark = pytest.mark.gpu
@@ -94,8 +96,8 @@ def test_update_contact_matches_oracle(exact, params, mu):
         assert np.count_nonzero(np.abs(gdir).max(1)) < 0.05 * g.n_cells
         tau_g, f_g = g.external_body_force_to_host()
         fscale = float(np.abs(o.F_f).max())
-        close(f_g, o.F_f, scale=fscale, rtol=1e-3, what="body impulse")
-        close(tau_g, o.F_tau, scale=max(float(np.abs(o.F_tau).max()), fscale), rtol=1e-3, what="body angular impulse")
+        close(f_g, o.F_f, scale=fscale, rtol=IMPULSE_RTOL, what="body impulse")
+        close(tau_g, o.F_tau, scale=max(float(np.abs(o.F_tau).max()), fscale), rtol=IMPULSE_RTOL, what="body angular impulse")
         # the floor pushes up
         assert f_g[0, 2] < 0  # impulse ON the body is downward
         o.grid_to_particle(DT)

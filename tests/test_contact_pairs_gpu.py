@@ -4,6 +4,8 @@ with analytic signed distance fields."""
 import numpy as np
 import pytest
 
+from tests.helpers import IMPULSE_RTOL
+
 pytestmark = pytest.mark.gpu
 DT = 1e-3
 F = np.float32
@@ -187,8 +189,8 @@ def test_moving_capsules_impulses_per_body_match_the_oracle():
           what="contact vel (capsules)")
     tau_g, f_g = g.external_body_force_to_host()
     fscale = float(np.abs(o.F_f).max())
-    close(f_g, o.F_f, scale=fscale, rtol=1e-3, what="per-body impulse")
-    close(tau_g, o.F_tau, scale=float(np.abs(o.F_tau).max()), rtol=1e-3, what="per-body angular impulse")
+    close(f_g, o.F_f, scale=fscale, rtol=IMPULSE_RTOL, what="per-body impulse")
+    close(tau_g, o.F_tau, scale=float(np.abs(o.F_tau).max()), rtol=IMPULSE_RTOL, what="per-body angular impulse")
     assert np.all(np.abs(o.F_f).max(1) > 0)      # every body took part
     # FinalizeExternalContactForces (deformable_driver.h:210-219): impulse / plant step, then what the
     # plant does with it (multibody_plant.cc:2396-2404) for a force reported at a point Bq != Bo
@@ -196,10 +198,10 @@ def test_moving_capsules_impulses_per_body_match_the_oracle():
     plant_dt = 4 * DT
     tau_F, f_F = g.finalize_external_contact_forces(plant_dt)
     assert np.array_equal(tau_F, tau_g / np.float32(plant_dt)) and np.array_equal(f_F, f_g / np.float32(plant_dt))
-    close(f_F, o.F_f / plant_dt, scale=fscale / plant_dt, rtol=1e-3, what="per-body force")
+    close(f_F, o.F_f / plant_dt, scale=fscale / plant_dt, rtol=IMPULSE_RTOL, what="per-body force")
     R = np.stack([np.asarray(c.R_WB, np.float32) for c in links])
     p_BoBq_B = np.array([[0.01, -0.02, 0.03]] * 4, np.float32)
     tau_Bo = capi.external_forces_at_body_origin(R, p_BoBq_B, tau_F, f_F)
     pw = np.einsum("nij,nj->ni", R.reshape(4, 3, 3).astype(np.float64), p_BoBq_B.astype(np.float64))
     want = (o.F_tau.astype(np.float64) + np.cross(pw, o.F_f.astype(np.float64))) / plant_dt
-    close(tau_Bo, want, scale=float(np.abs(want).max()), rtol=1e-3, what="per-body torque about Bo")
+    close(tau_Bo, want, scale=float(np.abs(want).max()), rtol=IMPULSE_RTOL, what="per-body torque about Bo")
