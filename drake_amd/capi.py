@@ -79,6 +79,12 @@ class ContactStats(C.Structure):
                 ("E0", C.c_float), ("norm_dir_sq", C.c_float), ("dofs", C.c_float)]
 
 
+class DistConfig(C.Structure):
+    _fields_ = [("rank", C.c_int32), ("world", C.c_int32), ("own_lo_block", C.c_int32), ("own_hi_block", C.c_int32),
+                ("left_lo_block", C.c_int32), ("right_hi_block", C.c_int32), ("zone_blocks", C.c_int32),
+                ("ghost_cells", C.c_int32), ("ghost_margin_cells", C.c_int32)]
+
+
 class Stats(C.Structure):
     _fields_ = [
         ("substeps", C.c_uint64), ("rebuilds", C.c_uint64), ("home_blocks", C.c_uint32), ("active_blocks", C.c_uint32),
@@ -107,7 +113,8 @@ SYMBOLS = [
     "mpm_chain_init", "mpm_chain_substeps", "mpm_chain_destroy", "mpm_download_array", "mpm_upload_particle_state",
     "mpm_newton_bisect_f64", "mpm_newton_bisect_f32", "mpm_finalize_external_contact_forces",
     "mpm_spatial_force_shift", "mpm_external_forces_at_body_origin", "mpm_set_grid_colliders",
-    "mpm_grid_collider_preset", "mpm_get_contact_stats",
+    "mpm_grid_collider_preset", "mpm_get_contact_stats", "mpm_dist_init", "mpm_dist_migration_buffer_bytes",
+    "mpm_dist_migrate_pack", "mpm_dist_migrate_apply", "mpm_dist_roles",
 ]
 
 ROOTFIND_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_double, C.POINTER(C.c_double), C.POINTER(C.c_double))
@@ -179,6 +186,10 @@ def load_library(build: bool = True):
         "mpm_spatial_force_shift": [sz, vp, vp, vp, vp],
         "mpm_set_grid_colliders": [vp, sz, vp],
         "mpm_get_contact_stats": [vp, P(ContactStats)],
+        "mpm_dist_init": [vp, P(DistConfig)],
+        "mpm_dist_migrate_pack": [vp, vp, vp, sz],
+        "mpm_dist_migrate_apply": [vp, vp, vp, sz],
+        "mpm_dist_roles": [vp, vp],
         "mpm_grid_collider_preset": [i, f, vp, sz, P(sz)],
         "mpm_external_forces_at_body_origin": [sz, vp, vp, vp, vp, vp],
     }
@@ -192,6 +203,8 @@ def load_library(build: bool = True):
     lib.mpm_newton_bisect_f32.argtypes = [ROOTFIND_FN, vp, f, f, f, f, f, i, i, P(f), P(i)]
     lib.mpm_newton_bisect_f32.restype = i
     lib.mpm_halo_buffer_bytes.argtypes = [sz]
+    lib.mpm_dist_migration_buffer_bytes.argtypes = [sz]
+    lib.mpm_dist_migration_buffer_bytes.restype = sz
     lib.mpm_halo_buffer_bytes.restype = sz
     _LIB = lib
     return lib
@@ -430,6 +443,34 @@ class GpuMpm:
     def substep_begin_halo(self, dt: float, zone_args, capacity_blocks: int):
         n, lo, hi, sh, bufs = zone_args
         self._ck(self.lib.mpm_substep_begin_halo(self.h, dt, n, lo, hi, sh, bufs, capacity_blocks))
+
+    # ---- one domain cut into x slabs (mpm_dist_*) -------------------------------------
+    def dist_init(self, rank: int, world: int, cuts, zone_blocks: int = 2, ghost_cells: int = 2,
+                  ghost_margin_cells: int = 2):
+        """cuts: world + 1 ascending x block indices; rank r owns blocks [cuts[r], cuts[r + 1])."""
+        assert len(cuts) == world + 1
+        cfg = DistConfig(rank, world, cuts[rank], cuts[rank + 1], cuts[rank - 1] if rank > 0 else 0,
+                         cuts[rank + 2] if rank + 2 <= world else cuts[world], zone_blocks, ghost_cells,
+                         ghost_margin_cells)
+        self._ck(self.lib.mpm_dist_init(self.h, C.byref(cfg)))
+
+    def dist_migration_buffer_bytes(self, capacity_particles: int) -> int:
+        return int(self.lib.mpm_dist_migration_buffer_bytes(capacity_particles))
+
+    def dist_migrate_pack(self, send_left_ptr: int, send_right_ptr: int, capacity_particles: int):
+        self._ck(self.lib.mpm_dist_migrate_pack(self.h, C.c_void_p(send_left_ptr), C.c_void_p(send_right_ptr),
+                                                capacity_particles))
+
+    def dist_migrate_apply(self, recv_left_ptr, recv_right_ptr, capacity_particles: int):
+        self._ck(self.lib.mpm_dist_migrate_apply(self.h, C.c_void_p(recv_left_ptr) if recv_left_ptr else None,
+                                                 C.c_void_p(recv_right_ptr) if recv_right_ptr else None,
+                                                 capacity_particles))
+
+    def dist_roles(self) -> np.ndarray:
+        """Per slot: 0 the particle is not on this rank, 1 owned, 2 ghost copy."""
+        out = np.zeros(self.n_particles, np.uint8)
+        self._ck(self.lib.mpm_dist_roles(self.h, _ptr(out)))
+        return out
 
     # ---- native chain: RCCL point-to-point on the engine's stream (mpm_chain_*) -----
     @staticmethod

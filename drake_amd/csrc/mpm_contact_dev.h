@@ -214,10 +214,12 @@ __global__ __launch_bounds__(256) void k_ct_gen_count(DP p, const int* pids_api,
     const int s = blockIdx.x * 256 + threadIdx.x;
     if (s >= p.Np) return;
     const PSet& S = p.set[p.ctl->cur];
-    const float4 q = S.q[0][p.imap[pids_api[s]]];
+    const int slot = p.imap[pids_api[s]];
+    // (partitioned domain: only the particles this rank owns make contacts here)
+    const float4 q = slot >= 0 ? S.q[0][slot] : make_float4(0.f, 0.f, 0.f, 0.f);
     const float x[3] = {q.x, q.y, q.z};
     int n = 0;
-    for (int j = 0; j < n_col; ++j) {
+    for (int j = 0; j < n_col && q.w > 0.f; ++j) {
         float g[3];
         n += collider_sdf(cols[j], x, g) < 0.f ? 1 : 0;
     }
@@ -309,7 +311,7 @@ __global__ __launch_bounds__(256) void k_ct_prepare(DP p, ContactDev c) {
 #pragma unroll
     for (int d = 0; d < 3; ++d) c.cfx[d * c.n + j] = c.pos[k * 3 + d] * p.dxinv - (float)b[d];
     const uint32_t slot = c.slot[k];
-    c.cmass[j] = S.q[0][slot].w * p.M.density;
+    c.cmass[j] = fabsf(S.q[0][slot].w) * p.M.density;
 #pragma unroll
     for (int i = 0; i < 3; ++i)
 #pragma unroll

@@ -20,11 +20,14 @@ constexpr unsigned ERR_DRIFT = 1u;      // particle outside the hard free zone
 constexpr unsigned ERR_CAPACITY = 2u;   // home/active table overflow
 constexpr unsigned ERR_DOMAIN = 4u;     // particle base cell outside the grid
 constexpr unsigned ERR_RANGE = 8u;      // a P2G node sum left the range of the fixed-point tile (or was NaN)
+constexpr unsigned ERR_HALO = 16u;      // partitioned domain: a particle's stencil left the zone shared with the neighbour
 
 // One of the two ping-pong particle sets.  Every particle is four 16-byte records in four
 // planes (one coalesced dwordx4 access per plane and wave), slots [0,Nf) are face particles,
 // [Nf,Np) vertex particles, each range sorted by cell key at the last rebuild:
 //   q[0] = (x, y, z, vol)      q[1] = (vx, vy, vz, C8)
+//          (partitioned domain: vol > 0 owned, vol < 0 ghost copy of a neighbour's particle with
+//           volume |vol|, vol == 0 released: dropped by the next re-sort)
 //   q[2] = (C0, C1, C2, C3)    q[3] = (C4, C5, C6, C7)          C row-major, as in the reference
 // Face particles carry four more records, indexed by face slot:
 //   fq[0] = (F0..F3)  fq[1] = (F4..F7)  fq[2] = (F8, Dm0, Dm1, Dm2)
@@ -53,9 +56,44 @@ struct Ctl {
     unsigned n_items;      // work items of the tile kernels (home blocks, heavy ones split)
     unsigned rebuilds;
     unsigned ticket;
-    unsigned reserved[2];
-    unsigned pad[2];
+    // Active particles occupy slots [0, nfa) (faces) and [Nf, Nf + nva) (vertices); the other slots
+    // are free.  A single-domain engine has nfa = Nf, nva = Nv for ever.  In a partitioned domain
+    // (mpm_dist_init) a rank only holds the particles it owns plus ghost copies of the neighbours'
+    // particles next to the cuts: migration appends add_f / add_v particles behind the active ones,
+    // the next re-sort drops the released ones and merges the new ones.
+    int nfa, nva;
+    int add_f, add_v;
+    int nfa_new, nva_new;   // counts after the re-sort in flight (k_rb_tables -> k_rb_finish)
 };
+
+// Partitioned domain: ranks cut ONE domain into x slabs at block boundaries.  Every
+// rank was finalised with the whole scene (replicated topology, full-capacity arrays) but only
+// works on the particles it owns -- base cell x in [own_lo, own_hi) -- plus ghost copies of the
+// neighbours' particles within ghost_cells of a cut.  Ghosts take part in FEM and G2P (so they stay
+// bit-identical to the owner's copy without communication) and contribute nothing to P2G; the node
+// sums of the blocks within zone_cells of a cut are exchanged every substep.
+struct Dist {
+    int on;
+    int rank, world;
+    int own_lo, own_hi;        // owned x range in cells
+    int nbr_lo, nbr_hi;        // outer ends of the left / right neighbour's ranges (cells)
+    int has_left, has_right;
+    int ghost_cells;           // ghost band for face particles
+    int vert_cells;            // ghost band for vertex particles: wider by the longest mesh edge, so that a
+                               // ghost face always finds its corner vertices on the same rank
+    int zone_cells;            // depth of the exchanged zone either side of a cut
+    unsigned char* prev;       // [original id] bit 0 / 1: was in the left / right neighbour's ghost band at the last migration
+};
+
+MPM_DEV bool dist_in_my_band(const Dist& d, int bx, bool face) {   // a neighbour's particle that I hold as a ghost
+    const int w = face ? d.ghost_cells : d.vert_cells;
+    return (d.has_left && bx >= d.own_lo - w && bx < d.own_lo) || (d.has_right && bx >= d.own_hi && bx < d.own_hi + w);
+}
+// bit 0 / 1: an owned particle at cell bx is inside the band in which the left / right neighbour keeps ghosts
+MPM_DEV int dist_in_neighbour_bands(const Dist& d, int bx, bool face) {
+    const int w = face ? d.ghost_cells : d.vert_cells;
+    return ((d.has_left && bx < d.own_lo + w) ? 1 : 0) | ((d.has_right && bx >= d.own_hi - w) ? 2 : 0);
+}
 
 struct DP {
     int Np, Nf, Nv;
@@ -117,7 +155,12 @@ struct DP {
     uint32_t* slab_mask;   // [item] 27-bit set of neighbour blocks reached by a stencil
     float4* gv;            // [active][64] (vx, vy, vz, m)  (momentum before the grid update)
     float4* gvs;           // [active][64] v* (velocity after the explicit update, before contact)
+    const float4* dm_orig; // [original face id] Dm^-1 as computed by Finalize (a face that joins a rank needs it)
+    Dist dist;
 };
+
+// idx-th active (or freshly appended) particle -> slot: faces first, then vertices
+MPM_DEV int active_slot(const DP& p, int idx, int nf_in) { return idx < nf_in ? idx : p.Nf + (idx - nf_in); }
 
 // Kernel ablation / cycle-counter switches exist only in the diagnostic build (-DMPM_DIAG=1,
 // `python -m drake_amd._build --diag`); in the production build they fold to 0 and cost nothing.

@@ -1,0 +1,188 @@
+// Partitioned domain ("particle domains tile across the GPUs", particle migration):
+// the kernels that hand particles from rank to rank.  See struct Dist in mpm_device.h for the model.
+//
+// Every `migrate_every` substeps, before the re-sort, a rank
+//   1. classifies its active particles by the x cell of their base node (k_dist_classify):
+//        owned, now in a neighbour's slab   -> record (role OWNED) to that neighbour; here the
+//                                              particle becomes a ghost, or is released if it is
+//                                              already beyond this rank's ghost band;
+//        owned, newly inside the band the neighbour keeps ghosts in -> record (role GHOST);
+//        ghost, outside this rank's band    -> released;
+//   2. exchanges the two record buffers with its neighbours (transport: the caller / mpm_chain);
+//   3. applies what it received (k_dist_apply): a particle it does not hold yet is appended behind
+//      the active ones, one it holds (a ghost being promoted) is overwritten in place;
+//   4. re-sorts (forced), which drops the released particles and merges the appended ones.
+// Ghost copies are never refreshed in between: they take part in FEM and G2P with the same inputs
+// and the same arithmetic as the owner's copy, so they stay bit-identical.
+//
+// Record = 7 x 16 bytes: (original id, role, F8, 0), q0..q3 (|vol| in q0.w), F0..3, F4..7.
+// Buffer = 16-byte header (record count) + capacity records.
+#pragma once
+#include "mpm_device.h"
+
+namespace mpm {
+
+constexpr int DIST_REC_F4 = 7;
+constexpr int ROLE_GHOST = 2, ROLE_OWNED = 1;
+
+MPM_DEV int dist_cell_x(const DP& p, float x) {
+    const uint32_t hi = (uint32_t)((1 << p.bits) - 3);
+    return (int)min(base_cell(x, p.dxinv), hi);
+}
+
+// mpm_dist_init: every particle is here and owned (replicated Finalize); keep what this rank owns,
+// mark the ghosts, release the rest.  No communication: all ranks start from the same state.
+__global__ __launch_bounds__(256) void k_dist_init_roles(DP p) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= p.Np) return;
+    const PSet& S = p.set[p.ctl->cur];
+    const Dist& d = p.dist;
+    float4 q = S.q[0][i];
+    const int bx = dist_cell_x(p, q.x);
+    const float vol = fabsf(q.w);
+    const bool mine = bx >= d.own_lo && bx < d.own_hi, face = i < p.Nf;
+    q.w = mine ? vol : (dist_in_my_band(d, bx, face) ? -vol : 0.f);
+    S.q[0][i] = q;
+    d.prev[S.pid[i]] = mine ? (unsigned char)dist_in_neighbour_bands(d, bx, face) : 0;
+}
+
+MPM_DEV void dist_emit(const DP& p, const PSet& S, unsigned slot, int gid, int role, float4 q0, bool emit, float4* buf,
+                       unsigned cap) {
+    const unsigned long long m = __ballot(emit);
+    if (!m) return;
+    const int lane = threadIdx.x & 63, lead = __builtin_ctzll(m);
+    unsigned base = 0;
+    if (lane == lead) base = atomicAdd(reinterpret_cast<unsigned*>(buf), (unsigned)__popcll(m));
+    base = (unsigned)__shfl((int)base, lead);
+    if (!emit) return;
+    const unsigned at = base + (unsigned)__popcll(m & ((1ull << lane) - 1ull));
+    if (at >= cap) {
+        atomicOr(&p.ctl->error, ERR_CAPACITY);
+        return;
+    }
+    float4* r = buf + 1 + (size_t)at * DIST_REC_F4;
+    const bool face = slot < (unsigned)p.Nf;
+    const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+    q0.w = fabsf(q0.w);
+    r[0] = make_float4(__int_as_float(gid), __int_as_float(role), face ? S.fq[2][slot].x : 0.f, 0.f);
+    r[1] = q0;
+    r[2] = S.q[1][slot];
+    r[3] = S.q[2][slot];
+    r[4] = S.q[3][slot];
+    r[5] = face ? S.fq[0][slot] : z;
+    r[6] = face ? S.fq[1][slot] : z;
+}
+
+__global__ __launch_bounds__(256) void k_dist_classify(DP p, float4* send_l, float4* send_r, unsigned cap) {
+    Ctl* c = p.ctl;
+    const PSet& S = p.set[c->cur];
+    const Dist& d = p.dist;
+    const int nf = c->nfa, total = nf + c->nva;
+    bool changed = false;
+    for (int base = blockIdx.x * 256; base < total; base += gridDim.x * 256) {   // (whole waves stay in the loop)
+        const int idx = base + threadIdx.x;
+        const bool live = idx < total;
+        const unsigned slot = (unsigned)active_slot(p, live ? idx : total - 1, nf);
+        float4 q0 = S.q[0][slot];
+        const int gid = S.pid[slot];
+        const int bx = dist_cell_x(p, q0.x);
+        const float vol = q0.w;
+        const bool face = slot < (unsigned)p.Nf;
+        bool to_l = false, to_r = false;
+        int role_l = ROLE_GHOST, role_r = ROLE_GHOST;
+        float new_vol = vol;
+        if (live && vol > 0.f) {
+            if (bx < d.own_lo || bx >= d.own_hi) {
+                // crossed a cut: the neighbour takes over
+                const bool left = bx < d.own_lo;
+                if ((left && (!d.has_left || bx < d.nbr_lo)) || (!left && (!d.has_right || bx >= d.nbr_hi)))
+                    atomicOr(&c->error, ERR_HALO);   // (beyond the neighbour's slab, or no neighbour there)
+                to_l = left; to_r = !left;
+                role_l = role_r = ROLE_OWNED;
+                new_vol = dist_in_my_band(d, bx, face) ? -vol : 0.f;
+                d.prev[gid] = 0;
+            } else {
+                const int in = dist_in_neighbour_bands(d, bx, face);
+                const unsigned char old = d.prev[gid];
+                to_l = (in & 1) && !(old & 1);
+                to_r = (in & 2) && !(old & 2);
+                d.prev[gid] = (unsigned char)in;
+            }
+        } else if (live && vol < 0.f) {
+            // a ghost stays while it is in this rank's band (its owner applies the same test to the same
+            // position); one that crossed INTO this rank's slab waits for its owner's record
+            const bool mine = bx >= d.own_lo && bx < d.own_hi;
+            if (!mine && !dist_in_my_band(d, bx, face)) new_vol = 0.f;
+        }
+        dist_emit(p, S, slot, gid, role_l, q0, to_l, send_l, cap);
+        dist_emit(p, S, slot, gid, role_r, q0, to_r, send_r, cap);
+        if (live && new_vol != vol) {
+            q0.w = new_vol;
+            S.q[0][slot] = q0;
+            changed |= new_vol == 0.f;
+        }
+    }
+    if (__ballot(changed) && (threadIdx.x & 63) == 0) c->need_rebuild = 1;
+}
+
+__global__ __launch_bounds__(256) void k_dist_apply(DP p, const float4* recv, unsigned cap) {
+    Ctl* c = p.ctl;
+    const PSet& S = p.set[c->cur];
+    const unsigned n = min(*reinterpret_cast<const unsigned*>(recv), cap);
+    for (unsigned k = blockIdx.x * 256 + threadIdx.x; k < n; k += gridDim.x * 256) {
+        const float4* r = recv + 1 + (size_t)k * DIST_REC_F4;
+        const float4 h = r[0];
+        const int gid = __float_as_int(h.x), role = __float_as_int(h.y);
+        if (gid < 0 || gid >= p.Np) {
+            atomicOr(&c->error, ERR_HALO);
+            continue;
+        }
+        const bool face = gid < p.Nf;
+        int slot = p.imap[gid];
+        if (slot < 0) {
+            // not held yet: append behind the active particles of its type (the re-sort merges it)
+            const int at = atomicAdd(face ? &c->add_f : &c->add_v, 1);
+            slot = face ? c->nfa + at : p.Nf + c->nva + at;
+            if (slot >= (face ? p.Nf : p.Np)) {
+                atomicOr(&c->error, ERR_CAPACITY);
+                continue;
+            }
+            S.pid[slot] = gid;
+            p.imap[gid] = slot;
+            if (face) {
+                const float4 dm = p.dm_orig[gid];
+                S.fq[2][slot] = make_float4(h.z, dm.x, dm.y, dm.z);
+                S.fq[3][slot] = make_float4(dm.w, __int_as_float(-1), __int_as_float(-1), __int_as_float(-1));
+            }
+        } else if (face) {
+            S.fq[2][slot].x = h.z;
+        }
+        float4 q0 = r[1];
+        q0.w = role == ROLE_OWNED ? q0.w : -q0.w;
+        S.q[0][slot] = q0;
+        S.q[1][slot] = r[2];
+        S.q[2][slot] = r[3];
+        S.q[3][slot] = r[4];
+        if (face) {
+            S.fq[0][slot] = r[5];
+            S.fq[1][slot] = r[6];
+        }
+        if (role == ROLE_OWNED) p.dist.prev[gid] = 0;
+    }
+    if (n && threadIdx.x == 0 && blockIdx.x == 0) c->need_rebuild = 1;
+}
+
+// role of the particle in each API slot: 0 not on this rank, 1 owned, 2 ghost
+__global__ __launch_bounds__(256) void k_dist_roles(DP p, const int* pids_api, unsigned char* out) {
+    const int s = blockIdx.x * 256 + threadIdx.x;
+    if (s >= p.Np) return;
+    const int j = p.imap[pids_api[s]];
+    unsigned char r = 0;
+    if (j >= 0) {
+        const float v = p.set[p.ctl->cur].q[0][j].w;
+        r = v > 0.f ? 1 : (v < 0.f ? 2 : 0);
+    }
+    out[s] = r;
+}
+
+}  // namespace mpm

@@ -20,6 +20,7 @@
 #include "mpm_contact.h"
 #include "mpm_chain.h"
 #include "mpm_feedback.h"
+#include "mpm_dist.h"
 
 extern "C" {
 
@@ -177,7 +178,7 @@ static int set_fixed_point_scales(mpm_engine* e) {
     D2H(e, &c, p.ctl, sizeof(Ctl));
     D2H(e, q0.data(), p.set[c.cur & 1].q[0], e->np * 16);
     double mass = 0;
-    for (size_t i = 0; i < e->np; ++i) mass += (double)q0[i * 4 + 3] * p.M.density;
+    for (size_t i = 0; i < e->np; ++i) mass += std::fabs((double)q0[i * 4 + 3]) * p.M.density;
     if (!(mass > 0) || !std::isfinite(mass)) mass = 1.0;
     const int k = 61 - (int)std::ceil(std::log2(mass));
     p.fix_m = std::ldexp(1.0, k);
@@ -271,6 +272,9 @@ int mpm_finalize(mpm_handle_t e) {
     ALLOC(p.gvs, (size_t)p.capA * 64, true);
     ALLOC(e->d_pids_api, np, false);
     ALLOC(e->d_apimap, np, false);
+    float4* dm_orig;
+    ALLOC(dm_orig, nf, false);
+    p.dm_orig = dm_orig;
 #undef ALLOC
 
     // ---- host-side layout: [faces | verts], indices offset by +nf ---------
@@ -332,6 +336,8 @@ int mpm_finalize(mpm_handle_t e) {
     Ctl c0{};
     c0.cur = 0;
     c0.need_rebuild = 1;
+    c0.nfa = (int)nf;
+    c0.nva = (int)nv;
     HIP_TRY(hipMemcpyAsync(p.ctl, &c0, sizeof(Ctl), hipMemcpyHostToDevice, e->stream));
     launch_rebuild(e);
     HIP_TRY(hipStreamSynchronize(e->stream));
@@ -401,6 +407,10 @@ int mpm_sync(mpm_handle_t e) {
                     "velocities differ by cells per substep, the state is diverging -- reduce dt");
     if (c.error & ERR_DOMAIN)
         return fail(MPM_ERR_DOMAIN, "a particle left the grid; results are invalid");
+    if (c.error & ERR_HALO)
+        return fail(MPM_ERR_HALO,
+                    "partitioned domain: a particle left the zone shared with the neighbouring rank (or reached a "
+                    "rank that is not a neighbour): migrate more often, or widen the zone / ghost band");
     if (c.error & ERR_RANGE)
         return fail(MPM_ERR_RANGE,
                     "a node sum of ParticleToGrid was not finite or exceeded the fixed-point range "
@@ -417,7 +427,10 @@ int mpm_sync(mpm_handle_t e) {
 int mpm_rebuild_mapping(mpm_handle_t e, int sort) {
     READY(e);
     launch_rebuild(e);
-    if (sort) return api_sort(e);
+    if (sort) {
+        REQUIRE(!e->dp.dist.on, "RebuildMapping(sort = true) is not available on a partitioned domain");
+        return api_sort(e);
+    }
     return 0;
 }
 
@@ -898,6 +911,83 @@ int mpm_external_body_force_to_host(mpm_handle_t e, float* tau_out, float* f_out
     if (e->cb.n_bodies == 0) return 0;
     if (tau_out) D2H(e, tau_out, e->cb.body_tau, e->cb.n_bodies * 12);
     if (f_out) D2H(e, f_out, e->cb.body_f, e->cb.n_bodies * 12);
+    return 0;
+}
+
+// ---- partitioned domain ----------------------------------------------------------------------
+int mpm_dist_init(mpm_handle_t e, const mpm_dist_config_t* cfg) {
+    READY(e);
+    REQUIRE(cfg, "null configuration");
+    REQUIRE(!e->dp.dist.on, "mpm_dist_init called twice");
+    REQUIRE(e->api_identity, "mpm_dist_init must precede RebuildMapping(sort = true)");
+    const int nb = e->dp.nb;
+    REQUIRE(cfg->world >= 1 && cfg->rank >= 0 && cfg->rank < cfg->world, "bad rank / world");
+    REQUIRE(cfg->own_lo_block >= 0 && cfg->own_lo_block < cfg->own_hi_block && cfg->own_hi_block <= nb,
+            "bad slab: need 0 <= own_lo_block < own_hi_block <= blocks per axis");
+    REQUIRE(cfg->zone_blocks >= 1 && cfg->ghost_cells >= 1 && cfg->ghost_margin_cells >= 1,
+            "zone_blocks, ghost_cells and ghost_margin_cells must be positive");
+    // a ghost vertex may sit ghost_cells + ghost_margin_cells beyond the cut and its stencil reaches 2 nodes further
+    REQUIRE(cfg->zone_blocks * 4 >= cfg->ghost_cells + cfg->ghost_margin_cells + 2,
+            "zone too shallow for the ghost band: need 4 * zone_blocks >= ghost_cells + ghost_margin_cells + 2");
+    const bool has_left = cfg->rank > 0, has_right = cfg->rank < cfg->world - 1;
+    // the zones of the two cuts must not overlap (a block is shared by at most two ranks)
+    REQUIRE(!(has_left && has_right) || cfg->own_hi_block - cfg->own_lo_block >= 2 * cfg->zone_blocks,
+            "slab narrower than two zones: use fewer ranks or zone_blocks = 1");
+    REQUIRE(!has_left || (cfg->left_lo_block >= 0 && cfg->left_lo_block < cfg->own_lo_block), "bad left neighbour range");
+    REQUIRE(!has_right || (cfg->right_hi_block > cfg->own_hi_block && cfg->right_hi_block <= nb), "bad right neighbour range");
+    Dist d{};
+    d.on = 1;
+    d.rank = cfg->rank; d.world = cfg->world;
+    d.own_lo = has_left ? cfg->own_lo_block * 4 : 0;
+    d.own_hi = has_right ? cfg->own_hi_block * 4 : nb * 4;
+    d.nbr_lo = has_left ? (cfg->rank > 1 ? cfg->left_lo_block * 4 : 0) : 0;
+    d.nbr_hi = has_right ? (cfg->rank < cfg->world - 2 ? cfg->right_hi_block * 4 : nb * 4) : nb * 4;
+    d.has_left = has_left; d.has_right = has_right;
+    d.ghost_cells = cfg->ghost_cells;
+    d.vert_cells = cfg->ghost_cells + cfg->ghost_margin_cells;
+    d.zone_cells = cfg->zone_blocks * 4;
+    if (int rc = e->dalloc(&d.prev, e->np, true)) return rc;
+    e->dp.dist = d;
+    e->dist_cfg = *cfg;
+    drop_step_graph(e);
+    hipLaunchKernelGGL(k_dist_init_roles, dim3(e->g_np), dim3(256), 0, e->stream, e->dp);
+    int one = 1;
+    H2D(e, &e->dp.ctl->need_rebuild, &one, sizeof(int));
+    launch_rebuild(e);
+    return mpm_sync(e);
+}
+
+size_t mpm_dist_migration_buffer_bytes(size_t capacity_particles) { return 16 + capacity_particles * DIST_REC_F4 * 16; }
+
+int mpm_dist_migrate_pack(mpm_handle_t e, void* send_left, void* send_right, size_t capacity_particles) {
+    READY(e);
+    REQUIRE(e->dp.dist.on, "mpm_dist_init first");
+    REQUIRE(send_left && send_right && capacity_particles > 0 && capacity_particles < (1u << 28), "bad migration buffers");
+    HIP_TRY(hipMemsetAsync(send_left, 0, 16, e->stream));
+    HIP_TRY(hipMemsetAsync(send_right, 0, 16, e->stream));
+    hipLaunchKernelGGL(k_dist_classify, dim3(std::min(e->g_np, 2048u)), dim3(256), 0, e->stream, e->dp,
+                       static_cast<float4*>(send_left), static_cast<float4*>(send_right), (unsigned)capacity_particles);
+    return 0;
+}
+
+int mpm_dist_migrate_apply(mpm_handle_t e, const void* recv_left, const void* recv_right, size_t capacity_particles) {
+    READY(e);
+    REQUIRE(e->dp.dist.on, "mpm_dist_init first");
+    for (const void* b : {recv_left, recv_right})
+        if (b)
+            hipLaunchKernelGGL(k_dist_apply, dim3(256), dim3(256), 0, e->stream, e->dp, static_cast<const float4*>(b),
+                               (unsigned)capacity_particles);
+    return 0;
+}
+
+int mpm_dist_roles(mpm_handle_t e, uint8_t* out) {
+    READY(e);
+    REQUIRE(out, "null output");
+    if (int rc = e->stage(e->np)) return rc;
+    hipLaunchKernelGGL(k_dist_roles, dim3(e->g_np), dim3(256), 0, e->stream, e->dp, (const int*)e->d_pids_api,
+                       (unsigned char*)e->d_stage);
+    HIP_TRY(hipMemcpyAsync(out, e->d_stage, e->np, hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(hipStreamSynchronize(e->stream));
     return 0;
 }
 

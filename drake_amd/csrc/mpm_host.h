@@ -89,6 +89,7 @@ struct mpm_engine {
     // contacts / rigid bodies
     ContactBuffers cb{};
     mpm_contact_stats_t last_contact{};   // of the last mpm_update_contact
+    mpm_dist_config_t dist_cfg{};         // partitioned domain (mpm_dist_init)
     std::string dump_dir = ".";
     // scratch for downloads
     void* d_stage = nullptr;

@@ -39,6 +39,7 @@ __global__ __launch_bounds__(256) void k_init_faces(DP p) {
     S.fq[1][i] = make_float4(Q[4], Q[5], Q[6], Q[7]);
     S.fq[2][i] = make_float4(Q[8], Di[0], Di[1], Di[2]);
     S.fq[3][i] = make_float4(Di[3], f3.y, f3.z, f3.w);
+    const_cast<float4*>(p.dm_orig)[i] = make_float4(Di[0], Di[1], Di[2], Di[3]);
     p.G4[(size_t)i * 3].x = v4;
 }
 
@@ -88,7 +89,7 @@ template <int FIELD>
 MPM_DEV void read_field(const DP& p, const PSet& S, int j, float* o) {
     if (FIELD == F_POS) { const float4 q = S.q[0][j]; o[0] = q.x; o[1] = q.y; o[2] = q.z; }
     if (FIELD == F_VEL) { const float4 q = S.q[1][j]; o[0] = q.x; o[1] = q.y; o[2] = q.z; }
-    if (FIELD == F_VOL) o[0] = S.q[0][j].w;
+    if (FIELD == F_VOL) o[0] = fabsf(S.q[0][j].w);   // (the sign marks ghost copies in a partitioned domain)
     if (FIELD == F_AFFINE) unpack_C(S.q[1][j], S.q[2][j], S.q[3][j], o);
     if (FIELD == F_FORCE) {
         const bool v = j >= p.Nf;
@@ -109,7 +110,7 @@ template <int FIELD>
 MPM_DEV void write_field(const PSet& S, int j, const float* v) {
     if (FIELD == F_POS) { float4 q = S.q[0][j]; q.x = v[0]; q.y = v[1]; q.z = v[2]; S.q[0][j] = q; }
     if (FIELD == F_VEL) { float4 q = S.q[1][j]; q.x = v[0]; q.y = v[1]; q.z = v[2]; S.q[1][j] = q; }
-    if (FIELD == F_VOL) S.q[0][j].w = v[0];
+    if (FIELD == F_VOL) S.q[0][j].w = S.q[0][j].w < 0.f ? -v[0] : v[0];
     if (FIELD == F_AFFINE) {
         S.q[2][j] = make_float4(v[0], v[1], v[2], v[3]);
         S.q[3][j] = make_float4(v[4], v[5], v[6], v[7]);
@@ -131,7 +132,13 @@ __global__ __launch_bounds__(256) void k_gather_field(DP p, float* out, int n, c
     if (s >= n) return;
     const PSet& S = p.set[p.ctl->cur];
     float v[9];
-    read_field<FIELD>(p, S, p.imap[order[s]], v);
+    const int j = p.imap[order[s]];
+    if (j >= 0) {
+        read_field<FIELD>(p, S, j, v);
+    } else {   // partitioned domain: the particle is not on this rank
+#pragma unroll
+        for (int c = 0; c < 9; ++c) v[c] = __int_as_float(0x7FC00000);
+    }
 #pragma unroll
     for (int c = 0; c < N; ++c) out[(size_t)s * N + c] = v[c];
 }
@@ -145,7 +152,8 @@ __global__ __launch_bounds__(256) void k_scatter_field(DP p, const float* in, in
     float v[9];
 #pragma unroll
     for (int c = 0; c < N; ++c) v[c] = in[(size_t)s * N + c];
-    write_field<FIELD>(S, p.imap[order[s]], v);
+    const int j = p.imap[order[s]];
+    if (j >= 0) write_field<FIELD>(S, j, v);
 }
 
 // taus()[slot] = a (x) b for face particles, zero for vertices
@@ -154,7 +162,7 @@ __global__ __launch_bounds__(256) void k_gather_taus(DP p, float* out, const int
     if (s >= p.Np) return;
     const int j = p.imap[pids_api[s]];
     float a[3] = {0.f, 0.f, 0.f}, b[3] = {0.f, 0.f, 0.f};
-    if (j < p.Nf) {
+    if (j >= 0 && j < p.Nf) {
         const float4 q = p.ab0[j];
         const float2 r = p.ab1[j];
         a[0] = q.x; a[1] = q.y; a[2] = q.z;
@@ -172,7 +180,12 @@ __global__ __launch_bounds__(256) void k_slot_keys(DP p, uint32_t* out, const in
     const int s = blockIdx.x * 256 + threadIdx.x;
     if (s >= p.Np) return;
     const PSet& S = p.set[p.ctl->cur];
-    const float4 x = S.q[0][p.imap[pids_api[s]]];
+    const int j = p.imap[pids_api[s]];
+    if (j < 0) {
+        out[s] = 0xFFFFFFFFu;
+        return;
+    }
+    const float4 x = S.q[0][j];
     out[s] = cell_key(base_cell(x.x, p.dxinv), base_cell(x.y, p.dxinv), base_cell(x.z, p.dxinv));
 }
 

@@ -23,13 +23,17 @@ namespace mpm {
 __global__ __launch_bounds__(256) void k_rb_count(DP p) {
     if (!p.ctl->need_rebuild) return;
     const PSet& S = p.set[p.ctl->cur];
+    // the particles to sort: the active ones and what a migration appended behind them
+    const int nf_in = p.ctl->nfa + p.ctl->add_f, total = nf_in + p.ctl->nva + p.ctl->add_v;
     // grid-stride over 256-particle chunks: a small fixed grid keeps the idle launches cheap
-    for (int base = blockIdx.x * 256; base < p.Np; base += gridDim.x * 256) {
-    const int i = base + threadIdx.x;
-    const bool valid = i < p.Np;
-    const int ii = valid ? i : p.Np - 1;
+    for (int base = blockIdx.x * 256; base < total; base += gridDim.x * 256) {
+    const int idx = base + threadIdx.x;
+    const bool listed = idx < total;
+    const int i = active_slot(p, listed ? idx : total - 1, nf_in);
+    const int ii = i;
     const uint32_t hi = (uint32_t)((1 << p.bits) - 3);
     const float4 xq = S.q[0][ii];
+    const bool valid = listed && xq.w != 0.f;   // volume 0: released by the migration, dropped here
     uint32_t bx = base_cell(xq.x, p.dxinv), by = base_cell(xq.y, p.dxinv), bz = base_cell(xq.z, p.dxinv);
     // (a negative coordinate saturates to cell 0 in the conversion, so test the float)
     const float lim = (float)(hi + 1u);
@@ -37,6 +41,14 @@ __global__ __launch_bounds__(256) void k_rb_count(DP p) {
     if (valid && !(inside(xq.x) && inside(xq.y) && inside(xq.z)) && !(p.ctl->error & ERR_DOMAIN))
         atomicOr(&p.ctl->error, ERR_DOMAIN);
     bx = min(bx, hi); by = min(by, hi); bz = min(bz, hi);
+    if (p.dist.on && valid && xq.w > 0.f) {
+        // an owned particle may sit up to zone - 3 cells beyond a cut: its stencil (2 more cells) and the
+        // motion until the next re-sort (the tile's free zone, < 1 cell past this test on average) stay
+        // inside the blocks whose sums the neighbour receives
+        const int slack = p.dist.zone_cells - 3;
+        if (((int)bx < p.dist.own_lo - slack || (int)bx >= p.dist.own_hi + slack) && !(p.ctl->error & ERR_HALO))
+            atomicOr(&p.ctl->error, ERR_HALO);
+    }
     const int t = ii >= p.Nf;
     const uint32_t key = cell_key(bx, by, bz);
     const int lane = threadIdx.x & 63;
@@ -76,8 +88,8 @@ __global__ __launch_bounds__(256) void k_rb_count(DP p) {
     // (type, block) pair touches the non-empty bitmap
     if (blk_lead && ret_blk == 0) atomicOr(&p.home_bits[key >> 11], 1u << ((key >> 6) & 31u));
     const uint32_t rank = (uint32_t)__shfl(ret_cell, my_lead) + (uint32_t)__popcll(my_same & ((1ull << lane) - 1ull));
-    if (valid) {
-        p.pkey[i] = key;
+    if (listed) {
+        p.pkey[i] = valid ? key : 0xFFFFFFFFu;
         p.prank[i] = rank;
     }
     }
@@ -196,6 +208,10 @@ __global__ __launch_bounds__(1024) void k_rb_tables(DP p) {
         int tf = 0, tv = 0;
         int rf = wg_scan_exclusive(cf, tf, s_w);
         int rv = wg_scan_exclusive(cv, tv, s_w);
+        if (tid == 0) {
+            c->nfa_new = tf;
+            c->nva_new = tv;
+        }
         for (unsigned h = h0; h < h1; ++h) {
             const uint32_t b = p.home_block[h];
             const int nf = p.blkcnt[0][b], nv = p.blkcnt[1][b];
@@ -356,8 +372,15 @@ __global__ __launch_bounds__(256) void k_rb_scatter(DP p) {
         }
     }
     const PSet& S = p.set[p.ctl->cur];
-    for (int j = i; j < p.Np; j += (int)(gridDim.x * 256u)) {
+    const int nf_in = p.ctl->nfa + p.ctl->add_f, total = nf_in + p.ctl->nva + p.ctl->add_v;
+    for (int idx = i; idx < total; idx += (int)(gridDim.x * 256u)) {
+        const int j = active_slot(p, idx, nf_in);
         const uint32_t key = p.pkey[j];
+        if (key == 0xFFFFFFFFu) {   // released: the particle leaves this rank
+            p.dst_of[j] = -1;
+            p.imap[S.pid[j]] = -1;
+            continue;
+        }
         const int t = j >= p.Nf;
         const int dst = (t ? p.Nf : 0) + p.blkstart[t][key >> 6] + p.cellcnt[t][key] + (int)p.prank[j];
         // only the permutation is scattered (4 bytes per particle); the particle planes are moved by
@@ -416,7 +439,9 @@ __global__ __launch_bounds__(256) void k_rb_finish(DP p) {
     // corners) is translated through dst_of, whose accesses stay local because mesh neighbours
     // were neighbours in the old order too
     auto moved = [&](int rec) { return rec < 0 ? rec : p.dst_of[(unsigned)rec / 3u] * 3 + (int)((unsigned)rec % 3u); };
-    for (unsigned j = i0; j < (unsigned)p.Np; j += gs) {
+    const int nf_out = c->nfa_new, total_out = nf_out + c->nva_new;
+    for (unsigned idx = i0; idx < (unsigned)total_out; idx += gs) {
+        const unsigned j = (unsigned)active_slot(p, (int)idx, nf_out);
         const unsigned i = p.src_of[j];
         const float4 a0 = S.q[0][i], a1 = S.q[1][i], a2 = S.q[2][i], a3 = S.q[3][i];
         const int pid = S.pid[i];
@@ -425,11 +450,19 @@ __global__ __launch_bounds__(256) void k_rb_finish(DP p) {
         if (j < (unsigned)p.Nf) {
             const float4 b0 = S.fq[0][i], b1 = S.fq[1][i], b2 = S.fq[2][i];
             float4 b3 = S.fq[3][i];
-            b3.y = __int_as_float(p.dst_of[__float_as_int(b3.y)]);
-            b3.z = __int_as_float(p.dst_of[__float_as_int(b3.z)]);
-            b3.w = __int_as_float(p.dst_of[__float_as_int(b3.w)]);
+            if (!p.dist.on) {
+                b3.y = __int_as_float(p.dst_of[__float_as_int(b3.y)]);
+                b3.z = __int_as_float(p.dst_of[__float_as_int(b3.z)]);
+                b3.w = __int_as_float(p.dst_of[__float_as_int(b3.w)]);
+            } else {
+                // partitioned domain: particles come and go, so the references are rebuilt from the
+                // (replicated) topology through the new id -> slot map; -1 = that corner is not here
+                b3.y = __int_as_float(p.imap[p.idx_orig[0][pid]]);
+                b3.z = __int_as_float(p.imap[p.idx_orig[1][pid]]);
+                b3.w = __int_as_float(p.imap[p.idx_orig[2][pid]]);
+            }
             D.fq[0][j] = b0; D.fq[1][j] = b1; D.fq[2][j] = b2; D.fq[3][j] = b3;
-        } else {
+        } else if (!p.dist.on) {
             int4 r0 = S.va[0][i - p.Nf], r1 = S.va[1][i - p.Nf];
             if (r0.x != -2) {
                 r0 = make_int4(moved(r0.x), moved(r0.y), moved(r0.z), moved(r0.w));
@@ -437,6 +470,23 @@ __global__ __launch_bounds__(256) void k_rb_finish(DP p) {
             }
             D.va[0][j - p.Nf] = r0;
             D.va[1][j - p.Nf] = r1;
+        } else {
+            // (face slot * 3 + corner) of the adjacent faces, ascending original face id; -3 = a face
+            // that is not on this rank (legal around a ghost vertex, an error around an owned one)
+            const int vo = pid - p.Nf, e0 = p.adj_off[vo], e1 = p.adj_off[vo + 1];
+            int rec[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                rec[q] = -1;
+                if (e0 + q < e1) {
+                    const int fc = p.adj_fc[e0 + q];
+                    const int fs = p.imap[fc >> 2];
+                    rec[q] = fs < 0 ? -3 : fs * 3 + (fc & 3);
+                }
+            }
+            if (e1 - e0 > 8) rec[0] = -2;
+            D.va[0][j - p.Nf] = make_int4(rec[0], rec[1], rec[2], rec[3]);
+            D.va[1][j - p.Nf] = make_int4(rec[4], rec[5], rec[6], rec[7]);
         }
     }
     // every cell row of a home block holds prefix values now: clear whole rows
@@ -464,6 +514,9 @@ __global__ __launch_bounds__(256) void k_rb_finish(DP p) {
                 c->cur ^= 1;
                 c->need_rebuild = 0;
                 c->rebuilds += 1;
+                c->nfa = c->nfa_new;
+                c->nva = c->nva_new;
+                c->add_f = c->add_v = 0;
             }
         }
     }

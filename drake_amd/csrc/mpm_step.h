@@ -15,11 +15,23 @@ namespace mpm {
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_fem(DP p, float dt) {
     const unsigned i = xcd_chunk(blockIdx.x, gridDim.x) * 256 + threadIdx.x;
-    if (i >= (unsigned)p.Nf) return;
+    if (i >= (unsigned)p.ctl->nfa) return;
     const PSet& S = p.set[p.ctl->cur];
     const float4 f0 = S.fq[0][i], f1 = S.fq[1][i], f2 = S.fq[2][i], f3 = S.fq[3][i];
     const unsigned s0 = (unsigned)__float_as_int(f3.y), s1 = (unsigned)__float_as_int(f3.z),
                    s2 = (unsigned)__float_as_int(f3.w);
+    if (p.dist.on && (int)(s0 | s1 | s2) < 0) {
+        // partitioned domain: a corner vertex of this face is not on this rank, so its state cannot
+        // be advanced here.  The vertex band is wider than the face band by ghost_margin_cells exactly
+        // so that this never happens; if it does, a mesh edge is longer than that margin.
+        atomicOr(&p.ctl->error, ERR_HALO);
+        const float nan = __int_as_float(0x7FC00000);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) p.G4[(size_t)i * 3 + c] = make_float4(nan, nan, nan, 0.f);
+        p.ab0[i] = make_float4(nan, nan, nan, nan);
+        p.ab1[i] = make_float2(nan, nan);
+        return;
+    }
     const float4 xa = S.q[0][s0], xb = S.q[0][s1], xc = S.q[0][s2];
     const float4 va = S.q[1][s0], vb = S.q[1][s1], vc = S.q[1][s2];
     float4 q0 = S.q[0][i], q1 = S.q[1][i];
@@ -35,7 +47,7 @@ __global__ __launch_bounds__(256) void k_fem(DP p, float dt) {
     const float Dm[4] = {f2.y, f2.z, f2.w, f3.x};
     float C[9];
     unpack_C(q1, q2, q3, C);
-    const float vol = q0.w;
+    const float vol = fabsf(q0.w);   // (the sign marks ghost copies in a partitioned domain)
 
     // normal column evolves with the affine velocity field (:216-226)
     float cF[9];
@@ -86,12 +98,24 @@ __global__ __launch_bounds__(256) void k_fem(DP p, float dt) {
 // load and one 16-byte gather per adjacent face.
 __global__ __launch_bounds__(256) void k_vforce(DP p) {
     const int k = (int)(xcd_chunk(blockIdx.x, gridDim.x) * 256 + threadIdx.x);
-    if (k >= p.Nv) return;
+    if (k >= p.ctl->nva) return;
     const int s = p.Nf + k;
     float f0 = 0.f, f1 = 0.f, f2 = 0.f;
     const PSet& S = p.set[p.ctl->cur];
     const int4 r0 = S.va[0][k], r1 = S.va[1][k];
     const int rec[8] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w};
+    if (p.dist.on) {
+        // a face next to this vertex is missing on this rank (-3): fine for a ghost vertex, whose force
+        // nobody uses; for an owned one the result would be wrong, so it becomes NaN and is reported
+        bool missing = false;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) missing |= rec[q] == -3;
+        if (missing) {
+            const float v = S.q[0][s].w > 0.f ? __int_as_float(0x7FC00000) : 0.f;
+            p.f[0][s] = v; p.f[1][s] = v; p.f[2][s] = v;
+            return;
+        }
+    }
     if (rec[0] != -2) {
         float4 g[8];
 #pragma unroll
@@ -109,7 +133,9 @@ __global__ __launch_bounds__(256) void k_vforce(DP p) {
         const int vo = S.pid[s] - p.Nf;
         for (int e = p.adj_off[vo]; e < p.adj_off[vo + 1]; ++e) {
             const int fc = p.adj_fc[e];
-            const float4 g = p.G4[(size_t)p.imap[fc >> 2] * 3 + (fc & 3)];
+            const int fs = p.imap[fc >> 2];
+            const float4 g = fs >= 0 ? p.G4[(size_t)fs * 3 + (fc & 3)]
+                                     : make_float4(S.q[0][s].w > 0.f ? __int_as_float(0x7FC00000) : 0.f, 0.f, 0.f, 0.f);
             f0 += -g.x;
             f1 += -g.y;
             f2 += -g.z;
@@ -296,7 +322,7 @@ __global__ __launch_bounds__(512, 4) void k_p2g(DP p, float dt) {  // <= 128 VGP
         const int4 rg = p.home_range[h];
         const int nfb = rg.y - rg.x;
         unsigned mymask = 0;
-        bool hard = false, in_range = true;
+        bool hard = false, in_range = true, halo_bad = false;
         // Every wave streams through its own groups of <= 64 particles; no workgroup barrier inside.
         // Groups are runs of whole cells (faces and vertices of the same cells together), laid out
         // at the last rebuild: a group usually spans two base cells.
@@ -343,7 +369,9 @@ __global__ __launch_bounds__(512, 4) void k_p2g(DP p, float dt) {  // <= 128 VGP
             if (prof) tq[0] = __builtin_readcyclecounter();
             const bool act = cur.act, is_face = cur.is_face;
             const Stencil st = make_stencil(p, cur.x[0], cur.x[1], cur.x[2], ox, oy, oz);
-            const float m = cur.vol * p.M.density;
+            // partitioned domain: a ghost copy (vol < 0) scatters nothing, its owner does
+            const bool own = cur.vol > 0.f;
+            const float m = own ? cur.vol * p.M.density : 0.f;
             float Y[16];
             {
                 float B[9];
@@ -371,8 +399,17 @@ __global__ __launch_bounds__(512, 4) void k_p2g(DP p, float dt) {  // <= 128 VGP
                     Y[r * 4 + 3] = B[r * 3 + 2] * p.dx;
                 }
                 Y[12] = m; Y[13] = 0.f; Y[14] = 0.f; Y[15] = 0.f;
+                if (!own) {
+#pragma unroll
+                    for (int k = 0; k < 12; ++k) Y[k] = 0.f;
+                }
             }
             if (act) hard |= st.hard_out;
+            if (p.dist.on && act && own) {
+                // the stencil of an owned particle must stay inside the blocks the neighbour receives
+                const int gx = ox + st.rx;
+                halo_bad |= gx < p.dist.own_lo - p.dist.zone_cells || gx + 2 >= p.dist.own_hi + p.dist.zone_cells;
+            }
             // the raw registers are dead now: start the next group's loads, they complete while this
             // group goes through the LDS / matrix-pipe phases below (which never wait on vmcnt)
             if (g + 8 < ngroups) cur = load_raw(g + 8);
@@ -499,6 +536,7 @@ __global__ __launch_bounds__(512, 4) void k_p2g(DP p, float dt) {  // <= 128 VGP
         if (mymask && lane == 0) atomicOr(&s_mask, mymask);
         if (__ballot(hard) && lane == 0) atomicOr(&ctl->error, ERR_DRIFT);
         if (__ballot(!in_range) && lane == 0) atomicOr(&ctl->error, ERR_RANGE);
+        if (p.dist.on && __ballot(halo_bad) && lane == 0) atomicOr(&ctl->error, ERR_HALO);
         __syncthreads();
         if ((diag_flags(p) & 4) && tid == 0) atomicAdd(&p.dbgbuf[15], (unsigned long long)__builtin_readcyclecounter() - tb1);
         float4* out = p.slab + (size_t)item * TILE_N;
@@ -693,9 +731,16 @@ MPM_DEV void load_tile(const DP& p, unsigned h, float4* tile, const float4* fiel
     }
 }
 
-MPM_DEV bool g2p_particle(const DP& p, const PSet& S, const float4* tile, unsigned i, float x, float y, float z,
-                             float vol, int ox, int oy, int oz, float dt) {
+// returns bit 0: the advected particle no longer fits the tile (re-sort needed); bit 1: partitioned
+// domain, the stencil of a ghost copy reached nodes whose sums this rank does not have in full
+MPM_DEV int g2p_particle(const DP& p, const PSet& S, const float4* tile, unsigned i, float x, float y, float z,
+                            float vol, int ox, int oy, int oz, float dt) {
     const Stencil st = make_stencil(p, x, y, z, ox, oy, oz);
+    int bits = 0;
+    if (p.dist.on && vol < 0.f) {
+        const int gx = ox + st.rx;
+        if (gx < p.dist.own_lo - p.dist.zone_cells || gx + 2 >= p.dist.own_hi + p.dist.zone_cells) bits = 2;
+    }
     float nv[3] = {0.f, 0.f, 0.f}, nC[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     const float4* base = tile + ((st.rx * TILE_W + st.ry) * TILE_W + st.rz);
     // The stencil weight is a product w_i(x) w_j(y) w_k(z), so the 27-node sums
@@ -739,7 +784,7 @@ MPM_DEV bool g2p_particle(const DP& p, const PSet& S, const float4* tile, unsign
     }
     if (diag_flags(p) & 256) {  // ablation: no stores
         if (nv[0] + nC[0] + nC[4] + nC[8] == 1.2345e30f) S.q[1][i].x = nv[0];
-        return false;
+        return 0;
     }
     const float sc = 4.f * p.dxinv;
     const float ca = (p.M.V + 1.f) * .5f, cb = (p.M.V - 1.f) * .5f;
@@ -760,7 +805,7 @@ MPM_DEV bool g2p_particle(const DP& p, const PSet& S, const float4* tile, unsign
     const float guard = .125f, top = (float)(TILE_W - 2) - guard;
     const float tx = xn * p.dxinv - .5f - (float)ox, ty = yn * p.dxinv - .5f - (float)oy,
                 tz = zn * p.dxinv - .5f - (float)oz;
-    return !(tx >= guard && tx < top && ty >= guard && ty < top && tz >= guard && tz < top);
+    return bits | (int)!(tx >= guard && tx < top && ty >= guard && ty < top && tz >= guard && tz < top);
 }
 
 constexpr int G2P_THREADS = 512;
@@ -795,7 +840,7 @@ __global__ __launch_bounds__(G2P_THREADS) void k_g2p(DP p, float dt) {
         // the first positions are requested before the tile is staged, later ones one iteration
         // ahead, so the HBM latency of the particle stream hides behind LDS work
         int u = (int)threadIdx.x;
-        bool left = false;
+        int left = 0;
         unsigned i = slot_of(u < total ? u : 0);
         float4 pq = S.q[0][i];
         load_tile(p, h, tile, p.gv, G2P_THREADS);
@@ -817,7 +862,8 @@ __global__ __launch_bounds__(G2P_THREADS) void k_g2p(DP p, float dt) {
         }
         // a plain store: the flag only ever goes 0 -> 1 inside this kernel (same-address atomics
         // from thousands of waves would serialise at the memory side)
-        if (__ballot(left) && (threadIdx.x & 63) == 0) p.ctl->need_rebuild = 1;
+        if (__ballot(left & 1) && (threadIdx.x & 63) == 0) p.ctl->need_rebuild = 1;
+        if (p.dist.on && __ballot(left & 2) && (threadIdx.x & 63) == 0) atomicOr(&p.ctl->error, ERR_HALO);
         if (prof && (threadIdx.x & 63) == 0) {
             const unsigned long long t2 = __builtin_readcyclecounter();
             atomicAdd(&p.dbgbuf[8], t1 - t0);

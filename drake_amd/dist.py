@@ -12,8 +12,11 @@ buffers are device tensors and the engine runs on torch's current stream, so not
 synchronises with the host.  With "gloo" (CPU tests, or two ranks sharing one GPU in the GPU
 test) the buffers are staged through host memory.
 
-Particles never change owner here: a scene must keep each rank's particles within
-`zone_blocks` layers of its own patch (true for the benchmark scenes, which move along z).
+`HaloChain` (weak scaling): every rank owns its own cloth patches in its own local frame; particles
+never change owner, a scene must keep each rank's particles within `zone_blocks` layers of its
+patch.  `DomainChain` (strong scaling): the ranks cut ONE domain into x slabs (global coordinates,
+pitch 0); every rank was finalised with the whole scene and keeps its slab's particles plus ghost
+copies next to the cuts (mpm_dist_init); particles migrate between neighbours every few substeps.
 """
 from __future__ import annotations
 
@@ -134,3 +137,68 @@ class HaloChain:
 def attach_engine_to_torch_stream(engine):
     """Run the engine on torch's current stream so that RCCL transfers and kernels are ordered."""
     engine.set_stream(torch.cuda.current_stream().cuda_stream)
+
+
+class DomainChain(HaloChain):
+    """One domain, `world` x slabs cut at the block indices `cuts` (world + 1 ascending values).
+
+    Per substep the same exchange as HaloChain (shift 0: all ranks use global block coordinates).
+    Every `migrate_every` substeps, before the substep, the ranks swap migration records:
+    mpm_dist_migrate_pack -> send/recv with both neighbours -> mpm_dist_migrate_apply."""
+
+    def __init__(self, engine, rank: int, world: int, cuts, zone_blocks: int = 2, ghost_cells: int = 2,
+                 ghost_margin_cells: int = 2, capacity_blocks: int = 512, migrate_every: int = 4,
+                 migrate_capacity: int = 8192, device: torch.device | None = None, group=None,
+                 split: bool | None = None):
+        assert len(cuts) == world + 1 and all(a < b for a, b in zip(cuts, cuts[1:]))
+        engine.dist_init(rank, world, list(cuts), zone_blocks, ghost_cells, ghost_margin_cells)
+        super().__init__(engine, rank, world, cut_lo_block=cuts[rank], cut_hi_block=cuts[rank + 1], pitch_blocks=0,
+                         zone_blocks=zone_blocks, capacity_blocks=capacity_blocks, device=device, group=group,
+                         split=split)
+        self.migrate_every, self.mig_cap = int(migrate_every), int(migrate_capacity)
+        self.steps = 0
+        nbytes = engine.dist_migration_buffer_bytes(self.mig_cap)
+        mk = lambda: torch.zeros(nbytes, dtype=torch.uint8, device=self.device)
+        # pack always fills a left and a right buffer; a missing neighbour's stays local
+        self.mig_send = {"l": mk(), "r": mk()}
+        self.mig_recv = {n: mk() for n in (self.left, self.right) if n is not None}
+        self._mig_ops = None
+
+    def migrate(self):
+        if self.world == 1:
+            return
+        e = self.e
+        e.dist_migrate_pack(self.mig_send["l"].data_ptr(), self.mig_send["r"].data_ptr(), self.mig_cap)
+        pairs = [(self.left, self.mig_send["l"]), (self.right, self.mig_send["r"])]
+        pairs = [(n, b) for n, b in pairs if n is not None]
+        if self.staged:
+            cuda = self.device.type == "cuda"
+            if cuda:
+                torch.cuda.synchronize()
+            reqs, hosts = [], {}
+            for n, b in pairs:
+                hosts[n] = torch.empty(b.numel(), dtype=torch.uint8)
+                reqs.append(dist.isend(b.cpu() if cuda else b, n, group=self.group))
+                reqs.append(dist.irecv(hosts[n], n, group=self.group))
+            for r in reqs:
+                r.wait()
+            for n in hosts:
+                self.mig_recv[n].copy_(hosts[n])
+            if cuda:
+                torch.cuda.synchronize()
+        else:
+            if self._mig_ops is None:
+                self._mig_ops = []
+                for n, b in pairs:
+                    self._mig_ops.append(dist.P2POp(dist.isend, b, n, group=self.group))
+                    self._mig_ops.append(dist.P2POp(dist.irecv, self.mig_recv[n], n, group=self.group))
+            for w in dist.batch_isend_irecv(self._mig_ops):
+                w.wait()
+        e.dist_migrate_apply(self.mig_recv[self.left].data_ptr() if self.left is not None else None,
+                             self.mig_recv[self.right].data_ptr() if self.right is not None else None, self.mig_cap)
+
+    def substep(self, dt: float, mpm_bc: int = -1):
+        if self.migrate_every > 0 and self.steps % self.migrate_every == 0 and self.steps > 0:
+            self.migrate()
+        self.steps += 1
+        super().substep(dt, mpm_bc)

@@ -48,7 +48,8 @@ typedef enum {
     MPM_ERR_CAPACITY = -4,    /* internal table overflow                       */
     MPM_ERR_NO_DEVICE = -5,   /* no usable GPU: there is no CPU fallback       */
     MPM_ERR_DOMAIN = -6,      /* a particle left the grid (the reference: undefined behaviour) */
-    MPM_ERR_RANGE = -7        /* a ParticleToGrid node sum was not finite / out of the accumulators' range */
+    MPM_ERR_RANGE = -7,       /* a ParticleToGrid node sum was not finite / out of the accumulators' range */
+    MPM_ERR_HALO = -8         /* partitioned domain: a particle left the zone shared with the neighbour rank */
 } mpm_status;
 
 /* Runtime form of the compile-time constants in settings.h:36-127. */
@@ -363,6 +364,41 @@ MPM_API int mpm_chain_init(mpm_handle_t h, const char id[128], int rank, int wor
                            int pitch_blocks, int zone_blocks, size_t capacity_blocks, int periodic);
 MPM_API int mpm_chain_substeps(mpm_handle_t h, int n_substeps, float dt, int mpm_bc);
 MPM_API int mpm_chain_destroy(mpm_handle_t h);
+
+/* ---- multi-GPU, ONE domain cut into x slabs (strong scaling) ------------------------------
+ * Every rank is created and finalised with the WHOLE scene (same mpm_add_qr_cloth calls: replicated
+ * topology, full-capacity arrays) and then keeps only its share: rank r owns the particles whose
+ * base cell lies in x blocks [own_lo_block, own_hi_block) (the outermost ranks extend to the walls),
+ * plus ghost copies of the neighbours' particles within ghost_cells of a cut.  Ghosts take part in
+ * CalcFemStateAndForce and GridToParticle on both ranks (same inputs, same arithmetic: the copies
+ * stay bit-identical without communication) and scatter nothing in ParticleToGrid.  Per substep the
+ * ranks exchange the node sums of the blocks within zone_blocks of a cut: mpm_substep_begin_halo with
+ * zones [cut - zone_blocks, cut + zone_blocks - 1] and shift 0, then mpm_substep_end_halo (or
+ * mpm_chain_substeps with pitch 0).  Every few substeps particles change hands:
+ *   mpm_dist_migrate_pack -> exchange the two record buffers with the neighbours ->
+ *   mpm_dist_migrate_apply -> (the next RebuildMapping merges / drops them).
+ * Requirements, checked: 4 * zone_blocks >= ghost_cells + ghost_margin_cells + 2; a slab with two
+ * neighbours is at least 2 * zone_blocks wide; a particle whose stencil leaves the shared zone, or a
+ * face that misses a corner vertex (mesh edge longer than ghost_margin_cells), raises MPM_ERR_HALO.
+ * Arrays downloaded from a rank hold NaN / -1 for particles it does not have; mpm_dist_roles tells
+ * which are owned (1), ghosts (2) or absent (0), per slot.  The reference has no multi-GPU path. */
+typedef struct {
+    int32_t rank, world;
+    int32_t own_lo_block, own_hi_block;     /* this rank's x blocks */
+    int32_t left_lo_block, right_hi_block;  /* outer ends of the neighbours' ranges (ignored without neighbour) */
+    int32_t zone_blocks;                    /* depth of the exchanged zone either side of a cut */
+    int32_t ghost_cells;                    /* width of the ghost band for face particles (>= longest mesh edge) */
+    int32_t ghost_margin_cells;             /* the band for vertex particles is wider by this much (>= longest
+                                               mesh edge), so that a ghost face always has its corners */
+} mpm_dist_config_t;
+MPM_API int mpm_dist_init(mpm_handle_t h, const mpm_dist_config_t *config);
+MPM_API size_t mpm_dist_migration_buffer_bytes(size_t capacity_particles);
+/* send_left / send_right: device buffers of mpm_dist_migration_buffer_bytes(capacity) each (both
+ * required; a rank without that neighbour gets an empty one).  recv_*: what the neighbours packed, or NULL. */
+MPM_API int mpm_dist_migrate_pack(mpm_handle_t h, void *send_left, void *send_right, size_t capacity_particles);
+MPM_API int mpm_dist_migrate_apply(mpm_handle_t h, const void *recv_left, const void *recv_right,
+                                   size_t capacity_particles);
+MPM_API int mpm_dist_roles(mpm_handle_t h, uint8_t *roles_out /* n_particles */);
 
 /* Optional, between the two: the part of UpdateGrid and GridToParticle that does not depend on the
  * neighbours' sums (blocks outside the zones given to begin, work items whose tiles do not touch a
