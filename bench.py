@@ -192,10 +192,18 @@ def main():
                     help="also call RebuildMapping(sort=true) every N substeps (SURVEY 8d config 2 variants; "
                          "0 = never, the reference's Drake behaviour and the reported metric)")
     ap.add_argument("--cpu-budget", type=float, default=20.0)
-    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
-                    help="weak: every rank owns one copy of the workload; strong: the ranks share ONE copy")
+    ap.add_argument("--scaling", choices=("weak", "strong"), default="strong",
+                    help="strong (default, BASELINE.json: substeps/s at 1M particles on 1/2/4/8 GPUs): the ranks share "
+                         "ONE copy of the workload; weak: every rank owns its own copy")
+    ap.add_argument("--launcher-selftest", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
 
+    if args.launcher_selftest and "WORLD_SIZE" in os.environ:
+        # (tests/test_bench_helpers.py: what a rank process sees, without touching torch or the GPU)
+        if os.environ.get("RANK") == "0":
+            print(json.dumps({k: os.environ.get(k) for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+                             | {"n_gpus": args.gpus}))
+        return
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # plain `python bench.py --gpus N`: become the launcher.  Nothing has touched the GPU yet.
         sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
@@ -206,7 +214,6 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    assert world == max(args.gpus, 1) or "WORLD_SIZE" in os.environ, (world, args.gpus)
     assert torch.cuda.is_available(), "bench.py needs a GPU (the engine has no CPU fallback)"
     # Multi-GPU transports, tried in this order (the JSON line names the one that was measured):
     #   1. the library's own chain: RCCL send/recv on the engine's stream (mpm_chain_*),
@@ -226,56 +233,102 @@ def main():
         dist.init_process_group("gloo")
 
     from drake_amd import GpuMpm, scenes
-    from drake_amd.dist import HaloChain
+    from drake_amd.dist import DomainChain, HaloChain
     bits, layers, res = scenes.CONFIGS[args.config]
     dt = args.dt
-    g = GpuMpm(bits, device=local_rank)
-    # Weak scaling: every rank owns one 1M-particle cloth stack.  The ranks' patches sit side by
-    # side along x (rank r's local frame is shifted by r * 0.5), so neighbouring stacks share grid
-    # nodes around the cut and exchange them every substep (drake_amd/dist.py).
-    scenes.populate(g, scenes.cloth_stack(layers, res, bits, seed=1234 + rank))
-    nv, nf, npart = g.n_verts, g.n_faces, g.n_particles
     nb = (1 << bits) // 4
-    chain = None
-    native = False
     stream = torch.cuda.Stream()
-    transport = "none"
-    cuts = dict(cut_lo_block=nb // 4, cut_hi_block=3 * nb // 4, pitch_blocks=nb // 2, zone_blocks=2, capacity_blocks=1024)
+    strong = world > 1 and args.scaling == "strong"
 
     def all_ok(flag):   # every rank takes the same decision
+        if world == 1:
+            return flag
         t = torch.tensor([1.0 if flag else 0.0])
         dist.all_reduce(t, op=dist.ReduceOp.MIN)
         return float(t.item()) == 1.0
 
-    if world > 1 and backend != "gloo":
-        # 1. native chain
-        box = [None]
-        try:
-            if rank == 0:
-                box[0] = GpuMpm.chain_unique_id()
-        except Exception as exc:  # noqa: BLE001
-            print(f"[bench] rank 0: no RCCL id ({exc!r})", file=sys.stderr)
-        dist.broadcast_object_list(box, src=0)
-        ok = box[0] is not None
-        if ok:
+    def make_engine(seed):
+        g = GpuMpm(bits, device=local_rank)
+        scenes.populate(g, scenes.cloth_stack(layers, res, bits, seed=seed))
+        return g
+
+    # ---- what every rank holds, and how the ranks are coupled -------------------------------------
+    if strong:
+        # ONE copy of the workload, cut into x slabs of equal width across the cloth (blocks nb/4 .. 3nb/4);
+        # every rank finalises the whole scene and keeps its slab (mpm_dist_init)
+        lo, hi = nb // 4, 3 * nb // 4
+        assert (hi - lo) % world == 0 and (hi - lo) // world >= 2, "the cloth's blocks do not split evenly over the ranks"
+        width = (hi - lo) // world
+        cuts = [0] + [lo + width * r for r in range(1, world)] + [nb]
+        zone = 2 if width >= 4 else 1
+        ghost, margin = (2, 2) if zone == 2 else (1, 1)
+        mig_every = 4 if zone == 2 else 2
+        geometry = dict(cuts=cuts, zone_blocks=zone, ghost_cells=ghost, ghost_margin_cells=margin, migrate_every=mig_every)
+        g = make_engine(1234)
+        chain_args = dict(cut_lo_block=cuts[rank], cut_hi_block=cuts[rank + 1], pitch_blocks=0, zone_blocks=zone,
+                          capacity_blocks=2048)
+        mig_cap = 65536
+    else:
+        # Weak scaling: every rank owns one copy of the workload.  The ranks' patches sit side by side
+        # along x (rank r's local frame is shifted by r * 0.5), so neighbouring stacks share grid nodes
+        # around the cut and exchange them every substep (drake_amd/dist.py).
+        g = make_engine(1234 + rank)
+        chain_args = dict(cut_lo_block=nb // 4, cut_hi_block=3 * nb // 4, pitch_blocks=nb // 2, zone_blocks=2,
+                          capacity_blocks=1024)
+        geometry = dict(patches="one per rank, pitch 0.5 along x")
+    nv, nf, npart = g.n_verts, g.n_faces, g.n_particles
+    chain = None
+    native = False
+    transport = "none"
+
+    if world > 1:
+        if strong:
+            g.dist_init(rank, world, cuts, zone, ghost, margin)
+        if backend != "gloo":
+            # 1. native chain
+            box = [None]
             try:
-                g.chain_init(box[0], rank, world, **cuts)
-                g.chain_substeps(1, dt, -1)
-                g.gpu_sync()
+                if rank == 0:
+                    box[0] = GpuMpm.chain_unique_id()
             except Exception as exc:  # noqa: BLE001
-                print(f"[bench] rank {rank}: native RCCL chain failed ({exc!r})", file=sys.stderr)
-                ok = False
-        native = all_ok(ok)
-        if native:
-            transport = "RCCL send/recv on the engine stream (mpm_chain)"
-        else:
+                print(f"[bench] rank 0: no RCCL id ({exc!r})", file=sys.stderr)
+            dist.broadcast_object_list(box, src=0)
+            ok = box[0] is not None
+            if ok:
+                try:
+                    g.chain_init(box[0], rank, world, **chain_args)
+                    if strong:
+                        g.chain_enable_migration(mig_every, mig_cap)
+                    g.chain_substeps(1, dt, -1)
+                    g.gpu_sync()
+                except Exception as exc:  # noqa: BLE001
+                    print(f"[bench] rank {rank}: native RCCL chain failed ({exc!r})", file=sys.stderr)
+                    ok = False
+            native = all_ok(ok)
+            if native:
+                transport = "RCCL send/recv on the engine stream (mpm_chain)"
+            else:
+                g.chain_destroy()
+
+        def python_chain(group):
+            if strong:
+                c = DomainChain.__new__(DomainChain)
+                # (the engine is partitioned already: build the chain object without a second mpm_dist_init)
+                HaloChain.__init__(c, g, rank, world, device=torch.device("cuda", local_rank), group=group, **chain_args)
+                c.migrate_every, c.mig_cap, c.steps, c._mig_ops = mig_every, mig_cap, 1, None
+                nbytes = g.dist_migration_buffer_bytes(mig_cap)
+                mk = lambda: torch.zeros(nbytes, dtype=torch.uint8, device=c.device)
+                c.mig_send = {"l": mk(), "r": mk()}
+                c.mig_recv = {n: mk() for n in (c.left, c.right) if n is not None}
+                return c
+            return HaloChain(g, rank, world, device=torch.device("cuda", local_rank), group=group, **chain_args)
+
+        if not native and backend != "gloo":
             # 2. torch.distributed over RCCL
             ok = True
             try:
-                g.chain_destroy()
                 g.set_stream(stream.cuda_stream)  # kernels and RCCL transfers ordered through one stream
-                chain = HaloChain(g, rank, world, device=torch.device("cuda", local_rank),
-                                  group=dist.new_group(backend="nccl"), **cuts)
+                chain = python_chain(dist.new_group(backend="nccl"))
                 with torch.cuda.stream(stream):
                     chain.run_substeps(1, dt, -1)
                 torch.cuda.synchronize()
@@ -286,11 +339,11 @@ def main():
                 transport = "RCCL via torch.distributed point-to-point"
             else:
                 chain = None
-    if world > 1 and not native and chain is None:
-        # 3. host-staged
-        g.set_stream(stream.cuda_stream)
-        chain = HaloChain(g, rank, world, device=torch.device("cuda", local_rank), group=None, **cuts)
-        transport = "host-staged (gloo)"
+        if not native and chain is None:
+            # 3. host-staged
+            g.set_stream(stream.cuda_stream)
+            chain = python_chain(None)
+            transport = "host-staged (gloo)"
 
     def barrier():
         if world > 1:
@@ -330,35 +383,51 @@ def main():
 
     # per-kernel timing with HIP events on the engine's stream: a separate, un-timed pass over the
     # SAME substeps (fresh engine, same scene, same warm-up), so that the kernel durations describe
-    # the timed region and not whatever the cloth does after it
+    # the timed region and not whatever the cloth does after it.  (Several ranks: the rank's own
+    # engine as it stands after the run, without the exchange -- kernel durations only.)
     if world == 1:
         g.destroy()
-        g = GpuMpm(bits, device=local_rank)
-        scenes.populate(g, scenes.cloth_stack(layers, res, bits, seed=1234 + rank))
+        g = make_engine(1234)
         g.run_substeps(args.warmup, dt, -1)
         g.gpu_sync()
-    phases, tot_ms = g.profile_substeps(min(args.steps, 4096), dt, -1)
+    phases, tot_ms = g.profile_substeps(min(args.steps, 4096 if world == 1 else 20), dt, -1)
     g.gpu_sync()
     st = g.stats()
-    assert st["error_flags"] == 0, st
     ncells = 64 * st["touched_blocks"]
-    ab = algorithmic_bytes(npart, nf, nv, ncells)
+    # the particles this rank's kernels worked on (all of them unless the domain is partitioned)
+    ab = algorithmic_bytes(st["active_faces"] + st["active_vertices"], st["active_faces"], st["active_vertices"], ncells)
     dom = max(KERNEL_OF, key=lambda k: phases[k])
     ach = ab[dom] / (phases[dom] * 1e-3) / 1e9
+    # the whole job: every particle once per substep (strong: one copy; weak: one copy per rank)
+    copies = 1 if (strong or world == 1) else world
+    # (cells: rank 0's count; a partitioned domain has about `world` times as many, a 1% term)
+    job_bytes = copies * algorithmic_bytes(npart, nf, nv, ncells * world if strong else ncells)["total"]
     roofline = dict(bound="hbm", kernel=KERNEL_OF[dom], achieved=ach, peak=HBM_PEAK_GBS, unit="GB/s",
-                    frac=ach / HBM_PEAK_GBS, traffic=measured_traffic(KERNEL_OF[dom], args.config),
+                    frac=ach / HBM_PEAK_GBS, traffic=measured_traffic(KERNEL_OF[dom], args.config) if world == 1 else None,
+                    traffic_source="profiles/pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this "
+                                   "command, collected by scripts/collect_profiles.sh and committed (replayed, not "
+                                   "measured in this run)",
                     algorithmic_bytes_per_launch=ab[dom], kernel_ms=phases[dom],
-                    substep_achieved=ab["total"] / (el / args.steps) / 1e9,
-                    substep_frac=ab["total"] / (el / args.steps) / 1e9 / HBM_PEAK_GBS, phase_ms=phases)
+                    substep_achieved=job_bytes / (el / args.steps) / 1e9,
+                    substep_frac=job_bytes / (el / args.steps) / 1e9 / (HBM_PEAK_GBS * world), phase_ms=phases)
 
     if rank == 0:
-        out = dict(metric="mpm_substeps_per_sec_1M_particles", value=world * args.steps / el, unit="substeps/s",
+        if world == 1:
+            par = "single GPU"
+        elif strong:
+            par = (f"{world} GPUs share ONE domain: x slabs cut at blocks {cuts}, ghost band {ghost}+{margin} cells, "
+                   f"zone {zone} blocks, migration every {mig_every} substeps, 1 rank/GPU, {transport} per substep")
+        else:
+            par = f"{world} GPUs: x-tiled patches, 1 rank/GPU, {transport} halo of grid-block sums per substep"
+        out = dict(metric="mpm_substeps_per_sec_1M_particles", value=copies * args.steps / el, unit="substeps/s",
                    n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=el / args.steps * 1e3,
-                   higher_is_better=True, scaling="weak", vs_baseline=None, dtype="f32", data="synthetic",
+                   higher_is_better=True, scaling="strong" if strong or world == 1 and args.scaling == "strong" else "weak",
+                   vs_baseline=None, dtype="f32", data="synthetic",
                    config=dict(workload=f"{args.config}: {npart} particles ({nf} faces + {nv} vertices), "
                                         f"{1 << bits}^3 grid, corotated cloth, no contact, dt={dt}",
-                               particles_per_gpu=npart, grid=f"{1 << bits}^3", touched_blocks=st["touched_blocks"],
-                               rebuilds=st["rebuilds"], slot_sort_every=args.sort_every, parallelism=("single GPU" if world == 1 else f"{world} GPUs: x-tiled patches, 1 rank/GPU, {transport} halo of grid-block sums per substep")),
+                               particles_total=npart * copies, particles_rank0=st["active_faces"] + st["active_vertices"],
+                               grid=f"{1 << bits}^3", touched_blocks=st["touched_blocks"], rebuilds=st["rebuilds"],
+                               slot_sort_every=args.sort_every, parallelism=par, geometry=geometry if world > 1 else None),
                    roofline=roofline)
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(bits, layers, res, dt, args.cpu_budget)

@@ -88,7 +88,8 @@ class DistConfig(C.Structure):
 class Stats(C.Structure):
     _fields_ = [
         ("substeps", C.c_uint64), ("rebuilds", C.c_uint64), ("home_blocks", C.c_uint32), ("active_blocks", C.c_uint32),
-        ("touched_blocks", C.c_uint32), ("error_flags", C.c_uint32),
+        ("touched_blocks", C.c_uint32), ("error_flags", C.c_uint32), ("active_faces", C.c_uint32),
+        ("active_vertices", C.c_uint32),
     ]
 
 
@@ -114,7 +115,7 @@ SYMBOLS = [
     "mpm_newton_bisect_f64", "mpm_newton_bisect_f32", "mpm_finalize_external_contact_forces",
     "mpm_spatial_force_shift", "mpm_external_forces_at_body_origin", "mpm_set_grid_colliders",
     "mpm_grid_collider_preset", "mpm_get_contact_stats", "mpm_dist_init", "mpm_dist_migration_buffer_bytes",
-    "mpm_dist_migrate_pack", "mpm_dist_migrate_apply", "mpm_dist_roles",
+    "mpm_dist_migrate_pack", "mpm_dist_migrate_apply", "mpm_dist_roles", "mpm_chain_enable_migration",
 ]
 
 ROOTFIND_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_double, C.POINTER(C.c_double), C.POINTER(C.c_double))
@@ -190,6 +191,7 @@ def load_library(build: bool = True):
         "mpm_dist_migrate_pack": [vp, vp, vp, sz],
         "mpm_dist_migrate_apply": [vp, vp, vp, sz],
         "mpm_dist_roles": [vp, vp],
+        "mpm_chain_enable_migration": [vp, i, sz],
         "mpm_grid_collider_preset": [i, f, vp, sz, P(sz)],
         "mpm_external_forces_at_body_origin": [sz, vp, vp, vp, vp, vp],
     }
@@ -487,6 +489,9 @@ class GpuMpm:
         assert len(unique_id) == 128
         self._ck(self.lib.mpm_chain_init(self.h, C.c_char_p(unique_id), rank, world, cut_lo_block, cut_hi_block,
                                          pitch_blocks, zone_blocks, capacity_blocks, 1 if periodic else 0))
+
+    def chain_enable_migration(self, every: int, capacity_particles: int):
+        self._ck(self.lib.mpm_chain_enable_migration(self.h, every, capacity_particles))
 
     def chain_substeps(self, n: int, dt: float, mpm_bc: int = -1):
         self._ck(self.lib.mpm_chain_substeps(self.h, n, dt, mpm_bc))

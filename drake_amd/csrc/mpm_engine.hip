@@ -648,9 +648,32 @@ int mpm_chain_destroy(mpm_handle_t e) {
     (void)hipStreamSynchronize(e->stream);
     const rccl_rt::Api* a = rccl_rt::api();
     if (c.comm && a) (void)a->comm_destroy(c.comm);
-    for (void* q : {c.send_l, c.send_r, c.recv_l, c.recv_r})
+    for (void* q : {c.send_l, c.send_r, c.recv_l, c.recv_r, c.mig_send_l, c.mig_send_r, c.mig_recv_l, c.mig_recv_r})
         if (q) (void)hipFree(q);
     c = mpm_engine::Chain();
+    return 0;
+}
+
+int mpm_chain_enable_migration(mpm_handle_t e, int every, size_t capacity_particles) {
+    READY(e);
+    mpm_engine::Chain& c = e->chain;
+    REQUIRE(c.comm, "mpm_chain_init first");
+    REQUIRE(e->dp.dist.on, "mpm_dist_init first");
+    REQUIRE(c.pitch == 0 && c.rank == e->dp.dist.rank && c.world == e->dp.dist.world,
+            "the chain of a partitioned domain has pitch 0 and the rank / world given to mpm_dist_init");
+    REQUIRE(every >= 1 && capacity_particles > 0 && capacity_particles < (1u << 28), "bad migration parameters");
+    for (void** q : {&c.mig_send_l, &c.mig_send_r, &c.mig_recv_l, &c.mig_recv_r}) {
+        if (*q) (void)hipFree(*q);
+        *q = nullptr;
+    }
+    c.mig_every = every;
+    c.mig_cap = capacity_particles;
+    c.mig_bytes = mpm_dist_migration_buffer_bytes(capacity_particles);
+    for (void** q : {&c.mig_send_l, &c.mig_send_r, &c.mig_recv_l, &c.mig_recv_r}) {
+        HIP_TRY(hipMalloc(q, c.mig_bytes));
+        HIP_TRY(hipMemsetAsync(*q, 0, c.mig_bytes, e->stream));
+    }
+    HIP_TRY(hipStreamSynchronize(e->stream));
     return 0;
 }
 
@@ -691,17 +714,37 @@ int mpm_chain_substeps(mpm_handle_t e, int n, float dt, int bc) {
     if (c.left >= 0) { lo[nz] = c.zone_lo[0]; hi[nz] = c.zone_hi[0]; sh[nz] = +c.pitch; sb[nz] = c.send_l; rb[nz] = c.recv_l; ++nz; }
     if (c.right >= 0) { lo[nz] = c.zone_lo[1]; hi[nz] = c.zone_hi[1]; sh[nz] = -c.pitch; sb[nz] = c.send_r; rb[nz] = c.recv_r; ++nz; }
     for (int s = 0; s < n; ++s) {
+        if (c.mig_every > 0 && c.steps > 0 && c.steps % (uint64_t)c.mig_every == 0 && nz > 0) {
+            // particles change hands (mpm_dist.h): records to / from both neighbours, same pairing as below
+            if (int rc = mpm_dist_migrate_pack(e, c.mig_send_l, c.mig_send_r, c.mig_cap)) return rc;
+            RCCL_TRY(a->group_start());
+            int rc_g = 0;
+            if (!rc_g && c.left >= 0) rc_g = a->send(c.mig_send_l, c.mig_bytes, 0, c.left, c.comm, e->stream);
+            if (!rc_g && c.right >= 0) rc_g = a->send(c.mig_send_r, c.mig_bytes, 0, c.right, c.comm, e->stream);
+            if (!rc_g && c.right >= 0) rc_g = a->recv(c.mig_recv_r, c.mig_bytes, 0, c.right, c.comm, e->stream);
+            if (!rc_g && c.left >= 0) rc_g = a->recv(c.mig_recv_l, c.mig_bytes, 0, c.left, c.comm, e->stream);
+            const int rc_e = a->group_end();   // (always closes the group, also after a failed call)
+            RCCL_TRY(rc_g);
+            RCCL_TRY(rc_e);
+            if (int rc = mpm_dist_migrate_apply(e, c.left >= 0 ? c.mig_recv_l : nullptr, c.right >= 0 ? c.mig_recv_r : nullptr,
+                                                c.mig_cap))
+                return rc;
+        }
+        c.steps += 1;
         if (int rc = mpm_substep_begin_halo(e, dt, nz, lo, hi, sh, sb, c.cap)) return rc;
         if (nz > 0) {
             RCCL_TRY(a->group_start());
             // what goes to the left arrives "from the right" over there: when both neighbours are the
             // same rank (ring of one or two) the k-th send pairs with the k-th receive, so the receives
             // are posted right-then-left against sends left-then-right
-            if (c.left >= 0) RCCL_TRY(a->send(c.send_l, c.bytes, 0 /* ncclChar */, c.left, c.comm, e->stream));
-            if (c.right >= 0) RCCL_TRY(a->send(c.send_r, c.bytes, 0, c.right, c.comm, e->stream));
-            if (c.right >= 0) RCCL_TRY(a->recv(c.recv_r, c.bytes, 0, c.right, c.comm, e->stream));
-            if (c.left >= 0) RCCL_TRY(a->recv(c.recv_l, c.bytes, 0, c.left, c.comm, e->stream));
-            RCCL_TRY(a->group_end());
+            int rc_g = 0;
+            if (!rc_g && c.left >= 0) rc_g = a->send(c.send_l, c.bytes, 0 /* ncclChar */, c.left, c.comm, e->stream);
+            if (!rc_g && c.right >= 0) rc_g = a->send(c.send_r, c.bytes, 0, c.right, c.comm, e->stream);
+            if (!rc_g && c.right >= 0) rc_g = a->recv(c.recv_r, c.bytes, 0, c.right, c.comm, e->stream);
+            if (!rc_g && c.left >= 0) rc_g = a->recv(c.recv_l, c.bytes, 0, c.left, c.comm, e->stream);
+            const int rc_e = a->group_end();   // a failed call must not leave the group open
+            RCCL_TRY(rc_g);
+            RCCL_TRY(rc_e);
         }
         if (int rc = mpm_substep_end_halo(e, dt, bc, nz, rb, c.cap)) return rc;
     }
@@ -826,6 +869,8 @@ int mpm_get_stats(mpm_handle_t e, mpm_stats_t* out) {
     out->home_blocks = c.n_home;
     out->active_blocks = c.n_active;
     out->error_flags = c.error;
+    out->active_faces = (uint32_t)c.nfa;
+    out->active_vertices = (uint32_t)c.nva;
     out->touched_blocks = 0;
     if (e->grid_state >= 1) {
         uint32_t cnt = 0;

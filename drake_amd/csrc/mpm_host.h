@@ -62,6 +62,11 @@ struct mpm_engine {
         int zone_lo[2] = {0, 0}, zone_hi[2] = {0, 0}, pitch = 0;
         size_t cap = 0, bytes = 0;
         void *send_l = nullptr, *send_r = nullptr, *recv_l = nullptr, *recv_r = nullptr;
+        // partitioned domain: migration records every mig_every substeps
+        int mig_every = 0;
+        size_t mig_cap = 0, mig_bytes = 0;
+        void *mig_send_l = nullptr, *mig_send_r = nullptr, *mig_recv_l = nullptr, *mig_recv_r = nullptr;
+        uint64_t steps = 0;
     } chain;
     bool halo_mid_done = false;   // mpm_substep_mid_halo ran in this substep
     int halo_nz = 0, halo_zlo[2] = {0, 0}, halo_zhi[2] = {0, 0};

@@ -115,6 +115,8 @@ typedef struct {
     uint32_t active_blocks;   /* blocks whose nodes are updated each substep   */
     uint32_t touched_blocks;  /* reference-exact touched count of last P2G     */
     uint32_t error_flags;     /* sticky device error bits (0 = none)           */
+    uint32_t active_faces;    /* particles this engine works on: all of them, or (partitioned   */
+    uint32_t active_vertices; /* domain) the ones it owns plus its ghost copies                 */
 } mpm_stats_t;
 
 MPM_API const char *mpm_last_error(void);
@@ -363,6 +365,9 @@ MPM_API int mpm_chain_unique_id(char id_out[128]);
 MPM_API int mpm_chain_init(mpm_handle_t h, const char id[128], int rank, int world, int cut_lo_block, int cut_hi_block,
                            int pitch_blocks, int zone_blocks, size_t capacity_blocks, int periodic);
 MPM_API int mpm_chain_substeps(mpm_handle_t h, int n_substeps, float dt, int mpm_bc);
+/* Partitioned domain (mpm_dist_init + mpm_chain_init with pitch_blocks = 0): mpm_chain_substeps also
+ * swaps migration records with the neighbours every `every` substeps (mpm_dist_migrate_pack / _apply). */
+MPM_API int mpm_chain_enable_migration(mpm_handle_t h, int every, size_t capacity_particles);
 MPM_API int mpm_chain_destroy(mpm_handle_t h);
 
 /* ---- multi-GPU, ONE domain cut into x slabs (strong scaling) ------------------------------

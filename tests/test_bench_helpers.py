@@ -37,3 +37,23 @@ def test_committed_pmc_summary_feeds_the_roofline_traffic():
     # the dominant kernel must not move (much) more than its algorithmic bytes
     ab = b.algorithmic_bytes(999952, 663552, 336400, 64 * 972)
     assert t["kernels"]["mpm::k_p2g"]["hbm_bytes_per_launch"] < 1.1 * ab["p2g"]
+
+
+def test_gpus_flag_launches_that_many_ranks():
+    """`python bench.py --gpus N` (how the driver calls it) must become N rank processes with the
+    torch.distributed environment set; rank 0 alone prints to stdout."""
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "MASTER_ADDR")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "3", "--launcher-selftest"],
+                         capture_output=True, text=True, timeout=120, env=env)
+    assert out.returncode == 0, out.stderr
+    lines = [ln for ln in out.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1
+    got = json.loads(lines[0])
+    assert got["WORLD_SIZE"] == "3" and got["RANK"] == "0" and got["LOCAL_RANK"] == "0" and got["n_gpus"] == 3
+    assert got["MASTER_ADDR"] == "127.0.0.1" and int(got["MASTER_PORT"]) > 0
+    # a failing rank fails the launch
+    bad = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--no-such-flag"],
+                         capture_output=True, text=True, timeout=120, env=env)
+    assert bad.returncode != 0
