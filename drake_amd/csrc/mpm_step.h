@@ -335,38 +335,50 @@ __global__ __launch_bounds__(512, 4) void k_p2g(DP p, float dt) {  // <= 128 VGP
             float ta[3], tb[3], frc[3];
             bool act, is_face;
         };
-        auto load_raw = [&](int g) {
+        // Loads group gq (clamped to the wave's last one: a harmless repeat) without any branch: a
+        // conditional load merges "loaded" and "not loaded" values right behind the load, and the
+        // compiler then waits for the data there -- ~3.7 us of exposed HBM latency per group.  The
+        // group descriptor is wave-uniform and comes through the scalar cache.
+        const int wvu = __builtin_amdgcn_readfirstlane(wv);
+        const int g_last = wvu < ngroups ? wvu + ((ngroups - 1 - wvu) & ~7) : 0;   // last group of this wave (if it has one)
+        // (the pointer is wave-uniform but was computed from vector loads: move it to scalar registers so
+        // that the descriptor is fetched by s_load, one group ahead of its use)
+        const unsigned long long gaddr = reinterpret_cast<unsigned long long>(groups);
+        const int4* sgroups = reinterpret_cast<const int4*>(
+            ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(gaddr >> 32)) << 32) |
+            (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)gaddr));
+        auto descriptor = [&](int gq) { return sgroups[min(gq, g_last)]; };
+        auto load_raw = [&](const int4& gr) {
             Raw r;
-            const int4 gr = groups[g];
             const int gf = gr.y - gr.x, gn = gf + (gr.w - gr.z);
             r.act = lane < gn;
             r.is_face = lane < gf;
             // unsigned index: lets the loads use the scalar-base + 32-bit-offset addressing form
-            const unsigned ii = (unsigned)(r.act ? (r.is_face ? gr.x + lane : gr.z + (lane - gf)) : (nfb ? rg.x : rg.z));
+            const unsigned dummy = (unsigned)(nfb ? rg.x : rg.z);
+            const unsigned ii = (unsigned)(r.act ? (r.is_face ? gr.x + lane : gr.z + (lane - gf)) : dummy);
             const float4 q0 = S.q[0][ii], q1 = S.q[1][ii], q2 = S.q[2][ii], q3 = S.q[3][ii];
             r.x[0] = q0.x; r.x[1] = q0.y; r.x[2] = q0.z; r.vol = q0.w;
             r.v[0] = q1.x; r.v[1] = q1.y; r.v[2] = q1.z;
             unpack_C(q1, q2, q3, r.C);
-            r.ta[0] = r.ta[1] = r.ta[2] = r.tb[0] = r.tb[1] = r.tb[2] = 0.f;
-            r.frc[0] = r.frc[1] = r.frc[2] = 0.f;
-            if (r.is_face) {
-                const float4 a = p.ab0[ii];
-                const float2 b = p.ab1[ii];
-                r.ta[0] = a.x; r.ta[1] = a.y; r.ta[2] = a.z; r.tb[0] = a.w; r.tb[1] = b.x; r.tb[2] = b.y;
-            } else {
+            // both kinds of per-particle extras are loaded by every lane, the unused one from a fixed
+            // slot (one cache line for the whole wave); the consumer picks by is_face
+            const unsigned fi = r.act && r.is_face ? ii : 0u;
+            const unsigned vi = r.act && !r.is_face ? ii : (unsigned)min(p.Nf, p.Np - 1);
+            const float4 a = p.ab0[fi];
+            const float2 b = p.ab1[fi];
+            r.ta[0] = a.x; r.ta[1] = a.y; r.ta[2] = a.z; r.tb[0] = a.w; r.tb[1] = b.x; r.tb[2] = b.y;
 #pragma unroll
-                for (int d = 0; d < 3; ++d) r.frc[d] = p.f[d][ii];
-            }
+            for (int d = 0; d < 3; ++d) r.frc[d] = p.f[d][vi];
             return r;
         };
         if ((diag_flags(p) & 4) && tid == 0) atomicAdd(&p.dbgbuf[14], (unsigned long long)__builtin_readcyclecounter() - tb0);
-        Raw cur;
-        if (wv < ngroups) cur = load_raw(wv);
+        Raw cur = load_raw(descriptor(wvu));
         const bool prof = (diag_flags(p) & 4) != 0 && wv == 0;
         unsigned long long tq[3] = {0, 0, 0}, pc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-        for (int g = wv; g < ngroups; g += 8) {
+        for (int g = wvu; g < ngroups; g += 8) {
             // ---- 1. one particle per lane (its raw state was prefetched) ----------
             if (prof) tq[0] = __builtin_readcyclecounter();
+            const int4 dnext = descriptor(g + 8);
             const bool act = cur.act, is_face = cur.is_face;
             const Stencil st = make_stencil(p, cur.x[0], cur.x[1], cur.x[2], ox, oy, oz);
             // partitioned domain: a ghost copy (vol < 0) scatters nothing, its owner does
@@ -412,7 +424,7 @@ __global__ __launch_bounds__(512, 4) void k_p2g(DP p, float dt) {  // <= 128 VGP
             }
             // the raw registers are dead now: start the next group's loads, they complete while this
             // group goes through the LDS / matrix-pipe phases below (which never wait on vmcnt)
-            if (g + 8 < ngroups) cur = load_raw(g + 8);
+            cur = load_raw(dnext);
             if (diag_flags(p) & 2) {
                 float acc = 0.f;
 #pragma unroll
