@@ -183,6 +183,11 @@ static int update_contact(mpm_engine* e, int frame, int substep, float dt, float
     const DP& p = e->dp;
     hipStream_t s = e->stream;
     const unsigned gc = (unsigned)((n + 255) / 256);
+    // The pairs name particles by the caller's slot; the engine's internal slots change with every
+    // re-sort (which the device decides by itself, e.g. inside a RebuildMapping between
+    // CopyContactPairs and this call): resolve them again now, from the kept caller indices.
+    hipLaunchKernelGGL(k_ct_slots, dim3(gc), dim3(256), 0, s, (int)n, (const uint32_t*)b.api_idx, e->d_pids_api,
+                       e->dp.imap, b.slot);
     const int n_con_wg = (int)std::min(gc, (unsigned)CT_ROWS);  // grid-stride contact part of k_ct_ls
     const int n_grid_wg = CT_ROWS;                               // grid-stride cell part
     const int n_dir_wg = CT_DIR_WG;

@@ -175,3 +175,47 @@ def test_single_newton_iteration_matches_oracle(exact, params, mu):
     close(g.download(A.CONTACT_VEL), o.c_vel, scale=sc["vel"], rtol=rt, what="1-iteration contact vel")
     tau_g, f_g = g.external_body_force_to_host()
     close(f_g, o.F_f, scale=float(np.abs(o.F_f).max()), rtol=10 * rt, what="1-iteration body impulse")
+
+
+def test_pairs_survive_a_resort_between_copy_and_update():
+    """CopyContactPairs names particles by the caller's slot; the engine's own particle order changes
+    with every internal re-sort.  A RebuildMapping that really re-sorts between CopyContactPairs and
+    UpdateContact must not change the solve."""
+    from drake_amd import ARR as A
+
+    def prepared(seed=5):
+        _, g = build_pair(layers=2, res=24, z0=Z_FLOOR - 0.004, vel_amp=0.3, seed=seed)
+        v = g.download(A.VELOCITIES)
+        v[:, 2] -= 0.5
+        g.upload_particle_state(None, v)
+        g.reallocate_external_bodies(1)
+        for _ in range(2):
+            g.substep(DT, -1)
+        return g
+
+    def grid(g):
+        g.rebuild_mapping(False)
+        g.calc_fem_state_and_force(DT)
+        g.particle_to_grid(DT)
+        g.update_grid(-1)
+
+    a = prepared()
+    grid(a)
+    cp = floor_contacts(a.sync_particle_state_to_cpu())
+    assert cp[0].size > 100
+    a.copy_contact_pairs(*cp)
+    ra = a.update_contact(DT, 0.5, 1e5, 1e-3)
+    b = prepared()
+    grid(b)
+    b.copy_contact_pairs(*cp)
+    n0 = b.stats()["rebuilds"]
+    b.upload_particle_state(b.sync_particle_state_to_cpu())   # same positions: only raises the re-sort flag
+    grid(b)                                                   # RebuildMapping re-sorts, the grid is rebuilt
+    assert b.stats()["rebuilds"] == n0 + 1
+    rb = b.update_contact(DT, 0.5, 1e5, 1e-3)
+    assert abs(ra["iterations"] - rb["iterations"]) <= 2
+    tol = solve_tolerance(a.contact_stats()["dofs"])
+    close(b.download(A.CONTACT_VEL), a.download(A.CONTACT_VEL), scale=1.0, rtol=tol, what="contact vel across a re-sort")
+    close(b.download(A.CONTACT_VEL0), a.download(A.CONTACT_VEL0), scale=1.0, rtol=1e-5, what="contact vel0 across a re-sort")
+    fa, fb = a.external_body_force_to_host()[1], b.external_body_force_to_host()[1]
+    close(fb, fa, scale=float(np.abs(fa).max()), rtol=IMPULSE_RTOL, what="body impulse across a re-sort")
