@@ -116,7 +116,11 @@ SYMBOLS = [
     "mpm_spatial_force_shift", "mpm_external_forces_at_body_origin", "mpm_set_grid_colliders",
     "mpm_grid_collider_preset", "mpm_get_contact_stats", "mpm_dist_init", "mpm_dist_migration_buffer_bytes",
     "mpm_dist_migrate_pack", "mpm_dist_migrate_apply", "mpm_dist_roles", "mpm_chain_enable_migration",
+    "mpm_dist_set_transport",
 ]
+
+EXCHANGE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t)
+ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_double), C.c_size_t)
 
 ROOTFIND_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_double, C.POINTER(C.c_double), C.POINTER(C.c_double))
 
@@ -192,6 +196,7 @@ def load_library(build: bool = True):
         "mpm_dist_migrate_apply": [vp, vp, vp, sz],
         "mpm_dist_roles": [vp, vp],
         "mpm_chain_enable_migration": [vp, i, sz],
+        "mpm_dist_set_transport": [vp, EXCHANGE_FN, ALLREDUCE_FN, vp, sz],
         "mpm_grid_collider_preset": [i, f, vp, sz, P(sz)],
         "mpm_external_forces_at_body_origin": [sz, vp, vp, vp, vp, vp],
     }
@@ -467,6 +472,31 @@ class GpuMpm:
         self._ck(self.lib.mpm_dist_migrate_apply(self.h, C.c_void_p(recv_left_ptr) if recv_left_ptr else None,
                                                  C.c_void_p(recv_right_ptr) if recv_right_ptr else None,
                                                  capacity_particles))
+
+    def dist_set_transport(self, exchange, allreduce, zone_capacity_blocks: int = 1024):
+        """Transport callbacks of the distributed contact solve (see mpm_dist_set_transport):
+        exchange(send_left, send_right, recv_left, recv_right, nbytes) with device addresses (ints),
+        allreduce(numpy float64 array) summing in place over the ranks."""
+        def _ex(_user, sl, sr, rl, rr, nbytes):
+            try:
+                exchange(sl, sr, rl, rr, int(nbytes))
+                return 0
+            except Exception as exc:  # noqa: BLE001
+                print(f"[drake_amd] exchange callback failed: {exc!r}")
+                return 1
+
+        def _ar(_user, values, n):
+            try:
+                a = np.ctypeslib.as_array(values, shape=(int(n),))
+                allreduce(a)
+                return 0
+            except Exception as exc:  # noqa: BLE001
+                print(f"[drake_amd] all-reduce callback failed: {exc!r}")
+                return 1
+
+        self._transport_cbs = (EXCHANGE_FN(_ex), ALLREDUCE_FN(_ar))   # keep them alive
+        self._ck(self.lib.mpm_dist_set_transport(self.h, self._transport_cbs[0], self._transport_cbs[1], None,
+                                                 zone_capacity_blocks))
 
     def dist_roles(self) -> np.ndarray:
         """Per slot: 0 the particle is not on this rank, 1 owned, 2 ghost copy."""

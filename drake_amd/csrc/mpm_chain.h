@@ -24,6 +24,7 @@ using GroupStart = int (*)();
 using GroupEnd = int (*)();
 using Send = int (*)(const void*, size_t, int, int, Comm, hipStream_t);
 using Recv = int (*)(void*, size_t, int, int, Comm, hipStream_t);
+using AllReduce = int (*)(const void*, void*, size_t, int, int, Comm, hipStream_t);
 using GetErrorString = const char* (*)(int);
 struct Api {
     void* lib = nullptr;
@@ -34,6 +35,7 @@ struct Api {
     GroupEnd group_end = nullptr;
     Send send = nullptr;
     Recv recv = nullptr;
+    AllReduce all_reduce = nullptr;
     GetErrorString error_string = nullptr;
 };
 // The process may already hold an RCCL (PyTorch ships one): use that instance, never a second one.
@@ -56,6 +58,7 @@ static const Api* api() {
     a.group_end = (GroupEnd)dlsym(a.lib, "ncclGroupEnd");
     a.send = (Send)dlsym(a.lib, "ncclSend");
     a.recv = (Recv)dlsym(a.lib, "ncclRecv");
+    a.all_reduce = (AllReduce)dlsym(a.lib, "ncclAllReduce");
     a.error_string = (GetErrorString)dlsym(a.lib, "ncclGetErrorString");
     if (!a.get_unique_id || !a.comm_init_rank || !a.comm_destroy || !a.group_start || !a.group_end || !a.send || !a.recv) {
         a.lib = nullptr;

@@ -10,6 +10,7 @@
 #include "mpm_host.h"
 #include "mpm_sort.h"
 #include "mpm_rootfind.h"
+#include "mpm_chain.h"
 
 template <class T>
 static int grow(T** ptr, size_t n) {
@@ -55,6 +56,7 @@ static int ensure_contact_capacity(mpm_engine* e, size_t n) {
         int rc;
         if ((rc = grow(&b.run, cells)) || (rc = grow(&b.node_flag, cells)) || (rc = grow(&b.node_list, cells)) ||
             (rc = grow(&b.node_runs, 27 * cells)) || (rc = grow(&b.gD, cells)) ||
+            (e->dp.dist.on && (rc = grow(&b.hg, 3 * cells))) ||
             (rc = grow(&b.part, (size_t)2 * CT_ROWS * CT_PART)) || (rc = grow(&b.part_dir, (size_t)2 * CT_DIR_WG)) ||
             (rc = grow(&b.st, 1)))
             return rc;
@@ -164,10 +166,80 @@ static ContactDev make_contact_dev(mpm_engine* e, float dt, float mu, float k, f
     c.cnode = b.cnode; c.cfx = b.cfx; c.cmass = b.cmass; c.cphi0 = b.cphi0; c.cR = b.cR; c.cv0 = b.cv0;
     c.crv = b.crv; c.cvel = b.cvel; c.crec = b.crec;
     c.run = b.run; c.node_flag = b.node_flag; c.node_list = b.node_list; c.node_runs = b.node_runs;
-    c.cap_nodes = (int)b.cap_cells; c.gD = b.gD;
+    c.cap_nodes = (int)b.cap_cells; c.gD = b.gD; c.hg = b.hg;
     c.part = b.part; c.part_dir = b.part_dir; c.st = b.st;
     c.body_tau = b.body_tau; c.body_f = b.body_f; c.n_bodies = (int)b.n_bodies;
     return c;
+}
+
+// ---- partitioned domain: transports of the distributed solve ----------------------------------
+static size_t zone_buffer_bytes(size_t cap, int nv) { return (((4 + cap) * 4 + 15) / 16) * 16 + cap * 64 * nv * 16; }
+
+// contact fields of the zone blocks to both neighbours and back: pack -> transport -> add
+static int zone_exchange3(mpm_engine* e, float4* field) {
+    ContactBuffers& b = e->cb;
+    const DP& p = e->dp;
+    hipStream_t s = e->stream;
+    const mpm_engine::Chain& ch = e->chain;
+    const size_t cap = ch.comm ? ch.cap : e->dist_zone_cap;
+    const size_t bytes = zone_buffer_bytes(cap, 3);
+    if (b.zone_bytes < bytes) {
+        for (void*& q : b.zone_buf) {
+            if (q) HIP_TRY(hipFree(q));
+            q = nullptr;
+            HIP_TRY(hipMalloc(&q, bytes));
+            HIP_TRY(hipMemsetAsync(q, 0, bytes, s));
+        }
+        b.zone_bytes = bytes;
+        b.zone_cap = cap;
+    }
+    const Dist& d = p.dist;
+    const int Z = d.zone_cells / 4;
+    // [0] = towards / from the left neighbour, [1] = right
+    ZoneX zs{}, zr{};
+    int n = 0, side[2];
+    if (d.has_left) { zs.lo[n] = d.own_lo / 4 - Z; zs.hi[n] = d.own_lo / 4 + Z - 1; zs.buf[n] = (uint32_t*)b.zone_buf[0]; zr.buf[n] = (uint32_t*)b.zone_buf[2]; side[n++] = 0; }
+    if (d.has_right) { zs.lo[n] = d.own_hi / 4 - Z; zs.hi[n] = d.own_hi / 4 + Z - 1; zs.buf[n] = (uint32_t*)b.zone_buf[1]; zr.buf[n] = (uint32_t*)b.zone_buf[3]; side[n++] = 1; }
+    if (n == 0) return 0;
+    (void)side;
+    for (int k = 0; k < n; ++k) HIP_TRY(hipMemsetAsync(zs.buf[k], 0, 16, s));
+    hipLaunchKernelGGL(k_zone_pack<3>, dim3(e->g_grid, n), dim3(256), 0, s, p, zs, (unsigned)cap, (const float4*)field);
+    if (ch.comm) {
+        const rccl_rt::Api* a = rccl_rt::api();
+        RCCL_TRY(a->group_start());
+        int rc_g = 0;
+        if (!rc_g && ch.left >= 0) rc_g = a->send(b.zone_buf[0], bytes, 0, ch.left, ch.comm, s);
+        if (!rc_g && ch.right >= 0) rc_g = a->send(b.zone_buf[1], bytes, 0, ch.right, ch.comm, s);
+        if (!rc_g && ch.right >= 0) rc_g = a->recv(b.zone_buf[3], bytes, 0, ch.right, ch.comm, s);
+        if (!rc_g && ch.left >= 0) rc_g = a->recv(b.zone_buf[2], bytes, 0, ch.left, ch.comm, s);
+        const int rc_e = a->group_end();
+        RCCL_TRY(rc_g);
+        RCCL_TRY(rc_e);
+    } else {
+        REQUIRE(e->dist_exchange, "partitioned domain: no transport for the contact solve (mpm_chain_init or mpm_dist_set_transport)");
+        HIP_TRY(hipStreamSynchronize(s));
+        if (e->dist_exchange(e->dist_user, b.zone_buf[0], b.zone_buf[1], b.zone_buf[2], b.zone_buf[3], bytes))
+            return fail(MPM_ERR_HIP, "the exchange callback of the distributed contact solve failed");
+    }
+    hipLaunchKernelGGL(k_zone_add<3>, dim3(64, n), dim3(256), 0, s, p, zr, (unsigned)cap, field);
+    return 0;
+}
+
+// sum of n (<= 32) doubles at dev over all ranks, in place
+static int dist_allreduce(mpm_engine* e, double* dev, size_t n) {
+    const mpm_engine::Chain& ch = e->chain;
+    if (ch.comm && rccl_rt::api()->all_reduce) {
+        RCCL_TRY(rccl_rt::api()->all_reduce(dev, dev, n, 8 /* ncclFloat64 */, 0 /* ncclSum */, ch.comm, e->stream));
+        return 0;
+    }
+    REQUIRE(e->dist_allreduce, "partitioned domain: no all-reduce for the contact solve (mpm_chain_init or mpm_dist_set_transport)");
+    double host[32];
+    HIP_TRY(hipMemcpyAsync(host, dev, n * 8, hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    if (e->dist_allreduce(e->dist_user, host, n)) return fail(MPM_ERR_HIP, "the all-reduce callback of the distributed contact solve failed");
+    HIP_TRY(hipMemcpyAsync(dev, host, n * 8, hipMemcpyHostToDevice, e->stream));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    return 0;
 }
 
 static int update_contact(mpm_engine* e, int frame, int substep, float dt, float mu, float stiffness, float damping,
@@ -203,6 +275,13 @@ static int update_contact(mpm_engine* e, int frame, int substep, float dt, float
             return fail(MPM_ERR_HIP, "contact sort failed");
     }
     hipLaunchKernelGGL(k_ct_prepare, dim3(gc), dim3(256), 0, s, p, c);
+    const bool dist = p.dist.on && p.dist.world > 1;
+    if (dist) {
+        // a node in a zone may be reached by the neighbour's contacts only: both ranks need it listed
+        hipLaunchKernelGGL(k_ct_flags_to_field, dim3(512), dim3(256), 0, s, p, c, 0);
+        if (int rc = zone_exchange3(e, b.hg)) return rc;
+        hipLaunchKernelGGL(k_ct_flags_to_field, dim3(512), dim3(256), 0, s, p, c, 1);
+    }
     hipLaunchKernelGGL(k_ct_node_list, dim3(1), dim3(1024), 0, s, p, c);
     hipLaunchKernelGGL(k_ct_node_runs, dim3(1024), dim3(256), 0, s, p, c);
     // pre-contact velocity at the contact points (cuda_mpm_solver.cu:267-272)
@@ -214,7 +293,34 @@ static int update_contact(mpm_engine* e, int frame, int substep, float dt, float
     ContactState st{};
     int iters = 0;
     float residual = 1e10f;
-    if (!exact) {
+    auto newton_direction = [&](int first) -> int {
+        hipLaunchKernelGGL(k_ct_contact_grad, dim3(gc), dim3(256), 0, s, p, c, first);
+        if (!dist) {
+            hipLaunchKernelGGL(k_ct_node_dir<0>, dim3(n_dir_wg), dim3(CT_WG), 0, s, p, c);
+            return 0;
+        }
+        hipLaunchKernelGGL(k_ct_node_dir<1>, dim3(n_dir_wg), dim3(CT_WG), 0, s, p, c);
+        if (int rc = zone_exchange3(e, b.hg)) return rc;
+        hipLaunchKernelGGL(k_ct_node_dir<2>, dim3(n_dir_wg), dim3(CT_WG), 0, s, p, c);
+        return 0;
+    };
+    if (!exact && dist) {
+        // one iteration at a time: every iteration has two exchanges with the other ranks
+        while (true) {
+            if (int rc = newton_direction(iters == 0)) return rc;
+            hipLaunchKernelGGL(k_ct_ls, dim3(n_con_wg + n_grid_wg), dim3(CT_WG), 0, s, p, c, n_con_wg, 0, 0.f);
+            hipLaunchKernelGGL(k_ct_decide, dim3(1), dim3(1024), 0, s, c, n_dir_wg, n_con_wg, n_grid_wg, 0, 1);
+            if (int rc = dist_allreduce(e, b.st->red, 32)) return rc;
+            hipLaunchKernelGGL(k_ct_decide, dim3(1), dim3(1024), 0, s, c, n_dir_wg, n_con_wg, n_grid_wg, 0, 2);
+            hipLaunchKernelGGL(k_ct_apply, dim3(CT_ROWS), dim3(CT_WG), 0, s, p, c);
+            iters += 1;
+            HIP_TRY(hipMemcpyAsync(&st, b.st, sizeof(ContactState), hipMemcpyDeviceToHost, s));
+            HIP_TRY(hipStreamSynchronize(s));
+            if (st.done || st.iters >= max_iters) break;   // (the same on every rank: decided from the global sums)
+        }
+        iters = st.iters;
+        residual = st.residual;
+    } else if (!exact) {
         // device-resident loop: iterations are launched in batches, kernels of an iteration
         // that starts after convergence return immediately
         const int batch = 8;
@@ -222,7 +328,7 @@ static int update_contact(mpm_engine* e, int frame, int substep, float dt, float
             for (int q = 0; q < batch; ++q) {
                 const int first = (iters + q) == 0;
                 hipLaunchKernelGGL(k_ct_contact_grad, dim3(gc), dim3(256), 0, s, p, c, first);
-                hipLaunchKernelGGL(k_ct_node_dir, dim3(n_dir_wg), dim3(CT_WG), 0, s, p, c);
+                hipLaunchKernelGGL(k_ct_node_dir<0>, dim3(n_dir_wg), dim3(CT_WG), 0, s, p, c);
                 hipLaunchKernelGGL(k_ct_ls, dim3(n_con_wg + n_grid_wg), dim3(CT_WG), 0, s, p, c, n_con_wg, 0, 0.f);
                 hipLaunchKernelGGL(k_ct_decide, dim3(1), dim3(1024), 0, s, c, n_dir_wg, n_con_wg, n_grid_wg, 0);
                 hipLaunchKernelGGL(k_ct_apply, dim3(CT_ROWS), dim3(CT_WG), 0, s, p, c);
@@ -240,7 +346,13 @@ static int update_contact(mpm_engine* e, int frame, int substep, float dt, float
         // DoNewtonWithBisectionFallback)
         auto probe = [&](float alpha, std::tuple<float, float, float>* out) -> int {
             hipLaunchKernelGGL(k_ct_ls, dim3(n_con_wg + n_grid_wg), dim3(CT_WG), 0, s, p, c, n_con_wg, 1, alpha);
-            hipLaunchKernelGGL(k_ct_decide, dim3(1), dim3(1024), 0, s, c, n_dir_wg, n_con_wg, n_grid_wg, 1);
+            if (dist) {
+                hipLaunchKernelGGL(k_ct_decide, dim3(1), dim3(1024), 0, s, c, n_dir_wg, n_con_wg, n_grid_wg, 1, 1);
+                if (int rc2 = dist_allreduce(e, b.st->red, 32)) return rc2;
+                hipLaunchKernelGGL(k_ct_decide, dim3(1), dim3(1024), 0, s, c, n_dir_wg, n_con_wg, n_grid_wg, 1, 2);
+            } else {
+                hipLaunchKernelGGL(k_ct_decide, dim3(1), dim3(1024), 0, s, c, n_dir_wg, n_con_wg, n_grid_wg, 1);
+            }
             HIP_TRY(hipMemcpyAsync(&st, b.st, sizeof(ContactState), hipMemcpyDeviceToHost, s));
             HIP_TRY(hipStreamSynchronize(s));
             *out = std::make_tuple((float)st.scal[0], (float)st.scal[1], (float)st.scal[2]);
@@ -248,10 +360,9 @@ static int update_contact(mpm_engine* e, int frame, int substep, float dt, float
         };
         const float f_tol = 1e-8f, x_tol = f_tol * c.relax;   // cuda_mpm_solver.cu:383-385
         while (residual > c.tol && iters < max_iters) {
-            hipLaunchKernelGGL(k_ct_contact_grad, dim3(gc), dim3(256), 0, s, p, c, iters == 0);
-            hipLaunchKernelGGL(k_ct_node_dir, dim3(n_dir_wg), dim3(CT_WG), 0, s, p, c);
-            std::tuple<float, float, float> f_lo, f_hi, f_root;
             int rc;
+            if ((rc = newton_direction(iters == 0))) return rc;
+            std::tuple<float, float, float> f_lo, f_hi, f_root;
             if ((rc = probe(0.f, &f_lo)) || (rc = probe(1.f, &f_hi))) return rc;
             s_E0_last = std::get<0>(f_lo);   // E(alpha = 0)
             float x_lo = 0.f;

@@ -45,6 +45,8 @@ struct ContactState {       // device-resident solver state
     float dofs;
     float pad2[2];
     double scal[4];         // exact line search: E, dE, d2E at the probed alpha
+    double red[32];         // partitioned domain: this rank's sums (energies[29], |Dir|^2, DoFs) on their way
+                            // through the all-reduce, then the global ones
 };
 
 struct ContactDev {
@@ -75,6 +77,8 @@ struct ContactDev {
     int2* node_runs;        // [27][cap_nodes] contact runs per listed node and stencil offset
     int cap_nodes;
     float4* gD;             // [cells] search direction (relaxed)
+    float4* hg;             // [cells][3] partitioned domain: contact Hessian (9) and gradient (3) sums per node,
+                            // this rank's contacts first, the neighbours' added by the zone exchange
     double* part;           // [2][CT_ROWS][CT_PART] line-search partial sums (contacts, cells)
     double* part_dir;       // [CT_DIR_WG][2] (|Dir|^2, DoFs) per workgroup of k_ct_node_dir
     ContactState* st;
@@ -119,6 +123,9 @@ struct ContactBuffers {
     int* node_list = nullptr;
     int2* node_runs = nullptr;
     float4* gD = nullptr;
+    float4* hg = nullptr;
+    void* zone_buf[4] = {nullptr, nullptr, nullptr, nullptr};   // send left / right, receive left / right
+    size_t zone_cap = 0, zone_bytes = 0;
     double* part = nullptr;
     double* part_dir = nullptr;
     ContactState* st = nullptr;
@@ -127,8 +134,8 @@ struct ContactBuffers {
 
     void release() {
         void* ptrs[] = {api_idx, colliders, gen_cnt, gen_sums, slot, body, dist, normal, pos, rigid_v, p_WB, vel, vel0, key, order, key2, order2, sort_hist,
-                        cnode, cfx, cmass, cphi0, cR, cv0, crv, cvel, crec, run, node_flag, node_list, node_runs, gD, part, part_dir, st,
-                        body_tau, body_f};
+                        cnode, cfx, cmass, cphi0, cR, cv0, crv, cvel, crec, run, node_flag, node_list, node_runs, gD, hg,
+                        zone_buf[0], zone_buf[1], zone_buf[2], zone_buf[3], part, part_dir, st, body_tau, body_f};
         for (void* q : ptrs)
             if (q) (void)hipFree(q);
         *this = ContactBuffers();
@@ -434,6 +441,80 @@ __global__ __launch_bounds__(256) void k_ct_gather_vel(DP p, ContactDev c, float
     out[k * 3 + 2] = v[2];
 }
 
+// ---- partitioned domain: node ownership and the exchange of per-node fields in the zones -------
+// A node belongs to the rank whose slab holds it; nodes of zone blocks exist on both ranks (same
+// values), so global sums count them on their owner only.
+MPM_DEV bool node_owned(const DP& p, int g) {
+    if (!p.dist.on) return true;
+    int bx, by, bz;
+    block_coords(p.act_block[g >> 6], bx, by, bz);
+    const int gx = bx * 4 + ((g & 63) >> 4);
+    return gx >= p.dist.own_lo && gx < p.dist.own_hi;
+}
+
+// Buffer: [0] block count, [4 ..) block ids (cap), then cap * 64 * NV float4.  Same shape as the
+// halo buffers of the grid sums (mpm_step.h) with NV vectors per cell.
+MPM_DEV size_t zone_data_offset(unsigned cap) { return ((size_t)(4 + cap) * 4 + 15) / 16; }
+struct ZoneX {
+    int lo[2], hi[2];
+    uint32_t* buf[2];
+};
+template <int NV>
+__global__ __launch_bounds__(256) void k_zone_pack(DP p, ZoneX z, unsigned cap, const float4* field) {
+    const int k = blockIdx.y;
+    uint32_t* buf = z.buf[k];
+    const unsigned n_active = p.ctl->n_active;
+    float4* data = reinterpret_cast<float4*>(buf) + zone_data_offset(cap);
+    for (unsigned a = blockIdx.x * 4 + (threadIdx.x >> 6); a < n_active; a += gridDim.x * 4) {
+        int bx, by, bz;
+        block_coords(p.act_block[a], bx, by, bz);
+        if (bx < z.lo[k] || bx > z.hi[k]) continue;   // wave-uniform
+        unsigned slot = 0;
+        if ((threadIdx.x & 63) == 0) slot = atomicAdd(&buf[0], 1u);
+        slot = __builtin_amdgcn_readfirstlane(slot);
+        if (slot >= cap) {
+            if ((threadIdx.x & 63) == 0) atomicOr(&p.ctl->error, ERR_CAPACITY);
+            continue;
+        }
+        if ((threadIdx.x & 63) == 0) buf[4 + slot] = p.act_block[a];
+        const size_t cell = (size_t)a * 64 + (threadIdx.x & 63);
+#pragma unroll
+        for (int v = 0; v < NV; ++v) data[((size_t)slot * 64 + (threadIdx.x & 63)) * NV + v] = field[cell * NV + v];
+    }
+}
+template <int NV>
+__global__ __launch_bounds__(256) void k_zone_add(DP p, ZoneX z, unsigned cap, float4* field) {
+    const uint32_t* buf = z.buf[blockIdx.y];
+    const unsigned n = min(buf[0], cap);
+    const float4* data = reinterpret_cast<const float4*>(buf) + zone_data_offset(cap);
+    for (unsigned e = blockIdx.x * 4 + (threadIdx.x >> 6); e < n; e += gridDim.x * 4) {
+        const uint32_t id = buf[4 + e];
+        if (id >= p.nblocks) continue;
+        const int a = p.lut_act[id];
+        if (a < 0) continue;   // nothing of this rank reaches that block
+        const size_t cell = (size_t)a * 64 + (threadIdx.x & 63);
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+            const float4 r = data[((size_t)e * 64 + (threadIdx.x & 63)) * NV + v];
+            float4 q = field[cell * NV + v];
+            q.x += r.x; q.y += r.y; q.z += r.z; q.w += r.w;
+            field[cell * NV + v] = q;
+        }
+    }
+}
+// node_flag (int) <-> the first vector of hg, for the one-off exchange of "this node sees a contact"
+__global__ __launch_bounds__(256) void k_ct_flags_to_field(DP p, ContactDev c, int back) {
+    const int ncell = (int)p.ctl->n_active * 64;
+    for (int g = blockIdx.x * 256 + threadIdx.x; g < ncell; g += gridDim.x * 256) {
+        if (!back) {
+            c.hg[(size_t)g * 3] = make_float4(c.node_flag[g] ? 1.f : 0.f, 0.f, 0.f, 0.f);
+            c.hg[(size_t)g * 3 + 1] = c.hg[(size_t)g * 3 + 2] = make_float4(0.f, 0.f, 0.f, 0.f);
+        } else {
+            c.node_flag[g] = c.hg[(size_t)g * 3].x > 0.f ? 1 : 0;
+        }
+    }
+}
+
 // ---- one Newton iteration ------------------------------------------------------
 
 // C1: refresh contact_vel (from the 2nd iteration on) and evaluate the contact Hessian and
@@ -502,6 +583,10 @@ MPM_DEV void wg_reduce_store(double* vals, double* out) {
 // term and solve for the Newton direction (cuda_mpm_kernels.cuh:1217-1274).  16 lanes per node:
 // the node's contacts are the runs of its 27 neighbour base cells; lane s takes every 16th
 // contact of a run, the 16 partial sums are folded in a fixed butterfly.
+// MODE 0: gather and solve in one pass.  Partitioned domain: MODE 1 gathers this rank's contacts into
+// c.hg (every cell of it is written: zeros where no contact reaches), the zone exchange adds the
+// neighbours' sums, MODE 2 solves from c.hg; |Dir|^2 and the DoF count only include owned nodes.
+template <int MODE>
 __global__ __launch_bounds__(CT_WG) void k_ct_node_dir(DP p, ContactDev c) {
     if (c.st->done) return;   // k_ct_decide does not read the records of a finished solve
     double acc[2] = {0, 0};
@@ -515,7 +600,13 @@ __global__ __launch_bounds__(CT_WG) void k_ct_node_dir(DP p, ContactDev c) {
             const int g = live ? c.node_list[q] : 0;
             float H[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, G[3] = {0.f, 0.f, 0.f};
             const float4 gq = p.gv[g];
-            if (live && gq.w > 0.f) {
+            if (MODE == 2) {
+                if (live && sub == 0) {
+                    const float4 h0 = c.hg[(size_t)g * 3], h1 = c.hg[(size_t)g * 3 + 1], h2 = c.hg[(size_t)g * 3 + 2];
+                    H[0] = h0.x; H[1] = h0.y; H[2] = h0.z; H[3] = h0.w; H[4] = h1.x; H[5] = h1.y; H[6] = h1.z; H[7] = h1.w;
+                    H[8] = h2.x; G[0] = h2.y; G[1] = h2.z; G[2] = h2.w;
+                }
+            } else if (live && gq.w > 0.f) {
                 // lane s owns the runs of stencil offsets s and s + 16 (27 offsets over 16 lanes): the
                 // table walks and the contact loads of different offsets overlap across the lanes, the
                 // loop over a run's contacts is a plain stream
@@ -546,14 +637,22 @@ __global__ __launch_bounds__(CT_WG) void k_ct_node_dir(DP p, ContactDev c) {
                 }
             }
             // fold the 16 lanes of the node (xor butterfly inside a row of 16)
+            if (MODE != 2) {
 #pragma unroll
-            for (int d = 8; d >= 1; d >>= 1) {
+                for (int d = 8; d >= 1; d >>= 1) {
 #pragma unroll
-                for (int t = 0; t < 9; ++t) H[t] += __shfl_xor(H[t], d, 16);
+                    for (int t = 0; t < 9; ++t) H[t] += __shfl_xor(H[t], d, 16);
 #pragma unroll
-                for (int t = 0; t < 3; ++t) G[t] += __shfl_xor(G[t], d, 16);
+                    for (int t = 0; t < 3; ++t) G[t] += __shfl_xor(G[t], d, 16);
+                }
             }
             if (!live || sub != 0) continue;
+            if (MODE == 1) {
+                c.hg[(size_t)g * 3] = make_float4(H[0], H[1], H[2], H[3]);
+                c.hg[(size_t)g * 3 + 1] = make_float4(H[4], H[5], H[6], H[7]);
+                c.hg[(size_t)g * 3 + 2] = make_float4(H[8], G[0], G[1], G[2]);
+                continue;
+            }
             float4 D = make_float4(0.f, 0.f, 0.f, 0.f);
             if (gq.w > 0.f) {
                 float hn = 0.f, gn = 0.f;
@@ -570,8 +669,10 @@ __global__ __launch_bounds__(CT_WG) void k_ct_node_dir(DP p, ContactDev c) {
                     float Hi[9], d[3];
                     inv33(H, Hi);
                     mulv3(Hi, G, d);
-                    acc[0] += (double)(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
-                    acc[1] += 1.0;
+                    if (node_owned(p, g)) {
+                        acc[0] += (double)(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
+                        acc[1] += 1.0;
+                    }
                     D = make_float4(d[0] * c.relax, d[1] * c.relax, d[2] * c.relax, 1.f);
                 }
             }
@@ -648,7 +749,7 @@ __global__ __launch_bounds__(CT_WG) void k_ct_ls(DP p, ContactDev c, int n_con_w
     const int b = (int)blockIdx.x - n_con_wg, nb = (int)gridDim.x - n_con_wg;
     for (int g = b * CT_WG + threadIdx.x; live && g < ncell; g += nb * CT_WG) {
         const float4 q = p.gv[g];
-        if (!(q.w > 0.f)) continue;
+        if (!(q.w > 0.f) || !node_owned(p, g)) continue;
         const float4 vs = p.gvs[g], D = c.gD[g];
         const float o[3] = {q.x - vs.x, q.y - vs.y, q.z - vs.z};
         if (!exact) {
@@ -674,7 +775,10 @@ __global__ __launch_bounds__(CT_WG) void k_ct_ls(DP p, ContactDev c, int n_con_w
 // S: fixed-order sum of the partial records, choice of the step, convergence test
 // (cuda_mpm_solver.cu:472-528, 567-570).  1024 threads: thread (r, e) sums entry e of the rows
 // r, r + 32, ... of every kind; wave 0 adds the 32 row groups in order and decides.
-__global__ __launch_bounds__(1024) void k_ct_decide(ContactDev c, int n_dir_wg, int n_con_wg, int n_grid_wg, int exact) {
+// `phase` (partitioned domain): 0 = sum and decide in one go; 1 = only leave this rank's sums in
+// st->red[0..31] (the host all-reduces them); 2 = decide from the global sums put back into st->red.
+__global__ __launch_bounds__(1024) void k_ct_decide(ContactDev c, int n_dir_wg, int n_con_wg, int n_grid_wg, int exact,
+                                                    int phase = 0) {
     __shared__ double s_sum[32][CT_PART];
     __shared__ double s_dir[16][2];
     ContactState* st = c.st;
@@ -687,6 +791,10 @@ __global__ __launch_bounds__(1024) void k_ct_decide(ContactDev c, int n_dir_wg, 
     const int e = threadIdx.x & 31, r = threadIdx.x >> 5;
     // entries 0..28: energies; 29: norm_dir; 30: dofs
     double v = 0;
+    if (phase == 2) {
+        if (threadIdx.x >= 64) return;
+        v = threadIdx.x < 32 ? st->red[threadIdx.x] : 0.0;
+    } else {
     if (e <= LS_CAND) {
         for (int w = r; w < n_con_wg; w += 32) v += c.part[(size_t)w * CT_PART + e];
         for (int w = r; w < n_grid_wg; w += 32) v += c.part[(size_t)(CT_ROWS + w) * CT_PART + e];
@@ -712,12 +820,17 @@ __global__ __launch_bounds__(1024) void k_ct_decide(ContactDev c, int n_dir_wg, 
     }
     __syncthreads();
     if (threadIdx.x >= 64) return;
-    const int lane = threadIdx.x;
     v = 0;
-    if (lane <= LS_CAND)
-        for (int q = 0; q < 32; ++q) v += s_sum[q][lane];
-    else if (lane <= LS_CAND + 2)
-        for (int q = 0; q < 16; ++q) v += s_dir[q][lane - LS_CAND - 1];
+    if (threadIdx.x <= LS_CAND)
+        for (int q = 0; q < 32; ++q) v += s_sum[q][threadIdx.x];
+    else if (threadIdx.x <= LS_CAND + 2)
+        for (int q = 0; q < 16; ++q) v += s_dir[q][threadIdx.x - LS_CAND - 1];
+    if (phase == 1) {
+        if (threadIdx.x < 32) st->red[threadIdx.x] = v;
+        return;
+    }
+    }
+    const int lane = threadIdx.x;
     if (lane == LS_CAND + 1) st->norm_dir_sq = (float)v;
     if (lane == LS_CAND + 2) st->dofs = (float)v;
     if (exact) {

@@ -1025,6 +1025,17 @@ int mpm_dist_migrate_apply(mpm_handle_t e, const void* recv_left, const void* re
     return 0;
 }
 
+int mpm_dist_set_transport(mpm_handle_t e, mpm_exchange_fn exchange, mpm_allreduce_fn allreduce, void* user,
+                           size_t zone_capacity_blocks) {
+    REQUIRE(e, "null handle");
+    REQUIRE(zone_capacity_blocks > 0 && zone_capacity_blocks < (1u << 24), "bad zone capacity");
+    e->dist_exchange = exchange;
+    e->dist_allreduce = allreduce;
+    e->dist_user = user;
+    e->dist_zone_cap = zone_capacity_blocks;
+    return 0;
+}
+
 int mpm_dist_roles(mpm_handle_t e, uint8_t* out) {
     READY(e);
     REQUIRE(out, "null output");

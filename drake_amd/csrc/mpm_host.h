@@ -95,6 +95,11 @@ struct mpm_engine {
     ContactBuffers cb{};
     mpm_contact_stats_t last_contact{};   // of the last mpm_update_contact
     mpm_dist_config_t dist_cfg{};         // partitioned domain (mpm_dist_init)
+    // transport of the distributed contact solve when there is no native chain (mpm_dist_set_transport)
+    mpm_exchange_fn dist_exchange = nullptr;
+    mpm_allreduce_fn dist_allreduce = nullptr;
+    void* dist_user = nullptr;
+    size_t dist_zone_cap = 1024;
     std::string dump_dir = ".";
     // scratch for downloads
     void* d_stage = nullptr;

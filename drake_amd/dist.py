@@ -164,6 +164,37 @@ class DomainChain(HaloChain):
         self.mig_recv = {n: mk() for n in (self.left, self.right) if n is not None}
         self._mig_ops = None
 
+    def install_contact_transport(self, zone_capacity_blocks: int = 512):
+        """Gives the engine what the distributed contact solve (mpm_update_contact on a partitioned
+        domain) needs when there is no native chain: a neighbour exchange of device buffers and an
+        all-reduce of a few doubles, both over this chain's process group (staged through the host)."""
+        import ctypes
+        import numpy as np
+        hip = ctypes.CDLL("libamdhip64.so")
+        hip.hipMemcpy.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
+
+        def exchange(sl, sr, rl, rr, nbytes):
+            reqs, hosts = [], []
+            for n, src, dst in ((self.left, sl, rl), (self.right, sr, rr)):
+                if n is None:
+                    continue
+                out = torch.empty(nbytes, dtype=torch.uint8)
+                assert hip.hipMemcpy(out.data_ptr(), src, nbytes, 2) == 0   # device -> host
+                inn = torch.empty(nbytes, dtype=torch.uint8)
+                reqs.append(dist.isend(out, n, group=self.group))
+                reqs.append(dist.irecv(inn, n, group=self.group))
+                hosts.append((inn, dst, out))
+            for r in reqs:
+                r.wait()
+            for inn, dst, _ in hosts:
+                assert hip.hipMemcpy(dst, inn.data_ptr(), nbytes, 1) == 0   # host -> device
+
+        def allreduce(values: "np.ndarray"):
+            t = torch.from_numpy(values)
+            dist.all_reduce(t, group=self.group)
+
+        self.e.dist_set_transport(exchange, allreduce, zone_capacity_blocks)
+
     def migrate(self):
         if self.world == 1:
             return

@@ -405,6 +405,26 @@ MPM_API int mpm_dist_migrate_apply(mpm_handle_t h, const void *recv_left, const 
                                    size_t capacity_particles);
 MPM_API int mpm_dist_roles(mpm_handle_t h, uint8_t *roles_out /* n_particles */);
 
+/* UpdateContact on a partitioned domain.  Every rank solves for the grid nodes it holds with the
+ * contacts of the particles it OWNS (pass only those to mpm_copy_contact_pairs;
+ * mpm_generate_contact_pairs does so by itself).  Per Newton iteration the ranks (1) exchange the
+ * contact Hessian / gradient sums of the nodes in the zones next to the cuts (a node there can be
+ * reached by contacts of both ranks), after which both compute the same direction for it, and (2)
+ * all-reduce the line-search energies, sum |Dir|^2 and the DoF count -- the scalars the reference
+ * reads back per iteration (cuda_mpm_solver.cu:318-319, 359-363, 515-517, 567-570); shared nodes are
+ * counted on their owner.  The step and the stopping decision then agree on all ranks.
+ * Transport: the native chain when mpm_chain_init was called (RCCL on the engine's stream), else the
+ * two callbacks below.  exchange: send_* / recv_* are device buffers of `bytes` bytes each, the
+ * engine's stream has been synchronised before the call and the received bytes must be in place on
+ * return (a missing neighbour's buffers are to be ignored).  allreduce: sum `n` doubles in place over
+ * all ranks (host memory).  Per-body impulses (mpm_external_body_force_to_host) are per-rank partial
+ * sums: add them over the ranks. */
+typedef int (*mpm_exchange_fn)(void *user, void *send_left, void *send_right, void *recv_left, void *recv_right,
+                               size_t bytes);
+typedef int (*mpm_allreduce_fn)(void *user, double *values, size_t n);
+MPM_API int mpm_dist_set_transport(mpm_handle_t h, mpm_exchange_fn exchange, mpm_allreduce_fn allreduce, void *user,
+                                   size_t zone_capacity_blocks);
+
 /* Optional, between the two: the part of UpdateGrid and GridToParticle that does not depend on the
  * neighbours' sums (blocks outside the zones given to begin, work items whose tiles do not touch a
  * zone), to be enqueued while the exchange is in flight; mpm_substep_end_halo then only does the rest. */

@@ -101,3 +101,120 @@ def test_partitioned_domain_matches_single_engine(world, cuts, migrate_every):
     close(pos, rp, scale=1.0, rtol=1e-5, what=f"domain x{world}: positions vs single engine")
     close(vel, rv, scale=vs, rtol=1e-4, what=f"domain x{world}: velocities vs single engine")
     close(F, rF, scale=1.0, rtol=1e-4, what=f"domain x{world}: F vs single engine")
+
+
+# ---- distributed contact solve ---------------------------------------------------------------
+FLOOR_Z = 0.5
+
+
+def _contact_scene():
+    from drake_amd import scenes
+    sheets = scenes.cloth_stack(2, 36, BITS, z0=FLOOR_Z - 0.004, side=0.4, seed=33, vel_amp=0.3)
+    for pos, vel, idx in sheets:
+        vel[:, 2] -= 0.5
+        vel[:, 0] += 0.3
+    return sheets
+
+
+def _floor():
+    from drake_amd import Collider
+    return [Collider(0, body=0, p_WB=(0.5, 0.5, FLOOR_Z))]
+
+
+def _contact_worker(rank, world, cuts, port, q, exact):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from drake_amd import ARR, GpuMpm, scenes
+    from drake_amd.dist import DomainChain
+    g = GpuMpm(BITS)
+    scenes.populate(g, _contact_scene())
+    chain = DomainChain(g, rank, world, cuts, zone_blocks=2, ghost_cells=2, ghost_margin_cells=2, capacity_blocks=512,
+                        migrate_every=4, migrate_capacity=4096, device=torch.device("cuda", 0))
+    chain.install_contact_transport(512)
+    out = []
+    for step in range(3):
+        # one coupled substep: the halves of the substep around the exchange, with the contact solve between
+        # UpdateGrid and GridToParticle (deformable_driver.h:244-258)
+        g.reallocate_external_bodies(1)
+        if chain.migrate_every and step and step % chain.migrate_every == 0:
+            chain.migrate()
+        g.substep_begin(DT)
+        chain.exchange()
+        g.update_grid_from_sums(-1)
+        n = g.generate_contact_pairs(_floor())
+        r = g.update_contact(DT, 0.5, 1e5, 1e-3, exact_line_search=exact)
+        cs = g.contact_stats()
+        tau, f = g.external_body_force_to_host()
+        g.grid_to_particle(DT)
+        out.append((n, r, cs, f.copy()))
+    g.gpu_sync()
+    q.put((rank, g.dist_roles(), g.download(ARR.POSITIONS), g.download(ARR.VELOCITIES), out, g.stats()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("exact", [False, True])
+def test_distributed_contact_solve_matches_single_engine(exact):
+    """Floor contact under a cloth that straddles the cut: two ranks, each with the contacts of the
+    particles it owns; zone exchange of the per-node Hessian / gradient sums and all-reduce of the
+    line-search scalars per Newton iteration.  Same iterations, same velocities, and the per-body
+    impulses add up to the single engine's."""
+    import torch.multiprocessing as mp
+    from drake_amd import ARR, GpuMpm, scenes
+    from tests.helpers import IMPULSE_RTOL, close, solve_tolerance
+    world, cuts = 2, [0, 8, 16]
+    ref = GpuMpm(BITS)
+    scenes.populate(ref, _contact_scene())
+    ref_out = []
+    for step in range(3):
+        ref.reallocate_external_bodies(1)
+        ref.rebuild_mapping(False)
+        ref.calc_fem_state_and_force(DT)
+        ref.particle_to_grid(DT)
+        ref.update_grid(-1)
+        n = ref.generate_contact_pairs(_floor())
+        r = ref.update_contact(DT, 0.5, 1e5, 1e-3, exact_line_search=exact)
+        cs = ref.contact_stats()
+        tau, f = ref.external_body_force_to_host()
+        ref.grid_to_particle(DT)
+        ref_out.append((n, r, cs, f.copy()))
+    rp, rv = ref.download(ARR.POSITIONS), ref.download(ARR.VELOCITIES)
+
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 30200 + (os.getpid() % 200) + (7 if exact else 0)
+    procs = [ctx.Process(target=_contact_worker, args=(r, world, cuts, port, q, exact)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = {}
+    for _ in range(world):
+        item = q.get(timeout=600)
+        got[item[0]] = item[1:]
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    n = ref.n_particles
+    pos, vel = np.full((n, 3), np.nan, np.float32), np.full((n, 3), np.nan, np.float32)
+    for r in range(world):
+        roles, p_r, v_r, out, st = got[r]
+        assert st["error_flags"] == 0
+        own = roles == 1
+        pos[own], vel[own] = p_r[own], v_r[own]
+    for step in range(3):
+        n_ref, r_ref, cs_ref, f_ref = ref_out[step]
+        n_sum = sum(got[r][3][step][0] for r in range(world))
+        assert n_sum == n_ref and all(got[r][3][step][0] > 20 for r in range(world))   # both ranks have contacts
+        its = [got[r][3][step][1]["iterations"] for r in range(world)]
+        assert its[0] == its[1]                       # the ranks take the same decisions
+        assert abs(its[0] - r_ref["iterations"]) <= max(1, r_ref["iterations"] // 10), (its, r_ref)
+        dofs = sum(got[r][3][step][2]["dofs"] for r in range(world)) / world
+        assert dofs == cs_ref["dofs"]                 # shared nodes counted once (both ranks hold the global count)
+        f_sum = sum(got[r][3][step][3] for r in range(world))
+        close(f_sum, f_ref, scale=float(np.abs(f_ref).max()), rtol=IMPULSE_RTOL, what=f"distributed contact: body impulse (exact={exact})")
+    tol = solve_tolerance(ref_out[-1][2]["dofs"])
+    close(pos, rp, scale=1.0, rtol=1e-5, what=f"distributed contact: positions (exact={exact})")
+    close(vel, rv, scale=1.0, rtol=tol, what=f"distributed contact: velocities (exact={exact})")
