@@ -108,3 +108,123 @@ def test_chain_exchange_sums_shared_blocks(world):
         for bx in (23, 24):  # active on both sides (the neighbour holds 7..24)
             for by in (10, 11):
                 np.testing.assert_array_equal(got[r][(bx, by, 16)], got[r + 1][(bx - 16, by, 16)])
+
+
+# ---- DomainChain: one domain, particles that change hands --------------------------------------
+REC = 112   # bytes per migration record (7 x 16, drake_amd/csrc/mpm_dist.h)
+
+
+class FakeDomainEngine(FakeEngine):
+    """1-D stand-in for a partitioned engine: particles are (gid, x in cells); rank r owns the cells
+    [lo, hi).  Speaks the engine's migration buffer format (count at byte 0, records of 112 bytes
+    from byte 16: original id, role, ..., x in the first float of the second 16-byte group)."""
+
+    def __init__(self, n_particles, nb):
+        super().__init__({})
+        self.x = {g: 2.0 + g * (nb * 4 - 4.0) / n_particles for g in range(n_particles)}   # everybody has everything
+        self.owned = set()
+        self.calls = []
+
+    def dist_init(self, rank, world, cuts, zone_blocks, ghost_cells, ghost_margin_cells):
+        self.rank, self.world = rank, world
+        self.lo = cuts[rank] * 4 if rank > 0 else -10 ** 9
+        self.hi = cuts[rank + 1] * 4 if rank < world - 1 else 10 ** 9
+        self.owned = {g for g, x in self.x.items() if self.lo <= x < self.hi}
+        self.x = {g: self.x[g] for g in self.owned}
+
+    @staticmethod
+    def dist_migration_buffer_bytes(cap):
+        return 16 + cap * REC
+
+    def _buf(self, ptr, cap):
+        raw = np.ctypeslib.as_array((ctypes.c_uint8 * (16 + cap * REC)).from_address(ptr))
+        return raw[:4].view(np.uint32), raw[16:].reshape(cap, REC)
+
+    def dist_migrate_pack(self, ptr_l, ptr_r, cap):
+        self.calls.append("pack")
+        for ptr, leaving in ((ptr_l, [g for g in self.owned if self.x[g] < self.lo]),
+                             (ptr_r, [g for g in self.owned if self.x[g] >= self.hi])):
+            cnt, recs = self._buf(ptr, cap)
+            cnt[0] = len(leaving)
+            for k, g in enumerate(sorted(leaving)):
+                recs[k, :8].view(np.int32)[:] = (g, 1)
+                recs[k, 16:20].view(np.float32)[0] = self.x[g]
+                self.owned.discard(g)
+                del self.x[g]
+
+    def dist_migrate_apply(self, ptr_l, ptr_r, cap):
+        self.calls.append("apply")
+        for ptr in (ptr_l, ptr_r):
+            if not ptr:
+                continue
+            cnt, recs = self._buf(ptr, cap)
+            for k in range(int(cnt[0])):
+                g, role = (int(v) for v in recs[k, :8].view(np.int32))
+                assert role == 1 and g not in self.owned
+                self.owned.add(g)
+                self.x[g] = float(recs[k, 16:20].view(np.float32)[0])
+
+    def halo_pack(self, lo, hi, shift, ptr, cap):
+        assert shift == 0            # one domain: every rank uses global block coordinates
+        self.calls.append(("halo", lo, hi))
+        super().halo_pack(lo, hi, shift, ptr, cap)
+
+    def substep_begin(self, dt):
+        self.calls.append("begin")
+
+    def substep_end(self, dt, bc):
+        for g in self.x:
+            self.x[g] += 0.7     # cells per substep, towards +x
+        self.calls.append("end")
+
+
+def _domain_worker(rank, world, cuts, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from drake_amd.dist import DomainChain
+    eng = FakeDomainEngine(300, cuts[-1])
+    chain = DomainChain(eng, rank, world, cuts, zone_blocks=2, ghost_cells=2, ghost_margin_cells=2, capacity_blocks=16,
+                        migrate_every=3, migrate_capacity=128)
+    start = set(eng.owned)
+    for _ in range(12):
+        chain.substep(1e-3, -1)
+    q.put((rank, start, set(eng.owned), dict(eng.x), eng.calls, (chain.zone_lo, chain.zone_hi)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,cuts", [(2, [0, 8, 16]), (3, [0, 6, 10, 16])])
+def test_domain_chain_migrates_particles_between_neighbours(world, cuts):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29800 + world + (os.getpid() % 200)
+    procs = [ctx.Process(target=_domain_worker, args=(r, world, cuts, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = {}
+    for _ in range(world):
+        item = q.get(timeout=120)
+        got[item[0]] = item[1:]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    # every particle has exactly one owner before and after, and particles did move to the right
+    for idx in (0, 1):
+        allg = [g for r in range(world) for g in got[r][idx]]
+        assert sorted(allg) == list(range(300))
+    assert len(got[world - 1][1]) > len(got[world - 1][0]) and len(got[0][1]) < len(got[0][0])
+    for r in range(world):
+        start, owned, x, calls, zones = got[r]
+        # ownership is current up to the last migration round (at most 2 substeps of 0.7 cells ago)
+        lo = cuts[r] * 4 if r > 0 else -1e9
+        hi = cuts[r + 1] * 4 if r < world - 1 else 1e9
+        assert all(lo <= x[g] < hi + 3 * 0.7 for g in owned)
+        # cadence: a migration round (pack, apply) before substeps 3, 6, 9 and no other
+        assert calls.count("pack") == 3 and calls.count("apply") == 3
+        begins = [i for i, c in enumerate(calls) if c == "begin"]
+        packs = [i for i, c in enumerate(calls) if c == "pack"]
+        assert [sum(1 for b in begins if b < pk) for pk in packs] == [3, 6, 9]
+        # the zones straddle this rank's cuts in global block coordinates
+        assert zones == ((cuts[r] - 2, cuts[r] + 1), (cuts[r + 1] - 2, cuts[r + 1] + 1))
