@@ -152,8 +152,8 @@ struct ContactBuffers {
         n_bodies = nb;
         // reset at the beginning of each time step (cuda_mpm_model.cu:334-337)
         if (cap_bodies) {
-            (void)hipMemsetAsync(body_tau, 0, cap_bodies * 12, s);
-            (void)hipMemsetAsync(body_f, 0, cap_bodies * 12, s);
+            if (hipMemsetAsync(body_tau, 0, cap_bodies * 12, s) != hipSuccess) return -2;
+            if (hipMemsetAsync(body_f, 0, cap_bodies * 12, s) != hipSuccess) return -2;
         }
         return 0;
     }

@@ -101,6 +101,7 @@ struct DP {
     int nb;                // blocks per axis
     unsigned nblocks, ncells;
     unsigned capH, capA, capI;
+    unsigned capS;         // slabs allocated (<= capI): grown by the host at synchronisation points, see slab_pool_grow
     int item_groups;       // a work item holds at most this many 64-particle wave groups
     int dbg;               // MPM_DBG environment variable (kernel ablation switches, 0 in production)
     float dx, dxinv, Dinv;

@@ -156,7 +156,7 @@ static void launch_fem(mpm_engine* e, float dt) {
     launch_fem_vertices(e);
 }
 static void launch_p2g(mpm_engine* e, float dt) {
-    hipLaunchKernelGGL(k_p2g, dim3(getenv("MPM_P2G_WGS") ? atoi(getenv("MPM_P2G_WGS")) : e->g_tile), dim3(512), 0, e->stream, e->dp, dt);
+    hipLaunchKernelGGL(k_p2g, dim3(e->g_tile), dim3(512), 0, e->stream, e->dp, dt);
     e->last_tile_kernel = 1;
 }
 static void launch_grid(mpm_engine* e, const GridColliders& gc) {
@@ -185,6 +185,13 @@ static int set_fixed_point_scales(mpm_engine* e) {
     p.fix_p = std::ldexp(1.0, k - 14);
     p.unfix_m = 1.0 / p.fix_m;
     p.unfix_p = 1.0 / p.fix_p;
+    // captured launches carry the scales by value
+    if (e->step_graph) (void)hipGraphExecDestroy(e->step_graph);
+    e->step_graph = nullptr;
+    for (auto& kg : e->halo_graph) {
+        if (kg.exec) (void)hipGraphExecDestroy(kg.exec);
+        kg.exec = nullptr;
+    }
     return 0;
 }
 
@@ -207,6 +214,11 @@ int mpm_finalize(mpm_handle_t e) {
     p.halo_cls = -1;
     p.item_groups = getenv("MPM_ITEM_GROUPS") ? std::max(1, atoi(getenv("MPM_ITEM_GROUPS"))) : 48;
     p.capI = p.capH + (unsigned)(np / (64 * (size_t)p.item_groups)) + 16u;
+    // Slabs (16 KB each) are allocated for the blocks a cloth of this size typically occupies, not for
+    // the worst case of one particle per block (capI: 4 GB at 256^3, 33 GB at 512^3); mpm_sync and
+    // mpm_get_stats double the pool when it is more than half full (slab_pool_grow).
+    p.capS = (unsigned)std::min<size_t>(p.capI, std::max<size_t>(4096, np / 256 + 1024));
+    if (getenv("MPM_SLAB_CAPACITY")) p.capS = (unsigned)std::min<size_t>(p.capI, std::max(1, atoi(getenv("MPM_SLAB_CAPACITY"))));
     p.dxinv = (float)(1 << e->bits);
     p.dx = 1.f / p.dxinv;
     p.Dinv = 4.f * p.dxinv * p.dxinv;
@@ -266,7 +278,8 @@ int mpm_finalize(mpm_handle_t e) {
     ALLOC(p.home_groups, np / 64 + p.capH + 2, false);
     ALLOC(p.act_block, p.capA, true);
     ALLOC(p.act_nbr_home, (size_t)p.capA * 27, true);
-    ALLOC(p.slab, (size_t)p.capI * TILE_N, true);
+    HIP_TRY(hipMalloc((void**)&p.slab, (size_t)p.capS * TILE_N * sizeof(float4)));   // (not in `allocs`: regrown)
+    HIP_TRY(hipMemsetAsync(p.slab, 0, (size_t)p.capS * TILE_N * sizeof(float4), e->stream));
     ALLOC(p.slab_mask, p.capI, true);
     ALLOC(p.gv, (size_t)p.capA * 64, true);
     ALLOC(p.gvs, (size_t)p.capA * 64, true);
@@ -325,6 +338,7 @@ int mpm_finalize(mpm_handle_t e) {
     e->g_nf = (unsigned)((nf + 255) / 256);
     e->g_nv = (unsigned)((nv + 255) / 256);
     e->g_tile = std::min(512u, p.capI);  // 2 resident workgroups per CU pulling blocks from a queue
+    if (getenv("MPM_P2G_WGS")) e->g_tile = (unsigned)std::max(1, atoi(getenv("MPM_P2G_WGS")));   // (tuning experiments)
     e->g_grid = std::min(1024u, (p.capA + 3) / 4);
     e->g_rb = getenv("MPM_RB_WGS") ? (unsigned)atoi(getenv("MPM_RB_WGS")) : 2048u;
 
@@ -362,6 +376,7 @@ int mpm_destroy(mpm_handle_t e) {
     for (auto& kg : e->halo_graph)
         if (kg.exec) (void)hipGraphExecDestroy(kg.exec);
     for (void* a : e->allocs) hipFree(a);
+    if (e->dp.slab) hipFree(e->dp.slab);
     if (e->d_stage) hipFree(e->d_stage);
     e->cb.release();
     if (e->own_stream) hipStreamDestroy(e->own_stream);
@@ -392,6 +407,29 @@ int mpm_set_stream(mpm_handle_t e, void* s) {
     return 0;
 }
 
+// The stream is idle and `c` is the current control block: double the slab pool when the work items
+// fill more than half of it.  Slabs only live from ParticleToGrid to UpdateGrid, so between substeps
+// there is nothing to copy; between those two calls the old contents are kept.
+static int slab_pool_grow(mpm_engine* e, const Ctl& c) {
+    DP& p = e->dp;
+    if (p.capS >= p.capI || c.n_items * 2u <= p.capS) return 0;
+    unsigned want = p.capS;
+    while (want < p.capI && c.n_items * 2u > want) want = (unsigned)std::min<size_t>(p.capI, (size_t)want * 2);
+    float4* bigger = nullptr;
+    HIP_TRY(hipMalloc((void**)&bigger, (size_t)want * TILE_N * sizeof(float4)));
+    HIP_TRY(hipMemcpyAsync(bigger, p.slab, (size_t)p.capS * TILE_N * sizeof(float4), hipMemcpyDeviceToDevice, e->stream));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    HIP_TRY(hipFree(p.slab));
+    p.slab = bigger;
+    p.capS = want;
+    drop_step_graph(e);   // captured launches carry the old pointer
+    for (auto& kg : e->halo_graph) {
+        if (kg.exec) (void)hipGraphExecDestroy(kg.exec);
+        kg.exec = nullptr;
+    }
+    return 0;
+}
+
 int mpm_sync(mpm_handle_t e) {
     REQUIRE(e, "null handle");
     if (int rc = use(e)) return rc;
@@ -400,7 +438,13 @@ int mpm_sync(mpm_handle_t e) {
     if (!e->finalized && !e->dp.ctl) return 0;
     Ctl c;
     D2H(e, &c, e->dp.ctl, sizeof(Ctl));
-    if (c.error & ERR_CAPACITY) return fail(MPM_ERR_CAPACITY, "block table overflow");
+    if (e->finalized && !c.error)
+        if (int rc = slab_pool_grow(e, c)) return rc;
+    if (c.error & ERR_CAPACITY)
+        return fail(MPM_ERR_CAPACITY,
+                    "a table of the engine overflowed (home / active blocks, slabs of the work items -- the pool is "
+                    "grown at synchronisation points: call mpm_sync more often while a cloth spreads out, or set "
+                    "MPM_SLAB_CAPACITY --, slabs over one block, halo or migration buffers)");
     if (c.error & ERR_DRIFT)
         return fail(MPM_ERR_DRIFT,
                     "a face particle was re-centred on its corners out of its block's tile: the corner "
@@ -472,8 +516,10 @@ int mpm_halo_pack(mpm_handle_t e, int bx_lo, int bx_hi, int shift_bx, void* dev_
     REQUIRE(e->grid_state == 3, "halo pack needs mpm_grid_gather first");
     REQUIRE(dev_buf && cap > 0 && cap < (1u << 24), "bad halo buffer");
     HIP_TRY(hipMemsetAsync(dev_buf, 0, 16, e->stream));
-    hipLaunchKernelGGL(k_halo_pack, dim3(e->g_grid), dim3(256), 0, e->stream, e->dp, bx_lo, bx_hi, shift_bx,
-                       (unsigned)cap, (uint32_t*)dev_buf);
+    HaloZones z{};
+    z.lo[0] = bx_lo; z.hi[0] = bx_hi; z.shift[0] = shift_bx;
+    z.buf[0] = static_cast<uint32_t*>(dev_buf);
+    hipLaunchKernelGGL(k_halo_pack2, dim3(e->g_grid, 1), dim3(256), 0, e->stream, e->dp, z, (unsigned)cap);
     return 0;
 }
 
@@ -481,7 +527,9 @@ int mpm_halo_add(mpm_handle_t e, const void* dev_buf, size_t cap) {
     READY(e);
     REQUIRE(e->grid_state == 3, "halo add needs mpm_grid_gather first");
     REQUIRE(dev_buf && cap > 0, "bad halo buffer");
-    hipLaunchKernelGGL(k_halo_add, dim3(64), dim3(256), 0, e->stream, e->dp, (unsigned)cap, (const uint32_t*)dev_buf);
+    HaloBufs hb{};
+    hb.buf[0] = static_cast<const uint32_t*>(dev_buf);
+    hipLaunchKernelGGL(k_halo_add2, dim3(64, 1), dim3(256), 0, e->stream, e->dp, hb, (unsigned)cap);
     return 0;
 }
 
@@ -869,6 +917,8 @@ int mpm_get_stats(mpm_handle_t e, mpm_stats_t* out) {
     out->home_blocks = c.n_home;
     out->active_blocks = c.n_active;
     out->error_flags = c.error;
+    if (!c.error)
+        if (int rc = slab_pool_grow(e, c)) return rc;
     out->active_faces = (uint32_t)c.nfa;
     out->active_vertices = (uint32_t)c.nva;
     out->touched_blocks = 0;
@@ -947,7 +997,9 @@ int mpm_set_dump_dir(mpm_handle_t e, const char* dir) {
 
 int mpm_reallocate_external_bodies(mpm_handle_t e, size_t n) {
     READY(e);
-    return e->cb.resize_bodies(n, e->stream);
+    if (e->cb.resize_bodies(n, e->stream))
+        return fail(MPM_ERR_HIP, "ReallocateExternelBodies: device allocation or reset failed");
+    return 0;
 }
 
 int mpm_external_body_force_to_host(mpm_handle_t e, float* tau_out, float* f_out) {

@@ -279,9 +279,11 @@ __global__ __launch_bounds__(1024) void k_rb_tables(DP p) {
             it += ni;
         }
         n_items = (unsigned)total_items;
-        if (n_items > p.capI) {
+        // (capS <= capI: the slab pool is sized by the blocks actually in use and grown by the host
+        // when it fills up; running out between two synchronisation points is a capacity error)
+        if (n_items > p.capS) {
             if (tid == 0) atomicOr(&c->error, ERR_CAPACITY);
-            n_items = p.capI;
+            n_items = p.capS;
         }
         __syncthreads();
         auto bucket_of = [&](unsigned w) {
@@ -328,7 +330,9 @@ __global__ __launch_bounds__(256) void k_rb_scatter(DP p) {
             int packed = -1;
             if (hn >= 0) {
                 const int2 it = p.home_items[hn];
-                packed = it.x | (it.y << 24);
+                // (first item | count << 24) must stay a non-negative int: 127 items per block, 2^24 items
+                if (it.y > 127 || it.x >= (1 << 24)) atomicOr(&p.ctl->error, ERR_CAPACITY);
+                packed = it.x | (min(it.y, 127) << 24);
             }
             p.act_nbr_items[w] = packed;
         }
@@ -383,6 +387,10 @@ __global__ __launch_bounds__(256) void k_rb_scatter(DP p) {
         }
         const int t = j >= p.Nf;
         const int dst = (t ? p.Nf : 0) + p.blkstart[t][key >> 6] + p.cellcnt[t][key] + (int)p.prank[j];
+        if ((unsigned)dst >= (unsigned)p.Np) {   // cannot happen with intact histograms (a diagnostic build can ablate them)
+            atomicOr(&p.ctl->error, ERR_CAPACITY);
+            continue;
+        }
         // only the permutation is scattered (4 bytes per particle); the particle planes are moved by
         // k_rb_finish as a gather, whose writes are fully coalesced
         p.src_of[dst] = (uint32_t)j;

@@ -896,52 +896,6 @@ __global__ __launch_bounds__(G2P_THREADS) void k_g2p(DP p, float dt) {
 MPM_DEV size_t halo_ids_offset() { return 4; }                       // in uint32 units
 MPM_DEV size_t halo_data_offset(unsigned cap) { return ((size_t)(4 + cap) * 4 + 15) / 16; }  // in float4 units
 
-__global__ __launch_bounds__(256) void k_halo_pack(DP p, int bx_lo, int bx_hi, int shift_bx, unsigned cap,
-                                                   uint32_t* buf) {
-    const unsigned n_active = p.ctl->n_active;
-    float4* data = reinterpret_cast<float4*>(buf) + halo_data_offset(cap);
-    for (unsigned a = blockIdx.x * 4 + (threadIdx.x >> 6); a < n_active; a += gridDim.x * 4) {
-        int bx, by, bz;
-        block_coords(p.act_block[a], bx, by, bz);
-        if (bx < bx_lo || bx > bx_hi) continue;   // wave-uniform
-        const int nbx = bx + shift_bx;
-        if (nbx < 0 || nbx >= p.nb) continue;
-        unsigned slot = 0;
-        if ((threadIdx.x & 63) == 0) slot = atomicAdd(&buf[0], 1u);
-        slot = __builtin_amdgcn_readfirstlane(slot);
-        if (slot >= cap) {
-            if ((threadIdx.x & 63) == 0) atomicOr(&p.ctl->error, ERR_CAPACITY);
-            continue;
-        }
-        if ((threadIdx.x & 63) == 0) buf[halo_ids_offset() + slot] = block_id((uint32_t)nbx, (uint32_t)by, (uint32_t)bz);
-        data[(size_t)slot * 64 + (threadIdx.x & 63)] = p.gv[(size_t)a * 64 + (threadIdx.x & 63)];
-    }
-}
-
-__global__ __launch_bounds__(256) void k_halo_add(DP p, unsigned cap, const uint32_t* buf) {
-    const unsigned n = min(buf[0], cap);
-    const float4* data = reinterpret_cast<const float4*>(buf) + halo_data_offset(cap);
-    for (unsigned e = blockIdx.x * 4 + (threadIdx.x >> 6); e < n; e += gridDim.x * 4) {
-        const uint32_t id = buf[halo_ids_offset() + e];
-        if (id >= p.nblocks) continue;
-        const int a = p.lut_act[id];
-        if (a < 0) continue;  // nothing of ours reaches that block
-        if (p.halo_nz > 0) {  // with a split update only zone blocks are still raw sums
-            int hx, hy, hz;
-            block_coords(id, hx, hy, hz);
-            if (!in_halo_zone(p, hx)) {
-                if ((threadIdx.x & 63) == 0) atomicOr(&p.ctl->error, ERR_CAPACITY);
-                continue;
-            }
-        }
-        const size_t g = (size_t)a * 64 + (threadIdx.x & 63);
-        const float4 r = data[(size_t)e * 64 + (threadIdx.x & 63)];
-        float4 q = p.gv[g];
-        q.x += r.x; q.y += r.y; q.z += r.z; q.w += r.w;
-        p.gv[g] = q;
-    }
-}
-
 // both zones / both received buffers of a chain rank in one launch each (blockIdx.y selects)
 struct HaloZones {
     int lo[2], hi[2], shift[2];

@@ -82,7 +82,8 @@ def test_update_contact_matches_oracle(exact, params, mu):
         assert rg["iterations"] <= ro["iterations"] + slack, (rg, ro, step, _diagnose(g, o))
         if params == "soft":
             assert abs(rg["iterations"] - ro["iterations"]) <= slack, (rg, ro, step)
-        assert rg["residual"] <= 1e-4 and ro["residual"] <= 1e-4
+        # (the oracle's float sums can stall just above the tolerance: "Tiny Alpha" steps, cuda_mpm_solver.cu:523-526)
+        assert rg["residual"] <= 1e-4 and ro["residual"] <= 1.5e-4
         close(g.download(A.CONTACT_VEL0), o.c_vel0, scale=sc["vel"], what="contact vel0")
         # converged solves agree to the solver's stopping tolerance (rounding-level agreement: the
         # single-iteration test below)
@@ -200,17 +201,16 @@ def test_pairs_survive_a_resort_between_copy_and_update():
         g.update_grid(-1)
 
     a = prepared()
-    grid(a)
     cp = floor_contacts(a.sync_particle_state_to_cpu())
     assert cp[0].size > 100
     a.copy_contact_pairs(*cp)
+    grid(a)
     ra = a.update_contact(DT, 0.5, 1e5, 1e-3)
     b = prepared()
-    grid(b)
     b.copy_contact_pairs(*cp)
     n0 = b.stats()["rebuilds"]
     b.upload_particle_state(b.sync_particle_state_to_cpu())   # same positions: only raises the re-sort flag
-    grid(b)                                                   # RebuildMapping re-sorts, the grid is rebuilt
+    grid(b)                                                   # this RebuildMapping re-sorts: every internal slot changes
     assert b.stats()["rebuilds"] == n0 + 1
     rb = b.update_contact(DT, 0.5, 1e5, 1e-3)
     assert abs(ra["iterations"] - rb["iterations"]) <= 2
