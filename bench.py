@@ -153,6 +153,48 @@ def cpu_baseline(domain_bits, layers, res, dt, budget_s=20.0):
                 wall_s=time.perf_counter() - t_begin)
 
 
+def contact_leg(device, steps=20, warmup=5):
+    """BASELINE.json configs[2] / SURVEY.md 8(d) config 3, outside the headline timed region: the same
+    1M-particle cloth stack pressed on a rigid floor (half-space z < 0.25), contact pairs made on the
+    device, UpdateContact with the bagging demo's parameters (k = 1e6, d = 1e-5, mu = 1, dt = 2e-4,
+    examples/multibody/deformable/mpm_bagging.cc:9,15-17).  One coupled substep = RebuildMapping ...
+    UpdateGrid, pairs, UpdateContact, GridToParticle (deformable_driver.h:244-258)."""
+    from drake_amd import Collider, GpuMpm, scenes
+    bits, layers, res = scenes.CONFIGS["cloth_1m"]
+    floor_z, k, d, mu, dt = 0.25, 1e6, 1e-5, 1.0, 2e-4
+    g = GpuMpm(bits, device=device)
+    sheets = scenes.cloth_stack(layers, res, bits, z0=floor_z - 0.004)
+    for pos, vel, idx in sheets:
+        vel[:, 2] -= 0.5
+    scenes.populate(g, sheets)
+    g.reallocate_external_bodies(1)
+    floor = [Collider(0, body=0, p_WB=(0.5, 0.5, floor_z))]
+    iters, contacts, t0 = [], [], 0.0
+    for s in range(warmup + steps):
+        if s == warmup:
+            g.gpu_sync()
+            t0 = time.perf_counter()
+        g.rebuild_mapping(False)
+        g.calc_fem_state_and_force(dt)
+        g.particle_to_grid(dt)
+        g.update_grid(-1)
+        n = g.generate_contact_pairs(floor)
+        r = g.update_contact(dt, mu, k, d)
+        g.grid_to_particle(dt)
+        if s >= warmup:
+            iters.append(r["iterations"])
+            contacts.append(n)
+    g.gpu_sync()
+    el = time.perf_counter() - t0
+    st = g.stats()
+    assert st["error_flags"] == 0, st
+    g.destroy()
+    return dict(ms_per_substep=el / steps * 1e3, substeps_per_s=steps / el, contacts=float(np.mean(contacts)),
+                newton_iterations=float(np.mean(iters)), steps=steps, warmup=warmup,
+                params=dict(stiffness=k, damping=d, friction_mu=mu, dt=dt, floor_z=floor_z, line_search="backtracking"),
+                workload="cloth_1m on a half-space, pairs from mpm_generate_contact_pairs (device)")
+
+
 def launch_ranks(n, argv):
     """`python bench.py --gpus N` without torchrun: start N rank processes of this same script
     (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in their environment, rendezvous on 127.0.0.1) and
@@ -195,6 +237,7 @@ def main():
     ap.add_argument("--scaling", choices=("weak", "strong"), default="strong",
                     help="strong (default, BASELINE.json: substeps/s at 1M particles on 1/2/4/8 GPUs): the ranks share "
                          "ONE copy of the workload; weak: every rank owns its own copy")
+    ap.add_argument("--no-contact-leg", action="store_true", help="skip the config-3 (contact) record")
     ap.add_argument("--launcher-selftest", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
 
@@ -429,6 +472,9 @@ def main():
                                grid=f"{1 << bits}^3", touched_blocks=st["touched_blocks"], rebuilds=st["rebuilds"],
                                slot_sort_every=args.sort_every, parallelism=par, geometry=geometry if world > 1 else None),
                    roofline=roofline)
+        if not args.no_contact_leg and world == 1:
+            g.destroy()
+            out["contact"] = contact_leg(local_rank)
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(bits, layers, res, dt, args.cpu_budget)
         print(json.dumps(out))

@@ -58,7 +58,7 @@ static int ensure_contact_capacity(mpm_engine* e, size_t n) {
             (rc = grow(&b.node_runs, 27 * cells)) || (rc = grow(&b.gD, cells)) ||
             (e->dp.dist.on && (rc = grow(&b.hg, 3 * cells))) ||
             (rc = grow(&b.part, (size_t)2 * CT_ROWS * CT_PART)) || (rc = grow(&b.part_dir, (size_t)2 * CT_DIR_WG)) ||
-            (rc = grow(&b.st, 1)))
+            (rc = grow(&b.st, 1)) || (rc = grow(&b.it_log, (size_t)3 * CT_LOG)))
             return rc;
         b.cap_cells = cells;
     }
@@ -167,7 +167,7 @@ static ContactDev make_contact_dev(mpm_engine* e, float dt, float mu, float k, f
     c.crv = b.crv; c.cvel = b.cvel; c.crec = b.crec;
     c.run = b.run; c.node_flag = b.node_flag; c.node_list = b.node_list; c.node_runs = b.node_runs;
     c.cap_nodes = (int)b.cap_cells; c.gD = b.gD; c.hg = b.hg;
-    c.part = b.part; c.part_dir = b.part_dir; c.st = b.st;
+    c.part = b.part; c.part_dir = b.part_dir; c.st = b.st; c.it_log = b.it_log;
     c.body_tau = b.body_tau; c.body_f = b.body_f; c.n_bodies = (int)b.n_bodies;
     return c;
 }
@@ -323,7 +323,9 @@ static int update_contact(mpm_engine* e, int frame, int substep, float dt, float
     } else if (!exact) {
         // device-resident loop: iterations are launched in batches, kernels of an iteration
         // that starts after convergence return immediately
-        const int batch = 8;
+        // (as many as the previous solve needed plus one, then a few at a time: iterations that start
+        // after convergence are idle launches of ~2 us each)
+        int batch = std::min(8, std::max(2, b.last_iters + 1));
         while (true) {
             for (int q = 0; q < batch; ++q) {
                 const int first = (iters + q) == 0;
@@ -334,12 +336,53 @@ static int update_contact(mpm_engine* e, int frame, int substep, float dt, float
                 hipLaunchKernelGGL(k_ct_apply, dim3(CT_ROWS), dim3(CT_WG), 0, s, p, c);
             }
             iters += batch;
+            batch = 3;
             HIP_TRY(hipMemcpyAsync(&st, b.st, sizeof(ContactState), hipMemcpyDeviceToHost, s));
             HIP_TRY(hipStreamSynchronize(s));
             if (st.done || st.iters >= max_iters) break;
         }
         iters = st.iters;
         residual = st.residual;
+    } else if (!dist) {
+        // Exact line search, device resident: a fixed pattern of launches per Newton iteration --
+        // direction, PROBES x (energies at st->alpha_probe, one-thread state machine = root finder of
+        // mpm_rootfind.h), apply, close -- whose kernels skip themselves according to the state: a search
+        // that needs more probes continues in the next pattern (direction skipped), patterns after
+        // convergence are idle.  One read-back per batch instead of one per probe.
+        const int PROBES = 6;
+        int batch = std::min(4, std::max(1, b.last_iters + 1));
+        while (true) {
+            for (int q = 0; q < batch; ++q) {
+                hipLaunchKernelGGL(k_ct_contact_grad, dim3(gc), dim3(256), 0, s, p, c, (iters + q) == 0);
+                hipLaunchKernelGGL(k_ct_node_dir<0>, dim3(n_dir_wg), dim3(CT_WG), 0, s, p, c);
+                for (int k = 0; k < PROBES; ++k) {
+                    hipLaunchKernelGGL(k_ct_ls, dim3(n_con_wg + n_grid_wg), dim3(CT_WG), 0, s, p, c, n_con_wg, 2, 0.f);
+                    hipLaunchKernelGGL(k_ct_decide, dim3(1), dim3(1024), 0, s, c, n_dir_wg, n_con_wg, n_grid_wg, 2, 0);
+                }
+                hipLaunchKernelGGL(k_ct_apply, dim3(CT_ROWS), dim3(CT_WG), 0, s, p, c, 1);
+                hipLaunchKernelGGL(k_ct_exact_finish, dim3(1), dim3(64), 0, s, c);
+            }
+            iters += batch;
+            batch = 2;
+            HIP_TRY(hipMemcpyAsync(&st, b.st, sizeof(ContactState), hipMemcpyDeviceToHost, s));
+            HIP_TRY(hipStreamSynchronize(s));
+            if (st.done || st.iters >= max_iters) break;
+            if (iters > 4 * max_iters + 64) break;   // (a search that never terminates cannot happen: the root finder is bounded)
+        }
+        iters = st.iters;
+        residual = st.residual;
+        s_alpha_last = st.alpha;
+        s_E0_last = st.E0;
+        if (iters > 0) {
+            std::vector<float> log((size_t)3 * std::min(iters, CT_LOG));
+            HIP_TRY(hipMemcpyAsync(log.data(), b.it_log, log.size() * 4, hipMemcpyDeviceToHost, s));
+            HIP_TRY(hipStreamSynchronize(s));
+            for (int i = 0; i < std::min(iters, CT_LOG); ++i) {
+                s_res.push_back(log[i * 3]);
+                s_ls.push_back((int)log[i * 3 + 1]);
+                s_energy.push_back(log[i * 3 + 2]);
+            }
+        }
     } else {
         // exact line search: Newton with bisection fallback on dE/dalpha, driven from the host
         // exactly like cuda_mpm_solver.cu:383-471 (itself a clone of Drake's
@@ -397,6 +440,7 @@ static int update_contact(mpm_engine* e, int frame, int substep, float dt, float
     hipLaunchKernelGGL(k_ct_gather_vel, dim3(gc), dim3(256), 0, s, p, c, b.vel);
     hipLaunchKernelGGL(k_ct_impulse, dim3(std::min(gc, 256u)), dim3(256), 0, s, c);
     HIP_TRY(hipGetLastError());
+    b.last_iters = iters;
     if (iters_out) *iters_out = iters;
     if (residual_out) *residual_out = residual;
     {

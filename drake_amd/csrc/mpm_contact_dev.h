@@ -22,6 +22,7 @@
 
 #include "mpm_device.h"
 #include "mpm_sort.h"
+#include "mpm_rootfind.h"
 
 namespace mpm {
 
@@ -47,7 +48,17 @@ struct ContactState {       // device-resident solver state
     double scal[4];         // exact line search: E, dE, d2E at the probed alpha
     double red[32];         // partitioned domain: this rank's sums (energies[29], |Dir|^2, DoFs) on their way
                             // through the all-reduce, then the global ones
+    // exact line search kept on the device (cuda_mpm_solver.cu:383-471): 0 = new Newton iteration, the
+    // probe at alpha = 0 is pending; 1 = probe at alpha = 1 pending; 2 = root finder running;
+    // 3 = step decided, to be applied
+    int ls_phase;
+    int ls_evals;           // evaluations of the root finder in this Newton iteration
+    float alpha_probe;      // where k_ct_ls evaluates next
+    float f_lo[3];          // (E, dE, d2E) at alpha = 0
+    RootFinder<float> rf;
 };
+
+constexpr int CT_LOG = 2048;   // per-iteration statistics kept for the JSON dump (residual, evaluations, energy)
 
 struct ContactDev {
     int n;                  // contacts
@@ -82,6 +93,7 @@ struct ContactDev {
     double* part;           // [2][CT_ROWS][CT_PART] line-search partial sums (contacts, cells)
     double* part_dir;       // [CT_DIR_WG][2] (|Dir|^2, DoFs) per workgroup of k_ct_node_dir
     ContactState* st;
+    float* it_log;          // [CT_LOG][3] exact search: residual, line-search evaluations, energy per Newton iteration
     float* body_tau;
     float* body_f;
     int n_bodies;
@@ -129,13 +141,15 @@ struct ContactBuffers {
     double* part = nullptr;
     double* part_dir = nullptr;
     ContactState* st = nullptr;
+    float* it_log = nullptr;
+    int last_iters = 0;         // Newton iterations of the previous solve (sizes the first batch of launches)
     float* body_tau = nullptr;  // F_Bq_W_tau
     float* body_f = nullptr;    // F_Bq_W_f
 
     void release() {
         void* ptrs[] = {api_idx, colliders, gen_cnt, gen_sums, slot, body, dist, normal, pos, rigid_v, p_WB, vel, vel0, key, order, key2, order2, sort_hist,
                         cnode, cfx, cmass, cphi0, cR, cv0, crv, cvel, crec, run, node_flag, node_list, node_runs, gD, hg,
-                        zone_buf[0], zone_buf[1], zone_buf[2], zone_buf[3], part, part_dir, st, body_tau, body_f};
+                        zone_buf[0], zone_buf[1], zone_buf[2], zone_buf[3], part, part_dir, st, it_log, body_tau, body_f};
         for (void* q : ptrs)
             if (q) (void)hipFree(q);
         *this = ContactBuffers();
@@ -521,7 +535,7 @@ __global__ __launch_bounds__(256) void k_ct_flags_to_field(DP p, ContactDev c, i
 // gradient in the world frame (cuda_mpm_kernels.cuh:1107-1154)
 __global__ __launch_bounds__(256) void k_ct_contact_grad(DP p, ContactDev c, int first) {
     const int j = blockIdx.x * 256 + threadIdx.x;
-    if (j >= c.n || c.st->done) return;
+    if (j >= c.n || c.st->done || c.st->ls_phase != 0) return;   // (exact search: still probing the previous direction)
     float v[3];
     if (first) {
         v[0] = c.cvel[j]; v[1] = c.cvel[c.n + j]; v[2] = c.cvel[2 * c.n + j];
@@ -588,7 +602,7 @@ MPM_DEV void wg_reduce_store(double* vals, double* out) {
 // neighbours' sums, MODE 2 solves from c.hg; |Dir|^2 and the DoF count only include owned nodes.
 template <int MODE>
 __global__ __launch_bounds__(CT_WG) void k_ct_node_dir(DP p, ContactDev c) {
-    if (c.st->done) return;   // k_ct_decide does not read the records of a finished solve
+    if (c.st->done || c.st->ls_phase != 0) return;   // k_ct_decide does not read the records of a finished solve
     double acc[2] = {0, 0};
     const int sub = threadIdx.x & 15;
     {
@@ -685,8 +699,14 @@ __global__ __launch_bounds__(CT_WG) void k_ct_node_dir(DP p, ContactDev c) {
 // C2 + G2: line-search energies for every candidate step: contact part
 // (cuda_mpm_kernels.cuh:1276-1473 with global_line_search = true) in workgroups [0, n_con_wg),
 // inertia part (cuda_mpm_kernels.cuh:1536-1589) in the rest
+// exact: 0 = backtracking (all candidate steps at once); 1 = (E, dE, d2E) at the step given by the
+// host; 2 = the same at st->alpha_probe, the device-resident search (skipped once the step is decided)
 __global__ __launch_bounds__(CT_WG) void k_ct_ls(DP p, ContactDev c, int n_con_wg, int exact, float alpha_probe) {
     if (c.st->done) return;   // k_ct_decide does not read the records of a finished solve
+    if (exact == 2) {
+        if (c.st->ls_phase == 3) return;
+        alpha_probe = c.st->alpha_probe;
+    }
     double acc[CT_PART];
 #pragma unroll
     for (int q = 0; q < CT_PART; ++q) acc[q] = 0;
@@ -833,6 +853,39 @@ __global__ __launch_bounds__(1024) void k_ct_decide(ContactDev c, int n_dir_wg, 
     const int lane = threadIdx.x;
     if (lane == LS_CAND + 1) st->norm_dir_sq = (float)v;
     if (lane == LS_CAND + 2) st->dofs = (float)v;
+    if (exact == 2) {
+        // device-resident exact search: one thread advances the state machine of cuda_mpm_solver.cu:383-471
+        if (lane < 3) st->scal[lane] = v;
+        const float E = __shfl((float)v, 0), dE = __shfl((float)v, 1), d2E = __shfl((float)v, 2);
+        if (lane != 0 || st->ls_phase == 3) return;
+        if (st->ls_phase == 0) {
+            st->f_lo[0] = E; st->f_lo[1] = dE; st->f_lo[2] = d2E;
+            st->E0 = E;
+            st->alpha_probe = 1.f;
+            st->ls_phase = 1;
+        } else if (st->ls_phase == 1) {
+            float x_lo = 0.f, f_lo = st->f_lo[1];
+            if (f_lo < 0.f && dE < 0.f) {   // both slopes negative: alpha = 1 is optimal (:395-398)
+                x_lo = 1.f;
+                f_lo = dE;
+            }
+            const float f_tol = 1e-8f, x_tol = f_tol * c.relax;
+            st->rf.start(x_lo, f_lo, 1.f, dE, 1.f, x_tol, f_tol, 200, RF_SIGN3 | RF_NO_ENDS | RF_STEP_LAST);
+            st->alpha_probe = st->rf.root;
+            st->ls_phase = 2;
+        } else {
+            st->energy = E;
+            st->rf.feed(dE, d2E);
+            if (st->rf.status != 0) {
+                st->alpha = st->rf.root;
+                st->ls_evals = st->rf.evals;
+                st->ls_phase = 3;
+            } else {
+                st->alpha_probe = st->rf.root;
+            }
+        }
+        return;
+    }
     if (exact) {
         if (lane < 3) st->scal[lane] = v;
         return;
@@ -855,9 +908,10 @@ __global__ __launch_bounds__(1024) void k_ct_decide(ContactDev c, int n_dir_wg, 
 }
 
 // G3: v -= alpha Dir (cuda_mpm_kernels.cuh:1591-1614); only nodes that see contacts have a direction
-__global__ __launch_bounds__(CT_WG) void k_ct_apply(DP p, ContactDev c) {
+__global__ __launch_bounds__(CT_WG) void k_ct_apply(DP p, ContactDev c, int exact_resident = 0) {
     ContactState* st = c.st;
     if (st->done == 1) return;
+    if (exact_resident && st->ls_phase != 3) return;   // the search of this direction is still running
     const float al = st->alpha;
     const int n_nodes = st->n_nodes;
     for (int q = blockIdx.x * CT_WG + threadIdx.x; q < n_nodes; q += gridDim.x * CT_WG) {
@@ -868,6 +922,22 @@ __global__ __launch_bounds__(CT_WG) void k_ct_apply(DP p, ContactDev c) {
         v.x -= al * D.x; v.y -= al * D.y; v.z -= al * D.z;
         p.gv[g] = v;
     }
+}
+
+// Device-resident exact search: closes a Newton iteration after k_ct_apply (cuda_mpm_solver.cu:567-570)
+__global__ void k_ct_exact_finish(ContactDev c) {
+    ContactState* st = c.st;
+    if (threadIdx.x != 0 || st->done == 1 || st->ls_phase != 3) return;
+    st->residual = sqrtf(st->norm_dir_sq) / st->dofs;
+    if (st->iters < CT_LOG) {
+        c.it_log[st->iters * 3] = st->residual;
+        c.it_log[st->iters * 3 + 1] = (float)st->ls_evals;
+        c.it_log[st->iters * 3 + 2] = st->energy;
+    }
+    st->iters += 1;
+    st->ls_total += st->ls_evals;
+    st->ls_phase = 0;
+    if (!(st->residual > c.tol) || st->iters >= c.max_iters) st->done = 1;
 }
 
 // apply_contact_impulse_to_rigid_bodies (cuda_mpm_kernels.cuh:1616-1658).  Impulses are summed

@@ -440,11 +440,6 @@ int mpm_sync(mpm_handle_t e) {
     D2H(e, &c, e->dp.ctl, sizeof(Ctl));
     if (e->finalized && !c.error)
         if (int rc = slab_pool_grow(e, c)) return rc;
-    if (c.error & ERR_CAPACITY)
-        return fail(MPM_ERR_CAPACITY,
-                    "a table of the engine overflowed (home / active blocks, slabs of the work items -- the pool is "
-                    "grown at synchronisation points: call mpm_sync more often while a cloth spreads out, or set "
-                    "MPM_SLAB_CAPACITY --, slabs over one block, halo or migration buffers)");
     if (c.error & ERR_DRIFT)
         return fail(MPM_ERR_DRIFT,
                     "a face particle was re-centred on its corners out of its block's tile: the corner "
@@ -459,6 +454,12 @@ int mpm_sync(mpm_handle_t e) {
         return fail(MPM_ERR_RANGE,
                     "a node sum of ParticleToGrid was not finite or exceeded the fixed-point range "
                     "(|node momentum| >= total mass * 2^15 length units per time unit): the state has diverged");
+    // (last: a diverging state also scatters particles over so many blocks that tables overflow)
+    if (c.error & ERR_CAPACITY)
+        return fail(MPM_ERR_CAPACITY,
+                    "a table of the engine overflowed (home / active blocks, slabs of the work items -- the pool is "
+                    "grown at synchronisation points: call mpm_sync more often while a cloth spreads out, or set "
+                    "MPM_SLAB_CAPACITY --, slabs over one block, halo or migration buffers)");
     return 0;
 }
 

@@ -140,4 +140,6 @@ def test_time_step_limit_of_the_256_grid_is_reported():
     assert g.stats()["error_flags"] == 0
     with pytest.raises(MpmError) as ei:
         run(1e-3, 400)
-    assert ei.value.code in (-3, -6), ei.value   # MPM_ERR_DRIFT (or the blow-up reaching the walls first)
+    # MPM_ERR_DRIFT, or whichever consequence of the blow-up is detected first: particles leaving the grid,
+    # non-finite node sums, particles scattered over more blocks than the tables hold
+    assert ei.value.code in (-3, -6, -7, -4), ei.value
