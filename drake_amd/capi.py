@@ -251,12 +251,30 @@ def _f32(a, shape=None):
     return a if shape is None else a.reshape(shape)
 
 
+_LIVE = None   # engines alive: destroyed before the interpreter (and with it the HIP runtime) goes down
+
+
+def _destroy_live():
+    for g in list(_LIVE or ()):
+        try:
+            g.destroy()
+        except Exception:  # noqa: BLE001
+            pass
+
+
 class GpuMpm:
     """One GpuMpmState + the GpuMpmSolver calls that act on it."""
 
     def __init__(self, domain_bits: int = 7, material: Material | None = None, device: int = 0):
+        global _LIVE
+        if _LIVE is None:
+            import atexit
+            import weakref
+            _LIVE = weakref.WeakSet()
+            atexit.register(_destroy_live)
         self.lib = load_library()
         self.h = C.c_void_p()
+        _LIVE.add(self)
         self.domain_bits = domain_bits
         self.n_cells = 1 << (3 * domain_bits)
         self.n_blocks = self.n_cells >> 6
