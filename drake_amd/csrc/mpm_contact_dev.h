@@ -429,17 +429,21 @@ MPM_DEV void gather_contact_velocity(const DP& p, const ContactDev& c, int j, fl
     bspline3(c.cfx[c.n + j], wy);
     bspline3(c.cfx[2 * c.n + j], wz);
     v[0] = v[1] = v[2] = 0.f;
+    // branch-free: a skipped node costs a load of cell 0 and a zero weight, but the 27 index loads and
+    // then the 27 node loads are all in flight together (a branch per node serialises them: one L2
+    // round trip each)
+    int g[27];
+#pragma unroll
+    for (int n = 0; n < 27; ++n) g[n] = c.cnode[n * c.n + j];
+    float4 q[27];
+#pragma unroll
+    for (int n = 0; n < 27; ++n) q[n] = p.gv[max(g[n], 0)];
 #pragma unroll
     for (int n = 0; n < 27; ++n) {
-        const int g = c.cnode[n * c.n + j];
-        if (g < 0) continue;
-        const float4 q = p.gv[g];
-        if (q.w > 1e-7f) {
-            const float w = stencil_weight(wx, wy, wz, n);
-            v[0] += w * q.x;
-            v[1] += w * q.y;
-            v[2] += w * q.z;
-        }
+        const float w = (g[n] >= 0 && q[n].w > 1e-7f) ? stencil_weight(wx, wy, wz, n) : 0.f;
+        v[0] += w * q[n].x;
+        v[1] += w * q[n].y;
+        v[2] += w * q[n].z;
     }
 }
 
@@ -624,30 +628,37 @@ __global__ __launch_bounds__(CT_WG) void k_ct_node_dir(DP p, ContactDev c) {
                 // lane s owns the runs of stencil offsets s and s + 16 (27 offsets over 16 lanes): the
                 // table walks and the contact loads of different offsets overlap across the lanes, the
                 // loop over a run's contacts is a plain stream
-#pragma unroll
-                for (int half = 0; half < 2; ++half) {
-                    const int o = sub + 16 * half;
-                    if (o >= 27) break;
+                // both run descriptors first, then the two runs side by side: the record loads of the two
+                // offsets are independent and overlap (one after the other they cost a round trip each)
+                const int o0 = sub, o1 = sub + 16;
+                const int2 ra = c.node_runs[(size_t)o0 * c.cap_nodes + q];
+                const int2 rb = o1 < 27 ? c.node_runs[(size_t)o1 * c.cap_nodes + q] : make_int2(0, 0);
+                auto add = [&](const float4& r0, const float4& r1, const float4& r2, const float4& r3, int o, bool on) {
                     // contacts whose base cell is node - (i, j, l) reach this node with weight N_i N_j N_l
                     const int i = o / 9, jj = (o / 3) % 3, l = o % 3;
-                    const int2 r = c.node_runs[(size_t)o * c.cap_nodes + q];
-#pragma unroll 2
-                    for (int k = r.x; k < r.y; ++k) {
-                        const float4* rec = c.crec + (size_t)k * 4;
-                        const float4 r0 = rec[0], r1 = rec[1], r2 = rec[2], r3 = rec[3];
-                        float wx[3], wy[3], wz[3];
-                        bspline3(r3.x, wx);
-                        bspline3(r3.y, wy);
-                        bspline3(r3.z, wz);
-                        const float w = (i == 0 ? wx[0] : (i == 1 ? wx[1] : wx[2])) *
-                                        (jj == 0 ? wy[0] : (jj == 1 ? wy[1] : wy[2])) *
-                                        (l == 0 ? wz[0] : (l == 1 ? wz[1] : wz[2]));
-                        const float w2 = w * w;
-                        H[0] += w2 * r0.x; H[1] += w2 * r0.y; H[2] += w2 * r0.z; H[3] += w2 * r0.w;
-                        H[4] += w2 * r1.x; H[5] += w2 * r1.y; H[6] += w2 * r1.z; H[7] += w2 * r1.w;
-                        H[8] += w2 * r2.x;
-                        G[0] += w * r2.y; G[1] += w * r2.z; G[2] += w * r2.w;
-                    }
+                    float wx[3], wy[3], wz[3];
+                    bspline3(r3.x, wx);
+                    bspline3(r3.y, wy);
+                    bspline3(r3.z, wz);
+                    float w = (i == 0 ? wx[0] : (i == 1 ? wx[1] : wx[2])) * (jj == 0 ? wy[0] : (jj == 1 ? wy[1] : wy[2])) *
+                              (l == 0 ? wz[0] : (l == 1 ? wz[1] : wz[2]));
+                    if (!on) w = 0.f;
+                    const float w2 = w * w;
+                    H[0] += w2 * r0.x; H[1] += w2 * r0.y; H[2] += w2 * r0.z; H[3] += w2 * r0.w;
+                    H[4] += w2 * r1.x; H[5] += w2 * r1.y; H[6] += w2 * r1.z; H[7] += w2 * r1.w;
+                    H[8] += w2 * r2.x;
+                    G[0] += w * r2.y; G[1] += w * r2.z; G[2] += w * r2.w;
+                };
+                const int na = ra.y - ra.x, nb = rb.y - rb.x, nmax = max(na, nb);
+                for (int t = 0; t < nmax; ++t) {
+                    const bool ona = t < na, onb = t < nb;
+                    // (a finished run re-reads record 0 of the contact array: finite numbers, weight 0)
+                    const float4* pa = c.crec + (size_t)(ona ? ra.x + t : 0) * 4;
+                    const float4* pb = c.crec + (size_t)(onb ? rb.x + t : 0) * 4;
+                    const float4 a0 = pa[0], a1 = pa[1], a2 = pa[2], a3 = pa[3];
+                    const float4 b0 = pb[0], b1 = pb[1], b2 = pb[2], b3 = pb[3];
+                    add(a0, a1, a2, a3, o0, ona);
+                    add(b0, b1, b2, b3, min(o1, 26), onb);
                 }
             }
             // fold the 16 lanes of the node (xor butterfly inside a row of 16)
@@ -718,14 +729,25 @@ __global__ __launch_bounds__(CT_WG) void k_ct_ls(DP p, ContactDev c, int n_con_w
             bspline3(c.cfx[c.n + j], wy);
             bspline3(c.cfx[2 * c.n + j], wz);
             float ov[3] = {0.f, 0.f, 0.f}, dd[3] = {0.f, 0.f, 0.f};
+            // branch-free gather in three sweeps (indices, then both node fields, then the sums): all
+            // loads of a sweep are in flight together
+            int gi[27];
 #pragma unroll
-            for (int n = 0; n < 27; ++n) {
-                const int g = c.cnode[n * c.n + j];
-                if (g < 0) continue;
-                const float w = stencil_weight(wx, wy, wz, n);
-                const float4 q = p.gv[g], D = c.gD[g];
-                ov[0] += w * q.x; ov[1] += w * q.y; ov[2] += w * q.z;
-                dd[0] += w * D.x; dd[1] += w * D.y; dd[2] += w * D.z;
+            for (int n = 0; n < 27; ++n) gi[n] = c.cnode[n * c.n + j];
+#pragma unroll
+            for (int n0 = 0; n0 < 27; n0 += 9) {   // (9 nodes at a time: 18 x 16 bytes of registers)
+                float4 q[9], D[9];
+#pragma unroll
+                for (int k = 0; k < 9; ++k) {
+                    q[k] = p.gv[max(gi[n0 + k], 0)];
+                    D[k] = c.gD[max(gi[n0 + k], 0)];
+                }
+#pragma unroll
+                for (int k = 0; k < 9; ++k) {
+                    const float w = gi[n0 + k] >= 0 ? stencil_weight(wx, wy, wz, n0 + k) : 0.f;
+                    ov[0] += w * q[k].x; ov[1] += w * q[k].y; ov[2] += w * q[k].z;
+                    dd[0] += w * D[k].x; dd[1] += w * D[k].y; dd[2] += w * D[k].z;
+                }
             }
             const ContactParams cp = {c.dt, c.mu, c.k, c.d, c.epsv};
             float R[9], v0[3];

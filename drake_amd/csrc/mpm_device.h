@@ -114,7 +114,8 @@ struct DP {
     // per-substep scratch
     float4* ab0;           // faces: tau = a (x) b with a = vol*P[:,2], b = F[:,2]: (a0, a1, a2, b0)
     float2* ab1;           //        (b1, b2)
-    float4* G4;            // faces: G4[face slot * 3 + c] = force triple the face exerts on corner c (negated when applied)
+    float3* G3;            // faces: G3[face slot * 3 + c] = force triple the face exerts on corner c (negated when
+                           // applied); 12-byte records: 36 B written per face and one dwordx3 gather per adjacency
     float* f[3];           // vertices: internal force
     // topology (original ids)
     const int* idx_orig[3];  // face -> original particle ids of its corners

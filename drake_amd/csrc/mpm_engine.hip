@@ -243,7 +243,7 @@ int mpm_finalize(mpm_handle_t e) {
     }
     ALLOC(p.ab0, nf, true);
     ALLOC(p.ab1, nf, true);
-    ALLOC(p.G4, 3 * nf, true);
+    ALLOC(p.G3, 3 * nf, true);
     for (int d = 0; d < 3; ++d) ALLOC(p.f[d], np, true);
     int* idx_orig[3];
     int *adj_off, *adj_fc;

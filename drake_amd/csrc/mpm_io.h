@@ -12,7 +12,7 @@ namespace mpm {
 
 // initialize_fem_state_kernel (cuda_mpm_kernels.cuh:13-70), faces in original
 // order (slot == original id at this point).  The per-face quarter volume is
-// parked in G4[face].x for k_init_vertex_volumes.
+// parked in G3[face * 3].x for k_init_vertex_volumes.
 __global__ __launch_bounds__(256) void k_init_faces(DP p) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= p.Nf) return;
@@ -40,7 +40,7 @@ __global__ __launch_bounds__(256) void k_init_faces(DP p) {
     S.fq[2][i] = make_float4(Q[8], Di[0], Di[1], Di[2]);
     S.fq[3][i] = make_float4(Di[3], f3.y, f3.z, f3.w);
     const_cast<float4*>(p.dm_orig)[i] = make_float4(Di[0], Di[1], Di[2], Di[3]);
-    p.G4[(size_t)i * 3].x = v4;
+    p.G3[(size_t)i * 3].x = v4;
 }
 
 // per vertex, the (face slot * 3 + corner) records of its adjacent faces (slot == original id
@@ -68,7 +68,7 @@ __global__ __launch_bounds__(256) void k_init_vertex_volumes(DP p) {
     const int k = blockIdx.x * 256 + threadIdx.x;
     if (k >= p.Nv) return;
     float v = 0.f;
-    for (int e = p.adj_off[k]; e < p.adj_off[k + 1]; ++e) v += p.G4[(size_t)(p.adj_fc[e] >> 2) * 3].x;
+    for (int e = p.adj_off[k]; e < p.adj_off[k + 1]; ++e) v += p.G3[(size_t)(p.adj_fc[e] >> 2) * 3].x;
     p.set[0].q[0][p.Nf + k].w = v;
 }
 

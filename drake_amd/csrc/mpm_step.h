@@ -27,7 +27,7 @@ __global__ __launch_bounds__(256) void k_fem(DP p, float dt) {
         atomicOr(&p.ctl->error, ERR_HALO);
         const float nan = __int_as_float(0x7FC00000);
 #pragma unroll
-        for (int c = 0; c < 3; ++c) p.G4[(size_t)i * 3 + c] = make_float4(nan, nan, nan, 0.f);
+        for (int c = 0; c < 3; ++c) p.G3[(size_t)i * 3 + c] = make_float3(nan, nan, nan);
         p.ab0[i] = make_float4(nan, nan, nan, nan);
         p.ab1[i] = make_float2(nan, nan);
         return;
@@ -87,9 +87,9 @@ __global__ __launch_bounds__(256) void k_fem(DP p, float dt) {
         Gm[d * 3 + 1] = a * g01 + b * g11;
         Gm[d * 3 + 2] = a * g02 + b * g12;
     }
-    // one 16-byte record per corner so that a vertex fetches its triple with a single load
+    // one 12-byte record per corner: a vertex fetches its triple with a single dwordx3 load
 #pragma unroll
-    for (int c = 0; c < 3; ++c) p.G4[(size_t)i * 3 + c] = make_float4(Gm[c], Gm[3 + c], Gm[6 + c], 0.f);
+    for (int c = 0; c < 3; ++c) p.G3[(size_t)i * 3 + c] = make_float3(Gm[c], Gm[3 + c], Gm[6 + c]);
 }
 
 // Vertex force = - sum over adjacent (face, corner) of that corner's force triple, summed in
@@ -117,9 +117,9 @@ __global__ __launch_bounds__(256) void k_vforce(DP p) {
         }
     }
     if (rec[0] != -2) {
-        float4 g[8];
+        float3 g[8];
 #pragma unroll
-        for (int q = 0; q < 8; ++q) g[q] = rec[q] >= 0 ? p.G4[rec[q]] : make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int q = 0; q < 8; ++q) g[q] = rec[q] >= 0 ? p.G3[rec[q]] : make_float3(0.f, 0.f, 0.f);
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
             if (rec[q] >= 0) {
@@ -134,8 +134,8 @@ __global__ __launch_bounds__(256) void k_vforce(DP p) {
         for (int e = p.adj_off[vo]; e < p.adj_off[vo + 1]; ++e) {
             const int fc = p.adj_fc[e];
             const int fs = p.imap[fc >> 2];
-            const float4 g = fs >= 0 ? p.G4[(size_t)fs * 3 + (fc & 3)]
-                                     : make_float4(S.q[0][s].w > 0.f ? __int_as_float(0x7FC00000) : 0.f, 0.f, 0.f, 0.f);
+            const float3 g = fs >= 0 ? p.G3[(size_t)fs * 3 + (fc & 3)]
+                                     : make_float3(S.q[0][s].w > 0.f ? __int_as_float(0x7FC00000) : 0.f, 0.f, 0.f);
             f0 += -g.x;
             f1 += -g.y;
             f2 += -g.z;
