@@ -79,8 +79,8 @@ def test_plumbing_64k_full_size_against_the_oracle():
     sc = natural_scales(o, dt)
     close(g.download(A.POSITIONS), o.pos, scale=1.0, what="64k traj pos")
     # ten free-running substeps of a stiff cloth amplify the per-step rounding differences
-    close(g.download(A.VELOCITIES), o.vel, scale=sc["vel"], rtol=2e-4, what="64k traj vel")
-    close(g.download(A.DEFORMATION_GRADIENTS), o.F, scale=1.0, rtol=2e-5, what="64k traj F")
+    close(g.download(A.VELOCITIES), o.vel, scale=sc["vel"], rtol=5e-5, what="64k traj vel")
+    close(g.download(A.DEFORMATION_GRADIENTS), o.F, scale=1.0, rtol=4e-5, what="64k traj F")
     o.rebuild_mapping(False)
     assert (g.download(A.SORT_KEYS) == o.sort_keys).mean() > 0.999
     assert np.array_equal(g.download(A.GRID_TOUCHED_FLAGS), o.g_flags)

@@ -125,9 +125,9 @@ def test_trajectory_with_sorts_and_rebuilds():
         out[pid_g] = a
         return out
 
-    # after 20 steps rounding differences have been amplified by the stiff cloth: 1e-4 of scale
+    # after 20 steps rounding differences have been amplified by the stiff cloth (observed: 2e-5 of scale)
     close(orig(g.download(A.POSITIONS)), so["pos"], scale=1.0, rtol=1e-5, what="traj pos")
-    close(orig(g.download(A.VELOCITIES)), so["vel"], scale=sc["vel"], rtol=2e-3, what="traj vel")
+    close(orig(g.download(A.VELOCITIES)), so["vel"], scale=sc["vel"], rtol=1e-4, what="traj vel")
     close(orig(g.download(A.VOLUMES)), so["vol"], what="traj vol")
     # index maps, per original particle: equal unless the particle sits within rounding of a cell face
     o.rebuild_mapping(False)  # keys of the current positions (the engine derives them on demand)
@@ -151,7 +151,7 @@ def test_substep_equals_phase_calls():
         g2.update_grid(-1)
         g2.grid_to_particle(DT)
     close(g1.download(A.POSITIONS), g2.download(A.POSITIONS), scale=1.0, rtol=1e-6, what="substep pos")
-    close(g1.download(A.VELOCITIES), g2.download(A.VELOCITIES), rtol=1e-4, what="substep vel")
+    close(g1.download(A.VELOCITIES), g2.download(A.VELOCITIES), rtol=1e-6, what="substep vel")
 
 
 def test_free_fall_and_conservation_large():
