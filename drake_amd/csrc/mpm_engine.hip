@@ -217,7 +217,7 @@ int mpm_finalize(mpm_handle_t e) {
     // Slabs (16 KB each) are allocated for the blocks a cloth of this size typically occupies, not for
     // the worst case of one particle per block (capI: 4 GB at 256^3, 33 GB at 512^3); mpm_sync and
     // mpm_get_stats double the pool when it is more than half full (slab_pool_grow).
-    p.capS = (unsigned)std::min<size_t>(p.capI, std::max<size_t>(4096, np / 256 + 1024));
+    p.capS = (unsigned)std::min<size_t>(p.capI, std::max<size_t>(4096, np / 256 + 1024 + np / (64 * (size_t)p.item_groups)));
     if (getenv("MPM_SLAB_CAPACITY")) p.capS = (unsigned)std::min<size_t>(p.capI, std::max(1, atoi(getenv("MPM_SLAB_CAPACITY"))));
     p.dxinv = (float)(1 << e->bits);
     p.dx = 1.f / p.dxinv;

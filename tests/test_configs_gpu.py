@@ -143,3 +143,64 @@ def test_time_step_limit_of_the_256_grid_is_reported():
     # MPM_ERR_DRIFT, or whichever consequence of the blow-up is detected first: particles leaving the grid,
     # non-finite node sums, particles scattered over more blocks than the tables hold
     assert ei.value.code in (-3, -6, -7, -4), ei.value
+
+
+def test_config5_scale_many_bodies_properties():
+    """BASELINE config 5 at its full size on one GPU (4,018,272 particles, 256^3, dt = 2e-4; the
+    configuration's 4 GPUs split this domain): a floor and 16 moving capsule "links" with prescribed
+    rigid velocities, pairs made on the device, UpdateContact with the bagging parameters.  The oracle is
+    not run at this size; checked are size-independent properties: every body gets contacts, the solve
+    converges, each body is pushed away from the cloth (impulse against its relative approach) by no more than the
+    momentum the solve took out of the grid, nothing is flagged."""
+    from drake_amd import ARR as A, Collider, GpuMpm, scenes
+    bits, layers, res = scenes.CONFIGS["cloth_4m"]
+    dt, k, d, mu = 2e-4, 1e6, 1e-5, 1.0
+    g = GpuMpm(bits)
+    z0 = 0.5
+    sheets = scenes.cloth_stack(layers, res, bits, z0=z0, vel_amp=0.05)
+    for pos, vel, idx in sheets:
+        vel[:, 2] -= 0.3
+    scenes.populate(g, sheets)
+    assert g.n_particles == 4018272
+    bodies = [Collider(0, body=0, p_WB=(0.5, 0.5, z0 - 0.001))]           # the world: a floor just under the stack
+    rot_y = np.array([[0, 0, 1], [0, 1, 0], [-1, 0, 0]], np.float32)      # capsule axis along x
+    for i in range(16):
+        y = 0.28 + 0.44 * (i % 8) / 7.0
+        top = i >= 8
+        z = z0 + (0.034 if top else -0.004)                                # above the 16 sheets (dx/2 apart) / under them
+        vz = -0.6 if top else 0.5
+        bodies.append(Collider(3, body=1 + i, p_WB=(0.35 + 0.3 * (i % 2), y, z), R_WB=rot_y, dims=(0.006, 0.05, 0),
+                               v=(0.1 * (-1) ** i, 0.0, vz), w=(0, 0, 0.5)))
+    g.reallocate_external_bodies(17)
+    for step in range(2):
+        g.rebuild_mapping(False)
+        g.calc_fem_state_and_force(dt)
+        g.particle_to_grid(dt)
+        g.update_grid(-1)
+        mv0 = g.download(A.GRID_MOMENTUM).astype(np.float64)               # v* per node
+        m = g.download(A.GRID_MASSES).astype(np.float64)
+        n = g.generate_contact_pairs(bodies)
+        pairs = g.download_contact_pairs()
+        assert n > 20000
+        counts = np.bincount(pairs[1], minlength=17)
+        assert np.all(counts > 0), counts
+        g.reallocate_external_bodies(17)                                    # per-substep accumulators for the check below
+        r = g.update_contact(dt, mu, k, d)
+        cs = g.contact_stats()
+        assert 0 < r["iterations"] < 500 and r["residual"] <= 1e-4, (r, cs)
+        tau, f = g.external_body_force_to_host()
+        assert np.isfinite(tau).all() and np.isfinite(f).all()
+        # the floor is pushed down, bodies coming from below are pushed down, bodies from above up
+        assert f[0, 2] < 0
+        assert np.all(f[1:9, 2] < 0) and np.all(f[9:, 2] > 0), f[:, 2]
+        # the solve moved the grid: nodes under the stack upwards, and the per-body impulse (mass of the
+        # contacting particles times their velocity change, cuda_mpm_kernels.cuh:1616-1658) is bounded by
+        # the momentum change of all the mass on those nodes
+        mv1 = g.download(A.GRID_MOMENTUM).astype(np.float64)
+        dpz = np.abs((mv1[:, 2] - mv0[:, 2]) * m).sum()
+        assert dpz > 0 and np.abs(f[:, 2].astype(np.float64)).sum() <= 1.05 * dpz, (dpz, f[:, 2])
+        g.grid_to_particle(dt)
+    g.gpu_sync()
+    assert g.stats()["error_flags"] == 0
+    v = g.download(A.VELOCITIES)
+    assert np.isfinite(v).all() and np.abs(v).max() < 20.0
