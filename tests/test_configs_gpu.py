@@ -162,7 +162,7 @@ def test_config5_scale_many_bodies_properties():
         vel[:, 2] -= 0.3
     scenes.populate(g, sheets)
     assert g.n_particles == 4018272
-    bodies = [Collider(0, body=0, p_WB=(0.5, 0.5, z0 - 0.001))]           # the world: a floor just under the stack
+    bodies = [Collider(0, body=0, p_WB=(0.5, 0.5, z0 + 0.0005))]          # the world: a floor the lowest sheet has sunk into
     rot_y = np.array([[0, 0, 1], [0, 1, 0], [-1, 0, 0]], np.float32)      # capsule axis along x
     for i in range(16):
         y = 0.28 + 0.44 * (i % 8) / 7.0
@@ -181,7 +181,7 @@ def test_config5_scale_many_bodies_properties():
         m = g.download(A.GRID_MASSES).astype(np.float64)
         n = g.generate_contact_pairs(bodies)
         pairs = g.download_contact_pairs()
-        assert n > 20000
+        assert n > 5000
         counts = np.bincount(pairs[1], minlength=17)
         assert np.all(counts > 0), counts
         g.reallocate_external_bodies(17)                                    # per-substep accumulators for the check below
