@@ -64,6 +64,7 @@ struct Ctl {
     int nfa, nva;
     int add_f, add_v;
     int nfa_new, nva_new;   // counts after the re-sort in flight (k_rb_tables -> k_rb_finish)
+    int pad1[2];
 };
 
 // Partitioned domain: ranks cut ONE domain into x slabs at block boundaries.  Every

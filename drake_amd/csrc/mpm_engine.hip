@@ -159,13 +159,15 @@ static void launch_p2g(mpm_engine* e, float dt) {
     hipLaunchKernelGGL(k_p2g, dim3(e->g_tile), dim3(512), 0, e->stream, e->dp, dt);
     e->last_tile_kernel = 1;
 }
+// (`p` may carry a halo class restriction)
+static void launch_g2p_with(mpm_engine* e, DP p, float dt) {
+    hipLaunchKernelGGL(k_g2p, dim3(std::min(768u, p.capI)), dim3(G2P_THREADS), 0, e->stream, p, dt);
+    e->last_tile_kernel = 2;
+}
 static void launch_grid(mpm_engine* e, const GridColliders& gc) {
     hipLaunchKernelGGL(k_grid<1>, dim3(e->g_grid), dim3(256), 0, e->stream, e->dp, gc);
 }
-static void launch_g2p(mpm_engine* e, float dt) {
-    hipLaunchKernelGGL(k_g2p, dim3(std::min(768u, e->dp.capI)), dim3(G2P_THREADS), 0, e->stream, e->dp, dt);
-    e->last_tile_kernel = 2;
-}
+static void launch_g2p(mpm_engine* e, float dt) { launch_g2p_with(e, e->dp, dt); }
 
 // The P2G tiles accumulate in 64-bit fixed point.  Scales are powers of two chosen from the
 // total particle mass M: a node can never hold more than M, and its momentum is allowed
@@ -638,7 +640,7 @@ int mpm_substep_mid_halo(mpm_handle_t e, float dt, int bc) {
     p.halo_nz = e->halo_nz;
     for (int i = 0; i < e->halo_nz; ++i) { p.halo_zlo[i] = e->halo_zlo[i]; p.halo_zhi[i] = e->halo_zhi[i]; }
     hipLaunchKernelGGL(k_grid<2>, dim3(e->g_grid), dim3(256), 0, e->stream, p, gc);
-    hipLaunchKernelGGL(k_g2p, dim3(std::min(768u, p.capI)), dim3(G2P_THREADS), 0, e->stream, p, dt);
+    launch_g2p_with(e, p, dt);
     e->halo_mid_done = true;
     return 0;
 }
@@ -667,7 +669,7 @@ int mpm_substep_end_halo(mpm_handle_t e, float dt, int bc, int n, const void* co
     auto body = [&]() {
         if (n > 0) hipLaunchKernelGGL(k_halo_add2, dim3(64, n), dim3(256), 0, e->stream, p, b, (unsigned)cap);
         hipLaunchKernelGGL(k_grid<2>, dim3(e->g_grid), dim3(256), 0, e->stream, p, gc);
-        hipLaunchKernelGGL(k_g2p, dim3(std::min(768u, p.capI)), dim3(G2P_THREADS), 0, e->stream, p, dt);
+        launch_g2p_with(e, p, dt);
     };
     if (halo_graphs() && !split) {
         if (int rc = replay_keyed(e, e->halo_graph[1], key, body)) return rc;

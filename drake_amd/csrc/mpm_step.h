@@ -172,9 +172,7 @@ __global__ __launch_bounds__(256) void k_vforce(DP p) {
 // ---------------------------------------------------------------------------
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-// staged floats per particle: the 13 live columns of Y, then the 1-D B-spline weights wx[3], wy[3], wz[3]
-constexpr int STG = 22;
-constexpr int STG_ROWS = 64 + 4;   // 64 particles + rows the operand prefetch may touch (index clamped)
+constexpr int STG = 20;  // staged floats per particle: 16 columns of Y, fx, fy, fz, pad
 
 template <int CTRL>
 MPM_DEV float quad_perm(float v) {
@@ -258,8 +256,8 @@ MPM_DEV unsigned tile_reach_mask(int rx, int ry, int rz) {
 
 __global__ __launch_bounds__(512, 4) void k_p2g(DP p, float dt) {  // <= 128 VGPRs: two workgroups per CU
     __shared__ long long tile[TILE_N * 4];  // (mvx, mvy, mvz, m) per node, fixed point
-    // wave-private staging (two workgroups per CU: 2 x (32,000 + 8 x 5,984 + 4) bytes of the 160 KB)
-    __shared__ __attribute__((aligned(16))) float stage_all[8][STG_ROWS * STG];
+    // wave-private staging: 64 particles (+8 slack rows touched by the operand prefetch)
+    __shared__ __attribute__((aligned(16))) float stage_all[8][(64 + 8) * STG];
     __shared__ unsigned s_mask;
     Ctl* ctl = p.ctl;
     const PSet& S = p.set[ctl->cur];
@@ -271,19 +269,15 @@ __global__ __launch_bounds__(512, 4) void k_p2g(DP p, float dt) {  // <= 128 VGP
 
     // ---- lane constants of the contraction ---------------------------------
     const int j16 = lane & 15, g4 = lane >> 4, tt = lane & 3, dcomp = (lane >> 2) & 3;
-    // A operand: the weight of node row n for particle p is wx[i] wy[j] wz[k] with (i, j, k) = digits of n.
-    // The nine 1-D weights of a particle are computed once when it is staged; a lane only multiplies
-    // the three that belong to its two node rows (j16 and 16 + j16).
-    int wofs[2][3];
+    float ax[2][3], ay[2][3], az[2][3];  // A operand: weight polynomials of node rows j16 and 16 + j16
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
-        const int n = min(16 * t + j16, 26);
-        wofs[t][0] = 13 + n / 9;
-        wofs[t][1] = 16 + (n / 3) % 3;
-        wofs[t][2] = 19 + n % 3;
+        const int n = 16 * t + j16;
+        const bool on = n < 27;
+        bspline_coeff(n / 9, on, ax[t][0], ax[t][1], ax[t][2]);
+        bspline_coeff((n / 3) % 3, true, ay[t][0], ay[t][1], ay[t][2]);
+        bspline_coeff(n % 3, true, az[t][0], az[t][1], az[t][2]);
     }
-    const bool row1_on = 16 + j16 < 27;
-    const bool col_on = j16 < 13;    // columns 13..15 of the B operand are zero
     float fac[2][4];     // epilogue: (1, i, j, k)[tt] of node row 16 t + 4 g4 + r
     int delta[2];        // float offset of this lane's node/component in the tile, -1 if none
 #pragma unroll
@@ -300,7 +294,7 @@ __global__ __launch_bounds__(512, 4) void k_p2g(DP p, float dt) {  // <= 128 VGP
     const float fscale = (float)(dcomp == 3 ? p.fix_m : p.fix_p);
     // A step reads 4 staged rows; rows that do not belong to the cell (the next cell's particles,
     // rows never written) are masked in the B operand only, so every row must hold finite numbers
-    for (int k = lane; k < STG_ROWS * STG; k += 64) stage[k] = 0.f;
+    for (int k = lane; k < (64 + 8) * STG; k += 64) stage[k] = 0.f;
 
     // Work items (a home block, or a run of the wave groups of a heavy one) are taken round-robin
     // from the heaviest-first order: workgroup w processes entries w, w + G, ...; with G resident
@@ -335,50 +329,37 @@ __global__ __launch_bounds__(512, 4) void k_p2g(DP p, float dt) {  // <= 128 VGP
             float ta[3], tb[3], frc[3];
             bool act, is_face;
         };
-        // Loads group gq (clamped to the wave's last one: a harmless repeat) without any branch: a
-        // conditional load merges "loaded" and "not loaded" values right behind the load, and the
-        // compiler then waits for the data there -- ~3.7 us of exposed HBM latency per group.  The
-        // group descriptor is wave-uniform and comes through the scalar cache.
-        const int wvu = __builtin_amdgcn_readfirstlane(wv);
-        const int g_last = wvu < ngroups ? wvu + ((ngroups - 1 - wvu) & ~7) : 0;   // last group of this wave (if it has one)
-        // (the pointer is wave-uniform but was computed from vector loads: move it to scalar registers so
-        // that the descriptor is fetched by s_load, one group ahead of its use)
-        const unsigned long long gaddr = reinterpret_cast<unsigned long long>(groups);
-        const int4* sgroups = reinterpret_cast<const int4*>(
-            ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(gaddr >> 32)) << 32) |
-            (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)gaddr));
-        auto descriptor = [&](int gq) { return sgroups[min(gq, g_last)]; };
-        auto load_raw = [&](const int4& gr) {
+        auto load_raw = [&](int g) {
             Raw r;
+            const int4 gr = groups[g];
             const int gf = gr.y - gr.x, gn = gf + (gr.w - gr.z);
             r.act = lane < gn;
             r.is_face = lane < gf;
             // unsigned index: lets the loads use the scalar-base + 32-bit-offset addressing form
-            const unsigned dummy = (unsigned)(nfb ? rg.x : rg.z);
-            const unsigned ii = (unsigned)(r.act ? (r.is_face ? gr.x + lane : gr.z + (lane - gf)) : dummy);
+            const unsigned ii = (unsigned)(r.act ? (r.is_face ? gr.x + lane : gr.z + (lane - gf)) : (nfb ? rg.x : rg.z));
             const float4 q0 = S.q[0][ii], q1 = S.q[1][ii], q2 = S.q[2][ii], q3 = S.q[3][ii];
             r.x[0] = q0.x; r.x[1] = q0.y; r.x[2] = q0.z; r.vol = q0.w;
             r.v[0] = q1.x; r.v[1] = q1.y; r.v[2] = q1.z;
             unpack_C(q1, q2, q3, r.C);
-            // both kinds of per-particle extras are loaded by every lane, the unused one from a fixed
-            // slot (one cache line for the whole wave); the consumer picks by is_face
-            const unsigned fi = r.act && r.is_face ? ii : 0u;
-            const unsigned vi = r.act && !r.is_face ? ii : (unsigned)min(p.Nf, p.Np - 1);
-            const float4 a = p.ab0[fi];
-            const float2 b = p.ab1[fi];
-            r.ta[0] = a.x; r.ta[1] = a.y; r.ta[2] = a.z; r.tb[0] = a.w; r.tb[1] = b.x; r.tb[2] = b.y;
+            r.ta[0] = r.ta[1] = r.ta[2] = r.tb[0] = r.tb[1] = r.tb[2] = 0.f;
+            r.frc[0] = r.frc[1] = r.frc[2] = 0.f;
+            if (r.is_face) {
+                const float4 a = p.ab0[ii];
+                const float2 b = p.ab1[ii];
+                r.ta[0] = a.x; r.ta[1] = a.y; r.ta[2] = a.z; r.tb[0] = a.w; r.tb[1] = b.x; r.tb[2] = b.y;
+            } else {
 #pragma unroll
-            for (int d = 0; d < 3; ++d) r.frc[d] = p.f[d][vi];
+                for (int d = 0; d < 3; ++d) r.frc[d] = p.f[d][ii];
+            }
             return r;
         };
-        if ((diag_flags(p) & 4) && tid == 0) atomicAdd(&p.dbgbuf[14], (unsigned long long)__builtin_readcyclecounter() - tb0);
-        Raw cur = load_raw(descriptor(wvu));
+        Raw cur;
+        if (wv < ngroups) cur = load_raw(wv);
         const bool prof = (diag_flags(p) & 4) != 0 && wv == 0;
         unsigned long long tq[3] = {0, 0, 0}, pc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-        for (int g = wvu; g < ngroups; g += 8) {
+        for (int g = wv; g < ngroups; g += 8) {
             // ---- 1. one particle per lane (its raw state was prefetched) ----------
             if (prof) tq[0] = __builtin_readcyclecounter();
-            const int4 dnext = descriptor(g + 8);
             const bool act = cur.act, is_face = cur.is_face;
             const Stencil st = make_stencil(p, cur.x[0], cur.x[1], cur.x[2], ox, oy, oz);
             // partitioned domain: a ghost copy (vol < 0) scatters nothing, its owner does
@@ -424,7 +405,7 @@ __global__ __launch_bounds__(512, 4) void k_p2g(DP p, float dt) {  // <= 128 VGP
             }
             // the raw registers are dead now: start the next group's loads, they complete while this
             // group goes through the LDS / matrix-pipe phases below (which never wait on vmcnt)
-            cur = load_raw(dnext);
+            if (g + 8 < ngroups) cur = load_raw(g + 8);
             if (diag_flags(p) & 2) {
                 float acc = 0.f;
 #pragma unroll
@@ -449,18 +430,12 @@ __global__ __launch_bounds__(512, 4) void k_p2g(DP p, float dt) {  // <= 128 VGP
             }
             // ---- 3. stage at the grouped position (wave-private LDS, in-order) --
             if (act) {
-                float2* sp = reinterpret_cast<float2*>(stage + pos * STG);   // rows are 88 bytes: 8-byte stores
-                sp[0] = make_float2(Y[0], Y[1]);
-                sp[1] = make_float2(Y[2], Y[3]);
-                sp[2] = make_float2(Y[4], Y[5]);
-                sp[3] = make_float2(Y[6], Y[7]);
-                sp[4] = make_float2(Y[8], Y[9]);
-                sp[5] = make_float2(Y[10], Y[11]);
-                sp[6] = make_float2(Y[12], st.wx[0]);
-                sp[7] = make_float2(st.wx[1], st.wx[2]);
-                sp[8] = make_float2(st.wy[0], st.wy[1]);
-                sp[9] = make_float2(st.wy[2], st.wz[0]);
-                sp[10] = make_float2(st.wz[1], st.wz[2]);
+                float4* sp = reinterpret_cast<float4*>(stage + pos * STG);
+                sp[0] = make_float4(Y[0], Y[1], Y[2], Y[3]);
+                sp[1] = make_float4(Y[4], Y[5], Y[6], Y[7]);
+                sp[2] = make_float4(Y[8], Y[9], Y[10], Y[11]);
+                sp[3] = make_float4(Y[12], Y[13], Y[14], Y[15]);
+                sp[4] = make_float4(st.fx[0], st.fx[1], st.fx[2], 0.f);
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
@@ -469,14 +444,11 @@ __global__ __launch_bounds__(512, 4) void k_p2g(DP p, float dt) {  // <= 128 VGP
             // ---- 4. per-cell contraction on the matrix pipe ----------------------
             unsigned long long todo = actmask;
             int s0 = 0;
-            float na[3], nb[3], ny;   // operands of the next step (three weight factors per node row, one column of Y)
-            auto fetch = [&](int row) {
-                const float* sn = stage + min(row, STG_ROWS - 1) * STG;
-                na[0] = sn[wofs[0][0]]; na[1] = sn[wofs[0][1]]; na[2] = sn[wofs[0][2]];
-                nb[0] = sn[wofs[1][0]]; nb[1] = sn[wofs[1][1]]; nb[2] = sn[wofs[1][2]];
-                ny = sn[j16];
-            };
-            fetch(g4);
+            float nfx, nfy, nfz, ny;
+            {
+                const float* sn = stage + g4 * STG;
+                nfx = sn[16]; nfy = sn[17]; nfz = sn[18]; ny = sn[j16];
+            }
             if (prof) tq[1] = __builtin_readcyclecounter();
             while (todo) {
                 const int ckey = __builtin_amdgcn_readlane(key, __builtin_ctzll(todo));
@@ -488,13 +460,20 @@ __global__ __launch_bounds__(512, 4) void k_p2g(DP p, float dt) {  // <= 128 VGP
                 // operands of a step are fetched one step ahead (the first step's during the previous
                 // cell's epilogue), so the LDS latency hides behind the MFMAs
                 for (int s = (diag_flags(p) & 8) ? s1 : s0; s < s1; s += 4) {
-                    const bool ok = col_on && s + g4 < s1;   // rows of other cells / never written: masked in B only
-                    float w0 = na[0] * na[1] * na[2];
-                    float w1 = nb[0] * nb[1] * nb[2];
+                    const bool ok = s + g4 < s1;
+                    const float fx = nfx, fy = nfy, fz = nfz;
                     float y = ny;
-                    fetch(s + 4 + g4);
-                    if (!row1_on) w1 = 0.f;
-                    if (diag_flags(p) & 128) { w0 = y; w1 = y; }
+                    {
+                        const float* sn = stage + (s + 4 + g4) * STG;
+                        nfx = sn[16]; nfy = sn[17]; nfz = sn[18]; ny = sn[j16];
+                    }
+                    float w0 = fmaf(fmaf(ax[0][2], fx, ax[0][1]), fx, ax[0][0]) *
+                               fmaf(fmaf(ay[0][2], fy, ay[0][1]), fy, ay[0][0]) *
+                               fmaf(fmaf(az[0][2], fz, az[0][1]), fz, az[0][0]);
+                    float w1 = fmaf(fmaf(ax[1][2], fx, ax[1][1]), fx, ax[1][0]) *
+                               fmaf(fmaf(ay[1][2], fy, ay[1][1]), fy, ay[1][0]) *
+                               fmaf(fmaf(az[1][2], fz, az[1][1]), fz, az[1][0]);
+                    if (diag_flags(p) & 128) { w0 = fx; w1 = fy; }
                     if (!ok) y = 0.f;   // (weights of foreign rows are finite: 0 * w = 0)
                     if (diag_flags(p) & 64) {
                         acc0[0] = fmaf(w0, y, acc0[0]);
@@ -505,7 +484,10 @@ __global__ __launch_bounds__(512, 4) void k_p2g(DP p, float dt) {  // <= 128 VGP
                     }
                 }
                 // the loop leaves row block (last step + 4) preloaded; the next cell starts at s1
-                if (((s1 - s0) & 3) != 0 || (diag_flags(p) & 8)) fetch(s1 + g4);
+                if (((s1 - s0) & 3) != 0 || (diag_flags(p) & 8)) {
+                    const float* sn = stage + (s1 + g4) * STG;
+                    nfx = sn[16]; nfy = sn[17]; nfz = sn[18]; ny = sn[j16];
+                }
                 if (prof) { asm volatile("" :: "v"(acc0), "v"(acc1)); const unsigned long long tm = __builtin_readcyclecounter(); pc[2] += tm - tq[2]; tq[2] = tm; }
                 s0 = s1;
                 // rows = nodes, columns = (component d, term tt): fold the 4 terms of each component
@@ -542,7 +524,6 @@ __global__ __launch_bounds__(512, 4) void k_p2g(DP p, float dt) {  // <= 128 VGP
             __builtin_amdgcn_wave_barrier();
         }
         if (prof) pc[7] = __builtin_readcyclecounter() - tb0;  // whole block, before the final barrier + slab
-        const unsigned long long tb1 = (diag_flags(p) & 4) ? __builtin_readcyclecounter() : 0ull;
         if (prof && lane == 0)
             for (int q = 0; q < 8; ++q) atomicAdd(&p.dbgbuf[q], pc[q]);
         if (mymask && lane == 0) atomicOr(&s_mask, mymask);
@@ -550,7 +531,6 @@ __global__ __launch_bounds__(512, 4) void k_p2g(DP p, float dt) {  // <= 128 VGP
         if (__ballot(!in_range) && lane == 0) atomicOr(&ctl->error, ERR_RANGE);
         if (p.dist.on && __ballot(halo_bad) && lane == 0) atomicOr(&ctl->error, ERR_HALO);
         __syncthreads();
-        if ((diag_flags(p) & 4) && tid == 0) atomicAdd(&p.dbgbuf[15], (unsigned long long)__builtin_readcyclecounter() - tb1);
         float4* out = p.slab + (size_t)item * TILE_N;
         for (int n = tid; n < TILE_N; n += 512) {
             const long long* q = tile + n * 4;
