@@ -272,7 +272,13 @@ def main():
         raise SystemExit(f"bench.py: rank {rank} needs GPU {local_rank} but only {ndev} are visible "
                          "(set MPM_BENCH_SHARE_GPU=1 to rehearse several ranks on one GPU)")
     torch.cuda.set_device(local_rank)
+    saved_stdout = None
     if world > 1:
+        # gloo and RCCL print banners on stdout; the contract is ONE JSON line there: everything else goes
+        # to stderr until the result is printed
+        sys.stdout.flush()
+        saved_stdout = os.dup(1)
+        os.dup2(2, 1)
         dist.init_process_group("gloo")
 
     from drake_amd import GpuMpm, scenes
@@ -477,7 +483,12 @@ def main():
             out["contact"] = contact_leg(local_rank)
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(bits, layers, res, dt, args.cpu_budget)
-        print(json.dumps(out))
+        sys.stdout.flush()
+        if saved_stdout is not None:
+            os.dup2(saved_stdout, 1)
+        print(json.dumps(out), flush=True)
+        if saved_stdout is not None:
+            os.dup2(2, 1)
     if world > 1:
         dist.destroy_process_group()
 
