@@ -39,7 +39,7 @@ static int ensure_contact_capacity(mpm_engine* e, size_t n) {
             (rc = grow(&b.order2, cap)) || (rc = grow(&b.cnode, 27 * cap)) || (rc = grow(&b.cfx, 3 * cap)) ||
             (rc = grow(&b.cmass, cap)) || (rc = grow(&b.cphi0, cap)) || (rc = grow(&b.cR, 9 * cap)) ||
             (rc = grow(&b.cv0, 3 * cap)) || (rc = grow(&b.crv, 3 * cap)) || (rc = grow(&b.cvel, 3 * cap)) ||
-            (rc = grow(&b.crec, 4 * cap)))
+            (rc = grow(&b.seg_part, cap * CT_SEG_F)))
             return rc;
         b.cap = cap;
     }
@@ -57,7 +57,7 @@ static int ensure_contact_capacity(mpm_engine* e, size_t n) {
         if ((rc = grow(&b.run, cells)) || (rc = grow(&b.node_flag, cells)) || (rc = grow(&b.node_list, cells)) ||
             (rc = grow(&b.node_runs, 27 * cells)) || (rc = grow(&b.gD, cells)) ||
             (e->dp.dist.on && (rc = grow(&b.hg, 3 * cells))) ||
-            (rc = grow(&b.part, (size_t)2 * CT_ROWS * CT_PART)) || (rc = grow(&b.part_dir, (size_t)2 * CT_DIR_WG)) ||
+            (rc = grow(&b.part, (size_t)(CT_ROWS_CON + CT_ROWS) * CT_PART)) || (rc = grow(&b.part_dir, (size_t)2 * CT_DIR_WG)) ||
             (rc = grow(&b.st, 1)) || (rc = grow(&b.it_log, (size_t)3 * CT_LOG)))
             return rc;
         b.cap_cells = cells;
@@ -164,7 +164,7 @@ static ContactDev make_contact_dev(mpm_engine* e, float dt, float mu, float k, f
     c.rigid_v = b.rigid_v; c.p_WB = b.p_WB; c.vel = b.vel; c.vel0 = b.vel0;
     c.key = b.key; c.order = b.order;
     c.cnode = b.cnode; c.cfx = b.cfx; c.cmass = b.cmass; c.cphi0 = b.cphi0; c.cR = b.cR; c.cv0 = b.cv0;
-    c.crv = b.crv; c.cvel = b.cvel; c.crec = b.crec;
+    c.crv = b.crv; c.cvel = b.cvel; c.seg_part = b.seg_part;
     c.run = b.run; c.node_flag = b.node_flag; c.node_list = b.node_list; c.node_runs = b.node_runs;
     c.cap_nodes = (int)b.cap_cells; c.gD = b.gD; c.hg = b.hg;
     c.part = b.part; c.part_dir = b.part_dir; c.st = b.st; c.it_log = b.it_log;
@@ -260,8 +260,9 @@ static int update_contact(mpm_engine* e, int frame, int substep, float dt, float
     // CopyContactPairs and this call): resolve them again now, from the kept caller indices.
     hipLaunchKernelGGL(k_ct_slots, dim3(gc), dim3(256), 0, s, (int)n, (const uint32_t*)b.api_idx, e->d_pids_api,
                        e->dp.imap, b.slot);
-    const int n_con_wg = (int)std::min(gc, (unsigned)CT_ROWS);  // grid-stride contact part of k_ct_ls
-    const int n_grid_wg = CT_ROWS;                               // grid-stride cell part
+    // grid-stride contact part of k_ct_ls: 4 lanes per contact
+    const int n_con_wg = (int)std::min<size_t>((n + CT_WG / 4 - 1) / (CT_WG / 4), CT_ROWS_CON);
+    const int n_grid_wg = CT_ROWS;                               // grid-stride node part
     const int n_dir_wg = CT_DIR_WG;
     // ---- set-up: contacts in base-cell order, per-cell runs, nodes that see contacts ---------
     HIP_TRY(hipMemsetAsync(b.st, 0, sizeof(ContactState), s));
@@ -293,15 +294,21 @@ static int update_contact(mpm_engine* e, int frame, int substep, float dt, float
     ContactState st{};
     int iters = 0;
     float residual = 1e10f;
+    const unsigned n_tile_wg = (unsigned)std::min<size_t>((n + CT_TILE - 1) / CT_TILE, CT_TILE_WG);
+    // contact gradients/Hessians and their per-cell sums, then (H, G) and the direction per node
+    auto launch_dir = [&](int first, int lazy) {
+        hipLaunchKernelGGL(k_ct_tile, dim3(n_tile_wg), dim3(256), 0, s, p, c, first, lazy);
+        hipLaunchKernelGGL(k_ct_node_dir<0>, dim3(n_dir_wg), dim3(CT_WG), 0, s, p, c, lazy);
+    };
     auto newton_direction = [&](int first) -> int {
-        hipLaunchKernelGGL(k_ct_contact_grad, dim3(gc), dim3(256), 0, s, p, c, first);
         if (!dist) {
-            hipLaunchKernelGGL(k_ct_node_dir<0>, dim3(n_dir_wg), dim3(CT_WG), 0, s, p, c);
+            launch_dir(first, 0);
             return 0;
         }
-        hipLaunchKernelGGL(k_ct_node_dir<1>, dim3(n_dir_wg), dim3(CT_WG), 0, s, p, c);
+        hipLaunchKernelGGL(k_ct_tile, dim3(n_tile_wg), dim3(256), 0, s, p, c, first, 0);
+        hipLaunchKernelGGL(k_ct_node_dir<1>, dim3(n_dir_wg), dim3(CT_WG), 0, s, p, c, 0);
         if (int rc = zone_exchange3(e, b.hg)) return rc;
-        hipLaunchKernelGGL(k_ct_node_dir<2>, dim3(n_dir_wg), dim3(CT_WG), 0, s, p, c);
+        hipLaunchKernelGGL(k_ct_node_dir<2>, dim3(n_dir_wg), dim3(CT_WG), 0, s, p, c, 0);
         return 0;
     };
     if (!exact && dist) {
@@ -326,14 +333,17 @@ static int update_contact(mpm_engine* e, int frame, int substep, float dt, float
         // (as many as the previous solve needed plus one, then a few at a time: iterations that start
         // after convergence are idle launches of ~2 us each)
         int batch = std::min(8, std::max(2, b.last_iters + 1));
+        // Four launches per iteration: contacts -> sums per cell, nodes -> direction, energies of all
+        // candidate steps, decision.  The accepted step reaches the grid velocity at the start of the
+        // next iteration (k_ct_node_dir, lazy; k_ct_tile reads v - alpha D meanwhile) and, for the last
+        // iteration, in the k_ct_apply after the loop.  MPM_CT_EAGER=1 keeps the separate k_ct_apply.
+        static const bool eager = getenv("MPM_CT_EAGER") != nullptr;
         while (true) {
             for (int q = 0; q < batch; ++q) {
-                const int first = (iters + q) == 0;
-                hipLaunchKernelGGL(k_ct_contact_grad, dim3(gc), dim3(256), 0, s, p, c, first);
-                hipLaunchKernelGGL(k_ct_node_dir<0>, dim3(n_dir_wg), dim3(CT_WG), 0, s, p, c);
+                launch_dir((iters + q) == 0, eager ? 0 : 1);
                 hipLaunchKernelGGL(k_ct_ls, dim3(n_con_wg + n_grid_wg), dim3(CT_WG), 0, s, p, c, n_con_wg, 0, 0.f);
-                hipLaunchKernelGGL(k_ct_decide, dim3(1), dim3(1024), 0, s, c, n_dir_wg, n_con_wg, n_grid_wg, 0);
-                hipLaunchKernelGGL(k_ct_apply, dim3(CT_ROWS), dim3(CT_WG), 0, s, p, c);
+                hipLaunchKernelGGL(k_ct_decide, dim3(1), dim3(1024), 0, s, c, n_dir_wg, n_con_wg, n_grid_wg, 0, 0);
+                if (eager) hipLaunchKernelGGL(k_ct_apply, dim3(CT_ROWS), dim3(CT_WG), 0, s, p, c, 0);
             }
             iters += batch;
             batch = 3;
@@ -341,6 +351,7 @@ static int update_contact(mpm_engine* e, int frame, int substep, float dt, float
             HIP_TRY(hipStreamSynchronize(s));
             if (st.done || st.iters >= max_iters) break;
         }
+        if (!eager) hipLaunchKernelGGL(k_ct_apply, dim3(CT_ROWS), dim3(CT_WG), 0, s, p, c, 2);
         iters = st.iters;
         residual = st.residual;
     } else if (!dist) {
@@ -353,8 +364,7 @@ static int update_contact(mpm_engine* e, int frame, int substep, float dt, float
         int batch = std::min(4, std::max(1, b.last_iters + 1));
         while (true) {
             for (int q = 0; q < batch; ++q) {
-                hipLaunchKernelGGL(k_ct_contact_grad, dim3(gc), dim3(256), 0, s, p, c, (iters + q) == 0);
-                hipLaunchKernelGGL(k_ct_node_dir<0>, dim3(n_dir_wg), dim3(CT_WG), 0, s, p, c);
+                launch_dir((iters + q) == 0, 0);
                 for (int k = 0; k < PROBES; ++k) {
                     hipLaunchKernelGGL(k_ct_ls, dim3(n_con_wg + n_grid_wg), dim3(CT_WG), 0, s, p, c, n_con_wg, 2, 0.f);
                     hipLaunchKernelGGL(k_ct_decide, dim3(1), dim3(1024), 0, s, c, n_dir_wg, n_con_wg, n_grid_wg, 2, 0);
@@ -441,6 +451,7 @@ static int update_contact(mpm_engine* e, int frame, int substep, float dt, float
     hipLaunchKernelGGL(k_ct_impulse, dim3(std::min(gc, 256u)), dim3(256), 0, s, c);
     HIP_TRY(hipGetLastError());
     b.last_iters = iters;
+    if (getenv("MPM_CT_DEBUG")) fprintf(stderr, "contact solve: n %zu nodes %d items %d iters %d\n", n, st.n_nodes, 0, iters);
     if (iters_out) *iters_out = iters;
     if (residual_out) *residual_out = residual;
     {

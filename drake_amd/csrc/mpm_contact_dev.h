@@ -27,10 +27,17 @@
 namespace mpm {
 
 constexpr int LS_CAND = 28;          // alpha = 2^-j, j = 0..27 (alpha < 1e-8 is accepted as is)
+constexpr int LS_SHALLOW = 4;        // candidates of the first pass; the other 24 only when none of these is accepted
 constexpr int CT_PART = LS_CAND + 4; // partial record: E1[28], E0, norm_dir, dofs, pad
 constexpr int CT_WG = 256;           // threads per workgroup of the contact kernels
 constexpr int CT_DIR_WG = 2048;      // workgroups of k_ct_node_dir (16 lanes per node)
-constexpr int CT_ROWS = 256;         // partial-sum records per kind (= max workgroups of the reducing kernels)
+constexpr int CT_TILE = 64;          // sorted contacts handled by one workgroup of k_ct_tile
+constexpr int CT_TILE_WG = 2048;     // workgroups of k_ct_tile at most
+static_assert(CT_TILE * 4 == 256, "k_ct_tile: 4 lanes per contact, one 16-byte piece of the record each");
+constexpr int CT_STAGE = 16;         // segments whose stencil nodes are staged in LDS at a time
+constexpr int CT_SEG_F = 27 * 12;    // floats of one segment's sums: (H[9], G[3]) per stencil node
+constexpr int CT_ROWS = 64;          // partial-sum records of the node part of k_ct_ls (= its workgroups)
+constexpr int CT_ROWS_CON = 1024;    // ... of the contact part (64 contacts per workgroup and pass)
 constexpr uint32_t CT_NO_CELL = 0x7FFFFFFFu;  // sort key of a contact whose base cell is outside the active grid
 
 struct ContactState {       // device-resident solver state
@@ -50,7 +57,8 @@ struct ContactState {       // device-resident solver state
                             // through the all-reduce, then the global ones
     // exact line search kept on the device (cuda_mpm_solver.cu:383-471): 0 = new Newton iteration, the
     // probe at alpha = 0 is pending; 1 = probe at alpha = 1 pending; 2 = root finder running;
-    // 3 = step decided, to be applied
+    // 3 = step decided, to be applied.  Backtracking search: 4 = none of the first LS_SHALLOW candidates
+    // was accepted, the next pass of k_ct_ls / k_ct_decide tries the rest (direction kernels skip)
     int ls_phase;
     int ls_evals;           // evaluations of the root finder in this Newton iteration
     float alpha_probe;      // where k_ct_ls evaluates next
@@ -80,17 +88,18 @@ struct ContactDev {
     float* cv0;             // [3][n] lagged relative velocity, contact frame
     float* crv;             // [3][n] rigid velocity at the contact point
     float* cvel;            // [3][n] contact velocity (sorted order)
-    float4* crec;           // [n][4] per contact: world-frame mass-weighted Hessian (9), gradient (3), fx (3), pad --
-                            // one 64-byte line, read by the 27 nodes of the stencil every iteration
     int2* run;              // [cells] (begin, end) of the contacts whose base cell this is
     int* node_flag;         // [cells] 1 if some contact's stencil reaches the node
     int* node_list;         // [<= cells] those nodes
-    int2* node_runs;        // [27][cap_nodes] contact runs per listed node and stencil offset
+    int2* node_runs;        // [27][cap_nodes] per listed node and stencil offset: contact run of the base cell there
+    float* seg_part;        // [n][27][12], filled at the first contact of every segment (= the contacts of one
+                            // cell inside one tile of CT_TILE sorted contacts): what the segment adds to (H, G) of
+                            // the 27 nodes of its stencil
     int cap_nodes;
     float4* gD;             // [cells] search direction (relaxed)
     float4* hg;             // [cells][3] partitioned domain: contact Hessian (9) and gradient (3) sums per node,
                             // this rank's contacts first, the neighbours' added by the zone exchange
-    double* part;           // [2][CT_ROWS][CT_PART] line-search partial sums (contacts, cells)
+    double* part;           // [CT_ROWS_CON + CT_ROWS][CT_PART] line-search partial sums (contacts, then cells)
     double* part_dir;       // [CT_DIR_WG][2] (|Dir|^2, DoFs) per workgroup of k_ct_node_dir
     ContactState* st;
     float* it_log;          // [CT_LOG][3] exact search: residual, line-search evaluations, energy per Newton iteration
@@ -129,11 +138,11 @@ struct ContactBuffers {
     int* cnode = nullptr;
     float *cfx = nullptr, *cmass = nullptr, *cphi0 = nullptr, *cR = nullptr, *cv0 = nullptr, *crv = nullptr,
           *cvel = nullptr;
-    float4* crec = nullptr;
     int2* run = nullptr;
     int* node_flag = nullptr;
     int* node_list = nullptr;
     int2* node_runs = nullptr;
+    float* seg_part = nullptr;
     float4* gD = nullptr;
     float4* hg = nullptr;
     void* zone_buf[4] = {nullptr, nullptr, nullptr, nullptr};   // send left / right, receive left / right
@@ -148,7 +157,7 @@ struct ContactBuffers {
 
     void release() {
         void* ptrs[] = {api_idx, colliders, gen_cnt, gen_sums, slot, body, dist, normal, pos, rigid_v, p_WB, vel, vel0, key, order, key2, order2, sort_hist,
-                        cnode, cfx, cmass, cphi0, cR, cv0, crv, cvel, crec, run, node_flag, node_list, node_runs, gD, hg,
+                        cnode, cfx, cmass, cphi0, cR, cv0, crv, cvel, run, node_flag, node_list, node_runs, seg_part, gD, hg,
                         zone_buf[0], zone_buf[1], zone_buf[2], zone_buf[3], part, part_dir, st, it_log, body_tau, body_f};
         for (void* q : ptrs)
             if (q) (void)hipFree(q);
@@ -396,8 +405,6 @@ __global__ __launch_bounds__(1024) void k_ct_node_list(DP p, ContactDev c) {
     if (tid == 0) c.st->n_nodes = carry;
 }
 
-// S4: per listed node, the contact runs of the 27 base cells whose stencil reaches it
-// (base = node - (i, j, l)), so that the Newton iterations do not repeat the table walks
 __global__ __launch_bounds__(256) void k_ct_node_runs(DP p, ContactDev c) {
     const int n_nodes = c.st->n_nodes;
     for (int t = blockIdx.x * 256 + threadIdx.x; t < n_nodes * 27; t += gridDim.x * 256) {
@@ -535,46 +542,6 @@ __global__ __launch_bounds__(256) void k_ct_flags_to_field(DP p, ContactDev c, i
 
 // ---- one Newton iteration ------------------------------------------------------
 
-// C1: refresh contact_vel (from the 2nd iteration on) and evaluate the contact Hessian and
-// gradient in the world frame (cuda_mpm_kernels.cuh:1107-1154)
-__global__ __launch_bounds__(256) void k_ct_contact_grad(DP p, ContactDev c, int first) {
-    const int j = blockIdx.x * 256 + threadIdx.x;
-    if (j >= c.n || c.st->done || c.st->ls_phase != 0) return;   // (exact search: still probing the previous direction)
-    float v[3];
-    if (first) {
-        v[0] = c.cvel[j]; v[1] = c.cvel[c.n + j]; v[2] = c.cvel[2 * c.n + j];
-    } else {
-        gather_contact_velocity(p, c, j, v);
-        c.cvel[j] = v[0]; c.cvel[c.n + j] = v[1]; c.cvel[2 * c.n + j] = v[2];
-    }
-    float R[9], v0[3];
-#pragma unroll
-    for (int t = 0; t < 9; ++t) R[t] = c.cR[t * c.n + j];
-#pragma unroll
-    for (int t = 0; t < 3; ++t) v0[t] = c.cv0[t * c.n + j];
-    const float vr[3] = {v[0] - c.crv[j], v[1] - c.crv[c.n + j], v[2] - c.crv[2 * c.n + j]};
-    float vl[3];
-    mulv3(R, vr, vl);
-    const ContactParams cp = {c.dt, c.mu, c.k, c.d, c.epsv};
-    float CH[9], CG[3];
-    contact_grad_hess(cp, c.cphi0[j], v0, vl, CH, CG);
-    // world frame: R^T G, R^T H R
-    float RT[9], tmp[9], WH[9], WG[3];
-#pragma unroll
-    for (int i = 0; i < 3; ++i)
-#pragma unroll
-        for (int jj = 0; jj < 3; ++jj) RT[jj * 3 + i] = R[i * 3 + jj];
-    mulv3(RT, CG, WG);
-    mul33(RT, CH, tmp);
-    mul33(tmp, R, WH);
-    const float mass = c.cmass[j];
-    float4* rec = c.crec + (size_t)j * 4;
-    rec[0] = make_float4(mass * WH[0], mass * WH[1], mass * WH[2], mass * WH[3]);
-    rec[1] = make_float4(mass * WH[4], mass * WH[5], mass * WH[6], mass * WH[7]);
-    rec[2] = make_float4(mass * WH[8], mass * WG[0], mass * WG[1], mass * WG[2]);
-    if (first) rec[3] = make_float4(c.cfx[j], c.cfx[c.n + j], c.cfx[2 * c.n + j], 0.f);
-}
-
 template <int count>
 MPM_DEV void wg_reduce_store(double* vals, double* out) {
     // vals: per-thread values; reduces over the workgroup (CT_WG threads) into out[count].  Fully
@@ -597,6 +564,187 @@ MPM_DEV void wg_reduce_store(double* vals, double* out) {
     __syncthreads();
 }
 
+// Segments of a tile of sorted contacts: a segment = the contacts of one cell inside the tile.  Wave 0
+// fills s_seg[0..nseg] (first contact of every segment, then cnt) and s_cseg[contact] (its segment).
+MPM_DEV void tile_segments(const ContactDev& c, int lo, int cnt, int* s_seg, int* s_cseg, int* s_nseg) {
+    const int tid = threadIdx.x;
+    if (tid >= 64) return;
+    const uint32_t key = c.key[lo + min(tid, cnt - 1)];
+    const uint32_t prev = __shfl_up(key, 1);
+    const bool head = tid < cnt && (tid == 0 || key != prev);
+    const unsigned long long m = __ballot(head);
+    const int before = __popcll(m & ((1ull << tid) - 1ull));   // heads in front of this contact
+    if (head) s_seg[before] = tid;
+    s_cseg[tid] = before - (head ? 0 : 1);
+    if (tid == 0) {
+        *s_nseg = __popcll(m);
+        s_seg[__popcll(m)] = cnt;
+    }
+}
+
+// C1 + G1a: one workgroup per tile of CT_TILE sorted contacts.
+//  0. Contacts of one cell share their 27 stencil nodes: the nodes of every segment are read once, into
+//     LDS (per contact, the 62k x 27 gathers of config 3 kept the L1 tag lookup busy for ~9 us).
+//  1. The 4 lanes of a contact gather its velocity from there (9 nodes each; the fourth lane stores the
+//     contact's nine 1-D weights meanwhile), all four evaluate the contact's gradient and Hessian
+//     (cuda_mpm_kernels.cuh:1107-1154, 1276-1473) in the world frame, and three of them store one
+//     16-byte piece of the record (mass-weighted symmetric H[6], G[3]) -- in LDS only.
+//  2. Per segment, the sums  H_n = sum w_n^2 H,  G_n = sum w_n G  over its contacts are formed by thread
+//     (segment, node, 1 of S interleaved subsets), the subsets added in fixed order, and written to
+//     seg_part at the index of the segment's first contact.  k_ct_node_dir adds up the segments of a
+//     node's 27 base cells.
+// (Per node instead, every record was read 27 times through L2 and only nodes x 16 lanes were busy:
+// 31-47 us per Newton iteration on config 3, 62k contacts in 4225 cells.)
+// lazy: the step of the previous Newton iteration has not been added to the grid yet (k_ct_node_dir does
+// that, after this kernel): velocities are read as v - alpha D.
+__global__ __launch_bounds__(256) void k_ct_tile(DP p, ContactDev c, int first, int lazy) {
+    if (c.st->done || c.st->ls_phase != 0) return;   // (line search of the previous direction still running)
+    __shared__ float s_part[8][CT_SEG_F];
+    __shared__ __attribute__((aligned(16))) float4 s_rec[CT_TILE * 3];
+    __shared__ __attribute__((aligned(16))) float4 s_nv[CT_STAGE * 27];
+    __shared__ float s_w[CT_TILE][9];
+    __shared__ int s_seg[CT_TILE + 1];
+    __shared__ int s_cseg[CT_TILE];
+    __shared__ int s_nseg;
+    const int n_tiles = (c.n + CT_TILE - 1) / CT_TILE;
+    const float al = lazy ? c.st->alpha : 0.f;
+    const int tid = threadIdx.x, lc = tid >> 2, part = tid & 3;
+    const ContactParams cp = {c.dt, c.mu, c.k, c.d, c.epsv};
+    for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const int lo = tile * CT_TILE, cnt = min(CT_TILE, c.n - lo);
+        tile_segments(c, lo, cnt, s_seg, s_cseg, &s_nseg);
+        __syncthreads();
+        const int nseg = s_nseg;
+        const int jc = min(lc, cnt - 1);   // (lanes past the end repeat the last contact and store nothing)
+        const int j = lo + jc;
+        float wx[3], wy[3], wz[3];
+        bspline3(c.cfx[j], wx);
+        bspline3(c.cfx[c.n + j], wy);
+        bspline3(c.cfx[2 * c.n + j], wz);
+        if (part == 3 && lc < cnt) {
+#pragma unroll
+            for (int t = 0; t < 3; ++t) {
+                s_w[lc][t] = wx[t];
+                s_w[lc][3 + t] = wy[t];
+                s_w[lc][6 + t] = wz[t];
+            }
+        }
+        float v[3] = {0.f, 0.f, 0.f};
+        if (first) {
+            v[0] = c.cvel[j]; v[1] = c.cvel[c.n + j]; v[2] = c.cvel[2 * c.n + j];
+        } else {
+            // grid_to_particle_kernel<CONTACT_TRANSFER=true> (cuda_mpm_kernels.cuh:860-866, 891-894):
+            // velocity at the contact point from nodes with m > 1e-7
+            const int myseg = s_cseg[jc];
+            const float wxi = part == 0 ? wx[0] : (part == 1 ? wx[1] : wx[2]);
+            for (int s0 = 0; s0 < nseg; s0 += CT_STAGE) {
+                const int ns = min(CT_STAGE, nseg - s0);
+                for (int t = tid; t < ns * 27; t += 256) {
+                    const int sg = t / 27, n = t - sg * 27;
+                    const int g = c.cnode[(size_t)n * c.n + lo + s_seg[s0 + sg]];
+                    const float4 q = p.gv[max(g, 0)], D = c.gD[max(g, 0)];
+                    const bool ok = g >= 0 && q.w > 1e-7f;
+                    s_nv[t] = ok ? make_float4(fmaf(-al, D.x, q.x), fmaf(-al, D.y, q.y), fmaf(-al, D.z, q.z), 1.f)
+                                 : make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+                __syncthreads();
+                if (part < 3 && myseg >= s0 && myseg < s0 + ns) {
+                    const float4* nv = s_nv + (myseg - s0) * 27 + part * 9;
+#pragma unroll
+                    for (int m = 0; m < 9; ++m) {
+                        const float4 q = nv[m];
+                        const float w = q.w != 0.f ? wxi * wy[m / 3] * wz[m % 3] : 0.f;
+                        v[0] += w * q.x; v[1] += w * q.y; v[2] += w * q.z;
+                    }
+                }
+                __syncthreads();
+            }
+#pragma unroll
+            for (int t = 0; t < 3; ++t) {
+                v[t] += __shfl_xor(v[t], 1);
+                v[t] += __shfl_xor(v[t], 2);
+            }
+        }
+        float R[9], v0[3];
+#pragma unroll
+        for (int t = 0; t < 9; ++t) R[t] = c.cR[t * c.n + j];
+#pragma unroll
+        for (int t = 0; t < 3; ++t) v0[t] = c.cv0[t * c.n + j];
+        const float vr[3] = {v[0] - c.crv[j], v[1] - c.crv[c.n + j], v[2] - c.crv[2 * c.n + j]};
+        float vl[3];
+        mulv3(R, vr, vl);
+        float CH[9], CG[3];
+        contact_grad_hess(cp, c.cphi0[j], v0, vl, CH, CG);
+        // world frame: R^T G and R^T H R, with the zeros of the contact-frame Hessian (its tangential 2 x 2
+        // block and the normal entry are all there is) left out of the products
+        float tm[9];   // R^T H
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            tm[i * 3] = R[i] * CH[0] + R[3 + i] * CH[3];
+            tm[i * 3 + 1] = R[i] * CH[1] + R[3 + i] * CH[4];
+            tm[i * 3 + 2] = R[6 + i] * CH[8];
+        }
+        const float mass = c.cmass[j];
+        float hs[6];   // xx xy xz yy yz zz
+        {
+            const int ii[6] = {0, 0, 0, 1, 1, 2}, jj2[6] = {0, 1, 2, 1, 2, 2};
+#pragma unroll
+            for (int t = 0; t < 6; ++t)
+                hs[t] = mass * (tm[ii[t] * 3] * R[jj2[t]] + tm[ii[t] * 3 + 1] * R[3 + jj2[t]] + tm[ii[t] * 3 + 2] * R[6 + jj2[t]]);
+        }
+        float WG[3];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) WG[i] = mass * (R[i] * CG[0] + R[3 + i] * CG[1] + R[6 + i] * CG[2]);
+        float4 piece;
+        if (part == 0) piece = make_float4(hs[0], hs[1], hs[2], hs[3]);
+        else if (part == 1) piece = make_float4(hs[4], hs[5], WG[0], WG[1]);
+        else piece = make_float4(WG[2], 0.f, 0.f, 0.f);
+        if (lc < cnt && part < 3) s_rec[lc * 3 + part] = piece;
+        __syncthreads();
+        // ---- sums per segment: S subsets per segment, 8 / S segments at a time ----------------
+        int S = 8, lgS = 3;
+        while (S > 1 && nseg * S > 8) {
+            S >>= 1;
+            --lgS;
+        }
+        const int per_round = 8 >> lgS;
+        const int slot = tid >> 5, o = tid & 31;
+        const int cl = slot >> lgS, sub = slot & (S - 1);
+        // a contact with base cell b reaches node b + (i, j, l) with weight N_i N_j N_l
+        const int wi = o / 9, wj = 3 + (o / 3) % 3, wl = 6 + o % 3;
+        for (int s0 = 0; s0 < nseg; s0 += per_round) {
+            const int sg = s0 + cl;
+            if (o < 27 && sg < nseg) {
+                float H[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, G[3] = {0.f, 0.f, 0.f};
+                const int kb = s_seg[sg + 1];
+                for (int k = s_seg[sg] + sub; k < kb; k += S) {
+                    const float4 r0 = s_rec[k * 3], r1 = s_rec[k * 3 + 1];
+                    const float gz = s_rec[k * 3 + 2].x;
+                    const float w = s_w[k][wi] * s_w[k][wj] * s_w[k][wl];
+                    const float w2 = w * w;
+                    H[0] += w2 * r0.x; H[1] += w2 * r0.y; H[2] += w2 * r0.z; H[3] += w2 * r0.w;
+                    H[4] += w2 * r1.x; H[5] += w2 * r1.y;
+                    G[0] += w * r1.z; G[1] += w * r1.w; G[2] += w * gz;
+                }
+                float* d = s_part[slot] + o * 12;
+                d[0] = H[0]; d[1] = H[1]; d[2] = H[2];
+                d[3] = H[1]; d[4] = H[3]; d[5] = H[4];
+                d[6] = H[2]; d[7] = H[4]; d[8] = H[5];
+                d[9] = G[0]; d[10] = G[1]; d[11] = G[2];
+            }
+            __syncthreads();
+            for (int e = tid; e < per_round * CT_SEG_F; e += 256) {
+                const int c2 = e / CT_SEG_F, ee = e - c2 * CT_SEG_F;
+                if (s0 + c2 >= nseg) break;
+                float a = s_part[c2 << lgS][ee];
+                for (int q = 1; q < S; ++q) a += s_part[(c2 << lgS) + q][ee];
+                c.seg_part[(size_t)(lo + s_seg[s0 + c2]) * CT_SEG_F + ee] = a;
+            }
+            __syncthreads();
+        }
+    }
+}
+
 // G1: per node that sees contacts, gather the Hessian/gradient of those contacts, add the inertia
 // term and solve for the Newton direction (cuda_mpm_kernels.cuh:1217-1274).  16 lanes per node:
 // the node's contacts are the runs of its 27 neighbour base cells; lane s takes every 16th
@@ -605,10 +753,13 @@ MPM_DEV void wg_reduce_store(double* vals, double* out) {
 // c.hg (every cell of it is written: zeros where no contact reaches), the zone exchange adds the
 // neighbours' sums, MODE 2 solves from c.hg; |Dir|^2 and the DoF count only include owned nodes.
 template <int MODE>
-__global__ __launch_bounds__(CT_WG) void k_ct_node_dir(DP p, ContactDev c) {
+__global__ __launch_bounds__(CT_WG) void k_ct_node_dir(DP p, ContactDev c, int lazy = 0) {
     if (c.st->done || c.st->ls_phase != 0) return;   // k_ct_decide does not read the records of a finished solve
     double acc[2] = {0, 0};
     const int sub = threadIdx.x & 15;
+    // lazy: the accepted step of the previous iteration is still to be added to the grid velocity
+    // (k_ct_apply's job otherwise); this kernel is the one that replaces D, so it does that first
+    const float al_prev = lazy ? c.st->alpha : 0.f;
     {
         const int n_nodes = c.st->n_nodes;
         const int stride = (gridDim.x * CT_WG) >> 4;
@@ -617,7 +768,13 @@ __global__ __launch_bounds__(CT_WG) void k_ct_node_dir(DP p, ContactDev c) {
             const bool live = q < n_nodes;
             const int g = live ? c.node_list[q] : 0;
             float H[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, G[3] = {0.f, 0.f, 0.f};
-            const float4 gq = p.gv[g];
+            float4 gq = p.gv[g];
+            if (lazy) {
+                const float4 Do = c.gD[g];
+                gq.x = fmaf(-al_prev, Do.x, gq.x);
+                gq.y = fmaf(-al_prev, Do.y, gq.y);
+                gq.z = fmaf(-al_prev, Do.z, gq.z);
+            }
             if (MODE == 2) {
                 if (live && sub == 0) {
                     const float4 h0 = c.hg[(size_t)g * 3], h1 = c.hg[(size_t)g * 3 + 1], h2 = c.hg[(size_t)g * 3 + 2];
@@ -625,35 +782,27 @@ __global__ __launch_bounds__(CT_WG) void k_ct_node_dir(DP p, ContactDev c) {
                     H[8] = h2.x; G[0] = h2.y; G[1] = h2.z; G[2] = h2.w;
                 }
             } else if (live && gq.w > 0.f) {
-                // lane s owns the runs of stencil offsets s and s + 16 (27 offsets over 16 lanes): the
-                // table walks and the contact loads of different offsets overlap across the lanes, the
-                // loop over a run's contacts is a plain stream
-                // (the two runs one after the other: side by side was measured slower, 30.7 -> 39.3 us -- the
-                // kernel is bound by the L2 traffic of the records, not by the latency of a load)
-#pragma unroll
-                for (int half = 0; half < 2; ++half) {
-                    const int o = sub + 16 * half;
-                    if (o >= 27) break;
-                    // contacts whose base cell is node - (i, j, l) reach this node with weight N_i N_j N_l
-                    const int i = o / 9, jj = (o / 3) % 3, l = o % 3;
-                    const int2 r = c.node_runs[(size_t)o * c.cap_nodes + q];
-#pragma unroll 2
-                    for (int k = r.x; k < r.y; ++k) {
-                        const float4* rec = c.crec + (size_t)k * 4;
-                        const float4 r0 = rec[0], r1 = rec[1], r2 = rec[2], r3 = rec[3];
-                        float wx[3], wy[3], wz[3];
-                        bspline3(r3.x, wx);
-                        bspline3(r3.y, wy);
-                        bspline3(r3.z, wz);
-                        const float w = (i == 0 ? wx[0] : (i == 1 ? wx[1] : wx[2])) *
-                                        (jj == 0 ? wy[0] : (jj == 1 ? wy[1] : wy[2])) *
-                                        (l == 0 ? wz[0] : (l == 1 ? wz[1] : wz[2]));
-                        const float w2 = w * w;
-                        H[0] += w2 * r0.x; H[1] += w2 * r0.y; H[2] += w2 * r0.z; H[3] += w2 * r0.w;
-                        H[4] += w2 * r1.x; H[5] += w2 * r1.y; H[6] += w2 * r1.z; H[7] += w2 * r1.w;
-                        H[8] += w2 * r2.x;
-                        G[0] += w * r2.y; G[1] += w * r2.z; G[2] += w * r2.w;
-                    }
+                // lane s adds up the segments of stencil offsets s and s + 16 (27 offsets over 16 lanes):
+                // contacts whose base cell is node - (i, j, l) reach this node with weight N_i N_j N_l,
+                // already applied by k_ct_tile
+                const int o1 = min(sub + 16, 26);
+                const int2 ra = c.node_runs[(size_t)sub * c.cap_nodes + q];
+                int2 rb = c.node_runs[(size_t)o1 * c.cap_nodes + q];
+                if (sub + 16 >= 27) rb = make_int2(0, 0);
+                // (a run is cut where it crosses a tile boundary; each piece has its sums at its first contact)
+                for (int k = ra.x; k < ra.y; k = (k | (CT_TILE - 1)) + 1) {
+                    const float4* part = reinterpret_cast<const float4*>(c.seg_part + ((size_t)k * 27 + sub) * 12);
+                    const float4 a0 = part[0], a1 = part[1], a2 = part[2];
+                    H[0] += a0.x; H[1] += a0.y; H[2] += a0.z; H[3] += a0.w;
+                    H[4] += a1.x; H[5] += a1.y; H[6] += a1.z; H[7] += a1.w;
+                    H[8] += a2.x; G[0] += a2.y; G[1] += a2.z; G[2] += a2.w;
+                }
+                for (int k = rb.x; k < rb.y; k = (k | (CT_TILE - 1)) + 1) {
+                    const float4* part = reinterpret_cast<const float4*>(c.seg_part + ((size_t)k * 27 + o1) * 12);
+                    const float4 a0 = part[0], a1 = part[1], a2 = part[2];
+                    H[0] += a0.x; H[1] += a0.y; H[2] += a0.z; H[3] += a0.w;
+                    H[4] += a1.x; H[5] += a1.y; H[6] += a1.z; H[7] += a1.w;
+                    H[8] += a2.x; G[0] += a2.y; G[1] += a2.z; G[2] += a2.w;
                 }
             }
             // fold the 16 lanes of the node (xor butterfly inside a row of 16)
@@ -697,6 +846,7 @@ __global__ __launch_bounds__(CT_WG) void k_ct_node_dir(DP p, ContactDev c) {
                 }
             }
             c.gD[g] = D;
+            if (lazy && gq.w > 0.f) p.gv[g] = gq;
         }
     }
     wg_reduce_store<2>(acc, c.part_dir + (size_t)blockIdx.x * 2);
@@ -713,44 +863,73 @@ __global__ __launch_bounds__(CT_WG) void k_ct_ls(DP p, ContactDev c, int n_con_w
         if (c.st->ls_phase == 3) return;
         alpha_probe = c.st->alpha_probe;
     }
-    double acc[CT_PART];
-#pragma unroll
-    for (int q = 0; q < CT_PART; ++q) acc[q] = 0;
-    const bool live = true;
+    const bool deep = !exact && c.st->ls_phase == 4;
     if ((int)blockIdx.x < n_con_wg) {
-        for (int j = blockIdx.x * CT_WG + threadIdx.x; live && j < c.n; j += n_con_wg * CT_WG) {
+        // A tile of CT_TILE sorted contacts at a time, 4 lanes per contact: the stencil nodes of every
+        // segment are staged in LDS once (see k_ct_tile), each lane adds up 9 of the 27 and evaluates its
+        // share of the candidate steps
+        __shared__ double s_red[CT_WG / 64][CT_PART];
+        __shared__ __attribute__((aligned(16))) float4 s_nv[CT_STAGE * 27];
+        __shared__ __attribute__((aligned(16))) float4 s_nD[CT_STAGE * 27];
+        __shared__ int s_seg[CT_TILE + 1];
+        __shared__ int s_cseg[CT_TILE];
+        __shared__ int s_nseg;
+        const int tid = threadIdx.x, lc = tid >> 2;
+        const int part = threadIdx.x & 3, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+        const ContactParams cp = {c.dt, c.mu, c.k, c.d, c.epsv};
+        double acc[6] = {0, 0, 0, 0, 0, 0}, e0 = 0;
+        const int n_tiles = (c.n + CT_TILE - 1) / CT_TILE;
+        for (int tile = blockIdx.x; tile < n_tiles; tile += n_con_wg) {
+            const int lo = tile * CT_TILE, cnt = min(CT_TILE, c.n - lo);
+            __syncthreads();   // the previous tile's tables are no longer read
+            tile_segments(c, lo, cnt, s_seg, s_cseg, &s_nseg);
+            __syncthreads();
+            const int nseg = s_nseg;
+            const int jc = min(lc, cnt - 1), j = lo + jc;
+            const bool counted = lc < cnt;   // (lanes past the end repeat the last contact and add nothing)
             float wx[3], wy[3], wz[3];
             bspline3(c.cfx[j], wx);
             bspline3(c.cfx[c.n + j], wy);
             bspline3(c.cfx[2 * c.n + j], wz);
+            const float wxi = part == 0 ? wx[0] : (part == 1 ? wx[1] : wx[2]);
+            const int myseg = s_cseg[jc];
             float ov[3] = {0.f, 0.f, 0.f}, dd[3] = {0.f, 0.f, 0.f};
-            // branch-free gather in three sweeps (indices, then both node fields, then the sums): all
-            // loads of a sweep are in flight together
-            int gi[27];
-#pragma unroll
-            for (int n = 0; n < 27; ++n) gi[n] = c.cnode[n * c.n + j];
-#pragma unroll
-            for (int n0 = 0; n0 < 27; n0 += 9) {   // (9 nodes at a time: 18 x 16 bytes of registers)
-                float4 q[9], D[9];
-#pragma unroll
-                for (int k = 0; k < 9; ++k) {
-                    q[k] = p.gv[max(gi[n0 + k], 0)];
-                    D[k] = c.gD[max(gi[n0 + k], 0)];
+            for (int s0 = 0; s0 < nseg; s0 += CT_STAGE) {
+                const int ns = min(CT_STAGE, nseg - s0);
+                for (int t = tid; t < ns * 27; t += CT_WG) {
+                    const int sg = t / 27, n = t - sg * 27;
+                    const int g = c.cnode[(size_t)n * c.n + lo + s_seg[s0 + sg]];
+                    float4 q = p.gv[max(g, 0)], D = c.gD[max(g, 0)];
+                    D.w = g >= 0 ? 1.f : 0.f;
+                    s_nv[t] = q;
+                    s_nD[t] = D;
                 }
+                __syncthreads();
+                if (part < 3 && myseg >= s0 && myseg < s0 + ns) {
+                    const int at = (myseg - s0) * 27 + part * 9;
 #pragma unroll
-                for (int k = 0; k < 9; ++k) {
-                    const float w = gi[n0 + k] >= 0 ? stencil_weight(wx, wy, wz, n0 + k) : 0.f;
-                    ov[0] += w * q[k].x; ov[1] += w * q[k].y; ov[2] += w * q[k].z;
-                    dd[0] += w * D[k].x; dd[1] += w * D[k].y; dd[2] += w * D[k].z;
+                    for (int m = 0; m < 9; ++m) {
+                        const float4 q = s_nv[at + m], D = s_nD[at + m];
+                        const float w = D.w != 0.f ? wxi * wy[m / 3] * wz[m % 3] : 0.f;
+                        ov[0] += w * q.x; ov[1] += w * q.y; ov[2] += w * q.z;
+                        dd[0] += w * D.x; dd[1] += w * D.y; dd[2] += w * D.z;
+                    }
                 }
+                __syncthreads();
             }
-            const ContactParams cp = {c.dt, c.mu, c.k, c.d, c.epsv};
+#pragma unroll
+            for (int t = 0; t < 3; ++t) {
+                ov[t] += __shfl_xor(ov[t], 1);
+                ov[t] += __shfl_xor(ov[t], 2);
+                dd[t] += __shfl_xor(dd[t], 1);
+                dd[t] += __shfl_xor(dd[t], 2);
+            }
             float R[9], v0[3];
 #pragma unroll
             for (int t = 0; t < 9; ++t) R[t] = c.cR[t * c.n + j];
 #pragma unroll
             for (int t = 0; t < 3; ++t) v0[t] = c.cv0[t * c.n + j];
-            const float phi0 = c.cphi0[j], mass = c.cmass[j];
+            const float phi0 = c.cphi0[j], mass = counted ? c.cmass[j] : 0.f;
             float ovl[3], ddl[3];
             {
                 const float t[3] = {ov[0] - c.crv[j], ov[1] - c.crv[c.n + j], ov[2] - c.crv[2 * c.n + j]};
@@ -758,15 +937,23 @@ __global__ __launch_bounds__(CT_WG) void k_ct_ls(DP p, ContactDev c, int n_con_w
                 mulv3(R, dd, ddl);
             }
             if (!exact) {
-                acc[LS_CAND] += (double)(mass * contact_cost(cp, phi0, v0, ovl));
-                float al = 1.f;
-#pragma unroll
-                for (int q = 0; q < LS_CAND; ++q) {
+                // shallow pass: lane `part` tries alpha = 2^-part; deep pass (none of those four was
+                // accepted): alpha = 2^-(4 + 6 part + m), m = 0..5
+                if (!deep) {
+                    if (part == 0) e0 += (double)(mass * contact_cost(cp, phi0, v0, ovl));
+                    const float al = ldexpf(1.f, -part);
                     const float nv[3] = {ovl[0] - al * ddl[0], ovl[1] - al * ddl[1], ovl[2] - al * ddl[2]};
-                    acc[q] += (double)(mass * contact_cost(cp, phi0, v0, nv));
-                    al *= .5f;
+                    acc[0] += (double)(mass * contact_cost(cp, phi0, v0, nv));
+                } else {
+                    float al = ldexpf(1.f, -(LS_SHALLOW + 6 * part));
+#pragma unroll
+                    for (int m = 0; m < 6; ++m) {
+                        const float nv[3] = {ovl[0] - al * ddl[0], ovl[1] - al * ddl[1], ovl[2] - al * ddl[2]};
+                        acc[m] += (double)(mass * contact_cost(cp, phi0, v0, nv));
+                        al *= .5f;
+                    }
                 }
-            } else {
+            } else if (part == 0) {
                 const float al = alpha_probe;
                 const float nv[3] = {ovl[0] - al * ddl[0], ovl[1] - al * ddl[1], ovl[2] - al * ddl[2]};
                 float CH[9], CG[3];
@@ -779,24 +966,63 @@ __global__ __launch_bounds__(CT_WG) void k_ct_ls(DP p, ContactDev c, int n_con_w
                 acc[2] += (double)(mass * dot3(t, ddl));
             }
         }
-        wg_reduce_store<LS_CAND + 1>(acc, c.part + (size_t)blockIdx.x * CT_PART);
+        // lanes with the same `part` are added up (fixed butterfly), then the 4 waves
+        for (int q = threadIdx.x; q < (CT_WG / 64) * CT_PART; q += CT_WG) (&s_red[0][0])[q] = 0.0;
+        __syncthreads();
+#pragma unroll
+        for (int m = 0; m < 6; ++m) {
+            if (!exact && !deep && m > 0) break;
+            double v = acc[m];
+#pragma unroll
+            for (int d = 4; d <= 32; d <<= 1) v += __shfl_xor(v, d);
+            const int at = exact ? (lane == 0 ? m : LS_CAND + 1) : (deep ? LS_SHALLOW + lane * 6 + m : lane);
+            if (lane < 4) s_red[wv][at] = v;
+        }
+        {
+            double v = e0;
+#pragma unroll
+            for (int d = 4; d <= 32; d <<= 1) v += __shfl_xor(v, d);
+            if (lane == 0) s_red[wv][LS_CAND] = v;
+        }
+        __syncthreads();
+        if (threadIdx.x <= LS_CAND) {
+            double v = 0;
+            for (int q = 0; q < CT_WG / 64; ++q) v += s_red[q][threadIdx.x];
+            c.part[(size_t)blockIdx.x * CT_PART + threadIdx.x] = v;
+        }
         return;
     }
-    const int ncell = (int)p.ctl->n_active * 64;
+    // inertia part.  Only nodes that see contacts take part: elsewhere the direction is zero and v == v*
+    // bit for bit (k_grid writes both from the same registers), so every energy term is an exact zero.
+    double acc[LS_CAND - LS_SHALLOW], e0 = 0;
+#pragma unroll
+    for (int q = 0; q < LS_CAND - LS_SHALLOW; ++q) acc[q] = 0;
+    const int n_nodes = c.st->n_nodes;
     const int b = (int)blockIdx.x - n_con_wg, nb = (int)gridDim.x - n_con_wg;
-    for (int g = b * CT_WG + threadIdx.x; live && g < ncell; g += nb * CT_WG) {
+    for (int i = b * CT_WG + threadIdx.x; i < n_nodes; i += nb * CT_WG) {
+        const int g = c.node_list[i];
         const float4 q = p.gv[g];
         if (!(q.w > 0.f) || !node_owned(p, g)) continue;
         const float4 vs = p.gvs[g], D = c.gD[g];
         const float o[3] = {q.x - vs.x, q.y - vs.y, q.z - vs.z};
         if (!exact) {
-            acc[LS_CAND] += (double)(.5f * q.w * (o[0] * o[0] + o[1] * o[1] + o[2] * o[2]));
-            float al = 1.f;
+            if (!deep) {
+                e0 += (double)(.5f * q.w * (o[0] * o[0] + o[1] * o[1] + o[2] * o[2]));
+                float al = 1.f;
 #pragma unroll
-            for (int k = 0; k < LS_CAND; ++k) {
-                const float n0 = o[0] - al * D.x, n1 = o[1] - al * D.y, n2 = o[2] - al * D.z;
-                acc[k] += (double)(.5f * q.w * (n0 * n0 + n1 * n1 + n2 * n2));
-                al *= .5f;
+                for (int k = 0; k < LS_SHALLOW; ++k) {
+                    const float n0 = o[0] - al * D.x, n1 = o[1] - al * D.y, n2 = o[2] - al * D.z;
+                    acc[k] += (double)(.5f * q.w * (n0 * n0 + n1 * n1 + n2 * n2));
+                    al *= .5f;
+                }
+            } else {
+                float al = ldexpf(1.f, -LS_SHALLOW);
+#pragma unroll
+                for (int k = 0; k < LS_CAND - LS_SHALLOW; ++k) {
+                    const float n0 = o[0] - al * D.x, n1 = o[1] - al * D.y, n2 = o[2] - al * D.z;
+                    acc[k] += (double)(.5f * q.w * (n0 * n0 + n1 * n1 + n2 * n2));
+                    al *= .5f;
+                }
             }
         } else {
             const float al = alpha_probe;
@@ -806,7 +1032,15 @@ __global__ __launch_bounds__(CT_WG) void k_ct_ls(DP p, ContactDev c, int n_con_w
             acc[2] += (double)(q.w * (D.x * D.x + D.y * D.y + D.z * D.z));
         }
     }
-    wg_reduce_store<LS_CAND + 1>(acc, c.part + (size_t)(CT_ROWS + b) * CT_PART);
+    double* row = c.part + (size_t)(CT_ROWS_CON + b) * CT_PART;
+    if (exact) {
+        wg_reduce_store<3>(acc, row);
+    } else if (!deep) {
+        wg_reduce_store<LS_SHALLOW>(acc, row);
+        wg_reduce_store<1>(&e0, row + LS_CAND);
+    } else {
+        wg_reduce_store<LS_CAND - LS_SHALLOW>(acc, row + LS_SHALLOW);
+    }
 }
 
 // S: fixed-order sum of the partial records, choice of the step, convergence test
@@ -814,17 +1048,13 @@ __global__ __launch_bounds__(CT_WG) void k_ct_ls(DP p, ContactDev c, int n_con_w
 // r, r + 32, ... of every kind; wave 0 adds the 32 row groups in order and decides.
 // `phase` (partitioned domain): 0 = sum and decide in one go; 1 = only leave this rank's sums in
 // st->red[0..31] (the host all-reduces them); 2 = decide from the global sums put back into st->red.
-__global__ __launch_bounds__(1024) void k_ct_decide(ContactDev c, int n_dir_wg, int n_con_wg, int n_grid_wg, int exact,
-                                                    int phase = 0) {
-    __shared__ double s_sum[32][CT_PART];
-    __shared__ double s_dir[16][2];
+// The decision of a Newton iteration from the partial sums (one workgroup of NT threads: the kernel
+// below, or the last workgroup of k_ct_ls to finish).
+template <int NT>
+MPM_DEV void ct_decide(const ContactDev& c, int n_dir_wg, int n_con_wg, int n_grid_wg, int exact, int phase,
+                       double (*s_sum)[CT_PART], double (*s_dir)[2]) {
+    constexpr int RG = NT / 32;   // row groups: thread (e, r) adds entry e of rows r, r + RG, ...
     ContactState* st = c.st;
-    if (st->done) {
-        // "finish after this update" becomes "finished" once that update (k_ct_apply of the
-        // previous iteration) has run
-        if (threadIdx.x == 0 && st->done == 2) st->done = 1;
-        return;
-    }
     const int e = threadIdx.x & 31, r = threadIdx.x >> 5;
     // entries 0..28: energies; 29: norm_dir; 30: dofs
     double v = 0;
@@ -833,15 +1063,30 @@ __global__ __launch_bounds__(1024) void k_ct_decide(ContactDev c, int n_dir_wg, 
         v = threadIdx.x < 32 ? st->red[threadIdx.x] : 0.0;
     } else {
     if (e <= LS_CAND) {
-        for (int w = r; w < n_con_wg; w += 32) v += c.part[(size_t)w * CT_PART + e];
-        for (int w = r; w < n_grid_wg; w += 32) v += c.part[(size_t)(CT_ROWS + w) * CT_PART + e];
+        // all loads first (fixed trip count, unrolled), then the sums in the same fixed order: a loop
+        // with a run-time bound waits for every load in turn (8 us for 16 dependent L2 round trips)
+        double t0[CT_ROWS_CON / RG], t1[CT_ROWS / RG];
+#pragma unroll
+        for (int k = 0; k < CT_ROWS_CON / RG; ++k) {
+            const int w = r + RG * k;
+            t0[k] = w < n_con_wg ? c.part[(size_t)w * CT_PART + e] : 0.0;
+        }
+#pragma unroll
+        for (int k = 0; k < CT_ROWS / RG; ++k) {
+            const int w = r + RG * k;
+            t1[k] = w < n_grid_wg ? c.part[(size_t)(CT_ROWS_CON + w) * CT_PART + e] : 0.0;
+        }
+#pragma unroll
+        for (int k = 0; k < CT_ROWS_CON / RG; ++k) v += t0[k];
+#pragma unroll
+        for (int k = 0; k < CT_ROWS / RG; ++k) v += t1[k];
     }
     s_sum[r][e] = v;
-    // the (|Dir|^2, DoFs) records of k_ct_node_dir: thread t adds records t, t + 1024, ..., then a
+    // the (|Dir|^2, DoFs) records of k_ct_node_dir: thread t adds records t, t + NT, ..., then a
     // fixed tree over the workgroup
     {
         double d0 = 0, d1 = 0;
-        for (int w = threadIdx.x; w < n_dir_wg; w += 1024) {
+        for (int w = threadIdx.x; w < n_dir_wg; w += NT) {
             d0 += c.part_dir[(size_t)w * 2];
             d1 += c.part_dir[(size_t)w * 2 + 1];
         }
@@ -859,9 +1104,9 @@ __global__ __launch_bounds__(1024) void k_ct_decide(ContactDev c, int n_dir_wg, 
     if (threadIdx.x >= 64) return;
     v = 0;
     if (threadIdx.x <= LS_CAND)
-        for (int q = 0; q < 32; ++q) v += s_sum[q][threadIdx.x];
+        for (int q = 0; q < RG; ++q) v += s_sum[q][threadIdx.x];
     else if (threadIdx.x <= LS_CAND + 2)
-        for (int q = 0; q < 16; ++q) v += s_dir[q][threadIdx.x - LS_CAND - 1];
+        for (int q = 0; q < NT / 64; ++q) v += s_dir[q][threadIdx.x - LS_CAND - 1];
     if (phase == 1) {
         if (threadIdx.x < 32) st->red[threadIdx.x] = v;
         return;
@@ -908,12 +1153,24 @@ __global__ __launch_bounds__(1024) void k_ct_decide(ContactDev c, int n_dir_wg, 
         return;
     }
     const float en = (float)v;
-    const float E0 = __shfl(en, LS_CAND);
-    const unsigned long long ok = __ballot(lane < LS_CAND && en <= E0);
+    const bool deep = st->ls_phase == 4;
+    const float E0 = deep ? st->E0 : __shfl(en, LS_CAND);
+    const int lo = deep ? LS_SHALLOW : 0, hi = deep ? LS_CAND : LS_SHALLOW;
+    const unsigned long long ok = __ballot(lane >= lo && lane < hi && en <= E0);
+    if (!ok && !deep) {
+        // (cuda_mpm_solver.cu's loop halves alpha until the energy does not increase: the rest of the
+        // candidates are evaluated by the next pass, the iteration is not over)
+        if (lane == 0) {
+            st->E0 = E0;
+            st->ls_phase = 4;
+        }
+        return;
+    }
     int j = ok ? __builtin_ctzll(ok) : LS_CAND - 1;  // "Tiny Alpha": accept 2^-27 anyway
     const float Ej = __shfl(en, j);
     const float nd = __shfl(en, LS_CAND + 1), dofs = __shfl(en, LS_CAND + 2);
     if (lane == 0) {
+        st->ls_phase = 0;
         st->alpha = ldexpf(1.f, -j);
         st->energy = Ej;
         st->E0 = E0;
@@ -924,11 +1181,29 @@ __global__ __launch_bounds__(1024) void k_ct_decide(ContactDev c, int n_dir_wg, 
     }
 }
 
-// G3: v -= alpha Dir (cuda_mpm_kernels.cuh:1591-1614); only nodes that see contacts have a direction
-__global__ __launch_bounds__(CT_WG) void k_ct_apply(DP p, ContactDev c, int exact_resident = 0) {
+__global__ __launch_bounds__(1024) void k_ct_decide(ContactDev c, int n_dir_wg, int n_con_wg, int n_grid_wg, int exact,
+                                                    int phase = 0) {
+    __shared__ double s_sum[32][CT_PART];
+    __shared__ double s_dir[16][2];
     ContactState* st = c.st;
-    if (st->done == 1) return;
-    if (exact_resident && st->ls_phase != 3) return;   // the search of this direction is still running
+    if (st->done) {
+        // "finish after this update" becomes "finished" once that update (k_ct_apply of the
+        // previous iteration) has run
+        if (threadIdx.x == 0 && st->done == 2) st->done = 1;
+        return;
+    }
+    ct_decide<1024>(c, n_dir_wg, n_con_wg, n_grid_wg, exact, phase, s_sum, s_dir);
+}
+
+// G3: v -= alpha Dir (cuda_mpm_kernels.cuh:1591-1614); only nodes that see contacts have a direction
+// mode 0: after the decision of every iteration (nothing once the solve is finished); 1: device-resident
+// exact search (only when the search of this direction has ended); 2: once after the loop, for the step
+// of the last iteration when k_ct_node_dir applies the others (lazy)
+__global__ __launch_bounds__(CT_WG) void k_ct_apply(DP p, ContactDev c, int mode = 0) {
+    ContactState* st = c.st;
+    if (mode != 2 && st->done == 1) return;
+    if (mode == 0 && st->ls_phase == 4) return;   // backtracking continues: no step accepted yet
+    if (mode == 1 && st->ls_phase != 3) return;   // the search of this direction is still running
     const float al = st->alpha;
     const int n_nodes = st->n_nodes;
     for (int q = blockIdx.x * CT_WG + threadIdx.x; q < n_nodes; q += gridDim.x * CT_WG) {
@@ -936,7 +1211,7 @@ __global__ __launch_bounds__(CT_WG) void k_ct_apply(DP p, ContactDev c, int exac
         float4 v = p.gv[g];
         if (!(v.w > 0.f)) continue;
         const float4 D = c.gD[g];
-        v.x -= al * D.x; v.y -= al * D.y; v.z -= al * D.z;
+        v.x = fmaf(-al, D.x, v.x); v.y = fmaf(-al, D.y, v.y); v.z = fmaf(-al, D.z, v.z);
         p.gv[g] = v;
     }
 }

@@ -86,12 +86,16 @@ def test_update_contact_matches_oracle(exact, params, mu):
             assert abs(rg["iterations"] - ro["iterations"]) <= slack, (rg, ro, step, _diagnose(g, o))
         else:
             assert 0 < rg["iterations"] < 2000 and 0 < ro["iterations"] <= 2000, (rg, ro, step, _diagnose(g, o))
-        # (the oracle's float sums can stall just above the tolerance: "Tiny Alpha" steps, cuda_mpm_solver.cu:523-526)
-        assert rg["residual"] <= 1e-4 and ro["residual"] <= 1.5e-4
+        # (the oracle's float sums can stall above the tolerance -- "Tiny Alpha" steps, cuda_mpm_solver.cu:523-526 --
+        # until it runs into its iteration limit; how often depends on the OpenMP summation order of the run.
+        # Its result is then only as close to the solution as its residual says: the comparison below
+        # widens by that factor)
+        assert rg["residual"] <= 1e-4 and ro["residual"] <= 1e-3
+        stalled = max(1.0, ro["residual"] / 1e-4)
         close(g.download(A.CONTACT_VEL0), o.c_vel0, scale=sc["vel"], what="contact vel0")
         # converged solves agree to the solver's stopping tolerance (rounding-level agreement: the
         # single-iteration test below)
-        tol = solve_tolerance(g.contact_stats()["dofs"])
+        tol = solve_tolerance(g.contact_stats()["dofs"]) * stalled
         close(g.download(A.CONTACT_VEL), o.c_vel, scale=1.0, rtol=tol, what="contact vel")
         wgt = (o.g_m / o.g_m.max())[:, None]
         close(g.download(A.GRID_MOMENTUM) * wgt, o.g_mv * wgt, scale=1.0, rtol=tol, what="grid v after contact")
@@ -101,8 +105,8 @@ def test_update_contact_matches_oracle(exact, params, mu):
         assert np.count_nonzero(np.abs(gdir).max(1)) < 0.05 * g.n_cells
         tau_g, f_g = g.external_body_force_to_host()
         fscale = float(np.abs(o.F_f).max())
-        close(f_g, o.F_f, scale=fscale, rtol=IMPULSE_RTOL, what="body impulse")
-        close(tau_g, o.F_tau, scale=max(float(np.abs(o.F_tau).max()), fscale), rtol=IMPULSE_RTOL, what="body angular impulse")
+        close(f_g, o.F_f, scale=fscale, rtol=IMPULSE_RTOL * stalled, what="body impulse")
+        close(tau_g, o.F_tau, scale=max(float(np.abs(o.F_tau).max()), fscale), rtol=IMPULSE_RTOL * stalled, what="body angular impulse")
         # the floor pushes up
         assert f_g[0, 2] < 0  # impulse ON the body is downward
         o.grid_to_particle(DT)
