@@ -242,6 +242,51 @@ static int dist_allreduce(mpm_engine* e, double* dev, size_t n) {
     return 0;
 }
 
+// The batched Newton loops: `pattern(i)` enqueues the launches of one iteration (kernels of an iteration
+// that starts after convergence return at once).  The solver state is read back after every batch, into
+// pinned memory, and the NEXT batch is enqueued before the host waits for that read-back: the device
+// never idles while the host finds out whether the solve has finished (a stream synchronisation plus
+// relaunch cost ~40 us per batch); the price is one batch of idle launches at the end.
+// (batch sizes: MPM_CT_BATCH="first,next" overrides the defaults, for measurements)
+static int ct_batch(int which, int dflt) {
+    static int v[2] = {-1, -1};
+    if (v[0] < 0) {
+        v[0] = v[1] = 0;
+        if (const char* t = getenv("MPM_CT_BATCH")) sscanf(t, "%d,%d", &v[0], &v[1]);
+    }
+    return v[which] > 0 ? v[which] : dflt;
+}
+
+template <class Pattern>
+static int run_batches(mpm_engine* e, Pattern&& pattern, int first_batch, int batch, int max_iters, ContactState* out,
+                       int max_patterns = 1 << 30) {
+    ContactBuffers& b = e->cb;
+    hipStream_t s = e->stream;
+    for (int i = 0; i < 2; ++i) {
+        if (!b.h_st[i]) HIP_TRY(hipHostMalloc((void**)&b.h_st[i], sizeof(ContactState), hipHostMallocDefault));
+        if (!b.h_ev[i]) HIP_TRY(hipEventCreateWithFlags(&b.h_ev[i], hipEventDisableTiming));
+    }
+    int launched = 0, slot = 0;
+    auto enqueue = [&](int count) -> int {
+        for (int q = 0; q < count; ++q) pattern(launched + q);
+        launched += count;
+        HIP_TRY(hipMemcpyAsync(b.h_st[slot], b.st, sizeof(ContactState), hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipEventRecord(b.h_ev[slot], s));
+        slot ^= 1;
+        return 0;
+    };
+    if (int rc = enqueue(first_batch)) return rc;
+    while (true) {
+        if (int rc = enqueue(batch)) return rc;            // speculative: idle if the previous batch finished
+        HIP_TRY(hipEventSynchronize(b.h_ev[slot]));        // (slot now names the older of the two)
+        const ContactState& st = *b.h_st[slot];
+        if (st.done || st.iters >= max_iters || launched > max_patterns) break;
+    }
+    HIP_TRY(hipEventSynchronize(b.h_ev[slot ^ 1]));        // the speculative batch has drained
+    *out = *b.h_st[slot ^ 1];
+    return 0;
+}
+
 static int update_contact(mpm_engine* e, int frame, int substep, float dt, float mu, float stiffness, float damping,
                           int dump, int exact, int max_iters, int* iters_out, float* residual_out) {
     ContactBuffers& b = e->cb;
@@ -332,25 +377,18 @@ static int update_contact(mpm_engine* e, int frame, int substep, float dt, float
         // that starts after convergence return immediately
         // (as many as the previous solve needed plus one, then a few at a time: iterations that start
         // after convergence are idle launches of ~2 us each)
-        int batch = std::min(8, std::max(2, b.last_iters + 1));
-        // Four launches per iteration: contacts -> sums per cell, nodes -> direction, energies of all
+        // Four launches per iteration: contacts -> sums per cell, nodes -> direction, energies of the
         // candidate steps, decision.  The accepted step reaches the grid velocity at the start of the
         // next iteration (k_ct_node_dir, lazy; k_ct_tile reads v - alpha D meanwhile) and, for the last
         // iteration, in the k_ct_apply after the loop.  MPM_CT_EAGER=1 keeps the separate k_ct_apply.
         static const bool eager = getenv("MPM_CT_EAGER") != nullptr;
-        while (true) {
-            for (int q = 0; q < batch; ++q) {
-                launch_dir((iters + q) == 0, eager ? 0 : 1);
-                hipLaunchKernelGGL(k_ct_ls, dim3(n_con_wg + n_grid_wg), dim3(CT_WG), 0, s, p, c, n_con_wg, 0, 0.f);
-                hipLaunchKernelGGL(k_ct_decide, dim3(1), dim3(1024), 0, s, c, n_dir_wg, n_con_wg, n_grid_wg, 0, 0);
-                if (eager) hipLaunchKernelGGL(k_ct_apply, dim3(CT_ROWS), dim3(CT_WG), 0, s, p, c, 0);
-            }
-            iters += batch;
-            batch = 3;
-            HIP_TRY(hipMemcpyAsync(&st, b.st, sizeof(ContactState), hipMemcpyDeviceToHost, s));
-            HIP_TRY(hipStreamSynchronize(s));
-            if (st.done || st.iters >= max_iters) break;
-        }
+        auto pattern = [&](int index) {
+            launch_dir(index == 0, eager ? 0 : 1);
+            hipLaunchKernelGGL(k_ct_ls, dim3(n_con_wg + n_grid_wg), dim3(CT_WG), 0, s, p, c, n_con_wg, 0, 0.f);
+            hipLaunchKernelGGL(k_ct_decide, dim3(1), dim3(1024), 0, s, c, n_dir_wg, n_con_wg, n_grid_wg, 0, 0);
+            if (eager) hipLaunchKernelGGL(k_ct_apply, dim3(CT_ROWS), dim3(CT_WG), 0, s, p, c, 0);
+        };
+        if (int rc = run_batches(e, pattern, ct_batch(0, 2), ct_batch(1, 2), max_iters, &st)) return rc;
         if (!eager) hipLaunchKernelGGL(k_ct_apply, dim3(CT_ROWS), dim3(CT_WG), 0, s, p, c, 2);
         iters = st.iters;
         residual = st.residual;
@@ -361,24 +399,19 @@ static int update_contact(mpm_engine* e, int frame, int substep, float dt, float
         // that needs more probes continues in the next pattern (direction skipped), patterns after
         // convergence are idle.  One read-back per batch instead of one per probe.
         const int PROBES = 6;
-        int batch = std::min(4, std::max(1, b.last_iters + 1));
-        while (true) {
-            for (int q = 0; q < batch; ++q) {
-                launch_dir((iters + q) == 0, 0);
-                for (int k = 0; k < PROBES; ++k) {
-                    hipLaunchKernelGGL(k_ct_ls, dim3(n_con_wg + n_grid_wg), dim3(CT_WG), 0, s, p, c, n_con_wg, 2, 0.f);
-                    hipLaunchKernelGGL(k_ct_decide, dim3(1), dim3(1024), 0, s, c, n_dir_wg, n_con_wg, n_grid_wg, 2, 0);
-                }
-                hipLaunchKernelGGL(k_ct_apply, dim3(CT_ROWS), dim3(CT_WG), 0, s, p, c, 1);
-                hipLaunchKernelGGL(k_ct_exact_finish, dim3(1), dim3(64), 0, s, c);
+        auto pattern = [&](int index) {
+            launch_dir(index == 0, 0);
+            for (int k = 0; k < PROBES; ++k) {
+                hipLaunchKernelGGL(k_ct_ls, dim3(n_con_wg + n_grid_wg), dim3(CT_WG), 0, s, p, c, n_con_wg, 2, 0.f);
+                hipLaunchKernelGGL(k_ct_decide, dim3(1), dim3(1024), 0, s, c, n_dir_wg, n_con_wg, n_grid_wg, 2, 0);
             }
-            iters += batch;
-            batch = 2;
-            HIP_TRY(hipMemcpyAsync(&st, b.st, sizeof(ContactState), hipMemcpyDeviceToHost, s));
-            HIP_TRY(hipStreamSynchronize(s));
-            if (st.done || st.iters >= max_iters) break;
-            if (iters > 4 * max_iters + 64) break;   // (a search that never terminates cannot happen: the root finder is bounded)
-        }
+            hipLaunchKernelGGL(k_ct_apply, dim3(CT_ROWS), dim3(CT_WG), 0, s, p, c, 1);
+            hipLaunchKernelGGL(k_ct_exact_finish, dim3(1), dim3(64), 0, s, c);
+        };
+        // (a search that never terminates cannot happen -- the root finder is bounded -- but the launches are)
+        if (int rc = run_batches(e, pattern, ct_batch(0, 1), ct_batch(1, 1), max_iters, &st,
+                                 4 * max_iters + 64))
+            return rc;
         iters = st.iters;
         residual = st.residual;
         s_alpha_last = st.alpha;

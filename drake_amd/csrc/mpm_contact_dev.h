@@ -30,7 +30,7 @@ constexpr int LS_CAND = 28;          // alpha = 2^-j, j = 0..27 (alpha < 1e-8 is
 constexpr int LS_SHALLOW = 4;        // candidates of the first pass; the other 24 only when none of these is accepted
 constexpr int CT_PART = LS_CAND + 4; // partial record: E1[28], E0, norm_dir, dofs, pad
 constexpr int CT_WG = 256;           // threads per workgroup of the contact kernels
-constexpr int CT_DIR_WG = 2048;      // workgroups of k_ct_node_dir (16 lanes per node)
+constexpr int CT_DIR_WG = 1024;      // workgroups of k_ct_node_dir (16 lanes per node)
 constexpr int CT_TILE = 64;          // sorted contacts handled by one workgroup of k_ct_tile
 constexpr int CT_TILE_WG = 2048;     // workgroups of k_ct_tile at most
 static_assert(CT_TILE * 4 == 256, "k_ct_tile: 4 lanes per contact, one 16-byte piece of the record each");
@@ -152,6 +152,8 @@ struct ContactBuffers {
     ContactState* st = nullptr;
     float* it_log = nullptr;
     int last_iters = 0;         // Newton iterations of the previous solve (sizes the first batch of launches)
+    ContactState* h_st[2] = {nullptr, nullptr};   // pinned read-back slots of the batched loops
+    hipEvent_t h_ev[2] = {nullptr, nullptr};
     float* body_tau = nullptr;  // F_Bq_W_tau
     float* body_f = nullptr;    // F_Bq_W_f
 
@@ -161,6 +163,10 @@ struct ContactBuffers {
                         zone_buf[0], zone_buf[1], zone_buf[2], zone_buf[3], part, part_dir, st, it_log, body_tau, body_f};
         for (void* q : ptrs)
             if (q) (void)hipFree(q);
+        for (int i = 0; i < 2; ++i) {
+            if (h_st[i]) (void)hipHostFree(h_st[i]);
+            if (h_ev[i]) (void)hipEventDestroy(h_ev[i]);
+        }
         *this = ContactBuffers();
     }
     int resize_bodies(size_t nb, hipStream_t s) {
@@ -1062,7 +1068,10 @@ MPM_DEV void ct_decide(const ContactDev& c, int n_dir_wg, int n_con_wg, int n_gr
         if (threadIdx.x >= 64) return;
         v = threadIdx.x < 32 ? st->red[threadIdx.x] : 0.0;
     } else {
-    if (e <= LS_CAND) {
+    // (only the entries this pass decides on: the others hold sums of an earlier pass)
+    const bool deep_pass = !exact && st->ls_phase == 4;
+    const bool needed = exact ? e < 3 : (deep_pass ? e >= LS_SHALLOW && e < LS_CAND : e < LS_SHALLOW || e == LS_CAND);
+    if (needed) {
         // all loads first (fixed trip count, unrolled), then the sums in the same fixed order: a loop
         // with a run-time bound waits for every load in turn (8 us for 16 dependent L2 round trips)
         double t0[CT_ROWS_CON / RG], t1[CT_ROWS / RG];
