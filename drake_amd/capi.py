@@ -129,6 +129,32 @@ def library_path() -> str:
     return _build.LIB
 
 
+def _preload_hip_runtime():
+    """One HIP runtime per process.  PyTorch's ROCm wheels carry their own libamdhip64.so (soname
+    libamdhip64.so.7, like /opt/rocm's, but torch asks for it as "libamdhip64.so"): loaded after this
+    library, torch would bring in a second runtime next to the one libmpm_hip.so is bound to, and the two
+    tear each other's state down at exit ("double free or corruption").  When torch is installed its copy
+    is loaded first, so that both resolve to it whichever is imported first; torch itself is not imported."""
+    import importlib.util
+    import sys
+    if "torch" in sys.modules:
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        return
+    if spec is None or not spec.submodule_search_locations:
+        return
+    libdir = os.path.join(list(spec.submodule_search_locations)[0], "lib")
+    path = os.path.join(libdir, "libamdhip64.so")
+    if os.path.exists(path):
+        C.CDLL(path, mode=C.RTLD_GLOBAL)
+    # the same for RCCL, which the engine binds lazily (csrc/mpm_chain.h): point it at torch's copy
+    rccl = os.path.join(libdir, "librccl.so")
+    if os.path.exists(rccl):
+        os.environ.setdefault("MPM_RCCL_LIBRARY", rccl)
+
+
 def load_library(build: bool = True):
     """Loads drake_amd/libmpm_hip.so, building it with hipcc first if needed.
     Raises if the library cannot be produced: there is no fallback path."""
@@ -138,6 +164,7 @@ def load_library(build: bool = True):
     path = _build.build() if build else _build.LIB
     if not os.path.exists(path):
         raise RuntimeError(f"{path} is missing: build it with `python -m drake_amd._build` (no CPU fallback exists)")
+    _preload_hip_runtime()
     lib = C.CDLL(path)
     lib.mpm_last_error.restype = C.c_char_p
     vp, f, i, sz = C.c_void_p, C.c_float, C.c_int, C.c_size_t

@@ -38,7 +38,9 @@ struct Api {
     AllReduce all_reduce = nullptr;
     GetErrorString error_string = nullptr;
 };
-// The process may already hold an RCCL (PyTorch ships one): use that instance, never a second one.
+// The process may already hold an RCCL (PyTorch ships one): use that instance, never a second one --
+// two copies of RCCL's dependencies (rocm_smi) in one process end in a double free at exit.  A process
+// that will load PyTorch later names its copy in MPM_RCCL_LIBRARY (drake_amd/capi.py does).
 static const Api* api() {
     static Api a;
     static bool tried = false;
@@ -47,6 +49,8 @@ static const Api* api() {
     const char* names[] = {"librccl.so.1", "librccl.so"};
     for (const char* n : names)
         if ((a.lib = dlopen(n, RTLD_NOW | RTLD_NOLOAD))) break;
+    if (!a.lib)
+        if (const char* path = getenv("MPM_RCCL_LIBRARY")) a.lib = dlopen(path, RTLD_NOW | RTLD_GLOBAL);
     if (!a.lib)
         for (const char* n : names)
             if ((a.lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL))) break;

@@ -697,8 +697,10 @@ int mpm_chain_destroy(mpm_handle_t e) {
     mpm_engine::Chain& c = e->chain;
     if (int rc = use(e)) return rc;
     (void)hipStreamSynchronize(e->stream);
-    const rccl_rt::Api* a = rccl_rt::api();
-    if (c.comm && a) (void)a->comm_destroy(c.comm);
+    if (c.comm) {   // (RCCL is only looked up by engines that use it)
+        const rccl_rt::Api* a = rccl_rt::api();
+        if (a) (void)a->comm_destroy(c.comm);
+    }
     for (void* q : {c.send_l, c.send_r, c.recv_l, c.recv_r, c.mig_send_l, c.mig_send_r, c.mig_recv_l, c.mig_recv_r})
         if (q) (void)hipFree(q);
     c = mpm_engine::Chain();
