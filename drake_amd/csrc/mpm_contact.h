@@ -44,11 +44,10 @@ static int ensure_contact_capacity(mpm_engine* e, size_t n) {
         b.cap = cap;
     }
     {
-        const int items = sort_items_for(n);
-        const size_t tiles = (n + (size_t)64 * items - 1) / ((size_t)64 * items);
-        if (256 * tiles > b.cap_hist) {
-            if (int rc = grow(&b.sort_hist, 256 * tiles + 256)) return rc;
-            b.cap_hist = 256 * tiles + 256;
+        const size_t want = sort_hist_ints(n);
+        if (want > b.cap_hist) {
+            if (int rc = grow(&b.sort_hist, want)) return rc;
+            b.cap_hist = want;
         }
     }
     const size_t cells = (size_t)e->dp.capA * 64;
@@ -89,6 +88,8 @@ static int copy_contacts(mpm_engine* e, size_t n, const uint32_t* particle, cons
     c.slot = b.slot;
     c.vel = b.vel;
     hipLaunchKernelGGL(k_ct_init_vel, dim3(g), dim3(256), 0, e->stream, e->dp, c);
+    // (how many blocks are active: bounds the sort keys of the solve, see update_contact)
+    HIP_TRY(hipMemcpyAsync(&b.n_active_hint, &e->dp.ctl->n_active, 4, hipMemcpyDeviceToHost, e->stream));
     HIP_TRY(hipStreamSynchronize(e->stream));  // the host arrays may be released by the caller
     return 0;
 }
@@ -120,8 +121,13 @@ static int generate_contacts(mpm_engine* e, size_t n_col, const mpm_collider_t* 
     hipLaunchKernelGGL(k_ct_gen_count, dim3(e->g_np), dim3(256), 0, s, p, (const int*)e->d_pids_api, (int)n_col,
                        (const Collider*)b.colliders, b.gen_cnt);
     if (device_exclusive_scan(s, b.gen_cnt, np + 1, b.gen_sums)) return fail(MPM_ERR_HIP, "contact scan failed");
-    int total = 0;
-    D2H(e, &total, b.gen_cnt + np, 4);   // the one number the host needs: how many pairs
+    // the one number the host needs: how many pairs (and, for the key width of the solve's sort -- see
+    // update_contact -- how many blocks are active); gen_sums[0..1] is free again after the scan
+    int two[2] = {0, 0};
+    hipLaunchKernelGGL(k_pair_of_ints, dim3(1), dim3(1), 0, s, b.gen_sums, (const int*)(b.gen_cnt + np), (const unsigned*)&p.ctl->n_active);
+    D2H(e, two, b.gen_sums, 8);
+    const int total = two[0];
+    b.n_active_hint = (unsigned)two[1];
     if (total <= 0) return 0;
     if (int rc = ensure_contact_capacity(e, (size_t)total)) return rc;
     ContactDev c{};
@@ -313,8 +319,13 @@ static int update_contact(mpm_engine* e, int frame, int substep, float dt, float
     HIP_TRY(hipMemsetAsync(b.st, 0, sizeof(ContactState), s));
     hipLaunchKernelGGL(k_ct_keys, dim3(1024), dim3(256), 0, s, p, c);
     {
+        // Keys are compact cells (active block * 64 + cell).  The number of active blocks is known from
+        // the hand-over of the pairs unless a re-sort may have run since (launch_rebuild clears the hint):
+        // with config 3's 1805 blocks that is 18 key bits, two passes of 9, instead of 22 bits for the
+        // table capacity, three passes of 8.
+        const size_t blocks = b.n_active_hint ? std::min<size_t>(b.n_active_hint, p.capA) : p.capA;
         int bits = 1;
-        while (((size_t)1 << bits) < (size_t)p.capA * 64) ++bits;
+        while (((size_t)1 << bits) < blocks * 64) ++bits;
         // CT_NO_CELL has all those bits set and more: it sorts behind every real cell as long as
         // one more bit takes part
         if (radix_sort_pairs(s, b.key, b.order, b.key2, b.order2, b.sort_hist, n, std::min(bits + 1, 31)))

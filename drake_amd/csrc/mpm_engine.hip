@@ -134,6 +134,7 @@ static int grid_colliders_for(mpm_engine* e, int bc, GridColliders* out) {
 
 static void launch_rebuild(mpm_engine* e) {
     const DP& p = e->dp;
+    e->cb.n_active_hint = 0;   // the block tables may change: contact pairs handed over before are re-keyed with the full width
     hipLaunchKernelGGL(k_rb_count, dim3(std::min(e->g_np, e->g_rb)), dim3(256), 0, e->stream, p);
     hipLaunchKernelGGL(k_rb_tables, dim3(33), dim3(1024), 0, e->stream, p);
     hipLaunchKernelGGL(k_rb_scatter, dim3(std::min(e->g_np, e->g_rb)), dim3(256), 0, e->stream, p);

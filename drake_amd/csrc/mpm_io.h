@@ -467,11 +467,9 @@ static int api_sort(mpm_engine* e) {
     const size_t np = e->np;
     if (!e->d_sort_keys) {
         int rc = 0;
-        const int items = sort_items_for(np);
-        const size_t tiles = (np + (size_t)64 * items - 1) / ((size_t)64 * items);
         if ((rc = e->dalloc(&e->d_sort_keys, np, false)) || (rc = e->dalloc(&e->d_sort_vals, np, false)) ||
             (rc = e->dalloc(&e->d_sort_keys2, np, false)) || (rc = e->dalloc(&e->d_sort_vals2, np, false)) ||
-            (rc = e->dalloc(&e->d_sort_hist, 256 * tiles + 256, false)) || (rc = e->dalloc(&e->d_pids_api2, np, false)))
+            (rc = e->dalloc(&e->d_sort_hist, sort_hist_ints(np), false)) || (rc = e->dalloc(&e->d_pids_api2, np, false)))
             return rc;
     }
     const int nbits = std::min(3 * e->bits, 16);

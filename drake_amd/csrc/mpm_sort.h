@@ -1,4 +1,5 @@
-// Stable LSD radix sort of (key, value) pairs on the device, 8 bits per pass.
+// Stable LSD radix sort of (key, value) pairs on the device, 8 to 11 bits per pass (as few passes as
+// the key width allows: a pass is three launches).
 //
 // Used where an order has to be *stable* and reproducible: the slot order of
 // RebuildMapping(sort = true) (the reference's 16-bit radix sort,
@@ -22,21 +23,23 @@
 
 namespace mpm {
 
+template <int DB>
 __global__ __launch_bounds__(64) void k_sort_hist(const uint32_t* keys, int n, int shift, int items, int* hist,
                                                   int ntiles) {
-    __shared__ int s_cnt[256];
+    constexpr int ND = 1 << DB;
+    __shared__ int s_cnt[ND];
     const int lane = threadIdx.x, tile = blockIdx.x;
-    for (int d = lane; d < 256; d += 64) s_cnt[d] = 0;
+    for (int d = lane; d < ND; d += 64) s_cnt[d] = 0;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     const int begin = tile * 64 * items;
     for (int it = 0; it < items; ++it) {
         const int i = begin + it * 64 + lane;
-        if (i < n) atomicAdd(&s_cnt[(keys[i] >> shift) & 255u], 1);
+        if (i < n) atomicAdd(&s_cnt[(keys[i] >> shift) & (uint32_t)(ND - 1)], 1);
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
-    for (int d = lane; d < 256; d += 64) hist[(size_t)d * ntiles + tile] = s_cnt[d];
+    for (int d = lane; d < ND; d += 64) hist[(size_t)d * ntiles + tile] = s_cnt[d];
 }
 
 // Exclusive scan of one int per thread across a 1024-thread workgroup (shared by the scans below).
@@ -154,12 +157,14 @@ __global__ __launch_bounds__(256) void k_scan_add(int* a, const int* sums) {
     }
 }
 
+template <int DB>
 __global__ __launch_bounds__(64) void k_sort_scatter(const uint32_t* keys, const uint32_t* vals, uint32_t* keys_out,
                                                      uint32_t* vals_out, int n, int shift, int items, const int* hist,
                                                      int ntiles) {
-    __shared__ int s_off[256];
+    constexpr int ND = 1 << DB;
+    __shared__ int s_off[ND];
     const int lane = threadIdx.x, tile = blockIdx.x;
-    for (int d = lane; d < 256; d += 64) s_off[d] = hist[(size_t)d * ntiles + tile];
+    for (int d = lane; d < ND; d += 64) s_off[d] = hist[(size_t)d * ntiles + tile];
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     const unsigned long long lt = (1ull << lane) - 1ull;
@@ -169,11 +174,11 @@ __global__ __launch_bounds__(64) void k_sort_scatter(const uint32_t* keys, const
         const bool valid = i < n;
         const uint32_t key = valid ? keys[i] : 0u;
         const uint32_t val = valid ? vals[i] : 0u;
-        const uint32_t digit = (key >> shift) & 255u;
+        const uint32_t digit = (key >> shift) & (uint32_t)(ND - 1);
         // lanes of this chunk with the same digit
         unsigned long long same = __ballot(valid);
 #pragma unroll
-        for (int b = 0; b < 8; ++b) {
+        for (int b = 0; b < DB; ++b) {
             const unsigned long long m = __ballot((digit >> b) & 1u);
             same &= ((digit >> b) & 1u) ? m : ~m;
         }
@@ -194,8 +199,6 @@ __global__ __launch_bounds__(64) void k_sort_scatter(const uint32_t* keys, const
 
 }  // namespace mpm
 
-// Sorts n pairs by the key bits [0, bits) (stable).  `a` holds the input and receives the result;
-// `b` and `hist` are scratch (hist: 256 * ceil(n / (64 * items)) ints).
 // In-place exclusive scan of n ints (storage padded to a multiple of 4096); sums: n/4096 + 2 ints,
 // sums[nblocks] receives the grand total.
 static int device_exclusive_scan(hipStream_t s, int* a, size_t n, int* sums) {
@@ -210,20 +213,56 @@ static int device_exclusive_scan(hipStream_t s, int* a, size_t n, int* sums) {
 
 static inline int sort_items_for(size_t n) { return n > (1u << 18) ? 64 : 16; }
 
+constexpr int SORT_MAX_DIGIT_BITS = 11;
+// ints of histogram scratch radix_sort_pairs needs for n pairs
+static inline size_t sort_hist_ints(size_t n) {
+    const size_t items = sort_items_for(n);
+    const size_t tiles = (n + 64 * items - 1) / (64 * items);
+    return ((size_t)1 << SORT_MAX_DIGIT_BITS) * (tiles + 1);
+}
+
+template <int DB>
+static void radix_pass(hipStream_t s, const uint32_t* ki, const uint32_t* vi, uint32_t* ko, uint32_t* vo, int* hist, int n,
+                       int shift, int items, int ntiles) {
+    using namespace mpm;
+    hipLaunchKernelGGL(k_sort_hist<DB>, dim3(ntiles), dim3(64), 0, s, ki, n, shift, items, hist, ntiles);
+    hipLaunchKernelGGL(k_sort_scan, dim3(1), dim3(1024), 0, s, hist, (1 << DB) * ntiles);
+    hipLaunchKernelGGL(k_sort_scatter<DB>, dim3(ntiles), dim3(64), 0, s, ki, vi, ko, vo, n, shift, items, (const int*)hist,
+                       ntiles);
+}
+
+// Sorts n pairs by the key bits [0, bits) (stable).  `a` holds the input and receives the result;
+// `b` and `hist` are scratch (hist: sort_hist_ints(n) ints).
 static int radix_sort_pairs(hipStream_t s, uint32_t* ka, uint32_t* va, uint32_t* kb, uint32_t* vb, int* hist, size_t n,
                             int bits) {
     using namespace mpm;
     if (n < 2 || bits <= 0) return 0;
     const int items = sort_items_for(n);
     const int ntiles = (int)((n + (size_t)64 * items - 1) / ((size_t)64 * items));
-    const int passes = (bits + 7) / 8;
+    // digit width: a pass costs three launches (~20 us at this size) plus the single-workgroup scan of
+    // its 2^db x ntiles histogram (~3 us per 16384 entries)
+    int db = 8, passes = (bits + 7) / 8;
+    {
+        double best = 1e30;
+        for (int d = 8; d <= SORT_MAX_DIGIT_BITS; ++d) {
+            const int ps = (bits + d - 1) / d;
+            const double cost = ps * (20.0 + 3.0 * (double)((((size_t)1 << d) * ntiles + 16383) / 16384));
+            if (cost < best) {
+                best = cost;
+                db = d;
+                passes = ps;
+            }
+        }
+    }
     uint32_t *ki = ka, *vi = va, *ko = kb, *vo = vb;
     for (int pass = 0; pass < passes; ++pass) {
-        hipLaunchKernelGGL(k_sort_hist, dim3(ntiles), dim3(64), 0, s, (const uint32_t*)ki, (int)n, pass * 8, items, hist,
-                           ntiles);
-        hipLaunchKernelGGL(k_sort_scan, dim3(1), dim3(1024), 0, s, hist, 256 * ntiles);
-        hipLaunchKernelGGL(k_sort_scatter, dim3(ntiles), dim3(64), 0, s, (const uint32_t*)ki, (const uint32_t*)vi, ko, vo,
-                           (int)n, pass * 8, items, (const int*)hist, ntiles);
+        const int shift = pass * db;
+        switch (db) {
+            case 8: radix_pass<8>(s, ki, vi, ko, vo, hist, (int)n, shift, items, ntiles); break;
+            case 9: radix_pass<9>(s, ki, vi, ko, vo, hist, (int)n, shift, items, ntiles); break;
+            case 10: radix_pass<10>(s, ki, vi, ko, vo, hist, (int)n, shift, items, ntiles); break;
+            default: radix_pass<11>(s, ki, vi, ko, vo, hist, (int)n, shift, items, ntiles); break;
+        }
         std::swap(ki, ko);
         std::swap(vi, vo);
     }
