@@ -171,6 +171,7 @@ __global__ __launch_bounds__(256) void k_vforce(DP p) {
 // order of particles inside a block is irrelevant.
 // ---------------------------------------------------------------------------
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 constexpr int STG = 20;  // staged floats per particle: 16 columns of Y, fx, fy, fz, pad
 
@@ -278,6 +279,9 @@ __global__ __launch_bounds__(512, 4) void k_p2g(DP p, float dt) {  // <= 128 VGP
         bspline_coeff((n / 3) % 3, true, ay[t][0], ay[t][1], ay[t][2]);
         bspline_coeff(n % 3, true, az[t][0], az[t][1], az[t][2]);
     }
+    const f32x2 cx0 = {ax[0][0], ax[1][0]}, cx1 = {ax[0][1], ax[1][1]}, cx2 = {ax[0][2], ax[1][2]};
+    const f32x2 cy0 = {ay[0][0], ay[1][0]}, cy1 = {ay[0][1], ay[1][1]}, cy2 = {ay[0][2], ay[1][2]};
+    const f32x2 cz0 = {az[0][0], az[1][0]}, cz1 = {az[0][1], az[1][1]}, cz2 = {az[0][2], az[1][2]};
     float fac[2][4];     // epilogue: (1, i, j, k)[tt] of node row 16 t + 4 g4 + r
     int delta[2];        // float offset of this lane's node/component in the tile, -1 if none
 #pragma unroll
@@ -467,12 +471,13 @@ __global__ __launch_bounds__(512, 4) void k_p2g(DP p, float dt) {  // <= 128 VGP
                         const float* sn = stage + (s + 4 + g4) * STG;
                         nfx = sn[16]; nfy = sn[17]; nfz = sn[18]; ny = sn[j16];
                     }
-                    float w0 = fmaf(fmaf(ax[0][2], fx, ax[0][1]), fx, ax[0][0]) *
-                               fmaf(fmaf(ay[0][2], fy, ay[0][1]), fy, ay[0][0]) *
-                               fmaf(fmaf(az[0][2], fz, az[0][1]), fz, az[0][0]);
-                    float w1 = fmaf(fmaf(ax[1][2], fx, ax[1][1]), fx, ax[1][0]) *
-                               fmaf(fmaf(ay[1][2], fy, ay[1][1]), fy, ay[1][0]) *
-                               fmaf(fmaf(az[1][2], fz, az[1][1]), fz, az[1][0]);
+                    // both rows' weights in one chain of packed operations (v_pk_fma_f32: the same fused
+                    // multiply-adds as two scalar chains, half the issue slots)
+                    const f32x2 fx2 = {fx, fx}, fy2 = {fy, fy}, fz2 = {fz, fz};
+                    const f32x2 w01 = __builtin_elementwise_fma(__builtin_elementwise_fma(cx2, fx2, cx1), fx2, cx0) *
+                                      __builtin_elementwise_fma(__builtin_elementwise_fma(cy2, fy2, cy1), fy2, cy0) *
+                                      __builtin_elementwise_fma(__builtin_elementwise_fma(cz2, fz2, cz1), fz2, cz0);
+                    float w0 = w01.x, w1 = w01.y;
                     if (diag_flags(p) & 128) { w0 = fx; w1 = fy; }
                     if (!ok) y = 0.f;   // (weights of foreign rows are finite: 0 * w = 0)
                     if (diag_flags(p) & 64) {
@@ -742,36 +747,42 @@ MPM_DEV int g2p_particle(const DP& p, const PSet& S, const float4* tile, unsigne
     // keeping all 27 node loads in flight costs ~200 VGPRs.
     const float ez[3] = {st.wz[0] * (0.f - st.fx[2]), st.wz[1] * (1.f - st.fx[2]), st.wz[2] * (2.f - st.fx[2])};
     const float ey[3] = {st.wy[0] * (0.f - st.fx[1]), st.wy[1] * (1.f - st.fx[1]), st.wy[2] * (2.f - st.fx[1])};
-    float B[3] = {0.f, 0.f, 0.f}, By[3] = {0.f, 0.f, 0.f}, Bz[3] = {0.f, 0.f, 0.f};
-#pragma unroll 1
-    for (int ab = (diag_flags(p) & 512) ? 8 : 0; ab < 9; ++ab) {
-        const int a = ab / 3, b = ab - 3 * a;
-        const float4* row = base + (a * TILE_W + b) * TILE_W;
-        const float4 g0 = row[0], g1 = row[1], g2 = row[2];
-        const float wb = b == 0 ? st.wy[0] : (b == 1 ? st.wy[1] : st.wy[2]);
-        const float eb = b == 0 ? ey[0] : (b == 1 ? ey[1] : ey[2]);
-        const float A[3] = {st.wz[0] * g0.x + st.wz[1] * g1.x + st.wz[2] * g2.x,
-                            st.wz[0] * g0.y + st.wz[1] * g1.y + st.wz[2] * g2.y,
-                            st.wz[0] * g0.z + st.wz[1] * g1.z + st.wz[2] * g2.z};
-        const float Az[3] = {ez[0] * g0.x + ez[1] * g1.x + ez[2] * g2.x, ez[0] * g0.y + ez[1] * g1.y + ez[2] * g2.y,
-                             ez[0] * g0.z + ez[1] * g1.z + ez[2] * g2.z};
+    // Packed arithmetic (v_pk_fma_f32, two lanes of fused multiply-adds per issue slot): the z contraction
+    // carries the pair (w_k, w_k (k - fz)) so that A and Az come out of one chain, and so do (B, Bz) and
+    // (v, C[:,2]).  Fully unrolled: no selects for the row weights, constant LDS offsets.
+    const f32x2 W0 = {st.wz[0], ez[0]}, W1 = {st.wz[1], ez[1]}, W2 = {st.wz[2], ez[2]};
+    const f32x2 zero2 = {0.f, 0.f};
 #pragma unroll
-        for (int r = 0; r < 3; ++r) {
-            B[r] += wb * A[r];
-            By[r] += eb * A[r];
-            Bz[r] += wb * Az[r];
-        }
-        if (b == 2) {   // plane a is complete
-            const float wa = a == 0 ? st.wx[0] : (a == 1 ? st.wx[1] : st.wx[2]);
-            const float ea = wa * ((float)a - st.fx[0]);
+    for (int a = 0; a < 3; ++a) {
+        f32x2 BB[3] = {zero2, zero2, zero2};   // (B, Bz)[r]
+        float By[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+        for (int b = 0; b < 3; ++b) {
+            const float4* row = base + (a * TILE_W + b) * TILE_W;
+            const float4 g0 = row[0], g1 = row[1], g2 = row[2];
+            const float wb = st.wy[b], eb = ey[b];
+            const f32x2 wb2 = {wb, wb};
+            const float c0[3] = {g0.x, g0.y, g0.z}, c1[3] = {g1.x, g1.y, g1.z}, c2[3] = {g2.x, g2.y, g2.z};
 #pragma unroll
             for (int r = 0; r < 3; ++r) {
-                nv[r] += wa * B[r];
-                nC[r * 3 + 0] += ea * B[r];
-                nC[r * 3 + 1] += wa * By[r];
-                nC[r * 3 + 2] += wa * Bz[r];
-                B[r] = By[r] = Bz[r] = 0.f;
+                const f32x2 s0 = {c0[r], c0[r]}, s1 = {c1[r], c1[r]}, s2 = {c2[r], c2[r]};
+                const f32x2 AA = __builtin_elementwise_fma(W2, s2, __builtin_elementwise_fma(W1, s1, W0 * s0));   // (A, Az)[r]
+                BB[r] = __builtin_elementwise_fma(wb2, AA, BB[r]);
+                By[r] = fmaf(eb, AA.x, By[r]);
             }
+        }
+        // plane a is complete
+        const float wa = st.wx[a];
+        const float ea = wa * ((float)a - st.fx[0]);
+        const f32x2 wa2 = {wa, wa};
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            f32x2 vc = {nv[r], nC[r * 3 + 2]};
+            vc = __builtin_elementwise_fma(wa2, BB[r], vc);
+            nv[r] = vc.x;
+            nC[r * 3 + 2] = vc.y;
+            nC[r * 3 + 0] = fmaf(ea, BB[r].x, nC[r * 3 + 0]);
+            nC[r * 3 + 1] = fmaf(wa, By[r], nC[r * 3 + 1]);
         }
     }
     if (diag_flags(p) & 256) {  // ablation: no stores

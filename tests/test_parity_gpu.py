@@ -141,8 +141,12 @@ def test_trajectory_with_sorts_and_rebuilds():
 
 def test_substep_equals_phase_calls():
     A = _A()
-    _, g1 = build_pair(seed=11)
+    o, g1 = build_pair(seed=11)
     _, g2 = build_pair(seed=11)
+    # (not bitwise: the order of the particles inside a cell comes out of atomics at every re-sort, and the
+    # per-cell partial sums of P2G are float sums in that order -- last-bit differences of the grid,
+    # which the stiff cloth turns into a few 1e-7 m/s; same scale as every other velocity comparison)
+    sc = natural_scales(o, DT)
     for _ in range(5):
         g1.substep(DT, -1)
         g2.rebuild_mapping(False)
@@ -151,7 +155,7 @@ def test_substep_equals_phase_calls():
         g2.update_grid(-1)
         g2.grid_to_particle(DT)
     close(g1.download(A.POSITIONS), g2.download(A.POSITIONS), scale=1.0, rtol=1e-6, what="substep pos")
-    close(g1.download(A.VELOCITIES), g2.download(A.VELOCITIES), rtol=1e-6, what="substep vel")
+    close(g1.download(A.VELOCITIES), g2.download(A.VELOCITIES), scale=sc["vel"], rtol=1e-6, what="substep vel")
 
 
 def test_free_fall_and_conservation_large():
