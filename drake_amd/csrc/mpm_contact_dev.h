@@ -879,7 +879,8 @@ __global__ __launch_bounds__(CT_WG) void k_ct_node_dir(DP p, ContactDev c, int l
 // inertia part (cuda_mpm_kernels.cuh:1536-1589) in the rest
 // exact: 0 = backtracking (all candidate steps at once); 1 = (E, dE, d2E) at the step given by the
 // host; 2 = the same at st->alpha_probe, the device-resident search (skipped once the step is decided)
-__global__ __launch_bounds__(CT_WG) void k_ct_ls(DP p, ContactDev c, int n_con_wg, int exact, float alpha_probe) {
+__global__ __launch_bounds__(CT_WG) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_ct_ls(DP p, ContactDev c, int n_con_wg, int exact,
+                                                                                             float alpha_probe) {
     if (c.st->done) return;   // k_ct_decide does not read the records of a finished solve
     if (exact == 2) {
         if (c.st->ls_phase == 3) return;

@@ -812,7 +812,7 @@ MPM_DEV int g2p_particle(const DP& p, const PSet& S, const float4* tile, unsigne
 }
 
 constexpr int G2P_THREADS = 512;
-__global__ __launch_bounds__(G2P_THREADS) void k_g2p(DP p, float dt) {
+__global__ __launch_bounds__(G2P_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_g2p(DP p, float dt) {
     __shared__ float4 tile[TILE_N];
     const Ctl* ctl = p.ctl;
     const PSet& S = p.set[ctl->cur];
