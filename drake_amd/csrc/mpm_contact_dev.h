@@ -1013,8 +1013,7 @@ __global__ __launch_bounds__(CT_WG) __attribute__((amdgpu_waves_per_eu(4, 4))) v
             for (int q = 0; q < CT_WG / 64; ++q) v += s_red[q][threadIdx.x];
             c.part[(size_t)blockIdx.x * CT_PART + threadIdx.x] = v;
         }
-        return;
-    }
+    } else {
     // inertia part.  Only nodes that see contacts take part: elsewhere the direction is zero and v == v*
     // bit for bit (k_grid writes both from the same registers), so every energy term is an exact zero.
     double acc[LS_CAND - LS_SHALLOW], e0 = 0;
@@ -1064,6 +1063,7 @@ __global__ __launch_bounds__(CT_WG) __attribute__((amdgpu_waves_per_eu(4, 4))) v
     } else {
         wg_reduce_store<LS_CAND - LS_SHALLOW>(acc, row + LS_SHALLOW);
     }
+    }
 }
 
 // S: fixed-order sum of the partial records, choice of the step, convergence test
@@ -1076,38 +1076,41 @@ __global__ __launch_bounds__(CT_WG) __attribute__((amdgpu_waves_per_eu(4, 4))) v
 template <int NT>
 MPM_DEV void ct_decide(const ContactDev& c, int n_dir_wg, int n_con_wg, int n_grid_wg, int exact, int phase,
                        double (*s_sum)[CT_PART], double (*s_dir)[2]) {
-    constexpr int RG = NT / 32;   // row groups: thread (e, r) adds entry e of rows r, r + RG, ...
     ContactState* st = c.st;
-    const int e = threadIdx.x & 31, r = threadIdx.x >> 5;
     // entries 0..28: energies; 29: norm_dir; 30: dofs
     double v = 0;
     if (phase == 2) {
         if (threadIdx.x >= 64) return;
         v = threadIdx.x < 32 ? st->red[threadIdx.x] : 0.0;
     } else {
-    // (only the entries this pass decides on: the others hold sums of an earlier pass)
+    // Only the entries this pass decides on are summed (the others hold sums of an earlier pass):
+    // 4 candidates + E(0) in the shallow pass, 24 in the deep one, (E, dE, d2E) for the exact search.
+    // Thread (slot, r) adds the slot's entry of rows r, r + RG, ... (contact rows first, then node
+    // rows), 16 loads in flight at a time; wave 0 adds the RG row groups in order and decides.
     const bool deep_pass = !exact && st->ls_phase == 4;
-    const bool needed = exact ? e < 3 : (deep_pass ? e >= LS_SHALLOW && e < LS_CAND : e < LS_SHALLOW || e == LS_CAND);
-    if (needed) {
-        // all loads first (fixed trip count, unrolled), then the sums in the same fixed order: a loop
-        // with a run-time bound waits for every load in turn (8 us for 16 dependent L2 round trips)
-        double t0[CT_ROWS_CON / RG], t1[CT_ROWS / RG];
+    const int lgNE = exact ? 2 : (deep_pass ? 5 : 3);
+    const int NE = 1 << lgNE, RG = NT >> lgNE;
+    const int slot = threadIdx.x & (NE - 1), r = threadIdx.x >> lgNE;
+    int e = -1;   // entry of this slot
+    if (exact) e = slot < 3 ? slot : -1;
+    else if (deep_pass) e = slot >= LS_SHALLOW && slot < LS_CAND ? slot : -1;
+    else e = slot < LS_SHALLOW ? slot : (slot == LS_SHALLOW ? LS_CAND : -1);
+    double* s_flat = &s_sum[0][0];   // NT doubles
+    if (e >= 0) {
+        const int rows = n_con_wg + n_grid_wg;
+        for (int k0 = r; k0 < rows; k0 += 16 * RG) {
+            double t[16];
 #pragma unroll
-        for (int k = 0; k < CT_ROWS_CON / RG; ++k) {
-            const int w = r + RG * k;
-            t0[k] = w < n_con_wg ? c.part[(size_t)w * CT_PART + e] : 0.0;
+            for (int k = 0; k < 16; ++k) {
+                const int w = k0 + k * RG;
+                const int row = w < n_con_wg ? w : CT_ROWS_CON + (w - n_con_wg);
+                t[k] = w < rows ? c.part[(size_t)row * CT_PART + e] : 0.0;
+            }
+#pragma unroll
+            for (int k = 0; k < 16; ++k) v += t[k];
         }
-#pragma unroll
-        for (int k = 0; k < CT_ROWS / RG; ++k) {
-            const int w = r + RG * k;
-            t1[k] = w < n_grid_wg ? c.part[(size_t)(CT_ROWS_CON + w) * CT_PART + e] : 0.0;
-        }
-#pragma unroll
-        for (int k = 0; k < CT_ROWS_CON / RG; ++k) v += t0[k];
-#pragma unroll
-        for (int k = 0; k < CT_ROWS / RG; ++k) v += t1[k];
     }
-    s_sum[r][e] = v;
+    s_flat[threadIdx.x] = v;   // [r][slot]
     // the (|Dir|^2, DoFs) records of k_ct_node_dir: thread t adds records t, t + NT, ..., then a
     // fixed tree over the workgroup
     {
@@ -1128,11 +1131,18 @@ MPM_DEV void ct_decide(const ContactDev& c, int n_dir_wg, int n_con_wg, int n_gr
     }
     __syncthreads();
     if (threadIdx.x >= 64) return;
+    // lane = entry from here on
     v = 0;
-    if (threadIdx.x <= LS_CAND)
-        for (int q = 0; q < RG; ++q) v += s_sum[q][threadIdx.x];
-    else if (threadIdx.x <= LS_CAND + 2)
+    if (threadIdx.x <= LS_CAND) {
+        int sl = -1;   // the slot that carries this entry
+        if (exact) sl = threadIdx.x < 3 ? (int)threadIdx.x : -1;
+        else if (deep_pass) sl = threadIdx.x >= LS_SHALLOW && threadIdx.x < LS_CAND ? (int)threadIdx.x : -1;
+        else sl = threadIdx.x < LS_SHALLOW ? (int)threadIdx.x : (threadIdx.x == LS_CAND ? LS_SHALLOW : -1);
+        if (sl >= 0)
+            for (int q = 0; q < RG; ++q) v += s_flat[(q << lgNE) + sl];
+    } else if (threadIdx.x <= LS_CAND + 2) {
         for (int q = 0; q < NT / 64; ++q) v += s_dir[q][threadIdx.x - LS_CAND - 1];
+    }
     if (phase == 1) {
         if (threadIdx.x < 32) st->red[threadIdx.x] = v;
         return;
