@@ -147,6 +147,9 @@ struct DP {
     // groups of a heavy one.  Every item has its own slab; k_grid sums all slabs of a block.
     int4* item_desc;       // [item] (home, first group, end group, 0)
     uint32_t* item_order;  // items, most groups first (static round-robin order)
+    int4* item_flat;       // [position in item_order][2]: (item, home, home block id, groups), (first face slot, end face
+                           // slot, first vertex slot, first group's index in home_groups) -- everything the tile kernels
+                           // need to start an item in ONE load instead of a chain of four dependent ones
     int2* home_items;      // [home] (first item, item count)
     int* act_nbr_items;    // [active][27] first item | count << 24 of the neighbour home block, or -1
     int* home_ngroups;     // [home] number of P2G wave groups

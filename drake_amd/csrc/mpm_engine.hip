@@ -275,6 +275,7 @@ int mpm_finalize(mpm_handle_t e) {
     ALLOC(p.home_nbr_act, (size_t)p.capH * 27, true);
     ALLOC(p.item_desc, p.capI, true);
     ALLOC(p.item_order, p.capI, true);
+    ALLOC(p.item_flat, (size_t)p.capI * 2, true);
     ALLOC(p.home_items, p.capH, true);
     ALLOC(p.act_nbr_items, (size_t)p.capA * 27, true);
     ALLOC(p.home_ngroups, p.capH, true);

@@ -307,6 +307,16 @@ __global__ __launch_bounds__(1024) void k_rb_tables(DP p) {
         }
         __syncthreads();
         for (unsigned w = tid; w < n_items; w += 1024) p.item_order[atomicAdd(&s_bucket[bucket_of(w)], 1)] = w;
+        __syncthreads();
+        // the same, flattened in processing order (see DP::item_flat)
+        for (unsigned q = tid; q < n_items; q += 1024) {
+            const unsigned w = p.item_order[q];
+            const int4 d = p.item_desc[w];
+            const unsigned h = (unsigned)d.x;
+            const int4 rg = p.home_range[h];
+            p.item_flat[2 * q] = make_int4((int)w, (int)h, (int)p.home_block[h], d.z - d.y);
+            p.item_flat[2 * q + 1] = make_int4(rg.x, rg.y, rg.z, (int)(group_pool_offset(p, rg, h) + (size_t)d.y));
+        }
     }
 
     if (tid == 0) {

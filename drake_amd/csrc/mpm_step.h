@@ -307,25 +307,24 @@ __global__ __launch_bounds__(512, 4) void k_p2g(DP p, float dt) {  // <= 128 VGP
     const unsigned n_items = ctl->n_items;
     for (unsigned q = blockIdx.x; q < n_items; q += gridDim.x) {
         __syncthreads();  // the previous item's slab has been written
-        const unsigned item = p.item_order[q];
-        const int4 idesc = p.item_desc[item];
-        const unsigned h = (unsigned)idesc.x;
+        const int4 fa = p.item_flat[2 * q], fb = p.item_flat[2 * q + 1];
+        const unsigned item = (unsigned)fa.x;
         const unsigned long long tb0 = (diag_flags(p) & 4) ? __builtin_readcyclecounter() : 0ull;
         for (int n = tid; n < TILE_N * 4; n += 512) tile[n] = 0;
         if (tid == 0) s_mask = 0;
         __syncthreads();
         int bx, by, bz;
-        block_coords(p.home_block[h], bx, by, bz);
+        block_coords((uint32_t)fa.z, bx, by, bz);
         const int ox = bx * 4 - FREE_ZONE, oy = by * 4 - FREE_ZONE, oz = bz * 4 - FREE_ZONE;
-        const int4 rg = p.home_range[h];
+        const int4 rg = make_int4(fb.x, fb.y, fb.z, 0);
         const int nfb = rg.y - rg.x;
         unsigned mymask = 0;
         bool hard = false, in_range = true, halo_bad = false;
         // Every wave streams through its own groups of <= 64 particles; no workgroup barrier inside.
         // Groups are runs of whole cells (faces and vertices of the same cells together), laid out
         // at the last rebuild: a group usually spans two base cells.
-        const int ngroups = idesc.z - idesc.y;
-        const int4* groups = p.home_groups + group_pool_offset(p, rg, h) + idesc.y;
+        const int ngroups = fa.w;
+        const int4* groups = p.home_groups + fb.w;
         struct Raw {
             float x[3], v[3], vol, C[9];
             // tau factors a, b (faces) and force (vertices) in separate registers: merging them
@@ -819,11 +818,11 @@ __global__ __launch_bounds__(G2P_THREADS) __attribute__((amdgpu_waves_per_eu(4, 
     const unsigned n_items = ctl->n_items;
     for (unsigned q = blockIdx.x; q < n_items; q += gridDim.x) {
         __syncthreads();  // everybody is done with the previous tile
-        const int4 idesc = p.item_desc[p.item_order[q]];
-        const unsigned h = (unsigned)idesc.x;
+        const int4 fa = p.item_flat[2 * q], fb = p.item_flat[2 * q + 1];
+        const unsigned h = (unsigned)fa.y;
         if (p.halo_cls >= 0) {   // split gather around the halo exchange (uniform over the workgroup)
             int hx, hy, hz;
-            block_coords(p.home_block[h], hx, hy, hz);
+            block_coords((uint32_t)fa.z, hx, hy, hz);
             if (!halo_item_selected(p, hx)) continue;
         }
         const bool prof = (diag_flags(p) & 4) != 0;
@@ -832,9 +831,8 @@ __global__ __launch_bounds__(G2P_THREADS) __attribute__((amdgpu_waves_per_eu(4, 
         int4 rg;
         {
             // the item's particles: from the first slot of its first wave group to the end of its last
-            const int4 hr = p.home_range[h];
-            const int4* groups = p.home_groups + group_pool_offset(p, hr, h);
-            const int4 ga = groups[idesc.y], gb = groups[idesc.z - 1];
+            const int4* groups = p.home_groups + fb.w;
+            const int4 ga = groups[0], gb = groups[fa.w - 1];
             rg = make_int4(ga.x, gb.y, ga.z, gb.w);
         }
         // faces then vertices as one index space: a single copy of the (large) particle body
@@ -850,7 +848,7 @@ __global__ __launch_bounds__(G2P_THREADS) __attribute__((amdgpu_waves_per_eu(4, 
         __syncthreads();
         if (prof) t1 = __builtin_readcyclecounter();
         int bx, by, bz;
-        block_coords(p.home_block[h], bx, by, bz);
+        block_coords((uint32_t)fa.z, bx, by, bz);
         const int ox = bx * 4 - FREE_ZONE, oy = by * 4 - FREE_ZONE, oz = bz * 4 - FREE_ZONE;
 #pragma unroll 1
         for (; u < total; u += G2P_THREADS) {
