@@ -136,15 +136,20 @@ def test_no_contacts_is_a_noop():
 
 
 @pytest.mark.parametrize("exact", [False, True])
-@pytest.mark.parametrize("params,mu", [("soft", 0.5), ("config3", 1.0)])
-def test_single_newton_iteration_matches_oracle(exact, params, mu):
+@pytest.mark.parametrize("params,mu,scene", [("soft", 0.5, "sparse"), ("config3", 1.0, "sparse"), ("config3", 1.0, "dense")])
+def test_single_newton_iteration_matches_oracle(exact, params, mu, scene):
     """max_newton_iterations = 1 ("one full Newton iteration's Dir / norm_dir"): the
     solver tolerance plays no role, so the direction (cuda_mpm_kernels.cuh:1217-1274), its norm, the
     line-search energies and the chosen step (cuda_mpm_solver.cu:383-528) are compared at rounding level."""
     from drake_amd import ARR as A
     from oracle import oracle as orc
     stiffness, damping, DT = CONTACT_PARAMS[params]
-    o, g = build_pair(layers=2, res=24, z0=Z_FLOOR - 0.004, vel_amp=0.3)
+    if scene == "sparse":
+        o, g = build_pair(layers=2, res=24, z0=Z_FLOOR - 0.004, vel_amp=0.3)
+    else:
+        # ~100 contacts per cell (two sheets of ~50 particles per cell each in every cell layer): the
+        # contacts of a cell straddle the 64-contact tiles of k_ct_tile, and a tile holds few segments
+        o, g = build_pair(layers=4, res=40, side=0.15, z0=Z_FLOOR - 0.02, vel_amp=0.3)
     o.vel[:, 2] -= 0.5
     o.vel[:, 0] += 0.3
     g.upload_particle_state(o.pos, o.vel, o.C, None, o.F)
@@ -156,6 +161,10 @@ def test_single_newton_iteration_matches_oracle(exact, params, mu):
         s.update_grid(-1)
     cp = floor_contacts(g.sync_particle_state_to_cpu())
     assert cp[0].size > 100
+    if scene == "dense":
+        cells = np.floor(cp[4] * 64 - 0.5).astype(np.int64)
+        _, per_cell = np.unique(cells[:, 0] * 4096 + cells[:, 1] * 64 + cells[:, 2], return_counts=True)
+        assert per_cell.max() > 64 and cp[0].size > 5000
     o.copy_contact_pairs(orc.ContactPairs(*cp))
     g.copy_contact_pairs(*cp)
     ro = o.update_contact(DT, mu, stiffness, damping, exact_line_search=exact, max_iters=1)
