@@ -165,6 +165,7 @@ static ContactDev make_contact_dev(mpm_engine* e, float dt, float mu, float k, f
     c.dt = dt; c.mu = mu; c.k = k; c.d = d;
     c.epsv = e->mat.epsv;
     c.relax = 0.3f;   // jacobi_relax_coeff, cuda_mpm_solver.cu:239
+    if (const char* t = getenv("MPM_CT_RELAX")) c.relax = (float)atof(t);   // (tests: overshoot on purpose, so that the backtracking has work)
     c.tol = 1e-4f;    // kTol, cuda_mpm_solver.cu:236
     c.slot = b.slot; c.body = b.body; c.dist = b.dist; c.normal = b.normal; c.pos = b.pos;
     c.rigid_v = b.rigid_v; c.p_WB = b.p_WB; c.vel = b.vel; c.vel0 = b.vel0;

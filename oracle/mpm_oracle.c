@@ -1311,6 +1311,11 @@ static void ls_thunk(void *ctx, float alpha, float *out) {
 static float g_last_diag[6];
 ORC_API void orc_last_contact_diag(float *out6) { memcpy(out6, g_last_diag, sizeof(g_last_diag)); }
 
+/* jacobi_relax_coeff (cuda_mpm_solver.cu:239) is a constant, 0.3, in the reference.  Tests raise it to make
+ * the Newton step overshoot, so that the backtracking loop (:472-528) has to halve it several times. */
+static float g_relax = 0.3f;
+ORC_API void orc_set_contact_relax(float r) { g_relax = r; }
+
 /* GpuMpmSolver::UpdateContact (cuda_mpm_solver.cu:214-621), Jacobi branch.
  * Grid arrays are dense, indexed by cell key.  On exit gv holds the post
  * contact grid velocities, cvel/cvel0 the contact velocities, tau/frc the
@@ -1327,7 +1332,7 @@ ORC_API int orc_update_contact(const orc_params *p, size_t nk, const float *cpos
                                float *energy_out) {
     if (!nk) return 0;                                           /* :216-217 */
     const uint32_t tc = touched_blocks * 64u;
-    const float kTol = 1e-4f, relax = 0.3f;                      /* :236,239 */
+    const float kTol = 1e-4f, relax = g_relax;                   /* :236,239 */
     if (max_iters <= 0) max_iters = 2000;                        /* :234 */
     float norm_dir = 1e10f;
     int count = 0;

@@ -287,6 +287,11 @@ class OracleMpm:
             self.L.orc_initialize_contact_velocities(C.c_size_t(nk), _f(self.c_vel), _u(pairs.particle), _f(self.vel))
 
     # -- GpuMpmSolver::UpdateContact (cuda_mpm_solver.cu:214-621)
+    def set_contact_relax(self, r: float):
+        """Test hook: the Jacobi relaxation coefficient (0.3 in the reference, cuda_mpm_solver.cu:239)."""
+        self.L.orc_set_contact_relax.argtypes = [C.c_float]
+        self.L.orc_set_contact_relax(float(r))
+
     def update_contact(self, dt, friction_mu, stiffness, damping, exact_line_search=False, max_iters=2000):
         pc = self.contacts
         nk = 0 if pc is None else len(pc)

@@ -197,6 +197,45 @@ def test_single_newton_iteration_matches_oracle(exact, params, mu, scene):
     close(f_g, o.F_f, scale=float(np.abs(o.F_f).max()), rtol=10 * rt, what="1-iteration body impulse")
 
 
+def test_backtracking_beyond_the_first_candidates_matches_oracle(monkeypatch):
+    """The engine evaluates the step lengths 1, 1/2, 1/4, 1/8 in a first pass and the other 24 only when none
+    of them is accepted (cuda_mpm_solver.cu:472-528 halves alpha one evaluation at a time).  With the Jacobi
+    relaxation raised from 0.3 to 40 (test hooks on both sides) the Newton step overshoots ~40-fold, so the
+    accepted step lies beyond the first pass: same step, same count of evaluations, same energies."""
+    from drake_amd import ARR as A
+    from oracle import oracle as orc
+    stiffness, damping, DT = CONTACT_PARAMS["soft"]
+    o, g = build_pair(layers=2, res=24, z0=Z_FLOOR - 0.004, vel_amp=0.3)
+    o.vel[:, 2] -= 0.5
+    g.upload_particle_state(o.pos, o.vel, o.C, None, o.F)
+    for s in (o, g):
+        s.reallocate_external_bodies(1)
+        s.rebuild_mapping(False)
+        s.calc_fem_state_and_force(DT)
+        s.particle_to_grid(DT)
+        s.update_grid(-1)
+    cp = floor_contacts(g.sync_particle_state_to_cpu())
+    o.copy_contact_pairs(orc.ContactPairs(*cp))
+    g.copy_contact_pairs(*cp)
+    monkeypatch.setenv("MPM_CT_RELAX", "40")
+    o.set_contact_relax(40.0)
+    try:
+        ro = o.update_contact(DT, 0.5, stiffness, damping, exact_line_search=False, max_iters=1)
+        rg = g.update_contact(DT, 0.5, stiffness, damping, exact_line_search=False, max_newton_iterations=1)
+    finally:
+        o.set_contact_relax(0.3)
+    cs = g.contact_stats()
+    assert ro["iterations"] == rg["iterations"] == 1
+    assert ro["alpha"] < 1.0 / 8.0, ro            # beyond the first pass
+    assert cs["alpha"] == ro["alpha"] and cs["line_search_evals"] == ro["ls_last"], (cs, ro)
+    close([cs["E0"]], [ro["E0"]], what="deep backtracking E(0)")
+    close([cs["energy"]], [ro["E1"]], scale=abs(ro["E0"]), what="deep backtracking E(alpha)")
+    close(g.download(A.GRID_DIR), o.g_D, what="deep backtracking Dir")
+    sc = natural_scales(o, DT)
+    wgt = (o.g_m / o.g_m.max())[:, None]
+    close(g.download(A.GRID_MOMENTUM) * wgt, o.g_mv * wgt, scale=sc["vel"], what="deep backtracking grid v")
+
+
 def test_pairs_survive_a_resort_between_copy_and_update():
     """CopyContactPairs names particles by the caller's slot; the engine's own particle order changes
     with every internal re-sort.  A RebuildMapping that really re-sorts between CopyContactPairs and
