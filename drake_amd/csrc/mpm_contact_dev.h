@@ -4,17 +4,21 @@
 //
 // Differences in organisation from the reference (same arithmetic):
 //   - the contact -> node scatter of Hessians/gradients (12 float atomics x 27
-//     nodes per contact per iteration, cuda_mpm_kernels.cuh:1184-1212) is a
-//     gather.  Contact positions are fixed during the solve, so once per
+//     nodes per contact per iteration, cuda_mpm_kernels.cuh:1184-1212) is two
+//     fixed-order sums.  Contact positions are fixed during the solve, so once per
 //     UpdateContact the contacts are sorted by the cell of their stencil base
-//     (stable radix sort, mpm_sort.h).  A node then finds all its contacts as
-//     the contiguous runs of its 27 neighbour cells and sums them in that fixed
-//     order, 16 lanes per node; the weights are recomputed from the contact's
-//     fractional position, so there is no per-(node, contact) adjacency in memory;
+//     (stable radix sort, mpm_sort.h).  Contacts of one cell share their 27 stencil
+//     nodes: k_ct_tile (a workgroup per 64 sorted contacts) reads those nodes once
+//     into LDS, evaluates the contacts and sums, per cell, what they add to each of
+//     the 27 nodes; k_ct_node_dir adds the sums of a node's 27 base cells, found
+//     through the per-cell runs.  No per-(node, contact) adjacency in memory;
 //   - all per-contact work arrays live in that sorted order (coalesced);
-//   - the backtracking line search evaluates all 28 step lengths 1, 1/2, ...,
-//     2^-27 in one pass and picks the first acceptable one on the device, so an
-//     iteration needs no host round trip (the reference syncs >= 3 times);
+//   - the backtracking line search evaluates the step lengths 1, 1/2, 1/4, 1/8 in
+//     one pass (the other 24, down to 2^-27, in a second pass when none of these is
+//     accepted) and picks the first acceptable one on the device, so an iteration
+//     needs no host round trip (the reference syncs >= 3 times);
+//   - the accepted step is added to the grid by the next iteration's k_ct_node_dir
+//     (the kernel that replaces the direction), not by a launch of its own;
 //   - global scalars are reduced per workgroup and then in a fixed order.
 #pragma once
 #include <hip/hip_runtime.h>
@@ -767,10 +771,10 @@ __global__ __launch_bounds__(256) void k_ct_tile(DP p, ContactDev c, int first, 
     }
 }
 
-// G1: per node that sees contacts, gather the Hessian/gradient of those contacts, add the inertia
+// G1b: per node that sees contacts, add up the per-cell sums of k_ct_tile, add the inertia
 // term and solve for the Newton direction (cuda_mpm_kernels.cuh:1217-1274).  16 lanes per node:
-// the node's contacts are the runs of its 27 neighbour base cells; lane s takes every 16th
-// contact of a run, the 16 partial sums are folded in a fixed butterfly.
+// the node's contacts are the runs of its 27 neighbour base cells; lane s adds the segment sums of the
+// stencil offsets s and s + 16, the 16 partial sums are folded in a fixed butterfly.
 // MODE 0: gather and solve in one pass.  Partitioned domain: MODE 1 gathers this rank's contacts into
 // c.hg (every cell of it is written: zeros where no contact reaches), the zone exchange adds the
 // neighbours' sums, MODE 2 solves from c.hg; |Dir|^2 and the DoF count only include owned nodes.
