@@ -7,12 +7,12 @@
 // pairs in UpdateContact.  The engine's own particle order does not use it (see
 // mpm_rebuild.h: that one is a counting sort fused with the block tables).
 //
-// One wave per workgroup owns a tile of 64 * items consecutive pairs:
+// A workgroup of 4 waves owns a tile of 64 * items consecutive pairs (a quarter of its chunks per wave):
 //   k_sort_hist    digit histogram of the tile                -> hist[digit][tile]
 //   k_sort_scan    exclusive scan of hist in (digit, tile) order (one workgroup)
 //   k_sort_scatter ranks the tile's pairs chunk by chunk with wave ballots (lanes in order,
 //                  chunks in order => stable) and writes them to their final position
-// No barriers and no global atomics; LDS holds the 256 running offsets of the tile.
+// No global atomics; LDS holds the running offsets of every wave of the tile.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -23,23 +23,26 @@
 
 namespace mpm {
 
+// A tile of 64 * items consecutive pairs belongs to one workgroup of SORT_WAVES waves; wave w owns the
+// w-th quarter of the tile's chunks (contiguous, so that the order of the waves is the order of the pairs).
+constexpr int SORT_WAVES = 4;
+
 template <int DB>
-__global__ __launch_bounds__(64) void k_sort_hist(const uint32_t* keys, int n, int shift, int items, int* hist,
-                                                  int ntiles) {
+__global__ __launch_bounds__(64 * SORT_WAVES) void k_sort_hist(const uint32_t* keys, int n, int shift, int items, int* hist,
+                                                              int ntiles) {
     constexpr int ND = 1 << DB;
     __shared__ int s_cnt[ND];
-    const int lane = threadIdx.x, tile = blockIdx.x;
-    for (int d = lane; d < ND; d += 64) s_cnt[d] = 0;
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    const int begin = tile * 64 * items;
-    for (int it = 0; it < items; ++it) {
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, tile = blockIdx.x;
+    for (int d = tid; d < ND; d += 64 * SORT_WAVES) s_cnt[d] = 0;
+    __syncthreads();
+    const int per_wave = items / SORT_WAVES;
+    const int begin = tile * 64 * items + wv * per_wave * 64;
+    for (int it = 0; it < per_wave; ++it) {
         const int i = begin + it * 64 + lane;
         if (i < n) atomicAdd(&s_cnt[(keys[i] >> shift) & (uint32_t)(ND - 1)], 1);
     }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    for (int d = lane; d < ND; d += 64) hist[(size_t)d * ntiles + tile] = s_cnt[d];
+    __syncthreads();
+    for (int d = tid; d < ND; d += 64 * SORT_WAVES) hist[(size_t)d * ntiles + tile] = s_cnt[d];
 }
 
 // Exclusive scan of one int per thread across a 1024-thread workgroup (shared by the scans below).
@@ -158,18 +161,36 @@ __global__ __launch_bounds__(256) void k_scan_add(int* a, const int* sums) {
 }
 
 template <int DB>
-__global__ __launch_bounds__(64) void k_sort_scatter(const uint32_t* keys, const uint32_t* vals, uint32_t* keys_out,
-                                                     uint32_t* vals_out, int n, int shift, int items, const int* hist,
-                                                     int ntiles) {
+__global__ __launch_bounds__(64 * SORT_WAVES) void k_sort_scatter(const uint32_t* keys, const uint32_t* vals, uint32_t* keys_out,
+                                                                 uint32_t* vals_out, int n, int shift, int items, const int* hist,
+                                                                 int ntiles) {
     constexpr int ND = 1 << DB;
-    __shared__ int s_off[ND];
-    const int lane = threadIdx.x, tile = blockIdx.x;
-    for (int d = lane; d < ND; d += 64) s_off[d] = hist[(size_t)d * ntiles + tile];
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
+    __shared__ int s_off[SORT_WAVES][ND];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, tile = blockIdx.x;
+    for (int d = tid; d < SORT_WAVES * ND; d += 64 * SORT_WAVES) (&s_off[0][0])[d] = 0;
+    __syncthreads();
+    const int per_wave = items / SORT_WAVES;
+    const int begin = tile * 64 * items + wv * per_wave * 64;
+    // digits of this wave's pairs, counted per wave ...
+    for (int it = 0; it < per_wave; ++it) {
+        const int i = begin + it * 64 + lane;
+        if (i < n) atomicAdd(&s_off[wv][(keys[i] >> shift) & (uint32_t)(ND - 1)], 1);
+    }
+    __syncthreads();
+    // ... and turned into every wave's first output position per digit: the tile's, then wave by wave
+    for (int d = tid; d < ND; d += 64 * SORT_WAVES) {
+        int run = hist[(size_t)d * ntiles + tile];
+#pragma unroll
+        for (int w = 0; w < SORT_WAVES; ++w) {
+            const int cnt = s_off[w][d];
+            s_off[w][d] = run;
+            run += cnt;
+        }
+    }
+    __syncthreads();
+    int* off = s_off[wv];   // (from here on every wave works on its own: wave-level fences only)
     const unsigned long long lt = (1ull << lane) - 1ull;
-    const int begin = tile * 64 * items;
-    for (int it = 0; it < items; ++it) {
+    for (int it = 0; it < per_wave; ++it) {
         const int i = begin + it * 64 + lane;
         const bool valid = i < n;
         const uint32_t key = valid ? keys[i] : 0u;
@@ -183,11 +204,11 @@ __global__ __launch_bounds__(64) void k_sort_scatter(const uint32_t* keys, const
             same &= ((digit >> b) & 1u) ? m : ~m;
         }
         int dst = 0;
-        if (valid) dst = s_off[digit] + (int)__popcll(same & lt);
+        if (valid) dst = off[digit] + (int)__popcll(same & lt);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         // the last lane of every digit group moves the running offset on
-        if (valid && (same >> lane) == 1ull) s_off[digit] = dst + 1;
+        if (valid && (same >> lane) == 1ull) off[digit] = dst + 1;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         if (valid) {
@@ -225,9 +246,9 @@ template <int DB>
 static void radix_pass(hipStream_t s, const uint32_t* ki, const uint32_t* vi, uint32_t* ko, uint32_t* vo, int* hist, int n,
                        int shift, int items, int ntiles) {
     using namespace mpm;
-    hipLaunchKernelGGL(k_sort_hist<DB>, dim3(ntiles), dim3(64), 0, s, ki, n, shift, items, hist, ntiles);
+    hipLaunchKernelGGL(k_sort_hist<DB>, dim3(ntiles), dim3(64 * SORT_WAVES), 0, s, ki, n, shift, items, hist, ntiles);
     hipLaunchKernelGGL(k_sort_scan, dim3(1), dim3(1024), 0, s, hist, (1 << DB) * ntiles);
-    hipLaunchKernelGGL(k_sort_scatter<DB>, dim3(ntiles), dim3(64), 0, s, ki, vi, ko, vo, n, shift, items, (const int*)hist,
+    hipLaunchKernelGGL(k_sort_scatter<DB>, dim3(ntiles), dim3(64 * SORT_WAVES), 0, s, ki, vi, ko, vo, n, shift, items, (const int*)hist,
                        ntiles);
 }
 
