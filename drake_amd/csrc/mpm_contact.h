@@ -53,7 +53,7 @@ static int ensure_contact_capacity(mpm_engine* e, size_t n) {
     const size_t cells = (size_t)e->dp.capA * 64;
     if (!b.run || b.cap_cells < cells) {
         int rc;
-        if ((rc = grow(&b.run, cells)) || (rc = grow(&b.node_flag, cells)) || (rc = grow(&b.node_list, cells)) ||
+        if ((rc = grow(&b.run, cells)) || (rc = grow(&b.node_flag, cells)) || (rc = grow(&b.node_list, cells)) || (rc = grow(&b.flag_bits, (size_t)e->dp.capA)) ||
             (rc = grow(&b.node_runs, 27 * cells)) || (rc = grow(&b.gD, cells)) ||
             (e->dp.dist.on && (rc = grow(&b.hg, 3 * cells))) ||
             (rc = grow(&b.part, (size_t)(CT_ROWS_CON + CT_ROWS) * CT_PART)) || (rc = grow(&b.part_dir, (size_t)2 * CT_DIR_WG)) ||
@@ -172,7 +172,7 @@ static ContactDev make_contact_dev(mpm_engine* e, float dt, float mu, float k, f
     c.key = b.key; c.order = b.order;
     c.cnode = b.cnode; c.cfx = b.cfx; c.cmass = b.cmass; c.cphi0 = b.cphi0; c.cR = b.cR; c.cv0 = b.cv0;
     c.crv = b.crv; c.cvel = b.cvel; c.seg_part = b.seg_part;
-    c.run = b.run; c.node_flag = b.node_flag; c.node_list = b.node_list; c.node_runs = b.node_runs;
+    c.run = b.run; c.node_flag = b.node_flag; c.node_list = b.node_list; c.flag_bits = b.flag_bits; c.node_runs = b.node_runs;
     c.cap_nodes = (int)b.cap_cells; c.gD = b.gD; c.hg = b.hg;
     c.part = b.part; c.part_dir = b.part_dir; c.st = b.st; c.it_log = b.it_log;
     c.body_tau = b.body_tau; c.body_f = b.body_f; c.n_bodies = (int)b.n_bodies;
@@ -340,6 +340,7 @@ static int update_contact(mpm_engine* e, int frame, int substep, float dt, float
         if (int rc = zone_exchange3(e, b.hg)) return rc;
         hipLaunchKernelGGL(k_ct_flags_to_field, dim3(512), dim3(256), 0, s, p, c, 1);
     }
+    hipLaunchKernelGGL(k_ct_flag_bits, dim3(256), dim3(256), 0, s, p, c);
     hipLaunchKernelGGL(k_ct_node_list, dim3(1), dim3(1024), 0, s, p, c);
     hipLaunchKernelGGL(k_ct_node_runs, dim3(1024), dim3(256), 0, s, p, c);
     // pre-contact velocity at the contact points (cuda_mpm_solver.cu:267-272)

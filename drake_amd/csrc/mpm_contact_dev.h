@@ -94,6 +94,7 @@ struct ContactDev {
     float* cvel;            // [3][n] contact velocity (sorted order)
     int2* run;              // [cells] (begin, end) of the contacts whose base cell this is
     int* node_flag;         // [cells] 1 if some contact's stencil reaches the node
+    unsigned long long* flag_bits;   // [active blocks] node_flag as one bit per cell
     int* node_list;         // [<= cells] those nodes
     int2* node_runs;        // [27][cap_nodes] per listed node and stencil offset: contact run of the base cell there
     float* seg_part;        // [n][27][12], filled at the first contact of every segment (= the contacts of one
@@ -144,6 +145,7 @@ struct ContactBuffers {
           *cvel = nullptr;
     int2* run = nullptr;
     int* node_flag = nullptr;
+    unsigned long long* flag_bits = nullptr;
     int* node_list = nullptr;
     int2* node_runs = nullptr;
     float* seg_part = nullptr;
@@ -164,7 +166,7 @@ struct ContactBuffers {
 
     void release() {
         void* ptrs[] = {api_idx, colliders, gen_cnt, gen_sums, slot, body, dist, normal, pos, rigid_v, p_WB, vel, vel0, key, order, key2, order2, sort_hist,
-                        cnode, cfx, cmass, cphi0, cR, cv0, crv, cvel, run, node_flag, node_list, node_runs, seg_part, gD, hg,
+                        cnode, cfx, cmass, cphi0, cR, cv0, crv, cvel, run, node_flag, flag_bits, node_list, node_runs, seg_part, gD, hg,
                         zone_buf[0], zone_buf[1], zone_buf[2], zone_buf[3], part, part_dir, st, it_log, body_tau, body_f};
         for (void* q : ptrs)
             if (q) (void)hipFree(q);
@@ -391,40 +393,30 @@ __global__ __launch_bounds__(256) void k_ct_prepare(DP p, ContactDev c) {
     c.cphi0[j] = -c.dist[k];
 }
 
-// S3: list of the nodes that see a contact (ascending), one workgroup; 16 cells per thread and
-// block (the cell count is a multiple of 64)
+// S3: the nodes that see contacts, in ascending order.  Two steps: the flags of a block (64 ints) become one
+// 64-bit word (a ballot per wave, all CUs), then ONE workgroup scans the words' bit counts and writes the
+// set bits out (one CU reading the int flags themselves took 21 us: 460 KB through a single L1).
+__global__ __launch_bounds__(256) void k_ct_flag_bits(DP p, ContactDev c) {
+    const int words = (int)p.ctl->n_active;   // one word per active block
+    const int lane = threadIdx.x & 63;
+    for (int w = (blockIdx.x * 256 + threadIdx.x) >> 6; w < words; w += (gridDim.x * 256) >> 6) {
+        const unsigned long long m = __ballot(c.node_flag[(size_t)w * 64 + lane] != 0);
+        if (lane == 0) c.flag_bits[w] = m;
+    }
+}
 __global__ __launch_bounds__(1024) void k_ct_node_list(DP p, ContactDev c) {
     __shared__ int s_w[16];
     const int tid = threadIdx.x;
-    const int ncell = (int)p.ctl->n_active * 64;
+    const int words = (int)p.ctl->n_active;
     int carry = 0;
-    // (the next block's flags are requested before this block is scanned: the loop is a chain of
-    // load -> scan -> scattered stores otherwise, ~3 us per 16384 cells)
-    int4 nf[4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const int g = tid * 16 + q * 4;
-        nf[q] = g < ncell ? *reinterpret_cast<const int4*>(c.node_flag + g) : make_int4(0, 0, 0, 0);
-    }
-    for (int base = 0; base < ncell; base += 16384) {
-        int4 f[4];
-        int sum = 0;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            f[q] = nf[q];
-            sum += f[q].x + f[q].y + f[q].z + f[q].w;
-            const int g = base + 16384 + tid * 16 + q * 4;
-            nf[q] = g < ncell ? *reinterpret_cast<const int4*>(c.node_flag + g) : make_int4(0, 0, 0, 0);
-        }
+    for (int base = 0; base < words; base += 1024) {
+        const int w = base + tid;
+        unsigned long long m = w < words ? c.flag_bits[w] : 0ull;
         int block_total;
-        int at = carry + wg1024_exclusive(sum, block_total, s_w);
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int g = base + tid * 16 + q * 4;
-            if (f[q].x) c.node_list[at++] = g;
-            if (f[q].y) c.node_list[at++] = g + 1;
-            if (f[q].z) c.node_list[at++] = g + 2;
-            if (f[q].w) c.node_list[at++] = g + 3;
+        int at = carry + wg1024_exclusive((int)__popcll(m), block_total, s_w);
+        while (m) {
+            c.node_list[at++] = w * 64 + (int)__builtin_ctzll(m);
+            m &= m - 1ull;
         }
         carry += block_total;
     }
