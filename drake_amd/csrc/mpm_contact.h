@@ -309,16 +309,14 @@ static int update_contact(mpm_engine* e, int frame, int substep, float dt, float
     const unsigned gc = (unsigned)((n + 255) / 256);
     // The pairs name particles by the caller's slot; the engine's internal slots change with every
     // re-sort (which the device decides by itself, e.g. inside a RebuildMapping between
-    // CopyContactPairs and this call): resolve them again now, from the kept caller indices.
-    hipLaunchKernelGGL(k_ct_slots, dim3(gc), dim3(256), 0, s, (int)n, (const uint32_t*)b.api_idx, e->d_pids_api,
-                       e->dp.imap, b.slot);
+    // CopyContactPairs and this call): k_ct_keys resolves them again, from the kept caller indices.
     // grid-stride contact part of k_ct_ls: 4 lanes per contact
     const int n_con_wg = (int)std::min<size_t>((n + CT_WG / 4 - 1) / (CT_WG / 4), CT_ROWS_CON);
     const int n_grid_wg = CT_ROWS;                               // grid-stride node part
     const int n_dir_wg = CT_DIR_WG;
     // ---- set-up: contacts in base-cell order, per-cell runs, nodes that see contacts ---------
     HIP_TRY(hipMemsetAsync(b.st, 0, sizeof(ContactState), s));
-    hipLaunchKernelGGL(k_ct_keys, dim3(1024), dim3(256), 0, s, p, c);
+    hipLaunchKernelGGL(k_ct_keys, dim3(1024), dim3(256), 0, s, p, c, (const uint32_t*)b.api_idx, (const int*)e->d_pids_api, b.slot);
     {
         // Keys are compact cells (active block * 64 + cell).  The number of active blocks is known from
         // the hand-over of the pairs unless a re-sort may have run since (launch_rebuild clears the hint):
@@ -493,8 +491,7 @@ static int update_contact(mpm_engine* e, int frame, int substep, float dt, float
         }
     }
     // contact velocities after the solve and the reaction on the rigid bodies
-    hipLaunchKernelGGL(k_ct_gather_vel, dim3(gc), dim3(256), 0, s, p, c, b.vel);
-    hipLaunchKernelGGL(k_ct_impulse, dim3(std::min(gc, 256u)), dim3(256), 0, s, c);
+    hipLaunchKernelGGL(k_ct_impulse, dim3(std::min(gc, 256u)), dim3(256), 0, s, p, c);
     HIP_TRY(hipGetLastError());
     b.last_iters = iters;
     if (getenv("MPM_CT_DEBUG")) fprintf(stderr, "contact solve: n %zu nodes %d items %d iters %d\n", n, st.n_nodes, 0, iters);

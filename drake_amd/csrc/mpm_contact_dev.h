@@ -325,7 +325,8 @@ MPM_DEV void contact_base(const DP& p, const float* pos, uint32_t* b) {
 }
 
 // S1: sort key = compact index of the stencil's base cell; clears the per-cell tables
-__global__ __launch_bounds__(256) void k_ct_keys(DP p, ContactDev c) {
+// (also re-resolves the pairs' particles: caller's slot -> engine id -> current internal slot, k_ct_slots' job)
+__global__ __launch_bounds__(256) void k_ct_keys(DP p, ContactDev c, const uint32_t* api_slot, const int* pids_api, uint32_t* slot_out) {
     const int gs = gridDim.x * 256, i0 = blockIdx.x * 256 + threadIdx.x;
     const int ncell = (int)p.ctl->n_active * 64;
     for (int g = i0; g < ncell; g += gs) {
@@ -339,6 +340,7 @@ __global__ __launch_bounds__(256) void k_ct_keys(DP p, ContactDev c) {
         const int cc = compact_cell(p, b[0], b[1], b[2]);
         c.key[k] = cc < 0 ? CT_NO_CELL : (uint32_t)cc;
         c.order[k] = (uint32_t)k;
+        slot_out[k] = (uint32_t)p.imap[pids_api[api_slot[k]]];
     }
 }
 
@@ -1268,17 +1270,21 @@ __global__ void k_ct_exact_finish(ContactDev c) {
 // per workgroup in LDS (bodies 0..31) before they touch the per-body accumulators: thousands of
 // float atomics on one address serialise at the memory side.
 constexpr int CT_LDS_BODIES = 32;
-__global__ __launch_bounds__(256) void k_ct_impulse(ContactDev c) {
+// (with the contact velocities after the solve, contact_vel, gathered here: k_ct_gather_vel's job)
+__global__ __launch_bounds__(256) void k_ct_impulse(DP p, ContactDev c) {
     __shared__ float s_acc[CT_LDS_BODIES][6];
     for (int q = threadIdx.x; q < CT_LDS_BODIES * 6; q += 256) (&s_acc[0][0])[q] = 0.f;
     __syncthreads();
     for (int j = blockIdx.x * 256 + threadIdx.x; j < c.n; j += gridDim.x * 256) {
         const int k = (int)c.order[j];   // sorted position j is the caller's contact k
         const float m = c.cmass[j];
+        float v[3];
+        gather_contact_velocity(p, c, j, v);
         float l[3], r[3];
 #pragma unroll
         for (int a = 0; a < 3; ++a) {
-            l[a] = m * -(c.vel[k * 3 + a] - c.vel0[k * 3 + a]);
+            c.vel[k * 3 + a] = v[a];
+            l[a] = m * -(v[a] - c.vel0[k * 3 + a]);
             r[a] = c.pos[k * 3 + a] - c.p_WB[k * 3 + a];
         }
         const float h[3] = {r[1] * l[2] - l[1] * r[2], r[2] * l[0] - l[2] * r[0], r[0] * l[1] - l[0] * r[1]};
