@@ -314,8 +314,17 @@ def main():
         mig_every = 4 if zone == 2 else 2
         geometry = dict(cuts=cuts, zone_blocks=zone, ghost_cells=ghost, ghost_margin_cells=margin, migrate_every=mig_every)
         g = make_engine(1234)
+        # exchange buffers travel whole every substep (1 KiB per block): sized to the zone, not to the grid --
+        # 2 * zone block layers of the ~active/(x extent) blocks each, with a factor 2 of headroom
+        # (an overflow is reported as MPM_ERR_CAPACITY, checked below)
+        active = g.stats()["active_blocks"]
+        per_layer = active / float(hi - lo + 2) if active else 1e9   # (tables not built yet: keep the largest size)
+        cap_blocks = 256
+        while cap_blocks < min(2048.0, 2.0 * (2 * zone) * per_layer):
+            cap_blocks *= 2
         chain_args = dict(cut_lo_block=cuts[rank], cut_hi_block=cuts[rank + 1], pitch_blocks=0, zone_blocks=zone,
-                          capacity_blocks=2048)
+                          capacity_blocks=min(cap_blocks, 2048))
+        geometry["exchange_capacity_blocks"] = chain_args["capacity_blocks"]
         mig_cap = 65536
     else:
         # Weak scaling: every rank owns one copy of the workload.  The ranks' patches sit side by side
