@@ -106,6 +106,7 @@ struct DP {
     int item_groups;       // a work item holds at most this many 64-particle wave groups
     int dbg;               // MPM_DBG environment variable (kernel ablation switches, 0 in production)
     float dx, dxinv, Dinv;
+    float anticip;         // re-sort: cells a particle is binned ahead per unit of velocity (0 = by position), see k_rb_count
     // fixed-point scales of the LDS tile accumulators (powers of two), see k_p2g
     double fix_m, fix_p, unfix_m, unfix_p;
     Material M;

@@ -133,13 +133,17 @@ static int grid_colliders_for(mpm_engine* e, int bc, GridColliders* out) {
 }
 
 static void launch_rebuild(mpm_engine* e) {
+    // anticipatory binning over the next `horizon` substeps of the last known length (not in a partitioned
+    // domain, where ownership and ghost bands are defined by the position itself)
+    static const float horizon = getenv("MPM_ANTICIPATE") ? (float)atof(getenv("MPM_ANTICIPATE")) : 32.f;
+    e->dp.anticip = e->dp.dist.on ? 0.f : horizon * e->last_dt * e->dp.dxinv;
     const DP& p = e->dp;
     e->cb.n_active_hint = 0;   // the block tables may change: contact pairs handed over before are re-keyed with the full width
     hipLaunchKernelGGL(k_rb_count, dim3(std::min(e->g_np, e->g_rb)), dim3(256), 0, e->stream, p);
     hipLaunchKernelGGL(k_rb_tables, dim3(33), dim3(1024), 0, e->stream, p);
     hipLaunchKernelGGL(k_rb_scatter, dim3(std::min(e->g_np, e->g_rb)), dim3(256), 0, e->stream, p);
     if (e->deterministic) hipLaunchKernelGGL(k_rb_canon, dim3(512), dim3(256), 0, e->stream, p);
-    hipLaunchKernelGGL(k_rb_finish, dim3((std::min(e->g_np, 2048u) + 7u) & ~7u), dim3(256), 0, e->stream, p);
+    hipLaunchKernelGGL(k_rb_finish, dim3((std::min(e->g_np, e->g_rb) + 7u) & ~7u), dim3(256), 0, e->stream, p);
 }
 static void drop_step_graph(mpm_engine* e) {
     if (e->step_graph) (void)hipGraphExecDestroy(e->step_graph);
@@ -153,6 +157,7 @@ static void launch_fem_vertices(mpm_engine* e) {
     if (e->nv) hipLaunchKernelGGL(k_vforce, dim3((e->g_nv + 7u) & ~7u), dim3(256), 0, e->stream, e->dp);
 }
 static void launch_fem(mpm_engine* e, float dt) {
+    e->last_dt = dt;
     launch_fem_faces(e, dt);
     launch_fem_vertices(e);
 }
@@ -818,6 +823,7 @@ int mpm_grid_to_particle(mpm_handle_t e, float dt) {
 int mpm_substep(mpm_handle_t e, float dt, int bc) { return mpm_run_substeps(e, 1, dt, bc); }
 
 static void launch_substep(mpm_engine* e, float dt, const GridColliders& gc) {
+    e->last_dt = dt;
     launch_rebuild(e);
     launch_fem(e, dt);
     launch_p2g(e, dt);

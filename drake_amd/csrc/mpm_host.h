@@ -51,6 +51,7 @@ struct mpm_engine {
     // RebuildMapping(sort = true): scratch of the device radix sort, second pids buffer
     uint32_t *d_sort_keys = nullptr, *d_sort_vals = nullptr, *d_sort_keys2 = nullptr, *d_sort_vals2 = nullptr;
     int* d_sort_hist = nullptr;
+    float last_dt = 0.f;   // length of the last substep (anticipatory binning of the re-sort)
     int* d_pids_api2 = nullptr;
     int* d_iota = nullptr;     // identity map, created on first use (views in original order)
     bool api_identity = true;

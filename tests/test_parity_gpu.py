@@ -253,6 +253,8 @@ def test_domain_error_and_fast_particles():
     assert ei.value.code == -6
     # fast motion is legal: the re-sort is requested by G2P for exactly the particles that left their
     # tile and runs before the next transfer, so 3.8 cells per substep is as good as 0.1
+    # (re-sorts: the one the upload asks for, then one per substep unless the anticipatory binning --
+    # particles are binned up to 1.75 cells ahead of where they are -- happens to keep everybody inside)
     g = small()
     vel = np.zeros((g.n_particles, 3), np.float32)
     vel[:, 2] = -60.0                       # 60 m/s * 1e-3 s = 3.8 cells of 1/64 per substep
@@ -261,7 +263,7 @@ def test_domain_error_and_fast_particles():
     for _ in range(3):
         g.substep(DT, -1)
     g.gpu_sync()
-    assert g.stats()["error_flags"] == 0 and g.stats()["rebuilds"] >= 3
+    assert g.stats()["error_flags"] == 0 and g.stats()["rebuilds"] >= 2
     dz = g.sync_particle_state_to_cpu()[:, 2] - z0
     np.testing.assert_allclose(dz, -(60.0 * 3 * DT + 9.8 * DT * DT * 6), rtol=1e-3)
 
@@ -282,7 +284,7 @@ def test_deterministic_mode_is_bitwise_reproducible():
         out = (g.sync_particle_state_to_cpu(), g.download(A.VELOCITIES), g.download(A.AFFINE),
                g.download(A.DEFORMATION_GRADIENTS))
         st = g.stats()
-        assert st["error_flags"] == 0 and st["rebuilds"] >= 5
+        assert st["error_flags"] == 0 and st["rebuilds"] >= 3
         return out
 
     a, b = run(True), run(True)
