@@ -51,6 +51,9 @@ struct Ctl {
     int cur;               // index of the current PSet
     int need_rebuild;      // raised by G2P when an advected particle no longer fits its block tile
     unsigned error;        // sticky ERR_* bits
+    unsigned skipped;      // substeps that were enqueued without their re-sort launches and found need_rebuild set:
+                           // their kernels returned at once, the host runs them again later (settle, mpm_engine.hip)
+    int skip_this;         // k_grid's verdict for the G2P of the same substep (G2P itself raises need_rebuild)
     unsigned n_home;       // blocks owning particles (tiles)
     unsigned n_active;     // blocks whose nodes are updated
     unsigned n_items;      // work items of the tile kernels (home blocks, heavy ones split)
@@ -106,6 +109,7 @@ struct DP {
     int item_groups;       // a work item holds at most this many 64-particle wave groups
     int dbg;               // MPM_DBG environment variable (kernel ablation switches, 0 in production)
     float dx, dxinv, Dinv;
+    int gated;             // 1: this substep was enqueued without the re-sort launches (see Ctl::skipped)
     float anticip;         // re-sort: cells a particle is binned ahead per unit of velocity (0 = by position), see k_rb_count
     // fixed-point scales of the LDS tile accumulators (powers of two), see k_p2g
     double fix_m, fix_p, unfix_m, unfix_p;

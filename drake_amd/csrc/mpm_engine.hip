@@ -401,8 +401,14 @@ int mpm_counts(mpm_handle_t e, size_t* nv, size_t* nf, size_t* np) {
     return 0;
 }
 
+static int settle(mpm_engine* e);
+
 int mpm_set_deterministic(mpm_handle_t e, int on) {
     REQUIRE(e, "null handle");
+    if (e->finalized) {
+        if (int rc = use(e)) return rc;
+        if (int rc = settle(e)) return rc;
+    }
     if (e->deterministic != (on != 0)) drop_step_graph(e);   // the captured substep has one kernel more or less
     e->deterministic = on != 0;
     return 0;
@@ -411,6 +417,8 @@ int mpm_set_deterministic(mpm_handle_t e, int on) {
 int mpm_set_stream(mpm_handle_t e, void* s) {
     REQUIRE(e, "null handle");
     if (int rc = use(e)) return rc;
+    if (e->finalized)
+        if (int rc = settle(e)) return rc;
     HIP_TRY(hipStreamSynchronize(e->stream));
     e->stream = s ? static_cast<hipStream_t>(s) : e->own_stream;
     return 0;
@@ -442,6 +450,8 @@ static int slab_pool_grow(mpm_engine* e, const Ctl& c) {
 int mpm_sync(mpm_handle_t e) {
     REQUIRE(e, "null handle");
     if (int rc = use(e)) return rc;
+    if (e->finalized)
+        if (int rc = settle(e)) return rc;
     HIP_TRY(hipStreamSynchronize(e->stream));
     HIP_TRY(hipGetLastError());
     if (!e->finalized && !e->dp.ctl) return 0;
@@ -473,10 +483,35 @@ int mpm_sync(mpm_handle_t e) {
 }
 
 // ---- the solver calls -----------------------------------------------------
-#define READY(e)                                        \
+static void launch_substep(mpm_engine* e, float dt, const GridColliders& gc, bool allow_gate);
+
+// Substeps that mpm_run_substeps enqueued without their re-sort launches and that found a re-sort pending
+// did nothing (Ctl::skipped): run them now, each with the re-sort in front.  Called by every entry point
+// before it looks at or changes the state.
+static int settle(mpm_engine* e) {
+    e->force_check = true;   // whatever comes next starts with the re-sort launches
+    e->dp.gated = 0;
+    if (!e->maybe_owed) return 0;
+    e->maybe_owed = false;
+    unsigned owed = 0;
+    D2H(e, &owed, &e->dp.ctl->skipped, sizeof(unsigned));   // (synchronises the stream)
+    if (!owed) return 0;
+    const unsigned zero = 0;
+    H2D(e, &e->dp.ctl->skipped, &zero, sizeof(unsigned));
+    GridColliders gc;
+    if (int rc = grid_colliders_for(e, e->owed_bc, &gc)) return rc;
+    for (unsigned k = 0; k < owed; ++k) launch_substep(e, e->owed_dt, gc, false);
+    e->force_check = true;
+    return 0;
+}
+
+#define READY_NO_SETTLE(e)                              \
     REQUIRE(e, "null handle");                          \
     REQUIRE((e)->finalized, "call mpm_finalize first"); \
     if (int rc__ = use(e)) return rc__
+#define READY(e)         \
+    READY_NO_SETTLE(e);  \
+    if (int rc2__ = settle(e)) return rc2__
 
 int mpm_rebuild_mapping(mpm_handle_t e, int sort) {
     READY(e);
@@ -822,9 +857,19 @@ int mpm_grid_to_particle(mpm_handle_t e, float dt) {
 
 int mpm_substep(mpm_handle_t e, float dt, int bc) { return mpm_run_substeps(e, 1, dt, bc); }
 
-static void launch_substep(mpm_engine* e, float dt, const GridColliders& gc) {
+// allow_gate: the substep may go without the re-sort launches (mpm_run_substeps outside graphs)
+static void launch_substep(mpm_engine* e, float dt, const GridColliders& gc, bool allow_gate) {
     e->last_dt = dt;
-    launch_rebuild(e);
+    const bool check = !allow_gate || e->force_check || e->check_every <= 1 || e->dp.dist.on ||
+                       (e->step_phase % (unsigned)e->check_every) == 0u;
+    e->step_phase += 1;
+    e->dp.gated = check ? 0 : 1;
+    if (check) {
+        launch_rebuild(e);
+        e->force_check = false;
+    } else {
+        e->maybe_owed = true;
+    }
     launch_fem(e, dt);
     launch_p2g(e, dt);
     launch_grid(e, gc);
@@ -841,7 +886,7 @@ static int step_graph_for(mpm_engine* e, float dt, int bc, const GridColliders& 
     drop_step_graph(e);
     hipGraph_t g = nullptr;
     HIP_TRY(hipStreamBeginCapture(e->stream, hipStreamCaptureModeThreadLocal));
-    for (int k = 0; k < e->step_graph_len; ++k) launch_substep(e, dt, gc);
+    for (int k = 0; k < e->step_graph_len; ++k) launch_substep(e, dt, gc, false);
     HIP_TRY(hipStreamEndCapture(e->stream, &g));
     const hipError_t err = hipGraphInstantiate(&e->step_graph, g, nullptr, nullptr, 0);
     (void)hipGraphDestroy(g);
@@ -854,7 +899,15 @@ static int step_graph_for(mpm_engine* e, float dt, int bc, const GridColliders& 
 }
 
 int mpm_run_substeps(mpm_handle_t e, int n, float dt, int bc) {
-    READY(e);
+    READY_NO_SETTLE(e);
+    static const int resort_every = getenv("MPM_RESORT_EVERY") ? atoi(getenv("MPM_RESORT_EVERY")) : 4;
+    e->check_every = resort_every;
+    // owed substeps are run with the parameters they were enqueued with: settle before these change
+    if (e->maybe_owed && (dt != e->owed_dt || bc != e->owed_bc || e->grid_colliders_version != e->owed_gcv))
+        if (int rc = settle(e)) return rc;
+    e->owed_dt = dt;
+    e->owed_bc = bc;
+    e->owed_gcv = e->grid_colliders_version;
     // MPM_GRAPH=<substeps per graph> replays captured graphs; measured slower than plain stream
     // dispatch on ROCm 7.2, hence opt-in
     static const int graph_len = getenv("MPM_GRAPH") ? atoi(getenv("MPM_GRAPH")) : 0;
@@ -866,7 +919,7 @@ int mpm_run_substeps(mpm_handle_t e, int n, float dt, int bc) {
         if (int rc = step_graph_for(e, dt, bc, gc)) return rc;
         for (; s + graph_len <= n; s += graph_len) HIP_TRY(hipGraphLaunch(e->step_graph, e->stream));
     }
-    for (; s < n; ++s) launch_substep(e, dt, gc);
+    for (; s < n; ++s) launch_substep(e, dt, gc, true);
     e->grid_state = 2;
     e->substeps += (uint64_t)std::max(n, 0);
     HIP_TRY(hipGetLastError());

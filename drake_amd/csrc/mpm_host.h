@@ -52,6 +52,14 @@ struct mpm_engine {
     uint32_t *d_sort_keys = nullptr, *d_sort_vals = nullptr, *d_sort_keys2 = nullptr, *d_sort_vals2 = nullptr;
     int* d_sort_hist = nullptr;
     float last_dt = 0.f;   // length of the last substep (anticipatory binning of the re-sort)
+    // gated substeps of mpm_run_substeps (see gated_out in mpm_step.h)
+    int check_every = 4;       // the re-sort launches precede every check_every-th substep (MPM_RESORT_EVERY; 1 = all)
+    unsigned step_phase = 0;
+    bool force_check = true;   // the next substep gets them whatever its number (after any other call)
+    bool maybe_owed = false;   // gated substeps were enqueued since the last settle()
+    float owed_dt = 0.f;
+    int owed_bc = 0;
+    uint64_t owed_gcv = 0;
     int* d_pids_api2 = nullptr;
     int* d_iota = nullptr;     // identity map, created on first use (views in original order)
     bool api_identity = true;

@@ -13,7 +13,14 @@ namespace mpm {
 // ---------------------------------------------------------------------------
 // FEM: one thread per face particle (slot order => coalesced face arrays).
 // ---------------------------------------------------------------------------
+// Gated substeps: the four re-sort launches only precede every few substeps of mpm_run_substeps (they
+// cost ~3 us each when idle).  A substep enqueued without them checks here whether a re-sort is pending
+// (raised by the G2P of an earlier substep): if so all of its kernels return at once and the host runs
+// that substep again, with the re-sort, at its next synchronisation point.
+MPM_DEV bool gated_out(const DP& p) { return p.gated && p.ctl->need_rebuild; }
+
 __global__ __launch_bounds__(256) void k_fem(DP p, float dt) {
+    if (gated_out(p)) return;
     const unsigned i = xcd_chunk(blockIdx.x, gridDim.x) * 256 + threadIdx.x;
     if (i >= (unsigned)p.ctl->nfa) return;
     const PSet& S = p.set[p.ctl->cur];
@@ -97,6 +104,7 @@ __global__ __launch_bounds__(256) void k_fem(DP p, float dt) {
 // kept per vertex slot (refreshed at every rebuild) so that a vertex needs one coalesced index
 // load and one 16-byte gather per adjacent face.
 __global__ __launch_bounds__(256) void k_vforce(DP p) {
+    if (gated_out(p)) return;
     const int k = (int)(xcd_chunk(blockIdx.x, gridDim.x) * 256 + threadIdx.x);
     if (k >= p.ctl->nva) return;
     const int s = p.Nf + k;
@@ -256,6 +264,7 @@ MPM_DEV unsigned tile_reach_mask(int rx, int ry, int rz) {
 }
 
 __global__ __launch_bounds__(512, 4) void k_p2g(DP p, float dt) {  // <= 128 VGPRs: two workgroups per CU
+    if (gated_out(p)) return;
     __shared__ long long tile[TILE_N * 4];  // (mvx, mvy, mvz, m) per node, fixed point
     // wave-private staging: 64 particles (+8 slack rows touched by the operand prefetch)
     __shared__ __attribute__((aligned(16))) float stage_all[8][(64 + 8) * STG];
@@ -583,6 +592,11 @@ template <int MODE>
 __global__ __launch_bounds__(256) void k_grid(DP p, GridColliders gc) {
     __shared__ int2 s_list[4][GRID_LIST];   // (item, offset index)
     const Ctl* ctl = p.ctl;
+    {
+        const bool out = gated_out(p);
+        if (blockIdx.x == 0 && threadIdx.x == 0) p.ctl->skip_this = out;
+        if (out) return;
+    }
     const unsigned n_active = ctl->n_active;
     const int tid = threadIdx.x;
     const int cell = tid & 63;
@@ -814,6 +828,10 @@ constexpr int G2P_THREADS = 512;
 __global__ __launch_bounds__(G2P_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_g2p(DP p, float dt) {
     __shared__ float4 tile[TILE_N];
     const Ctl* ctl = p.ctl;
+    if (p.gated && ctl->skip_this) {   // (not need_rebuild itself: this kernel raises it while it runs)
+        if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&p.ctl->skipped, 1u);
+        return;
+    }
     const PSet& S = p.set[ctl->cur];
     const unsigned n_items = ctl->n_items;
     for (unsigned q = blockIdx.x; q < n_items; q += gridDim.x) {

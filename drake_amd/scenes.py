@@ -66,6 +66,8 @@ CONFIGS = {
     # name: (domain_bits, layers, res)  -- SURVEY.md section 8d / BASELINE.json configs
     "plumbing_64k": (6, 8, 52),       # Np = 63,248
     "cloth_1m": (7, 16, 145),         # Np = 999,952
+    "cloth_125k": (7, 2, 145),        # Np = 124,994 (the share of one of 8 ranks)
+    "cloth_250k": (7, 4, 145),        # Np = 249,988
     "cloth_500k": (7, 8, 145),        # Np = 499,976 (scaling probe)
     "cloth_2m": (7, 32, 145),         # Np = 1,999,904 (scaling probe)
     "cloth_8m": (8, 32, 290),         # Np = 8,036,544

@@ -158,6 +158,40 @@ def test_substep_equals_phase_calls():
     close(g1.download(A.VELOCITIES), g2.download(A.VELOCITIES), scale=sc["vel"], rtol=1e-6, what="substep vel")
 
 
+def test_batched_substeps_with_resorts_in_between_equal_phase_calls():
+    """mpm_run_substeps enqueues the four re-sort launches only in front of every fourth substep; a substep
+    without them that finds a re-sort pending does nothing and is run again, with the re-sort, at the next
+    synchronisation point (Ctl::skipped / settle).  Sheets that cross a cell every other substep force
+    re-sorts inside the batch: the result must be the one of phase-by-phase calls, which re-sort on demand
+    before every substep."""
+    A = _A()
+    o, g1 = build_pair(seed=5, vel_amp=0.1)
+    _, g2 = build_pair(seed=5, vel_amp=0.1)
+    vel = o.vel.copy()
+    vel[:, 0] += 9.0           # 9 m/s * 1e-3 s * 64 cells = 0.58 cells per substep
+    for g in (g1, g2):
+        g.upload_particle_state(None, vel)
+    n = 14
+    g1.run_substeps(5, DT, -1)
+    g1.run_substeps(n - 5, DT, -1)      # (a second batch while substeps of the first may still be owed)
+    for _ in range(n):
+        g2.rebuild_mapping(False)
+        g2.calc_fem_state_and_force(DT)
+        g2.particle_to_grid(DT)
+        g2.update_grid(-1)
+        g2.grid_to_particle(DT)
+    s1, s2 = g1.stats(), g2.stats()
+    assert s1["error_flags"] == 0 and s2["error_flags"] == 0
+    assert s1["rebuilds"] >= 3 and s2["rebuilds"] >= 3, (s1, s2)
+    sc = natural_scales(o, DT)
+    x1, x2 = g1.download(A.POSITIONS), g2.download(A.POSITIONS)
+    assert np.abs(x1[:, 0] - o.pos[:, 0]).min() > 0.9 * 9.0 * n * DT      # everybody made all n substeps
+    close(x1, x2, scale=1.0, rtol=1e-6, what="batched substeps pos")
+    # (the two runs re-sort at different substeps: different particle order inside the cells, last-bit
+    # differences of the grid sums; the same 1e-5 as everywhere)
+    close(g1.download(A.VELOCITIES), g2.download(A.VELOCITIES), scale=max(sc["vel"], 9.0), rtol=RTOL, what="batched substeps vel")
+
+
 def test_free_fall_and_conservation_large():
     """Size-independent properties at a size the oracle is not run on: 250k particles on 128^3."""
     from drake_amd import ARR as A, GpuMpm, scenes
