@@ -247,6 +247,8 @@ MPM_DEV Stencil make_stencil(const DP& p, float x, float y, float z, int ox, int
 }
 
 // neighbour blocks (27-bit set) reached by the 3^3 stencil of base cell (rx, ry, rz) of a tile
+// (an outer product of three 3-bit sets, formed with shifts and masks: this runs on the scalar unit once
+// per cell group of every wave, and the scalar unit is shared by the 16 waves of a CU)
 MPM_DEV unsigned tile_reach_mask(int rx, int ry, int rz) {
     // block offset (-1,0,1) of the first and last stencil node per axis, as bit sets
     auto bits = [](int r) -> unsigned {
@@ -254,13 +256,13 @@ MPM_DEV unsigned tile_reach_mask(int rx, int ry, int rz) {
         return (1u << lo) | (1u << hi2);
     };
     const unsigned mx = bits(rx), my = bits(ry), mz = bits(rz);
-    unsigned m27 = 0;
-#pragma unroll
-    for (int a = 0; a < 3; ++a)
-#pragma unroll
-        for (int b = 0; b < 3; ++b)
-            if (((mx >> a) & 1u) && ((my >> b) & 1u)) m27 |= mz << (a * 9 + b * 3);
-    return m27;
+    // bit (a * 9 + b * 3 + c) = mx[a] & my[b] & mz[c]
+    const unsigned zrep = mz * 0x49u;                                                // mz at bits 0, 3, 6
+    const unsigned yexp = ((my & 1u) * 0x7u) | ((my & 2u) * 0x1Cu) | ((my & 4u) * 0x70u);   // my[b] over bits 3b..3b+2
+    const unsigned m9 = zrep & yexp;
+    const unsigned rep = m9 * 0x40201u;                                              // m9 at bits 0, 9, 18
+    const unsigned xexp = ((mx & 1u) * 0x1FFu) | ((mx & 2u) * (0x1FFu << 8)) | ((mx & 4u) * (0x1FFu << 16));
+    return rep & xexp;
 }
 
 __global__ __launch_bounds__(512, 4) void k_p2g(DP p, float dt) {  // <= 128 VGPRs: two workgroups per CU
