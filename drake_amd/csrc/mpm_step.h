@@ -250,18 +250,17 @@ MPM_DEV Stencil make_stencil(const DP& p, float x, float y, float z, int ox, int
 // (an outer product of three 3-bit sets, formed with shifts and masks: this runs on the scalar unit once
 // per cell group of every wave, and the scalar unit is shared by the 16 waves of a CU)
 MPM_DEV unsigned tile_reach_mask(int rx, int ry, int rz) {
-    // block offset (-1,0,1) of the first and last stencil node per axis, as bit sets
-    auto bits = [](int r) -> unsigned {
-        const int lo = (r - FREE_ZONE + 4) >> 2, hi2 = (r + 2 - FREE_ZONE + 4) >> 2;  // 0..2
-        return (1u << lo) | (1u << hi2);
-    };
-    const unsigned mx = bits(rx), my = bits(ry), mz = bits(rz);
-    // bit (a * 9 + b * 3 + c) = mx[a] & my[b] & mz[c]
-    const unsigned zrep = mz * 0x49u;                                                // mz at bits 0, 3, 6
-    const unsigned yexp = ((my & 1u) * 0x7u) | ((my & 2u) * 0x1Cu) | ((my & 4u) * 0x70u);   // my[b] over bits 3b..3b+2
-    const unsigned m9 = zrep & yexp;
-    const unsigned rep = m9 * 0x40201u;                                              // m9 at bits 0, 9, 18
-    const unsigned xexp = ((mx & 1u) * 0x1FFu) | ((mx & 2u) * (0x1FFu << 8)) | ((mx & 4u) * (0x1FFu << 16));
+    // Per axis the stencil of base cell r in 0..7 (tile coordinates, block origin at FREE_ZONE = 2) reaches the
+    // block offsets {-1,0}, {0}, {0,+1}, {+1} for r >> 1 = 0, 1, 2, 3: as 3-bit sets 3, 2, 6, 4.
+    static_assert(FREE_ZONE == 2, "the packed tables below are for a free zone of 2 cells");
+    const int ix = rx >> 1, iy = ry >> 1, iz = rz >> 1;
+    // bit (a * 9 + b * 3 + c) = mx[a] & my[b] & mz[c].  z set replicated at bits 0, 3, 6 and y set spread over
+    // bits 3b..3b+2, both 9 bits per table entry:
+    const unsigned long long Z = 0x926D924DBull, Y = 0xE07E0703Full;
+    const unsigned m9 = (unsigned)((Z >> (9 * iz)) & (Y >> (9 * iy))) & 0x1FFu;
+    const unsigned rep = m9 * 0x40201u;                       // m9 at bits 0, 9, 18
+    const int lo = (ix + 1) >> 1, hi = (ix >> 1) + 1;         // x offsets lo..hi
+    const unsigned xexp = ((1u << (9 * (hi + 1))) - 1u) ^ ((1u << (9 * lo)) - 1u);
     return rep & xexp;
 }
 
