@@ -197,8 +197,10 @@ MPM_DEV float quad_perm(float v) {
 // both exact because they are parts of the same 24-bit mantissa (doing this on the SIGNED value
 // would form 2^32 - |q| for small negative q, which does not fit a float: +-128 quanta of noise).
 // Below 2^24 quanta q has fractional bits: they are rounded to nearest even, so the conversion is
-// unbiased whatever the particle count.  Returns false when |q| does not fit 62 bits.
-MPM_DEV bool lds_add_fixed(long long* a, float v, float scale) {
+// unbiased whatever the particle count.  `worst` collects the bit pattern of the largest |q| (NaN and
+// infinity have the largest patterns of all): the caller compares it with 2^62 once, at the end -- a
+// boolean per call lives in a scalar register pair and costs scalar instructions in every loop.
+MPM_DEV void lds_add_fixed(long long* a, float v, float scale, unsigned& worst) {
     const float q = v * scale;
     const float aq = fabsf(q);
     const float h = floorf(aq * 0x1p-32f);
@@ -207,7 +209,7 @@ MPM_DEV bool lds_add_fixed(long long* a, float v, float scale) {
     const unsigned long long fx = q < 0.f ? 0ull - mag : mag;
     __hip_atomic_fetch_add(reinterpret_cast<unsigned long long*>(a), fx, __ATOMIC_RELAXED,
                            __HIP_MEMORY_SCOPE_WORKGROUP);
-    return aq < 0x1p62f;   // (false for NaN too)
+    worst = max(worst, __float_as_uint(aq));
 }
 
 // coefficients (c0 + c1 f + c2 f^2) of the quadratic B-spline weight of stencil offset a
@@ -222,7 +224,7 @@ struct Stencil {
     int rx, ry, rz;      // base cell relative to the tile origin (block origin - FREE_ZONE)
     float fx[3];
     float wx[3], wy[3], wz[3];
-    bool hard_out;       // base cell outside the tile (clamped): see MPM_ERR_DRIFT
+    unsigned out_bits;   // rx | ry | rz before the clamp: > TILE_W - 3 when the base cell is outside the tile (MPM_ERR_DRIFT)
 };
 
 MPM_DEV Stencil make_stencil(const DP& p, float x, float y, float z, int ox, int oy, int oz) {
@@ -238,7 +240,8 @@ MPM_DEV Stencil make_stencil(const DP& p, float x, float y, float z, int ox, int
     bspline3(s.fx[2], s.wz);
     int rx = (int)bx - ox, ry = (int)by - oy, rz = (int)bz - oz;
     const int hi_h = TILE_W - 3;
-    s.hard_out = rx < 0 || ry < 0 || rz < 0 || rx > hi_h || ry > hi_h || rz > hi_h;
+    static_assert(((TILE_W - 3) & (TILE_W - 2)) == 0, "rx | ry | rz <= hi_h is only equivalent to all three in range for hi_h = 2^k - 1");
+    s.out_bits = (unsigned)(rx | ry | rz);   // (a negative coordinate sets the high bits)
     rx = min(max(rx, 0), hi_h);
     ry = min(max(ry, 0), hi_h);
     rz = min(max(rz, 0), hi_h);
@@ -329,7 +332,8 @@ __global__ __launch_bounds__(512, 4) void k_p2g(DP p, float dt) {  // <= 128 VGP
         const int4 rg = make_int4(fb.x, fb.y, fb.z, 0);
         const int nfb = rg.y - rg.x;
         unsigned mymask = 0;
-        bool hard = false, in_range = true, halo_bad = false;
+        bool halo_bad = false;
+        unsigned out_worst = 0, fix_worst = 0;   // error conditions, collected as integers in vector registers
         // Every wave streams through its own groups of <= 64 particles; no workgroup barrier inside.
         // Groups are runs of whole cells (faces and vertices of the same cells together), laid out
         // at the last rebuild: a group usually spans two base cells.
@@ -410,7 +414,7 @@ __global__ __launch_bounds__(512, 4) void k_p2g(DP p, float dt) {  // <= 128 VGP
                     for (int k = 0; k < 12; ++k) Y[k] = 0.f;
                 }
             }
-            if (act) hard |= st.hard_out;
+            out_worst = max(out_worst, act ? st.out_bits : 0u);
             if (p.dist.on && act && own) {
                 // the stencil of an owned particle must stay inside the blocks the neighbour receives
                 const int gx = ox + st.rx;
@@ -523,7 +527,7 @@ __global__ __launch_bounds__(512, 4) void k_p2g(DP p, float dt) {  // <= 128 VGP
                     val = tt == 1 ? v[1] : val;
                     val = tt == 2 ? v[2] : val;
                     val = tt == 3 ? v[3] : val;
-                    if (delta[t] >= 0 && !(diag_flags(p) & 16)) in_range &= lds_add_fixed(tb + delta[t], val, fscale);
+                    if (delta[t] >= 0 && !(diag_flags(p) & 16)) lds_add_fixed(tb + delta[t], val, fscale, fix_worst);
                 }
                 if (prof) pc[3] += __builtin_readcyclecounter() - tq[2];
             }
@@ -541,8 +545,8 @@ __global__ __launch_bounds__(512, 4) void k_p2g(DP p, float dt) {  // <= 128 VGP
         if (prof && lane == 0)
             for (int q = 0; q < 8; ++q) atomicAdd(&p.dbgbuf[q], pc[q]);
         if (mymask && lane == 0) atomicOr(&s_mask, mymask);
-        if (__ballot(hard) && lane == 0) atomicOr(&ctl->error, ERR_DRIFT);
-        if (__ballot(!in_range) && lane == 0) atomicOr(&ctl->error, ERR_RANGE);
+        if (__ballot(out_worst > (unsigned)(TILE_W - 3)) && lane == 0) atomicOr(&ctl->error, ERR_DRIFT);
+        if (__ballot(fix_worst >= __float_as_uint(0x1p62f)) && lane == 0) atomicOr(&ctl->error, ERR_RANGE);
         if (p.dist.on && __ballot(halo_bad) && lane == 0) atomicOr(&ctl->error, ERR_HALO);
         __syncthreads();
         float4* out = p.slab + (size_t)item * TILE_N;
