@@ -467,7 +467,9 @@ def main():
                                    "measured in this run)",
                     algorithmic_bytes_per_launch=ab[dom], kernel_ms=phases[dom],
                     substep_achieved=job_bytes / (el / args.steps) / 1e9,
-                    substep_frac=job_bytes / (el / args.steps) / 1e9 / (HBM_PEAK_GBS * world), phase_ms=phases)
+                    substep_frac=job_bytes / (el / args.steps) / 1e9 / (HBM_PEAK_GBS * world), phase_ms=phases,
+                    phase_note="separate pass with HIP events around every phase (mpm_profile_substeps); it launches the "
+                               "re-sort kernels with every substep, the timed run with every fourth (gated substeps)")
 
     if rank == 0:
         if world == 1:
