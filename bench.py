@@ -32,7 +32,8 @@ KERNEL_OF = dict(fem="mpm::k_fem", vforce="mpm::k_vforce", p2g="mpm::k_p2g", gri
 
 def algorithmic_bytes(np_, nf, nv, ncells):
     """bytes one substep has to move, fp32, one pass per phase.
-    The reference's FEM kernel (200 B/face + 36 B/vertex) is two kernels here."""
+    The reference's FEM kernel (200 B/face + 36 B/vertex) is two kernels here (k_fem, and k_vforce or -- in
+    mpm_run_substeps -- the prologue of k_p2g's work items)."""
     fem = 200 * nf
     vforce = 36 * nv
     p2g = 116 * np_ + 16 * ncells
@@ -454,6 +455,11 @@ def main():
     ncells = 64 * st["touched_blocks"]
     # the particles this rank's kernels worked on (all of them unless the domain is partitioned)
     ab = algorithmic_bytes(st["active_faces"] + st["active_vertices"], st["active_faces"], st["active_vertices"], ncells)
+    if world == 1:
+        # mpm_run_substeps / mpm_profile_substeps: k_p2g also gathers the vertex forces of its work items (no
+        # k_vforce launch), so its algorithmic bytes are both rows of SURVEY 8(d)
+        ab["p2g"] += ab["vforce"]
+        ab["vforce"] = 0
     dom = max(KERNEL_OF, key=lambda k: phases[k])
     ach = ab[dom] / (phases[dom] * 1e-3) / 1e9
     # the whole job: every particle once per substep (strong: one copy; weak: one copy per rank)
@@ -469,7 +475,8 @@ def main():
                     substep_achieved=job_bytes / (el / args.steps) / 1e9,
                     substep_frac=job_bytes / (el / args.steps) / 1e9 / (HBM_PEAK_GBS * world), phase_ms=phases,
                     phase_note="separate pass with HIP events around every phase (mpm_profile_substeps); it launches the "
-                               "re-sort kernels with every substep, the timed run with every fourth (gated substeps)")
+                               "re-sort kernels with every substep, the timed run with every fourth (gated substeps); "
+                               "one GPU: the vertex-force phase is empty, k_p2g does that work per work item")
 
     if rank == 0:
         if world == 1:

@@ -870,8 +870,11 @@ static void launch_substep(mpm_engine* e, float dt, const GridColliders& gc, boo
     } else {
         e->maybe_owed = true;
     }
-    launch_fem(e, dt);
+    // (the vertex forces are computed by k_p2g, per work item: no k_vforce launch)
+    launch_fem_faces(e, dt);
+    e->dp.fuse_vforce = 1;
     launch_p2g(e, dt);
+    e->dp.fuse_vforce = 0;
     launch_grid(e, gc);
     launch_g2p(e, dt);
 }
@@ -941,9 +944,11 @@ int mpm_profile_substeps(mpm_handle_t e, int n, float dt, int bc, float* phase_m
         HIP_TRY(hipEventRecord(q[1], e->stream));
         launch_fem_faces(e, dt);
         HIP_TRY(hipEventRecord(q[2], e->stream));
-        launch_fem_vertices(e);
+        // (as in mpm_run_substeps: the vertex forces are part of k_p2g; this phase is empty)
         HIP_TRY(hipEventRecord(q[3], e->stream));
+        e->dp.fuse_vforce = 1;
         launch_p2g(e, dt);
+        e->dp.fuse_vforce = 0;
         HIP_TRY(hipEventRecord(q[4], e->stream));
         launch_grid(e, gc);
         HIP_TRY(hipEventRecord(q[5], e->stream));

@@ -103,13 +103,10 @@ __global__ __launch_bounds__(256) void k_fem(DP p, float dt) {
 // ascending original face id (the order sequential atomics would produce).  The adjacency is
 // kept per vertex slot (refreshed at every rebuild) so that a vertex needs one coalesced index
 // load and one 16-byte gather per adjacent face.
-__global__ __launch_bounds__(256) void k_vforce(DP p) {
-    if (gated_out(p)) return;
-    const int k = (int)(xcd_chunk(blockIdx.x, gridDim.x) * 256 + threadIdx.x);
-    if (k >= p.ctl->nva) return;
+// the force on vertex `k` (slot p.Nf + k) from the corner records of its adjacent faces, written to p.f
+MPM_DEV void vertex_force(const DP& p, const PSet& S, int k) {
     const int s = p.Nf + k;
     float f0 = 0.f, f1 = 0.f, f2 = 0.f;
-    const PSet& S = p.set[p.ctl->cur];
     const int4 r0 = S.va[0][k], r1 = S.va[1][k];
     const int rec[8] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w};
     if (p.dist.on) {
@@ -152,6 +149,15 @@ __global__ __launch_bounds__(256) void k_vforce(DP p) {
     p.f[0][s] = f0;
     p.f[1][s] = f1;
     p.f[2][s] = f2;
+}
+
+// (the phase-by-phase API and the partitioned-domain chains; mpm_run_substeps lets k_p2g do this per work
+// item, see DP::fuse_vforce)
+__global__ __launch_bounds__(256) void k_vforce(DP p) {
+    if (gated_out(p)) return;
+    const int k = (int)(xcd_chunk(blockIdx.x, gridDim.x) * 256 + threadIdx.x);
+    if (k >= p.ctl->nva) return;
+    vertex_force(p, p.set[p.ctl->cur], k);
 }
 
 // ---------------------------------------------------------------------------
@@ -325,6 +331,13 @@ __global__ __launch_bounds__(512, 4) void k_p2g(DP p, float dt) {  // <= 128 VGP
         const unsigned long long tb0 = (diag_flags(p) & 4) ? __builtin_readcyclecounter() : 0ull;
         for (int n = tid; n < TILE_N * 4; n += 512) tile[n] = 0;
         if (tid == 0) s_mask = 0;
+        if (p.fuse_vforce) {
+            // the vertex forces of this item (k_vforce's job: one launch less per substep; the forces still go
+            // through p.f, written and read back by this workgroup -- the barrier below orders the two)
+            const int4* gq = p.home_groups + fb.w;
+            const int v0 = gq[0].z, v1 = gq[fa.w - 1].w;   // the item's vertex slots
+            for (int sv = v0 + tid; sv < v1; sv += 512) vertex_force(p, S, sv - p.Nf);
+        }
         __syncthreads();
         int bx, by, bz;
         block_coords((uint32_t)fa.z, bx, by, bz);
