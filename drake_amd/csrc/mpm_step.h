@@ -331,7 +331,7 @@ __global__ __launch_bounds__(512, 4) void k_p2g(DP p, float dt) {  // <= 128 VGP
         const unsigned long long tb0 = (diag_flags(p) & 4) ? __builtin_readcyclecounter() : 0ull;
         for (int n = tid; n < TILE_N * 4; n += 512) tile[n] = 0;
         if (tid == 0) s_mask = 0;
-        if (p.fuse_vforce) {
+        if (p.fuse_vforce && fa.w > 0) {
             // the vertex forces of this item (k_vforce's job: one launch less per substep; the forces still go
             // through p.f, written and read back by this workgroup -- the barrier below orders the two)
             const int4* gq = p.home_groups + fb.w;
