@@ -165,6 +165,15 @@ static void launch_p2g(mpm_engine* e, float dt) {
     hipLaunchKernelGGL(k_p2g, dim3(e->g_tile), dim3(512), 0, e->stream, e->dp, dt);
     e->last_tile_kernel = 1;
 }
+// FEM faces, then P2G with the vertex forces of every work item computed inside it (no k_vforce launch): the
+// batched substeps use this; the phase-by-phase calls keep the two FEM kernels, whose forces a caller may read
+static void launch_fem_p2g(mpm_engine* e, float dt) {
+    e->last_dt = dt;
+    launch_fem_faces(e, dt);
+    e->dp.fuse_vforce = 1;
+    launch_p2g(e, dt);
+    e->dp.fuse_vforce = 0;
+}
 // (`p` may carry a halo class restriction)
 static void launch_g2p_with(mpm_engine* e, DP p, float dt) {
     hipLaunchKernelGGL(k_g2p, dim3(std::min(768u, p.capI)), dim3(G2P_THREADS), 0, e->stream, p, dt);
@@ -591,8 +600,7 @@ int mpm_update_grid_from_sums(mpm_handle_t e, int bc) {
 int mpm_substep_begin(mpm_handle_t e, float dt) {
     READY(e);
     launch_rebuild(e);
-    launch_fem(e, dt);
-    launch_p2g(e, dt);
+    launch_fem_p2g(e, dt);
     hipLaunchKernelGGL(k_grid<0>, dim3(e->g_grid), dim3(256), 0, e->stream, e->dp, GridColliders{});
     e->grid_state = 3;
     return 0;
@@ -652,8 +660,7 @@ int mpm_substep_begin_halo(mpm_handle_t e, float dt, int n, const int* bx_lo, co
     }
     auto body = [&]() {
         launch_rebuild(e);
-        launch_fem(e, dt);
-        launch_p2g(e, dt);
+        launch_fem_p2g(e, dt);
         hipLaunchKernelGGL(k_grid<0>, dim3(e->g_grid), dim3(256), 0, e->stream, p, GridColliders{});
         if (n > 0)
             hipLaunchKernelGGL(k_halo_pack2, dim3(e->g_grid, n), dim3(256), 0, e->stream, e->dp, z, (unsigned)cap);
@@ -870,11 +877,7 @@ static void launch_substep(mpm_engine* e, float dt, const GridColliders& gc, boo
     } else {
         e->maybe_owed = true;
     }
-    // (the vertex forces are computed by k_p2g, per work item: no k_vforce launch)
-    launch_fem_faces(e, dt);
-    e->dp.fuse_vforce = 1;
-    launch_p2g(e, dt);
-    e->dp.fuse_vforce = 0;
+    launch_fem_p2g(e, dt);
     launch_grid(e, gc);
     launch_g2p(e, dt);
 }
