@@ -109,6 +109,7 @@ struct DP {
     int item_groups;       // a work item holds at most this many 64-particle wave groups
     int dbg;               // MPM_DBG environment variable (kernel ablation switches, 0 in production)
     float dx, dxinv, Dinv;
+    unsigned q_stride, f_stride;   // distance (elements) between the planes PSet::q[0..3] and f[0..2] (one allocation each)
     int fuse_vforce;       // 1: k_p2g computes the vertex forces of its work items itself (no k_vforce launch)
     int gated;             // 1: this substep was enqueued without the re-sort launches (see Ctl::skipped)
     float anticip;         // re-sort: cells a particle is binned ahead per unit of velocity (0 = by position), see k_rb_count

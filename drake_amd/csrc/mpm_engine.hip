@@ -248,20 +248,33 @@ int mpm_finalize(mpm_handle_t e) {
 
     // ---- device buffers ---------------------------------------------------
     int rc = 0;
+    p.q_stride = (unsigned)((np + 63) & ~(size_t)63);
+    p.f_stride = (unsigned)((np + 63) & ~(size_t)63);
 #define ALLOC(ptr, n, zero)                         \
     if ((rc = e->dalloc(&(ptr), (n), (zero)))) return rc
     ALLOC(p.ctl, 1, true);
     ALLOC(p.dbgbuf, 16, true);
     for (int s = 0; s < 2; ++s) {
         PSet& S = p.set[s];
-        for (int d = 0; d < 4; ++d) { ALLOC(S.q[d], np, true); ALLOC(S.fq[d], nf, true); }
+        // (the four particle planes in one allocation, q_stride apart: k_p2g addresses them from ONE base
+        // pointer -- it runs out of scalar registers otherwise)
+        {
+            float4* base = nullptr;
+            ALLOC(base, 4 * (size_t)p.q_stride, true);
+            for (int d = 0; d < 4; ++d) S.q[d] = base + (size_t)d * p.q_stride;
+        }
+        for (int d = 0; d < 4; ++d) ALLOC(S.fq[d], nf, true);
         ALLOC(S.pid, np, true);
         for (int d = 0; d < 2; ++d) ALLOC(S.va[d], nv, true);
     }
     ALLOC(p.ab0, nf, true);
     ALLOC(p.ab1, nf, true);
     ALLOC(p.G3, 3 * nf, true);
-    for (int d = 0; d < 3; ++d) ALLOC(p.f[d], np, true);
+    {
+        float* base = nullptr;
+        ALLOC(base, 3 * (size_t)p.f_stride, true);
+        for (int d = 0; d < 3; ++d) p.f[d] = base + (size_t)d * p.f_stride;
+    }
     int* idx_orig[3];
     int *adj_off, *adj_fc;
     for (int d = 0; d < 3; ++d) { ALLOC(idx_orig[d], nf, false); p.idx_orig[d] = idx_orig[d]; }

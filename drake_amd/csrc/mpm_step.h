@@ -367,7 +367,9 @@ __global__ __launch_bounds__(512, 4) void k_p2g(DP p, float dt) {  // <= 128 VGP
             r.is_face = lane < gf;
             // unsigned index: lets the loads use the scalar-base + 32-bit-offset addressing form
             const unsigned ii = (unsigned)(r.act ? (r.is_face ? gr.x + lane : gr.z + (lane - gf)) : (nfb ? rg.x : rg.z));
-            const float4 q0 = S.q[0][ii], q1 = S.q[1][ii], q2 = S.q[2][ii], q3 = S.q[3][ii];
+            // (one base pointer and a stride for the four planes: see DP::q_stride)
+            const float4* qb = S.q[0] + ii;
+            const float4 q0 = qb[0], q1 = qb[p.q_stride], q2 = qb[2 * (size_t)p.q_stride], q3 = qb[3 * (size_t)p.q_stride];
             r.x[0] = q0.x; r.x[1] = q0.y; r.x[2] = q0.z; r.vol = q0.w;
             r.v[0] = q1.x; r.v[1] = q1.y; r.v[2] = q1.z;
             unpack_C(q1, q2, q3, r.C);
@@ -378,8 +380,9 @@ __global__ __launch_bounds__(512, 4) void k_p2g(DP p, float dt) {  // <= 128 VGP
                 const float2 b = p.ab1[ii];
                 r.ta[0] = a.x; r.ta[1] = a.y; r.ta[2] = a.z; r.tb[0] = a.w; r.tb[1] = b.x; r.tb[2] = b.y;
             } else {
+                const float* fbase = p.f[0] + ii;
 #pragma unroll
-                for (int d = 0; d < 3; ++d) r.frc[d] = p.f[d][ii];
+                for (int d = 0; d < 3; ++d) r.frc[d] = fbase[(size_t)d * p.f_stride];
             }
             return r;
         };
