@@ -363,19 +363,40 @@ __global__ __launch_bounds__(256) void k_ct_prepare(DP p, ContactDev c) {
     for (int d = 0; d < 3; ++d) c.cfx[d * c.n + j] = c.pos[k * 3 + d] * p.dxinv - (float)b[d];
     const uint32_t slot = c.slot[k];
     c.cmass[j] = fabsf(S.q[0][slot].w) * p.M.density;
+    // The 27 stencil cells lie in at most 2 x 2 x 2 blocks: 8 block look-ups (Morton spread + table) instead
+    // of 27.  (A contact whose base cell lies outside the active grid cannot be found by the nodes' run
+    // lookup: it is left out of the solve altogether; contact points at particle positions, which is what
+    // the driver produces, never are.)
+    {
+        const uint32_t bb[3] = {b[0] >> 2, b[1] >> 2, b[2] >> 2};
+        uint32_t sx[2], sy[2], sz[2];
 #pragma unroll
-    for (int i = 0; i < 3; ++i)
+        for (int h = 0; h < 2; ++h) {
+            const uint32_t last = (uint32_t)p.nb - 1u;   // (a neighbour beyond the grid is never selected below)
+            sx[h] = spread3(min(bb[0] + h, last)) * 4u;
+            sy[h] = spread3(min(bb[1] + h, last)) * 2u;
+            sz[h] = spread3(min(bb[2] + h, last));
+        }
+        int act[8];
 #pragma unroll
-        for (int jj = 0; jj < 3; ++jj)
+        for (int q = 0; q < 8; ++q) act[q] = p.lut_act[sx[q >> 2] + sy[(q >> 1) & 1] + sz[q & 1]];
 #pragma unroll
-            for (int l = 0; l < 3; ++l) {
-                // (a contact whose base cell lies outside the active grid cannot be found by the
-                // nodes' run lookup: it is left out of the solve altogether; contact points at
-                // particle positions, which is what the driver produces, never are)
-                const int g = key != CT_NO_CELL ? compact_cell(p, b[0] + i, b[1] + jj, b[2] + l) : -1;
-                c.cnode[(i * 9 + jj * 3 + l) * c.n + j] = g;
-                if (g >= 0) c.node_flag[g] = 1;
-            }
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int jj = 0; jj < 3; ++jj)
+#pragma unroll
+                for (int l = 0; l < 3; ++l) {
+                    const uint32_t x = b[0] + i, y = b[1] + jj, z = b[2] + l;
+                    const int hx = (int)((x >> 2) - bb[0]), hy = (int)((y >> 2) - bb[1]), hz = (int)((z >> 2) - bb[2]);
+                    const int q = hx * 4 + hy * 2 + hz;
+                    int a = act[0];
+#pragma unroll
+                    for (int t = 1; t < 8; ++t) a = q == t ? act[t] : a;
+                    const int g = (key == CT_NO_CELL || a < 0) ? -1 : a * 64 + (int)(((x & 3u) << 4) | ((y & 3u) << 2) | (z & 3u));
+                    c.cnode[(i * 9 + jj * 3 + l) * c.n + j] = g;
+                    if (g >= 0) c.node_flag[g] = 1;
+                }
+    }
     const float nh[3] = {-c.normal[k * 3], -c.normal[k * 3 + 1], -c.normal[k * 3 + 2]};
     float R[9];
     frame_from_normal(nh, R);
