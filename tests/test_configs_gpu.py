@@ -86,6 +86,30 @@ def test_plumbing_64k_full_size_against_the_oracle():
     assert np.array_equal(g.download(A.GRID_TOUCHED_FLAGS), o.g_flags)
 
 
+def test_cloth_1m_full_size_against_the_oracle():
+    """BASELINE config 2, the headline workload (999,952 particles, 128^3, dt = 1e-3): one substep phase by
+    phase against the oracle at full size (sort keys, F, tau, forces, grid masses / momenta / touched set,
+    v, v*, positions, velocities, C), then four batched substeps (mpm_run_substeps: gated re-sort launches,
+    vertex forces inside k_p2g) against the oracle's."""
+    from drake_amd import ARR as A, scenes
+    bits, layers, res = scenes.CONFIGS["cloth_1m"]
+    dt = 1e-3
+    o, g = build_pair(sheets=scenes.cloth_stack(layers, res, bits), domain_bits=bits)
+    assert o.n_particles == 999952 == g.n_particles
+    _phase_by_phase(o, g, -1, dt, 1, "1m ")
+    g.upload_particle_state(o.pos, o.vel, o.C, None, o.F)
+    g.run_substeps(4, dt, -1)
+    for _ in range(4):
+        o.substep(dt, -1)
+    g.gpu_sync()
+    assert g.stats()["error_flags"] == 0
+    sc = natural_scales(o, dt)
+    close(g.download(A.POSITIONS), o.pos, scale=1.0, what="1m traj pos")
+    # (free-running substeps of a stiff cloth amplify the per-step rounding differences: as for config 1)
+    close(g.download(A.VELOCITIES), o.vel, scale=sc["vel"], rtol=5e-5, what="1m traj vel")
+    close(g.download(A.DEFORMATION_GRADIENTS), o.F, scale=1.0, rtol=8e-5, what="1m traj F")
+
+
 def test_cloth_8m_on_256_grid_properties():
     """BASELINE config 4 at its full single-GPU size (8,036,544 particles, 256^3, dt = 2e-4), which the
     oracle is not run on: mass bookkeeping, free fall, momentum = mass * g * t, no error flags."""
