@@ -200,6 +200,67 @@ def test_single_newton_iteration_matches_oracle(exact, params, mu, scene):
     close(f_g, o.F_f, scale=float(np.abs(o.F_f).max()), rtol=10 * rt, what="1-iteration body impulse")
 
 
+def test_config3_full_size_against_the_oracle():
+    """BASELINE config 3 at its full size: the 1M-particle stack (999,952 particles, 128^3) with its lowest
+    sheets below a floor, the bagging demo's contact parameters (k = 1e6, d = 1e-5, mu = 1, dt = 2e-4).
+    One Newton iteration against the oracle at rounding level, then the converged solve."""
+    from drake_amd import ARR as A, scenes
+    from oracle import oracle as orc
+    stiffness, damping, DT = CONTACT_PARAMS["config3"]
+    bits, layers, res = scenes.CONFIGS["cloth_1m"]
+    sheets = scenes.cloth_stack(layers, res, bits, z0=Z_FLOOR - 0.006, vel_amp=0.2)
+    for pos, vel, idx in sheets:
+        vel[:, 2] -= 0.5
+        vel[:, 0] += 0.3
+    o, g = build_pair(sheets=sheets, domain_bits=bits)
+    assert g.n_particles == 999952
+
+    def prepare():
+        g.upload_particle_state(o.pos, o.vel, o.C, None, o.F)
+        for s in (o, g):
+            s.reallocate_external_bodies(1)
+            s.rebuild_mapping(False)
+            s.calc_fem_state_and_force(DT)
+            s.particle_to_grid(DT)
+            s.update_grid(-1)
+        cp = floor_contacts(g.sync_particle_state_to_cpu())
+        o.copy_contact_pairs(orc.ContactPairs(*cp))
+        g.copy_contact_pairs(*cp)
+        return cp
+
+    cp = prepare()
+    assert cp[0].size > 50000
+    # one iteration: direction, its norm, energies, step
+    ro = o.update_contact(DT, 1.0, stiffness, damping, max_iters=1)
+    rg = g.update_contact(DT, 1.0, stiffness, damping, max_newton_iterations=1)
+    cs = g.contact_stats()
+    assert ro["iterations"] == rg["iterations"] == 1 and cs["dofs"] == ro["dofs"] > 10000
+    close(g.download(A.GRID_DIR), o.g_D, what="1m 1-iteration Dir")
+    # (global sums over ~2e4 nodes / 6e4 contacts: the oracle adds them in float like the reference's
+    # atomics, the engine in double -- the per-node direction above is the 1e-5 comparison)
+    close([cs["norm_dir_sq"]], [ro["norm_dir_sq"]], rtol=1e-4, what="1m 1-iteration |Dir|^2")
+    close([cs["E0"]], [ro["E0"]], rtol=1e-4, what="1m 1-iteration E(0)")
+    close([cs["energy"]], [ro["E1"]], scale=abs(ro["E0"]), rtol=1e-4, what="1m 1-iteration E(alpha)")
+    assert cs["alpha"] == ro["alpha"]
+    sc = natural_scales(o, DT)
+    wgt = (o.g_m / o.g_m.max())[:, None]
+    close(g.download(A.GRID_MOMENTUM) * wgt, o.g_mv * wgt, scale=sc["vel"], what="1m 1-iteration grid v")
+    # the converged solve from the same state
+    cp = prepare()
+    ro = o.update_contact(DT, 1.0, stiffness, damping, max_iters=600)
+    rg = g.update_contact(DT, 1.0, stiffness, damping, max_newton_iterations=600)
+    assert rg["residual"] <= 1e-4 and ro["residual"] <= 5e-3, (rg, ro)
+    stalled = max(1.0, ro["residual"] / 1e-4)
+    tol = solve_tolerance(g.contact_stats()["dofs"], iterations=max(rg["iterations"], ro["iterations"])) * stalled
+    close(g.download(A.CONTACT_VEL), o.c_vel, scale=1.0, rtol=tol, what="1m contact vel")
+    tau_g, f_g = g.external_body_force_to_host()
+    assert f_g[0, 2] < 0
+    close(f_g, o.F_f, scale=float(np.abs(o.F_f).max()), rtol=IMPULSE_RTOL * tol / solve_tolerance(g.contact_stats()["dofs"]),
+          what="1m body impulse")
+    g.gpu_sync()
+    assert g.stats()["error_flags"] == 0
+
+
 def test_backtracking_beyond_the_first_candidates_matches_oracle(monkeypatch):
     """The engine evaluates the step lengths 1, 1/2, 1/4, 1/8 in a first pass and the other 24 only when none
     of them is accepted (cuda_mpm_solver.cu:472-528 halves alpha one evaluation at a time).  With the Jacobi
