@@ -483,6 +483,7 @@ __global__ __launch_bounds__(512, 4) void k_p2g(DP p, float dt) {  // <= 128 VGP
                 nfx = sn[16]; nfy = sn[17]; nfz = sn[18]; ny = sn[j16];
             }
             if (prof) tq[1] = __builtin_readcyclecounter();
+            __builtin_amdgcn_s_setprio(2);   // (waves in the contraction keep the matrix pipe fed: ahead of waves that derive / group)
             while (todo) {
                 const int ckey = __builtin_amdgcn_readlane(key, __builtin_ctzll(todo));
                 const unsigned long long same = __ballot(key == ckey) & todo;
@@ -553,6 +554,7 @@ __global__ __launch_bounds__(512, 4) void k_p2g(DP p, float dt) {  // <= 128 VGP
                 pc[1] += te - tq[1];      // contraction phase
                 pc[6] += 1;
             }
+            __builtin_amdgcn_s_setprio(0);
             // the next group's staging writes must not overtake this group's reads
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
