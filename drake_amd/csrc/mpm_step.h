@@ -43,6 +43,7 @@ __global__ __launch_bounds__(256) void k_fem(DP p, float dt) {
     const float4 va = S.q[1][s0], vb = S.q[1][s1], vc = S.q[1][s2];
     float4 q0 = S.q[0][i], q1 = S.q[1][i];
     const float4 q2 = S.q[2][i], q3 = S.q[3][i];
+    __builtin_amdgcn_s_setprio(2);   // (a wave that has its data computes and stores ahead of waves still issuing loads)
     const float x0[3] = {xa.x, xa.y, xa.z}, x1[3] = {xb.x, xb.y, xb.z}, x2[3] = {xc.x, xc.y, xc.z};
     // the face particle sits at the centroid and moves with the mean velocity (:203-207);
     // vol (q0.w) and C8 (q1.w) ride along unchanged
