@@ -330,10 +330,10 @@ def main():
         active = g.stats()["active_blocks"]
         per_layer = active / float(hi - lo + 2) if active else 1e9   # (tables not built yet: keep the largest size)
         cap_blocks = 256
-        while cap_blocks < min(2048.0, 2.0 * (2 * zone) * per_layer):
+        while cap_blocks < min(8192.0, 2.0 * (2 * zone) * per_layer):
             cap_blocks *= 2
         chain_args = dict(cut_lo_block=cuts[rank], cut_hi_block=cuts[rank + 1], pitch_blocks=0, zone_blocks=zone,
-                          capacity_blocks=min(cap_blocks, 2048))
+                          capacity_blocks=min(cap_blocks, 8192))
         geometry["exchange_capacity_blocks"] = chain_args["capacity_blocks"]
         mig_cap = 65536
     else:
