@@ -26,20 +26,24 @@ def _stale() -> bool:
     return False
 
 
-def build(force: bool = False, verbose: bool = False, extra=()) -> str:
+def build(force: bool = False, verbose: bool = False, extra=(), out: str | None = None) -> str:
+    """`out`: write the library somewhere else (A/B variants of an experiment, loaded through
+    MPM_HIP_LIBRARY; the product is always drake_amd/libmpm_hip.so)."""
     if os.environ.get("MPM_DIAG_BUILD") == "1":
         extra = tuple(extra) + ("-DMPM_DIAG=1",)
         force = True
-    if not force and not _stale():
+    if out is None and os.environ.get("MPM_HIP_LIBRARY"):
+        return os.environ["MPM_HIP_LIBRARY"]   # an experiment's prebuilt variant (scratch/ab_build.py)
+    if out is None and not force and not _stale():
         return LIB
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     if not os.path.exists(hipcc):
         raise RuntimeError("hipcc not found: the HIP engine cannot be built (there is no CPU fallback)")
-    cmd = [hipcc, *FLAGS, *extra, "-o", LIB] + [os.path.join(CSRC, s) for s in SOURCES]
+    cmd = [hipcc, *FLAGS, *extra, "-o", out or LIB] + [os.path.join(CSRC, s) for s in SOURCES]
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     subprocess.check_call(cmd)
-    return LIB
+    return out or LIB
 
 
 if __name__ == "__main__":

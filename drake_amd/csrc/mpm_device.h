@@ -29,13 +29,21 @@ constexpr unsigned ERR_HALO = 16u;      // partitioned domain: a particle's sten
 //          (partitioned domain: vol > 0 owned, vol < 0 ghost copy of a neighbour's particle with
 //           volume |vol|, vol == 0 released: dropped by the next re-sort)
 //   q[2] = (C0, C1, C2, C3)    q[3] = (C4, C5, C6, C7)          C row-major, as in the reference
-// Face particles carry four more records, indexed by face slot:
-//   fq[0] = (F0..F3)  fq[1] = (F4..F7)  fq[2] = (F8, Dm0, Dm1, Dm2)
-//   fq[3] = (Dm3, v0, v1, v2)   v* = slots of the three corner vertices (int bits)
+// Face particles carry four more records and two scalars, indexed by face slot.  What CalcFemStateAndForce
+// rewrites every substep (F) is kept apart from what only a re-sort moves (Dm^-1, volume, corners), so
+// that k_fem reads and writes exactly the 36 bytes of F:
+//   fq[0] = (F0..F3)  fq[1] = (F4..F7)  f8 = F8                                  (written by k_fem)
+//   fq[2] = (Dm0, Dm1, Dm3, |vol|)   Dm^-1 of a QR cloth is upper triangular (cuda_mpm_kernels.cuh:13-70:
+//           Dm = R of a Givens QR), Dm^-1[2] is +-0 and not stored; |vol| is a copy of |q[0].w|
+//   fq[3] = (0, v0, v1, v2)   v* = slots of the three corner vertices (int bits)
+//   c8    = C8 of the face particle as GridToParticle left it: k_fem reads it here instead of fetching
+//           the 16-byte record q[1] for 4 useful bytes (q[1].w carries the same value for ParticleToGrid)
 struct PSet {
     float4* q[4];
     int* pid;      // slot -> original particle id ([faces | verts] order of Finalize)
     float4* fq[4];
+    float* f8;
+    float* c8;
     int4* va[2];   // vertex (slot - Nf) -> up to 8 (face slot * 3 + corner) records, -1 = none, -2 in [0].x = use the CSR
 };
 
@@ -112,6 +120,7 @@ struct DP {
     unsigned q_stride, f_stride;   // distance (elements) between the planes PSet::q[0..3] and f[0..2] (one allocation each)
     int fuse_vforce;       // 1: k_p2g computes the vertex forces of its work items itself (no k_vforce launch)
     int gated;             // 1: this substep was enqueued without the re-sort launches (see Ctl::skipped)
+    int lean_g2p;          // 1: k_g2p leaves q[1] of the face particles alone (see g2p_particle); per launch
     float anticip;         // re-sort: cells a particle is binned ahead per unit of velocity (0 = by position), see k_rb_count
     // fixed-point scales of the LDS tile accumulators (powers of two), see k_p2g
     double fix_m, fix_p, unfix_m, unfix_p;
@@ -157,6 +166,9 @@ struct DP {
     int4* item_flat;       // [position in item_order][2]: (item, home, home block id, groups), (first face slot, end face
                            // slot, first vertex slot, first group's index in home_groups) -- everything the tile kernels
                            // need to start an item in ONE load instead of a chain of four dependent ones
+    int4* item_rng;        // [position in item_order] the item's own slots: (first face, end face, first vertex, end vertex)
+                           // (from the wave groups, which k_rb_scatter lays out: written there, through item_pos)
+    uint32_t* item_pos;    // [item] position in item_order
     int2* home_items;      // [home] (first item, item count)
     int* act_nbr_items;    // [active][27] first item | count << 24 of the neighbour home block, or -1
     int* home_ngroups;     // [home] number of P2G wave groups

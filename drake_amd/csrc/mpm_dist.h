@@ -64,9 +64,11 @@ MPM_DEV void dist_emit(const DP& p, const PSet& S, unsigned slot, int gid, int r
     const bool face = slot < (unsigned)p.Nf;
     const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
     q0.w = fabsf(q0.w);
-    r[0] = make_float4(__int_as_float(gid), __int_as_float(role), face ? S.fq[2][slot].x : 0.f, 0.f);
+    r[0] = make_float4(__int_as_float(gid), __int_as_float(role), face ? S.f8[slot] : 0.f, 0.f);
     r[1] = q0;
-    r[2] = S.q[1][slot];
+    float4 q1 = S.q[1][slot];
+    if (face) q1.w = S.c8[slot];   // (the authoritative C8 of a face particle, see PSet)
+    r[2] = q1;
     r[3] = S.q[2][slot];
     r[4] = S.q[3][slot];
     r[5] = face ? S.fq[0][slot] : z;
@@ -151,11 +153,13 @@ __global__ __launch_bounds__(256) void k_dist_apply(DP p, const float4* recv, un
             p.imap[gid] = slot;
             if (face) {
                 const float4 dm = p.dm_orig[gid];
-                S.fq[2][slot] = make_float4(h.z, dm.x, dm.y, dm.z);
-                S.fq[3][slot] = make_float4(dm.w, __int_as_float(-1), __int_as_float(-1), __int_as_float(-1));
+                S.fq[2][slot] = make_float4(dm.x, dm.y, dm.w, fabsf(r[1].w));
+                S.fq[3][slot] = make_float4(0.f, __int_as_float(-1), __int_as_float(-1), __int_as_float(-1));
             }
-        } else if (face) {
-            S.fq[2][slot].x = h.z;
+        }
+        if (face) {
+            S.f8[slot] = h.z;
+            S.c8[slot] = r[2].w;
         }
         float4 q0 = r[1];
         q0.w = role == ROLE_OWNED ? q0.w : -q0.w;

@@ -65,6 +65,8 @@ int mpm_create(int domain_bits, const mpm_material_t* material, int device, mpm_
         return fail(MPM_ERR_HIP, std::string("mpm_create: ") + hipGetErrorString(err));
     }
     e->stream = e->own_stream;
+    if (getenv("MPM_RESORT_EVERY")) e->check_every = std::max(1, atoi(getenv("MPM_RESORT_EVERY")));
+    if (getenv("MPM_GRAPH")) e->graph_len = std::max(0, atoi(getenv("MPM_GRAPH")));
     *out = e;
     return 0;
 }
@@ -264,6 +266,8 @@ int mpm_finalize(mpm_handle_t e) {
             for (int d = 0; d < 4; ++d) S.q[d] = base + (size_t)d * p.q_stride;
         }
         for (int d = 0; d < 4; ++d) ALLOC(S.fq[d], nf, true);
+        ALLOC(S.f8, nf, true);
+        ALLOC(S.c8, nf, true);
         ALLOC(S.pid, np, true);
         for (int d = 0; d < 2; ++d) ALLOC(S.va[d], nv, true);
     }
@@ -303,6 +307,8 @@ int mpm_finalize(mpm_handle_t e) {
     ALLOC(p.item_desc, p.capI, true);
     ALLOC(p.item_order, p.capI, true);
     ALLOC(p.item_flat, (size_t)p.capI * 2, true);
+    ALLOC(p.item_rng, p.capI, true);
+    ALLOC(p.item_pos, p.capI, true);
     ALLOC(p.home_items, p.capH, true);
     ALLOC(p.act_nbr_items, (size_t)p.capA * 27, true);
     ALLOC(p.home_ngroups, p.capH, true);
@@ -505,7 +511,7 @@ int mpm_sync(mpm_handle_t e) {
 }
 
 // ---- the solver calls -----------------------------------------------------
-static void launch_substep(mpm_engine* e, float dt, const GridColliders& gc, bool allow_gate);
+static void launch_substep(mpm_engine* e, float dt, const GridColliders& gc, bool allow_gate, bool lean = false);
 
 // Substeps that mpm_run_substeps enqueued without their re-sort launches and that found a re-sort pending
 // did nothing (Ctl::skipped): run them now, each with the re-sort in front.  Called by every entry point
@@ -878,7 +884,8 @@ int mpm_grid_to_particle(mpm_handle_t e, float dt) {
 int mpm_substep(mpm_handle_t e, float dt, int bc) { return mpm_run_substeps(e, 1, dt, bc); }
 
 // allow_gate: the substep may go without the re-sort launches (mpm_run_substeps outside graphs)
-static void launch_substep(mpm_engine* e, float dt, const GridColliders& gc, bool allow_gate) {
+// lean: another substep follows in the same batch, GridToParticle need not refresh what only a download reads
+static void launch_substep(mpm_engine* e, float dt, const GridColliders& gc, bool allow_gate, bool lean) {
     e->last_dt = dt;
     const bool check = !allow_gate || e->force_check || e->check_every <= 1 || e->dp.dist.on ||
                        (e->step_phase % (unsigned)e->check_every) == 0u;
@@ -892,7 +899,9 @@ static void launch_substep(mpm_engine* e, float dt, const GridColliders& gc, boo
     }
     launch_fem_p2g(e, dt);
     launch_grid(e, gc);
+    e->dp.lean_g2p = lean && !e->dp.dist.on;
     launch_g2p(e, dt);
+    e->dp.lean_g2p = 0;
 }
 
 // A substep is nine dependent kernels with constant arguments and no host decisions (the re-sort
@@ -919,8 +928,6 @@ static int step_graph_for(mpm_engine* e, float dt, int bc, const GridColliders& 
 
 int mpm_run_substeps(mpm_handle_t e, int n, float dt, int bc) {
     READY_NO_SETTLE(e);
-    static const int resort_every = getenv("MPM_RESORT_EVERY") ? atoi(getenv("MPM_RESORT_EVERY")) : 4;
-    e->check_every = resort_every;
     // owed substeps are run with the parameters they were enqueued with: settle before these change
     if (e->maybe_owed && (dt != e->owed_dt || bc != e->owed_bc || e->grid_colliders_version != e->owed_gcv))
         if (int rc = settle(e)) return rc;
@@ -929,7 +936,7 @@ int mpm_run_substeps(mpm_handle_t e, int n, float dt, int bc) {
     e->owed_gcv = e->grid_colliders_version;
     // MPM_GRAPH=<substeps per graph> replays captured graphs; measured slower than plain stream
     // dispatch on ROCm 7.2, hence opt-in
-    static const int graph_len = getenv("MPM_GRAPH") ? atoi(getenv("MPM_GRAPH")) : 0;
+    const int graph_len = e->graph_len;
     GridColliders gc;
     if (int rc = grid_colliders_for(e, bc, &gc)) return rc;
     int s = 0;
@@ -938,7 +945,7 @@ int mpm_run_substeps(mpm_handle_t e, int n, float dt, int bc) {
         if (int rc = step_graph_for(e, dt, bc, gc)) return rc;
         for (; s + graph_len <= n; s += graph_len) HIP_TRY(hipGraphLaunch(e->step_graph, e->stream));
     }
-    for (; s < n; ++s) launch_substep(e, dt, gc, true);
+    for (; s < n; ++s) launch_substep(e, dt, gc, true, s + 1 < n);
     e->grid_state = 2;
     e->substeps += (uint64_t)std::max(n, 0);
     HIP_TRY(hipGetLastError());
@@ -968,7 +975,9 @@ int mpm_profile_substeps(mpm_handle_t e, int n, float dt, int bc, float* phase_m
         HIP_TRY(hipEventRecord(q[4], e->stream));
         launch_grid(e, gc);
         HIP_TRY(hipEventRecord(q[5], e->stream));
+        e->dp.lean_g2p = s + 1 < n && !e->dp.dist.on;   // (as in mpm_run_substeps)
         launch_g2p(e, dt);
+        e->dp.lean_g2p = 0;
         HIP_TRY(hipEventRecord(q[6], e->stream));
     }
     e->grid_state = 2;

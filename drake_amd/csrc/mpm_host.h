@@ -53,7 +53,10 @@ struct mpm_engine {
     int* d_sort_hist = nullptr;
     float last_dt = 0.f;   // length of the last substep (anticipatory binning of the re-sort)
     // gated substeps of mpm_run_substeps (see gated_out in mpm_step.h)
-    int check_every = 4;       // the re-sort launches precede every check_every-th substep (MPM_RESORT_EVERY; 1 = all)
+    // the re-sort launches precede every check_every-th substep of mpm_run_substeps (1 = all); read from
+    // MPM_RESORT_EVERY when the engine is created, like graph_len (MPM_GRAPH): per handle, not per process
+    int check_every = 4;
+    int graph_len = 0;         // > 0: mpm_run_substeps replays captured graphs of this many substeps
     unsigned step_phase = 0;
     bool force_check = true;   // the next substep gets them whatever its number (after any other call)
     bool maybe_owed = false;   // gated substeps were enqueued since the last settle()

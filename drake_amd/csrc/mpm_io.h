@@ -37,8 +37,10 @@ __global__ __launch_bounds__(256) void k_init_faces(DP p) {
     S.q[1][i] = make_float4((va.x + vb.x + vc.x) / 3.f, (va.y + vb.y + vc.y) / 3.f, (va.z + vb.z + vc.z) / 3.f, 0.f);
     S.fq[0][i] = make_float4(Q[0], Q[1], Q[2], Q[3]);
     S.fq[1][i] = make_float4(Q[4], Q[5], Q[6], Q[7]);
-    S.fq[2][i] = make_float4(Q[8], Di[0], Di[1], Di[2]);
-    S.fq[3][i] = make_float4(Di[3], f3.y, f3.z, f3.w);
+    S.f8[i] = Q[8];
+    S.c8[i] = 0.f;
+    S.fq[2][i] = make_float4(Di[0], Di[1], Di[3], v4);   // (Di[2] = -0 / det: Dm is upper triangular)
+    S.fq[3][i] = make_float4(0.f, f3.y, f3.z, f3.w);
     const_cast<float4*>(p.dm_orig)[i] = make_float4(Di[0], Di[1], Di[2], Di[3]);
     p.G3[(size_t)i * 3].x = v4;
 }
@@ -98,28 +100,32 @@ MPM_DEV void read_field(const DP& p, const PSet& S, int j, float* o) {
     if (FIELD == F_DEFGRAD) {
         const float4 a = S.fq[0][j], b = S.fq[1][j];
         o[0] = a.x; o[1] = a.y; o[2] = a.z; o[3] = a.w; o[4] = b.x; o[5] = b.y; o[6] = b.z; o[7] = b.w;
-        o[8] = S.fq[2][j].x;
+        o[8] = S.f8[j];
     }
-    if (FIELD == F_DMINV) {
-        const float4 c = S.fq[2][j];
-        o[0] = c.y; o[1] = c.z; o[2] = c.w; o[3] = S.fq[3][j].x;
+    if (FIELD == F_DMINV) {   // as Finalize computed it, entry [2] (a signed zero) included
+        const float4 c = p.dm_orig[S.pid[j]];
+        o[0] = c.x; o[1] = c.y; o[2] = c.z; o[3] = c.w;
     }
 }
 
 template <int FIELD>
-MPM_DEV void write_field(const PSet& S, int j, const float* v) {
+MPM_DEV void write_field(const DP& p, const PSet& S, int j, const float* v) {
     if (FIELD == F_POS) { float4 q = S.q[0][j]; q.x = v[0]; q.y = v[1]; q.z = v[2]; S.q[0][j] = q; }
     if (FIELD == F_VEL) { float4 q = S.q[1][j]; q.x = v[0]; q.y = v[1]; q.z = v[2]; S.q[1][j] = q; }
-    if (FIELD == F_VOL) S.q[0][j].w = S.q[0][j].w < 0.f ? -v[0] : v[0];
+    if (FIELD == F_VOL) {
+        S.q[0][j].w = S.q[0][j].w < 0.f ? -v[0] : v[0];
+        if (j < p.Nf) S.fq[2][j].w = fabsf(v[0]);   // (the copy k_fem reads)
+    }
     if (FIELD == F_AFFINE) {
         S.q[2][j] = make_float4(v[0], v[1], v[2], v[3]);
         S.q[3][j] = make_float4(v[4], v[5], v[6], v[7]);
         S.q[1][j].w = v[8];
+        if (j < p.Nf) S.c8[j] = v[8];
     }
     if (FIELD == F_DEFGRAD) {
         S.fq[0][j] = make_float4(v[0], v[1], v[2], v[3]);
         S.fq[1][j] = make_float4(v[4], v[5], v[6], v[7]);
-        S.fq[2][j].x = v[8];
+        S.f8[j] = v[8];
     }
 }
 
@@ -153,7 +159,7 @@ __global__ __launch_bounds__(256) void k_scatter_field(DP p, const float* in, in
 #pragma unroll
     for (int c = 0; c < N; ++c) v[c] = in[(size_t)s * N + c];
     const int j = p.imap[order[s]];
-    if (j >= 0) write_field<FIELD>(S, j, v);
+    if (j >= 0) write_field<FIELD>(p, S, j, v);
 }
 
 // taus()[slot] = a (x) b for face particles, zero for vertices

@@ -325,6 +325,7 @@ __global__ __launch_bounds__(1024) void k_rb_tables(DP p) {
         // the same, flattened in processing order (see DP::item_flat)
         for (unsigned q = tid; q < n_items; q += 1024) {
             const unsigned w = p.item_order[q];
+            p.item_pos[w] = q;
             const int4 d = p.item_desc[w];
             const unsigned h = (unsigned)d.x;
             const int4 rg = p.home_range[h];
@@ -401,6 +402,18 @@ __global__ __launch_bounds__(256) void k_rb_scatter(DP p) {
                     out[g] = make_int4(rg.x + f0, rg.x + f1, rg.z + v0, rg.z + v1);
                 }
                 if (lane == 0) p.home_ngroups[h] = ng;
+                // the slot ranges of the block's work items (what the tile kernels would otherwise fetch from the
+                // first and the last group of the item, behind one more dependent load)
+                const int2 hi = p.home_items[h];
+                for (int k = (int)lane; k < hi.y; k += 64) {
+                    const unsigned it = (unsigned)(hi.x + k);
+                    if (it >= p.ctl->n_items) continue;   // (slab pool exhausted: the item is not scheduled)
+                    const int4 d = p.item_desc[it];
+                    int f0, v0, f1, v1;
+                    split(d.y * 64, f0, v0);
+                    split(d.z * 64, f1, v1);
+                    p.item_rng[p.item_pos[it]] = make_int4(rg.x + f0, rg.x + f1, rg.z + v0, rg.z + v1);
+                }
             }
         }
     }
@@ -499,6 +512,8 @@ __global__ __launch_bounds__(256) void k_rb_finish(DP p) {
                 b3.w = __int_as_float(p.imap[p.idx_orig[2][pid]]);
             }
             D.fq[0][j] = b0; D.fq[1][j] = b1; D.fq[2][j] = b2; D.fq[3][j] = b3;
+            D.f8[j] = S.f8[i];
+            D.c8[j] = S.c8[i];
         } else if (!p.dist.on) {
             int4 r0 = S.va[0][i - p.Nf], r1 = S.va[1][i - p.Nf];
             if (r0.x != -2) {

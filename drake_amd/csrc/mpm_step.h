@@ -24,7 +24,11 @@ __global__ __launch_bounds__(256) void k_fem(DP p, float dt) {
     const unsigned i = xcd_chunk(blockIdx.x, gridDim.x) * 256 + threadIdx.x;
     if (i >= (unsigned)p.ctl->nfa) return;
     const PSet& S = p.set[p.ctl->cur];
+    // 104 bytes in (F 36, Dm^-1 | vol | corners 32, C 36) + the corner gathers; 128 bytes out (F 36, face x v 32,
+    // tau factors 24, corner forces 36).  The face particle's own q[0] / q[1] are written, never read: its
+    // volume comes from the static record, C8 from the c8 plane (see PSet).
     const float4 f0 = S.fq[0][i], f1 = S.fq[1][i], f2 = S.fq[2][i], f3 = S.fq[3][i];
+    const float F8 = S.f8[i], C8 = S.c8[i];
     const unsigned s0 = (unsigned)__float_as_int(f3.y), s1 = (unsigned)__float_as_int(f3.z),
                    s2 = (unsigned)__float_as_int(f3.w);
     if (p.dist.on && (int)(s0 | s1 | s2) < 0) {
@@ -41,21 +45,20 @@ __global__ __launch_bounds__(256) void k_fem(DP p, float dt) {
     }
     const float4 xa = S.q[0][s0], xb = S.q[0][s1], xc = S.q[0][s2];
     const float4 va = S.q[1][s0], vb = S.q[1][s1], vc = S.q[1][s2];
-    float4 q0 = S.q[0][i], q1 = S.q[1][i];
     const float4 q2 = S.q[2][i], q3 = S.q[3][i];
+    // partitioned domain: the sign of q[0].w is the particle's role (ghost copies are negative) and changes
+    // with migration; a single-domain engine never looks at the face particle's own record
+    const float volw = p.dist.on ? S.q[0][i].w : f2.w;
     __builtin_amdgcn_s_setprio(2);   // (a wave that has its data computes and stores ahead of waves still issuing loads)
     const float x0[3] = {xa.x, xa.y, xa.z}, x1[3] = {xb.x, xb.y, xb.z}, x2[3] = {xc.x, xc.y, xc.z};
     // the face particle sits at the centroid and moves with the mean velocity (:203-207);
-    // vol (q0.w) and C8 (q1.w) ride along unchanged
-    q0.x = (xa.x + xb.x + xc.x) / 3.f; q0.y = (xa.y + xb.y + xc.y) / 3.f; q0.z = (xa.z + xb.z + xc.z) / 3.f;
-    q1.x = (va.x + vb.x + vc.x) / 3.f; q1.y = (va.y + vb.y + vc.y) / 3.f; q1.z = (va.z + vb.z + vc.z) / 3.f;
-    S.q[0][i] = q0;
-    S.q[1][i] = q1;
-    const float F[9] = {f0.x, f0.y, f0.z, f0.w, f1.x, f1.y, f1.z, f1.w, f2.x};
-    const float Dm[4] = {f2.y, f2.z, f2.w, f3.x};
-    float C[9];
-    unpack_C(q1, q2, q3, C);
-    const float vol = fabsf(q0.w);   // (the sign marks ghost copies in a partitioned domain)
+    // vol and C8 ride along unchanged
+    S.q[0][i] = make_float4((xa.x + xb.x + xc.x) / 3.f, (xa.y + xb.y + xc.y) / 3.f, (xa.z + xb.z + xc.z) / 3.f, volw);
+    S.q[1][i] = make_float4((va.x + vb.x + vc.x) / 3.f, (va.y + vb.y + vc.y) / 3.f, (va.z + vb.z + vc.z) / 3.f, C8);
+    const float F[9] = {f0.x, f0.y, f0.z, f0.w, f1.x, f1.y, f1.z, f1.w, F8};
+    const float Dm0 = f2.x, Dm1 = f2.y, Dm3 = f2.z;   // Dm^-1 = [Dm0 Dm1; 0 Dm3]
+    const float C[9] = {q2.x, q2.y, q2.z, q2.w, q3.x, q3.y, q3.z, q3.w, C8};
+    const float vol = f2.w;
 
     // normal column evolves with the affine velocity field (:216-226)
     float cF[9];
@@ -66,16 +69,16 @@ __global__ __launch_bounds__(256) void k_fem(DP p, float dt) {
     cF[6] = F[6]; cF[7] = F[7];
     cF[8] = dt * C[6] * F[2] + dt * C[7] * F[5] + (1.f + dt * C[8]) * F[8];
     project_strain(p.M, cF);
-    // in-plane columns from the deformed edges (:230-250)
+    // in-plane columns from the deformed edges (:230-250); the Dm^-1[2] = 0 terms are left out
 #pragma unroll
     for (int d = 0; d < 3; ++d) {
         const float e0 = x1[d] - x0[d], e1 = x2[d] - x0[d];
-        cF[d * 3 + 0] = e0 * Dm[0] + e1 * Dm[2];
-        cF[d * 3 + 1] = e0 * Dm[1] + e1 * Dm[3];
+        cF[d * 3 + 0] = e0 * Dm0;
+        cF[d * 3 + 1] = e0 * Dm1 + e1 * Dm3;
     }
     S.fq[0][i] = make_float4(cF[0], cF[1], cF[2], cF[3]);
     S.fq[1][i] = make_float4(cF[4], cF[5], cF[6], cF[7]);
-    S.fq[2][i] = make_float4(cF[8], Dm[0], Dm[1], Dm[2]);
+    S.f8[i] = cF[8];
 
     float P[9];
     cloth_dphi_dF(p.M, cF, P);
@@ -85,15 +88,15 @@ __global__ __launch_bounds__(256) void k_fem(DP p, float dt) {
     p.ab0[i] = make_float4(P[2], P[5], P[8], cF[2]);
     p.ab1[i] = make_float2(cF[5], cF[8]);
     // grad_N = Dm^-T [[-1,1,0],[-1,0,1]]  (:269-276)
-    const float g00 = -Dm[0] - Dm[2], g01 = Dm[0], g02 = Dm[2];
-    const float g10 = -Dm[1] - Dm[3], g11 = Dm[1], g12 = Dm[3];
+    const float g00 = -Dm0, g01 = Dm0;
+    const float g10 = -Dm1 - Dm3, g11 = Dm1, g12 = Dm3;
     float Gm[9];
 #pragma unroll
     for (int d = 0; d < 3; ++d) {
         const float a = P[d * 3 + 0], b = P[d * 3 + 1];
         Gm[d * 3 + 0] = a * g00 + b * g10;
         Gm[d * 3 + 1] = a * g01 + b * g11;
-        Gm[d * 3 + 2] = a * g02 + b * g12;
+        Gm[d * 3 + 2] = b * g12;
     }
     // one 12-byte record per corner: a vertex fetches its triple with a single dwordx3 load
 #pragma unroll
@@ -104,10 +107,10 @@ __global__ __launch_bounds__(256) void k_fem(DP p, float dt) {
 // ascending original face id (the order sequential atomics would produce).  The adjacency is
 // kept per vertex slot (refreshed at every rebuild) so that a vertex needs one coalesced index
 // load and one 16-byte gather per adjacent face.
-// the force on vertex `k` (slot p.Nf + k) from the corner records of its adjacent faces, written to p.f
-MPM_DEV void vertex_force(const DP& p, const PSet& S, int k) {
+// the force on vertex `k` (slot p.Nf + k) from the corner records of its adjacent faces
+MPM_DEV void vertex_force_value(const DP& p, const PSet& S, int k, float& f0, float& f1, float& f2) {
     const int s = p.Nf + k;
-    float f0 = 0.f, f1 = 0.f, f2 = 0.f;
+    f0 = f1 = f2 = 0.f;
     const int4 r0 = S.va[0][k], r1 = S.va[1][k];
     const int rec[8] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w};
     if (p.dist.on) {
@@ -117,8 +120,7 @@ MPM_DEV void vertex_force(const DP& p, const PSet& S, int k) {
 #pragma unroll
         for (int q = 0; q < 8; ++q) missing |= rec[q] == -3;
         if (missing) {
-            const float v = S.q[0][s].w > 0.f ? __int_as_float(0x7FC00000) : 0.f;
-            p.f[0][s] = v; p.f[1][s] = v; p.f[2][s] = v;
+            f0 = f1 = f2 = S.q[0][s].w > 0.f ? __int_as_float(0x7FC00000) : 0.f;
             return;
         }
     }
@@ -147,6 +149,11 @@ MPM_DEV void vertex_force(const DP& p, const PSet& S, int k) {
             f2 += -g.z;
         }
     }
+}
+MPM_DEV void vertex_force(const DP& p, const PSet& S, int k) {   // ... written to p.f
+    float f0, f1, f2;
+    vertex_force_value(p, S, k, f0, f1, f2);
+    const int s = p.Nf + k;
     p.f[0][s] = f0;
     p.f[1][s] = f1;
     p.f[2][s] = f2;
@@ -188,7 +195,26 @@ __global__ __launch_bounds__(256) void k_vforce(DP p) {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
-constexpr int STG = 20;  // staged floats per particle: 16 columns of Y, fx, fy, fz, pad
+// A/B switches of the round-3 P2G experiments (defaults = what ships; scratch/ab_build.py builds variants,
+// scratch/ab_run.py times them on one box; results in DESIGN.md section 8)
+#ifndef MPM_P2G_STG16
+#define MPM_P2G_STG16 1
+#endif
+#ifndef MPM_P2G_LDSF
+#define MPM_P2G_LDSF 0   // vertex forces handed over in LDS: 8 MB less traffic, 0.2 - 1.2 us slower (measured)
+#endif
+#if MPM_P2G_STG16
+// staged floats per particle: the 13 columns of Y that carry numbers, then fx, fy, fz in the three columns of the
+// mass component that Y leaves empty (their products are discarded by a zero in `fac`)
+constexpr int STG = 16, STG_FX = 13;
+#else
+constexpr int STG = 20, STG_FX = 16;  // 16 columns of Y, fx, fy, fz, pad
+#endif
+#if MPM_P2G_LDSF
+// vertex forces of a work item handed from its prologue to its particle loop in LDS (12 bytes per vertex; an item
+// with more vertices than this keeps the rest in p.f): what is left of the 80 KB that let two workgroups share a CU
+constexpr int LDSF_CAP = 1080;
+#endif
 
 template <int CTRL>
 MPM_DEV float quad_perm(float v) {
@@ -207,8 +233,7 @@ MPM_DEV float quad_perm(float v) {
 // unbiased whatever the particle count.  `worst` collects the bit pattern of the largest |q| (NaN and
 // infinity have the largest patterns of all): the caller compares it with 2^62 once, at the end -- a
 // boolean per call lives in a scalar register pair and costs scalar instructions in every loop.
-MPM_DEV void lds_add_fixed(long long* a, float v, float scale, unsigned& worst) {
-    const float q = v * scale;
+MPM_DEV void lds_add_fixed(long long* a, float q, unsigned& worst) {   // q = value * scale
     const float aq = fabsf(q);
     const float h = floorf(aq * 0x1p-32f);
     const unsigned lo = (unsigned)rintf(fmaf(-h, 0x1p32f, aq));
@@ -280,6 +305,11 @@ __global__ __launch_bounds__(512, 4) void k_p2g(DP p, float dt) {  // <= 128 VGP
     // wave-private staging: 64 particles (+8 slack rows touched by the operand prefetch)
     __shared__ __attribute__((aligned(16))) float stage_all[8][(64 + 8) * STG];
     __shared__ unsigned s_mask;
+#if MPM_P2G_LDSF
+    __shared__ float s_frc[LDSF_CAP * 3];
+    static_assert(sizeof(long long) * TILE_N * 4 + sizeof(float) * 8 * (64 + 8) * STG + sizeof(float) * LDSF_CAP * 3 + 4 <= 81920,
+                  "two workgroups per CU need <= 80 KB of LDS each");
+#endif
     Ctl* ctl = p.ctl;
     const PSet& S = p.set[ctl->cur];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -302,7 +332,9 @@ __global__ __launch_bounds__(512, 4) void k_p2g(DP p, float dt) {  // <= 128 VGP
     const f32x2 cx0 = {ax[0][0], ax[1][0]}, cx1 = {ax[0][1], ax[1][1]}, cx2 = {ax[0][2], ax[1][2]};
     const f32x2 cy0 = {ay[0][0], ay[1][0]}, cy1 = {ay[0][1], ay[1][1]}, cy2 = {ay[0][2], ay[1][2]};
     const f32x2 cz0 = {az[0][0], az[1][0]}, cz1 = {az[0][1], az[1][1]}, cz2 = {az[0][2], az[1][2]};
-    float fac[2][4];     // epilogue: (1, i, j, k)[tt] of node row 16 t + 4 g4 + r
+    // epilogue: (1, i, j, k)[tt] of node row 16 t + 4 g4 + r, times the fixed-point scale of this lane's
+    // component (a power of two: scaling before or after the sums gives the same bits)
+    float fac[2][4];
     int delta[2];        // float offset of this lane's node/component in the tile, -1 if none
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
@@ -311,11 +343,18 @@ __global__ __launch_bounds__(512, 4) void k_p2g(DP p, float dt) {  // <= 128 VGP
             const int n = 16 * t + 4 * g4 + r;
             const int ni = n / 9, nj = (n / 3) % 3, nk = n % 3;
             fac[t][r] = n >= 27 ? 0.f : (tt == 0 ? 1.f : (float)(tt == 1 ? ni : (tt == 2 ? nj : nk)));
+            if (MPM_P2G_STG16 && dcomp == 3 && tt != 0) fac[t][r] = 0.f;   // (columns 13..15 carry fx, fy, fz)
         }
         const int n = 16 * t + 4 * g4 + tt;
         delta[t] = n < 27 ? (((n / 9) * TILE_W + (n / 3) % 3) * TILE_W + n % 3) * 4 + dcomp : -1;
     }
-    const float fscale = (float)(dcomp == 3 ? p.fix_m : p.fix_p);
+    {
+        const float fscale = (float)(dcomp == 3 ? p.fix_m : p.fix_p);
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) fac[t][r] *= fscale;
+    }
     // A step reads 4 staged rows; rows that do not belong to the cell (the next cell's particles,
     // rows never written) are masked in the B operand only, so every row must hold finite numbers
     for (int k = lane; k < (64 + 8) * STG; k += 64) stage[k] = 0.f;
@@ -332,33 +371,42 @@ __global__ __launch_bounds__(512, 4) void k_p2g(DP p, float dt) {  // <= 128 VGP
         const unsigned long long tb0 = (diag_flags(p) & 4) ? __builtin_readcyclecounter() : 0ull;
         for (int n = tid; n < TILE_N * 4; n += 512) tile[n] = 0;
         if (tid == 0) s_mask = 0;
-        if (p.fuse_vforce && fa.w > 0) {
-            // the vertex forces of this item (k_vforce's job: one launch less per substep; the forces still go
-            // through p.f, written and read back by this workgroup -- the barrier below orders the two)
-            const int4* gq = p.home_groups + fb.w;
-            const int v0 = gq[0].z, v1 = gq[fa.w - 1].w;   // the item's vertex slots
-            for (int sv = v0 + tid; sv < v1; sv += 512) vertex_force(p, S, sv - p.Nf);
-        }
-        __syncthreads();
         int bx, by, bz;
         block_coords((uint32_t)fa.z, bx, by, bz);
         const int ox = bx * 4 - FREE_ZONE, oy = by * 4 - FREE_ZONE, oz = bz * 4 - FREE_ZONE;
         const int4 rg = make_int4(fb.x, fb.y, fb.z, 0);
         const int nfb = rg.y - rg.x;
-        unsigned mymask = 0;
-        bool halo_bad = false;
-        unsigned out_worst = 0, fix_worst = 0;   // error conditions, collected as integers in vector registers
         // Every wave streams through its own groups of <= 64 particles; no workgroup barrier inside.
         // Groups are runs of whole cells (faces and vertices of the same cells together), laid out
         // at the last rebuild: a group usually spans two base cells.
         const int ngroups = fa.w;
         const int4* groups = p.home_groups + fb.w;
+        const int4 irg = p.item_rng[q];
+        const int v0_item = irg.z;   // first vertex slot of the item
+#if MPM_P2G_LDSF
+        // (uniform over the workgroup: an item with more vertices than the LDS array holds -- a mesh with far more
+        // vertices than faces -- hands all its forces over through p.f)
+        const bool f_lds = p.fuse_vforce && irg.w - irg.z <= LDSF_CAP;
+#endif
         struct Raw {
             float x[3], v[3], vol, C[9];
             // tau factors a, b (faces) and force (vertices) in separate registers: merging them
             // into one array makes the compiler route the prefetch through scratch memory
             float ta[3], tb[3], frc[3];
             bool act, is_face;
+        };
+        // the force on a vertex particle from wherever the prologue left it (fused mode), or from k_vforce's p.f
+        auto force_of = [&](unsigned ii, float* f) {
+#if MPM_P2G_LDSF
+            if (f_lds) {
+                const unsigned k = ii - (unsigned)v0_item;
+                f[0] = s_frc[k * 3]; f[1] = s_frc[k * 3 + 1]; f[2] = s_frc[k * 3 + 2];
+                return;
+            }
+#endif
+            const float* fbase = p.f[0] + ii;
+#pragma unroll
+            for (int d = 0; d < 3; ++d) f[d] = fbase[(size_t)d * p.f_stride];
         };
         auto load_raw = [&](int g) {
             Raw r;
@@ -381,16 +429,37 @@ __global__ __launch_bounds__(512, 4) void k_p2g(DP p, float dt) {  // <= 128 VGP
                 const float2 b = p.ab1[ii];
                 r.ta[0] = a.x; r.ta[1] = a.y; r.ta[2] = a.z; r.tb[0] = a.w; r.tb[1] = b.x; r.tb[2] = b.y;
             } else {
-                const float* fbase = p.f[0] + ii;
-#pragma unroll
-                for (int d = 0; d < 3; ++d) r.frc[d] = fbase[(size_t)d * p.f_stride];
+                force_of(ii, r.frc);
             }
             return r;
         };
         Raw cur;
+        if (p.fuse_vforce && fa.w > 0) {
+            // the vertex forces of this item (k_vforce's job: one launch less per substep), handed to the particle
+            // loop below in LDS -- the barrier orders the two; vertices beyond the LDS array go through p.f
+            for (int sv = v0_item + tid; sv < irg.w; sv += 512) {
+#if MPM_P2G_LDSF
+                float f0, f1, f2;
+                vertex_force_value(p, S, sv - p.Nf, f0, f1, f2);
+                const int k = sv - v0_item;
+                if (f_lds) {
+                    s_frc[k * 3] = f0; s_frc[k * 3 + 1] = f1; s_frc[k * 3 + 2] = f2;
+                } else {
+                    p.f[0][sv] = f0; p.f[1][sv] = f1; p.f[2][sv] = f2;
+                }
+#else
+                vertex_force(p, S, sv - p.Nf);
+#endif
+            }
+        }
+        __syncthreads();
+        unsigned mymask = 0;
+        bool halo_bad = false;
+        unsigned out_worst = 0, fix_worst = 0;   // error conditions, collected as integers in vector registers
         if (wv < ngroups) cur = load_raw(wv);
         const bool prof = (diag_flags(p) & 4) != 0 && wv == 0;
         unsigned long long tq[3] = {0, 0, 0}, pc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (prof && lane == 0) atomicAdd(&p.dbgbuf[14], (unsigned long long)__builtin_readcyclecounter() - tb0);   // prologue
         for (int g = wv; g < ngroups; g += 8) {
             // ---- 1. one particle per lane (its raw state was prefetched) ----------
             if (prof) tq[0] = __builtin_readcyclecounter();
@@ -468,8 +537,12 @@ __global__ __launch_bounds__(512, 4) void k_p2g(DP p, float dt) {  // <= 128 VGP
                 sp[0] = make_float4(Y[0], Y[1], Y[2], Y[3]);
                 sp[1] = make_float4(Y[4], Y[5], Y[6], Y[7]);
                 sp[2] = make_float4(Y[8], Y[9], Y[10], Y[11]);
+#if MPM_P2G_STG16
+                sp[3] = make_float4(Y[12], st.fx[0], st.fx[1], st.fx[2]);
+#else
                 sp[3] = make_float4(Y[12], Y[13], Y[14], Y[15]);
                 sp[4] = make_float4(st.fx[0], st.fx[1], st.fx[2], 0.f);
+#endif
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
@@ -481,7 +554,7 @@ __global__ __launch_bounds__(512, 4) void k_p2g(DP p, float dt) {  // <= 128 VGP
             float nfx, nfy, nfz, ny;
             {
                 const float* sn = stage + g4 * STG;
-                nfx = sn[16]; nfy = sn[17]; nfz = sn[18]; ny = sn[j16];
+                nfx = sn[STG_FX]; nfy = sn[STG_FX + 1]; nfz = sn[STG_FX + 2]; ny = sn[j16];
             }
             if (prof) tq[1] = __builtin_readcyclecounter();
             __builtin_amdgcn_s_setprio(2);   // (waves in the contraction keep the matrix pipe fed: ahead of waves that derive / group)
@@ -500,7 +573,7 @@ __global__ __launch_bounds__(512, 4) void k_p2g(DP p, float dt) {  // <= 128 VGP
                     float y = ny;
                     {
                         const float* sn = stage + (s + 4 + g4) * STG;
-                        nfx = sn[16]; nfy = sn[17]; nfz = sn[18]; ny = sn[j16];
+                        nfx = sn[STG_FX]; nfy = sn[STG_FX + 1]; nfz = sn[STG_FX + 2]; ny = sn[j16];
                     }
                     // both rows' weights in one chain of packed operations (v_pk_fma_f32: the same fused
                     // multiply-adds as two scalar chains, half the issue slots)
@@ -522,7 +595,7 @@ __global__ __launch_bounds__(512, 4) void k_p2g(DP p, float dt) {  // <= 128 VGP
                 // the loop leaves row block (last step + 4) preloaded; the next cell starts at s1
                 if (((s1 - s0) & 3) != 0 || (diag_flags(p) & 8)) {
                     const float* sn = stage + (s1 + g4) * STG;
-                    nfx = sn[16]; nfy = sn[17]; nfz = sn[18]; ny = sn[j16];
+                    nfx = sn[STG_FX]; nfy = sn[STG_FX + 1]; nfz = sn[STG_FX + 2]; ny = sn[j16];
                 }
                 if (prof) { asm volatile("" :: "v"(acc0), "v"(acc1)); const unsigned long long tm = __builtin_readcyclecounter(); pc[2] += tm - tq[2]; tq[2] = tm; }
                 s0 = s1;
@@ -533,19 +606,17 @@ __global__ __launch_bounds__(512, 4) void k_p2g(DP p, float dt) {  // <= 128 VGP
 #pragma unroll
                 for (int t = 0; t < 2; ++t) {
                     const f32x4 a = t ? acc1 : acc0;
-                    float v[4];
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        float x = a[r] * fac[t][r];
-                        x += quad_perm<0xB1>(x);
-                        x += quad_perm<0x4E>(x);
-                        v[r] = x;
-                    }
-                    float val = v[0];
-                    val = tt == 1 ? v[1] : val;
-                    val = tt == 2 ? v[2] : val;
-                    val = tt == 3 ? v[3] : val;
-                    if (delta[t] >= 0 && !(diag_flags(p) & 16)) lds_add_fixed(tb + delta[t], val, fscale, fix_worst);
+                    // Lane (g4, dcomp, tt) of a quad holds the four terms' products of rows r = 0..3 and has to end up
+                    // with the sum over the quad's four lanes of row r = tt: a 4 x 4 transpose-and-add in two
+                    // exchanges (lane ^ 1, then lane ^ 2), each lane passing on what its partner keeps -- 4 + 2
+                    // selects and 3 DPP adds instead of folding all four rows on every lane (8 DPP adds + 4 moves)
+                    // and selecting afterwards.  Same operands in the same order: the sums are bit-identical.
+                    const float x0 = a[0] * fac[t][0], x1 = a[1] * fac[t][1], x2 = a[2] * fac[t][2], x3 = a[3] * fac[t][3];
+                    const bool b0 = (tt & 1) != 0, b1 = (tt & 2) != 0;
+                    const float ua = (b0 ? x1 : x0) + quad_perm<0xB1>(b0 ? x0 : x1);   // row b0, lanes l and l ^ 1
+                    const float ub = (b0 ? x3 : x2) + quad_perm<0xB1>(b0 ? x2 : x3);   // row 2 + b0
+                    const float val = (b1 ? ub : ua) + quad_perm<0x4E>(b1 ? ua : ub);
+                    if (delta[t] >= 0 && !(diag_flags(p) & 16)) lds_add_fixed(tb + delta[t], val, fix_worst);
                 }
                 if (prof) pc[3] += __builtin_readcyclecounter() - tq[2];
             }
@@ -568,6 +639,7 @@ __global__ __launch_bounds__(512, 4) void k_p2g(DP p, float dt) {  // <= 128 VGP
         if (__ballot(fix_worst >= __float_as_uint(0x1p62f)) && lane == 0) atomicOr(&ctl->error, ERR_RANGE);
         if (p.dist.on && __ballot(halo_bad) && lane == 0) atomicOr(&ctl->error, ERR_HALO);
         __syncthreads();
+        if (prof && lane == 0) atomicAdd(&p.dbgbuf[15], (unsigned long long)__builtin_readcyclecounter() - tb0 - pc[7]);   // wave 0 at the closing barrier
         float4* out = p.slab + (size_t)item * TILE_N;
         for (int n = tid; n < TILE_N; n += 512) {
             const long long* q = tile + n * 4;
@@ -833,12 +905,18 @@ MPM_DEV int g2p_particle(const DP& p, const PSet& S, const float4* tile, unsigne
     for (int r = 0; r < 3; ++r)
 #pragma unroll
         for (int c = 0; c < 3; ++c) Cn[r * 3 + c] = ca * (sc * nC[r * 3 + c]) + cb * (sc * nC[c * 3 + r]);
-    // four 16-byte stores per particle
+    // four 16-byte stores per particle (in this order: it keeps the kernel at 126 VGPRs without scratch)
     const float xn = x + nv[0] * dt, yn = y + nv[1] * dt, zn = z + nv[2] * dt;
     S.q[0][i] = make_float4(xn, yn, zn, vol);
-    S.q[1][i] = make_float4(nv[0], nv[1], nv[2], Cn[8]);
     S.q[2][i] = make_float4(Cn[0], Cn[1], Cn[2], Cn[3]);
     S.q[3][i] = make_float4(Cn[4], Cn[5], Cn[6], Cn[7]);
+    // A face particle's velocity is only looked at from outside (downloads): CalcFemStateAndForce replaces it by the
+    // mean of the corners before anything in a substep reads it, and takes C8 from the c8 plane.  Between the substeps
+    // of one mpm_run_substeps batch the record is therefore not written (DP::lean_g2p; the last substep of a batch and
+    // the phase-by-phase calls write it).
+    const bool is_face = i < (unsigned)p.Nf;
+    if (!(p.lean_g2p && is_face)) S.q[1][i] = make_float4(nv[0], nv[1], nv[2], Cn[8]);
+    if (is_face) S.c8[i] = Cn[8];
     // Does the advected particle still fit this block's tile?  Vertices are tested where the next
     // P2G will find them; a face is re-centred on its corners by the FEM kernel first, which moves
     // it by O(dt * velocity spread inside the face), hence the 1/8-cell guard band.
@@ -870,13 +948,7 @@ __global__ __launch_bounds__(G2P_THREADS) __attribute__((amdgpu_waves_per_eu(4, 
         const bool prof = (diag_flags(p) & 4) != 0;
         unsigned long long t0 = 0, t1 = 0;
         if (prof) t0 = __builtin_readcyclecounter();
-        int4 rg;
-        {
-            // the item's particles: from the first slot of its first wave group to the end of its last
-            const int4* groups = p.home_groups + fb.w;
-            const int4 ga = groups[0], gb = groups[fa.w - 1];
-            rg = make_int4(ga.x, gb.y, ga.z, gb.w);
-        }
+        const int4 rg = p.item_rng[q];   // the item's particles: face slots [x, y), vertex slots [z, w)
         // faces then vertices as one index space: a single copy of the (large) particle body
         const int nfb = rg.y - rg.x, total = nfb + (rg.w - rg.z);
         auto slot_of = [&](int u) { return (unsigned)(u < nfb ? rg.x + u : rg.z + (u - nfb)); };

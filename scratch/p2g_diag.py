@@ -25,4 +25,6 @@ print("per group: derive %.0f contraction %.0f (mfma %.0f epilogue %.0f) cycles;
       (c[0] / groups, c[1] / groups, c[2] / groups, c[3] / groups, cells / groups, steps / cells))
 print("per item: total %.0f cycles, wave0 block part %.0f; items/substep %.1f" % (c[12] / c[13], c[7] / c[13] , c[13] / n))
 print("g2p per item: stage %.0f gather %.0f iters %.2f" % (c[8] / c[11], c[9] / c[11], c[10] / c[11]))
+ph, tot = g.profile_substeps(50, 1e-3, -1)
+print("diag-build phase times (us)", {k: round(v * 1e3, 1) for k, v in ph.items()}, round(tot * 1e3, 1))
 print("p2g per item: pre-loop %.0f, wave-0 wait at the closing barrier %.0f" % (c[14] / c[13], c[15] / c[13]))
