@@ -116,7 +116,8 @@ SYMBOLS = [
     "mpm_spatial_force_shift", "mpm_external_forces_at_body_origin", "mpm_set_grid_colliders",
     "mpm_grid_collider_preset", "mpm_get_contact_stats", "mpm_dist_init", "mpm_dist_migration_buffer_bytes",
     "mpm_dist_migrate_pack", "mpm_dist_migrate_apply", "mpm_dist_roles", "mpm_chain_enable_migration",
-    "mpm_dist_set_transport",
+    "mpm_dist_set_transport", "mpm_device_synchronize", "mpm_debug_owed_substeps",
+    "mpm_memcpy_d2h", "mpm_memcpy_h2d",
 ]
 
 EXCHANGE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t)
@@ -185,6 +186,9 @@ def load_library(build: bool = True):
         "mpm_update_grid": [vp, i],
         "mpm_grid_to_particle": [vp, f],
         "mpm_sync": [vp],
+        "mpm_debug_owed_substeps": [vp, P(C.c_uint32)],
+        "mpm_memcpy_d2h": [vp, vp, vp, sz],
+        "mpm_memcpy_h2d": [vp, vp, vp, sz],
         "mpm_sync_particle_state_to_cpu": [vp, vp],
         "mpm_dump_obj": [vp, C.c_char_p],
         "mpm_copy_contact_pairs": [vp, sz, vp, vp, vp, vp, vp, vp, vp],
@@ -228,6 +232,8 @@ def load_library(build: bool = True):
         "mpm_external_forces_at_body_origin": [sz, vp, vp, vp, vp, vp],
     }
     for name, args in sigs.items():
+        if os.environ.get("MPM_HIP_LIBRARY") and not hasattr(lib, name):
+            continue   # (an older A/B variant of an experiment, scratch/ab_run.py)
         fn = getattr(lib, name)
         fn.argtypes = args
         fn.restype = C.c_int
@@ -237,6 +243,9 @@ def load_library(build: bool = True):
     lib.mpm_newton_bisect_f32.argtypes = [ROOTFIND_FN, vp, f, f, f, f, f, i, i, P(f), P(i)]
     lib.mpm_newton_bisect_f32.restype = i
     lib.mpm_halo_buffer_bytes.argtypes = [sz]
+    if hasattr(lib, "mpm_device_synchronize"):
+        lib.mpm_device_synchronize.argtypes = []
+        lib.mpm_device_synchronize.restype = C.c_int
     lib.mpm_dist_migration_buffer_bytes.argtypes = [sz]
     lib.mpm_dist_migration_buffer_bytes.restype = sz
     lib.mpm_halo_buffer_bytes.restype = sz
@@ -395,6 +404,25 @@ class GpuMpm:
 
     def gpu_sync(self):
         self._ck(self.lib.mpm_sync(self.h))
+
+    @staticmethod
+    def device_synchronize():
+        """GpuMpmSolver::GpuSync() as the reference calls it: no state argument (cuda_mpm_solver.cu:164-166)."""
+        lib = load_library()
+        rc = lib.mpm_device_synchronize()
+        if rc:
+            raise MpmError(rc, (lib.mpm_last_error() or b"").decode())
+
+    def memcpy_d2h(self, dst_host_ptr: int, src_device_ptr: int, nbytes: int):
+        self._ck(self.lib.mpm_memcpy_d2h(self.h, dst_host_ptr, src_device_ptr, nbytes))
+
+    def memcpy_h2d(self, dst_device_ptr: int, src_host_ptr: int, nbytes: int):
+        self._ck(self.lib.mpm_memcpy_h2d(self.h, dst_device_ptr, src_host_ptr, nbytes))
+
+    def owed_substeps(self) -> int:
+        n = C.c_uint32()
+        self._ck(self.lib.mpm_debug_owed_substeps(self.h, C.byref(n)))
+        return n.value
 
     def sync_particle_state_to_cpu(self):
         pos = np.empty((self.n_particles, 3), np.float32)

@@ -1,6 +1,7 @@
 // Host orchestration of the contact solve (CopyContactPairs / UpdateContact,
 // cuda_mpm_solver.cu:193-621).
 #pragma once
+#include <memory>
 #include <cmath>
 #include <fstream>
 #include <tuple>
@@ -96,6 +97,7 @@ static int copy_contacts(mpm_engine* e, size_t n, const uint32_t* particle, cons
 
 // Device-side CalcMpmContactPairs + CopyContactPairs for analytic colliders (include/mpm_hip.h)
 static int generate_contacts(mpm_engine* e, size_t n_col, const mpm_collider_t* cols, size_t* n_out) {
+    TraceRange tr("mpm:contact pairs (device)");
     static_assert(sizeof(Collider) == sizeof(mpm_collider_t), "collider layouts differ");
     ContactBuffers& b = e->cb;
     const DP& p = e->dp;
@@ -314,7 +316,13 @@ static int update_contact(mpm_engine* e, int frame, int substep, float dt, float
     const int n_con_wg = (int)std::min<size_t>((n + CT_WG / 4 - 1) / (CT_WG / 4), CT_ROWS_CON);
     const int n_grid_wg = CT_ROWS;                               // grid-stride node part
     const int n_dir_wg = CT_DIR_WG;
+    TraceRange tr_all("mpm:UpdateContact");
     // ---- set-up: contacts in base-cell order, per-cell runs, nodes that see contacts ---------
+    std::unique_ptr<TraceRange> tr_phase(new TraceRange("mpm:UpdateContact set-up (sort, per-cell runs, node list)"));
+    auto trace_phase = [&](const char* name) {   // (phases end where the next begins; early returns close them too)
+        tr_phase.reset();
+        tr_phase.reset(new TraceRange(name));
+    };
     HIP_TRY(hipMemsetAsync(b.st, 0, sizeof(ContactState), s));
     hipLaunchKernelGGL(k_ct_keys, dim3(1024), dim3(256), 0, s, p, c, (const uint32_t*)b.api_idx, (const int*)e->d_pids_api, b.slot);
     {
@@ -344,6 +352,7 @@ static int update_contact(mpm_engine* e, int frame, int substep, float dt, float
     // pre-contact velocity at the contact points (cuda_mpm_solver.cu:267-272)
     hipLaunchKernelGGL(k_ct_gather_vel, dim3(gc), dim3(256), 0, s, p, c, b.vel0);
 
+    trace_phase("mpm:UpdateContact Newton iterations");
     std::vector<float> s_res, s_energy;
     std::vector<int> s_ls;
     float s_alpha_last = 0.f, s_E0_last = 0.f;
@@ -491,6 +500,7 @@ static int update_contact(mpm_engine* e, int frame, int substep, float dt, float
         }
     }
     // contact velocities after the solve and the reaction on the rigid bodies
+    trace_phase("mpm:UpdateContact impulses");
     hipLaunchKernelGGL(k_ct_impulse, dim3(std::min(gc, 256u)), dim3(256), 0, s, p, c);
     HIP_TRY(hipGetLastError());
     b.last_iters = iters;

@@ -21,6 +21,8 @@ constexpr unsigned ERR_CAPACITY = 2u;   // home/active table overflow
 constexpr unsigned ERR_DOMAIN = 4u;     // particle base cell outside the grid
 constexpr unsigned ERR_RANGE = 8u;      // a P2G node sum left the range of the fixed-point tile (or was NaN)
 constexpr unsigned ERR_HALO = 16u;      // partitioned domain: a particle's stencil left the zone shared with the neighbour
+constexpr unsigned ERR_SLABS = 32u;     // the re-sort made more work items than the slab pool holds (Ctl::n_items_wanted): the host
+                                        // grows the pool and repeats the re-sort (recover_slab_overflow, mpm_engine.hip)
 
 // One of the two ping-pong particle sets.  Every particle is four 16-byte records in four
 // planes (one coalesced dwordx4 access per plane and wave), slots [0,Nf) are face particles,
@@ -75,7 +77,8 @@ struct Ctl {
     int nfa, nva;
     int add_f, add_v;
     int nfa_new, nva_new;   // counts after the re-sort in flight (k_rb_tables -> k_rb_finish)
-    int pad1[2];
+    unsigned n_items_wanted;   // work items the last re-sort made, before the clamp to the slab pool (> n_items: ERR_SLABS)
+    int pad1;
 };
 
 // Partitioned domain: ranks cut ONE domain into x slabs at block boundaries.  Every
@@ -119,7 +122,10 @@ struct DP {
     float dx, dxinv, Dinv;
     unsigned q_stride, f_stride;   // distance (elements) between the planes PSet::q[0..3] and f[0..2] (one allocation each)
     int fuse_vforce;       // 1: k_p2g computes the vertex forces of its work items itself (no k_vforce launch)
-    int gated;             // 1: this substep was enqueued without the re-sort launches (see Ctl::skipped)
+    int gated;             // bit 0: this substep was enqueued without the re-sort launches and returns at once when it finds a
+                           // re-sort pending; bit 1: it returns at once when the slab pool has overflowed (every substep
+                           // of mpm_run_substeps; the phase-by-phase calls cannot be repeated by the engine).  Either way it
+                           // counts itself in Ctl::skipped and the host runs it again (settle, mpm_engine.hip)
     int lean_g2p;          // 1: k_g2p leaves q[1] of the face particles alone (see g2p_particle); per launch
     float anticip;         // re-sort: cells a particle is binned ahead per unit of velocity (0 = by position), see k_rb_count
     // fixed-point scales of the LDS tile accumulators (powers of two), see k_p2g

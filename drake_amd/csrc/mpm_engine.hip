@@ -10,6 +10,7 @@
 #include <cstring>
 #include <fstream>
 #include <functional>
+#include <mutex>
 #include <numeric>
 #include <string>
 #include <vector>
@@ -21,6 +22,10 @@
 #include "mpm_chain.h"
 #include "mpm_feedback.h"
 #include "mpm_dist.h"
+
+// every engine alive in this process (mpm_device_synchronize)
+static std::mutex g_live_mutex;
+static std::vector<mpm_engine*> g_live;
 
 extern "C" {
 
@@ -67,6 +72,10 @@ int mpm_create(int domain_bits, const mpm_material_t* material, int device, mpm_
     e->stream = e->own_stream;
     if (getenv("MPM_RESORT_EVERY")) e->check_every = std::max(1, atoi(getenv("MPM_RESORT_EVERY")));
     if (getenv("MPM_GRAPH")) e->graph_len = std::max(0, atoi(getenv("MPM_GRAPH")));
+    {
+        std::lock_guard<std::mutex> lock(g_live_mutex);
+        g_live.push_back(e);
+    }
     *out = e;
     return 0;
 }
@@ -140,12 +149,20 @@ static void launch_rebuild(mpm_engine* e) {
     static const float horizon = getenv("MPM_ANTICIPATE") ? (float)atof(getenv("MPM_ANTICIPATE")) : 32.f;
     e->dp.anticip = e->dp.dist.on ? 0.f : horizon * e->last_dt * e->dp.dxinv;
     const DP& p = e->dp;
-    e->cb.n_active_hint = 0;   // the block tables may change: contact pairs handed over before are re-keyed with the full width
+    TraceRange tr("mpm:RebuildMapping (conditional re-sort)");
+    // (host state only -- nothing below may depend on this function running: captured graphs replay the launches
+    // without it.  Callers that enqueue a possible re-sort call may_resort() themselves.)
     hipLaunchKernelGGL(k_rb_count, dim3(std::min(e->g_np, e->g_rb)), dim3(256), 0, e->stream, p);
     hipLaunchKernelGGL(k_rb_tables, dim3(33), dim3(1024), 0, e->stream, p);
     hipLaunchKernelGGL(k_rb_scatter, dim3(std::min(e->g_np, e->g_rb)), dim3(256), 0, e->stream, p);
     if (e->deterministic) hipLaunchKernelGGL(k_rb_canon, dim3(512), dim3(256), 0, e->stream, p);
     hipLaunchKernelGGL(k_rb_finish, dim3((std::min(e->g_np, e->g_rb) + 7u) & ~7u), dim3(256), 0, e->stream, p);
+}
+// A re-sort may be about to run (directly or inside a replayed graph): the block tables may change, so contact
+// pairs handed over before are re-keyed with the full width, and the anticipatory binning uses this substep length.
+static void may_resort(mpm_engine* e, float dt) {
+    e->cb.n_active_hint = 0;
+    if (dt > 0.f) e->last_dt = dt;
 }
 static void drop_step_graph(mpm_engine* e) {
     if (e->step_graph) (void)hipGraphExecDestroy(e->step_graph);
@@ -153,9 +170,11 @@ static void drop_step_graph(mpm_engine* e) {
 }
 
 static void launch_fem_faces(mpm_engine* e, float dt) {
+    TraceRange tr("mpm:CalcFemStateAndForce (faces)");
     if (e->nf) hipLaunchKernelGGL(k_fem, dim3((e->g_nf + 7u) & ~7u), dim3(256), 0, e->stream, e->dp, dt);
 }
 static void launch_fem_vertices(mpm_engine* e) {
+    TraceRange tr("mpm:CalcFemStateAndForce (vertex forces)");
     if (e->nv) hipLaunchKernelGGL(k_vforce, dim3((e->g_nv + 7u) & ~7u), dim3(256), 0, e->stream, e->dp);
 }
 static void launch_fem(mpm_engine* e, float dt) {
@@ -164,6 +183,7 @@ static void launch_fem(mpm_engine* e, float dt) {
     launch_fem_vertices(e);
 }
 static void launch_p2g(mpm_engine* e, float dt) {
+    TraceRange tr(e->dp.fuse_vforce ? "mpm:ParticleToGrid (+ vertex forces)" : "mpm:ParticleToGrid");
     hipLaunchKernelGGL(k_p2g, dim3(e->g_tile), dim3(512), 0, e->stream, e->dp, dt);
     e->last_tile_kernel = 1;
 }
@@ -178,10 +198,12 @@ static void launch_fem_p2g(mpm_engine* e, float dt) {
 }
 // (`p` may carry a halo class restriction)
 static void launch_g2p_with(mpm_engine* e, DP p, float dt) {
+    TraceRange tr("mpm:GridToParticle");
     hipLaunchKernelGGL(k_g2p, dim3(std::min(768u, p.capI)), dim3(G2P_THREADS), 0, e->stream, p, dt);
     e->last_tile_kernel = 2;
 }
 static void launch_grid(mpm_engine* e, const GridColliders& gc) {
+    TraceRange tr("mpm:UpdateGrid");
     hipLaunchKernelGGL(k_grid<1>, dim3(e->g_grid), dim3(256), 0, e->stream, e->dp, gc);
 }
 static void launch_g2p(mpm_engine* e, float dt) { launch_g2p_with(e, e->dp, dt); }
@@ -189,6 +211,7 @@ static void launch_g2p(mpm_engine* e, float dt) { launch_g2p_with(e, e->dp, dt);
 // The P2G tiles accumulate in 64-bit fixed point.  Scales are powers of two chosen from the
 // total particle mass M: a node can never hold more than M, and its momentum is allowed
 // |v| < 2^15 length units per time unit.  Resolution: M * 2^-61 (mass), M * 2^-47 (momentum).
+static int recover_slab_overflow(mpm_engine* e, Ctl& c);
 static int set_fixed_point_scales(mpm_engine* e) {
     DP& p = e->dp;
     std::vector<float> q0(e->np * 4);
@@ -393,6 +416,12 @@ int mpm_finalize(mpm_handle_t e) {
     launch_rebuild(e);
     HIP_TRY(hipStreamSynchronize(e->stream));
     HIP_TRY(hipGetLastError());
+    {
+        // a scene with few particles per block needs more slabs than the estimate above: grow and re-sort
+        Ctl c;
+        D2H(e, &c, p.ctl, sizeof(Ctl));
+        if (int rc2 = recover_slab_overflow(e, c)) return rc2;
+    }
     if (p.dbg) {
         int a = 0, b = 0, c = 0;
         (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, k_p2g, 512, 0);
@@ -406,6 +435,10 @@ int mpm_finalize(mpm_handle_t e) {
 
 int mpm_destroy(mpm_handle_t e) {
     if (!e) return 0;
+    {
+        std::lock_guard<std::mutex> lock(g_live_mutex);
+        g_live.erase(std::remove(g_live.begin(), g_live.end(), e), g_live.end());
+    }
     hipSetDevice(e->device);
     if (e->own_stream) hipStreamSynchronize(e->own_stream);
     (void)mpm_chain_destroy(e);
@@ -457,9 +490,10 @@ int mpm_set_stream(mpm_handle_t e, void* s) {
 // there is nothing to copy; between those two calls the old contents are kept.
 static int slab_pool_grow(mpm_engine* e, const Ctl& c) {
     DP& p = e->dp;
-    if (p.capS >= p.capI || c.n_items * 2u <= p.capS) return 0;
+    const unsigned items = std::max(c.n_items, c.n_items_wanted);
+    if (p.capS >= p.capI || items * 2u <= p.capS) return 0;
     unsigned want = p.capS;
-    while (want < p.capI && c.n_items * 2u > want) want = (unsigned)std::min<size_t>(p.capI, (size_t)want * 2);
+    while (want < p.capI && items * 2u > want) want = (unsigned)std::min<size_t>(p.capI, (size_t)want * 2);
     float4* bigger = nullptr;
     HIP_TRY(hipMalloc((void**)&bigger, (size_t)want * TILE_N * sizeof(float4)));
     HIP_TRY(hipMemcpyAsync(bigger, p.slab, (size_t)p.capS * TILE_N * sizeof(float4), hipMemcpyDeviceToDevice, e->stream));
@@ -471,6 +505,26 @@ static int slab_pool_grow(mpm_engine* e, const Ctl& c) {
     for (auto& kg : e->halo_graph) {
         if (kg.exec) (void)hipGraphExecDestroy(kg.exec);
         kg.exec = nullptr;
+    }
+    return 0;
+}
+
+// The stream is idle and `c` is the control block.  If the last re-sort made more work items than the slab pool
+// holds and nothing else is wrong, grow the pool to twice the wanted count, clear the flag and repeat the re-sort;
+// `c` is refreshed.  Only legitimate while no substep has used the truncated tables: right after a re-sort
+// (mpm_finalize, mpm_dist_init) or when every substep since has skipped itself (DP::gated bit 1).
+static int recover_slab_overflow(mpm_engine* e, Ctl& c) {
+    for (int round = 0; round < 4 && (c.error & ERR_SLABS); ++round) {
+        if (c.error & ~ERR_SLABS) break;        // something else failed too: report it
+        if (e->dp.capS >= e->dp.capI) break;    // (cannot happen: capI covers every legal item count)
+        if (int rc = slab_pool_grow(e, c)) return rc;
+        const unsigned zero = 0;
+        const int one = 1;
+        H2D(e, &e->dp.ctl->error, &zero, sizeof(unsigned));
+        H2D(e, &e->dp.ctl->need_rebuild, &one, sizeof(int));
+        may_resort(e, 0.f);
+        launch_rebuild(e);
+        D2H(e, &c, e->dp.ctl, sizeof(Ctl));
     }
     return 0;
 }
@@ -502,7 +556,7 @@ int mpm_sync(mpm_handle_t e) {
                     "a node sum of ParticleToGrid was not finite or exceeded the fixed-point range "
                     "(|node momentum| >= total mass * 2^15 length units per time unit): the state has diverged");
     // (last: a diverging state also scatters particles over so many blocks that tables overflow)
-    if (c.error & ERR_CAPACITY)
+    if (c.error & (ERR_CAPACITY | ERR_SLABS))
         return fail(MPM_ERR_CAPACITY,
                     "a table of the engine overflowed (home / active blocks, slabs of the work items -- the pool is "
                     "grown at synchronisation points: call mpm_sync more often while a cloth spreads out, or set "
@@ -520,15 +574,23 @@ static int settle(mpm_engine* e) {
     e->force_check = true;   // whatever comes next starts with the re-sort launches
     e->dp.gated = 0;
     if (!e->maybe_owed) return 0;
-    e->maybe_owed = false;
-    unsigned owed = 0;
-    D2H(e, &owed, &e->dp.ctl->skipped, sizeof(unsigned));   // (synchronises the stream)
-    if (!owed) return 0;
-    const unsigned zero = 0;
-    H2D(e, &e->dp.ctl->skipped, &zero, sizeof(unsigned));
-    GridColliders gc;
-    if (int rc = grid_colliders_for(e, e->owed_bc, &gc)) return rc;
-    for (unsigned k = 0; k < owed; ++k) launch_substep(e, e->owed_dt, gc, false);
+    // (a few rounds: a substep that is run again may itself overflow the slab pool -- a cloth that keeps spreading)
+    for (int round = 0; round < 8 && e->maybe_owed; ++round) {
+        e->maybe_owed = false;
+        Ctl c;
+        D2H(e, &c, e->dp.ctl, sizeof(Ctl));   // (synchronises the stream)
+        // every substep since the overflowing re-sort has skipped itself: the pool can be grown and the re-sort repeated
+        if (int rc = recover_slab_overflow(e, c)) return rc;
+        const unsigned owed = c.skipped;
+        if (!owed) break;
+        const unsigned zero = 0;
+        H2D(e, &e->dp.ctl->skipped, &zero, sizeof(unsigned));
+        GridColliders gc;
+        if (int rc = grid_colliders_for(e, e->owed_bc, &gc)) return rc;
+        may_resort(e, e->owed_dt);
+        for (unsigned k = 0; k < owed; ++k) launch_substep(e, e->owed_dt, gc, false);
+        e->dp.gated = 0;
+    }
     e->force_check = true;
     return 0;
 }
@@ -541,8 +603,57 @@ static int settle(mpm_engine* e) {
     READY_NO_SETTLE(e);  \
     if (int rc2__ = settle(e)) return rc2__
 
+int mpm_memcpy_d2h(mpm_handle_t e, void* dst_host, const void* src_device, size_t bytes) {
+    REQUIRE(e, "null handle");
+    REQUIRE(bytes == 0 || (dst_host && src_device), "null pointer");
+    if (int rc = use(e)) return rc;
+    if (bytes) D2H(e, dst_host, src_device, bytes);
+    return 0;
+}
+
+int mpm_memcpy_h2d(mpm_handle_t e, void* dst_device, const void* src_host, size_t bytes) {
+    REQUIRE(e, "null handle");
+    REQUIRE(bytes == 0 || (dst_device && src_host), "null pointer");
+    if (int rc = use(e)) return rc;
+    if (bytes) H2D(e, dst_device, src_host, bytes);
+    return 0;
+}
+
+int mpm_debug_owed_substeps(mpm_handle_t e, uint32_t* out) {
+    READY_NO_SETTLE(e);
+    REQUIRE(out, "null output");
+    unsigned owed = 0;
+    D2H(e, &owed, &e->dp.ctl->skipped, sizeof(unsigned));
+    *out = owed;
+    return 0;
+}
+
+int mpm_device_synchronize(void) {
+    int dev = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    std::vector<mpm_engine*> mine;
+    {
+        std::lock_guard<std::mutex> lock(g_live_mutex);
+        for (mpm_engine* e : g_live)
+            if (e->device == dev) mine.push_back(e);
+    }
+    int first = 0;
+    std::string first_msg;
+    for (mpm_engine* e : mine) {
+        const int rc = mpm_sync(e);   // settles what mpm_run_substeps deferred, waits, reports sticky errors
+        if (rc && !first) {
+            first = rc;
+            first_msg = g_last_error;
+        }
+    }
+    HIP_TRY(hipSetDevice(dev));
+    HIP_TRY(hipDeviceSynchronize());
+    return first ? fail(first, first_msg) : 0;
+}
+
 int mpm_rebuild_mapping(mpm_handle_t e, int sort) {
     READY(e);
+    may_resort(e, 0.f);
     launch_rebuild(e);
     if (sort) {
         REQUIRE(!e->dp.dist.on, "RebuildMapping(sort = true) is not available on a partitioned domain");
@@ -618,6 +729,7 @@ int mpm_update_grid_from_sums(mpm_handle_t e, int bc) {
 
 int mpm_substep_begin(mpm_handle_t e, float dt) {
     READY(e);
+    may_resort(e, dt);
     launch_rebuild(e);
     launch_fem_p2g(e, dt);
     hipLaunchKernelGGL(k_grid<0>, dim3(e->g_grid), dim3(256), 0, e->stream, e->dp, GridColliders{});
@@ -664,6 +776,7 @@ static uint64_t bits_of(float f) { uint32_t u; std::memcpy(&u, &f, 4); return u;
 int mpm_substep_begin_halo(mpm_handle_t e, float dt, int n, const int* bx_lo, const int* bx_hi, const int* shift_bx,
                            void* const* send_bufs, size_t cap) {
     READY(e);
+    may_resort(e, dt);
     REQUIRE(n >= 0 && n <= 2 && (n == 0 || (bx_lo && bx_hi && shift_bx && send_bufs)), "bad halo zone list");
     REQUIRE(n == 0 || (cap > 0 && cap < (1u << 24)), "bad halo buffer");
     DP p = e->dp;   // per-launch copy: k_grid<0> resets the entry counters of the send buffers
@@ -890,13 +1003,12 @@ static void launch_substep(mpm_engine* e, float dt, const GridColliders& gc, boo
     const bool check = !allow_gate || e->force_check || e->check_every <= 1 || e->dp.dist.on ||
                        (e->step_phase % (unsigned)e->check_every) == 0u;
     e->step_phase += 1;
-    e->dp.gated = check ? 0 : 1;
+    e->dp.gated = check ? 2 : 3;   // (bit 1: it also skips itself while the slab pool is too small, see DP::gated)
     if (check) {
         launch_rebuild(e);
         e->force_check = false;
-    } else {
-        e->maybe_owed = true;
     }
+    e->maybe_owed = true;
     launch_fem_p2g(e, dt);
     launch_grid(e, gc);
     e->dp.lean_g2p = lean && !e->dp.dist.on;
@@ -937,6 +1049,7 @@ int mpm_run_substeps(mpm_handle_t e, int n, float dt, int bc) {
     // MPM_GRAPH=<substeps per graph> replays captured graphs; measured slower than plain stream
     // dispatch on ROCm 7.2, hence opt-in
     const int graph_len = e->graph_len;
+    may_resort(e, dt);
     GridColliders gc;
     if (int rc = grid_colliders_for(e, bc, &gc)) return rc;
     int s = 0;
@@ -958,6 +1071,7 @@ int mpm_profile_substeps(mpm_handle_t e, int n, float dt, int bc, float* phase_m
     GridColliders gc;
     if (int rc = grid_colliders_for(e, bc, &gc)) return rc;
     const int NE = MPM_PHASE_COUNT + 1;
+    may_resort(e, dt);
     std::vector<hipEvent_t> ev((size_t)n * NE);
     for (auto& x : ev) HIP_TRY(hipEventCreate(&x));
     for (int s = 0; s < n; ++s) {
@@ -1146,7 +1260,13 @@ int mpm_dist_init(mpm_handle_t e, const mpm_dist_config_t* cfg) {
     hipLaunchKernelGGL(k_dist_init_roles, dim3(e->g_np), dim3(256), 0, e->stream, e->dp);
     int one = 1;
     H2D(e, &e->dp.ctl->need_rebuild, &one, sizeof(int));
+    may_resort(e, 0.f);
     launch_rebuild(e);
+    {
+        Ctl c;
+        D2H(e, &c, e->dp.ctl, sizeof(Ctl));
+        if (int rc = recover_slab_overflow(e, c)) return rc;
+    }
     return mpm_sync(e);
 }
 
@@ -1200,6 +1320,11 @@ int mpm_set_grid_colliders(mpm_handle_t e, size_t n, const mpm_grid_collider_t* 
     REQUIRE(e, "null handle");
     REQUIRE(n <= (size_t)MAX_GRID_COLLIDERS, "too many grid colliders (at most 16)");
     REQUIRE(n == 0 || colliders, "null collider array");
+    if (e->finalized) {
+        // substeps that mpm_run_substeps deferred are owed with the table they were enqueued with
+        if (int rc = use(e)) return rc;
+        if (int rc = settle(e)) return rc;
+    }
     GridColliders gc{};
     for (size_t k = 0; k < n; ++k) {
         const mpm_grid_collider_t& c = colliders[k];

@@ -11,6 +11,7 @@
 #include "mpm_rebuild.h"
 #include "mpm_step.h"
 #include "mpm_contact_dev.h"
+#include "mpm_trace.h"
 
 using namespace mpm;
 

@@ -42,11 +42,21 @@ __global__ __launch_bounds__(256) void k_rb_count(DP p) {
     // too: the order inside a block only has to be approximately by cell.)
     float px = xq.x, py = xq.y, pz = xq.z;
     if (p.anticip > 0.f) {
-        const float4 vq = S.q[1][ii];
+        float vx, vy, vz;
+        if (listed && ii < p.Nf) {
+            // a face particle moves with the mean velocity of its corners (CalcFemStateAndForce puts it there before
+            // anything else looks at it); its own velocity record may be a substep old (lean GridToParticle)
+            const float4 f3 = S.fq[3][ii];
+            const float4 a = S.q[1][__float_as_int(f3.y)], b = S.q[1][__float_as_int(f3.z)], c = S.q[1][__float_as_int(f3.w)];
+            vx = (a.x + b.x + c.x) / 3.f; vy = (a.y + b.y + c.y) / 3.f; vz = (a.z + b.z + c.z) / 3.f;
+        } else {
+            const float4 vq = S.q[1][ii];
+            vx = vq.x; vy = vq.y; vz = vq.z;
+        }
         const float A = 1.75f;
-        px += fminf(fmaxf(vq.x * p.anticip, -A), A) * p.dx;
-        py += fminf(fmaxf(vq.y * p.anticip, -A), A) * p.dx;
-        pz += fminf(fmaxf(vq.z * p.anticip, -A), A) * p.dx;
+        px += fminf(fmaxf(vx * p.anticip, -A), A) * p.dx;
+        py += fminf(fmaxf(vy * p.anticip, -A), A) * p.dx;
+        pz += fminf(fmaxf(vz * p.anticip, -A), A) * p.dx;
     }
     uint32_t bx = base_cell(px, p.dxinv), by = base_cell(py, p.dxinv), bz = base_cell(pz, p.dxinv);
     // (a negative coordinate saturates to cell 0 in the conversion, so test the float)
@@ -298,10 +308,13 @@ __global__ __launch_bounds__(1024) void k_rb_tables(DP p) {
             it += ni;
         }
         n_items = (unsigned)total_items;
-        // (capS <= capI: the slab pool is sized by the blocks actually in use and grown by the host
-        // when it fills up; running out between two synchronisation points is a capacity error)
+        if (tid == 0) c->n_items_wanted = n_items;
+        // (capS <= capI: the slab pool is sized by the blocks actually in use and grown by the host when it fills
+        // up.  Running out is reported with the count that was wanted: substeps of mpm_run_substeps skip themselves
+        // until the host has grown the pool and repeated this re-sort; phase-by-phase substeps cannot be repeated,
+        // for them it ends as a capacity error)
         if (n_items > p.capS) {
-            if (tid == 0) atomicOr(&c->error, ERR_CAPACITY);
+            if (tid == 0) atomicOr(&c->error, ERR_SLABS);
             n_items = p.capS;
         }
         __syncthreads();

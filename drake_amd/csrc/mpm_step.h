@@ -17,7 +17,9 @@ namespace mpm {
 // cost ~3 us each when idle).  A substep enqueued without them checks here whether a re-sort is pending
 // (raised by the G2P of an earlier substep): if so all of its kernels return at once and the host runs
 // that substep again, with the re-sort, at its next synchronisation point.
-MPM_DEV bool gated_out(const DP& p) { return p.gated && p.ctl->need_rebuild; }
+MPM_DEV bool gated_out(const DP& p) {
+    return ((p.gated & 1) && p.ctl->need_rebuild) || ((p.gated & 2) && (p.ctl->error & ERR_SLABS));
+}
 
 __global__ __launch_bounds__(256) void k_fem(DP p, float dt) {
     if (gated_out(p)) return;

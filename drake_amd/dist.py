@@ -168,10 +168,8 @@ class DomainChain(HaloChain):
         """Gives the engine what the distributed contact solve (mpm_update_contact on a partitioned
         domain) needs when there is no native chain: a neighbour exchange of device buffers and an
         all-reduce of a few doubles, both over this chain's process group (staged through the host)."""
-        import ctypes
         import numpy as np
-        hip = ctypes.CDLL("libamdhip64.so")
-        hip.hipMemcpy.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
+        e = self.e   # copies go through the engine (its stream, its HIP runtime): nothing here opens libamdhip64
 
         def exchange(sl, sr, rl, rr, nbytes):
             reqs, hosts = [], []
@@ -179,7 +177,7 @@ class DomainChain(HaloChain):
                 if n is None:
                     continue
                 out = torch.empty(nbytes, dtype=torch.uint8)
-                assert hip.hipMemcpy(out.data_ptr(), src, nbytes, 2) == 0   # device -> host
+                e.memcpy_d2h(out.data_ptr(), src, nbytes)
                 inn = torch.empty(nbytes, dtype=torch.uint8)
                 reqs.append(dist.isend(out, n, group=self.group))
                 reqs.append(dist.irecv(inn, n, group=self.group))
@@ -187,7 +185,7 @@ class DomainChain(HaloChain):
             for r in reqs:
                 r.wait()
             for inn, dst, _ in hosts:
-                assert hip.hipMemcpy(dst, inn.data_ptr(), nbytes, 1) == 0   # host -> device
+                e.memcpy_h2d(dst, inn.data_ptr(), nbytes)
 
         def allreduce(values: "np.ndarray"):
             t = torch.from_numpy(values)

@@ -56,7 +56,7 @@ int main(int argc, char** argv) {
                 solver.UpdateGrid(&state);
                 solver.GridToParticle(&state, dt);
             }
-            solver.GpuSync(&state);
+            solver.GpuSync();   // the reference's call, cuda_mpm_test.cc:73: no state argument
             const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
             std::printf("step=%d time=%.3fms\n", frame, ms);
         }

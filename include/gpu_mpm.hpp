@@ -154,7 +154,7 @@ class GpuMpmSolver {
     void ParticleToGrid(GpuMpmState<T>* s, const T& dt) const { mpm_check(mpm_particle_to_grid(s->h_, dt)); }
     void UpdateGrid(GpuMpmState<T>* s, int mpm_bc = -1) const { mpm_check(mpm_update_grid(s->h_, mpm_bc)); }
     void GridToParticle(GpuMpmState<T>* s, const T& dt) const { mpm_check(mpm_grid_to_particle(s->h_, dt)); }
-    void GpuSync() const {}
+    void GpuSync() const { mpm_check(mpm_device_synchronize()); }   // cuda_mpm_solver.cu:164-166
     void GpuSync(GpuMpmState<T>* s) const { mpm_check(mpm_sync(s->h_)); }
     void SyncParticleStateToCpu(GpuMpmState<T>* s) const {
         s->h_positions_.resize(s->n_particles());

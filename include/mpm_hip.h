@@ -234,6 +234,23 @@ MPM_API int mpm_grid_to_particle(mpm_handle_t h, float dt);
  * device error flags as MPM_ERR_DRIFT / MPM_ERR_CAPACITY / MPM_ERR_DOMAIN. */
 MPM_API int mpm_sync(mpm_handle_t h);
 
+/* GpuMpmSolver::GpuSync() as the reference declares and calls it -- no state argument, a
+ * cudaDeviceSynchronize() (cuda_mpm_solver.cu:164-166, cuda_mpm_test.cc:73): every engine the calling
+ * thread's current HIP device holds is brought up to date (substeps that mpm_run_substeps deferred are run,
+ * sticky errors are reported as by mpm_sync -- the first one found is returned), then the whole device is
+ * synchronised.  The handles' own rule applies: no other thread may be inside a call on one of them. */
+MPM_API int mpm_device_synchronize(void);
+
+/* Blocking copies between caller-owned host memory and device memory, ordered on the engine's stream (a plain
+ * hipMemcpy on the null stream is not ordered with it).  For transports that stage the engine's exchange buffers
+ * through the host (mpm_dist_set_transport): they must not bring a second HIP runtime into the process. */
+MPM_API int mpm_memcpy_d2h(mpm_handle_t h, void *dst_host, const void *src_device, size_t bytes);
+MPM_API int mpm_memcpy_h2d(mpm_handle_t h, void *dst_device, const void *src_host, size_t bytes);
+
+/* Tests: substeps that mpm_run_substeps has enqueued but that found a re-sort pending and are still owed
+ * (run by the next call that synchronises).  Waits for the stream; does NOT run them. */
+MPM_API int mpm_debug_owed_substeps(mpm_handle_t h, uint32_t *out);
+
 /* Bitwise reproducibility from run to run (off by default; the environment variable
  * MPM_DETERMINISTIC=1 turns it on at mpm_create).  A substep never uses float atomics, but the
  * engine's re-sort orders the particles inside a cell by the arrival of integer atomics; with

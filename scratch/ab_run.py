@@ -27,6 +27,6 @@ if len(sys.argv) > 1 and sys.argv[1] == "--child":
 else:
     for r in range(int(os.environ.get("MPM_AB_ROUNDS", "2"))):
         for name in sys.argv[1:]:
-            lib = os.path.join(ROOT, "drake_amd", "variants", f"libmpm_hip_{name}.so")
+            lib = os.environ.get("MPM_HIP_LIBRARY") if name == "cur" else os.path.join(ROOT, "drake_amd", "variants", f"libmpm_hip_{name}.so")
             env = dict(os.environ, MPM_HIP_LIBRARY=lib)
             subprocess.run([sys.executable, os.path.abspath(__file__), "--child", name], env=env, timeout=300)

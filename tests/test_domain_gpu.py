@@ -152,7 +152,12 @@ def _contact_worker(rank, world, cuts, port, q, exact):
         g.grid_to_particle(DT)
         out.append((n, r, cs, f.copy()))
     g.gpu_sync()
-    q.put((rank, g.dist_roles(), g.download(ARR.POSITIONS), g.download(ARR.VELOCITIES), out, g.stats()))
+    # one HIP runtime in the process: the staged transport copies through the engine, it does not open libamdhip64
+    # itself (two runtimes tear each other's state down at exit)
+    with open("/proc/self/maps") as f:
+        hip_copies = {ln.split()[-1] for ln in f if "libamdhip64" in ln}
+    st = dict(g.stats(), hip_runtime_copies=len(hip_copies))
+    q.put((rank, g.dist_roles(), g.download(ARR.POSITIONS), g.download(ARR.VELOCITIES), out, st))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -202,6 +207,7 @@ def test_distributed_contact_solve_matches_single_engine(exact):
     for r in range(world):
         roles, p_r, v_r, out, st = got[r]
         assert st["error_flags"] == 0
+        assert st["hip_runtime_copies"] == 1, st
         own = roles == 1
         pos[own], vel[own] = p_r[own], v_r[own]
     for step in range(3):

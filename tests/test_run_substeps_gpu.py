@@ -1,0 +1,123 @@
+"""mpm_run_substeps against the phase-by-phase calls it batches: gated re-sort launches (substeps that find a
+re-sort pending are deferred and run again by the next synchronising call), GridToParticle's lean mode between the
+substeps of a batch, a collider table that changes between batches, and GpuSync() without a state argument
+(cuda_mpm_solver.cu:164-166, called as in cuda_mpm_test.cc:73)."""
+import numpy as np
+import pytest
+
+from drake_amd import scenes
+
+pytestmark = pytest.mark.gpu
+
+DT = 5e-4
+
+
+def _engine(deterministic=True):
+    from drake_amd import GpuMpm
+    g = GpuMpm(7)
+    # (the re-sort orders every cell's particles by their previous slot: trajectories are then a pure function of the
+    # call sequence's arithmetic, and the batched and the phase-by-phase runs can be compared to the bit)
+    g.set_deterministic(deterministic)
+    sheets = scenes.cloth_stack(4, 100, 7, z0=0.45, vel_amp=0.3, seed=3)
+    for pos, vel, idx in sheets:
+        vel[:, 0] += 2.0     # fast sideways: a re-sort every few substeps
+        vel[:, 1] -= 1.0
+    scenes.populate(g, sheets)
+    return g
+
+
+def _phase_substep(g, bc):
+    g.rebuild_mapping(False)
+    g.calc_fem_state_and_force(DT)
+    g.particle_to_grid(DT)
+    g.update_grid(bc)
+    g.grid_to_particle(DT)
+
+
+def test_uneven_batches_match_phase_calls():
+    from drake_amd import ARR as A
+    a, b = _engine(), _engine()
+    n, done = 240, 0
+    rng = np.random.default_rng(0)
+    while done < n:
+        k = int(min(n - done, rng.integers(1, 9)))
+        a.run_substeps(k, DT, 0)
+        done += k
+        if rng.random() < 0.2:
+            a.download(A.POSITIONS)          # a synchronising call in the middle
+    for _ in range(n):
+        _phase_substep(b, 0)
+    sa, sb = a.stats(), b.stats()
+    assert sa["error_flags"] == 0 and sb["error_flags"] == 0
+    assert sa["substeps"] == sb["substeps"] == n
+    assert sa["rebuilds"] > 5, sa                      # the scene does exercise the deferral
+    assert sa["rebuilds"] == sb["rebuilds"]
+    # same arithmetic in the same order (fused vertex forces, lean GridToParticle and deferred substeps included)
+    for arr in (A.POSITIONS, A.VELOCITIES, A.AFFINE, A.DEFORMATION_GRADIENTS):
+        xa, xb = a.download(arr), b.download(arr)
+        assert np.isfinite(xa).all()
+        assert np.array_equal(xa, xb), (arr, float(np.abs(xa - xb).max()))
+
+
+def test_last_substep_of_a_batch_writes_the_face_velocities():
+    """GridToParticle skips the velocity record of face particles between the substeps of a batch (nothing inside
+    a substep reads it); what a caller downloads after the batch is the last substep's, as after phase calls."""
+    from drake_amd import ARR as A
+    a, b = _engine(), _engine()
+    a.run_substeps(7, DT, -1)
+    for _ in range(7):
+        _phase_substep(b, -1)
+    nf = a.n_faces
+    idx_a, idx_b = a.download(A.INDEX_MAPPINGS), b.download(A.INDEX_MAPPINGS)
+    va, vb = a.download(A.VELOCITIES), b.download(A.VELOCITIES)
+    ca, cb = a.download(A.AFFINE), b.download(A.AFFINE)
+    assert np.array_equal(idx_a, idx_b)
+    faces = idx_a[:nf]
+    scale = float(np.abs(vb).max())
+    assert float(np.abs(va[faces] - vb[faces]).max()) < 1e-4 * scale
+    assert float(np.abs(ca[faces] - cb[faces]).max()) < 1e-4 * float(np.abs(cb).max())
+    # one substep earlier the face velocities were different (the test would not notice a stale record otherwise)
+    c = _engine()
+    for _ in range(6):
+        _phase_substep(c, -1)
+    vc = c.download(A.VELOCITIES)
+    assert float(np.abs(vc[faces] - vb[faces]).max()) > 1e-3 * scale
+
+
+def test_collider_table_changed_between_batches():
+    """mpm_set_grid_colliders between two mpm_run_substeps batches: substeps deferred by the first batch are run with
+    the table they were enqueued with (they used to be replayed against the new one)."""
+    from drake_amd import ARR as A, BC_TABLE, GridCollider
+    a, b = _engine(), _engine()
+    tables = [[GridCollider(shape=0, mode=1, p=(0.5 + 0.02 * k, 0.5, 0.42), radius=0.08, v=(0.3, 0.0, 0.0), friction=0.3)]
+              for k in range(12)]
+    rng = np.random.default_rng(1)
+    counts = [int(rng.integers(7, 16)) for _ in tables]
+    for tb, k in zip(tables, counts):
+        a.set_grid_colliders(tb)
+        a.run_substeps(k, DT, BC_TABLE)
+    for tb, k in zip(tables, counts):
+        b.set_grid_colliders(tb)
+        for _ in range(k):
+            _phase_substep(b, BC_TABLE)
+    assert a.stats()["rebuilds"] > 2     # (re-sorts happened inside the batches)
+    assert np.array_equal(a.download(A.POSITIONS), b.download(A.POSITIONS))
+    assert np.array_equal(a.download(A.VELOCITIES), b.download(A.VELOCITIES))
+
+
+def test_gpu_sync_without_a_state_argument():
+    """solver.GpuSync() (no argument: the reference's cudaDeviceSynchronize) after mpm_run_substeps: every engine of
+    the device is complete afterwards -- nothing owed, all substeps done, the stream idle."""
+    from drake_amd import ARR as A, GpuMpm
+    a, other, b = _engine(), _engine(), _engine()
+    for _ in range(12):
+        a.run_substeps(5, DT, -1)
+        other.run_substeps(3, DT, -1)
+        GpuMpm.device_synchronize()
+        assert a.owed_substeps() == 0 and other.owed_substeps() == 0
+    for _ in range(60):
+        _phase_substep(b, -1)
+    # read the raw state WITHOUT another settling call in between: owed == 0 means the download below adds nothing
+    sa = a.stats()
+    assert sa["substeps"] == 60 and sa["error_flags"] == 0 and sa["rebuilds"] > 2
+    assert np.array_equal(a.download(A.POSITIONS), b.download(A.POSITIONS))
