@@ -428,9 +428,11 @@ static int update_contact(mpm_engine* e, int frame, int substep, float dt, float
             hipLaunchKernelGGL(k_ct_apply, dim3(CT_ROWS), dim3(CT_WG), 0, s, p, c, 1);
             hipLaunchKernelGGL(k_ct_exact_finish, dim3(1), dim3(64), 0, s, c);
         };
-        // (a search that never terminates cannot happen -- the root finder is bounded -- but the launches are)
+        // (a search that never terminates cannot happen -- the root finder stops after 200 evaluations, which in
+        // float it often needs: |dx| < 3e-9 is out of reach -- but the launches are bounded too: every Newton
+        // iteration may take 200 / PROBES + 1 patterns)
         if (int rc = run_batches(e, pattern, ct_batch(0, 1), ct_batch(1, 1), max_iters, &st,
-                                 4 * max_iters + 64))
+                                 (200 / PROBES + 2) * max_iters + 64))
             return rc;
         iters = st.iters;
         residual = st.residual;

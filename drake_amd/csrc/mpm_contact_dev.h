@@ -1284,6 +1284,7 @@ __global__ void k_ct_exact_finish(ContactDev c) {
     st->iters += 1;
     st->ls_total += st->ls_evals;
     st->ls_phase = 0;
+    st->alpha_probe = 0.f;   // the next direction's search starts with (E, dE, d2E) at alpha = 0 (cuda_mpm_solver.cu:386-390)
     if (!(st->residual > c.tol) || st->iters >= c.max_iters) st->done = 1;
 }
 

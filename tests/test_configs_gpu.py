@@ -76,11 +76,13 @@ def test_plumbing_64k_full_size_against_the_oracle():
     assert g.stats()["error_flags"] == 0
     pid = g.download(A.PIDS)
     assert np.array_equal(pid, o.pids)    # nobody sorted the slot order
-    sc = natural_scales(o, dt)
     close(g.download(A.POSITIONS), o.pos, scale=1.0, what="64k traj pos")
-    # ten free-running substeps of a stiff cloth amplify the per-step rounding differences
-    close(g.download(A.VELOCITIES), o.vel, scale=sc["vel"], rtol=5e-5, what="64k traj vel")
-    close(g.download(A.DEFORMATION_GRADIENTS), o.F, scale=1.0, rtol=4e-5, what="64k traj F")
+    # Ten free-running substeps of a stiff cloth amplify the per-step rounding differences.  Measured with the oracle
+    # in float and in double (tests/test_precision_gpu.py, same scene): after 10 substeps the float oracle is 2.0e-4 of
+    # max|v| and 3.6e-5 in F away from the double one, the engine likewise; the two float results may differ by the
+    # sum, and the tolerances are 3x the measured distance, against the plain maximum of the field
+    close(g.download(A.VELOCITIES), o.vel, rtol=6e-4, what="64k traj vel")
+    close(g.download(A.DEFORMATION_GRADIENTS), o.F, scale=1.0, rtol=1.1e-4, what="64k traj F")
     o.rebuild_mapping(False)
     assert (g.download(A.SORT_KEYS) == o.sort_keys).mean() > 0.999
     assert np.array_equal(g.download(A.GRID_TOUCHED_FLAGS), o.g_flags)
@@ -103,11 +105,12 @@ def test_cloth_1m_full_size_against_the_oracle():
         o.substep(dt, -1)
     g.gpu_sync()
     assert g.stats()["error_flags"] == 0
-    sc = natural_scales(o, dt)
     close(g.download(A.POSITIONS), o.pos, scale=1.0, what="1m traj pos")
-    # (free-running substeps of a stiff cloth amplify the per-step rounding differences: as for config 1)
-    close(g.download(A.VELOCITIES), o.vel, scale=sc["vel"], rtol=5e-5, what="1m traj vel")
-    close(g.download(A.DEFORMATION_GRADIENTS), o.F, scale=1.0, rtol=8e-5, what="1m traj F")
+    # (as for config 1; measured after 4 substeps on this scene: float oracle vs double oracle 1.2e-3 of max|v| and
+    # 5.1e-5 in F -- the cloth starts with velocities of 0.01 m/s, the rounding of F alone moves them by that much;
+    # 3x the measured distance, against the plain maximum of the field)
+    close(g.download(A.VELOCITIES), o.vel, rtol=3.6e-3, what="1m traj vel")
+    close(g.download(A.DEFORMATION_GRADIENTS), o.F, scale=1.0, rtol=1.5e-4, what="1m traj F")
 
 
 def test_cloth_8m_on_256_grid_properties():

@@ -4,7 +4,34 @@ import pytest
 
 from tests.helpers import IMPULSE_RTOL
 
-from tests.helpers import build_pair, close, natural_scales, solve_tolerance
+from tests.helpers import build_pair, close, natural_scales, oracle_f64_copy, solve_tolerance
+
+# A converged float oracle may stop up to this factor above the solver's tolerance ("Tiny Alpha" steps); beyond
+# that the double-precision build of the same source is the reference (its energy sums do not stall)
+MAX_STALL = 3.0
+
+
+def converged_reference(o, o64, ro, solve64):
+    """(reference state, factor by which its residual exceeds kTol) for comparing a converged engine solve"""
+    if ro["residual"] <= MAX_STALL * 1e-4:
+        return o, max(1.0, ro["residual"] / 1e-4)
+    r64 = solve64(o64)
+    assert r64["residual"] <= 1e-4, (r64, ro)
+    return o64, 1.0
+
+
+def close_rel(a, b, frac, what):
+    """Relative bounds on top of the solver-tolerance bound (a regression of the Newton path must not
+    hide inside the tail tolerance): rms(a - b) <= frac * rms(b), and no single entry further off than
+    5 * frac * max|b| (two solves that stop at different points of the noise-limited tail differ most at single
+    contacts: measured up to 5.6 % of max|v| on the 1M-particle config 3, 0.9 % rms)."""
+    from tests.helpers import MARGINS
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    err, ref = float(np.abs(a - b).max()), float(np.abs(b).max())
+    rms_e, rms_b = float(np.sqrt(np.mean((a - b) ** 2))), float(np.sqrt(np.mean(b ** 2)))
+    MARGINS.append((rms_e / (frac * rms_b + 1e-300), what + " (rms, relative)", frac, rms_e / (rms_b + 1e-300), err / (ref + 1e-300)))
+    assert rms_e <= frac * rms_b, f"{what}: rms error {rms_e:.3e} > {frac:.0%} of rms(ref) {rms_b:.3e}"
+    assert err <= 5 * frac * ref, f"{what}: {err:.3e} > {5 * frac:.0%} of max|ref| {ref:.3e}"
 
 pytestmark = pytest.mark.gpu
 DT = 1e-3
@@ -73,6 +100,7 @@ def test_update_contact_matches_oracle(exact, params, mu):
         # (iteration limit: the reference's 2000, cuda_mpm_solver.cu:234; 600 for config 3, where a stalled
         # oracle -- see below -- would otherwise spend minutes of CPU time on its last 1400 iterations)
         cap = 600 if params == "config3" else 0
+        o64 = oracle_f64_copy(o)
         ro = o.update_contact(DT, mu, stiffness, damping, exact_line_search=exact, max_iters=cap)
         rg = g.update_contact(DT, mu, stiffness, damping, exact_line_search=exact, max_newton_iterations=cap)
         sc = natural_scales(o, DT)
@@ -91,11 +119,13 @@ def test_update_contact_matches_oracle(exact, params, mu):
             assert 0 < rg["iterations"] < cap and 0 < ro["iterations"] <= cap, (rg, ro, step, _diagnose(g, o))
         # (the oracle's float sums can stall above the tolerance -- "Tiny Alpha" steps, cuda_mpm_solver.cu:523-526 --
         # until it runs into its iteration limit; how often depends on the OpenMP summation order of the run.
-        # Its result is then only as close to the solution as its residual says: the comparison below
-        # widens by that factor)
-        assert rg["residual"] <= 1e-4 and ro["residual"] <= 5e-3
-        stalled = max(1.0, ro["residual"] / 1e-4)
+        # Up to MAX_STALL times the tolerance the comparison widens by that factor; beyond it the reference is the
+        # double-precision build of the oracle, which converges)
+        assert rg["residual"] <= 1e-4
         close(g.download(A.CONTACT_VEL0), o.c_vel0, scale=sc["vel"], what="contact vel0")
+        o_float = o
+        o, stalled = converged_reference(o_float, o64, ro, lambda d: d.update_contact(
+            DT, mu, stiffness, damping, exact_line_search=exact, max_iters=cap or 2000))
         # converged solves agree to the solver's stopping tolerance (rounding-level agreement: the
         # single-iteration test below)
         dofs = g.contact_stats()["dofs"]
@@ -112,11 +142,18 @@ def test_update_contact_matches_oracle(exact, params, mu):
         fscale = float(np.abs(o.F_f).max())
         close(f_g, o.F_f, scale=fscale, rtol=imp_rtol, what="body impulse")
         close(tau_g, o.F_tau, scale=max(float(np.abs(o.F_tau).max()), fscale), rtol=imp_rtol, what="body angular impulse")
+        # whatever the tail tolerance allows, a converged solve is within 2 % rms of the reference's contact velocities
+        # (10 % of the largest one at any single contact) and within 2 % on the impulses
+        close_rel(g.download(A.CONTACT_VEL), o.c_vel, 0.02, "contact vel")
+        close_rel(f_g, o.F_f, 0.02, "body impulse")
         # the floor pushes up
         assert f_g[0, 2] < 0  # impulse ON the body is downward
         o.grid_to_particle(DT)
         g.grid_to_particle(DT)
         close(g.download(A.VELOCITIES), o.vel, scale=1.0, rtol=tol, what="vel after contact step")
+        if o is not o_float:   # the float oracle carries the trajectory on
+            o_float.grid_to_particle(DT)
+            o = o_float
     g.gpu_sync()
 
 
@@ -200,6 +237,56 @@ def test_single_newton_iteration_matches_oracle(exact, params, mu, scene):
     close(f_g, o.F_f, scale=float(np.abs(o.F_f).max()), rtol=10 * rt, what="1-iteration body impulse")
 
 
+@pytest.mark.parametrize("exact", [False, True])
+def test_five_newton_iterations_match_oracle(exact):
+    """max_newton_iterations = 5 on both sides, config-3 parameters, the dense scene: the
+    solver's stopping tolerance still plays no role, but unlike the single iteration this goes through the lazy update
+    (k_ct_tile reading v - alpha D, k_ct_node_dir writing it back), the batched / pipelined loop and, for the exact
+    search, the device-resident root finder across pattern boundaries (cuda_mpm_solver.cu:274-570)."""
+    from drake_amd import ARR as A
+    from oracle import oracle as orc
+    stiffness, damping, DT = CONTACT_PARAMS["config3"]
+    o, g = build_pair(layers=4, res=40, side=0.15, z0=Z_FLOOR - 0.02, vel_amp=0.3)
+    o.vel[:, 2] -= 0.5
+    o.vel[:, 0] += 0.3
+    g.upload_particle_state(o.pos, o.vel, o.C, None, o.F)
+    for s in (o, g):
+        s.reallocate_external_bodies(1)
+        s.rebuild_mapping(False)
+        s.calc_fem_state_and_force(DT)
+        s.particle_to_grid(DT)
+        s.update_grid(-1)
+    cp = floor_contacts(g.sync_particle_state_to_cpu())
+    assert cp[0].size > 5000
+    o.copy_contact_pairs(orc.ContactPairs(*cp))
+    g.copy_contact_pairs(*cp)
+    ro = o.update_contact(DT, 1.0, stiffness, damping, exact_line_search=exact, max_iters=5)
+    rg = g.update_contact(DT, 1.0, stiffness, damping, exact_line_search=exact, max_newton_iterations=5)
+    cs = g.contact_stats()
+    assert ro["iterations"] == rg["iterations"] == cs["iterations"] == 5
+    # Backtracking: 1e-4 (measured 2e-6 .. 7e-6 per iteration: the two paths do not drift apart).  Exact search: the
+    # root finder works on dE/dalpha, a float sum that is noise below ~1e-6 of its terms; with x_tol = 3e-9 it ends
+    # after its 200 evaluations (or earlier, when the noise happens to cross |f'| < 1e-8) wherever the noise leaves it
+    # -- on BOTH sides, cuda_mpm_solver.cu:383-471 -- so alpha agrees to ~5e-5 and five iterations compound to ~3e-4
+    rt = 1e-3 if exact else 1e-4
+    close(g.download(A.GRID_DIR), o.g_D, rtol=rt, what="5-iteration Dir")
+    assert cs["dofs"] == ro["dofs"] > 0
+    close([cs["norm_dir_sq"]], [ro["norm_dir_sq"]], rtol=rt, what="5-iteration |Dir|^2")
+    close([rg["residual"]], [ro["residual"]], rtol=rt, what="5-iteration residual")
+    close([cs["E0"]], [ro["E0"]], rtol=rt, what="5-iteration E(0)")
+    close([cs["energy"]], [ro["E1"]], scale=abs(ro["E0"]), rtol=rt, what="5-iteration E(alpha)")
+    if exact:
+        close([cs["alpha"]], [ro["alpha"]], scale=1.0, rtol=2e-4, what="5-iteration alpha (exact search)")
+    else:
+        assert cs["alpha"] == ro["alpha"]
+    sc = natural_scales(o, DT)
+    wgt = (o.g_m / o.g_m.max())[:, None]
+    close(g.download(A.GRID_MOMENTUM) * wgt, o.g_mv * wgt, scale=sc["vel"], rtol=rt, what="5-iteration grid v")
+    close(g.download(A.CONTACT_VEL), o.c_vel, scale=sc["vel"], rtol=rt, what="5-iteration contact vel")
+    tau_g, f_g = g.external_body_force_to_host()
+    close(f_g, o.F_f, scale=float(np.abs(o.F_f).max()), rtol=10 * rt, what="5-iteration body impulse")
+
+
 def test_config3_full_size_against_the_oracle():
     """BASELINE config 3 at its full size: the 1M-particle stack (999,952 particles, 128^3) with its lowest
     sheets below a floor, the bagging demo's contact parameters (k = 1e6, d = 1e-5, mu = 1, dt = 2e-4).
@@ -247,16 +334,19 @@ def test_config3_full_size_against_the_oracle():
     close(g.download(A.GRID_MOMENTUM) * wgt, o.g_mv * wgt, scale=sc["vel"], what="1m 1-iteration grid v")
     # the converged solve from the same state
     cp = prepare()
+    o64 = oracle_f64_copy(o)
     ro = o.update_contact(DT, 1.0, stiffness, damping, max_iters=600)
     rg = g.update_contact(DT, 1.0, stiffness, damping, max_newton_iterations=600)
-    assert rg["residual"] <= 1e-4 and ro["residual"] <= 5e-3, (rg, ro)
-    stalled = max(1.0, ro["residual"] / 1e-4)
+    assert rg["residual"] <= 1e-4, (rg, ro)
+    o, stalled = converged_reference(o, o64, ro, lambda d: d.update_contact(DT, 1.0, stiffness, damping, max_iters=600))
     tol = solve_tolerance(g.contact_stats()["dofs"], iterations=max(rg["iterations"], ro["iterations"])) * stalled
     close(g.download(A.CONTACT_VEL), o.c_vel, scale=1.0, rtol=tol, what="1m contact vel")
+    close_rel(g.download(A.CONTACT_VEL), o.c_vel, 0.02, "1m contact vel")
     tau_g, f_g = g.external_body_force_to_host()
     assert f_g[0, 2] < 0
     close(f_g, o.F_f, scale=float(np.abs(o.F_f).max()), rtol=IMPULSE_RTOL * tol / solve_tolerance(g.contact_stats()["dofs"]),
           what="1m body impulse")
+    close_rel(f_g, o.F_f, 0.02, "1m body impulse")
     g.gpu_sync()
     assert g.stats()["error_flags"] == 0
 

@@ -125,9 +125,11 @@ def test_trajectory_with_sorts_and_rebuilds():
         out[pid_g] = a
         return out
 
-    # after 20 steps rounding differences have been amplified by the stiff cloth (observed: 2e-5 of scale)
+    # after 20 steps rounding differences have been amplified by the stiff cloth: against the plain max|v| (1 m/s
+    # here), 3e-4 = the order the float-vs-double oracle distance reaches on the benchmark scenes in 10 substeps
+    # (tests/test_precision_gpu.py); observed 6e-5
     close(orig(g.download(A.POSITIONS)), so["pos"], scale=1.0, rtol=1e-5, what="traj pos")
-    close(orig(g.download(A.VELOCITIES)), so["vel"], scale=sc["vel"], rtol=1e-4, what="traj vel")
+    close(orig(g.download(A.VELOCITIES)), so["vel"], rtol=3e-4, what="traj vel")
     close(orig(g.download(A.VOLUMES)), so["vol"], what="traj vol")
     # index maps, per original particle: equal unless the particle sits within rounding of a cell face
     o.rebuild_mapping(False)  # keys of the current positions (the engine derives them on demand)

@@ -1,0 +1,119 @@
+"""What float rounding alone does to the MPM state, measured instead of argued.
+
+The oracle is built twice from the same source: in float, like the reference (settings.h:37), and in double
+(`make -C oracle f64`).  The distance between the two is the effect of float rounding on every field -- no
+implementation that computes in float can be expected to sit closer to the exact result than that.  The engine
+(float, different summation order, fused multiply-adds) must be as close to the double result as the float oracle is,
+within a factor of two, per field, after every phase of a substep and over 4- and 10-substep trajectories:
+
+        max |engine - oracle64|  <=  2 * max |oracle32 - oracle64|
+
+The numbers this test prints are the basis of the velocity tolerances in tests/helpers.py: on
+BASELINE configs 1 and 2 the float oracle itself is 2e-4 .. 7e-4 of max|v| away from the double one after 10 substeps
+(stiff explicit update: one ulp of F is dt * E / (rho * dx) * 1e-7 of velocity per substep, and it compounds), so
+"1e-5 relative" on velocities over a trajectory is below what float arithmetic delivers on either side."""
+import numpy as np
+import pytest
+
+from drake_amd import scenes
+
+pytestmark = pytest.mark.gpu
+
+DT = 1e-3
+FACTOR = 2.0
+REPORT = []
+
+
+def _triple(config):
+    from drake_amd import GpuMpm
+    from oracle import oracle as orc
+    bits, layers, res = scenes.CONFIGS[config]
+    sheets = scenes.cloth_stack(layers, res, bits)
+    o32, o64, g = orc.OracleMpm(bits), orc.OracleMpm(bits, real=np.float64), GpuMpm(bits)
+    for pos, vel, idx in sheets:
+        for s in (o32, o64, g):
+            s.add_qr_cloth(pos, vel, idx)
+    for s in (o32, o64, g):
+        s.finalize()
+    return o32, o64, g
+
+
+def _check(what, gpu, a32, a64, weight=None, floor=0.0):
+    """max|gpu - o64| <= FACTOR * max|o32 - o64| (+ floor: quantities that are exact in float on one side)"""
+    gpu, a32, a64 = (np.asarray(x, np.float64) for x in (gpu, a32, a64))
+    if weight is not None:
+        gpu, a32, a64 = gpu * weight, a32 * weight, a64 * weight
+    e_gpu, e_32 = float(np.abs(gpu - a64).max()), float(np.abs(a32 - a64).max())
+    ref = max(float(np.abs(a64).max()), float(np.abs(a32).max()), 1e-300)   # (an undeformed cloth has tau = 0 in double)
+    rms_gpu, rms_32 = float(np.sqrt(np.mean((gpu - a64) ** 2))), float(np.sqrt(np.mean((a32 - a64) ** 2)))
+    REPORT.append((what, e_gpu / ref, e_32 / ref, rms_gpu / ref, rms_32 / ref))
+    assert np.isfinite(gpu).all(), what
+    assert e_gpu <= FACTOR * e_32 + floor, (f"{what}: engine {e_gpu:.3e} from the double oracle, float oracle {e_32:.3e} "
+                                            f"(max|ref| {ref:.3e})")
+    # and not systematically worse either
+    assert rms_gpu <= FACTOR * rms_32 + floor, f"{what}: rms engine {rms_gpu:.3e}, float oracle {rms_32:.3e}"
+
+
+def _phases(o32, o64, g, tag):
+    from drake_amd import ARR as A
+    for s in (o32, o64, g):
+        s.rebuild_mapping(False)
+        s.calc_fem_state_and_force(DT)
+    _check(f"{tag} fem F", g.download(A.DEFORMATION_GRADIENTS), o32.F, o64.F)
+    _check(f"{tag} fem tau", g.download(A.TAUS), o32.taus, o64.taus)
+    _check(f"{tag} fem force", g.download(A.FORCES), o32.forces, o64.forces)
+    _check(f"{tag} fem face v", g.download(A.VELOCITIES), o32.vel, o64.vel)
+    for s in (o32, o64, g):
+        s.particle_to_grid(DT)
+    _check(f"{tag} p2g mass", g.download(A.GRID_MASSES), o32.g_m, o64.g_m)
+    _check(f"{tag} p2g momentum", g.download(A.GRID_MOMENTUM), o32.g_mv, o64.g_mv)
+    assert np.array_equal(g.download(A.GRID_TOUCHED_FLAGS), o32.g_flags)
+    for s in (o32, o64, g):
+        s.update_grid(-1)
+    # (a node's velocity is a quotient of two sums that are both tiny on the stencil fringe; what reaches the
+    # particles is w * v with the same tiny w: mass-weighted, as in tests/test_parity_gpu.py)
+    w = (o64.g_m / o64.g_m.max())[:, None]
+    _check(f"{tag} grid v", g.download(A.GRID_MOMENTUM), o32.g_mv, o64.g_mv, weight=w)
+    _check(f"{tag} grid v*", g.download(A.GRID_V_STAR), o32.g_vstar, o64.g_vstar, weight=w)
+    for s in (o32, o64, g):
+        s.grid_to_particle(DT)
+    _state(o32, o64, g, f"{tag} g2p")
+
+
+def _state(o32, o64, g, tag):
+    from drake_amd import ARR as A
+    _check(f"{tag} x", g.download(A.POSITIONS), o32.pos, o64.pos, floor=1e-7)   # (positions ~0.5: one float ulp is 6e-8)
+    _check(f"{tag} v", g.download(A.VELOCITIES), o32.vel, o64.vel)
+    _check(f"{tag} C", g.download(A.AFFINE), o32.C, o64.C)
+    _check(f"{tag} F", g.download(A.DEFORMATION_GRADIENTS), o32.F, o64.F)
+
+
+@pytest.mark.parametrize("config", ["plumbing_64k", "cloth_1m"])
+def test_engine_is_as_close_to_double_as_the_float_oracle(config):
+    o32, o64, g = _triple(config)
+    # phase by phase in the first substep, then again in the fourth (the cloth is strained by then)
+    _phases(o32, o64, g, f"{config} substep 1")
+    for _ in range(2):
+        for s in (o32, o64, g):
+            s.substep(DT, -1)
+    _phases(o32, o64, g, f"{config} substep 4")
+    _state(o32, o64, g, f"{config} after 4 substeps")
+    for _ in range(6):
+        for s in (o32, o64, g):
+            s.substep(DT, -1)
+    _state(o32, o64, g, f"{config} after 10 substeps")
+    assert g.stats()["error_flags"] == 0
+
+
+def test_zz_report():
+    """(prints the table; the numbers justify the tolerances of tests/helpers.py)"""
+    lines = ["distance from the double-precision oracle, relative to max|field|:  engine max | float oracle max | "
+             "engine rms | float oracle rms"]
+    for what, eg, e3, rg, r3 in REPORT:
+        lines.append(f"  {eg:9.2e} {e3:9.2e} {rg:9.2e} {r3:9.2e}  {what}")
+    print("\n".join(lines))
+    import os
+    out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    if os.path.isdir(out):
+        with open(os.path.join(out, "precision_report.txt"), "w") as f:
+            f.write("\n".join(lines) + "\n")
