@@ -97,6 +97,9 @@ def host_description():
                 cgroup_cpu_quota=quota, cores_available=avail)
 
 
+HOST = None   # host_description(), taken in main() before anything touches the GPU (it forks lscpu)
+
+
 def cpu_baseline(domain_bits, layers, res, dt, budget_s=20.0):
     """The oracle (a port of the reference's kernels to plain C + OpenMP; the reference has no CPU
     path of its own) timed on the host cores on the FULL workload (same scene, grid and dt as the
@@ -104,7 +107,7 @@ def cpu_baseline(domain_bits, layers, res, dt, budget_s=20.0):
     fastest on this box (`cores` = that thread count), the 1-thread rate, and the host's CPU."""
     from drake_amd import scenes
     from oracle import oracle as orc
-    host = host_description()
+    host = HOST or host_description()
     o = orc.OracleMpm(domain_bits)
     o.fast_scatter = True  # atomics-free multi-core scatter (same arithmetic, see oracle/mpm_oracle.c)
     for pos, vel, idx in scenes.cloth_stack(layers, res, domain_bits):
@@ -196,11 +199,32 @@ def contact_leg(device, steps=20, warmup=5):
     el_s, iters_s, contacts_s = coupled(100, 100 + steps)
     settled = dict(ms_per_substep=el_s / steps * 1e3, contacts=float(np.mean(contacts_s)),
                    newton_iterations=float(np.mean(iters_s)), after_substeps=warmup + steps + 100)
+    # roofline of the Newton iteration (~ 2 * 76 B per contact + 300 B per cell carrying contact
+    # Hessians per iteration), on the settled stack: one more coupled substep up to the solve, then the four kernels of
+    # an iteration re-launched back to back on that state and timed with HIP events (mpm_profile_contact_iteration)
+    g.rebuild_mapping(False)
+    g.calc_fem_state_and_force(dt)
+    g.particle_to_grid(dt)
+    g.update_grid(-1)
+    nk = g.generate_contact_pairs(floor)
+    g.update_contact(dt, mu, k, d)
+    ncc = g.contact_stats()["nodes"]
+    kms = g.profile_contact_iteration(20)
+    g.grid_to_particle(dt)
+    it_bytes = 2 * 76 * nk + 300 * ncc
+    it_ms = sum(kms.values())
+    dom = max(kms, key=kms.get)
+    ach = it_bytes / (it_ms * 1e-3) / 1e9
+    roofline = dict(bound="hbm", kernel="mpm::" + dom, achieved=ach, peak=HBM_PEAK_GBS, unit="GB/s", frac=ach / HBM_PEAK_GBS,
+                    traffic=None, algorithmic_bytes_per_iteration=it_bytes, contacts=nk, cells_with_contacts=ncc,
+                    kernel_ms=kms, iteration_ms=it_ms,
+                    note="achieved = bytes of one Newton iteration / duration of its four kernels (latency-bound: "
+                         "four dependent launches of 8-16 us move ~8 MB)")
     st = g.stats()
     assert st["error_flags"] == 0, st
     g.destroy()
     return dict(ms_per_substep=el / steps * 1e3, substeps_per_s=steps / el, contacts=float(np.mean(contacts)),
-                newton_iterations=float(np.mean(iters)), steps=steps, warmup=warmup, settled=settled,
+                newton_iterations=float(np.mean(iters)), steps=steps, warmup=warmup, settled=settled, roofline=roofline,
                 params=dict(stiffness=k, damping=d, friction_mu=mu, dt=dt, floor_z=floor_z, line_search="backtracking"),
                 workload="cloth_1m on a half-space, pairs from mpm_generate_contact_pairs (device)")
 
@@ -260,6 +284,9 @@ def main():
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # plain `python bench.py --gpus N`: become the launcher.  Nothing has touched the GPU yet.
         sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
+
+    global HOST
+    HOST = host_description()   # (forks lscpu: before the first GPU call of this process)
 
     import torch
     import torch.distributed as dist
@@ -448,6 +475,21 @@ def main():
         el = float(t.item())
     st = g.stats()
     assert st["error_flags"] == 0, st
+    # The steady state next to the driver's window: SURVEY 8(d)'s 200 substeps after 20 (the cloth has picked up
+    # speed, re-sorts included), whatever --steps / --warmup were.  Not `value`.
+    steady = None
+    if world == 1 and chain is None and args.sort_every == 0:
+        g.destroy()
+        g = make_engine(1234)
+        run(20)
+        g.gpu_sync()
+        r0 = g.stats()["rebuilds"]
+        ts = time.perf_counter()
+        run(200)
+        g.gpu_sync()
+        el_s = time.perf_counter() - ts
+        steady = dict(ms_per_step=el_s / 200 * 1e3, substeps_per_s=200 / el_s, steps=200, warmup=20,
+                      rebuilds=g.stats()["rebuilds"] - r0)
 
     # per-kernel timing with HIP events on the engine's stream: a separate, un-timed pass over the
     # SAME substeps (fresh engine, same scene, same warm-up), so that the kernel durations describe
@@ -505,6 +547,8 @@ def main():
                                grid=f"{1 << bits}^3", touched_blocks=st["touched_blocks"], rebuilds=st["rebuilds"],
                                slot_sort_every=args.sort_every, parallelism=par, geometry=geometry if world > 1 else None),
                    roofline=roofline)
+        if steady is not None:
+            out["steady_state"] = steady
         if not args.no_contact_leg and world == 1:
             g.destroy()
             out["contact"] = contact_leg(local_rank)

@@ -117,7 +117,7 @@ SYMBOLS = [
     "mpm_grid_collider_preset", "mpm_get_contact_stats", "mpm_dist_init", "mpm_dist_migration_buffer_bytes",
     "mpm_dist_migrate_pack", "mpm_dist_migrate_apply", "mpm_dist_roles", "mpm_chain_enable_migration",
     "mpm_dist_set_transport", "mpm_device_synchronize", "mpm_debug_owed_substeps",
-    "mpm_memcpy_d2h", "mpm_memcpy_h2d",
+    "mpm_memcpy_d2h", "mpm_memcpy_h2d", "mpm_profile_contact_iteration",
 ]
 
 EXCHANGE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t)
@@ -188,6 +188,7 @@ def load_library(build: bool = True):
         "mpm_sync": [vp],
         "mpm_debug_owed_substeps": [vp, P(C.c_uint32)],
         "mpm_memcpy_d2h": [vp, vp, vp, sz],
+        "mpm_profile_contact_iteration": [vp, i, P(C.c_float)],
         "mpm_memcpy_h2d": [vp, vp, vp, sz],
         "mpm_sync_particle_state_to_cpu": [vp, vp],
         "mpm_dump_obj": [vp, C.c_char_p],
@@ -418,6 +419,12 @@ class GpuMpm:
 
     def memcpy_h2d(self, dst_device_ptr: int, src_host_ptr: int, nbytes: int):
         self._ck(self.lib.mpm_memcpy_h2d(self.h, dst_device_ptr, src_host_ptr, nbytes))
+
+    def profile_contact_iteration(self, reps: int = 20):
+        """ms per launch of (k_ct_tile, k_ct_node_dir, k_ct_ls, k_ct_decide) on the last solve's state."""
+        ms = (C.c_float * 4)()
+        self._ck(self.lib.mpm_profile_contact_iteration(self.h, reps, ms))
+        return dict(zip(("k_ct_tile", "k_ct_node_dir", "k_ct_ls", "k_ct_decide"), (float(x) for x in ms)))
 
     def owed_substeps(self) -> int:
         n = C.c_uint32()

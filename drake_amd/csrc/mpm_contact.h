@@ -296,6 +296,51 @@ static int run_batches(mpm_engine* e, Pattern&& pattern, int first_batch, int ba
     return 0;
 }
 
+// The four kernels of one backtracking Newton iteration, each launched `reps` times back to back on the state the last
+// mpm_update_contact left (contacts sorted, per-cell runs, node list: all still valid), timed with one pair of events
+// per kernel: duration per launch including the hand-over to the next launch, the same notion as a rocprofv3 kernel
+// average.  The kernels run whatever the solver state says (ContactDev::force); velocities are not changed (no lazy
+// update, no apply), the solver's scalars are scratch afterwards.
+static int profile_contact_iteration(mpm_engine* e, int reps, float* kernel_ms) {
+    ContactBuffers& b = e->cb;
+    REQUIRE(b.n > 0 && b.last_iters > 0, "mpm_profile_contact_iteration needs a finished mpm_update_contact on this state");
+    const mpm_contact_stats_t& lc = e->last_contact;
+    (void)lc;
+    ContactDev c = make_contact_dev(e, e->last_contact_dt, e->last_contact_mu, e->last_contact_k, e->last_contact_d, 1 << 30);
+    c.force = 1;
+    const DP& p = e->dp;
+    hipStream_t s = e->stream;
+    const size_t n = b.n;
+    const int n_con_wg = (int)std::min<size_t>((n + CT_WG / 4 - 1) / (CT_WG / 4), CT_ROWS_CON);
+    const int n_grid_wg = CT_ROWS, n_dir_wg = CT_DIR_WG;
+    const unsigned n_tile_wg = (unsigned)std::min<size_t>((n + CT_TILE - 1) / CT_TILE, CT_TILE_WG);
+    hipEvent_t ev[5];
+    for (auto& x : ev) HIP_TRY(hipEventCreate(&x));
+    auto phase = [&](int k) {
+        for (int r = 0; r < reps; ++r) {
+            if (k == 0) hipLaunchKernelGGL(k_ct_tile, dim3(n_tile_wg), dim3(256), 0, s, p, c, 0, 0);
+            if (k == 1) hipLaunchKernelGGL(k_ct_node_dir<0>, dim3(n_dir_wg), dim3(CT_WG), 0, s, p, c, 0);
+            if (k == 2) hipLaunchKernelGGL(k_ct_ls, dim3(n_con_wg + n_grid_wg), dim3(CT_WG), 0, s, p, c, n_con_wg, 0, 0.f);
+            if (k == 3) hipLaunchKernelGGL(k_ct_decide, dim3(1), dim3(1024), 0, s, c, n_dir_wg, n_con_wg, n_grid_wg, 0, 0);
+        }
+    };
+    phase(0);   // warm-up
+    for (int k = 0; k < 4; ++k) {
+        HIP_TRY(hipEventRecord(ev[k], s));
+        phase(k);
+    }
+    HIP_TRY(hipEventRecord(ev[4], s));
+    HIP_TRY(hipStreamSynchronize(s));
+    for (int k = 0; k < 4; ++k) {
+        float ms = 0;
+        HIP_TRY(hipEventElapsedTime(&ms, ev[k], ev[k + 1]));
+        kernel_ms[k] = ms / (float)reps;
+    }
+    for (auto& x : ev) (void)hipEventDestroy(x);
+    HIP_TRY(hipMemsetAsync(b.st, 0, sizeof(ContactState), s));
+    return 0;
+}
+
 static int update_contact(mpm_engine* e, int frame, int substep, float dt, float mu, float stiffness, float damping,
                           int dump, int exact, int max_iters, int* iters_out, float* residual_out) {
     ContactBuffers& b = e->cb;
@@ -306,6 +351,7 @@ static int update_contact(mpm_engine* e, int frame, int substep, float dt, float
         return fail(MPM_ERR_INVALID, "call mpm_reallocate_external_bodies before mpm_update_contact");
     }
     ContactDev c = make_contact_dev(e, dt, mu, stiffness, damping, max_iters);
+    e->last_contact_dt = dt; e->last_contact_mu = mu; e->last_contact_k = stiffness; e->last_contact_d = damping;
     const DP& p = e->dp;
     hipStream_t s = e->stream;
     const unsigned gc = (unsigned)((n + 255) / 256);

@@ -75,6 +75,7 @@ constexpr int CT_LOG = 2048;   // per-iteration statistics kept for the JSON dum
 struct ContactDev {
     int n;                  // contacts
     int max_iters;
+    int force;              // mpm_profile_contact_iteration: the iteration kernels run whatever the solver state says
     float dt, mu, k, d, epsv, relax, tol;
     // as handed over by CopyContactPairs (contact order of the caller)
     const uint32_t* slot;   // internal particle slot
@@ -639,7 +640,7 @@ MPM_DEV void tile_segments(const ContactDev& c, int lo, int cnt, int* s_seg, int
 // lazy: the step of the previous Newton iteration has not been added to the grid yet (k_ct_node_dir does
 // that, after this kernel): velocities are read as v - alpha D.
 __global__ __launch_bounds__(256) void k_ct_tile(DP p, ContactDev c, int first, int lazy) {
-    if (c.st->done || c.st->ls_phase != 0) return;   // (line search of the previous direction still running)
+    if (!c.force && (c.st->done || c.st->ls_phase != 0)) return;   // (line search of the previous direction still running)
     __shared__ float s_part[8][CT_SEG_F];
     __shared__ __attribute__((aligned(16))) float4 s_rec[CT_TILE * 3];
     __shared__ __attribute__((aligned(16))) float4 s_nv[CT_STAGE * 27];
@@ -795,7 +796,7 @@ __global__ __launch_bounds__(256) void k_ct_tile(DP p, ContactDev c, int first, 
 // neighbours' sums, MODE 2 solves from c.hg; |Dir|^2 and the DoF count only include owned nodes.
 template <int MODE>
 __global__ __launch_bounds__(CT_WG) void k_ct_node_dir(DP p, ContactDev c, int lazy = 0) {
-    if (c.st->done || c.st->ls_phase != 0) return;   // k_ct_decide does not read the records of a finished solve
+    if (!c.force && (c.st->done || c.st->ls_phase != 0)) return;   // k_ct_decide does not read the records of a finished solve
     double acc[2] = {0, 0};
     const int sub = threadIdx.x & 15;
     // lazy: the accepted step of the previous iteration is still to be added to the grid velocity
@@ -900,7 +901,7 @@ __global__ __launch_bounds__(CT_WG) void k_ct_node_dir(DP p, ContactDev c, int l
 // host; 2 = the same at st->alpha_probe, the device-resident search (skipped once the step is decided)
 __global__ __launch_bounds__(CT_WG) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_ct_ls(DP p, ContactDev c, int n_con_wg, int exact,
                                                                                              float alpha_probe) {
-    if (c.st->done) return;   // k_ct_decide does not read the records of a finished solve
+    if (c.st->done && !c.force) return;   // k_ct_decide does not read the records of a finished solve
     if (exact == 2) {
         if (c.st->ls_phase == 3) return;
         alpha_probe = c.st->alpha_probe;
@@ -1241,7 +1242,7 @@ __global__ __launch_bounds__(1024) void k_ct_decide(ContactDev c, int n_dir_wg, 
     __shared__ double s_sum[32][CT_PART];
     __shared__ double s_dir[16][2];
     ContactState* st = c.st;
-    if (st->done) {
+    if (st->done && !c.force) {
         // "finish after this update" becomes "finished" once that update (k_ct_apply of the
         // previous iteration) has run
         if (threadIdx.x == 0 && st->done == 2) st->done = 1;

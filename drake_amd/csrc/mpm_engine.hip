@@ -603,6 +603,12 @@ static int settle(mpm_engine* e) {
     READY_NO_SETTLE(e);  \
     if (int rc2__ = settle(e)) return rc2__
 
+int mpm_profile_contact_iteration(mpm_handle_t e, int reps, float kernel_ms[4]) {
+    READY(e);
+    REQUIRE(kernel_ms && reps > 0 && reps <= 1000, "bad arguments");
+    return profile_contact_iteration(e, reps, kernel_ms);
+}
+
 int mpm_memcpy_d2h(mpm_handle_t e, void* dst_host, const void* src_device, size_t bytes) {
     REQUIRE(e, "null handle");
     REQUIRE(bytes == 0 || (dst_host && src_device), "null pointer");

@@ -107,6 +107,7 @@ struct mpm_engine {
     // contacts / rigid bodies
     ContactBuffers cb{};
     mpm_contact_stats_t last_contact{};   // of the last mpm_update_contact
+    float last_contact_dt = 0.f, last_contact_mu = 0.f, last_contact_k = 0.f, last_contact_d = 0.f;   // its parameters
     mpm_dist_config_t dist_cfg{};         // partitioned domain (mpm_dist_init)
     // transport of the distributed contact solve when there is no native chain (mpm_dist_set_transport)
     mpm_exchange_fn dist_exchange = nullptr;

@@ -241,6 +241,13 @@ MPM_API int mpm_sync(mpm_handle_t h);
  * synchronised.  The handles' own rule applies: no other thread may be inside a call on one of them. */
 MPM_API int mpm_device_synchronize(void);
 
+/* bench.py, the contact leg's roofline: the four kernels of one backtracking Newton iteration of the solve that
+ * mpm_update_contact has just finished (contact gradients / Hessians per cell, direction per node, line-search
+ * energies, decision), each launched `reps` times back to back and timed with HIP events on the engine's stream:
+ * kernel_ms[4] = duration per launch of (k_ct_tile, k_ct_node_dir, k_ct_ls, k_ct_decide).  Grid velocities are
+ * left alone; call it before the next mpm_update_contact. */
+MPM_API int mpm_profile_contact_iteration(mpm_handle_t h, int reps, float kernel_ms[4]);
+
 /* Blocking copies between caller-owned host memory and device memory, ordered on the engine's stream (a plain
  * hipMemcpy on the null stream is not ordered with it).  For transports that stage the engine's exchange buffers
  * through the host (mpm_dist_set_transport): they must not bring a second HIP runtime into the process. */
