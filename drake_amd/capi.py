@@ -117,7 +117,7 @@ SYMBOLS = [
     "mpm_grid_collider_preset", "mpm_get_contact_stats", "mpm_dist_init", "mpm_dist_migration_buffer_bytes",
     "mpm_dist_migrate_pack", "mpm_dist_migrate_apply", "mpm_dist_roles", "mpm_chain_enable_migration",
     "mpm_dist_set_transport", "mpm_device_synchronize", "mpm_debug_owed_substeps",
-    "mpm_memcpy_d2h", "mpm_memcpy_h2d", "mpm_profile_contact_iteration",
+    "mpm_memcpy_d2h", "mpm_memcpy_h2d", "mpm_profile_contact_iteration", "mpm_contact_frame",
 ]
 
 EXCHANGE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t)
@@ -252,6 +252,19 @@ def load_library(build: bool = True):
     lib.mpm_halo_buffer_bytes.restype = sz
     _LIB = lib
     return lib
+
+
+def contact_frame(u):
+    """Rows (tangent, tangent, u) of the contact frame the solver builds for the unit normal u (host build of the
+    kernels' own inline function)."""
+    u = _f32(u, (3,))
+    J = np.zeros(9, np.float32)
+    lib = load_library()
+    lib.mpm_contact_frame.argtypes = [C.c_void_p, C.c_void_p]
+    rc = lib.mpm_contact_frame(_ptr(u), _ptr(J))
+    if rc:
+        raise MpmError(rc, (lib.mpm_last_error() or b"").decode())
+    return J.reshape(3, 3)
 
 
 def spatial_force_shift(tau, f, offset):

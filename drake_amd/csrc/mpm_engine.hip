@@ -603,6 +603,12 @@ static int settle(mpm_engine* e) {
     READY_NO_SETTLE(e);  \
     if (int rc2__ = settle(e)) return rc2__
 
+int mpm_contact_frame(const float u[3], float J[9]) {
+    REQUIRE(u && J, "null argument");
+    frame_from_normal(u, J);
+    return 0;
+}
+
 int mpm_profile_contact_iteration(mpm_handle_t e, int reps, float kernel_ms[4]) {
     READY(e);
     REQUIRE(kernel_ms && reps > 0 && reps <= 1000, "bad arguments");

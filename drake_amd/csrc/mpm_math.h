@@ -241,7 +241,7 @@ MPM_DEV void cloth_dphi_dF(const Material& M, const float* F, float* out) {
 
 // Right-handed orthonormal frame whose row `2` is the unit vector u
 // (math_tools.cuh:599-638 with axis_index = 2): rows are (v, w, u).
-MPM_DEV void frame_from_normal(const float* u, float* J) {
+__host__ __device__ inline void frame_from_normal(const float* u, float* J) {   // (host too: mpm_contact_frame, a test entry)
     // i = index of the smallest |component|; written with selects so that no
     // register array is indexed dynamically.
     const float a0 = fabsf(u[0]), a1 = fabsf(u[1]), a2 = fabsf(u[2]);

@@ -241,6 +241,12 @@ MPM_API int mpm_sync(mpm_handle_t h);
  * synchronised.  The handles' own rule applies: no other thread may be inside a call on one of them. */
 MPM_API int mpm_device_synchronize(void);
 
+/* Tests: the frame of a contact with unit normal u (rows of J: two tangents, then u) exactly as the contact
+ * kernels build it -- the same inline function, compiled for the host (math_tools.cuh:599-638 with axis_index 2,
+ * a clone of RotationMatrix::MakeFromOneUnitVector; pinned on the reference's test vectors of
+ * math/test/rotation_matrix_test.cc:1215-1252 in tests/test_contact_frame.py).  No device is touched. */
+MPM_API int mpm_contact_frame(const float u[3], float J[9]);
+
 /* bench.py, the contact leg's roofline: the four kernels of one backtracking Newton iteration of the solve that
  * mpm_update_contact has just finished (contact gradients / Hessians per cell, direction per node, line-search
  * energies, decision), each launched `reps` times back to back and timed with HIP events on the engine's stream:
