@@ -351,17 +351,12 @@ def main():
         mig_every = 4 if zone == 2 else 2
         geometry = dict(cuts=cuts, zone_blocks=zone, ghost_cells=ghost, ghost_margin_cells=margin, migrate_every=mig_every)
         g = make_engine(1234)
-        # exchange buffers travel whole every substep (1 KiB per block): sized to the zone, not to the grid --
-        # 2 * zone block layers of the ~active/(x extent) blocks each, with a factor 2 of headroom
-        # (an overflow is reported as MPM_ERR_CAPACITY, checked below)
-        active = g.stats()["active_blocks"]
-        per_layer = active / float(hi - lo + 2) if active else 1e9   # (tables not built yet: keep the largest size)
-        cap_blocks = 256
-        while cap_blocks < min(8192.0, 2.0 * (2 * zone) * per_layer):
-            cap_blocks *= 2
+        # The native chain sends a fixed capacity per substep (1 KiB per block; a RCCL send needs its size when it is
+        # enqueued), so the capacity is what the ranks' zones hold right after the partition, agreed between them,
+        # with a factor 2 of headroom for the blocks the cloth reaches later (an overflow is MPM_ERR_CAPACITY, checked
+        # below) -- not a guess made before the block tables exist.  Filled in after mpm_dist_init, below.
         chain_args = dict(cut_lo_block=cuts[rank], cut_hi_block=cuts[rank + 1], pitch_blocks=0, zone_blocks=zone,
-                          capacity_blocks=min(cap_blocks, 8192))
-        geometry["exchange_capacity_blocks"] = chain_args["capacity_blocks"]
+                          capacity_blocks=None)
         mig_cap = 65536
     else:
         # Weak scaling: every rank owns one copy of the workload.  The ranks' patches sit side by side
@@ -379,6 +374,16 @@ def main():
     if world > 1:
         if strong:
             g.dist_init(rank, world, cuts, zone, ghost, margin)
+            mine = max(g.halo_zone_blocks(cuts[rank] - zone, cuts[rank] + zone - 1) if rank > 0 else 0,
+                       g.halo_zone_blocks(cuts[rank + 1] - zone, cuts[rank + 1] + zone - 1) if rank < world - 1 else 0)
+            t = torch.tensor([float(mine)])
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            cap_blocks = 64
+            while cap_blocks < 2.0 * float(t.item()):
+                cap_blocks *= 2
+            chain_args["capacity_blocks"] = cap_blocks
+            geometry["exchange_capacity_blocks"] = cap_blocks
+            geometry["zone_blocks_now"] = int(t.item())
         if backend != "gloo":
             # 1. native chain
             box = [None]

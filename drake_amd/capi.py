@@ -117,7 +117,7 @@ SYMBOLS = [
     "mpm_grid_collider_preset", "mpm_get_contact_stats", "mpm_dist_init", "mpm_dist_migration_buffer_bytes",
     "mpm_dist_migrate_pack", "mpm_dist_migrate_apply", "mpm_dist_roles", "mpm_chain_enable_migration",
     "mpm_dist_set_transport", "mpm_device_synchronize", "mpm_debug_owed_substeps",
-    "mpm_memcpy_d2h", "mpm_memcpy_h2d", "mpm_profile_contact_iteration", "mpm_contact_frame",
+    "mpm_memcpy_d2h", "mpm_memcpy_h2d", "mpm_profile_contact_iteration", "mpm_contact_frame", "mpm_halo_zone_blocks",
 ]
 
 EXCHANGE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t)
@@ -189,6 +189,7 @@ def load_library(build: bool = True):
         "mpm_debug_owed_substeps": [vp, P(C.c_uint32)],
         "mpm_memcpy_d2h": [vp, vp, vp, sz],
         "mpm_profile_contact_iteration": [vp, i, P(C.c_float)],
+        "mpm_halo_zone_blocks": [vp, i, i, P(C.c_uint32)],
         "mpm_memcpy_h2d": [vp, vp, vp, sz],
         "mpm_sync_particle_state_to_cpu": [vp, vp],
         "mpm_dump_obj": [vp, C.c_char_p],
@@ -515,6 +516,12 @@ class GpuMpm:
 
     def halo_buffer_bytes(self, capacity_blocks: int) -> int:
         return int(self.lib.mpm_halo_buffer_bytes(capacity_blocks))
+
+    def halo_zone_blocks(self, bx_lo: int, bx_hi: int) -> int:
+        """Active blocks with x block coordinate in [bx_lo, bx_hi]: what a halo pack of that zone holds right now."""
+        n = C.c_uint32()
+        self._ck(self.lib.mpm_halo_zone_blocks(self.h, bx_lo, bx_hi, C.byref(n)))
+        return n.value
 
     def halo_pack(self, bx_lo: int, bx_hi: int, shift_bx: int, dev_ptr: int, capacity_blocks: int):
         self._ck(self.lib.mpm_halo_pack(self.h, bx_lo, bx_hi, shift_bx, C.c_void_p(dev_ptr), capacity_blocks))

@@ -603,6 +603,31 @@ static int settle(mpm_engine* e) {
     READY_NO_SETTLE(e);  \
     if (int rc2__ = settle(e)) return rc2__
 
+int mpm_halo_zone_blocks(mpm_handle_t e, int bx_lo, int bx_hi, uint32_t* count_out) {
+    READY(e);
+    REQUIRE(count_out, "null output");
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    Ctl c;
+    D2H(e, &c, e->dp.ctl, sizeof(Ctl));
+    std::vector<uint32_t> blocks(c.n_active);
+    if (c.n_active) D2H(e, blocks.data(), e->dp.act_block, (size_t)c.n_active * 4);
+    auto compact3 = [](uint32_t v) {   // (host copy of mpm_math.h's: every third bit)
+        v &= 0x09249249u;
+        v = (v ^ (v >> 2)) & 0x030C30C3u;
+        v = (v ^ (v >> 4)) & 0x0300F00Fu;
+        v = (v ^ (v >> 8)) & 0xFF0000FFu;
+        v = (v ^ (v >> 16)) & 0x000003FFu;
+        return v;
+    };
+    uint32_t n = 0;
+    for (uint32_t b : blocks) {
+        const int bx = (int)compact3(b >> 2);
+        n += bx >= bx_lo && bx <= bx_hi;
+    }
+    *count_out = n;
+    return 0;
+}
+
 int mpm_contact_frame(const float u[3], float J[9]) {
     REQUIRE(u && J, "null argument");
     frame_from_normal(u, J);

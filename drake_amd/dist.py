@@ -50,10 +50,11 @@ class HaloChain:
         mk = lambda: torch.zeros(nbytes, dtype=torch.uint8, device=self.device)
         self.send = {n: mk() for n in (self.left, self.right) if n is not None}
         self.recv = {n: mk() for n in (self.left, self.right) if n is not None}
-        if self.staged:
-            self.h_send = {n: torch.zeros(nbytes, dtype=torch.uint8).pin_memory() if self.device.type == "cuda"
-                           else None for n in self.send}
-            self.h_recv = {n: torch.zeros(nbytes, dtype=torch.uint8) for n in self.recv}
+        # byte offsets of the buffer layout (mpm_halo_buffer_bytes): header 16, ids at 16, data 16-byte aligned behind
+        # `capacity` ids; 1 KiB of node sums per block
+        self._data_off = (((4 + capacity_blocks) * 4 + 15) // 16) * 16
+        self.bytes_sent = {}      # per neighbour, of the last staged exchange (tests)
+        self.blocks_sent = {}
 
     # -- one exchange: pack -> send/recv -> add ------------------------------------
     def _zones(self):
@@ -91,19 +92,44 @@ class HaloChain:
         for n in self.recv:
             e.halo_add(self.recv[n].data_ptr(), self.cap)
 
+    def _compact(self, buf):
+        """header | ids[count] | sums[count]: the count-sized message of a packed buffer (16 + 4 count + 1024 count bytes)"""
+        count = int(buf[:4].cpu().view(torch.int32)[0])
+        assert 0 <= count <= self.cap, (count, self.cap)
+        return count, torch.cat([buf[:16], buf[16:16 + 4 * count], buf[self._data_off:self._data_off + 1024 * count]]).cpu()
+
+    def _expand(self, msg, buf):
+        count = int(msg[:4].view(torch.int32)[0])
+        assert msg.numel() == 16 + 1028 * count and count <= self.cap
+        dev = msg.to(buf.device)
+        buf[:16 + 4 * count] = dev[:16 + 4 * count]
+        buf[self._data_off:self._data_off + 1024 * count] = dev[16 + 4 * count:]
+
     def _exchange_staged(self):
+        """Through host memory (gloo): the host knows the counts here, so only the filled part of every buffer
+        travels -- 16 + 4 count + 1024 count bytes -- behind an 8-byte size message."""
         cuda = self.device.type == "cuda"
         if cuda:
             torch.cuda.synchronize()
-        reqs = []
+        msgs, sizes_out, sizes_in, reqs = {}, {}, {}, []
         for n in self.send:
-            src = self.send[n].cpu() if cuda else self.send[n]
-            reqs.append(dist.isend(src, n, group=self.group))
-            reqs.append(dist.irecv(self.h_recv[n], n, group=self.group))
+            self.blocks_sent[n], msgs[n] = self._compact(self.send[n])
+            self.bytes_sent[n] = msgs[n].numel()
+            sizes_out[n] = torch.tensor([msgs[n].numel()], dtype=torch.int64)
+            sizes_in[n] = torch.zeros(1, dtype=torch.int64)
+            reqs.append(dist.isend(sizes_out[n], n, group=self.group))
+            reqs.append(dist.irecv(sizes_in[n], n, group=self.group))
+        for r in reqs:
+            r.wait()
+        reqs, inbox = [], {}
+        for n in self.send:
+            inbox[n] = torch.empty(int(sizes_in[n][0]), dtype=torch.uint8)
+            reqs.append(dist.isend(msgs[n], n, group=self.group))
+            reqs.append(dist.irecv(inbox[n], n, group=self.group))
         for r in reqs:
             r.wait()
         for n in self.recv:
-            self.recv[n].copy_(self.h_recv[n])
+            self._expand(inbox[n], self.recv[n])
         if cuda:
             torch.cuda.synchronize()
 

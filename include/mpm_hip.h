@@ -241,6 +241,12 @@ MPM_API int mpm_sync(mpm_handle_t h);
  * synchronised.  The handles' own rule applies: no other thread may be inside a call on one of them. */
 MPM_API int mpm_device_synchronize(void);
 
+/* Active blocks whose x block coordinate lies in [bx_lo, bx_hi]: what mpm_halo_pack would pack for that zone right
+ * now (the set changes with re-sorts only).  For sizing exchange buffers after mpm_dist_init / mpm_finalize: the
+ * native chain sends a fixed capacity per substep (a RCCL send needs its size when it is enqueued), so that capacity
+ * should be a small multiple of this count, agreed between the neighbours, not a guess. */
+MPM_API int mpm_halo_zone_blocks(mpm_handle_t h, int bx_lo, int bx_hi, uint32_t *count_out);
+
 /* Tests: the frame of a contact with unit normal u (rows of J: two tangents, then u) exactly as the contact
  * kernels build it -- the same inline function, compiled for the host (math_tools.cuh:599-638 with axis_index 2,
  * a clone of RotationMatrix::MakeFromOneUnitVector; pinned on the reference's test vectors of

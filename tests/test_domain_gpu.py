@@ -36,11 +36,25 @@ def _worker(rank, world, cuts, port, q, migrate_every):
     chain = DomainChain(g, rank, world, cuts, zone_blocks=2, ghost_cells=2, ghost_margin_cells=2, capacity_blocks=512,
                         migrate_every=migrate_every, migrate_capacity=4096, device=torch.device("cuda", 0))
     roles0 = g.dist_roles()
+    sent_ok = True
     for _ in range(STEPS):
         chain.substep(DT, -1)
+        # the staged exchange sends only what the pack kernel filled: 16 + 4 count + 1024 count bytes per direction,
+        # count = the zone's active blocks (the capacity, 512 blocks = 526 KB, never travels)
+        for n, zone in ((chain.left, chain.zone_lo), (chain.right, chain.zone_hi)):
+            if n is None:
+                continue
+            count = chain.blocks_sent[n]
+            sent_ok &= chain.bytes_sent[n] == 16 + 4 * count + 1024 * count
+            sent_ok &= 0 < count < 512
+    # (the set only changes with re-sorts: compare the last exchange with the engine's own count of the zone)
+    for n, zone in ((chain.left, chain.zone_lo), (chain.right, chain.zone_hi)):
+        if n is not None:
+            sent_ok &= chain.blocks_sent[n] == g.halo_zone_blocks(zone[0], zone[1])
     g.gpu_sync()
+    st = dict(g.stats(), count_sized_messages=bool(sent_ok))
     q.put((rank, g.dist_roles(), roles0, g.download(ARR.POSITIONS), g.download(ARR.VELOCITIES),
-           g.download(ARR.DEFORMATION_GRADIENTS), g.stats()))
+           g.download(ARR.DEFORMATION_GRADIENTS), st))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -78,6 +92,7 @@ def test_partitioned_domain_matches_single_engine(world, cuts, migrate_every):
     for r in range(world):
         roles, roles0, p_r, v_r, F_r, st = got[r]
         assert st["error_flags"] == 0, (r, st)
+        assert st["count_sized_messages"], (r, st)
         own = roles == 1
         owners += own
         owners0 += roles0 == 1
