@@ -384,6 +384,12 @@ def main():
             chain_args["capacity_blocks"] = cap_blocks
             geometry["exchange_capacity_blocks"] = cap_blocks
             geometry["zone_blocks_now"] = int(t.item())
+            # per-rank topology: what rank 0 allocates after the partition, against the whole scene
+            s0 = g.stats()
+            geometry["rank0_allocation"] = dict(
+                face_slots=s0["face_slots"], vertex_slots=s0["vertex_slots"], held_faces=s0["active_faces"],
+                held_vertices=s0["active_vertices"], scene_faces=nf, scene_vertices=nv,
+                particle_array_MB=round(s0["particle_bytes"] / 1e6, 1), scene_index_MB=round(s0["scene_index_bytes"] / 1e6, 1))
         if backend != "gloo":
             # 1. native chain
             box = [None]

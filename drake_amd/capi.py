@@ -89,7 +89,8 @@ class Stats(C.Structure):
     _fields_ = [
         ("substeps", C.c_uint64), ("rebuilds", C.c_uint64), ("home_blocks", C.c_uint32), ("active_blocks", C.c_uint32),
         ("touched_blocks", C.c_uint32), ("error_flags", C.c_uint32), ("active_faces", C.c_uint32),
-        ("active_vertices", C.c_uint32),
+        ("active_vertices", C.c_uint32), ("face_slots", C.c_uint32), ("vertex_slots", C.c_uint32),
+        ("particle_bytes", C.c_uint64), ("scene_index_bytes", C.c_uint64),
     ]
 
 

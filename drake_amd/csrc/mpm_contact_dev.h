@@ -256,7 +256,7 @@ MPM_DEV float collider_sdf(const Collider& c, const float* x, float* grad) {
 __global__ __launch_bounds__(256) void k_ct_gen_count(DP p, const int* pids_api, int n_col, const Collider* cols,
                                                       int* cnt) {
     const int s = blockIdx.x * 256 + threadIdx.x;
-    if (s >= p.Np) return;
+    if (s >= p.NpG) return;
     const PSet& S = p.set[p.ctl->cur];
     const int slot = p.imap[pids_api[s]];
     // (partitioned domain: only the particles this rank owns make contacts here)
@@ -274,7 +274,7 @@ __global__ __launch_bounds__(256) void k_ct_gen_count(DP p, const int* pids_api,
 __global__ __launch_bounds__(256) void k_ct_gen_write(DP p, const int* pids_api, int n_col, const Collider* cols,
                                                       const int* offs, int cap, uint32_t* api_idx, ContactDev c) {
     const int s = blockIdx.x * 256 + threadIdx.x;
-    if (s >= p.Np) return;
+    if (s >= p.NpG) return;
     int at = offs[s];
     if (offs[s + 1] == at) return;
     const PSet& S = p.set[p.ctl->cur];

@@ -82,9 +82,9 @@ struct Ctl {
 };
 
 // Partitioned domain: ranks cut ONE domain into x slabs at block boundaries.  Every
-// rank was finalised with the whole scene (replicated topology, full-capacity arrays) but only
-// works on the particles it owns -- base cell x in [own_lo, own_hi) -- plus ghost copies of the
-// neighbours' particles within ghost_cells of a cut.  Ghosts take part in FEM and G2P (so they stay
+// rank was finalised with the whole scene; mpm_dist_init shrinks it to the particles it owns -- base
+// cell x in [own_lo, own_hi) -- plus ghost copies of the neighbours' particles within ghost_cells of a
+// cut, with the mesh topology kept per slot by original id (DP::fg / vg) instead of scene-sized tables.  Ghosts take part in FEM and G2P (so they stay
 // bit-identical to the owner's copy without communication) and contribute nothing to P2G; the node
 // sums of the blocks within zone_cells of a cut are exchanged every substep.
 struct Dist {
@@ -111,7 +111,11 @@ MPM_DEV int dist_in_neighbour_bands(const Dist& d, int bx, bool face) {
 }
 
 struct DP {
+    // SLOT space: face particles live in slots [0, Nf), vertex particles in [Nf, Np).  In a single-domain engine that
+    // is also the id space of Finalize ([faces | verts]); a partitioned engine (mpm_dist_init) shrinks its slot space to
+    // what the rank holds (share + ghost bands + head room) while the ids stay those of the whole scene:
     int Np, Nf, Nv;
+    int NpG, NfG;          // ID space: original ids [0, NfG) are faces, [NfG, NpG) vertices (= Nf, Np unless partitioned)
     int bits;              // grid is (1<<bits)^3 cells
     int nb;                // blocks per axis
     unsigned nblocks, ncells;
@@ -135,6 +139,11 @@ struct DP {
     unsigned long long* dbgbuf;  // 16 diagnostic counters (only written when dbg & 4)
     PSet set[2];
     // per-substep scratch
+    // partitioned domain, per-rank topology (null otherwise): what a particle needs to find its mesh neighbours by
+    // ORIGINAL id, kept per slot, moved by the re-sort and carried by the migration records -- no array of the size of
+    // the whole scene's topology stays on a rank
+    int4* fg[2];           // [set][face slot] original ids of the three corner vertices
+    int4* vg[2][2];        // [set][2][vertex slot - Nf] up to eight (original face id << 2 | corner), -1 = none
     float4* ab0;           // faces: tau = a (x) b with a = vol*P[:,2], b = F[:,2]: (a0, a1, a2, b0)
     float2* ab1;           //        (b1, b2)
     float3* G3;            // faces: G3[face slot * 3 + c] = force triple the face exerts on corner c (negated when

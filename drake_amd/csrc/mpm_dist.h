@@ -15,14 +15,19 @@
 // Ghost copies are never refreshed in between: they take part in FEM and G2P with the same inputs
 // and the same arithmetic as the owner's copy, so they stay bit-identical.
 //
-// Record = 7 x 16 bytes: (original id, role, F8, 0), q0..q3 (|vol| in q0.w), F0..3, F4..7.
+// Record = 9 x 16 bytes: (original id, role, F8, 0), q0..q3 (|vol| in q0.w, the authoritative C8 of a face in q1.w),
+// F0..3, F4..7, and the particle's piece of the mesh by ORIGINAL ids -- a face: (Dm^-1 0, 1, 3, |vol|) and its three
+// corner vertices; a vertex: its up to eight (face id << 2 | corner) adjacency records -- so that the receiving rank
+// needs no table of the whole scene's topology (per-rank topology).
 // Buffer = 16-byte header (record count) + capacity records.
 #pragma once
 #include "mpm_device.h"
 
 namespace mpm {
 
-constexpr int DIST_REC_F4 = 7;
+constexpr int DIST_REC_F4 = 9;
+MPM_DEV float4 as_f4(const int4& v) { return make_float4(__int_as_float(v.x), __int_as_float(v.y), __int_as_float(v.z), __int_as_float(v.w)); }
+MPM_DEV int4 as_i4(const float4& v) { return make_int4(__float_as_int(v.x), __float_as_int(v.y), __float_as_int(v.z), __float_as_int(v.w)); }
 constexpr int ROLE_GHOST = 2, ROLE_OWNED = 1;
 
 MPM_DEV int dist_cell_x(const DP& p, float x) {
@@ -73,6 +78,14 @@ MPM_DEV void dist_emit(const DP& p, const PSet& S, unsigned slot, int gid, int r
     r[4] = S.q[3][slot];
     r[5] = face ? S.fq[0][slot] : z;
     r[6] = face ? S.fq[1][slot] : z;
+    const int cs = p.ctl->cur;
+    if (face) {
+        r[7] = S.fq[2][slot];
+        r[8] = as_f4(p.fg[cs][slot]);
+    } else {
+        r[7] = as_f4(p.vg[cs][0][slot - p.Nf]);
+        r[8] = as_f4(p.vg[cs][1][slot - p.Nf]);
+    }
 }
 
 __global__ __launch_bounds__(256) void k_dist_classify(DP p, float4* send_l, float4* send_r, unsigned cap) {
@@ -135,11 +148,11 @@ __global__ __launch_bounds__(256) void k_dist_apply(DP p, const float4* recv, un
         const float4* r = recv + 1 + (size_t)k * DIST_REC_F4;
         const float4 h = r[0];
         const int gid = __float_as_int(h.x), role = __float_as_int(h.y);
-        if (gid < 0 || gid >= p.Np) {
+        if (gid < 0 || gid >= p.NpG) {
             atomicOr(&c->error, ERR_HALO);
             continue;
         }
-        const bool face = gid < p.Nf;
+        const bool face = gid < p.NfG;
         int slot = p.imap[gid];
         if (slot < 0) {
             // not held yet: append behind the active particles of its type (the re-sort merges it)
@@ -151,10 +164,16 @@ __global__ __launch_bounds__(256) void k_dist_apply(DP p, const float4* recv, un
             }
             S.pid[slot] = gid;
             p.imap[gid] = slot;
+            const int cs = c->cur;
             if (face) {
-                const float4 dm = p.dm_orig[gid];
-                S.fq[2][slot] = make_float4(dm.x, dm.y, dm.w, fabsf(r[1].w));
+                // its static record and its corners by original id come with it; the slots of the corners are
+                // looked up by the re-sort that follows (-1 until then)
+                S.fq[2][slot] = make_float4(r[7].x, r[7].y, r[7].z, fabsf(r[1].w));
                 S.fq[3][slot] = make_float4(0.f, __int_as_float(-1), __int_as_float(-1), __int_as_float(-1));
+                p.fg[cs][slot] = as_i4(r[8]);
+            } else {
+                p.vg[cs][0][slot - p.Nf] = as_i4(r[7]);
+                p.vg[cs][1][slot - p.Nf] = as_i4(r[8]);
             }
         }
         if (face) {
@@ -179,7 +198,7 @@ __global__ __launch_bounds__(256) void k_dist_apply(DP p, const float4* recv, un
 // role of the particle in each API slot: 0 not on this rank, 1 owned, 2 ghost
 __global__ __launch_bounds__(256) void k_dist_roles(DP p, const int* pids_api, unsigned char* out) {
     const int s = blockIdx.x * 256 + threadIdx.x;
-    if (s >= p.Np) return;
+    if (s >= p.NpG) return;
     const int j = p.imap[pids_api[s]];
     unsigned char r = 0;
     if (j >= 0) {
@@ -187,6 +206,30 @@ __global__ __launch_bounds__(256) void k_dist_roles(DP p, const int* pids_api, u
         r = v > 0.f ? 1 : (v < 0.f ? 2 : 0);
     }
     out[s] = r;
+}
+
+// mpm_dist_init: per-slot topology by original id for the particles this rank keeps, from the tables of the whole
+// scene that Finalize built (which are released afterwards).  A vertex with more than eight adjacent faces is not
+// supported in a partitioned domain (ERR_CAPACITY; cloth meshes have six).
+__global__ __launch_bounds__(256) void k_dist_build_topology(DP p) {
+    const Ctl* c = p.ctl;
+    const PSet& S = p.set[c->cur];
+    const int cs = c->cur, nf = c->nfa, total = nf + c->nva;
+    for (int idx = blockIdx.x * 256 + threadIdx.x; idx < total; idx += gridDim.x * 256) {
+        const int slot = active_slot(p, idx, nf);
+        const int gid = S.pid[slot];
+        if (slot < p.Nf) {
+            p.fg[cs][slot] = make_int4(p.idx_orig[0][gid], p.idx_orig[1][gid], p.idx_orig[2][gid], 0);
+        } else {
+            const int vo = gid - p.NfG, e0 = p.adj_off[vo], e1 = p.adj_off[vo + 1];
+            int rec[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) rec[q] = e0 + q < e1 ? p.adj_fc[e0 + q] : -1;
+            if (e1 - e0 > 8) atomicOr(&p.ctl->error, ERR_CAPACITY);
+            p.vg[cs][0][slot - p.Nf] = make_int4(rec[0], rec[1], rec[2], rec[3]);
+            p.vg[cs][1][slot - p.Nf] = make_int4(rec[4], rec[5], rec[6], rec[7]);
+        }
+    }
 }
 
 }  // namespace mpm

@@ -13,6 +13,7 @@
 #include <mutex>
 #include <numeric>
 #include <string>
+#include <type_traits>
 #include <vector>
 
 #include "../../include/mpm_hip.h"
@@ -214,13 +215,16 @@ static void launch_g2p(mpm_engine* e, float dt) { launch_g2p_with(e, e->dp, dt);
 static int recover_slab_overflow(mpm_engine* e, Ctl& c);
 static int set_fixed_point_scales(mpm_engine* e) {
     DP& p = e->dp;
-    std::vector<float> q0(e->np * 4);
+    // (slot space: the whole scene, or -- rare: volumes uploaded to a partitioned engine -- what this rank holds;
+    // the scales of mpm_finalize are the whole scene's on every rank, which keeps ghost copies bit-identical)
+    const size_t slots = (size_t)p.Np;
+    std::vector<float> q0(slots * 4);
     HIP_TRY(hipStreamSynchronize(e->stream));
     Ctl c;
     D2H(e, &c, p.ctl, sizeof(Ctl));
-    D2H(e, q0.data(), p.set[c.cur & 1].q[0], e->np * 16);
+    D2H(e, q0.data(), p.set[c.cur & 1].q[0], slots * 16);
     double mass = 0;
-    for (size_t i = 0; i < e->np; ++i) mass += std::fabs((double)q0[i * 4 + 3]) * p.M.density;
+    for (size_t i = 0; i < slots; ++i) mass += std::fabs((double)q0[i * 4 + 3]) * p.M.density;
     if (!(mass > 0) || !std::isfinite(mass)) mass = 1.0;
     const int k = 61 - (int)std::ceil(std::log2(mass));
     p.fix_m = std::ldexp(1.0, k);
@@ -246,6 +250,7 @@ int mpm_finalize(mpm_handle_t e) {
     REQUIRE(np < (size_t)1 << 30, "too many particles");
     DP& p = e->dp;
     p.Np = (int)np; p.Nf = (int)nf; p.Nv = (int)nv;
+    p.NpG = (int)np; p.NfG = (int)nf;
     p.bits = e->bits;
     p.dbg = getenv("MPM_DBG") ? atoi(getenv("MPM_DBG")) : 0;
     p.nb = 1 << (e->bits - 2);
@@ -1168,6 +1173,25 @@ int mpm_get_stats(mpm_handle_t e, mpm_stats_t* out) {
         if (int rc = slab_pool_grow(e, c)) return rc;
     out->active_faces = (uint32_t)c.nfa;
     out->active_vertices = (uint32_t)c.nva;
+    out->face_slots = (uint32_t)e->dp.Nf;
+    out->vertex_slots = (uint32_t)e->dp.Nv;
+    {
+        const DP& p = e->dp;
+        size_t pb = 0, sb = 0;
+        for (int s = 0; s < 2; ++s) {
+            const PSet& S = p.set[s];
+            pb += e->bytes_of(S.q[0]) + e->bytes_of(S.pid) + e->bytes_of(S.f8) + e->bytes_of(S.c8) + e->bytes_of(p.fg[s]);
+            for (int d = 0; d < 4; ++d) pb += e->bytes_of(S.fq[d]);
+            for (int d = 0; d < 2; ++d) pb += e->bytes_of(S.va[d]) + e->bytes_of(p.vg[s][d]);
+        }
+        pb += e->bytes_of(p.ab0) + e->bytes_of(p.ab1) + e->bytes_of(p.G3) + e->bytes_of(p.f[0]) + e->bytes_of(p.pkey) +
+              e->bytes_of(p.prank) + e->bytes_of(p.src_of) + e->bytes_of(p.dst_of) + e->bytes_of(p.home_groups);
+        sb += e->bytes_of(p.imap) + e->bytes_of(e->d_pids_api) + e->bytes_of(e->d_apimap) + e->bytes_of(p.dist.prev);
+        for (int d = 0; d < 3; ++d) sb += e->bytes_of(p.idx_orig[d]);
+        sb += e->bytes_of(p.adj_off) + e->bytes_of(p.adj_fc) + e->bytes_of(p.dm_orig);
+        out->particle_bytes = pb;
+        out->scene_index_bytes = sb;
+    }
     out->touched_blocks = 0;
     if (e->grid_state >= 1) {
         uint32_t cnt = 0;
@@ -1259,6 +1283,130 @@ int mpm_external_body_force_to_host(mpm_handle_t e, float* tau_out, float* f_out
 }
 
 // ---- partitioned domain ----------------------------------------------------------------------
+namespace mpm {
+// after the arrays have moved: vertex slots start at new_nf instead of old_nf
+__global__ __launch_bounds__(256) void k_dist_shift_slots(DP p, int old_nf, int new_nf, int nfa) {
+    const PSet& S = p.set[p.ctl->cur];
+    const int gs = gridDim.x * 256, t0 = blockIdx.x * 256 + threadIdx.x;
+    auto shifted = [&](int s) { return s >= old_nf ? s - old_nf + new_nf : s; };
+    for (int i = t0; i < nfa; i += gs) {
+        float4 f3 = S.fq[3][i];
+        f3.y = __int_as_float(shifted(__float_as_int(f3.y)));
+        f3.z = __int_as_float(shifted(__float_as_int(f3.z)));
+        f3.w = __int_as_float(shifted(__float_as_int(f3.w)));
+        S.fq[3][i] = f3;
+    }
+    for (int g = t0; g < p.NpG; g += gs) p.imap[g] = shifted(p.imap[g]);
+}
+}  // namespace mpm
+
+// mpm_dist_init, last step.  The rank was finalised with the whole scene (every rank runs the same Finalize, so ghost
+// copies start bit-identical to their owners'); the first partitioned re-sort has compacted what it keeps into slots
+// [0, nfa) and [Nf, Nf + nva).  Every array indexed by particle slot is now re-allocated at 1.5 x that (+ head room for
+// what migration appends between re-sorts), the kept ranges are copied, slot references are shifted, and the tables of
+// the whole scene's topology (corner ids per face, adjacency CSR, Dm^-1 by original id) are released: per slot the rank
+// keeps the same information by original id (DP::fg / vg), and migration records carry it.  What stays whole-scene
+// sized is the id -> slot map and the slot-order bookkeeping (13 bytes per particle of the scene, mpm_stats_t).
+static int dist_shrink(mpm_engine* e) {
+    DP& p = e->dp;
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    Ctl c;
+    D2H(e, &c, p.ctl, sizeof(Ctl));
+    const size_t nfa = (size_t)c.nfa, nva = (size_t)c.nva;
+    const size_t old_nf = (size_t)p.Nf, old_nv = (size_t)p.Nv;
+    auto cap_of = [](size_t held, size_t all) { return std::min(all, std::max<size_t>(held + held / 2 + 256, 1024)); };
+    const size_t new_nf = cap_of(nfa, old_nf), new_nv = cap_of(nva, old_nv), new_np = new_nf + new_nv;
+    const int cur = c.cur & 1;
+    int rc = 0;
+    // one array: allocate n_new elements, keep `keep` elements from old[from_old ...] at new[to_new ...]
+    auto move = [&](auto*& ptr, size_t n_new, size_t keep, size_t from_old, size_t to_new) -> int {
+        using T = std::remove_pointer_t<std::remove_reference_t<decltype(ptr)>>;
+        T* fresh = nullptr;
+        if (int r = e->dalloc(&fresh, n_new, true)) return r;
+        if (keep) HIP_TRY(hipMemcpyAsync(fresh + to_new, ptr + from_old, keep * sizeof(T), hipMemcpyDeviceToDevice, e->stream));
+        HIP_TRY(hipStreamSynchronize(e->stream));
+        e->dfree(ptr);
+        ptr = fresh;
+        return 0;
+    };
+    const unsigned new_q_stride = (unsigned)((new_np + 63) & ~(size_t)63);
+    for (int s = 0; s < 2; ++s) {
+        PSet& S = p.set[s];
+        const bool live = s == cur;
+        {   // the four planes of one allocation
+            float4* base = nullptr;
+            if ((rc = e->dalloc(&base, 4 * (size_t)new_q_stride, true))) return rc;
+            if (live)
+                for (int d = 0; d < 4; ++d) {
+                    if (nfa) HIP_TRY(hipMemcpyAsync(base + (size_t)d * new_q_stride, S.q[d], nfa * 16, hipMemcpyDeviceToDevice, e->stream));
+                    if (nva) HIP_TRY(hipMemcpyAsync(base + (size_t)d * new_q_stride + new_nf, S.q[d] + old_nf, nva * 16,
+                                                    hipMemcpyDeviceToDevice, e->stream));
+                }
+            HIP_TRY(hipStreamSynchronize(e->stream));
+            float4* old_base = S.q[0];
+            e->dfree(old_base);
+            for (int d = 0; d < 4; ++d) S.q[d] = base + (size_t)d * new_q_stride;
+        }
+        {   // pid: faces then vertices
+            int* fresh = nullptr;
+            if ((rc = e->dalloc(&fresh, new_np, true))) return rc;
+            if (live && nfa) HIP_TRY(hipMemcpyAsync(fresh, S.pid, nfa * 4, hipMemcpyDeviceToDevice, e->stream));
+            if (live && nva) HIP_TRY(hipMemcpyAsync(fresh + new_nf, S.pid + old_nf, nva * 4, hipMemcpyDeviceToDevice, e->stream));
+            HIP_TRY(hipStreamSynchronize(e->stream));
+            e->dfree(S.pid);
+            S.pid = fresh;
+        }
+        for (int d = 0; d < 4; ++d)
+            if ((rc = move(S.fq[d], new_nf, live ? nfa : 0, 0, 0))) return rc;
+        if ((rc = move(S.f8, new_nf, live ? nfa : 0, 0, 0)) || (rc = move(S.c8, new_nf, live ? nfa : 0, 0, 0))) return rc;
+        if ((rc = move(p.fg[s], new_nf, live ? nfa : 0, 0, 0))) return rc;
+        for (int d = 0; d < 2; ++d)
+            if ((rc = move(S.va[d], new_nv, live ? nva : 0, 0, 0)) || (rc = move(p.vg[s][d], new_nv, live ? nva : 0, 0, 0))) return rc;
+    }
+    // per-substep outputs and re-sort scratch: nothing to keep
+    if ((rc = move(p.ab0, new_nf, 0, 0, 0)) || (rc = move(p.ab1, new_nf, 0, 0, 0)) || (rc = move(p.G3, 3 * new_nf, 0, 0, 0))) return rc;
+    {
+        float* base = nullptr;
+        if ((rc = e->dalloc(&base, 3 * (size_t)new_q_stride, true))) return rc;
+        float* old_base = p.f[0];
+        e->dfree(old_base);
+        for (int d = 0; d < 3; ++d) p.f[d] = base + (size_t)d * new_q_stride;
+    }
+    if ((rc = move(p.pkey, new_np, 0, 0, 0)) || (rc = move(p.prank, new_np, 0, 0, 0)) || (rc = move(p.src_of, new_np, 0, 0, 0)) ||
+        (rc = move(p.dst_of, new_np, 0, 0, 0)))
+        return rc;
+    if ((rc = move(p.home_groups, new_np / 64 + p.capH + 2, 0, 0, 0))) return rc;
+    // the whole scene's topology tables
+    for (int d = 0; d < 3; ++d) {
+        int* t = const_cast<int*>(p.idx_orig[d]);
+        e->dfree(t);
+        p.idx_orig[d] = nullptr;
+    }
+    {
+        int* a = const_cast<int*>(p.adj_off);
+        int* b = const_cast<int*>(p.adj_fc);
+        float4* dm = const_cast<float4*>(p.dm_orig);
+        e->dfree(a); e->dfree(b); e->dfree(dm);
+        p.adj_off = nullptr; p.adj_fc = nullptr; p.dm_orig = nullptr;
+    }
+    p.Np = (int)new_np; p.Nf = (int)new_nf; p.Nv = (int)new_nv;
+    p.q_stride = new_q_stride;
+    p.f_stride = new_q_stride;
+    drop_step_graph(e);
+    for (auto& kg : e->halo_graph) {
+        if (kg.exec) (void)hipGraphExecDestroy(kg.exec);
+        kg.exec = nullptr;
+    }
+    hipLaunchKernelGGL(k_dist_shift_slots, dim3(1024), dim3(256), 0, e->stream, p, (int)old_nf, (int)new_nf, (int)nfa);
+    // block tables, work items and wave groups hold slot ranges: rebuild them on the new slot space
+    const int one = 1;
+    H2D(e, &p.ctl->need_rebuild, &one, sizeof(int));
+    may_resort(e, 0.f);
+    launch_rebuild(e);
+    D2H(e, &c, p.ctl, sizeof(Ctl));
+    return recover_slab_overflow(e, c);
+}
+
 int mpm_dist_init(mpm_handle_t e, const mpm_dist_config_t* cfg) {
     READY(e);
     REQUIRE(cfg, "null configuration");
@@ -1291,6 +1439,13 @@ int mpm_dist_init(mpm_handle_t e, const mpm_dist_config_t* cfg) {
     d.vert_cells = cfg->ghost_cells + cfg->ghost_margin_cells;
     d.zone_cells = cfg->zone_blocks * 4;
     if (int rc = e->dalloc(&d.prev, e->np, true)) return rc;
+    // per-slot topology by original id, for every particle at first (nobody has been released yet)
+    for (int s = 0; s < 2; ++s) {
+        if (int rc = e->dalloc(&e->dp.fg[s], e->nf, false)) return rc;
+        for (int k = 0; k < 2; ++k)
+            if (int rc = e->dalloc(&e->dp.vg[s][k], e->nv, false)) return rc;
+    }
+    hipLaunchKernelGGL(k_dist_build_topology, dim3(std::min(e->g_np, 2048u)), dim3(256), 0, e->stream, e->dp);
     e->dp.dist = d;
     e->dist_cfg = *cfg;
     drop_step_graph(e);
@@ -1303,7 +1458,12 @@ int mpm_dist_init(mpm_handle_t e, const mpm_dist_config_t* cfg) {
         Ctl c;
         D2H(e, &c, e->dp.ctl, sizeof(Ctl));
         if (int rc = recover_slab_overflow(e, c)) return rc;
+        if (c.error & ERR_CAPACITY)
+            return fail(MPM_ERR_INVALID, "mpm_dist_init: a vertex with more than eight adjacent faces is not supported "
+                                         "in a partitioned domain");
     }
+    // the rank keeps its share: the particle arrays shrink to it, the whole scene's topology tables go
+    if (int rc = dist_shrink(e)) return rc;
     return mpm_sync(e);
 }
 

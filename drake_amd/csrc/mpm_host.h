@@ -46,6 +46,7 @@ struct mpm_engine {
     size_t nv = 0, nf = 0, np = 0;
     DP dp{};
     std::vector<void*> allocs;
+    std::vector<size_t> alloc_bytes;   // (parallel to allocs)
     // slot (API) order bookkeeping: slot -> original id and its inverse
     int* d_pids_api = nullptr;
     int* d_apimap = nullptr;
@@ -131,9 +132,28 @@ struct mpm_engine {
         const size_t bytes = std::max<size_t>(n, 1) * sizeof(T);
         HIP_TRY(hipMalloc(&ptr, bytes));
         allocs.push_back(ptr);
+        alloc_bytes.push_back(bytes);
         if (zero) HIP_TRY(hipMemsetAsync(ptr, 0, bytes, stream));
         else if (poison()) HIP_TRY(hipMemsetAsync(ptr, 0xFF, bytes, stream));
         *out = static_cast<T*>(ptr);
+        return 0;
+    }
+    // releases one dalloc'ed array (mpm_dist_init: the whole-scene sized arrays a partitioned rank gives back)
+    template <class T>
+    void dfree(T*& ptr) {
+        if (!ptr) return;
+        for (size_t k = 0; k < allocs.size(); ++k)
+            if (allocs[k] == (void*)ptr) {
+                (void)hipFree(allocs[k]);
+                allocs.erase(allocs.begin() + (long)k);
+                alloc_bytes.erase(alloc_bytes.begin() + (long)k);
+                break;
+            }
+        ptr = nullptr;
+    }
+    size_t bytes_of(const void* ptr) const {
+        for (size_t k = 0; k < allocs.size(); ++k)
+            if (allocs[k] == ptr) return alloc_bytes[k];
         return 0;
     }
     int stage(size_t bytes) {

@@ -103,8 +103,13 @@ MPM_DEV void read_field(const DP& p, const PSet& S, int j, float* o) {
         o[8] = S.f8[j];
     }
     if (FIELD == F_DMINV) {   // as Finalize computed it, entry [2] (a signed zero) included
-        const float4 c = p.dm_orig[S.pid[j]];
-        o[0] = c.x; o[1] = c.y; o[2] = c.z; o[3] = c.w;
+        if (p.dm_orig) {
+            const float4 c = p.dm_orig[S.pid[j]];
+            o[0] = c.x; o[1] = c.y; o[2] = c.z; o[3] = c.w;
+        } else {   // (partitioned domain: the table of the whole scene is gone; entry [2] is a zero either way)
+            const float4 c = S.fq[2][j];
+            o[0] = c.x; o[1] = c.y; o[2] = 0.f; o[3] = c.z;
+        }
     }
 }
 
@@ -165,7 +170,7 @@ __global__ __launch_bounds__(256) void k_scatter_field(DP p, const float* in, in
 // taus()[slot] = a (x) b for face particles, zero for vertices
 __global__ __launch_bounds__(256) void k_gather_taus(DP p, float* out, const int* pids_api) {
     const int s = blockIdx.x * 256 + threadIdx.x;
-    if (s >= p.Np) return;
+    if (s >= p.NpG) return;
     const int j = p.imap[pids_api[s]];
     float a[3] = {0.f, 0.f, 0.f}, b[3] = {0.f, 0.f, 0.f};
     if (j >= 0 && j < p.Nf) {
@@ -184,7 +189,7 @@ __global__ __launch_bounds__(256) void k_gather_taus(DP p, float* out, const int
 // (compute_base_cell_node_index_kernel, cuda_mpm_kernels.cuh:365-382)
 __global__ __launch_bounds__(256) void k_slot_keys(DP p, uint32_t* out, const int* pids_api) {
     const int s = blockIdx.x * 256 + threadIdx.x;
-    if (s >= p.Np) return;
+    if (s >= p.NpG) return;
     const PSet& S = p.set[p.ctl->cur];
     const int j = p.imap[pids_api[s]];
     if (j < 0) {
@@ -231,6 +236,7 @@ static int device_iota(mpm_engine* e, int** out) {
         std::iota(iota.begin(), iota.end(), 0);
         HIP_TRY(hipMalloc((void**)&e->d_iota, e->np * 4));
         e->allocs.push_back(e->d_iota);
+        e->alloc_bytes.push_back(e->np * 4);
         H2D(e, e->d_iota, iota.data(), e->np * 4);
     }
     *out = e->d_iota;
@@ -451,7 +457,7 @@ namespace mpm {
 __global__ __launch_bounds__(256) void k_api_sort_keys(DP p, const int* pids_api, uint32_t mask, uint32_t* keys,
                                                        uint32_t* vals) {
     const int s = blockIdx.x * 256 + threadIdx.x;
-    if (s >= p.Np) return;
+    if (s >= p.NpG) return;
     const PSet& S = p.set[p.ctl->cur];
     const float4 x = S.q[0][p.imap[pids_api[s]]];
     keys[s] = cell_key(base_cell(x.x, p.dxinv), base_cell(x.y, p.dxinv), base_cell(x.z, p.dxinv)) & mask;

@@ -518,11 +518,13 @@ __global__ __launch_bounds__(256) void k_rb_finish(DP p) {
                 b3.z = __int_as_float(p.dst_of[__float_as_int(b3.z)]);
                 b3.w = __int_as_float(p.dst_of[__float_as_int(b3.w)]);
             } else {
-                // partitioned domain: particles come and go, so the references are rebuilt from the
-                // (replicated) topology through the new id -> slot map; -1 = that corner is not here
-                b3.y = __int_as_float(p.imap[p.idx_orig[0][pid]]);
-                b3.z = __int_as_float(p.imap[p.idx_orig[1][pid]]);
-                b3.w = __int_as_float(p.imap[p.idx_orig[2][pid]]);
+                // partitioned domain: particles come and go, so the references are rebuilt from the face's corner
+                // ids (per-slot topology, carried along) through the new id -> slot map; -1 = that corner is not here
+                const int4 cg = p.fg[c->cur][i];
+                p.fg[c->cur ^ 1][j] = cg;
+                b3.y = __int_as_float(p.imap[cg.x]);
+                b3.z = __int_as_float(p.imap[cg.y]);
+                b3.w = __int_as_float(p.imap[cg.z]);
             }
             D.fq[0][j] = b0; D.fq[1][j] = b1; D.fq[2][j] = b2; D.fq[3][j] = b3;
             D.f8[j] = S.f8[i];
@@ -538,18 +540,19 @@ __global__ __launch_bounds__(256) void k_rb_finish(DP p) {
         } else {
             // (face slot * 3 + corner) of the adjacent faces, ascending original face id; -3 = a face
             // that is not on this rank (legal around a ghost vertex, an error around an owned one)
-            const int vo = pid - p.Nf, e0 = p.adj_off[vo], e1 = p.adj_off[vo + 1];
+            const int4 g0 = p.vg[c->cur][0][i - p.Nf], g1 = p.vg[c->cur][1][i - p.Nf];
+            p.vg[c->cur ^ 1][0][j - p.Nf] = g0;
+            p.vg[c->cur ^ 1][1][j - p.Nf] = g1;
+            const int fcs[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
             int rec[8];
 #pragma unroll
             for (int q = 0; q < 8; ++q) {
                 rec[q] = -1;
-                if (e0 + q < e1) {
-                    const int fc = p.adj_fc[e0 + q];
-                    const int fs = p.imap[fc >> 2];
-                    rec[q] = fs < 0 ? -3 : fs * 3 + (fc & 3);
+                if (fcs[q] >= 0) {
+                    const int fs = p.imap[fcs[q] >> 2];
+                    rec[q] = fs < 0 ? -3 : fs * 3 + (fcs[q] & 3);
                 }
             }
-            if (e1 - e0 > 8) rec[0] = -2;
             D.va[0][j - p.Nf] = make_int4(rec[0], rec[1], rec[2], rec[3]);
             D.va[1][j - p.Nf] = make_int4(rec[4], rec[5], rec[6], rec[7]);
         }

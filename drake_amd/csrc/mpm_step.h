@@ -140,7 +140,7 @@ MPM_DEV void vertex_force_value(const DP& p, const PSet& S, int k, float& f0, fl
         }
     } else {
         // more than 8 faces around this vertex: walk the original adjacency
-        const int vo = S.pid[s] - p.Nf;
+        const int vo = S.pid[s] - p.NfG;
         for (int e = p.adj_off[vo]; e < p.adj_off[vo + 1]; ++e) {
             const int fc = p.adj_fc[e];
             const int fs = p.imap[fc >> 2];

@@ -117,6 +117,12 @@ typedef struct {
     uint32_t error_flags;     /* sticky device error bits (0 = none)           */
     uint32_t active_faces;    /* particles this engine works on: all of them, or (partitioned   */
     uint32_t active_vertices; /* domain) the ones it owns plus its ghost copies                 */
+    uint32_t face_slots;      /* particle slots allocated: the scene's counts, or -- after mpm_dist_init, which   */
+    uint32_t vertex_slots;    /* shrinks the rank to its share -- 1.5 x what the rank held then, plus head room     */
+    uint64_t particle_bytes;  /* device bytes of all arrays indexed by particle slot                              */
+    uint64_t scene_index_bytes; /* device bytes indexed by ORIGINAL particle id (id -> slot map, slot-order
+                                   bookkeeping, topology tables of Finalize): whole-scene sized on every rank;
+                                   a partitioned engine keeps only the maps, 13 bytes per particle of the scene */
 } mpm_stats_t;
 
 MPM_API const char *mpm_last_error(void);

@@ -33,8 +33,10 @@ def _worker(rank, world, cuts, port, q, migrate_every):
     from drake_amd.dist import DomainChain
     g = GpuMpm(BITS)
     scenes.populate(g, _scene())     # every rank: the whole scene
+    st_whole = g.stats()
     chain = DomainChain(g, rank, world, cuts, zone_blocks=2, ghost_cells=2, ghost_margin_cells=2, capacity_blocks=512,
                         migrate_every=migrate_every, migrate_capacity=4096, device=torch.device("cuda", 0))
+    st_init = g.stats()
     roles0 = g.dist_roles()
     sent_ok = True
     for _ in range(STEPS):
@@ -52,7 +54,7 @@ def _worker(rank, world, cuts, port, q, migrate_every):
         if n is not None:
             sent_ok &= chain.blocks_sent[n] == g.halo_zone_blocks(zone[0], zone[1])
     g.gpu_sync()
-    st = dict(g.stats(), count_sized_messages=bool(sent_ok))
+    st = dict(g.stats(), count_sized_messages=bool(sent_ok), stats_after_init=st_init, stats_whole_scene=st_whole)
     q.put((rank, g.dist_roles(), roles0, g.download(ARR.POSITIONS), g.download(ARR.VELOCITIES),
            g.download(ARR.DEFORMATION_GRADIENTS), st))
     dist.barrier()
@@ -93,6 +95,18 @@ def test_partitioned_domain_matches_single_engine(world, cuts, migrate_every):
         roles, roles0, p_r, v_r, F_r, st = got[r]
         assert st["error_flags"] == 0, (r, st)
         assert st["count_sized_messages"], (r, st)
+        # per-rank topology: after mpm_dist_init the rank's particle arrays hold 1.5 x its share + ghost bands (+ head
+        # room), not the whole scene, and the scene-sized topology tables are gone (13 bytes per particle of the scene
+        # remain: the id -> slot map, the slot-order bookkeeping, one byte of migration state)
+        si, sw = st["stats_after_init"], st["stats_whole_scene"]
+        held_f, held_v = si["active_faces"], si["active_vertices"]
+        assert si["face_slots"] <= held_f + held_f // 2 + 256 and si["vertex_slots"] <= held_v + held_v // 2 + 256, si
+        assert si["face_slots"] <= sw["face_slots"] and si["vertex_slots"] <= sw["vertex_slots"], (si, sw)
+        if world == 2:   # (this small scene's ghost bands are a third of a three-rank slab: only here is there room to give back)
+            assert si["face_slots"] < sw["face_slots"], (si, sw)
+        bytes_per_slot = sw["particle_bytes"] / (sw["face_slots"] + sw["vertex_slots"])
+        assert si["particle_bytes"] <= 1.6 * bytes_per_slot * 1.5 * (held_f + held_v) + (1 << 20), (si, sw)
+        assert si["scene_index_bytes"] <= 13 * n + 64 and sw["scene_index_bytes"] > 40 * n * 0.6, (si, sw)
         own = roles == 1
         owners += own
         owners0 += roles0 == 1
