@@ -108,7 +108,13 @@ def test_collider_table_changed_between_batches():
 def test_gpu_sync_without_a_state_argument():
     """solver.GpuSync() (no argument: the reference's cudaDeviceSynchronize) after mpm_run_substeps: every engine of
     the device is complete afterwards -- nothing owed, all substeps done, the stream idle."""
-    from drake_amd import ARR as A, GpuMpm
+    from drake_amd import ARR as A, GpuMpm, capi
+    # GpuSync() reports the sticky errors of EVERY engine alive on the device, like the reference's device-wide call
+    # would surface a fault of any of them: engines that earlier tests left behind (kept alive by the tracebacks of
+    # expected failures) are destroyed first
+    import gc
+    gc.collect()
+    capi._destroy_live()
     a, other, b = _engine(), _engine(), _engine()
     for _ in range(12):
         a.run_substeps(5, DT, -1)
