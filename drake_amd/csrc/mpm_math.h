@@ -15,11 +15,50 @@ struct Material {
     int gravity_axis, wall;
 };
 
+// Reciprocal, square root and reciprocal square root of the constitutive update.  k_fem issues ~1000 vector
+// instructions per face, of which an IEEE-correct division costs ten (v_div_scale x2, v_rcp, four fma, v_div_fmas,
+// v_div_fixup) and a correctly rounded sqrtf eight: with 19 divisions and 10 square roots per face the kernel was as
+// close to the vector ALU's limit (84 % busy at 6 waves per SIMD) as to the memory system's.  The hardware
+// approximations (1 ulp each) followed by ONE Newton step in fused multiply-adds (2 - 3 instructions) give results
+// within ~0.6 ulp without the scaling / fix-up instructions: 3 - 4 instructions instead of 8 - 10.  (The bare
+// approximations were measured too: k_fem 2.4 us faster still, but its stress -- a difference of nearly equal
+// numbers, 2 mu (F - R) -- was 6x noisier than with correctly rounded operations, more than the float oracle's own
+// distance from double allows, tests/test_precision_gpu.py.)  -DMPM_FEM_MATH=0 restores the correctly rounded forms,
+// =2 the bare approximations (A/B measurements).
+#ifndef MPM_FEM_MATH
+#define MPM_FEM_MATH 1
+#endif
+#define MPM_FEM_IEEE (MPM_FEM_MATH == 0)
+#if MPM_FEM_MATH == 0
+MPM_DEV float f_rcp(float x) { return 1.f / x; }
+MPM_DEV float f_sqrt(float x) { return sqrtf(x); }
+MPM_DEV float f_rsqrt(float x) { return 1.f / sqrtf(x); }
+#elif MPM_FEM_MATH == 2
+MPM_DEV float f_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+MPM_DEV float f_sqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
+MPM_DEV float f_rsqrt(float x) { return __builtin_amdgcn_rsqf(x); }
+#else
+MPM_DEV float f_rcp(float x) {
+    const float r = __builtin_amdgcn_rcpf(x);
+    return fmaf(fmaf(-x, r, 1.f), r, r);                 // r + r (1 - x r)
+}
+MPM_DEV float f_rsqrt(float x) {
+    const float y = __builtin_amdgcn_rsqf(x);
+    const float e = fmaf(-x * y, y, 1.f);                // 1 - x y^2
+    return fmaf(.5f * y, e, y);                          // y + y e / 2
+}
+MPM_DEV float f_sqrt(float x) {
+    const float y = __builtin_amdgcn_rsqf(x);
+    const float s = x * y;
+    return x > 0.f ? fmaf(fmaf(-s, s, x), .5f * y, s) : 0.f;   // s + (x - s^2) y / 2
+}
+#endif
+
 // ---- 2x2 ------------------------------------------------------------------
 MPM_DEV float det2(const float* m) { return m[0] * m[3] - m[1] * m[2]; }
 
 MPM_DEV void inv2(const float* m, float* o) {  // math_tools.cuh:142-149
-    const float di = 1.f / det2(m);
+    const float di = f_rcp(det2(m));
     o[0] = m[3] * di;
     o[1] = -m[1] * di;
     o[2] = -m[2] * di;
@@ -40,7 +79,7 @@ MPM_DEV void polar2(const float* A, float* U, float* S) {
     } else {
         B0 = A[0] + A[3]; B1 = A[1] - A[2]; B2 = A[2] - A[1]; B3 = A[3] + A[0];
     }
-    const float k = 1.f / sqrtf(fabsf(B0 * B3 - B1 * B2));
+    const float k = f_rsqrt(fabsf(B0 * B3 - B1 * B2));
     U[0] = B0 * k; U[1] = B1 * k; U[2] = B2 * k; U[3] = B3 * k;
     S[0] = (A[0] * A[0] + A[2] * A[2] + adet) * k;
     S[1] = (A[0] * A[1] + A[2] * A[3]) * k;
@@ -61,9 +100,9 @@ MPM_DEV void svd2_rotation(const float* A, float* R) {
         c = 1.f; s = 0.f; s1 = S[0]; s2 = S[3];
     } else {
         const float tao = .5f * (S[0] - S[3]);
-        const float w = sqrtf(tao * tao + S[1] * S[1]);
-        const float t = (tao > 0.f) ? S[1] / (tao + w) : S[1] / (tao - w);
-        c = 1.f / sqrtf(t * t + 1.f);
+        const float w = f_sqrt(tao * tao + S[1] * S[1]);
+        const float t = S[1] * f_rcp(tao > 0.f ? tao + w : tao - w);
+        c = f_rsqrt(t * t + 1.f);
         s = -t * c;
         s1 = c * c * S[0] - 2.f * c * s * S[1] + s * s * S[3];
         s2 = s * s * S[0] + 2.f * c * s * S[1] + c * c * S[3];
@@ -122,7 +161,7 @@ MPM_DEV float dot3(const float* a, const float* b) { return a[0] * b[0] + a[1] *
 MPM_DEV void inv33(const float* m, float* o) {  // math_tools.cuh:113-134
     const float det = m[0] * (m[4] * m[8] - m[7] * m[5]) - m[3] * (m[1] * m[8] - m[7] * m[2]) +
                       m[6] * (m[1] * m[5] - m[4] * m[2]);
-    const float di = 1.f / det;
+    const float di = f_rcp(det);
     o[0] = (m[4] * m[8] - m[5] * m[7]) * di;
     o[3] = (m[5] * m[6] - m[3] * m[8]) * di;
     o[6] = (m[3] * m[7] - m[4] * m[6]) * di;
@@ -139,10 +178,10 @@ MPM_DEV void inv33(const float* m, float* o) {  // math_tools.cuh:113-134
 template <int COLS>
 MPM_DEV void givens_step(float* R, float* Qt, int ri, int rk, int col) {
     const float a = R[ri * COLS + col], b = R[rk * COLS + col];
-    const float sq = sqrtf(a * a + b * b);
+    const float q2 = a * a + b * b;
     float c = 1.f, s = 0.f;
-    if (sq > 0.f) {
-        const float t = 1.f / sq;
+    if (q2 > 0.f) {
+        const float t = f_rsqrt(q2);
         c = a * t;
         s = -b * t;
     }

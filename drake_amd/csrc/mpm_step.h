@@ -55,8 +55,11 @@ __global__ __launch_bounds__(256) void k_fem(DP p, float dt) {
     const float x0[3] = {xa.x, xa.y, xa.z}, x1[3] = {xb.x, xb.y, xb.z}, x2[3] = {xc.x, xc.y, xc.z};
     // the face particle sits at the centroid and moves with the mean velocity (:203-207);
     // vol and C8 ride along unchanged
-    S.q[0][i] = make_float4((xa.x + xb.x + xc.x) / 3.f, (xa.y + xb.y + xc.y) / 3.f, (xa.z + xb.z + xc.z) / 3.f, volw);
-    S.q[1][i] = make_float4((va.x + vb.x + vc.x) / 3.f, (va.y + vb.y + vc.y) / 3.f, (va.z + vb.z + vc.z) / 3.f, C8);
+    // (a third as a product: an IEEE division costs ten vector instructions, see f_rcp in mpm_math.h)
+    const float third = MPM_FEM_IEEE ? 0.f : (1.f / 3.f);
+    auto mean3 = [&](float a, float b, float c) { return MPM_FEM_IEEE ? (a + b + c) / 3.f : (a + b + c) * third; };
+    S.q[0][i] = make_float4(mean3(xa.x, xb.x, xc.x), mean3(xa.y, xb.y, xc.y), mean3(xa.z, xb.z, xc.z), volw);
+    S.q[1][i] = make_float4(mean3(va.x, vb.x, vc.x), mean3(va.y, vb.y, vc.y), mean3(va.z, vb.z, vc.z), C8);
     const float F[9] = {f0.x, f0.y, f0.z, f0.w, f1.x, f1.y, f1.z, f1.w, F8};
     const float Dm0 = f2.x, Dm1 = f2.y, Dm3 = f2.z;   // Dm^-1 = [Dm0 Dm1; 0 Dm3]
     const float C[9] = {q2.x, q2.y, q2.z, q2.w, q3.x, q3.y, q3.z, q3.w, C8};

@@ -13,7 +13,7 @@ pytestmark = pytest.mark.gpu
 def _phase_by_phase(o, g, bc, dt, steps, tag):
     from drake_amd import ARR as A
     for _ in range(steps):
-        sc = natural_scales(o, dt)
+        sc = natural_scales(o, dt, bc)
         g.upload_particle_state(o.pos, o.vel, o.C, None, o.F)
         o.rebuild_mapping(False)
         g.rebuild_mapping(False)

@@ -55,7 +55,7 @@ def test_phase_by_phase(bc):
     side = {-1: 0.3, 0: 0.3, 1: 0.34, 2: 0.3, 3: 0.5}[bc]
     o, g = build_pair(z0=z0, side=side)
     for step in range(3):
-        sc = natural_scales(o)
+        sc = natural_scales(o, DT, bc)
         # same inputs on both sides for every step, so each kernel is judged on one step's rounding
         # (the stiff cloth amplifies differences from step to step; trajectories are tested below)
         g.upload_particle_state(o.pos, o.vel, o.C, None, o.F)

@@ -12,6 +12,8 @@ The numbers this test prints are the basis of the velocity tolerances in tests/h
 BASELINE configs 1 and 2 the float oracle itself is 2e-4 .. 7e-4 of max|v| away from the double one after 10 substeps
 (stiff explicit update: one ulp of F is dt * E / (rho * dx) * 1e-7 of velocity per substep, and it compounds), so
 "1e-5 relative" on velocities over a trajectory is below what float arithmetic delivers on either side."""
+import os
+
 import numpy as np
 import pytest
 
@@ -48,6 +50,8 @@ def _check(what, gpu, a32, a64, weight=None, floor=0.0):
     rms_gpu, rms_32 = float(np.sqrt(np.mean((gpu - a64) ** 2))), float(np.sqrt(np.mean((a32 - a64) ** 2)))
     REPORT.append((what, e_gpu / ref, e_32 / ref, rms_gpu / ref, rms_32 / ref))
     assert np.isfinite(gpu).all(), what
+    if os.environ.get("MPM_PRECISION_REPORT_ONLY"):   # (measurements: the whole table, no verdict)
+        return
     assert e_gpu <= FACTOR * e_32 + floor, (f"{what}: engine {e_gpu:.3e} from the double oracle, float oracle {e_32:.3e} "
                                             f"(max|ref| {ref:.3e})")
     # and not systematically worse either
@@ -60,8 +64,11 @@ def _phases(o32, o64, g, tag):
         s.rebuild_mapping(False)
         s.calc_fem_state_and_force(DT)
     _check(f"{tag} fem F", g.download(A.DEFORMATION_GRADIENTS), o32.F, o64.F)
-    _check(f"{tag} fem tau", g.download(A.TAUS), o32.taus, o64.taus)
-    _check(f"{tag} fem force", g.download(A.FORCES), o32.forces, o64.forces)
+    # (an undeformed cloth has tau = force = 0 in exact arithmetic: what the three produce there is rounding noise of
+    # the rotation, measured against its natural size -- one ulp of strain through vol * E, and through vol * E / dx)
+    vol_e = float(np.max(o64.vol)) * float(o64.p.youngs)
+    _check(f"{tag} fem tau", g.download(A.TAUS), o32.taus, o64.taus, floor=8 * 1.2e-7 * vol_e)
+    _check(f"{tag} fem force", g.download(A.FORCES), o32.forces, o64.forces, floor=8 * 1.2e-7 * vol_e * (1 << o64.domain_bits))
     _check(f"{tag} fem face v", g.download(A.VELOCITIES), o32.vel, o64.vel)
     for s in (o32, o64, g):
         s.particle_to_grid(DT)
