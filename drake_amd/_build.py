@@ -11,7 +11,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libmpm_hip.so")
 SOURCES = ["mpm_engine.hip"]
 ARCH = "gfx950"
-FLAGS = ["-O3", "-std=c++17", "-fPIC", "-shared", "-fvisibility=hidden", f"--offload-arch={ARCH}",
+FLAGS = ["-O3", "-std=c++17", "-fPIC", "-shared", "-fvisibility=hidden", f"--offload-arch={ARCH}", "-fno-slp-vectorize",
          "-munsafe-fp-atomics", "-fno-gpu-rdc", "-Wall", "-Wno-unused-function", "-Wno-unused-value", "-Wno-unused-result"]
 
 

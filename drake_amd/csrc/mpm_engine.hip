@@ -185,7 +185,7 @@ static void launch_fem(mpm_engine* e, float dt) {
 }
 static void launch_p2g(mpm_engine* e, float dt) {
     TraceRange tr(e->dp.fuse_vforce ? "mpm:ParticleToGrid (+ vertex forces)" : "mpm:ParticleToGrid");
-    hipLaunchKernelGGL(k_p2g, dim3(e->g_tile), dim3(512), 0, e->stream, e->dp, dt);
+    hipLaunchKernelGGL(k_p2g, dim3(e->g_tile), dim3(P2G_THREADS), 0, e->stream, e->dp, dt);
     e->last_tile_kernel = 1;
 }
 // FEM faces, then P2G with the vertex forces of every work item computed inside it (no k_vforce launch): the
@@ -429,7 +429,7 @@ int mpm_finalize(mpm_handle_t e) {
     }
     if (p.dbg) {
         int a = 0, b = 0, c = 0;
-        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, k_p2g, 512, 0);
+        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, k_p2g, P2G_THREADS, 0);
         (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, k_g2p, G2P_THREADS, 0);
         (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&c, k_fem, 256, 0);
         std::fprintf(stderr, "[mpm_hip] resident workgroups per CU: p2g %d, g2p %d, fem %d\n", a, b, c);

@@ -304,15 +304,20 @@ MPM_DEV unsigned tile_reach_mask(int rx, int ry, int rz) {
     return rep & xexp;
 }
 
-__global__ __launch_bounds__(512, 4) void k_p2g(DP p, float dt) {  // <= 128 VGPRs: two workgroups per CU
+#ifndef MPM_P2G_WAVES
+#define MPM_P2G_WAVES 8
+#endif
+constexpr int P2G_WAVES = MPM_P2G_WAVES, P2G_THREADS = 64 * P2G_WAVES;
+// two workgroups per CU: 8 waves each at <= 128 VGPRs (4 per SIMD), or 10 at <= 96 (5 per SIMD; -DMPM_P2G_WAVES=10)
+__global__ __launch_bounds__(P2G_THREADS) __attribute__((amdgpu_waves_per_eu(P2G_WAVES / 2, P2G_WAVES / 2))) void k_p2g(DP p, float dt) {
     if (gated_out(p)) return;
     __shared__ long long tile[TILE_N * 4];  // (mvx, mvy, mvz, m) per node, fixed point
     // wave-private staging: 64 particles (+8 slack rows touched by the operand prefetch)
-    __shared__ __attribute__((aligned(16))) float stage_all[8][(64 + 8) * STG];
+    __shared__ __attribute__((aligned(16))) float stage_all[P2G_WAVES][(64 + 8) * STG];
     __shared__ unsigned s_mask;
 #if MPM_P2G_LDSF
     __shared__ float s_frc[LDSF_CAP * 3];
-    static_assert(sizeof(long long) * TILE_N * 4 + sizeof(float) * 8 * (64 + 8) * STG + sizeof(float) * LDSF_CAP * 3 + 4 <= 81920,
+    static_assert(sizeof(long long) * TILE_N * 4 + sizeof(float) * P2G_WAVES * (64 + 8) * STG + sizeof(float) * LDSF_CAP * 3 + 4 <= 81920,
                   "two workgroups per CU need <= 80 KB of LDS each");
 #endif
     Ctl* ctl = p.ctl;
@@ -374,7 +379,7 @@ __global__ __launch_bounds__(512, 4) void k_p2g(DP p, float dt) {  // <= 128 VGP
         const int4 fa = p.item_flat[2 * q], fb = p.item_flat[2 * q + 1];
         const unsigned item = (unsigned)fa.x;
         const unsigned long long tb0 = (diag_flags(p) & 4) ? __builtin_readcyclecounter() : 0ull;
-        for (int n = tid; n < TILE_N * 4; n += 512) tile[n] = 0;
+        for (int n = tid; n < TILE_N * 4; n += P2G_THREADS) tile[n] = 0;
         if (tid == 0) s_mask = 0;
         int bx, by, bz;
         block_coords((uint32_t)fa.z, bx, by, bz);
@@ -442,7 +447,7 @@ __global__ __launch_bounds__(512, 4) void k_p2g(DP p, float dt) {  // <= 128 VGP
         if (p.fuse_vforce && fa.w > 0) {
             // the vertex forces of this item (k_vforce's job: one launch less per substep), handed to the particle
             // loop below in LDS -- the barrier orders the two; vertices beyond the LDS array go through p.f
-            for (int sv = v0_item + tid; sv < irg.w; sv += 512) {
+            for (int sv = v0_item + tid; sv < irg.w; sv += P2G_THREADS) {
 #if MPM_P2G_LDSF
                 float f0, f1, f2;
                 vertex_force_value(p, S, sv - p.Nf, f0, f1, f2);
@@ -465,7 +470,7 @@ __global__ __launch_bounds__(512, 4) void k_p2g(DP p, float dt) {  // <= 128 VGP
         const bool prof = (diag_flags(p) & 4) != 0 && wv == 0;
         unsigned long long tq[3] = {0, 0, 0}, pc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         if (prof && lane == 0) atomicAdd(&p.dbgbuf[14], (unsigned long long)__builtin_readcyclecounter() - tb0);   // prologue
-        for (int g = wv; g < ngroups; g += 8) {
+        for (int g = wv; g < ngroups; g += P2G_WAVES) {
             // ---- 1. one particle per lane (its raw state was prefetched) ----------
             if (prof) tq[0] = __builtin_readcyclecounter();
             const bool act = cur.act, is_face = cur.is_face;
@@ -513,7 +518,7 @@ __global__ __launch_bounds__(512, 4) void k_p2g(DP p, float dt) {  // <= 128 VGP
             }
             // the raw registers are dead now: start the next group's loads, they complete while this
             // group goes through the LDS / matrix-pipe phases below (which never wait on vmcnt)
-            if (g + 8 < ngroups) cur = load_raw(g + 8);
+            if (g + P2G_WAVES < ngroups) cur = load_raw(g + P2G_WAVES);
             if (diag_flags(p) & 2) {
                 float acc = 0.f;
 #pragma unroll
@@ -646,7 +651,7 @@ __global__ __launch_bounds__(512, 4) void k_p2g(DP p, float dt) {  // <= 128 VGP
         __syncthreads();
         if (prof && lane == 0) atomicAdd(&p.dbgbuf[15], (unsigned long long)__builtin_readcyclecounter() - tb0 - pc[7]);   // wave 0 at the closing barrier
         float4* out = p.slab + (size_t)item * TILE_N;
-        for (int n = tid; n < TILE_N; n += 512) {
+        for (int n = tid; n < TILE_N; n += P2G_THREADS) {
             const long long* q = tile + n * 4;
             out[n] = make_float4((float)((double)q[0] * p.unfix_p), (float)((double)q[1] * p.unfix_p),
                                  (float)((double)q[2] * p.unfix_p), (float)((double)q[3] * p.unfix_m));
@@ -931,8 +936,14 @@ MPM_DEV int g2p_particle(const DP& p, const PSet& S, const float4* tile, unsigne
     return bits | (int)!(tx >= guard && tx < top && ty >= guard && ty < top && tz >= guard && tz < top);
 }
 
-constexpr int G2P_THREADS = 512;
-__global__ __launch_bounds__(G2P_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_g2p(DP p, float dt) {
+#ifndef MPM_G2P_THREADS
+#define MPM_G2P_THREADS 512
+#endif
+#ifndef MPM_G2P_WAVES
+#define MPM_G2P_WAVES 4
+#endif
+constexpr int G2P_THREADS = MPM_G2P_THREADS;
+__global__ __launch_bounds__(G2P_THREADS) __attribute__((amdgpu_waves_per_eu(MPM_G2P_WAVES, MPM_G2P_WAVES))) void k_g2p(DP p, float dt) {
     __shared__ float4 tile[TILE_N];
     const Ctl* ctl = p.ctl;
     if (p.gated && ctl->skip_this) {   // (not need_rebuild itself: this kernel raises it while it runs)

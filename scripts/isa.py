@@ -15,7 +15,7 @@ if "--out" in args:
     k = args.index("--out"); out = args[k + 1]; del args[k:k + 2]
 name = args[0]
 asm = "/tmp/isa_%d.s" % os.getpid()
-subprocess.run(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-munsafe-fp-atomics", "-fno-gpu-rdc",
+subprocess.run(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-fno-slp-vectorize", "-munsafe-fp-atomics", "-fno-gpu-rdc",
                 "--cuda-device-only", "-S", *extra, "-o", asm, os.path.join(src, "mpm_engine.hip")], check=True,
                stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
 lines = open(asm).read().splitlines()
