@@ -200,7 +200,7 @@ static void launch_fem_p2g(mpm_engine* e, float dt) {
 // (`p` may carry a halo class restriction)
 static void launch_g2p_with(mpm_engine* e, DP p, float dt) {
     TraceRange tr("mpm:GridToParticle");
-    hipLaunchKernelGGL(k_g2p, dim3(std::min(768u, p.capI)), dim3(G2P_THREADS), 0, e->stream, p, dt);
+    hipLaunchKernelGGL(k_g2p, dim3(std::min(768u, p.capI) * G2P_SPLIT), dim3(G2P_THREADS), 0, e->stream, p, dt);
     e->last_tile_kernel = 2;
 }
 static void launch_grid(mpm_engine* e, const GridColliders& gc) {
@@ -299,8 +299,8 @@ int mpm_finalize(mpm_handle_t e) {
         ALLOC(S.pid, np, true);
         for (int d = 0; d < 2; ++d) ALLOC(S.va[d], nv, true);
     }
-    ALLOC(p.ab0, nf, true);
-    ALLOC(p.ab1, nf, true);
+    ALLOC(p.ab0, std::max<size_t>(nf, 1), true);   // (k_p2g's vertex lanes read element 0 when an item has no face)
+    ALLOC(p.ab1, std::max<size_t>(nf, 1), true);
     ALLOC(p.G3, 3 * nf, true);
     {
         float* base = nullptr;

@@ -418,28 +418,35 @@ __global__ __launch_bounds__(P2G_THREADS) __attribute__((amdgpu_waves_per_eu(P2G
 #pragma unroll
             for (int d = 0; d < 3; ++d) f[d] = fbase[(size_t)d * p.f_stride];
         };
-        auto load_raw = [&](int g) {
+        // a group's descriptor is fetched one group ahead of its records (which are fetched one group ahead of their
+        // use): no dependent round trip in front of the record loads
+        auto desc_of = [&](int g) { return groups[min(g, ngroups - 1)]; };
+        int4 gd_next = make_int4(0, 0, 0, 0);
+        auto load_raw = [&](int4 gr) {
             Raw r;
-            const int4 gr = groups[g];
             const int gf = gr.y - gr.x, gn = gf + (gr.w - gr.z);
             r.act = lane < gn;
             r.is_face = lane < gf;
             // unsigned index: lets the loads use the scalar-base + 32-bit-offset addressing form
-            const unsigned ii = (unsigned)(r.act ? (r.is_face ? gr.x + lane : gr.z + (lane - gf)) : (nfb ? rg.x : rg.z));
+            const unsigned any_slot = (unsigned)(nfb ? rg.x : rg.z);   // (a particle of the item: always valid)
+            const unsigned ii = r.act ? (unsigned)(r.is_face ? gr.x + lane : gr.z + (lane - gf)) : any_slot;
             // (one base pointer and a stride for the four planes: see DP::q_stride)
             const float4* qb = S.q[0] + ii;
             const float4 q0 = qb[0], q1 = qb[p.q_stride], q2 = qb[2 * (size_t)p.q_stride], q3 = qb[3 * (size_t)p.q_stride];
             r.x[0] = q0.x; r.x[1] = q0.y; r.x[2] = q0.z; r.vol = q0.w;
             r.v[0] = q1.x; r.v[1] = q1.y; r.v[2] = q1.z;
             unpack_C(q1, q2, q3, r.C);
-            r.ta[0] = r.ta[1] = r.ta[2] = r.tb[0] = r.tb[1] = r.tb[2] = 0.f;
-            r.frc[0] = r.frc[1] = r.frc[2] = 0.f;
-            if (r.is_face) {
-                const float4 a = p.ab0[ii];
-                const float2 b = p.ab1[ii];
+            // Face lanes need the tau factors, vertex lanes the force.  Both are loaded by ALL lanes, from a
+            // valid slot of the other kind where the lane has no use for them (one cache line for the wave), instead
+            // of `if (face) load ab else load f` over zero-filled registers: the fill of registers that the other
+            // lanes' loads are still writing made the compiler put `s_waitcnt vmcnt` in front of it, i.e. the wave
+            // waited for its whole prefetch (a memory round trip per group) before starting the contraction.
+            {
+                const unsigned fi = r.is_face ? ii : (unsigned)(nfb ? rg.x : 0), vi = r.is_face ? any_slot : ii;
+                const float4 a = p.ab0[fi];
+                const float2 b = p.ab1[fi];
                 r.ta[0] = a.x; r.ta[1] = a.y; r.ta[2] = a.z; r.tb[0] = a.w; r.tb[1] = b.x; r.tb[2] = b.y;
-            } else {
-                force_of(ii, r.frc);
+                force_of(vi, r.frc);
             }
             return r;
         };
@@ -466,7 +473,10 @@ __global__ __launch_bounds__(P2G_THREADS) __attribute__((amdgpu_waves_per_eu(P2G
         unsigned mymask = 0;
         bool halo_bad = false;
         unsigned out_worst = 0, fix_worst = 0;   // error conditions, collected as integers in vector registers
-        if (wv < ngroups) cur = load_raw(wv);
+        if (wv < ngroups) {
+            cur = load_raw(desc_of(wv));
+            gd_next = desc_of(wv + P2G_WAVES);
+        }
         const bool prof = (diag_flags(p) & 4) != 0 && wv == 0;
         unsigned long long tq[3] = {0, 0, 0}, pc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         if (prof && lane == 0) atomicAdd(&p.dbgbuf[14], (unsigned long long)__builtin_readcyclecounter() - tb0);   // prologue
@@ -518,7 +528,10 @@ __global__ __launch_bounds__(P2G_THREADS) __attribute__((amdgpu_waves_per_eu(P2G
             }
             // the raw registers are dead now: start the next group's loads, they complete while this
             // group goes through the LDS / matrix-pipe phases below (which never wait on vmcnt)
-            if (g + P2G_WAVES < ngroups) cur = load_raw(g + P2G_WAVES);
+            if (g + P2G_WAVES < ngroups) {
+                cur = load_raw(gd_next);
+                gd_next = desc_of(g + 2 * P2G_WAVES);
+            }
             if (diag_flags(p) & 2) {
                 float acc = 0.f;
 #pragma unroll
@@ -824,24 +837,36 @@ __global__ __launch_bounds__(256) void k_grid(DP p, GridColliders gc) {
 // G2P
 // ---------------------------------------------------------------------------
 // Stage the (TILE_W)^3 node velocities around a home block into LDS.
+#ifndef MPM_G2P_THREADS
+#define MPM_G2P_THREADS 512
+#endif
+#ifndef MPM_G2P_WAVES
+#define MPM_G2P_WAVES 4
+#endif
+#ifndef MPM_G2P_SPLIT
+#define MPM_G2P_SPLIT 1   // workgroups per work item (each takes every SPLIT-th batch of the item's particles)
+#endif
+constexpr int G2P_THREADS = MPM_G2P_THREADS, G2P_SPLIT = MPM_G2P_SPLIT;
+constexpr int LOAD_TILE_NQ = (TILE_N + G2P_THREADS - 1) / G2P_THREADS;
 MPM_DEV void load_tile(const DP& p, unsigned h, float4* tile, const float4* field, int nthreads) {
     const int* nbr = p.home_nbr_act + (size_t)h * 27;
-    // two nodes per thread (TILE_N <= 2 * nthreads), branch-free and in three sweeps so that the
-    // table loads and then the node loads of both are in flight together
-    int a[2], cell[2];
+    // NQ nodes per thread (TILE_N <= NQ * nthreads), branch-free and in three sweeps so that the
+    // table loads and then the node loads of all are in flight together
+    constexpr int NQ = LOAD_TILE_NQ;
+    int a[NQ], cell[NQ];
 #pragma unroll
-    for (int q = 0; q < 2; ++q) {
+    for (int q = 0; q < NQ; ++q) {
         const int n = min((int)threadIdx.x + q * nthreads, TILE_N - 1);
         const int tx = n / (TILE_W * TILE_W), ty = (n / TILE_W) % TILE_W, tz = n % TILE_W;
         const int qx = tx - FREE_ZONE + 4, qy = ty - FREE_ZONE + 4, qz = tz - FREE_ZONE + 4;  // >= 2
         a[q] = nbr[(qx >> 2) * 9 + (qy >> 2) * 3 + (qz >> 2)];
         cell[q] = ((qx & 3) << 4) + ((qy & 3) << 2) + (qz & 3);
     }
-    float4 v[2];
+    float4 v[NQ];
 #pragma unroll
-    for (int q = 0; q < 2; ++q) v[q] = field[(size_t)max(a[q], 0) * 64 + cell[q]];
+    for (int q = 0; q < NQ; ++q) v[q] = field[(size_t)max(a[q], 0) * 64 + cell[q]];
 #pragma unroll
-    for (int q = 0; q < 2; ++q) {
+    for (int q = 0; q < NQ; ++q) {
         const int n = (int)threadIdx.x + q * nthreads;
         if (n < TILE_N) tile[n] = a[q] >= 0 ? v[q] : make_float4(0.f, 0.f, 0.f, 0.f);
     }
@@ -936,13 +961,6 @@ MPM_DEV int g2p_particle(const DP& p, const PSet& S, const float4* tile, unsigne
     return bits | (int)!(tx >= guard && tx < top && ty >= guard && ty < top && tz >= guard && tz < top);
 }
 
-#ifndef MPM_G2P_THREADS
-#define MPM_G2P_THREADS 512
-#endif
-#ifndef MPM_G2P_WAVES
-#define MPM_G2P_WAVES 4
-#endif
-constexpr int G2P_THREADS = MPM_G2P_THREADS;
 __global__ __launch_bounds__(G2P_THREADS) __attribute__((amdgpu_waves_per_eu(MPM_G2P_WAVES, MPM_G2P_WAVES))) void k_g2p(DP p, float dt) {
     __shared__ float4 tile[TILE_N];
     const Ctl* ctl = p.ctl;
@@ -952,7 +970,8 @@ __global__ __launch_bounds__(G2P_THREADS) __attribute__((amdgpu_waves_per_eu(MPM
     }
     const PSet& S = p.set[ctl->cur];
     const unsigned n_items = ctl->n_items;
-    for (unsigned q = blockIdx.x; q < n_items; q += gridDim.x) {
+    for (unsigned vq = blockIdx.x; vq < n_items * G2P_SPLIT; vq += gridDim.x) {
+        const unsigned q = vq / G2P_SPLIT, part = vq % G2P_SPLIT;
         __syncthreads();  // everybody is done with the previous tile
         const int4 fa = p.item_flat[2 * q], fb = p.item_flat[2 * q + 1];
         const unsigned h = (unsigned)fa.y;
@@ -970,7 +989,7 @@ __global__ __launch_bounds__(G2P_THREADS) __attribute__((amdgpu_waves_per_eu(MPM
         auto slot_of = [&](int u) { return (unsigned)(u < nfb ? rg.x + u : rg.z + (u - nfb)); };
         // the first positions are requested before the tile is staged, later ones one iteration
         // ahead, so the HBM latency of the particle stream hides behind LDS work
-        int u = (int)threadIdx.x;
+        int u = (int)(threadIdx.x + part * G2P_THREADS);
         int left = 0;
         unsigned i = slot_of(u < total ? u : 0);
         float4 pq = S.q[0][i];
@@ -981,10 +1000,10 @@ __global__ __launch_bounds__(G2P_THREADS) __attribute__((amdgpu_waves_per_eu(MPM
         block_coords((uint32_t)fa.z, bx, by, bz);
         const int ox = bx * 4 - FREE_ZONE, oy = by * 4 - FREE_ZONE, oz = bz * 4 - FREE_ZONE;
 #pragma unroll 1
-        for (; u < total; u += G2P_THREADS) {
+        for (; u < total; u += G2P_THREADS * G2P_SPLIT) {
             const unsigned ci = i;
             const float4 c = pq;
-            const int un = u + G2P_THREADS;
+            const int un = u + G2P_THREADS * G2P_SPLIT;
             if (un < total) {
                 i = slot_of(un);
                 pq = S.q[0][i];
