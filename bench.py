@@ -523,7 +523,13 @@ def main():
         ab["p2g"] += ab["vforce"]
         ab["vforce"] = 0
     dom = max(KERNEL_OF, key=lambda k: phases[k])
-    ach = ab[dom] / (phases[dom] * 1e-3) / 1e9
+    # An interval between two events holds the kernel AND the two event packets' own processing.  On one GPU the
+    # vertex-force phase of this pass is EMPTY (k_p2g does that work), i.e. a live measurement of exactly that:
+    # two events with nothing between them (about 5 us).  It is subtracted, so that `kernel_ms` is comparable with
+    # the kernel trace's average duration (profiles/rNN_kernel_stats.csv); the raw interval is reported next to it.
+    ev_ms = phases["vforce"] if world == 1 else 0.0
+    dom_ms = phases[dom] - ev_ms
+    ach = ab[dom] / (dom_ms * 1e-3) / 1e9
     # the whole job: every particle once per substep (strong: one copy; weak: one copy per rank)
     copies = 1 if (strong or world == 1) else world
     # (cells: rank 0's count; a partitioned domain has about `world` times as many, a 1% term)
@@ -533,12 +539,15 @@ def main():
                     traffic_source="profiles/pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this "
                                    "command, collected by scripts/collect_profiles.sh and committed (replayed, not "
                                    "measured in this run)",
-                    algorithmic_bytes_per_launch=ab[dom], kernel_ms=phases[dom],
+                    algorithmic_bytes_per_launch=ab[dom], kernel_ms=dom_ms, kernel_ms_event_interval=phases[dom],
+                    event_overhead_ms=ev_ms,
                     substep_achieved=job_bytes / (el / args.steps) / 1e9,
                     substep_frac=job_bytes / (el / args.steps) / 1e9 / (HBM_PEAK_GBS * world), phase_ms=phases,
                     phase_note="separate pass with HIP events around every phase (mpm_profile_substeps); it launches the "
                                "re-sort kernels with every substep, the timed run with every fourth (gated substeps); "
-                               "one GPU: the vertex-force phase is empty, k_p2g does that work per work item")
+                               "one GPU: the vertex-force phase is empty (k_p2g does that work per work item), so its "
+                               "interval is the cost of an event pair, which kernel_ms has subtracted; phase_ms are raw "
+                               "intervals")
 
     if rank == 0:
         if world == 1:

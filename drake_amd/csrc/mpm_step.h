@@ -515,7 +515,7 @@ __global__ __launch_bounds__(P2G_THREADS) __attribute__((amdgpu_waves_per_eu(P2G
                     Y[r * 4 + 3] = B[r * 3 + 2] * p.dx;
                 }
                 Y[12] = m; Y[13] = 0.f; Y[14] = 0.f; Y[15] = 0.f;
-                if (!own) {
+                if (p.dist.on && !own) {   // (only a partitioned domain has ghost copies: a scalar branch otherwise)
 #pragma unroll
                     for (int k = 0; k < 12; ++k) Y[k] = 0.f;
                 }
