@@ -477,9 +477,13 @@ def main():
     barrier()
     t0 = time.perf_counter()
     run(args.steps)
+    t_enq = time.perf_counter()
     g.gpu_sync()
+    t_sync = time.perf_counter()
     barrier()
     el = time.perf_counter() - t0
+    # (where the wall time of the timed region went: enqueueing, the engine's own completion, the contract's barrier)
+    region = dict(enqueue_ms=(t_enq - t0) * 1e3, engine_complete_ms=(t_sync - t0) * 1e3, with_barrier_ms=el * 1e3)
     if world > 1:
         t = torch.tensor([el], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -567,6 +571,7 @@ def main():
                                grid=f"{1 << bits}^3", touched_blocks=st["touched_blocks"], rebuilds=st["rebuilds"],
                                slot_sort_every=args.sort_every, parallelism=par, geometry=geometry if world > 1 else None),
                    roofline=roofline)
+        out["timed_region"] = region
         if steady is not None:
             out["steady_state"] = steady
         if not args.no_contact_leg and world == 1:
