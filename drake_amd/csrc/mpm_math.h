@@ -21,9 +21,9 @@ struct Material {
 // close to the vector ALU's limit (84 % busy at 6 waves per SIMD) as to the memory system's.  The hardware
 // approximations (1 ulp each) followed by ONE Newton step in fused multiply-adds (2 - 3 instructions) give results
 // within ~0.6 ulp without the scaling / fix-up instructions: 3 - 4 instructions instead of 8 - 10.  (The bare
-// approximations were measured too: k_fem 2.4 us faster still, but its stress -- a difference of nearly equal
-// numbers, 2 mu (F - R) -- was 6x noisier than with correctly rounded operations, more than the float oracle's own
-// distance from double allows, tests/test_precision_gpu.py.)  -DMPM_FEM_MATH=0 restores the correctly rounded forms,
+// approximations were measured too: 44 instructions fewer still, but the stress -- a difference of nearly equal
+// numbers, 2 mu (F - R) -- came out 6x noisier than with correctly rounded operations, more than a float evaluation's
+// own distance from a double one allows, tests/test_precision_gpu.py.)  -DMPM_FEM_MATH=0 restores the correctly rounded forms,
 // =2 the bare approximations (A/B measurements).
 #ifndef MPM_FEM_MATH
 #define MPM_FEM_MATH 1
