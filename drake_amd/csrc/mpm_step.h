@@ -973,7 +973,7 @@ __global__ __launch_bounds__(G2P_THREADS) __attribute__((amdgpu_waves_per_eu(MPM
     for (unsigned vq = blockIdx.x; vq < n_items * G2P_SPLIT; vq += gridDim.x) {
         const unsigned q = vq / G2P_SPLIT, part = vq % G2P_SPLIT;
         __syncthreads();  // everybody is done with the previous tile
-        const int4 fa = p.item_flat[2 * q], fb = p.item_flat[2 * q + 1];
+        const int4 fa = p.item_flat[2 * q];
         const unsigned h = (unsigned)fa.y;
         if (p.halo_cls >= 0) {   // split gather around the halo exchange (uniform over the workgroup)
             int hx, hy, hz;
