@@ -90,7 +90,8 @@ class Stats(C.Structure):
         ("substeps", C.c_uint64), ("rebuilds", C.c_uint64), ("home_blocks", C.c_uint32), ("active_blocks", C.c_uint32),
         ("touched_blocks", C.c_uint32), ("error_flags", C.c_uint32), ("active_faces", C.c_uint32),
         ("active_vertices", C.c_uint32), ("face_slots", C.c_uint32), ("vertex_slots", C.c_uint32),
-        ("particle_bytes", C.c_uint64), ("scene_index_bytes", C.c_uint64),
+        ("particle_bytes", C.c_uint64), ("scene_index_bytes", C.c_uint64), ("resort_checks", C.c_uint64),
+        ("quiet_time_s", C.c_float), ("since_resort_s", C.c_float),
     ]
 
 
@@ -654,7 +655,7 @@ class GpuMpm:
     def stats(self) -> dict:
         s = Stats()
         self._ck(self.lib.mpm_get_stats(self.h, C.byref(s)))
-        return {k: int(getattr(s, k)) for k, _ in Stats._fields_}
+        return {k: (float(getattr(s, k)) if t is C.c_float else int(getattr(s, k))) for k, t in Stats._fields_}
 
     _SHAPES = {
         ARR.POSITIONS: ("np", 3, np.float32), ARR.VELOCITIES: ("np", 3, np.float32), ARR.VOLUMES: ("np", 1, np.float32),

@@ -78,7 +78,12 @@ struct Ctl {
     int add_f, add_v;
     int nfa_new, nva_new;   // counts after the re-sort in flight (k_rb_tables -> k_rb_finish)
     unsigned n_items_wanted;   // work items the last re-sort made, before the clamp to the slab pool (> n_items: ERR_SLABS)
-    int pad1;
+    // Quiet time: how long after the last re-sort no particle can leave its tile if all of them keep moving
+    // ballistically (velocity + gravity) -- k_rb_count's estimate, the minimum over the particles.  A hint for the
+    // host (mpm_run_substeps launches no re-sort checks while it holds, see launch_substep); nothing depends on it
+    // being right: a substep that finds a re-sort pending without its check launches skips itself (DP::gated).
+    float quiet_time;          // seconds, as of the last re-sort (0: not estimated)
+    float time_since_resort;   // seconds of substeps run since then (k_g2p adds its dt)
 };
 
 // Partitioned domain: ranks cut ONE domain into x slabs at block boundaries.  Every
@@ -159,7 +164,8 @@ struct DP {
     uint32_t* prank;
     uint32_t* src_of;      // sorted slot -> previous slot
     int* dst_of;           // previous slot -> sorted slot
-    unsigned* tickets;     // 32 arrival counters, 128 bytes apart (k_rb_finish)
+    unsigned* tickets;     // 32 arrival counters, 128 bytes apart (k_rb_finish); next to each, a slot of the quiet-time
+                           // minimum in the making (k_rb_count)
     uint32_t* halo_hdr[2]; // per launch: halo send buffers whose entry counters k_grid<0> resets (or null)
     // per launch: restrict k_grid<2> / k_g2p to the part of the grid that does (1) or does not (0)
     // depend on the halo exchange; -1 = everything.  Zones are x-block ranges [lo, hi].

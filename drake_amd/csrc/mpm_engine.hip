@@ -72,6 +72,7 @@ int mpm_create(int domain_bits, const mpm_material_t* material, int device, mpm_
     }
     e->stream = e->own_stream;
     if (getenv("MPM_RESORT_EVERY")) e->check_every = std::max(1, atoi(getenv("MPM_RESORT_EVERY")));
+    if (getenv("MPM_QUIET_FACTOR")) e->quiet_factor = std::min(1.f, std::max(0.f, (float)atof(getenv("MPM_QUIET_FACTOR"))));
     if (getenv("MPM_GRAPH")) e->graph_len = std::max(0, atoi(getenv("MPM_GRAPH")));
     {
         std::lock_guard<std::mutex> lock(g_live_mutex);
@@ -435,7 +436,14 @@ int mpm_finalize(mpm_handle_t e) {
         std::fprintf(stderr, "[mpm_hip] resident workgroups per CU: p2g %d, g2p %d, fem %d\n", a, b, c);
     }
     e->finalized = true;
-    return mpm_sync(e);
+    if (int rc2 = mpm_sync(e)) return rc2;
+    {
+        // the first re-sort's quiet time: the first batch of substeps starts with it (launch_substep)
+        Ctl c;
+        D2H(e, &c, p.ctl, sizeof(Ctl));
+        e->quiet_left = c.error || c.need_rebuild ? 0.f : c.quiet_time;
+    }
+    return 0;
 }
 
 int mpm_destroy(mpm_handle_t e) {
@@ -578,6 +586,8 @@ static void launch_substep(mpm_engine* e, float dt, const GridColliders& gc, boo
 static int settle(mpm_engine* e) {
     e->force_check = true;   // whatever comes next starts with the re-sort launches
     e->dp.gated = 0;
+    e->quiet_left = 0.f;     // (the call that settles may change the state: the hint is only kept from a settle that
+                             // has just read it, below, to the substeps enqueued right after)
     if (!e->maybe_owed) return 0;
     // (a few rounds: a substep that is run again may itself overflow the slab pool -- a cloth that keeps spreading)
     for (int round = 0; round < 8 && e->maybe_owed; ++round) {
@@ -587,6 +597,12 @@ static int settle(mpm_engine* e) {
         // every substep since the overflowing re-sort has skipped itself: the pool can be grown and the re-sort repeated
         if (int rc = recover_slab_overflow(e, c)) return rc;
         const unsigned owed = c.skipped;
+        // what is left of the quiet time the last re-sort estimated (Ctl::quiet_time): substeps enqueued from here
+        // on go without check launches while it lasts (launch_substep).  Nothing left when a re-sort is pending.
+        e->quiet_left = owed || c.need_rebuild || c.error ? 0.f : std::max(0.f, c.quiet_time - c.time_since_resort);
+        if (e->dp.dbg & 32)
+            std::fprintf(stderr, "[mpm_hip] settle: quiet time %.4g s, %.4g s since the re-sort, %u owed, re-sort pending %d, checks launched %llu\n",
+                         c.quiet_time, c.time_since_resort, owed, c.need_rebuild, (unsigned long long)e->checks_launched);
         if (!owed) break;
         const unsigned zero = 0;
         H2D(e, &e->dp.ctl->skipped, &zero, sizeof(unsigned));
@@ -1042,13 +1058,25 @@ int mpm_substep(mpm_handle_t e, float dt, int bc) { return mpm_run_substeps(e, 1
 // lean: another substep follows in the same batch, GridToParticle need not refresh what only a download reads
 static void launch_substep(mpm_engine* e, float dt, const GridColliders& gc, bool allow_gate, bool lean) {
     e->last_dt = dt;
-    const bool check = !allow_gate || e->force_check || e->check_every <= 1 || e->dp.dist.on ||
-                       (e->step_phase % (unsigned)e->check_every) == 0u;
+    // Re-sort check launches: with every substep that may not skip itself; otherwise none while the quiet time that
+    // the last re-sort estimated lasts (half of it: the estimate is ballistic, elastic forces are not in it), then
+    // with every check_every-th substep.  A wrong guess costs time, not correctness: substeps that find a re-sort
+    // pending without their check skip themselves and are run again by settle().
+    bool check = !allow_gate || e->force_check || e->check_every <= 1 || e->dp.dist.on;
+    if (!check) {
+        if (e->quiet_factor * e->quiet_left > dt) {
+            e->quiet_left -= dt / e->quiet_factor;
+        } else {
+            e->quiet_left = 0.f;
+            check = (e->step_phase % (unsigned)e->check_every) == 0u;
+        }
+    }
     e->step_phase += 1;
     e->dp.gated = check ? 2 : 3;   // (bit 1: it also skips itself while the slab pool is too small, see DP::gated)
     if (check) {
         launch_rebuild(e);
         e->force_check = false;
+        e->checks_launched += 1;
     }
     e->maybe_owed = true;
     launch_fem_p2g(e, dt);
@@ -1175,6 +1203,9 @@ int mpm_get_stats(mpm_handle_t e, mpm_stats_t* out) {
     out->active_vertices = (uint32_t)c.nva;
     out->face_slots = (uint32_t)e->dp.Nf;
     out->vertex_slots = (uint32_t)e->dp.Nv;
+    out->resort_checks = e->checks_launched;
+    out->quiet_time_s = c.quiet_time;
+    out->since_resort_s = c.time_since_resort;
     {
         const DP& p = e->dp;
         size_t pb = 0, sb = 0;

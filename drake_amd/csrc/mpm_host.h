@@ -61,6 +61,9 @@ struct mpm_engine {
     int graph_len = 0;         // > 0: mpm_run_substeps replays captured graphs of this many substeps
     unsigned step_phase = 0;
     bool force_check = true;   // the next substep gets them whatever its number (after any other call)
+    float quiet_left = 0.f;    // seconds of Ctl::quiet_time left as of the last settle() (0: unknown)
+    uint64_t checks_launched = 0;   // (diagnostics)
+    float quiet_factor = .5f;  // share of it that is trusted (MPM_QUIET_FACTOR; 0 = check launches as before)
     bool maybe_owed = false;   // gated substeps were enqueued since the last settle()
     float owed_dt = 0.f;
     int owed_bc = 0;

@@ -20,9 +20,19 @@ namespace mpm {
 // (cell, type) and issues one integer atomic per distinct cell and block
 // instead of one per particle (device-scope atomics are resolved at the
 // memory side and are expensive when thousands of them hit one address).
+// time until a point at distance d (cells) from a bound is there, moving at v towards it with acceleration a
+MPM_DEV float time_to_travel(float d, float v, float a) {
+    if (!(d > 0.f)) return 0.f;
+    const float disc = v * v + 2.f * a * d;
+    if (!(disc >= 0.f)) return __int_as_float(0x7F800000);   // turns around before it gets there
+    const float den = v + sqrtf(disc);
+    return den > 0.f ? 2.f * d / den : __int_as_float(0x7F800000);
+}
+
 __global__ __launch_bounds__(256) void k_rb_count(DP p) {
     if (!p.ctl->need_rebuild) return;
     const PSet& S = p.set[p.ctl->cur];
+    float quiet = __int_as_float(0x7F800000);   // Ctl::quiet_time: this thread's particles
     // the particles to sort: the active ones and what a migration appended behind them
     const int nf_in = p.ctl->nfa + p.ctl->add_f, total = nf_in + p.ctl->nva + p.ctl->add_v;
     // grid-stride over 256-particle chunks: a small fixed grid keeps the idle launches cheap
@@ -41,8 +51,8 @@ __global__ __launch_bounds__(256) void k_rb_count(DP p) {
     // Slow particles are binned where they are.  (The cell part of the key follows the shifted position
     // too: the order inside a block only has to be approximately by cell.)
     float px = xq.x, py = xq.y, pz = xq.z;
-    if (p.anticip > 0.f) {
-        float vx, vy, vz;
+    float vx = 0.f, vy = 0.f, vz = 0.f;
+    if (!p.dist.on) {   // (a partitioned domain bins by position and checks with every substep)
         if (listed && ii < p.Nf) {
             // a face particle moves with the mean velocity of its corners (CalcFemStateAndForce puts it there before
             // anything else looks at it); its own velocity record may be a substep old (lean GridToParticle)
@@ -53,6 +63,8 @@ __global__ __launch_bounds__(256) void k_rb_count(DP p) {
             const float4 vq = S.q[1][ii];
             vx = vq.x; vy = vq.y; vz = vq.z;
         }
+    }
+    if (p.anticip > 0.f) {
         const float A = 1.75f;
         px += fminf(fmaxf(vx * p.anticip, -A), A) * p.dx;
         py += fminf(fmaxf(vy * p.anticip, -A), A) * p.dx;
@@ -65,6 +77,19 @@ __global__ __launch_bounds__(256) void k_rb_count(DP p) {
     if (valid && !(inside(xq.x) && inside(xq.y) && inside(xq.z)) && !(p.ctl->error & ERR_DOMAIN))
         atomicOr(&p.ctl->error, ERR_DOMAIN);
     bx = min(bx, hi); by = min(by, hi); bz = min(bz, hi);
+    if (valid && !p.dist.on) {
+        // the test k_g2p applies to the advected position (guard band included), in the tile of the block the
+        // particle is binned to
+        const float guard = .125f, top = (float)(TILE_W - 2) - guard;
+        const float pos[3] = {xq.x, xq.y, xq.z}, vel[3] = {vx, vy, vz};
+        const uint32_t bc[3] = {bx, by, bz};
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const float t = pos[k] * p.dxinv - .5f - (float)((int)(bc[k] & ~3u) - FREE_ZONE);
+            const float v = vel[k] * p.dxinv, a = k == p.M.gravity_axis ? p.M.gravity * p.dxinv : 0.f;
+            quiet = fminf(quiet, fminf(time_to_travel(top - t, v, a), time_to_travel(t - guard, -v, -a)));
+        }
+    }
     if (p.dist.on && valid && xq.w > 0.f) {
         // an owned particle may sit up to zone - 3 cells beyond a cut: its stencil (2 more cells) and the
         // motion until the next re-sort (the tile's free zone, < 1 cell past this test on average) stay
@@ -116,6 +141,20 @@ __global__ __launch_bounds__(256) void k_rb_count(DP p) {
         p.pkey[i] = valid ? key : 0xFFFFFFFFu;
         p.prank[i] = rank;
     }
+    }
+    if (!p.dist.on) {
+        // minimum over the workgroup, then over 32 slots, 128 bytes apart (same-address device atomics serialise at the
+        // memory side: one slot for everybody cost 80 us per re-sort); k_rb_finish takes the minimum of the slots.
+        // The slots hold the COMPLEMENT of the float's bits and take maxima, so that zero-filled memory means "none".
+        __shared__ unsigned s_quiet[4];
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) quiet = fminf(quiet, __shfl_xor(quiet, d));
+        if ((threadIdx.x & 63) == 0) s_quiet[threadIdx.x >> 6] = __float_as_uint(quiet);
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const unsigned m = min(min(s_quiet[0], s_quiet[1]), min(s_quiet[2], s_quiet[3]));
+            atomicMax(&p.tickets[(blockIdx.x & 31u) * 32u + 1u], ~m);
+        }
     }
 }
 
@@ -585,6 +624,14 @@ __global__ __launch_bounds__(256) void k_rb_finish(DP p) {
                 c->nfa = c->nfa_new;
                 c->nva = c->nva_new;
                 c->add_f = c->add_v = 0;
+                // k_rb_count's minimum (0 where it was not taken: a partitioned domain)
+                unsigned q = 0u;
+                for (unsigned k = 0; k < 32u; ++k) {
+                    q = max(q, p.tickets[k * 32u + 1u]);
+                    p.tickets[k * 32u + 1u] = 0u;
+                }
+                c->quiet_time = q ? __uint_as_float(~q) : 0.f;
+                c->time_since_resort = 0.f;
             }
         }
     }

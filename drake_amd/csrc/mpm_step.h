@@ -968,6 +968,7 @@ __global__ __launch_bounds__(G2P_THREADS) __attribute__((amdgpu_waves_per_eu(MPM
         if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&p.ctl->skipped, 1u);
         return;
     }
+    if (blockIdx.x == 0 && threadIdx.x == 0) p.ctl->time_since_resort += dt;   // (see Ctl::quiet_time)
     const PSet& S = p.set[ctl->cur];
     const unsigned n_items = ctl->n_items;
     for (unsigned vq = blockIdx.x; vq < n_items * G2P_SPLIT; vq += gridDim.x) {

@@ -127,3 +127,53 @@ def test_gpu_sync_without_a_state_argument():
     sa = a.stats()
     assert sa["substeps"] == 60 and sa["error_flags"] == 0 and sa["rebuilds"] > 2
     assert np.array_equal(a.download(A.POSITIONS), b.download(A.POSITIONS))
+
+
+def test_quiet_time_spares_the_check_launches():
+    """The re-sort estimates how long no particle can leave its tile if all of them keep moving ballistically
+    (Ctl::quiet_time); while half of that lasts, mpm_run_substeps enqueues substeps without the launches of the
+    conditional re-sort.  The estimate is a hint -- a wrong one defers substeps, it cannot change results -- so the
+    test checks (a) that it is a lower bound of the time to the first re-sort of a falling cloth, (b) that the
+    launches are indeed left out, (c) that the trajectory is the one of an engine that never trusts it."""
+    import os
+    from drake_amd import ARR as A, GpuMpm
+
+    def engine(factor):
+        old = os.environ.get("MPM_QUIET_FACTOR")
+        os.environ["MPM_QUIET_FACTOR"] = factor
+        try:
+            g = GpuMpm(7)
+        finally:
+            if old is None:
+                del os.environ["MPM_QUIET_FACTOR"]
+            else:
+                os.environ["MPM_QUIET_FACTOR"] = old
+        g.set_deterministic(True)
+        scenes.populate(g, scenes.cloth_stack(4, 100, 7, z0=0.6, vel_amp=0.05, seed=5))
+        return g
+
+    a, b, c = engine("0.5"), engine("0"), engine("0.5")
+    # (read from c: every call other than mpm_run_substeps drops the hint -- it may change the state -- and the
+    # substeps after it get their check launches; a and b go from Finalize straight into the batch)
+    quiet = c.stats()["quiet_time_s"]
+    assert 0.02 < quiet < 0.2, quiet          # ~ sqrt(2 * 1.9 cells * dx / g) = 0.055 s on this grid
+    n = 24
+    a.run_substeps(n, DT, -1)
+    b.run_substeps(n, DT, -1)
+    sa, sb = a.stats(), b.stats()
+    assert sa["error_flags"] == 0 and sb["error_flags"] == 0
+    assert sa["resort_checks"] <= 2 and sb["resort_checks"] >= n // 4, (sa, sb)
+    assert sa["rebuilds"] == sb["rebuilds"]
+    for arr in (A.POSITIONS, A.VELOCITIES, A.AFFINE, A.DEFORMATION_GRADIENTS):
+        assert np.array_equal(a.download(arr), b.download(arr)), arr
+    # (a) phase by phase (a check with every substep): the first re-sort after Finalize's does not come earlier
+    r0 = c.stats()["rebuilds"]
+    first = None
+    for s in range(400):
+        _phase_substep(c, -1)
+        if c.stats()["rebuilds"] > r0:
+            first = s          # the re-sort ran at the head of substep s: s substeps had been completed before it
+            break
+    assert first is not None
+    assert first * DT >= 0.9 * quiet, (first, quiet)
+    assert first * DT <= 3.0 * quiet, (first, quiet)   # ... and it is not uselessly small either
