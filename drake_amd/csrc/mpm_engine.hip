@@ -475,7 +475,7 @@ int mpm_counts(mpm_handle_t e, size_t* nv, size_t* nf, size_t* np) {
     return 0;
 }
 
-static int settle(mpm_engine* e);
+static int settle(mpm_engine* e, Ctl* fresh = nullptr);
 
 int mpm_set_deterministic(mpm_handle_t e, int on) {
     REQUIRE(e, "null handle");
@@ -545,13 +545,16 @@ static int recover_slab_overflow(mpm_engine* e, Ctl& c) {
 int mpm_sync(mpm_handle_t e) {
     REQUIRE(e, "null handle");
     if (int rc = use(e)) return rc;
-    if (e->finalized)
-        if (int rc = settle(e)) return rc;
-    HIP_TRY(hipStreamSynchronize(e->stream));
-    HIP_TRY(hipGetLastError());
-    if (!e->finalized && !e->dp.ctl) return 0;
     Ctl c;
-    D2H(e, &c, e->dp.ctl, sizeof(Ctl));
+    e->settle_read_ctl = false;
+    if (e->finalized)
+        if (int rc = settle(e, &c)) return rc;
+    if (!e->settle_read_ctl) {   // (otherwise settle() has just synchronised and read the control block: once is enough)
+        HIP_TRY(hipStreamSynchronize(e->stream));
+        HIP_TRY(hipGetLastError());
+        if (!e->finalized && !e->dp.ctl) return 0;
+        D2H(e, &c, e->dp.ctl, sizeof(Ctl));
+    }
     if (e->finalized && !c.error)
         if (int rc = slab_pool_grow(e, c)) return rc;
     if (c.error & ERR_DRIFT)
@@ -583,7 +586,9 @@ static void launch_substep(mpm_engine* e, float dt, const GridColliders& gc, boo
 // Substeps that mpm_run_substeps enqueued without their re-sort launches and that found a re-sort pending
 // did nothing (Ctl::skipped): run them now, each with the re-sort in front.  Called by every entry point
 // before it looks at or changes the state.
-static int settle(mpm_engine* e) {
+// `fresh`: receives the control block if this call read it and enqueued nothing afterwards (the stream is idle and
+// *fresh is the state); untouched otherwise.
+static int settle(mpm_engine* e, Ctl* fresh) {
     e->force_check = true;   // whatever comes next starts with the re-sort launches
     e->dp.gated = 0;
     e->quiet_left = 0.f;     // (the call that settles may change the state: the hint is only kept from a settle that
@@ -603,7 +608,13 @@ static int settle(mpm_engine* e) {
         if (e->dp.dbg & 32)
             std::fprintf(stderr, "[mpm_hip] settle: quiet time %.4g s, %.4g s since the re-sort, %u owed, re-sort pending %d, checks launched %llu\n",
                          c.quiet_time, c.time_since_resort, owed, c.need_rebuild, (unsigned long long)e->checks_launched);
-        if (!owed) break;
+        if (!owed) {
+            if (fresh) {
+                *fresh = c;
+                e->settle_read_ctl = true;
+            }
+            break;
+        }
         const unsigned zero = 0;
         H2D(e, &e->dp.ctl->skipped, &zero, sizeof(unsigned));
         GridColliders gc;
@@ -1062,9 +1073,12 @@ static void launch_substep(mpm_engine* e, float dt, const GridColliders& gc, boo
     // the last re-sort estimated lasts (half of it: the estimate is ballistic, elastic forces are not in it), then
     // with every check_every-th substep.  A wrong guess costs time, not correctness: substeps that find a re-sort
     // pending without their check skip themselves and are run again by settle().
-    bool check = !allow_gate || e->force_check || e->check_every <= 1 || e->dp.dist.on;
+    // (a quiet time left over from the settle() that has just read it also stands for "no re-sort pending, nothing
+    // has touched the state since": the check that otherwise follows every other call is not needed either)
+    const bool quiet = allow_gate && e->quiet_factor * e->quiet_left > dt;
+    bool check = !allow_gate || (e->force_check && !quiet) || e->check_every <= 1 || e->dp.dist.on;
     if (!check) {
-        if (e->quiet_factor * e->quiet_left > dt) {
+        if (quiet) {
             e->quiet_left -= dt / e->quiet_factor;
         } else {
             e->quiet_left = 0.f;
