@@ -461,6 +461,7 @@ int mpm_destroy(mpm_handle_t e) {
     for (void* a : e->allocs) hipFree(a);
     if (e->dp.slab) hipFree(e->dp.slab);
     if (e->d_stage) hipFree(e->d_stage);
+    if (e->h_ctl) (void)hipHostFree(e->h_ctl);
     e->cb.release();
     if (e->own_stream) hipStreamDestroy(e->own_stream);
     delete e;
@@ -598,7 +599,11 @@ static int settle(mpm_engine* e, Ctl* fresh) {
     for (int round = 0; round < 8 && e->maybe_owed; ++round) {
         e->maybe_owed = false;
         Ctl c;
-        D2H(e, &c, e->dp.ctl, sizeof(Ctl));   // (synchronises the stream)
+        // (synchronises the stream.  Into pinned memory: a copy into pageable memory is staged by the runtime and
+        // costs ~10 us more, which a caller that synchronises after every frame of substeps pays every time)
+        if (!e->h_ctl) HIP_TRY(hipHostMalloc((void**)&e->h_ctl, sizeof(Ctl), hipHostMallocDefault));
+        D2H(e, e->h_ctl, e->dp.ctl, sizeof(Ctl));
+        c = *e->h_ctl;
         // every substep since the overflowing re-sort has skipped itself: the pool can be grown and the re-sort repeated
         if (int rc = recover_slab_overflow(e, c)) return rc;
         const unsigned owed = c.skipped;

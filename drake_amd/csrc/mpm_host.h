@@ -63,6 +63,7 @@ struct mpm_engine {
     bool force_check = true;   // the next substep gets them whatever its number (after any other call)
     float quiet_left = 0.f;    // seconds of Ctl::quiet_time left as of the last settle() (0: unknown)
     uint64_t checks_launched = 0;   // (diagnostics)
+    Ctl* h_ctl = nullptr;           // pinned landing place of the control block (settle)
     bool settle_read_ctl = false;   // settle() handed its copy of the control block to the caller (mpm_sync)
     float quiet_factor = .5f;  // share of it that is trusted (MPM_QUIET_FACTOR; 0 = check launches as before)
     bool maybe_owed = false;   // gated substeps were enqueued since the last settle()

@@ -42,7 +42,29 @@ __global__ __launch_bounds__(256) void k_rb_count(DP p) {
     const int i = active_slot(p, listed ? idx : total - 1, nf_in);
     const int ii = i;
     const uint32_t hi = (uint32_t)((1 << p.bits) - 3);
-    const float4 xq = S.q[0][ii];
+    // A face particle sits at the centroid of its corners and moves with their mean velocity: CalcFemStateAndForce
+    // puts it there before anything else looks at it, so that is where it is binned.  Its own position / velocity
+    // records may be a substep old (GridToParticle's lean mode does not write them).  In a partitioned domain the
+    // record is current (no lean mode there) and carries the particle's role in its w.
+    const bool face_from_corners = listed && ii < p.Nf && !p.dist.on;
+    float4 xq;
+    float4 rec = make_float4(.5f, .5f, .5f, 0.f);   // a face's own position record (only checked against the grid)
+    float vx = 0.f, vy = 0.f, vz = 0.f;
+    if (face_from_corners) {
+        rec = S.q[0][ii];
+        const float4 f3 = S.fq[3][ii];
+        const int s0 = __float_as_int(f3.y), s1 = __float_as_int(f3.z), s2 = __float_as_int(f3.w);
+        const float4 xa = S.q[0][s0], xb = S.q[0][s1], xc = S.q[0][s2];
+        const float4 a = S.q[1][s0], b = S.q[1][s1], c = S.q[1][s2];
+        xq = make_float4((xa.x + xb.x + xc.x) / 3.f, (xa.y + xb.y + xc.y) / 3.f, (xa.z + xb.z + xc.z) / 3.f, 1.f);
+        vx = (a.x + b.x + c.x) / 3.f; vy = (a.y + b.y + c.y) / 3.f; vz = (a.z + b.z + c.z) / 3.f;
+    } else {
+        xq = S.q[0][ii];
+        if (!p.dist.on) {   // (a partitioned domain bins by position and checks with every substep)
+            const float4 vq = S.q[1][ii];
+            vx = vq.x; vy = vq.y; vz = vq.z;
+        }
+    }
     const bool valid = listed && xq.w != 0.f;   // volume 0: released by the migration, dropped here
     // Anticipatory binning: a particle may sit up to FREE_ZONE cells outside its home block, on either side.
     // Binned by where it will be a few substeps from now (at most 1.75 cells ahead, which leaves it
@@ -51,19 +73,6 @@ __global__ __launch_bounds__(256) void k_rb_count(DP p) {
     // Slow particles are binned where they are.  (The cell part of the key follows the shifted position
     // too: the order inside a block only has to be approximately by cell.)
     float px = xq.x, py = xq.y, pz = xq.z;
-    float vx = 0.f, vy = 0.f, vz = 0.f;
-    if (!p.dist.on) {   // (a partitioned domain bins by position and checks with every substep)
-        if (listed && ii < p.Nf) {
-            // a face particle moves with the mean velocity of its corners (CalcFemStateAndForce puts it there before
-            // anything else looks at it); its own velocity record may be a substep old (lean GridToParticle)
-            const float4 f3 = S.fq[3][ii];
-            const float4 a = S.q[1][__float_as_int(f3.y)], b = S.q[1][__float_as_int(f3.z)], c = S.q[1][__float_as_int(f3.w)];
-            vx = (a.x + b.x + c.x) / 3.f; vy = (a.y + b.y + c.y) / 3.f; vz = (a.z + b.z + c.z) / 3.f;
-        } else {
-            const float4 vq = S.q[1][ii];
-            vx = vq.x; vy = vq.y; vz = vq.z;
-        }
-    }
     if (p.anticip > 0.f) {
         const float A = 1.75f;
         px += fminf(fmaxf(vx * p.anticip, -A), A) * p.dx;
@@ -74,7 +83,11 @@ __global__ __launch_bounds__(256) void k_rb_count(DP p) {
     // (a negative coordinate saturates to cell 0 in the conversion, so test the float)
     const float lim = (float)(hi + 1u);
     auto inside = [&](float x) { const float t = x * p.dxinv - .5f; return t >= 0.f && t < lim; };
-    if (valid && !(inside(xq.x) && inside(xq.y) && inside(xq.z)) && !(p.ctl->error & ERR_DOMAIN))
+    // (a face's own record too: stale inside a batch of substeps, but then it was inside the grid when it was written;
+    // a caller's upload that puts it outside is reported like any other particle's)
+    if (valid && !(inside(xq.x) && inside(xq.y) && inside(xq.z) &&
+                   (!face_from_corners || (inside(rec.x) && inside(rec.y) && inside(rec.z)))) &&
+        !(p.ctl->error & ERR_DOMAIN))
         atomicOr(&p.ctl->error, ERR_DOMAIN);
     bx = min(bx, hi); by = min(by, hi); bz = min(bz, hi);
     if (valid && !p.dist.on) {

@@ -942,15 +942,20 @@ MPM_DEV int g2p_particle(const DP& p, const PSet& S, const float4* tile, unsigne
         for (int c = 0; c < 3; ++c) Cn[r * 3 + c] = ca * (sc * nC[r * 3 + c]) + cb * (sc * nC[c * 3 + r]);
     // four 16-byte stores per particle (in this order: it keeps the kernel at 126 VGPRs without scratch)
     const float xn = x + nv[0] * dt, yn = y + nv[1] * dt, zn = z + nv[2] * dt;
-    S.q[0][i] = make_float4(xn, yn, zn, vol);
+    // A face particle's position and velocity are only looked at from outside (downloads): CalcFemStateAndForce
+    // replaces them by the means of the corners before anything in a substep reads them (the re-sort bins a face by
+    // the same means), and takes C8 from the c8 plane.  Between the substeps of one mpm_run_substeps batch the two
+    // records are therefore not written (DP::lean_g2p; the last substep of a batch and the phase-by-phase calls
+    // write them): 36 instead of 68 bytes out per face.
+    const bool is_face = i < (unsigned)p.Nf;
+    const bool full = !(p.lean_g2p && is_face);
+    // (in this order: another one costs the kernel its register budget)
     S.q[2][i] = make_float4(Cn[0], Cn[1], Cn[2], Cn[3]);
     S.q[3][i] = make_float4(Cn[4], Cn[5], Cn[6], Cn[7]);
-    // A face particle's velocity is only looked at from outside (downloads): CalcFemStateAndForce replaces it by the
-    // mean of the corners before anything in a substep reads it, and takes C8 from the c8 plane.  Between the substeps
-    // of one mpm_run_substeps batch the record is therefore not written (DP::lean_g2p; the last substep of a batch and
-    // the phase-by-phase calls write it).
-    const bool is_face = i < (unsigned)p.Nf;
-    if (!(p.lean_g2p && is_face)) S.q[1][i] = make_float4(nv[0], nv[1], nv[2], Cn[8]);
+    if (full) {
+        S.q[0][i] = make_float4(xn, yn, zn, vol);
+        S.q[1][i] = make_float4(nv[0], nv[1], nv[2], Cn[8]);
+    }
     if (is_face) S.c8[i] = Cn[8];
     // Does the advected particle still fit this block's tile?  Vertices are tested where the next
     // P2G will find them; a face is re-centred on its corners by the FEM kernel first, which moves
