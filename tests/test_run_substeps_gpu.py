@@ -60,8 +60,9 @@ def test_uneven_batches_match_phase_calls():
 
 
 def test_last_substep_of_a_batch_writes_the_face_velocities():
-    """GridToParticle skips the velocity record of face particles between the substeps of a batch (nothing inside
-    a substep reads it); what a caller downloads after the batch is the last substep's, as after phase calls."""
+    """GridToParticle skips the position and velocity records of face particles between the substeps of a batch
+    (nothing inside a substep reads them); what a caller downloads after the batch is the last substep's, as after
+    phase calls."""
     from drake_amd import ARR as A
     a, b = _engine(), _engine()
     a.run_substeps(7, DT, -1)
@@ -71,17 +72,21 @@ def test_last_substep_of_a_batch_writes_the_face_velocities():
     idx_a, idx_b = a.download(A.INDEX_MAPPINGS), b.download(A.INDEX_MAPPINGS)
     va, vb = a.download(A.VELOCITIES), b.download(A.VELOCITIES)
     ca, cb = a.download(A.AFFINE), b.download(A.AFFINE)
+    xa, xb = a.download(A.POSITIONS), b.download(A.POSITIONS)
     assert np.array_equal(idx_a, idx_b)
     faces = idx_a[:nf]
     scale = float(np.abs(vb).max())
     assert float(np.abs(va[faces] - vb[faces]).max()) < 1e-4 * scale
     assert float(np.abs(ca[faces] - cb[faces]).max()) < 1e-4 * float(np.abs(cb).max())
+    # (the positions of face particles are left out between the substeps of a batch as well)
+    assert float(np.abs(xa[faces] - xb[faces]).max()) < 1e-6
     # one substep earlier the face velocities were different (the test would not notice a stale record otherwise)
     c = _engine()
     for _ in range(6):
         _phase_substep(c, -1)
     vc = c.download(A.VELOCITIES)
     assert float(np.abs(vc[faces] - vb[faces]).max()) > 1e-3 * scale
+    assert float(np.abs(c.download(A.POSITIONS)[faces] - xb[faces]).max()) > 1e-5
 
 
 def test_collider_table_changed_between_batches():
