@@ -135,7 +135,9 @@ struct DP {
                            // re-sort pending; bit 1: it returns at once when the slab pool has overflowed (every substep
                            // of mpm_run_substeps; the phase-by-phase calls cannot be repeated by the engine).  Either way it
                            // counts itself in Ctl::skipped and the host runs it again (settle, mpm_engine.hip)
-    int lean_g2p;          // 1: k_g2p leaves q[1] of the face particles alone (see g2p_particle); per launch
+    int lean_g2p;          // 1: another substep of the same mpm_run_substeps batch follows, nobody can look at the state
+                           // in between: k_g2p leaves the x / v records of the face particles alone (see g2p_particle),
+                           // k_p2g keeps the vertex forces of its work items in LDS only; per substep
     float anticip;         // re-sort: cells a particle is binned ahead per unit of velocity (0 = by position), see k_rb_count
     // fixed-point scales of the LDS tile accumulators (powers of two), see k_p2g
     double fix_m, fix_p, unfix_m, unfix_p;

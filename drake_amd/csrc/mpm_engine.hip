@@ -1098,9 +1098,9 @@ static void launch_substep(mpm_engine* e, float dt, const GridColliders& gc, boo
         e->checks_launched += 1;
     }
     e->maybe_owed = true;
+    e->dp.lean_g2p = lean && !e->dp.dist.on;   // (k_p2g: the forces stay in LDS; k_g2p: no face x / v records)
     launch_fem_p2g(e, dt);
     launch_grid(e, gc);
-    e->dp.lean_g2p = lean && !e->dp.dist.on;
     launch_g2p(e, dt);
     e->dp.lean_g2p = 0;
 }
@@ -1172,13 +1172,13 @@ int mpm_profile_substeps(mpm_handle_t e, int n, float dt, int bc, float* phase_m
         HIP_TRY(hipEventRecord(q[2], e->stream));
         // (as in mpm_run_substeps: the vertex forces are part of k_p2g; this phase is empty)
         HIP_TRY(hipEventRecord(q[3], e->stream));
+        e->dp.lean_g2p = s + 1 < n && !e->dp.dist.on;   // (as in mpm_run_substeps)
         e->dp.fuse_vforce = 1;
         launch_p2g(e, dt);
         e->dp.fuse_vforce = 0;
         HIP_TRY(hipEventRecord(q[4], e->stream));
         launch_grid(e, gc);
         HIP_TRY(hipEventRecord(q[5], e->stream));
-        e->dp.lean_g2p = s + 1 < n && !e->dp.dist.on;   // (as in mpm_run_substeps)
         launch_g2p(e, dt);
         e->dp.lean_g2p = 0;
         HIP_TRY(hipEventRecord(q[6], e->stream));

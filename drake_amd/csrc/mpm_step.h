@@ -206,7 +206,7 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 #define MPM_P2G_STG16 1
 #endif
 #ifndef MPM_P2G_LDSF
-#define MPM_P2G_LDSF 0   // vertex forces handed over in LDS: 8 MB less traffic, 0.2 - 1.2 us slower (measured)
+#define MPM_P2G_LDSF 1   // vertex forces handed over in LDS: 8 MB less traffic per substep for 0.3 us (measured)
 #endif
 #if MPM_P2G_STG16
 // staged floats per particle: the 13 columns of Y that carry numbers, then fx, fy, fz in the three columns of the
@@ -409,7 +409,8 @@ __global__ __launch_bounds__(P2G_THREADS) __attribute__((amdgpu_waves_per_eu(P2G
         auto force_of = [&](unsigned ii, float* f) {
 #if MPM_P2G_LDSF
             if (f_lds) {
-                const unsigned k = ii - (unsigned)v0_item;
+                // (face lanes come with a slot that is not a vertex of the item: any entry will do, they do not use it)
+                const unsigned k = min(ii - (unsigned)v0_item, (unsigned)(LDSF_CAP - 1));
                 f[0] = s_frc[k * 3]; f[1] = s_frc[k * 3 + 1]; f[2] = s_frc[k * 3 + 2];
                 return;
             }
@@ -461,7 +462,9 @@ __global__ __launch_bounds__(P2G_THREADS) __attribute__((amdgpu_waves_per_eu(P2G
                 const int k = sv - v0_item;
                 if (f_lds) {
                     s_frc[k * 3] = f0; s_frc[k * 3 + 1] = f1; s_frc[k * 3 + 2] = f2;
-                } else {
+                }
+                // (p.f is what a caller downloads as the forces: between the substeps of one batch nobody can)
+                if (!f_lds || !p.lean_g2p) {
                     p.f[0][sv] = f0; p.f[1][sv] = f1; p.f[2][sv] = f2;
                 }
 #else

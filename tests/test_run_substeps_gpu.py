@@ -53,7 +53,8 @@ def test_uneven_batches_match_phase_calls():
     assert sa["rebuilds"] > 5, sa                      # the scene does exercise the deferral
     assert sa["rebuilds"] == sb["rebuilds"]
     # same arithmetic in the same order (fused vertex forces, lean GridToParticle and deferred substeps included)
-    for arr in (A.POSITIONS, A.VELOCITIES, A.AFFINE, A.DEFORMATION_GRADIENTS):
+    # (the forces too: the last substep of a batch writes them out, the others keep them inside ParticleToGrid)
+    for arr in (A.POSITIONS, A.VELOCITIES, A.AFFINE, A.DEFORMATION_GRADIENTS, A.FORCES, A.TAUS):
         xa, xb = a.download(arr), b.download(arr)
         assert np.isfinite(xa).all()
         assert np.array_equal(xa, xb), (arr, float(np.abs(xa - xb).max()))
