@@ -492,7 +492,7 @@ def main():
     assert st["error_flags"] == 0, st
     # (substeps of warm-up + timed region that carried the launches of the conditional re-sort; the others went without,
     # inside the quiet time the last re-sort estimated)
-    region["resort_check_launches_since_finalize"] = st.get("resort_checks")
+    region["resort_check_launches_since_finalize"] = st["resort_checks"] - 1   # (Finalize's own sort is one)
     region["substeps_since_finalize"] = args.warmup + args.steps
     # The steady state next to the driver's window: SURVEY 8(d)'s 200 substeps after 20 (the cloth has picked up
     # speed, re-sorts included), whatever --steps / --warmup were.  Not `value`.

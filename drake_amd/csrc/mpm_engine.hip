@@ -72,6 +72,7 @@ int mpm_create(int domain_bits, const mpm_material_t* material, int device, mpm_
     }
     e->stream = e->own_stream;
     if (getenv("MPM_RESORT_EVERY")) e->check_every = std::max(1, atoi(getenv("MPM_RESORT_EVERY")));
+    if (getenv("MPM_DEFER_PHASES")) e->defer_phases = atoi(getenv("MPM_DEFER_PHASES")) != 0;
     if (getenv("MPM_QUIET_FACTOR")) e->quiet_factor = std::min(1.f, std::max(0.f, (float)atof(getenv("MPM_QUIET_FACTOR"))));
     if (getenv("MPM_GRAPH")) e->graph_len = std::max(0, atoi(getenv("MPM_GRAPH")));
     {
@@ -151,6 +152,7 @@ static void launch_rebuild(mpm_engine* e) {
     static const float horizon = getenv("MPM_ANTICIPATE") ? (float)atof(getenv("MPM_ANTICIPATE")) : 32.f;
     e->dp.anticip = e->dp.dist.on ? 0.f : horizon * e->last_dt * e->dp.dxinv;
     const DP& p = e->dp;
+    e->checks_launched += 1;
     TraceRange tr("mpm:RebuildMapping (conditional re-sort)");
     // (host state only -- nothing below may depend on this function running: captured graphs replay the launches
     // without it.  Callers that enqueue a possible re-sort call may_resort() themselves.)
@@ -589,7 +591,18 @@ static void launch_substep(mpm_engine* e, float dt, const GridColliders& gc, boo
 // before it looks at or changes the state.
 // `fresh`: receives the control block if this call read it and enqueued nothing afterwards (the stream is idle and
 // *fresh is the state); untouched otherwise.
+static int flush_phases(mpm_engine* e);
+static int settle_owed(mpm_engine* e, Ctl* fresh);
 static int settle(mpm_engine* e, Ctl* fresh) {
+    if (int rc = settle_owed(e, fresh)) return rc;
+    // phase calls that were waiting for the rest of their substep (see PendingPhases) come after everything owed
+    if (e->pend.n) {
+        e->settle_read_ctl = false;   // (what settle_owed read is no longer the state)
+        return flush_phases(e);
+    }
+    return 0;
+}
+static int settle_owed(mpm_engine* e, Ctl* fresh) {
     e->force_check = true;   // whatever comes next starts with the re-sort launches
     e->dp.gated = 0;
     e->quiet_left = 0.f;     // (the call that settles may change the state: the hint is only kept from a settle that
@@ -725,7 +738,42 @@ int mpm_device_synchronize(void) {
     return first ? fail(first, first_msg) : 0;
 }
 
+// The reference's five calls per substep (cuda_mpm_test.cc:64-72, deformable_driver.h:244-258), taken one by one, are
+// nine launches with the re-sort check in front of every substep and the vertex forces as a kernel of their own.
+// When they arrive in the standard order -- RebuildMapping(false), CalcFemStateAndForce(dt), ParticleToGrid(dt),
+// UpdateGrid(bc), GridToParticle(dt) -- nothing is launched until the last one, and the substep then goes through the
+// same path as mpm_run_substeps(1): check launches only when a re-sort can be due, vertex forces inside ParticleToGrid,
+// deferral if a re-sort is pending.  Any other call in between (a download, the contact calls, a different order, a
+// different dt) first launches what was held back, call by call as before, so every intermediate state a caller can
+// look at is the one the reference would show.  MPM_DEFER_PHASES=0 turns this off.
+static bool can_defer(const mpm_engine* e) { return e->defer_phases && e->finalized && !e->dp.dist.on; }
+static int flush_phases(mpm_engine* e) {
+    const int n = e->pend.n;
+    e->pend.n = 0;
+    if (n >= 1) {
+        may_resort(e, 0.f);
+        launch_rebuild(e);
+    }
+    if (n >= 2) launch_fem(e, e->pend.dt);
+    if (n >= 3) {
+        launch_p2g(e, e->pend.dt);
+        e->grid_state = 1;
+    }
+    if (n >= 4) {
+        GridColliders gc;
+        if (int rc = grid_colliders_for(e, e->pend.bc, &gc)) return rc;
+        launch_grid(e, gc);
+        e->grid_state = 2;
+    }
+    return 0;
+}
+
 int mpm_rebuild_mapping(mpm_handle_t e, int sort) {
+    if (e && can_defer(e) && !sort && e->pend.n == 0) {
+        READY_NO_SETTLE(e);
+        e->pend.n = 1;
+        return 0;
+    }
     READY(e);
     may_resort(e, 0.f);
     launch_rebuild(e);
@@ -737,12 +785,23 @@ int mpm_rebuild_mapping(mpm_handle_t e, int sort) {
 }
 
 int mpm_calc_fem_state_and_force(mpm_handle_t e, float dt) {
+    if (e && can_defer(e) && e->pend.n == 1) {
+        READY_NO_SETTLE(e);
+        e->pend.n = 2;
+        e->pend.dt = dt;
+        return 0;
+    }
     READY(e);
     launch_fem(e, dt);
     return 0;
 }
 
 int mpm_particle_to_grid(mpm_handle_t e, float dt) {
+    if (e && can_defer(e) && e->pend.n == 2 && dt == e->pend.dt) {
+        READY_NO_SETTLE(e);
+        e->pend.n = 3;
+        return 0;
+    }
     READY(e);
     launch_p2g(e, dt);
     e->grid_state = 1;
@@ -750,6 +809,14 @@ int mpm_particle_to_grid(mpm_handle_t e, float dt) {
 }
 
 int mpm_update_grid(mpm_handle_t e, int bc) {
+    if (e && can_defer(e) && e->pend.n == 3) {
+        READY_NO_SETTLE(e);
+        GridColliders probe;
+        if (int rc = grid_colliders_for(e, bc, &probe)) return rc;   // (a bad mpm_bc is reported by this call)
+        e->pend.n = 4;
+        e->pend.bc = bc;
+        return 0;
+    }
     READY(e);
     REQUIRE(e->grid_state >= 1, "UpdateGrid before ParticleToGrid");
     GridColliders gc;
@@ -1061,6 +1128,11 @@ int mpm_chain_substeps(mpm_handle_t e, int n, float dt, int bc) {
 }
 
 int mpm_grid_to_particle(mpm_handle_t e, float dt) {
+    if (e && can_defer(e) && e->pend.n == 4 && dt == e->pend.dt) {
+        // the substep is complete: one gated substep, as mpm_run_substeps(1) enqueues it
+        e->pend.n = 0;
+        return mpm_run_substeps(e, 1, dt, e->pend.bc);
+    }
     READY(e);
     REQUIRE(e->grid_state == 2, "GridToParticle before UpdateGrid");
     launch_g2p(e, dt);
@@ -1095,7 +1167,6 @@ static void launch_substep(mpm_engine* e, float dt, const GridColliders& gc, boo
     if (check) {
         launch_rebuild(e);
         e->force_check = false;
-        e->checks_launched += 1;
     }
     e->maybe_owed = true;
     e->dp.lean_g2p = lean && !e->dp.dist.on;   // (k_p2g: the forces stay in LDS; k_g2p: no face x / v records)
@@ -1129,8 +1200,9 @@ static int step_graph_for(mpm_engine* e, float dt, int bc, const GridColliders& 
 
 int mpm_run_substeps(mpm_handle_t e, int n, float dt, int bc) {
     READY_NO_SETTLE(e);
-    // owed substeps are run with the parameters they were enqueued with: settle before these change
-    if (e->maybe_owed && (dt != e->owed_dt || bc != e->owed_bc || e->grid_colliders_version != e->owed_gcv))
+    // owed substeps are run with the parameters they were enqueued with: settle before these change (and before phase
+    // calls that were held back, which come first)
+    if (e->pend.n || (e->maybe_owed && (dt != e->owed_dt || bc != e->owed_bc || e->grid_colliders_version != e->owed_gcv)))
         if (int rc = settle(e)) return rc;
     e->owed_dt = dt;
     e->owed_bc = bc;

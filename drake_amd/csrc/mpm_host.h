@@ -62,6 +62,14 @@ struct mpm_engine {
     unsigned step_phase = 0;
     bool force_check = true;   // the next substep gets them whatever its number (after any other call)
     float quiet_left = 0.f;    // seconds of Ctl::quiet_time left as of the last settle() (0: unknown)
+    // phase calls of a substep in the reference's order that have been accepted but not launched (mpm_engine.hip,
+    // mpm_rebuild_mapping): n of RebuildMapping(false), CalcFemStateAndForce(dt), ParticleToGrid(dt), UpdateGrid(bc)
+    struct PendingPhases {
+        int n = 0;
+        float dt = 0.f;
+        int bc = 0;
+    } pend;
+    bool defer_phases = true;       // MPM_DEFER_PHASES=0: every phase call launches its kernels at once
     uint64_t checks_launched = 0;   // (diagnostics)
     Ctl* h_ctl = nullptr;           // pinned landing place of the control block (settle)
     bool settle_read_ctl = false;   // settle() handed its copy of the control block to the caller (mpm_sync)

@@ -123,8 +123,9 @@ typedef struct {
     uint64_t scene_index_bytes; /* device bytes indexed by ORIGINAL particle id (id -> slot map, slot-order
                                    bookkeeping, topology tables of Finalize): whole-scene sized on every rank;
                                    a partitioned engine keeps only the maps, 13 bytes per particle of the scene */
-    uint64_t resort_checks;   /* substeps that were enqueued WITH the launches of the conditional re-sort (mpm_run_substeps
-                                 leaves them out while the quiet time below lasts, then sends them with every 4th)     */
+    uint64_t resort_checks;   /* times the kernels of the conditional re-sort were launched, Finalize's first sort
+                                 included (mpm_run_substeps and complete phase-by-phase substeps leave them out while
+                                 the quiet time below lasts, then send them with every 4th substep)                   */
     float quiet_time_s;       /* the last re-sort's estimate of how long no particle can leave its block's tile when
                                  all of them move ballistically (velocity + gravity); 0 = not estimated                */
     float since_resort_s;     /* simulated time since that re-sort                                                     */

@@ -183,3 +183,67 @@ def test_quiet_time_spares_the_check_launches():
     assert first is not None
     assert first * DT >= 0.9 * quiet, (first, quiet)
     assert first * DT <= 3.0 * quiet, (first, quiet)   # ... and it is not uselessly small either
+
+
+def test_phase_calls_held_back_until_the_substep_is_complete():
+    """The reference's five calls per substep launch nothing until GridToParticle arrives and then go the way of
+    mpm_run_substeps(1); a call that looks at an intermediate state first launches what was held back.  Against an
+    engine that launches every call at once (MPM_DEFER_PHASES=0): the same bits everywhere a caller can look."""
+    import os
+    from drake_amd import ARR as A, GpuMpm
+
+    def engine(defer):
+        old = os.environ.get("MPM_DEFER_PHASES")
+        os.environ["MPM_DEFER_PHASES"] = defer
+        try:
+            g = GpuMpm(7)
+        finally:
+            if old is None:
+                del os.environ["MPM_DEFER_PHASES"]
+            else:
+                os.environ["MPM_DEFER_PHASES"] = old
+        g.set_deterministic(True)
+        sheets = scenes.cloth_stack(4, 100, 7, z0=0.45, vel_amp=0.3, seed=3)
+        for pos, vel, idx in sheets:
+            vel[:, 0] += 2.0
+        scenes.populate(g, sheets)
+        return g
+
+    a, b = engine("1"), engine("0")
+    looks = {
+        1: (A.PIDS, A.INDEX_MAPPINGS),                      # after RebuildMapping
+        2: (A.FORCES, A.TAUS, A.DEFORMATION_GRADIENTS),     # after CalcFemStateAndForce
+        3: (A.GRID_MASSES, A.GRID_MOMENTUM),                # after ParticleToGrid
+        4: (A.GRID_MOMENTUM, A.GRID_V_STAR),                # after UpdateGrid
+        5: (A.POSITIONS, A.VELOCITIES, A.AFFINE),           # after GridToParticle
+    }
+    rng = np.random.default_rng(2)
+    for step in range(60):
+        look_at = int(rng.integers(0, 8))                   # 0, 6, 7: a substep nobody looks into
+        for g in (a, b):
+            g.rebuild_mapping(False)
+            if look_at == 1:
+                got = [g.download(x) for x in looks[1]]
+            g.calc_fem_state_and_force(DT)
+            if look_at == 2:
+                got = [g.download(x) for x in looks[2]]
+            g.particle_to_grid(DT)
+            if look_at == 3:
+                got = [g.download(x) for x in looks[3]]
+            g.update_grid(0)
+            if look_at == 4:
+                got = [g.download(x) for x in looks[4]]
+            g.grid_to_particle(DT)
+            if look_at == 5:
+                got = [g.download(x) for x in looks[5]]
+            if g is a:
+                got_a = got if look_at in looks else None
+        if look_at in looks:
+            for x, ya, yb in zip(looks[look_at], got_a, got):
+                assert np.array_equal(ya, yb), (step, look_at, x)
+    sa, sb = a.stats(), b.stats()
+    assert sa["error_flags"] == 0 and sb["error_flags"] == 0
+    assert sa["substeps"] == sb["substeps"] == 60 and sa["rebuilds"] == sb["rebuilds"] and sa["rebuilds"] > 2
+    assert sa["resort_checks"] < sb["resort_checks"]        # (the held-back substeps went without most check launches)
+    for arr in (A.POSITIONS, A.VELOCITIES, A.AFFINE, A.DEFORMATION_GRADIENTS):
+        assert np.array_equal(a.download(arr), b.download(arr)), arr
