@@ -754,9 +754,11 @@ static int flush_phases(mpm_engine* e) {
         may_resort(e, 0.f);
         launch_rebuild(e);
     }
-    if (n >= 2) launch_fem(e, e->pend.dt);
+    if (n == 2) launch_fem(e, e->pend.dt);
     if (n >= 3) {
-        launch_p2g(e, e->pend.dt);
+        // (nobody looked at the forces between CalcFemStateAndForce and ParticleToGrid: the vertex forces are
+        // gathered inside k_p2g, which also writes them out -- one launch less, the same numbers)
+        launch_fem_p2g(e, e->pend.dt);
         e->grid_state = 1;
     }
     if (n >= 4) {
