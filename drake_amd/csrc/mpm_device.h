@@ -135,6 +135,8 @@ struct DP {
                            // re-sort pending; bit 1: it returns at once when the slab pool has overflowed (every substep
                            // of mpm_run_substeps; the phase-by-phase calls cannot be repeated by the engine).  Either way it
                            // counts itself in Ctl::skipped and the host runs it again (settle, mpm_engine.hip)
+    int lean_resort;       // 1: the conditional re-sort is followed by CalcFemStateAndForce at once (a whole substep was
+                           // enqueued): k_rb_finish does not move the x / v records of face particles; per launch
     int lean_g2p;          // 1: another substep of the same mpm_run_substeps batch follows, nobody can look at the state
                            // in between: k_g2p leaves the x / v records of the face particles alone (see g2p_particle),
                            // k_p2g keeps the vertex forces of its work items in LDS only; per substep

@@ -1167,7 +1167,9 @@ static void launch_substep(mpm_engine* e, float dt, const GridColliders& gc, boo
     e->step_phase += 1;
     e->dp.gated = check ? 2 : 3;   // (bit 1: it also skips itself while the slab pool is too small, see DP::gated)
     if (check) {
+        e->dp.lean_resort = !e->dp.dist.on;
         launch_rebuild(e);
+        e->dp.lean_resort = 0;
         e->force_check = false;
     }
     e->maybe_owed = true;

@@ -558,9 +558,16 @@ __global__ __launch_bounds__(256) void k_rb_finish(DP p) {
     for (unsigned idx = i0; idx < (unsigned)total_out; idx += gs) {
         const unsigned j = (unsigned)active_slot(p, (int)idx, nf_out);
         const unsigned i = p.src_of[j];
-        const float4 a0 = S.q[0][i], a1 = S.q[1][i], a2 = S.q[2][i], a3 = S.q[3][i];
+        // (a face particle's x / v records are not moved when CalcFemStateAndForce is the next thing to run -- it
+        // writes both before anything reads them: DP::lean_resort, the re-sorts of whole substeps)
+        const bool xv = !(p.lean_resort && j < (unsigned)p.Nf);
+        const float4 a2 = S.q[2][i], a3 = S.q[3][i];
         const int pid = S.pid[i];
-        D.q[0][j] = a0; D.q[1][j] = a1; D.q[2][j] = a2; D.q[3][j] = a3;
+        if (xv) {
+            const float4 a0 = S.q[0][i], a1 = S.q[1][i];
+            D.q[0][j] = a0; D.q[1][j] = a1;
+        }
+        D.q[2][j] = a2; D.q[3][j] = a3;
         D.pid[j] = pid;
         if (j < (unsigned)p.Nf) {
             const float4 b0 = S.fq[0][i], b1 = S.fq[1][i], b2 = S.fq[2][i];
