@@ -34,7 +34,8 @@ constexpr unsigned ERR_SLABS = 32u;     // the re-sort made more work items than
 // Face particles carry four more records and two scalars, indexed by face slot.  What CalcFemStateAndForce
 // rewrites every substep (F) is kept apart from what only a re-sort moves (Dm^-1, volume, corners), so
 // that k_fem reads and writes exactly the 36 bytes of F:
-//   fq[0] = (F0..F3)  fq[1] = (F4..F7)  f8 = F8                                  (written by k_fem)
+//   fq[0] = (F2, F5, F8, F0)  fq[1] = (F1, F3, F4, F6)  f8 = F7     (written by k_fem; pack_F below: the normal
+//           column F[:,2] first, k_p2g reads it from here as the second factor of tau)
 //   fq[2] = (Dm0, Dm1, Dm3, |vol|)   Dm^-1 of a QR cloth is upper triangular (cuda_mpm_kernels.cuh:13-70:
 //           Dm = R of a Givens QR), Dm^-1[2] is +-0 and not stored; |vol| is a copy of |q[0].w|
 //   fq[3] = (0, v0, v1, v2)   v* = slots of the three corner vertices (int bits)
@@ -153,8 +154,8 @@ struct DP {
     // the whole scene's topology stays on a rank
     int4* fg[2];           // [set][face slot] original ids of the three corner vertices
     int4* vg[2][2];        // [set][2][vertex slot - Nf] up to eight (original face id << 2 | corner), -1 = none
-    float4* ab0;           // faces: tau = a (x) b with a = vol*P[:,2], b = F[:,2]: (a0, a1, a2, b0)
-    float2* ab1;           //        (b1, b2)
+    float3* ta;            // faces: tau = a (x) b with a = vol*P[:,2] (12-byte records); b = F[:,2] is the first three
+                           // floats of fq[0] (see pack_F)
     float3* G3;            // faces: G3[face slot * 3 + c] = force triple the face exerts on corner c (negated when
                            // applied); 12-byte records: 36 B written per face and one dwordx3 gather per adjacency
     float* f[3];           // vertices: internal force
@@ -218,6 +219,20 @@ MPM_DEV int active_slot(const DP& p, int idx, int nf_in) { return idx < nf_in ? 
 #define MPM_DIAG 0
 #endif
 MPM_DEV int diag_flags(const DP& p) { return MPM_DIAG ? p.dbg : 0; }
+
+// The deformation gradient of a face (row-major F[0..8]) in its three planes: fq[0] = (F2, F5, F8, F0), fq[1] = (F1, F3,
+// F4, F6), f8 = F7.  The normal column F[:,2] comes first and together: it is the factor b of tau = a (x) b that
+// k_p2g needs, which reads it from here instead of from a second copy (8 bytes per face less for k_fem to write).
+MPM_DEV void pack_F(const float* F, float4& r0, float4& r1, float& r2) {
+    r0 = make_float4(F[2], F[5], F[8], F[0]);
+    r1 = make_float4(F[1], F[3], F[4], F[6]);
+    r2 = F[7];
+}
+MPM_DEV void unpack_F(const float4& r0, const float4& r1, float r2, float* F) {
+    F[2] = r0.x; F[5] = r0.y; F[8] = r0.z; F[0] = r0.w;
+    F[1] = r1.x; F[3] = r1.y; F[4] = r1.z; F[6] = r1.w;
+    F[7] = r2;
+}
 
 // A home block with n particles has ceil(n/64) wave groups; its list starts at this pool offset
 // (blocks are laid out in slot order, so the offsets never overlap).

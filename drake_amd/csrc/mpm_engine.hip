@@ -302,8 +302,7 @@ int mpm_finalize(mpm_handle_t e) {
         ALLOC(S.pid, np, true);
         for (int d = 0; d < 2; ++d) ALLOC(S.va[d], nv, true);
     }
-    ALLOC(p.ab0, std::max<size_t>(nf, 1), true);   // (k_p2g's vertex lanes read element 0 when an item has no face)
-    ALLOC(p.ab1, std::max<size_t>(nf, 1), true);
+    ALLOC(p.ta, std::max<size_t>(nf, 1), true);   // (k_p2g's vertex lanes read element 0 when an item has no face)
     ALLOC(p.G3, 3 * nf, true);
     {
         float* base = nullptr;
@@ -1310,7 +1309,7 @@ int mpm_get_stats(mpm_handle_t e, mpm_stats_t* out) {
             for (int d = 0; d < 4; ++d) pb += e->bytes_of(S.fq[d]);
             for (int d = 0; d < 2; ++d) pb += e->bytes_of(S.va[d]) + e->bytes_of(p.vg[s][d]);
         }
-        pb += e->bytes_of(p.ab0) + e->bytes_of(p.ab1) + e->bytes_of(p.G3) + e->bytes_of(p.f[0]) + e->bytes_of(p.pkey) +
+        pb += e->bytes_of(p.ta) + e->bytes_of(p.G3) + e->bytes_of(p.f[0]) + e->bytes_of(p.pkey) +
               e->bytes_of(p.prank) + e->bytes_of(p.src_of) + e->bytes_of(p.dst_of) + e->bytes_of(p.home_groups);
         sb += e->bytes_of(p.imap) + e->bytes_of(e->d_pids_api) + e->bytes_of(e->d_apimap) + e->bytes_of(p.dist.prev);
         for (int d = 0; d < 3; ++d) sb += e->bytes_of(p.idx_orig[d]);
@@ -1490,7 +1489,7 @@ static int dist_shrink(mpm_engine* e) {
             if ((rc = move(S.va[d], new_nv, live ? nva : 0, 0, 0)) || (rc = move(p.vg[s][d], new_nv, live ? nva : 0, 0, 0))) return rc;
     }
     // per-substep outputs and re-sort scratch: nothing to keep
-    if ((rc = move(p.ab0, new_nf, 0, 0, 0)) || (rc = move(p.ab1, new_nf, 0, 0, 0)) || (rc = move(p.G3, 3 * new_nf, 0, 0, 0))) return rc;
+    if ((rc = move(p.ta, new_nf, 0, 0, 0)) || (rc = move(p.G3, 3 * new_nf, 0, 0, 0))) return rc;
     {
         float* base = nullptr;
         if ((rc = e->dalloc(&base, 3 * (size_t)new_q_stride, true))) return rc;

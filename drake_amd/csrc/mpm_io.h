@@ -35,9 +35,7 @@ __global__ __launch_bounds__(256) void k_init_faces(DP p) {
     const float v4 = sqrtf(cx * cx + cy * cy + cz * cz) / 8.f * p.dx;
     S.q[0][i] = make_float4((xa.x + xb.x + xc.x) / 3.f, (xa.y + xb.y + xc.y) / 3.f, (xa.z + xb.z + xc.z) / 3.f, v4);
     S.q[1][i] = make_float4((va.x + vb.x + vc.x) / 3.f, (va.y + vb.y + vc.y) / 3.f, (va.z + vb.z + vc.z) / 3.f, 0.f);
-    S.fq[0][i] = make_float4(Q[0], Q[1], Q[2], Q[3]);
-    S.fq[1][i] = make_float4(Q[4], Q[5], Q[6], Q[7]);
-    S.f8[i] = Q[8];
+    pack_F(Q, S.fq[0][i], S.fq[1][i], S.f8[i]);
     S.c8[i] = 0.f;
     S.fq[2][i] = make_float4(Di[0], Di[1], Di[3], v4);   // (Di[2] = -0 / det: Dm is upper triangular)
     S.fq[3][i] = make_float4(0.f, f3.y, f3.z, f3.w);
@@ -98,9 +96,7 @@ MPM_DEV void read_field(const DP& p, const PSet& S, int j, float* o) {
         o[0] = v ? p.f[0][j] : 0.f; o[1] = v ? p.f[1][j] : 0.f; o[2] = v ? p.f[2][j] : 0.f;
     }
     if (FIELD == F_DEFGRAD) {
-        const float4 a = S.fq[0][j], b = S.fq[1][j];
-        o[0] = a.x; o[1] = a.y; o[2] = a.z; o[3] = a.w; o[4] = b.x; o[5] = b.y; o[6] = b.z; o[7] = b.w;
-        o[8] = S.f8[j];
+        unpack_F(S.fq[0][j], S.fq[1][j], S.f8[j], o);
     }
     if (FIELD == F_DMINV) {   // as Finalize computed it, entry [2] (a signed zero) included
         if (p.dm_orig) {
@@ -128,9 +124,7 @@ MPM_DEV void write_field(const DP& p, const PSet& S, int j, const float* v) {
         if (j < p.Nf) S.c8[j] = v[8];
     }
     if (FIELD == F_DEFGRAD) {
-        S.fq[0][j] = make_float4(v[0], v[1], v[2], v[3]);
-        S.fq[1][j] = make_float4(v[4], v[5], v[6], v[7]);
-        S.f8[j] = v[8];
+        pack_F(v, S.fq[0][j], S.fq[1][j], S.f8[j]);
     }
 }
 
@@ -174,10 +168,10 @@ __global__ __launch_bounds__(256) void k_gather_taus(DP p, float* out, const int
     const int j = p.imap[pids_api[s]];
     float a[3] = {0.f, 0.f, 0.f}, b[3] = {0.f, 0.f, 0.f};
     if (j >= 0 && j < p.Nf) {
-        const float4 q = p.ab0[j];
-        const float2 r = p.ab1[j];
+        const float3 q = p.ta[j];
+        const float4 r = p.set[p.ctl->cur].fq[0][j];
         a[0] = q.x; a[1] = q.y; a[2] = q.z;
-        b[0] = q.w; b[1] = r.x; b[2] = r.y;
+        b[0] = r.x; b[1] = r.y; b[2] = r.z;
     }
 #pragma unroll
     for (int r = 0; r < 3; ++r)

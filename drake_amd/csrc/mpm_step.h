@@ -26,8 +26,8 @@ __global__ __launch_bounds__(256) void k_fem(DP p, float dt) {
     const unsigned i = xcd_chunk(blockIdx.x, gridDim.x) * 256 + threadIdx.x;
     if (i >= (unsigned)p.ctl->nfa) return;
     const PSet& S = p.set[p.ctl->cur];
-    // 104 bytes in (F 36, Dm^-1 | vol | corners 32, C 36) + the corner gathers; 128 bytes out (F 36, face x v 32,
-    // tau factors 24, corner forces 36).  The face particle's own q[0] / q[1] are written, never read: its
+    // 104 bytes in (F 36, Dm^-1 | vol | corners 32, C 36) + the corner gathers; 116 bytes out (F 36, face x v 32,
+    // tau factor a 12 -- the other one is F's normal column, see pack_F --, corner forces 36).  The face particle's own q[0] / q[1] are written, never read: its
     // volume comes from the static record, C8 from the c8 plane (see PSet).
     const float4 f0 = S.fq[0][i], f1 = S.fq[1][i], f2 = S.fq[2][i], f3 = S.fq[3][i];
     const float F8 = S.f8[i], C8 = S.c8[i];
@@ -41,8 +41,7 @@ __global__ __launch_bounds__(256) void k_fem(DP p, float dt) {
         const float nan = __int_as_float(0x7FC00000);
 #pragma unroll
         for (int c = 0; c < 3; ++c) p.G3[(size_t)i * 3 + c] = make_float3(nan, nan, nan);
-        p.ab0[i] = make_float4(nan, nan, nan, nan);
-        p.ab1[i] = make_float2(nan, nan);
+        p.ta[i] = make_float3(nan, nan, nan);
         return;
     }
     const float4 xa = S.q[0][s0], xb = S.q[0][s1], xc = S.q[0][s2];
@@ -60,7 +59,8 @@ __global__ __launch_bounds__(256) void k_fem(DP p, float dt) {
     auto mean3 = [&](float a, float b, float c) { return MPM_FEM_IEEE ? (a + b + c) / 3.f : (a + b + c) * third; };
     S.q[0][i] = make_float4(mean3(xa.x, xb.x, xc.x), mean3(xa.y, xb.y, xc.y), mean3(xa.z, xb.z, xc.z), volw);
     S.q[1][i] = make_float4(mean3(va.x, vb.x, vc.x), mean3(va.y, vb.y, vc.y), mean3(va.z, vb.z, vc.z), C8);
-    const float F[9] = {f0.x, f0.y, f0.z, f0.w, f1.x, f1.y, f1.z, f1.w, F8};
+    float F[9];
+    unpack_F(f0, f1, F8, F);
     const float Dm0 = f2.x, Dm1 = f2.y, Dm3 = f2.z;   // Dm^-1 = [Dm0 Dm1; 0 Dm3]
     const float C[9] = {q2.x, q2.y, q2.z, q2.w, q3.x, q3.y, q3.z, q3.w, C8};
     const float vol = f2.w;
@@ -81,17 +81,14 @@ __global__ __launch_bounds__(256) void k_fem(DP p, float dt) {
         cF[d * 3 + 0] = e0 * Dm0;
         cF[d * 3 + 1] = e0 * Dm1 + e1 * Dm3;
     }
-    S.fq[0][i] = make_float4(cF[0], cF[1], cF[2], cF[3]);
-    S.fq[1][i] = make_float4(cF[4], cF[5], cF[6], cF[7]);
-    S.f8[i] = cF[8];
+    pack_F(cF, S.fq[0][i], S.fq[1][i], S.f8[i]);
 
     float P[9];
     cloth_dphi_dF(p.M, cF, P);
 #pragma unroll
     for (int d = 0; d < 9; ++d) P[d] *= vol;
-    // tau = (V P[:,2]) (x) F[:,2]  (:265-267), kept factored
-    p.ab0[i] = make_float4(P[2], P[5], P[8], cF[2]);
-    p.ab1[i] = make_float2(cF[5], cF[8]);
+    // tau = (V P[:,2]) (x) F[:,2]  (:265-267), kept factored: the second factor is in fq[0] already
+    p.ta[i] = make_float3(P[2], P[5], P[8]);
     // grad_N = Dm^-T [[-1,1,0],[-1,0,1]]  (:269-276)
     const float g00 = -Dm0, g01 = Dm0;
     const float g10 = -Dm1 - Dm3, g11 = Dm1, g12 = Dm3;
@@ -444,9 +441,9 @@ __global__ __launch_bounds__(P2G_THREADS) __attribute__((amdgpu_waves_per_eu(P2G
             // waited for its whole prefetch (a memory round trip per group) before starting the contraction.
             {
                 const unsigned fi = r.is_face ? ii : (unsigned)(nfb ? rg.x : 0), vi = r.is_face ? any_slot : ii;
-                const float4 a = p.ab0[fi];
-                const float2 b = p.ab1[fi];
-                r.ta[0] = a.x; r.ta[1] = a.y; r.ta[2] = a.z; r.tb[0] = a.w; r.tb[1] = b.x; r.tb[2] = b.y;
+                const float3 a = p.ta[fi];
+                const float3 b = *reinterpret_cast<const float3*>(&S.fq[0][fi]);   // F[:,2], see pack_F
+                r.ta[0] = a.x; r.ta[1] = a.y; r.ta[2] = a.z; r.tb[0] = b.x; r.tb[1] = b.y; r.tb[2] = b.z;
                 force_of(vi, r.frc);
             }
             return r;
