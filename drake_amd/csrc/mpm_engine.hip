@@ -923,7 +923,9 @@ int mpm_substep_begin_halo(mpm_handle_t e, float dt, int n, const int* bx_lo, co
     REQUIRE(n == 0 || (cap > 0 && cap < (1u << 24)), "bad halo buffer");
     DP p = e->dp;   // per-launch copy: k_grid<0> resets the entry counters of the send buffers
     HaloZones z{};
-    std::vector<uint64_t> key = {1, bits_of(dt), (uint64_t)n, (uint64_t)cap, (uint64_t)(uintptr_t)e->stream};
+    // (mpm_chain_substeps: another substep of the same batch follows, see DP::lean_g2p)
+    const int lean = e->chain_lean && !e->dp.dist.on;
+    std::vector<uint64_t> key = {1, bits_of(dt), (uint64_t)n, (uint64_t)cap, (uint64_t)(uintptr_t)e->stream, (uint64_t)lean};
     for (int i = 0; i < n; ++i) {
         REQUIRE(send_bufs[i], "null halo buffer");
         p.halo_hdr[i] = static_cast<uint32_t*>(send_bufs[i]);
@@ -933,8 +935,12 @@ int mpm_substep_begin_halo(mpm_handle_t e, float dt, int n, const int* bx_lo, co
                                (uint64_t)(uintptr_t)send_bufs[i]});
     }
     auto body = [&]() {
+        e->dp.lean_resort = !e->dp.dist.on;   // (CalcFemStateAndForce follows at once)
         launch_rebuild(e);
+        e->dp.lean_resort = 0;
+        e->dp.lean_g2p = lean;
         launch_fem_p2g(e, dt);
+        e->dp.lean_g2p = 0;
         hipLaunchKernelGGL(k_grid<0>, dim3(e->g_grid), dim3(256), 0, e->stream, p, GridColliders{});
         if (n > 0)
             hipLaunchKernelGGL(k_halo_pack2, dim3(e->g_grid, n), dim3(256), 0, e->stream, e->dp, z, (unsigned)cap);
@@ -975,8 +981,9 @@ int mpm_substep_end_halo(mpm_handle_t e, float dt, int bc, int n, const void* co
     GridColliders gc;
     if (int rc = grid_colliders_for(e, bc, &gc)) return rc;
     HaloBufs b{};
+    const int lean = e->chain_lean && !e->dp.dist.on;
     std::vector<uint64_t> key = {2, bits_of(dt), (uint64_t)(uint32_t)bc, (uint64_t)n, (uint64_t)cap,
-                                 (uint64_t)(uintptr_t)e->stream, e->grid_colliders_version};
+                                 (uint64_t)(uintptr_t)e->stream, e->grid_colliders_version, (uint64_t)lean};
     for (int i = 0; i < n; ++i) {
         REQUIRE(recv_bufs[i], "null halo buffer");
         b.buf[i] = static_cast<const uint32_t*>(recv_bufs[i]);
@@ -984,6 +991,7 @@ int mpm_substep_end_halo(mpm_handle_t e, float dt, int bc, int n, const void* co
     }
     const bool split = e->halo_mid_done;
     DP p = e->dp;
+    p.lean_g2p = lean;
     if (split) {   // the interior is done: only what the received sums touch is left
         p.halo_cls = 1;
         p.halo_nz = e->halo_nz;
@@ -1084,6 +1092,10 @@ int mpm_chain_substeps(mpm_handle_t e, int n, float dt, int bc) {
     mpm_engine::Chain& c = e->chain;
     REQUIRE(c.comm, "mpm_chain_init first");
     const rccl_rt::Api* a = rccl_rt::api();
+    struct LeanReset {   // (whatever way this function is left)
+        mpm_engine* e;
+        ~LeanReset() { e->chain_lean = 0; }
+    } lean_reset{e};
     // zones / buffers in the order (left, right), leaving out a missing neighbour
     int lo[2], hi[2], sh[2], nz = 0;
     void *sb[2], *rb[2];
@@ -1107,7 +1119,11 @@ int mpm_chain_substeps(mpm_handle_t e, int n, float dt, int bc) {
                 return rc;
         }
         c.steps += 1;
-        if (int rc = mpm_substep_begin_halo(e, dt, nz, lo, hi, sh, sb, c.cap)) return rc;
+        e->chain_lean = s + 1 < n;   // (reset below; the two calls are public entry points of their own as well)
+        if (int rc = mpm_substep_begin_halo(e, dt, nz, lo, hi, sh, sb, c.cap)) {
+            e->chain_lean = 0;
+            return rc;
+        }
         if (nz > 0) {
             RCCL_TRY(a->group_start());
             // what goes to the left arrives "from the right" over there: when both neighbours are the
@@ -1122,7 +1138,9 @@ int mpm_chain_substeps(mpm_handle_t e, int n, float dt, int bc) {
             RCCL_TRY(rc_g);
             RCCL_TRY(rc_e);
         }
-        if (int rc = mpm_substep_end_halo(e, dt, bc, nz, rb, c.cap)) return rc;
+        const int rc_end = mpm_substep_end_halo(e, dt, bc, nz, rb, c.cap);
+        e->chain_lean = 0;
+        if (rc_end) return rc_end;
     }
     HIP_TRY(hipGetLastError());
     return 0;

@@ -69,6 +69,7 @@ struct mpm_engine {
         float dt = 0.f;
         int bc = 0;
     } pend;
+    int chain_lean = 0;             // mpm_chain_substeps: another substep of the batch follows (DP::lean_g2p)
     bool defer_phases = true;       // MPM_DEFER_PHASES=0: every phase call launches its kernels at once
     uint64_t checks_launched = 0;   // (diagnostics)
     Ctl* h_ctl = nullptr;           // pinned landing place of the control block (settle)
