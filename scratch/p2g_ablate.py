@@ -19,7 +19,7 @@ if len(sys.argv) > 1 and sys.argv[1] == "child":
             best = dict(ph)
     print(json.dumps({"dbg": int(os.environ.get("MPM_DBG", "0")), **{k: round(v * 1e3, 1) for k, v in best.items()}}))
     sys.exit(0)
-for flags in (0, 2, 1, 8, 16, 64, 128, 8 | 16, 0):
+for flags in (0, 128, 16, 2, 1, 8, 0):
     env = dict(os.environ, MPM_DBG=str(flags), MPM_HIP_LIBRARY=os.path.join(ROOT, "drake_amd/variants/libmpm_hip_diag.so"))
     r = subprocess.run([sys.executable, os.path.abspath(__file__), "child"], env=env, capture_output=True, text=True, timeout=300)
     print(r.stdout.strip().splitlines()[-1] if r.stdout.strip() else ("FAILED " + r.stderr[-300:]), flush=True)
