@@ -175,6 +175,11 @@ struct DP {
     // per launch: restrict k_grid<2> / k_g2p to the part of the grid that does (1) or does not (0)
     // depend on the halo exchange; -1 = everything.  Zones are x-block ranges [lo, hi].
     int halo_cls, halo_nz, halo_zlo[2], halo_zhi[2];
+    // per launch of k_grid<0> in a chain substep: the zones whose raw node sums go straight into the send buffers
+    // (what k_halo_pack2 does as a kernel of its own for the public mpm_halo_pack)
+    int halo_pn, halo_plo[2], halo_phi[2], halo_pshift[2];
+    unsigned halo_pcap;
+    uint32_t* halo_pbuf[2];
     int* cellcnt[2];       // [type][cell key]; zero outside a rebuild
     int* blkcnt[2];        // [type][block id]; zero outside a rebuild
     int* blkstart[2];

@@ -921,16 +921,18 @@ int mpm_substep_begin_halo(mpm_handle_t e, float dt, int n, const int* bx_lo, co
     may_resort(e, dt);
     REQUIRE(n >= 0 && n <= 2 && (n == 0 || (bx_lo && bx_hi && shift_bx && send_bufs)), "bad halo zone list");
     REQUIRE(n == 0 || (cap > 0 && cap < (1u << 24)), "bad halo buffer");
-    DP p = e->dp;   // per-launch copy: k_grid<0> resets the entry counters of the send buffers
-    HaloZones z{};
+    DP p = e->dp;   // per-launch copy: k_grid<0> packs the zones' sums into the send buffers as it gathers them
+    DP pp = e->dp;  // ... and k_p2g, in front of it, resets their entry counters
+    p.halo_pn = n;
+    p.halo_pcap = (unsigned)cap;
     // (mpm_chain_substeps: another substep of the same batch follows, see DP::lean_g2p)
     const int lean = e->chain_lean && !e->dp.dist.on;
     std::vector<uint64_t> key = {1, bits_of(dt), (uint64_t)n, (uint64_t)cap, (uint64_t)(uintptr_t)e->stream, (uint64_t)lean};
     for (int i = 0; i < n; ++i) {
         REQUIRE(send_bufs[i], "null halo buffer");
-        p.halo_hdr[i] = static_cast<uint32_t*>(send_bufs[i]);
-        z.lo[i] = bx_lo[i]; z.hi[i] = bx_hi[i]; z.shift[i] = shift_bx[i];
-        z.buf[i] = static_cast<uint32_t*>(send_bufs[i]);
+        pp.halo_hdr[i] = static_cast<uint32_t*>(send_bufs[i]);
+        p.halo_plo[i] = bx_lo[i]; p.halo_phi[i] = bx_hi[i]; p.halo_pshift[i] = shift_bx[i];
+        p.halo_pbuf[i] = static_cast<uint32_t*>(send_bufs[i]);
         key.insert(key.end(), {(uint64_t)(uint32_t)bx_lo[i], (uint64_t)(uint32_t)bx_hi[i], (uint64_t)(uint32_t)shift_bx[i],
                                (uint64_t)(uintptr_t)send_bufs[i]});
     }
@@ -939,11 +941,11 @@ int mpm_substep_begin_halo(mpm_handle_t e, float dt, int n, const int* bx_lo, co
         launch_rebuild(e);
         e->dp.lean_resort = 0;
         e->dp.lean_g2p = lean;
+        for (int i = 0; i < 2; ++i) e->dp.halo_hdr[i] = pp.halo_hdr[i];
         launch_fem_p2g(e, dt);
+        for (int i = 0; i < 2; ++i) e->dp.halo_hdr[i] = nullptr;
         e->dp.lean_g2p = 0;
         hipLaunchKernelGGL(k_grid<0>, dim3(e->g_grid), dim3(256), 0, e->stream, p, GridColliders{});
-        if (n > 0)
-            hipLaunchKernelGGL(k_halo_pack2, dim3(e->g_grid, n), dim3(256), 0, e->stream, e->dp, z, (unsigned)cap);
     };
     if (halo_graphs()) {
         if (int rc = replay_keyed(e, e->halo_graph[0], key, body)) return rc;

@@ -308,6 +308,8 @@ constexpr int P2G_WAVES = MPM_P2G_WAVES, P2G_THREADS = 64 * P2G_WAVES;
 // two workgroups per CU: 8 waves each at <= 128 VGPRs (4 per SIMD), or 10 at <= 96 (5 per SIMD; -DMPM_P2G_WAVES=10)
 __global__ __launch_bounds__(P2G_THREADS) __attribute__((amdgpu_waves_per_eu(P2G_WAVES / 2, P2G_WAVES / 2))) void k_p2g(DP p, float dt) {
     if (gated_out(p)) return;
+    // chain substep: the entry counters of the halo send buffers, which the k_grid<0> behind this kernel fills
+    if (blockIdx.x == 0 && threadIdx.x < 2 && p.halo_hdr[threadIdx.x]) p.halo_hdr[threadIdx.x][0] = 0u;
     __shared__ long long tile[TILE_N * 4];  // (mvx, mvy, mvz, m) per node, fixed point
     // wave-private staging: 64 particles (+8 slack rows touched by the operand prefetch)
     __shared__ __attribute__((aligned(16))) float stage_all[P2G_WAVES][(64 + 8) * STG];
@@ -707,6 +709,9 @@ MPM_DEV int __reduce_max_sync_i32(int v) {
     return v;
 }
 
+// halo buffer layout: [0] count, [4..) block ids (cap), then cap * 64 float4 (see the multi-GPU section below)
+MPM_DEV size_t halo_ids_offset() { return 4; }                       // in uint32 units
+MPM_DEV size_t halo_data_offset(unsigned cap) { return ((size_t)(4 + cap) * 4 + 15) / 16; }  // in float4 units
 template <int MODE>
 __global__ __launch_bounds__(256) void k_grid(DP p, GridColliders gc) {
     __shared__ int2 s_list[4][GRID_LIST];   // (item, offset index)
@@ -778,6 +783,25 @@ __global__ __launch_bounds__(256) void k_grid(DP p, GridColliders gc) {
         const size_t gi = (size_t)a * 64 + cell;
         if (MODE == 0) {
             p.gv[gi] = s;
+            if (p.halo_pn > 0) {   // chain substep: blocks next to a cut go into the send buffers from here
+                int bx, by, bz;
+                block_coords(p.act_block[a], bx, by, bz);
+                for (int k = 0; k < p.halo_pn; ++k) {
+                    if (bx < p.halo_plo[k] || bx > p.halo_phi[k]) continue;   // wave-uniform
+                    const int nbx = bx + p.halo_pshift[k];
+                    if (nbx < 0 || nbx >= p.nb) continue;
+                    uint32_t* buf = p.halo_pbuf[k];
+                    unsigned slot = 0;
+                    if (cell == 0) slot = atomicAdd(&buf[0], 1u);
+                    slot = __builtin_amdgcn_readfirstlane(slot);
+                    if (slot >= p.halo_pcap) {
+                        if (cell == 0) atomicOr(&p.ctl->error, ERR_CAPACITY);
+                        continue;
+                    }
+                    if (cell == 0) buf[halo_ids_offset() + slot] = block_id((uint32_t)nbx, (uint32_t)by, (uint32_t)bz);
+                    (reinterpret_cast<float4*>(buf) + halo_data_offset(p.halo_pcap))[(size_t)slot * 64 + cell] = s;
+                }
+            }
             continue;
         }
         float4 vs = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -1037,8 +1061,6 @@ __global__ __launch_bounds__(G2P_THREADS) __attribute__((amdgpu_waves_per_eu(MPM
 // its own sums (k_halo_add) and both then run the same grid update (k_grid<2>) on shared blocks.
 // Buffer: [0] count, [4..) block ids (cap), then cap * 64 float4.
 // ---------------------------------------------------------------------------
-MPM_DEV size_t halo_ids_offset() { return 4; }                       // in uint32 units
-MPM_DEV size_t halo_data_offset(unsigned cap) { return ((size_t)(4 + cap) * 4 + 15) / 16; }  // in float4 units
 
 // both zones / both received buffers of a chain rank in one launch each (blockIdx.y selects)
 struct HaloZones {
