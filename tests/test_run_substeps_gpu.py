@@ -247,3 +247,61 @@ def test_phase_calls_held_back_until_the_substep_is_complete():
     assert sa["resort_checks"] < sb["resort_checks"]        # (the held-back substeps went without most check launches)
     for arr in (A.POSITIONS, A.VELOCITIES, A.AFFINE, A.DEFORMATION_GRADIENTS):
         assert np.array_equal(a.download(arr), b.download(arr)), arr
+
+
+def test_long_mixed_run_matches_an_engine_without_the_scheduling():
+    """900 substeps as uneven batches and phase-by-phase substeps, a collider table that moves, downloads in between:
+    the engine with the quiet time, the held-back phase calls, the lean modes and a re-sort check every fourth substep
+    against one with all of that switched off (a check with every substep, every call launched at once) -- the same
+    bits at every look and at the end (scratch/soak.py is the 3000-substep version)."""
+    import os
+    from drake_amd import ARR as A, BC_TABLE, GpuMpm, GridCollider
+
+    def engine(on):
+        env = dict(MPM_QUIET_FACTOR="0.5" if on else "0", MPM_DEFER_PHASES="1" if on else "0",
+                   MPM_RESORT_EVERY="4" if on else "1")
+        old = {k: os.environ.get(k) for k in env}
+        os.environ.update(env)
+        try:
+            g = GpuMpm(7)
+        finally:
+            for k, v in old.items():
+                if v is None:
+                    os.environ.pop(k, None)
+                else:
+                    os.environ[k] = v
+        g.set_deterministic(True)
+        sheets = scenes.cloth_stack(6, 120, 7, z0=0.55, vel_amp=0.4, seed=11)
+        for pos, vel, idx in sheets:
+            vel[:, 0] += 1.0
+        scenes.populate(g, sheets)
+        return g
+
+    a, b = engine(True), engine(False)
+    rng = np.random.default_rng(5)
+    done = looks = 0
+    while done < 900:
+        mode, k = int(rng.integers(0, 10)), int(rng.integers(1, 60))
+        tb = [GridCollider(shape=1, mode=1, p=(0.5, 0.5, 0.30), n=(0.0, 0.0, 1.0), v=(0.0, 0.0, 0.0), friction=0.4),
+              GridCollider(shape=0, mode=1, p=(0.3 + 0.0001 * done, 0.5, 0.36), radius=0.07, v=(0.2, 0.0, 0.0), friction=0.3)]
+        n = k if mode < 6 else min(k, 12)
+        for g in (a, b):
+            g.set_grid_colliders(tb)
+            if mode < 6:
+                g.run_substeps(n, DT, BC_TABLE)
+            else:
+                for _ in range(n):
+                    _phase_substep(g, BC_TABLE)
+        done += n
+        if rng.random() < 0.3:
+            arr = (A.POSITIONS, A.VELOCITIES, A.AFFINE, A.DEFORMATION_GRADIENTS, A.FORCES)[int(rng.integers(0, 5))]
+            xa, xb = a.download(arr), b.download(arr)
+            assert np.isfinite(xa).all(), (done, arr)
+            assert np.array_equal(xa, xb), (done, arr, float(np.abs(xa - xb).max()))
+            looks += 1
+    sa, sb = a.stats(), b.stats()
+    assert sa["error_flags"] == 0 and sb["error_flags"] == 0
+    assert sa["substeps"] == sb["substeps"] == done and sa["rebuilds"] == sb["rebuilds"] and sa["rebuilds"] > 5
+    assert sa["resort_checks"] < sb["resort_checks"] // 2 and looks > 5
+    for arr in (A.POSITIONS, A.VELOCITIES, A.AFFINE, A.DEFORMATION_GRADIENTS):
+        assert np.array_equal(a.download(arr), b.download(arr)), arr
