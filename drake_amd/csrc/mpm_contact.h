@@ -13,12 +13,18 @@
 #include "mpm_rootfind.h"
 #include "mpm_chain.h"
 
+// (the poison switch of the engine whose buffers are being grown: set by the callers of grow() from their handle)
+static thread_local bool g_grow_poison = false;
+struct GrowPoison {
+    explicit GrowPoison(const mpm_engine* e) { g_grow_poison = e->poison(); }
+    ~GrowPoison() { g_grow_poison = false; }
+};
 template <class T>
 static int grow(T** ptr, size_t n) {
     if (*ptr) HIP_TRY(hipFree(*ptr));
     *ptr = nullptr;
     HIP_TRY(hipMalloc((void**)ptr, std::max<size_t>(n, 1) * sizeof(T)));
-    if (mpm_engine::poison()) {  // debugging aid only: full device syncs around a null-stream fill
+    if (g_grow_poison) {  // debugging aid only: full device syncs around a null-stream fill
         HIP_TRY(hipDeviceSynchronize());
         HIP_TRY(hipMemset(*ptr, 0xFF, std::max<size_t>(n, 1) * sizeof(T)));
         HIP_TRY(hipDeviceSynchronize());
@@ -28,6 +34,7 @@ static int grow(T** ptr, size_t n) {
 
 // GpuMpmState::ReallocateContacts (cuda_mpm_model.cu:267-317) + the uploads of CopyContactPairs
 static int ensure_contact_capacity(mpm_engine* e, size_t n) {
+    GrowPoison gp(e);
     ContactBuffers& b = e->cb;
     if (n > b.cap) {
         const size_t cap = n + n / 4;
@@ -97,6 +104,7 @@ static int copy_contacts(mpm_engine* e, size_t n, const uint32_t* particle, cons
 
 // Device-side CalcMpmContactPairs + CopyContactPairs for analytic colliders (include/mpm_hip.h)
 static int generate_contacts(mpm_engine* e, size_t n_col, const mpm_collider_t* cols, size_t* n_out) {
+    GrowPoison gp(e);
     TraceRange tr("mpm:contact pairs (device)");
     static_assert(sizeof(Collider) == sizeof(mpm_collider_t), "collider layouts differ");
     ContactBuffers& b = e->cb;
@@ -167,7 +175,7 @@ static ContactDev make_contact_dev(mpm_engine* e, float dt, float mu, float k, f
     c.dt = dt; c.mu = mu; c.k = k; c.d = d;
     c.epsv = e->mat.epsv;
     c.relax = 0.3f;   // jacobi_relax_coeff, cuda_mpm_solver.cu:239
-    if (const char* t = getenv("MPM_CT_RELAX")) c.relax = (float)atof(t);   // (tests: overshoot on purpose, so that the backtracking has work)
+    if (e->ct_relax > 0.f) c.relax = e->ct_relax;   // (tests: overshoot on purpose, so that the backtracking has work)
     c.tol = 1e-4f;    // kTol, cuda_mpm_solver.cu:236
     c.slot = b.slot; c.body = b.body; c.dist = b.dist; c.normal = b.normal; c.pos = b.pos;
     c.rigid_v = b.rigid_v; c.p_WB = b.p_WB; c.vel = b.vel; c.vel0 = b.vel0;
@@ -257,14 +265,7 @@ static int dist_allreduce(mpm_engine* e, double* dev, size_t n) {
 // never idles while the host finds out whether the solve has finished (a stream synchronisation plus
 // relaunch cost ~40 us per batch); the price is one batch of idle launches at the end.
 // (batch sizes: MPM_CT_BATCH="first,next" overrides the defaults, for measurements)
-static int ct_batch(int which, int dflt) {
-    static int v[2] = {-1, -1};
-    if (v[0] < 0) {
-        v[0] = v[1] = 0;
-        if (const char* t = getenv("MPM_CT_BATCH")) sscanf(t, "%d,%d", &v[0], &v[1]);
-    }
-    return v[which] > 0 ? v[which] : dflt;
-}
+static int ct_batch(const mpm_engine* e, int which, int dflt) { return e->ct_batch[which] > 0 ? e->ct_batch[which] : dflt; }
 
 template <class Pattern>
 static int run_batches(mpm_engine* e, Pattern&& pattern, int first_batch, int batch, int max_iters, ContactState* out,
@@ -447,14 +448,14 @@ static int update_contact(mpm_engine* e, int frame, int substep, float dt, float
         // candidate steps, decision.  The accepted step reaches the grid velocity at the start of the
         // next iteration (k_ct_node_dir, lazy; k_ct_tile reads v - alpha D meanwhile) and, for the last
         // iteration, in the k_ct_apply after the loop.  MPM_CT_EAGER=1 keeps the separate k_ct_apply.
-        static const bool eager = getenv("MPM_CT_EAGER") != nullptr;
+        const bool eager = e->ct_eager;   // (per handle, read at mpm_create)
         auto pattern = [&](int index) {
             launch_dir(index == 0, eager ? 0 : 1);
             hipLaunchKernelGGL(k_ct_ls, dim3(n_con_wg + n_grid_wg), dim3(CT_WG), 0, s, p, c, n_con_wg, 0, 0.f);
             hipLaunchKernelGGL(k_ct_decide, dim3(1), dim3(1024), 0, s, c, n_dir_wg, n_con_wg, n_grid_wg, 0, 0);
             if (eager) hipLaunchKernelGGL(k_ct_apply, dim3(CT_ROWS), dim3(CT_WG), 0, s, p, c, 0);
         };
-        if (int rc = run_batches(e, pattern, ct_batch(0, 2), ct_batch(1, 2), max_iters, &st)) return rc;
+        if (int rc = run_batches(e, pattern, ct_batch(e, 0, 2), ct_batch(e, 1, 2), max_iters, &st)) return rc;
         if (!eager) hipLaunchKernelGGL(k_ct_apply, dim3(CT_ROWS), dim3(CT_WG), 0, s, p, c, 2);
         iters = st.iters;
         residual = st.residual;
@@ -477,7 +478,7 @@ static int update_contact(mpm_engine* e, int frame, int substep, float dt, float
         // (a search that never terminates cannot happen -- the root finder stops after 200 evaluations, which in
         // float it often needs: |dx| < 3e-9 is out of reach -- but the launches are bounded too: every Newton
         // iteration may take 200 / PROBES + 1 patterns)
-        if (int rc = run_batches(e, pattern, ct_batch(0, 1), ct_batch(1, 1), max_iters, &st,
+        if (int rc = run_batches(e, pattern, ct_batch(e, 0, 1), ct_batch(e, 1, 1), max_iters, &st,
                                  (200 / PROBES + 2) * max_iters + 64))
             return rc;
         iters = st.iters;
@@ -552,7 +553,7 @@ static int update_contact(mpm_engine* e, int frame, int substep, float dt, float
     hipLaunchKernelGGL(k_ct_impulse, dim3(std::min(gc, 256u)), dim3(256), 0, s, p, c);
     HIP_TRY(hipGetLastError());
     b.last_iters = iters;
-    if (getenv("MPM_CT_DEBUG")) fprintf(stderr, "contact solve: n %zu nodes %d items %d iters %d\n", n, st.n_nodes, 0, iters);
+    if (e->ct_debug) fprintf(stderr, "contact solve: n %zu nodes %d items %d iters %d\n", n, st.n_nodes, 0, iters);
     if (iters_out) *iters_out = iters;
     if (residual_out) *residual_out = residual;
     {

@@ -149,8 +149,7 @@ static int grid_colliders_for(mpm_engine* e, int bc, GridColliders* out) {
 static void launch_rebuild(mpm_engine* e) {
     // anticipatory binning over the next `horizon` substeps of the last known length (not in a partitioned
     // domain, where ownership and ghost bands are defined by the position itself)
-    static const float horizon = getenv("MPM_ANTICIPATE") ? (float)atof(getenv("MPM_ANTICIPATE")) : 32.f;
-    e->dp.anticip = e->dp.dist.on ? 0.f : horizon * e->last_dt * e->dp.dxinv;
+    e->dp.anticip = e->dp.dist.on ? 0.f : e->anticipate_horizon * e->last_dt * e->dp.dxinv;
     const DP& p = e->dp;
     e->checks_launched += 1;
     TraceRange tr("mpm:RebuildMapping (conditional re-sort)");
@@ -715,21 +714,25 @@ int mpm_debug_owed_substeps(mpm_handle_t e, uint32_t* out) {
 }
 
 int mpm_device_synchronize(void) {
+    // The reference's GpuSync() is a plain cudaDeviceSynchronize (cuda_mpm_solver.cu:164-166): it completes the work
+    // of the device and says nothing about the state of any simulation.  Here "the work" includes substeps that
+    // mpm_run_substeps deferred, so every engine of the device is settled and flushed first; the sticky SIMULATION
+    // errors of an engine (diverged, capacity, ...) stay with that engine -- its own mpm_sync / mpm_get_stats report
+    // them -- and only a failure of the runtime itself is an error of this call.  The list is walked under the lock
+    // that mpm_create / mpm_destroy take: an engine cannot be destroyed by another thread while it is being settled.
     int dev = 0;
     HIP_TRY(hipGetDevice(&dev));
-    std::vector<mpm_engine*> mine;
-    {
-        std::lock_guard<std::mutex> lock(g_live_mutex);
-        for (mpm_engine* e : g_live)
-            if (e->device == dev) mine.push_back(e);
-    }
     int first = 0;
     std::string first_msg;
-    for (mpm_engine* e : mine) {
-        const int rc = mpm_sync(e);   // settles what mpm_run_substeps deferred, waits, reports sticky errors
-        if (rc && !first) {
-            first = rc;
-            first_msg = g_last_error;
+    {
+        std::lock_guard<std::mutex> lock(g_live_mutex);
+        for (mpm_engine* e : g_live) {
+            if (e->device != dev) continue;
+            const int rc = mpm_sync(e);
+            if (rc == MPM_ERR_HIP && !first) {
+                first = rc;
+                first_msg = g_last_error;
+            }
         }
     }
     HIP_TRY(hipSetDevice(dev));
@@ -909,10 +912,6 @@ static int replay_keyed(mpm_engine* e, mpm_engine::KeyedGraph& kg, const std::ve
     HIP_TRY(hipGraphLaunch(kg.exec, e->stream));
     return 0;
 }
-static bool halo_graphs() {
-    static const bool on = getenv("MPM_HALO_GRAPH") != nullptr && atoi(getenv("MPM_HALO_GRAPH")) != 0;
-    return on;
-}
 static uint64_t bits_of(float f) { uint32_t u; std::memcpy(&u, &f, 4); return u; }
 
 int mpm_substep_begin_halo(mpm_handle_t e, float dt, int n, const int* bx_lo, const int* bx_hi, const int* shift_bx,
@@ -947,7 +946,7 @@ int mpm_substep_begin_halo(mpm_handle_t e, float dt, int n, const int* bx_lo, co
         e->dp.lean_g2p = 0;
         hipLaunchKernelGGL(k_grid<0>, dim3(e->g_grid), dim3(256), 0, e->stream, p, GridColliders{});
     };
-    if (halo_graphs()) {
+    if (e->use_halo_graphs) {
         if (int rc = replay_keyed(e, e->halo_graph[0], key, body)) return rc;
     } else {
         body();
@@ -1004,7 +1003,7 @@ int mpm_substep_end_halo(mpm_handle_t e, float dt, int bc, int n, const void* co
         hipLaunchKernelGGL(k_grid<2>, dim3(e->g_grid), dim3(256), 0, e->stream, p, gc);
         launch_g2p_with(e, p, dt);
     };
-    if (halo_graphs() && !split) {
+    if (e->use_halo_graphs && !split) {
         if (int rc = replay_keyed(e, e->halo_graph[1], key, body)) return rc;
     } else {
         body();
@@ -1240,7 +1239,11 @@ int mpm_run_substeps(mpm_handle_t e, int n, float dt, int bc) {
     if (graph_len > 0 && n >= graph_len) {
         e->step_graph_len = graph_len;
         if (int rc = step_graph_for(e, dt, bc, gc)) return rc;
-        for (; s + graph_len <= n; s += graph_len) HIP_TRY(hipGraphLaunch(e->step_graph, e->stream));
+        for (; s + graph_len <= n; s += graph_len) {
+            HIP_TRY(hipGraphLaunch(e->step_graph, e->stream));
+            // (launch_substep sets this while a graph is CAPTURED; a replay enqueues the same self-skipping substeps)
+            e->maybe_owed = true;
+        }
     }
     for (; s < n; ++s) launch_substep(e, dt, gc, true, s + 1 < n);
     e->grid_state = 2;
@@ -1591,6 +1594,14 @@ int mpm_dist_init(mpm_handle_t e, const mpm_dist_config_t* cfg) {
             if (int rc = e->dalloc(&e->dp.vg[s][k], e->nv, false)) return rc;
     }
     hipLaunchKernelGGL(k_dist_build_topology, dim3(std::min(e->g_np, 2048u)), dim3(256), 0, e->stream, e->dp);
+    {
+        // (read here, before the re-sort: table overflows of the re-sort raise the same bit and are a different story)
+        unsigned err = 0;
+        D2H(e, &err, &e->dp.ctl->error, sizeof(unsigned));
+        if (err & ERR_CAPACITY)
+            return fail(MPM_ERR_INVALID, "mpm_dist_init: a vertex with more than eight adjacent faces is not supported "
+                                         "in a partitioned domain");
+    }
     e->dp.dist = d;
     e->dist_cfg = *cfg;
     drop_step_graph(e);
@@ -1603,9 +1614,6 @@ int mpm_dist_init(mpm_handle_t e, const mpm_dist_config_t* cfg) {
         Ctl c;
         D2H(e, &c, e->dp.ctl, sizeof(Ctl));
         if (int rc = recover_slab_overflow(e, c)) return rc;
-        if (c.error & ERR_CAPACITY)
-            return fail(MPM_ERR_INVALID, "mpm_dist_init: a vertex with more than eight adjacent faces is not supported "
-                                         "in a partitioned domain");
     }
     // the rank keeps its share: the particle arrays shrink to it, the whole scene's topology tables go
     if (int rc = dist_shrink(e)) return rc;

@@ -134,11 +134,25 @@ struct mpm_engine {
     void* d_stage = nullptr;
     size_t stage_bytes = 0;
 
+    // Environment switches are read once per HANDLE, when the engine object is made (mpm_create): two engines of one
+    // process can differ, and nothing is cached per process.
     // MPM_POISON=1 (tests): buffers that are not zero-initialised start as 0xFF bytes (NaN floats,
     // -1 ints), so that a read of something never written shows up on every box
-    static bool poison() {
-        static const bool on = getenv("MPM_POISON") != nullptr;
-        return on;
+    bool poison_fill = getenv("MPM_POISON") != nullptr;
+    bool poison() const { return poison_fill; }
+    // MPM_ANTICIPATE: horizon (substeps) of the re-sort's anticipatory binning (launch_rebuild)
+    float anticipate_horizon = getenv("MPM_ANTICIPATE") ? (float)atof(getenv("MPM_ANTICIPATE")) : 32.f;
+    // MPM_HALO_GRAPH=1: the two halves of a chain substep are replayed from captured graphs
+    bool use_halo_graphs = getenv("MPM_HALO_GRAPH") != nullptr && atoi(getenv("MPM_HALO_GRAPH")) != 0;
+    // MPM_CT_EAGER=1: the contact solve applies every accepted step with a kernel of its own (update_contact)
+    bool ct_eager = getenv("MPM_CT_EAGER") != nullptr;
+    // MPM_CT_RELAX: Jacobi relaxation of the contact solve instead of the reference's 0.3 (tests: overshoot on purpose)
+    float ct_relax = getenv("MPM_CT_RELAX") ? (float)atof(getenv("MPM_CT_RELAX")) : 0.f;
+    // MPM_CT_BATCH="first,next": Newton iterations enqueued per batch of the contact solve (measurements)
+    int ct_batch[2] = {0, 0};
+    bool ct_debug = getenv("MPM_CT_DEBUG") != nullptr;
+    mpm_engine() {
+        if (const char* t = getenv("MPM_CT_BATCH")) sscanf(t, "%d,%d", &ct_batch[0], &ct_batch[1]);
     }
     template <class T>
     int dalloc(T** out, size_t n, bool zero) {

@@ -248,9 +248,12 @@ MPM_API int mpm_sync(mpm_handle_t h);
 
 /* GpuMpmSolver::GpuSync() as the reference declares and calls it -- no state argument, a
  * cudaDeviceSynchronize() (cuda_mpm_solver.cu:164-166, cuda_mpm_test.cc:73): every engine the calling
- * thread's current HIP device holds is brought up to date (substeps that mpm_run_substeps deferred are run,
- * sticky errors are reported as by mpm_sync -- the first one found is returned), then the whole device is
- * synchronised.  The handles' own rule applies: no other thread may be inside a call on one of them. */
+ * thread's current HIP device holds is brought up to date (substeps that mpm_run_substeps deferred are run),
+ * then the whole device is synchronised.  Like the reference's call it reports nothing about the state of a
+ * simulation: the sticky errors of an engine (MPM_ERR_DRIFT, _CAPACITY, ...) stay with that engine's own
+ * mpm_sync / mpm_get_stats, only a failure of the HIP runtime is an error here.  The engine list is walked under
+ * the lock mpm_create / mpm_destroy take; the handles' own rule applies besides: no other thread may be inside
+ * another call on one of them. */
 MPM_API int mpm_device_synchronize(void);
 
 /* Active blocks whose x block coordinate lies in [bx_lo, bx_hi]: what mpm_halo_pack would pack for that zone right
@@ -434,7 +437,12 @@ MPM_API int mpm_chain_destroy(mpm_handle_t h);
  * neighbours is at least 2 * zone_blocks wide; a particle whose stencil leaves the shared zone, or a
  * face that misses a corner vertex (mesh edge longer than ghost_margin_cells), raises MPM_ERR_HALO.
  * Arrays downloaded from a rank hold NaN / -1 for particles it does not have; mpm_dist_roles tells
- * which are owned (1), ghosts (2) or absent (0), per slot.  The reference has no multi-GPU path. */
+ * which are owned (1), ghosts (2) or absent (0), per slot.  The reference has no multi-GPU path.
+ * Limits: a vertex with more than eight adjacent faces is refused (MPM_ERR_INVALID: the per-slot
+ * topology holds eight; cloth meshes have six).  After the call a rank's particle arrays are sized for
+ * slot_headroom x what it holds (default 1.5; MPM_DIST_HEADROOM, 0 = keep the whole scene's size); a rank whose share
+ * outgrows that is re-allocated at the migration that would overflow it (the stream is idle there), up to
+ * the whole scene's size. */
 typedef struct {
     int32_t rank, world;
     int32_t own_lo_block, own_hi_block;     /* this rank's x blocks */
