@@ -311,6 +311,8 @@ def main():
     torch.cuda.set_device(local_rank)
     saved_stdout = None
     if world > 1:
+        # (a failed communicator set-up then says why on stderr, in RCCL's own words)
+        os.environ.setdefault("NCCL_DEBUG", "WARN")
         # gloo and RCCL print banners on stdout; the contract is ONE JSON line there: everything else goes
         # to stderr until the result is printed
         sys.stdout.flush()
@@ -319,7 +321,7 @@ def main():
         dist.init_process_group("gloo")
 
     from drake_amd import GpuMpm, scenes
-    from drake_amd.dist import DomainChain, HaloChain
+    from drake_amd.dist import DomainChain, HaloChain, strong_geometry
     bits, layers, res = scenes.CONFIGS[args.config]
     dt = args.dt
     nb = (1 << bits) // 4
@@ -342,14 +344,11 @@ def main():
     if strong:
         # ONE copy of the workload, cut into x slabs of equal width across the cloth (blocks nb/4 .. 3nb/4);
         # every rank finalises the whole scene and keeps its slab (mpm_dist_init)
-        lo, hi = nb // 4, 3 * nb // 4
-        assert (hi - lo) % world == 0 and (hi - lo) // world >= 2, "the cloth's blocks do not split evenly over the ranks"
-        width = (hi - lo) // world
-        cuts = [0] + [lo + width * r for r in range(1, world)] + [nb]
-        zone = 2 if width >= 4 else 1
-        ghost, margin = (2, 2) if zone == 2 else (1, 1)
-        mig_every = 4 if zone == 2 else 2
-        geometry = dict(cuts=cuts, zone_blocks=zone, ghost_cells=ghost, ghost_margin_cells=margin, migrate_every=mig_every)
+        # (drake_amd/dist.py: strong_geometry -- the same function the tests of the 4- and 8-rank partitions use: zone 2
+        # blocks where a slab is at least 4 blocks wide, else 1; ghost bands from the mesh; adaptive migration cadence)
+        geometry = strong_geometry(bits, world)
+        cuts, zone = geometry["cuts"], geometry["zone_blocks"]
+        ghost, margin, mig_every = geometry["ghost_cells"], geometry["ghost_margin_cells"], geometry["migrate_every"]
         g = make_engine(1234)
         # The native chain sends a fixed capacity per substep (1 KiB per block; a RCCL send needs its size when it is
         # enqueued), so the capacity is what the ranks' zones hold right after the partition, agreed between them,
@@ -384,6 +383,8 @@ def main():
             chain_args["capacity_blocks"] = cap_blocks
             geometry["exchange_capacity_blocks"] = cap_blocks
             geometry["zone_blocks_now"] = int(t.item())
+            geometry.update({k: round(v, 4) for k, v in g.dist_geometry().items() if k.endswith("_cells")})
+            geometry["migrate_every"] = "adaptive (half of the ranks' common quiet-time estimate)" if mig_every == 0 else mig_every
             # per-rank topology: what rank 0 allocates after the partition, against the whole scene
             s0 = g.stats()
             geometry["rank0_allocation"] = dict(
@@ -408,7 +409,8 @@ def main():
                     g.chain_substeps(1, dt, -1)
                     g.gpu_sync()
                 except Exception as exc:  # noqa: BLE001
-                    print(f"[bench] rank {rank}: native RCCL chain failed ({exc!r})", file=sys.stderr)
+                    print(f"[bench] rank {rank}: native RCCL chain failed: {exc} (RCCL's own diagnosis is on stderr above: "
+                          "NCCL_DEBUG=WARN)", file=sys.stderr, flush=True)
                     ok = False
             native = all_ok(ok)
             if native:
@@ -418,15 +420,9 @@ def main():
 
         def python_chain(group):
             if strong:
-                c = DomainChain.__new__(DomainChain)
-                # (the engine is partitioned already: build the chain object without a second mpm_dist_init)
-                HaloChain.__init__(c, g, rank, world, device=torch.device("cuda", local_rank), group=group, **chain_args)
-                c.migrate_every, c.mig_cap, c.steps, c._mig_ops = mig_every, mig_cap, 1, None
-                nbytes = g.dist_migration_buffer_bytes(mig_cap)
-                mk = lambda: torch.zeros(nbytes, dtype=torch.uint8, device=c.device)
-                c.mig_send = {"l": mk(), "r": mk()}
-                c.mig_recv = {n: mk() for n in (c.left, c.right) if n is not None}
-                return c
+                # (the engine is partitioned already: no second mpm_dist_init)
+                return DomainChain(g, rank, world, cuts, zone, ghost, margin, chain_args["capacity_blocks"], mig_every,
+                                   mig_cap, device=torch.device("cuda", local_rank), group=group, partitioned=True)
             return HaloChain(g, rank, world, device=torch.device("cuda", local_rank), group=group, **chain_args)
 
         if not native and backend != "gloo":
@@ -439,7 +435,7 @@ def main():
                     chain.run_substeps(1, dt, -1)
                 torch.cuda.synchronize()
             except Exception as exc:  # noqa: BLE001
-                print(f"[bench] rank {rank}: torch RCCL halo exchange failed ({exc!r})", file=sys.stderr)
+                print(f"[bench] rank {rank}: torch RCCL halo exchange failed: {exc}", file=sys.stderr, flush=True)
                 ok = False
             if all_ok(ok):
                 transport = "RCCL via torch.distributed point-to-point"
@@ -474,6 +470,7 @@ def main():
 
     run(args.warmup)
     g.gpu_sync()
+    rebuilds_before = g.stats()["rebuilds"]   # (a synchronising call: the window starts from an idle, settled engine)
     barrier()
     t0 = time.perf_counter()
     run(args.steps)
@@ -490,6 +487,11 @@ def main():
         el = float(t.item())
     st = g.stats()
     assert st["error_flags"] == 0, st
+    region["resorts_in_timed_window"] = st["rebuilds"] - rebuilds_before
+    if strong:
+        dg = g.dist_geometry()
+        region["migrations_since_partition"] = dg["migrations"]
+        region["slot_space_resizes"] = dg["slot_resizes"]
     # (substeps of warm-up + timed region that carried the launches of the conditional re-sort; the others went without,
     # inside the quiet time the last re-sort estimated)
     region["resort_check_launches_since_finalize"] = st["resort_checks"] - 1   # (Finalize's own sort is one)
@@ -509,6 +511,34 @@ def main():
         el_s = time.perf_counter() - ts
         steady = dict(ms_per_step=el_s / 200 * 1e3, substeps_per_s=200 / el_s, steps=200, warmup=20,
                       rebuilds=g.stats()["rebuilds"] - r0)
+
+    # The reference's own call pattern (cuda_mpm_test.cc:64-74): five GpuMpmSolver calls per substep, GpuSync() after every
+    # frame of 40 substeps.  Not `value` (which goes through mpm_run_substeps, an entry point the reference does not have).
+    ref_pattern = None
+    if world == 1 and chain is None and args.sort_every == 0:
+        g.destroy()
+        g = make_engine(1234)
+
+        def frame(n=40):
+            for _ in range(n):
+                g.rebuild_mapping(False)
+                g.calc_fem_state_and_force(dt)
+                g.particle_to_grid(dt)
+                g.update_grid(-1)
+                g.grid_to_particle(dt)
+            GpuMpm.device_synchronize()   # GpuSync(), no state argument
+
+        frame(20)
+        r0 = g.stats()["rebuilds"]
+        frames = 4
+        ts = time.perf_counter()
+        for _ in range(frames):
+            frame()
+        el_r = time.perf_counter() - ts
+        ref_pattern = dict(ms_per_step=el_r / (40 * frames) * 1e3, substeps_per_s=40 * frames / el_r, frames=frames,
+                           substeps_per_frame=40, warmup_substeps=20, rebuilds=g.stats()["rebuilds"] - r0,
+                           calls="RebuildMapping(false), CalcFemStateAndForce, ParticleToGrid, UpdateGrid, GridToParticle per "
+                                 "substep; GpuSync() per frame (cuda_mpm_test.cc:64-74)")
 
     # per-kernel timing with HIP events on the engine's stream: a separate, un-timed pass over the
     # SAME substeps (fresh engine, same scene, same warm-up), so that the kernel durations describe
@@ -531,13 +561,16 @@ def main():
         ab["p2g"] += ab["vforce"]
         ab["vforce"] = 0
     dom = max(KERNEL_OF, key=lambda k: phases[k])
-    # An interval between two events holds the kernel AND the two event packets' own processing.  On one GPU the
-    # vertex-force phase of this pass is EMPTY (k_p2g does that work), i.e. a live measurement of exactly that:
-    # two events with nothing between them (about 5 us).  It is subtracted, so that `kernel_ms` is comparable with
-    # the kernel trace's average duration (profiles/rNN_kernel_stats.csv); the raw interval is reported next to it.
-    ev_ms = phases["vforce"] if world == 1 else 0.0
-    dom_ms = phases[dom] - ev_ms
+    # An interval between two events holds the kernel AND the two event packets' own processing.  `achieved` / `frac`
+    # are taken on the RAW interval -- the conservative figure: the kernel cannot have taken longer.  mpm_profile_substeps
+    # also records one explicit back-to-back event pair per substep (the vertex-force slot: k_p2g does that work, nothing
+    # is launched between its two events), i.e. the cost of an event pair measured live; `*_net` are the same figures
+    # with it subtracted.  The rocprofv3 kernel trace of this command (profiles/rNN_kernel_stats.csv) lies between the two.
+    ev_ms = phases["vforce"]
+    dom_ms = phases[dom]
+    dom_net_ms = max(dom_ms - ev_ms, 1e-6)
     ach = ab[dom] / (dom_ms * 1e-3) / 1e9
+    ach_net = ab[dom] / (dom_net_ms * 1e-3) / 1e9
     # the whole job: every particle once per substep (strong: one copy; weak: one copy per rank)
     copies = 1 if (strong or world == 1) else world
     # (cells: rank 0's count; a partitioned domain has about `world` times as many, a 1% term)
@@ -547,22 +580,23 @@ def main():
                     traffic_source="profiles/pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this "
                                    "command, collected by scripts/collect_profiles.sh and committed (replayed, not "
                                    "measured in this run)",
-                    algorithmic_bytes_per_launch=ab[dom], kernel_ms=dom_ms, kernel_ms_event_interval=phases[dom],
-                    event_overhead_ms=ev_ms,
+                    algorithmic_bytes_per_launch=ab[dom], kernel_ms=dom_ms,
+                    kernel_ms_note="HIP-event interval around the kernel, raw (event packets included): an upper bound",
+                    achieved_net=ach_net, frac_net=ach_net / HBM_PEAK_GBS, kernel_ms_net=dom_net_ms, event_pair_ms=ev_ms,
                     substep_achieved=job_bytes / (el / args.steps) / 1e9,
                     substep_frac=job_bytes / (el / args.steps) / 1e9 / (HBM_PEAK_GBS * world), phase_ms=phases,
                     phase_note="separate pass with HIP events around every phase (mpm_profile_substeps); it launches the "
                                "re-sort kernels with every substep, the timed run with every fourth (gated substeps); "
-                               "one GPU: the vertex-force phase is empty (k_p2g does that work per work item), so its "
-                               "interval is the cost of an event pair, which kernel_ms has subtracted; phase_ms are raw "
-                               "intervals")
+                               "the vertex-force slot is empty (k_p2g does that work per work item): its interval is "
+                               "the cost of an event pair; phase_ms are raw intervals")
 
     if rank == 0:
         if world == 1:
             par = "single GPU"
         elif strong:
-            par = (f"{world} GPUs share ONE domain: x slabs cut at blocks {cuts}, ghost band {ghost}+{margin} cells, "
-                   f"zone {zone} blocks, migration every {mig_every} substeps, 1 rank/GPU, {transport} per substep")
+            par = (f"{world} GPUs share ONE domain: x slabs cut at blocks {cuts}, ghost bands "
+                   f"{geometry.get('face_band_cells')} / {geometry.get('vertex_band_cells')} cells (faces / vertices), "
+                   f"zone {zone} blocks, migration {geometry['migrate_every']}, 1 rank/GPU, {transport} per substep")
         else:
             par = f"{world} GPUs: x-tiled patches, 1 rank/GPU, {transport} halo of grid-block sums per substep"
         out = dict(metric="mpm_substeps_per_sec_1M_particles", value=copies * args.steps / el, unit="substeps/s",
@@ -573,11 +607,14 @@ def main():
                                         f"{1 << bits}^3 grid, corotated cloth, no contact, dt={dt}",
                                particles_total=npart * copies, particles_rank0=st["active_faces"] + st["active_vertices"],
                                grid=f"{1 << bits}^3", touched_blocks=st["touched_blocks"], rebuilds=st["rebuilds"],
+                               resorts_in_timed_window=region["resorts_in_timed_window"],
                                slot_sort_every=args.sort_every, parallelism=par, geometry=geometry if world > 1 else None),
-                   roofline=roofline)
+                   transport=transport, roofline=roofline)
         out["timed_region"] = region
         if steady is not None:
             out["steady_state"] = steady
+        if ref_pattern is not None:
+            out["reference_call_pattern"] = ref_pattern
         if not args.no_contact_leg and world == 1:
             g.destroy()
             out["contact"] = contact_leg(local_rank)

@@ -85,6 +85,11 @@ class DistConfig(C.Structure):
                 ("ghost_cells", C.c_int32), ("ghost_margin_cells", C.c_int32)]
 
 
+class DistGeometry(C.Structure):
+    _fields_ = [("face_band_cells", C.c_float), ("vertex_band_cells", C.c_float), ("drift_budget_cells", C.c_float),
+                ("longest_edge_cells", C.c_float), ("slot_resizes", C.c_uint32), ("migrations", C.c_uint32)]
+
+
 class Stats(C.Structure):
     _fields_ = [
         ("substeps", C.c_uint64), ("rebuilds", C.c_uint64), ("home_blocks", C.c_uint32), ("active_blocks", C.c_uint32),
@@ -120,6 +125,7 @@ SYMBOLS = [
     "mpm_dist_migrate_pack", "mpm_dist_migrate_apply", "mpm_dist_roles", "mpm_chain_enable_migration",
     "mpm_dist_set_transport", "mpm_device_synchronize", "mpm_debug_owed_substeps",
     "mpm_memcpy_d2h", "mpm_memcpy_h2d", "mpm_profile_contact_iteration", "mpm_contact_frame", "mpm_halo_zone_blocks",
+    "mpm_dist_get_geometry", "mpm_dist_set_headroom", "mpm_dist_migration_quiet_time",
 ]
 
 EXCHANGE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t)
@@ -230,6 +236,9 @@ def load_library(build: bool = True):
         "mpm_dist_migrate_pack": [vp, vp, vp, sz],
         "mpm_dist_migrate_apply": [vp, vp, vp, sz],
         "mpm_dist_roles": [vp, vp],
+        "mpm_dist_get_geometry": [vp, P(DistGeometry)],
+        "mpm_dist_set_headroom": [vp, f],
+        "mpm_dist_migration_quiet_time": [vp, P(f)],
         "mpm_chain_enable_migration": [vp, i, sz],
         "mpm_dist_set_transport": [vp, EXCHANGE_FN, ALLREDUCE_FN, vp, sz],
         "mpm_grid_collider_preset": [i, f, vp, sz, P(sz)],
@@ -555,13 +564,29 @@ class GpuMpm:
 
     # ---- one domain cut into x slabs (mpm_dist_*) -------------------------------------
     def dist_init(self, rank: int, world: int, cuts, zone_blocks: int = 2, ghost_cells: int = 2,
-                  ghost_margin_cells: int = 2):
-        """cuts: world + 1 ascending x block indices; rank r owns blocks [cuts[r], cuts[r + 1])."""
+                  ghost_margin_cells: int = 2, headroom: float | None = None):
+        """cuts: world + 1 ascending x block indices; rank r owns blocks [cuts[r], cuts[r + 1]).
+        ghost_cells = ghost_margin_cells = 0: band widths from the mesh (see mpm_dist_init).  headroom: slot space
+        of the rank as a multiple of what it holds (None: the library's default 1.5; 0: no shrink)."""
         assert len(cuts) == world + 1
+        if headroom is not None:
+            self._ck(self.lib.mpm_dist_set_headroom(self.h, float(headroom)))
         cfg = DistConfig(rank, world, cuts[rank], cuts[rank + 1], cuts[rank - 1] if rank > 0 else 0,
                          cuts[rank + 2] if rank + 2 <= world else cuts[world], zone_blocks, ghost_cells,
                          ghost_margin_cells)
         self._ck(self.lib.mpm_dist_init(self.h, C.byref(cfg)))
+
+    def dist_geometry(self) -> dict:
+        g = DistGeometry()
+        self._ck(self.lib.mpm_dist_get_geometry(self.h, C.byref(g)))
+        return {k: getattr(g, k) for k, _ in DistGeometry._fields_}
+
+    def dist_migration_quiet_time(self) -> float:
+        """Seconds for which, by this rank's ballistic estimate at its last mpm_dist_migrate_pack, no particle it holds
+        drifts further along x than the bands allow (may be inf)."""
+        t = C.c_float(0.0)
+        self._ck(self.lib.mpm_dist_migration_quiet_time(self.h, C.byref(t)))
+        return float(t.value)
 
     def dist_migration_buffer_bytes(self, capacity_particles: int) -> int:
         return int(self.lib.mpm_dist_migration_buffer_bytes(capacity_particles))

@@ -85,11 +85,16 @@ struct Ctl {
     // being right: a substep that finds a re-sort pending without its check launches skips itself (DP::gated).
     float quiet_time;          // seconds, as of the last re-sort (0: not estimated)
     float time_since_resort;   // seconds of substeps run since then (k_g2p adds its dt)
+    // Partitioned domain: how long after the last migration no particle of this rank can have drifted further along x
+    // than the bands allow (Dist::mig_delta) if all of them keep moving ballistically -- k_dist_classify's estimate, the
+    // minimum over the particles this rank holds (k_dist_mig_reduce).  The ranks agree on the minimum and migrate again
+    // when half of it has passed (mpm_chain_substeps, drake_amd/dist.py: DomainChain).
+    float mig_quiet;
 };
 
 // Partitioned domain: ranks cut ONE domain into x slabs at block boundaries.  Every
 // rank was finalised with the whole scene; mpm_dist_init shrinks it to the particles it owns -- base
-// cell x in [own_lo, own_hi) -- plus ghost copies of the neighbours' particles within ghost_cells of a
+// cell x in [own_lo, own_hi) -- plus ghost copies of the neighbours' particles within the ghost bands of a
 // cut, with the mesh topology kept per slot by original id (DP::fg / vg) instead of scene-sized tables.  Ghosts take part in FEM and G2P (so they stay
 // bit-identical to the owner's copy without communication) and contribute nothing to P2G; the node
 // sums of the blocks within zone_cells of a cut are exchanged every substep.
@@ -99,21 +104,38 @@ struct Dist {
     int own_lo, own_hi;        // owned x range in cells
     int nbr_lo, nbr_hi;        // outer ends of the left / right neighbour's ranges (cells)
     int has_left, has_right;
-    int ghost_cells;           // ghost band for face particles
-    int vert_cells;            // ghost band for vertex particles: wider by the longest mesh edge, so that a
-                               // ghost face always finds its corner vertices on the same rank
+    // Ghost bands, in cells beyond a cut, measured on xi = x / dx - 0.5 (the coordinate whose floor is the base cell):
+    // fractional widths, so that a thin zone still leaves room for drift between two migrations (mpm_dist_init).
+    float ghost_w;             // ghost band for face particles
+    float vert_w;              // ghost band for vertex particles: wider by the reach of a face (centroid -> corner), so
+                               // that a ghost face always finds its corner vertices on the same rank
+    float hyst;                // hysteresis (cells) of ownership and of band membership: a particle changes owner when it
+                               // is this far beyond a cut, and a ghost that was inside a band stays until it is this far
+                               // outside -- a cloth that vibrates about a cut or a band edge causes no traffic (and no
+                               // re-sort: a migration that moves nothing forces none)
     int zone_cells;            // depth of the exchanged zone either side of a cut
+    float mig_delta;           // drift along x (cells) that every held particle may accumulate between two migrations
+    float mig_reach;           // only particles within this distance (cells) of a cut can matter before they have
+                               // travelled there: the others' time estimate includes the way to this region
+    unsigned* mig_min;         // 32 slots, 128 bytes apart: complement of the smallest time estimate (k_dist_classify)
     unsigned char* prev;       // [original id] bit 0 / 1: was in the left / right neighbour's ghost band at the last migration
 };
 
-MPM_DEV bool dist_in_my_band(const Dist& d, int bx, bool face) {   // a neighbour's particle that I hold as a ghost
-    const int w = face ? d.ghost_cells : d.vert_cells;
-    return (d.has_left && bx >= d.own_lo - w && bx < d.own_lo) || (d.has_right && bx >= d.own_hi && bx < d.own_hi + w);
+// xi of a position: base cell = floor(xi) (clamped to the grid)
+MPM_DEV float dist_xi(float x, float dxinv) { return x * dxinv - .5f; }
+// a neighbour's particle (base cell bx outside [own_lo, own_hi)) that I hold as a ghost; `extra` widens the band (the
+// hysteresis for a ghost that is already held)
+MPM_DEV bool dist_in_my_band(const Dist& d, int bx, float xi, bool face, float extra = 0.f) {
+    const float w = (face ? d.ghost_w : d.vert_w) + extra;
+    return (d.has_left && bx < d.own_lo && xi >= (float)d.own_lo - w) || (d.has_right && bx >= d.own_hi && xi < (float)d.own_hi + w);
 }
-// bit 0 / 1: an owned particle at cell bx is inside the band in which the left / right neighbour keeps ghosts
-MPM_DEV int dist_in_neighbour_bands(const Dist& d, int bx, bool face) {
-    const int w = face ? d.ghost_cells : d.vert_cells;
-    return ((d.has_left && bx < d.own_lo + w) ? 1 : 0) | ((d.has_right && bx >= d.own_hi - w) ? 2 : 0);
+// bit 0 / 1: an owned particle at xi is inside the band in which the left / right neighbour keeps ghosts (the same
+// comparison of the same float on both ranks: owner and ghost rank always agree); `old` = the bits of the last
+// migration: a side that was set stays set until the particle is d.hyst beyond the band
+MPM_DEV int dist_in_neighbour_bands(const Dist& d, float xi, bool face, int old = 0) {
+    const float w = face ? d.ghost_w : d.vert_w;
+    const float wl = w + ((old & 1) ? d.hyst : 0.f), wr = w + ((old & 2) ? d.hyst : 0.f);
+    return ((d.has_left && xi < (float)d.own_lo + wl) ? 1 : 0) | ((d.has_right && xi >= (float)d.own_hi - wr) ? 2 : 0);
 }
 
 struct DP {
@@ -127,7 +149,9 @@ struct DP {
     unsigned nblocks, ncells;
     unsigned capH, capA, capI;
     unsigned capS;         // slabs allocated (<= capI): grown by the host at synchronisation points, see slab_pool_grow
-    int item_groups;       // a work item holds at most this many 64-particle wave groups
+    int item_groups;       // a work item holds at most this many 64-particle wave groups ...
+    int item_groups_small; // ... or this many when the engine holds fewer than item_small_below wave groups in all (a
+    int item_small_below;  // partitioned rank with a small share): more, smaller items keep the CUs busy (k_rb_tables)
     int dbg;               // MPM_DBG environment variable (kernel ablation switches, 0 in production)
     float dx, dxinv, Dinv;
     unsigned q_stride, f_stride;   // distance (elements) between the planes PSet::q[0..3] and f[0..2] (one allocation each)
@@ -265,6 +289,15 @@ MPM_DEV int neighbor_block(uint32_t b, int o, int nb) {
 // contiguous eighth of the index range so that shared lines are fetched into one L2, not eight.
 // Launch with a grid rounded up to a multiple of 8; chunks past the end are empty.
 MPM_DEV unsigned xcd_chunk(unsigned b, unsigned grid) { return (b & 7u) * (grid >> 3) + (b >> 3); }
+// The same when only the first n indices exist (a partitioned rank holds a fraction of the slots the launch was sized
+// for): the eight XCDs share the ACTIVE range evenly -- with the plain mapping a rank that holds an eighth of the scene
+// runs its whole FEM pass on one XCD.  Returns the 256-index chunk of workgroup b, or ~0u if it has none.  For n = the
+// launch's full range (grid = chunks rounded up to a multiple of 8) this is xcd_chunk.
+MPM_DEV unsigned xcd_chunk_active(unsigned b, unsigned n) {
+    const unsigned per = (((n + 255u) >> 8) + 7u) >> 3;   // chunks per XCD
+    const unsigned k = b >> 3;
+    return k < per ? (b & 7u) * per + k : 0xFFFFFFFFu;
+}
 
 MPM_DEV bool in_halo_zone(const DP& p, int bx) {
     bool z = false;

@@ -22,6 +22,7 @@
 // Buffer = 16-byte header (record count) + capacity records.
 #pragma once
 #include "mpm_device.h"
+#include "mpm_rebuild.h"   // time_to_travel
 
 namespace mpm {
 
@@ -44,11 +45,12 @@ __global__ __launch_bounds__(256) void k_dist_init_roles(DP p) {
     const Dist& d = p.dist;
     float4 q = S.q[0][i];
     const int bx = dist_cell_x(p, q.x);
+    const float xi = dist_xi(q.x, p.dxinv);
     const float vol = fabsf(q.w);
     const bool mine = bx >= d.own_lo && bx < d.own_hi, face = i < p.Nf;
-    q.w = mine ? vol : (dist_in_my_band(d, bx, face) ? -vol : 0.f);
+    q.w = mine ? vol : (dist_in_my_band(d, bx, xi, face) ? -vol : 0.f);
     S.q[0][i] = q;
-    d.prev[S.pid[i]] = mine ? (unsigned char)dist_in_neighbour_bands(d, bx, face) : 0;
+    d.prev[S.pid[i]] = mine ? (unsigned char)dist_in_neighbour_bands(d, xi, face) : 0;
 }
 
 MPM_DEV void dist_emit(const DP& p, const PSet& S, unsigned slot, int gid, int role, float4 q0, bool emit, float4* buf,
@@ -57,7 +59,12 @@ MPM_DEV void dist_emit(const DP& p, const PSet& S, unsigned slot, int gid, int r
     if (!m) return;
     const int lane = threadIdx.x & 63, lead = __builtin_ctzll(m);
     unsigned base = 0;
-    if (lane == lead) base = atomicAdd(reinterpret_cast<unsigned*>(buf), (unsigned)__popcll(m));
+    // header: [0] records, [1] how many of them are faces (the receiver sizes its slot space from the two counts)
+    const unsigned long long mf = __ballot(emit && slot < (unsigned)p.Nf);
+    if (lane == lead) {
+        base = atomicAdd(reinterpret_cast<unsigned*>(buf), (unsigned)__popcll(m));
+        if (mf) atomicAdd(reinterpret_cast<unsigned*>(buf) + 1, (unsigned)__popcll(mf));
+    }
     base = (unsigned)__shfl((int)base, lead);
     if (!emit) return;
     const unsigned at = base + (unsigned)__popcll(m & ((1ull << lane) - 1ull));
@@ -94,6 +101,7 @@ __global__ __launch_bounds__(256) void k_dist_classify(DP p, float4* send_l, flo
     const Dist& d = p.dist;
     const int nf = c->nfa, total = nf + c->nva;
     bool changed = false;
+    float quiet = __int_as_float(0x7F800000);   // Ctl::mig_quiet: this thread's particles
     for (int base = blockIdx.x * 256; base < total; base += gridDim.x * 256) {   // (whole waves stay in the loop)
         const int idx = base + threadIdx.x;
         const bool live = idx < total;
@@ -101,33 +109,45 @@ __global__ __launch_bounds__(256) void k_dist_classify(DP p, float4* send_l, flo
         float4 q0 = S.q[0][slot];
         const int gid = S.pid[slot];
         const int bx = dist_cell_x(p, q0.x);
+        const float xi = dist_xi(q0.x, p.dxinv);
         const float vol = q0.w;
         const bool face = slot < (unsigned)p.Nf;
+        if (live && vol != 0.f) {
+            // how long until this particle has drifted mig_delta cells along x (ballistic: its velocity, gravity if that
+            // acts along x); one that is further than mig_reach from both cuts has to get there first
+            const float vx = fabsf(S.q[1][slot].x) * p.dxinv;
+            const float ax = p.M.gravity_axis == 0 ? fabsf(p.M.gravity) * p.dxinv : 0.f;
+            float far = __int_as_float(0x7F800000);
+            if (d.has_left) far = fminf(far, fabsf(xi - (float)d.own_lo));
+            if (d.has_right) far = fminf(far, fabsf(xi - (float)d.own_hi));
+            quiet = fminf(quiet, time_to_travel(d.mig_delta + fmaxf(far - d.mig_reach, 0.f), vx, ax));
+        }
         bool to_l = false, to_r = false;
         int role_l = ROLE_GHOST, role_r = ROLE_GHOST;
         float new_vol = vol;
         if (live && vol > 0.f) {
-            if (bx < d.own_lo || bx >= d.own_hi) {
+            // (ownership changes d.hyst cells beyond a cut, not at it: see Dist::hyst)
+            const bool left = d.has_left && xi < (float)d.own_lo - d.hyst, right = d.has_right && xi >= (float)d.own_hi + d.hyst;
+            if (left || right) {
                 // crossed a cut: the neighbour takes over
-                const bool left = bx < d.own_lo;
-                if ((left && (!d.has_left || bx < d.nbr_lo)) || (!left && (!d.has_right || bx >= d.nbr_hi)))
-                    atomicOr(&c->error, ERR_HALO);   // (beyond the neighbour's slab, or no neighbour there)
+                if ((left && bx < d.nbr_lo) || (right && bx >= d.nbr_hi))
+                    atomicOr(&c->error, ERR_HALO);   // (beyond the neighbour's slab)
                 to_l = left; to_r = !left;
                 role_l = role_r = ROLE_OWNED;
-                new_vol = dist_in_my_band(d, bx, face) ? -vol : 0.f;
+                new_vol = dist_in_my_band(d, bx, xi, face) ? -vol : 0.f;
                 d.prev[gid] = 0;
             } else {
-                const int in = dist_in_neighbour_bands(d, bx, face);
                 const unsigned char old = d.prev[gid];
+                const int in = dist_in_neighbour_bands(d, xi, face, old);
                 to_l = (in & 1) && !(old & 1);
                 to_r = (in & 2) && !(old & 2);
                 d.prev[gid] = (unsigned char)in;
             }
         } else if (live && vol < 0.f) {
-            // a ghost stays while it is in this rank's band (its owner applies the same test to the same
-            // position); one that crossed INTO this rank's slab waits for its owner's record
+            // a ghost stays while it is in this rank's band, d.hyst beyond it included (its owner applies the same test
+            // to the same position); one that crossed INTO this rank's slab waits for its owner's record
             const bool mine = bx >= d.own_lo && bx < d.own_hi;
-            if (!mine && !dist_in_my_band(d, bx, face)) new_vol = 0.f;
+            if (!mine && !dist_in_my_band(d, bx, xi, face, d.hyst)) new_vol = 0.f;
         }
         dist_emit(p, S, slot, gid, role_l, q0, to_l, send_l, cap);
         dist_emit(p, S, slot, gid, role_r, q0, to_r, send_r, cap);
@@ -138,6 +158,25 @@ __global__ __launch_bounds__(256) void k_dist_classify(DP p, float4* send_l, flo
         }
     }
     if (__ballot(changed) && (threadIdx.x & 63) == 0) c->need_rebuild = 1;
+    // minimum over the workgroup, then over 32 slots, 128 bytes apart (like k_rb_count's quiet time: complements, maxima)
+    __shared__ unsigned s_quiet[4];
+#pragma unroll
+    for (int dd = 32; dd >= 1; dd >>= 1) quiet = fminf(quiet, __shfl_xor(quiet, dd));
+    if ((threadIdx.x & 63) == 0) s_quiet[threadIdx.x >> 6] = __float_as_uint(quiet);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned m = min(min(s_quiet[0], s_quiet[1]), min(s_quiet[2], s_quiet[3]));
+        atomicMax(&d.mig_min[(blockIdx.x & 31u) * 32u], ~m);
+    }
+}
+
+// the 32 slots of k_dist_classify -> Ctl::mig_quiet (seconds; infinity when the rank holds nothing that moves)
+__global__ __launch_bounds__(64) void k_dist_mig_reduce(DP p) {
+    unsigned q = threadIdx.x < 32 ? p.dist.mig_min[threadIdx.x * 32u] : 0u;
+    if (threadIdx.x < 32) p.dist.mig_min[threadIdx.x * 32u] = 0u;
+#pragma unroll
+    for (int dd = 32; dd >= 1; dd >>= 1) q = max(q, (unsigned)__shfl_xor((int)q, dd));
+    if (threadIdx.x == 0) p.ctl->mig_quiet = q ? __uint_as_float(~q) : __int_as_float(0x7F800000);
 }
 
 __global__ __launch_bounds__(256) void k_dist_apply(DP p, const float4* recv, unsigned cap) {

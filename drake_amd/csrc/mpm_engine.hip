@@ -262,7 +262,9 @@ int mpm_finalize(mpm_handle_t e) {
     p.capA = (unsigned)std::min<size_t>(p.nblocks, (size_t)27 * p.capH);
     p.halo_cls = -1;
     p.item_groups = getenv("MPM_ITEM_GROUPS") ? std::max(1, atoi(getenv("MPM_ITEM_GROUPS"))) : 48;
-    p.capI = p.capH + (unsigned)(np / (64 * (size_t)p.item_groups)) + 16u;
+    p.item_groups_small = getenv("MPM_ITEM_GROUPS_SMALL") ? std::max(1, atoi(getenv("MPM_ITEM_GROUPS_SMALL"))) : 16;
+    p.item_small_below = getenv("MPM_ITEM_SMALL_BELOW") ? atoi(getenv("MPM_ITEM_SMALL_BELOW")) : 6500;
+    p.capI = p.capH + (unsigned)(np / (64 * (size_t)std::min(p.item_groups, p.item_groups_small))) + 16u;
     // Slabs (16 KB each) are allocated for the blocks a cloth of this size typically occupies, not for
     // the worst case of one particle per block (capI: 4 GB at 256^3, 33 GB at 512^3); mpm_sync and
     // mpm_get_stats double the pool when it is more than half full (slab_pool_grow).
@@ -543,6 +545,13 @@ static int recover_slab_overflow(mpm_engine* e, Ctl& c) {
     return 0;
 }
 
+// The stream is idle and `c` is the control block as it stands: what is left of the quiet time the last re-sort
+// estimated.  Substeps enqueued right after go without check launches while it lasts (launch_substep); any call that
+// may change the state resets it (settle_owed).
+static void note_quiet_time(mpm_engine* e, const Ctl& c) {
+    e->quiet_left = c.skipped || c.need_rebuild || c.error ? 0.f : std::max(0.f, c.quiet_time - c.time_since_resort);
+}
+
 int mpm_sync(mpm_handle_t e) {
     REQUIRE(e, "null handle");
     if (int rc = use(e)) return rc;
@@ -558,6 +567,7 @@ int mpm_sync(mpm_handle_t e) {
     }
     if (e->finalized && !c.error)
         if (int rc = slab_pool_grow(e, c)) return rc;
+    if (e->finalized) note_quiet_time(e, c);   // (also when settle() had nothing to do and this call read the block itself)
     if (c.error & ERR_DRIFT)
         return fail(MPM_ERR_DRIFT,
                     "a face particle was re-centred on its corners out of its block's tile: the corner "
@@ -998,9 +1008,21 @@ int mpm_substep_end_halo(mpm_handle_t e, float dt, int bc, int n, const void* co
         p.halo_nz = e->halo_nz;
         for (int i = 0; i < e->halo_nz; ++i) { p.halo_zlo[i] = e->halo_zlo[i]; p.halo_zhi[i] = e->halo_zhi[i]; }
     }
+    // The received sums are added inside the grid update (k_grid<2> looks its zone blocks up in the buffers): one launch
+    // less per substep than add + update.  Needs the zones of the matching mpm_substep_begin_halo, buffer i <-> zone i.
+    DP pg = p;
+    const bool folded = n > 0 && n == e->halo_nz;
+    if (folded) {
+        pg.halo_pn = n;
+        pg.halo_pcap = (unsigned)cap;
+        for (int i = 0; i < n; ++i) {
+            pg.halo_plo[i] = e->halo_zlo[i]; pg.halo_phi[i] = e->halo_zhi[i];
+            pg.halo_pbuf[i] = const_cast<uint32_t*>(b.buf[i]);
+        }
+    }
     auto body = [&]() {
-        if (n > 0) hipLaunchKernelGGL(k_halo_add2, dim3(64, n), dim3(256), 0, e->stream, p, b, (unsigned)cap);
-        hipLaunchKernelGGL(k_grid<2>, dim3(e->g_grid), dim3(256), 0, e->stream, p, gc);
+        if (n > 0 && !folded) hipLaunchKernelGGL(k_halo_add2, dim3(64, n), dim3(256), 0, e->stream, p, b, (unsigned)cap);
+        hipLaunchKernelGGL(k_grid<2>, dim3(e->g_grid), dim3(256), 0, e->stream, pg, gc);
         launch_g2p_with(e, p, dt);
     };
     if (e->use_halo_graphs && !split) {
@@ -1033,7 +1055,8 @@ int mpm_chain_destroy(mpm_handle_t e) {
         const rccl_rt::Api* a = rccl_rt::api();
         if (a) (void)a->comm_destroy(c.comm);
     }
-    for (void* q : {c.send_l, c.send_r, c.recv_l, c.recv_r, c.mig_send_l, c.mig_send_r, c.mig_recv_l, c.mig_recv_r})
+    for (void* q : {c.send_l, c.send_r, c.recv_l, c.recv_r, c.mig_send_l, c.mig_send_r, c.mig_recv_l, c.mig_recv_r,
+                    (void*)c.mig_quiet_all})
         if (q) (void)hipFree(q);
     c = mpm_engine::Chain();
     return 0;
@@ -1046,11 +1069,15 @@ int mpm_chain_enable_migration(mpm_handle_t e, int every, size_t capacity_partic
     REQUIRE(e->dp.dist.on, "mpm_dist_init first");
     REQUIRE(c.pitch == 0 && c.rank == e->dp.dist.rank && c.world == e->dp.dist.world,
             "the chain of a partitioned domain has pitch 0 and the rank / world given to mpm_dist_init");
-    REQUIRE(every >= 1 && capacity_particles > 0 && capacity_particles < (1u << 28), "bad migration parameters");
-    for (void** q : {&c.mig_send_l, &c.mig_send_r, &c.mig_recv_l, &c.mig_recv_r}) {
+    REQUIRE(every >= 0 && capacity_particles > 0 && capacity_particles < (1u << 28), "bad migration parameters");
+    REQUIRE(every > 0 || rccl_rt::api()->all_reduce, "adaptive migration (every = 0) needs ncclAllReduce");
+    for (void** q : {&c.mig_send_l, &c.mig_send_r, &c.mig_recv_l, &c.mig_recv_r, (void**)&c.mig_quiet_all}) {
         if (*q) (void)hipFree(*q);
         *q = nullptr;
     }
+    HIP_TRY(hipMalloc((void**)&c.mig_quiet_all, 16));
+    c.mig_budget = 0.f;    // (the first substep starts with a migration: it yields the first estimate)
+    c.mig_elapsed = 0.f;
     c.mig_every = every;
     c.mig_cap = capacity_particles;
     c.mig_bytes = mpm_dist_migration_buffer_bytes(capacity_particles);
@@ -1103,7 +1130,14 @@ int mpm_chain_substeps(mpm_handle_t e, int n, float dt, int bc) {
     if (c.left >= 0) { lo[nz] = c.zone_lo[0]; hi[nz] = c.zone_hi[0]; sh[nz] = +c.pitch; sb[nz] = c.send_l; rb[nz] = c.recv_l; ++nz; }
     if (c.right >= 0) { lo[nz] = c.zone_lo[1]; hi[nz] = c.zone_hi[1]; sh[nz] = -c.pitch; sb[nz] = c.send_r; rb[nz] = c.recv_r; ++nz; }
     for (int s = 0; s < n; ++s) {
-        if (c.mig_every > 0 && c.steps > 0 && c.steps % (uint64_t)c.mig_every == 0 && nz > 0) {
+        // Migration: every mig_every substeps, or (mig_every = 0, adaptive) when half of the time has passed in which,
+        // by the ranks' common estimate, no particle can have drifted further than the bands allow (Dist::mig_delta).
+        bool due = false;
+        if (c.mig_cap > 0 && nz > 0) {
+            if (c.mig_every > 0) due = c.steps > 0 && c.steps % (uint64_t)c.mig_every == 0;
+            else due = !(c.mig_elapsed + dt <= c.mig_budget);
+        }
+        if (due) {
             // particles change hands (mpm_dist.h): records to / from both neighbours, same pairing as below
             if (int rc = mpm_dist_migrate_pack(e, c.mig_send_l, c.mig_send_r, c.mig_cap)) return rc;
             RCCL_TRY(a->group_start());
@@ -1115,10 +1149,27 @@ int mpm_chain_substeps(mpm_handle_t e, int n, float dt, int bc) {
             const int rc_e = a->group_end();   // (always closes the group, also after a failed call)
             RCCL_TRY(rc_g);
             RCCL_TRY(rc_e);
+            if (c.mig_every == 0) {
+                // the ranks agree on the smallest estimate (one float, ncclMin), read back at the synchronisation
+                // point that mpm_dist_migrate_apply is anyway
+                RCCL_TRY(a->all_reduce(&e->dp.ctl->mig_quiet, c.mig_quiet_all, 1, 7 /* ncclFloat32 */, 3 /* ncclMin */, c.comm,
+                                       e->stream));
+            }
             if (int rc = mpm_dist_migrate_apply(e, c.left >= 0 ? c.mig_recv_l : nullptr, c.right >= 0 ? c.mig_recv_r : nullptr,
                                                 c.mig_cap))
                 return rc;
+            if (c.mig_every == 0) {
+                float t = 0.f;
+                D2H(e, &t, c.mig_quiet_all, sizeof(float));   // (the stream is idle: apply has just synchronised it)
+                // (the estimate is ballistic: forces can speed particles up before the next look.  The interval may at
+                // most double from one migration to the next -- 4 substeps after the first --, so a change of the
+                // velocities is seen after at most as long as they have been watched)
+                const float t_est = e->mig_safety * (t >= 0.f ? t : 0.f);   // (NaN -> 0: migrate again next substep)
+                c.mig_budget = std::min(t_est, std::max(4.f * dt, 2.f * c.mig_elapsed));
+                c.mig_elapsed = 0.f;
+            }
         }
+        c.mig_elapsed += dt;
         c.steps += 1;
         e->chain_lean = s + 1 < n;   // (reset below; the two calls are public entry points of their own as well)
         if (int rc = mpm_substep_begin_halo(e, dt, nz, lo, hi, sh, sb, c.cap)) {
@@ -1316,6 +1367,7 @@ int mpm_get_stats(mpm_handle_t e, mpm_stats_t* out) {
     out->error_flags = c.error;
     if (!c.error)
         if (int rc = slab_pool_grow(e, c)) return rc;
+    note_quiet_time(e, c);   // (a read-only call: the hint its settle() dropped still holds)
     out->active_faces = (uint32_t)c.nfa;
     out->active_vertices = (uint32_t)c.nva;
     out->face_slots = (uint32_t)e->dp.Nf;
@@ -1448,22 +1500,29 @@ __global__ __launch_bounds__(256) void k_dist_shift_slots(DP p, int old_nf, int 
 }
 }  // namespace mpm
 
-// mpm_dist_init, last step.  The rank was finalised with the whole scene (every rank runs the same Finalize, so ghost
-// copies start bit-identical to their owners'); the first partitioned re-sort has compacted what it keeps into slots
-// [0, nfa) and [Nf, Nf + nva).  Every array indexed by particle slot is now re-allocated at 1.5 x that (+ head room for
-// what migration appends between re-sorts), the kept ranges are copied, slot references are shifted, and the tables of
-// the whole scene's topology (corner ids per face, adjacency CSR, Dm^-1 by original id) are released: per slot the rank
-// keeps the same information by original id (DP::fg / vg), and migration records carry it.  What stays whole-scene
-// sized is the id -> slot map and the slot-order bookkeeping (13 bytes per particle of the scene, mpm_stats_t).
-static int dist_shrink(mpm_engine* e) {
+// Slot space of a partitioned rank.  The rank was finalised with the whole scene (every rank runs the same Finalize, so
+// ghost copies start bit-identical to their owners'); the first partitioned re-sort has compacted what it keeps into
+// slots [0, nfa) and [Nf, Nf + nva).  dist_resize re-allocates every array indexed by particle slot for `new_nf` face and
+// `new_nv` vertex slots, copies the held ranges, shifts the slot references and asks for a re-sort (block tables, work
+// items and wave groups hold slot ranges).  mpm_dist_init calls it once to SHRINK the rank to headroom x its share and
+// to release the tables of the whole scene's topology (corner ids per face, adjacency CSR, Dm^-1 by original id: per
+// slot the rank keeps the same information by original id, DP::fg / vg, and migration records carry it); a migration
+// that would overflow the slot space calls it again to GROW (mpm_dist_migrate_apply: the stream is idle there).  What
+// stays whole-scene sized is the id -> slot map and the slot-order bookkeeping (13 bytes per particle of the scene).
+static size_t dist_slot_capacity(const mpm_engine* e, size_t held, size_t all) {
+    if (!(e->dist_headroom > 0.f)) return all;   // (0: keep the whole scene's size)
+    return std::min(all, std::max<size_t>((size_t)((double)held * std::max(1.f, e->dist_headroom)) + 256, 1024));
+}
+static int dist_resize(mpm_engine* e, size_t new_nf, size_t new_nv, bool first) {
     DP& p = e->dp;
     HIP_TRY(hipStreamSynchronize(e->stream));
     Ctl c;
     D2H(e, &c, p.ctl, sizeof(Ctl));
-    const size_t nfa = (size_t)c.nfa, nva = (size_t)c.nva;
-    const size_t old_nf = (size_t)p.Nf, old_nv = (size_t)p.Nv;
-    auto cap_of = [](size_t held, size_t all) { return std::min(all, std::max<size_t>(held + held / 2 + 256, 1024)); };
-    const size_t new_nf = cap_of(nfa, old_nf), new_nv = cap_of(nva, old_nv), new_np = new_nf + new_nv;
+    // (what a migration appended behind the active particles and the re-sort has not merged yet is kept too)
+    const size_t nfa = (size_t)(c.nfa + c.add_f), nva = (size_t)(c.nva + c.add_v);
+    const size_t old_nf = (size_t)p.Nf;
+    REQUIRE(new_nf >= nfa && new_nv >= nva, "dist_resize: smaller than what the rank holds");
+    const size_t new_np = new_nf + new_nv;
     const int cur = c.cur & 1;
     int rc = 0;
     // one array: allocate n_new elements, keep `keep` elements from old[from_old ...] at new[to_new ...]
@@ -1524,13 +1583,13 @@ static int dist_shrink(mpm_engine* e) {
         (rc = move(p.dst_of, new_np, 0, 0, 0)))
         return rc;
     if ((rc = move(p.home_groups, new_np / 64 + p.capH + 2, 0, 0, 0))) return rc;
-    // the whole scene's topology tables
-    for (int d = 0; d < 3; ++d) {
-        int* t = const_cast<int*>(p.idx_orig[d]);
-        e->dfree(t);
-        p.idx_orig[d] = nullptr;
-    }
-    {
+    if (first) {
+        // the whole scene's topology tables
+        for (int d = 0; d < 3; ++d) {
+            int* t = const_cast<int*>(p.idx_orig[d]);
+            e->dfree(t);
+            p.idx_orig[d] = nullptr;
+        }
         int* a = const_cast<int*>(p.adj_off);
         int* b = const_cast<int*>(p.adj_fc);
         float4* dm = const_cast<float4*>(p.dm_orig);
@@ -1549,6 +1608,8 @@ static int dist_shrink(mpm_engine* e) {
     // block tables, work items and wave groups hold slot ranges: rebuild them on the new slot space
     const int one = 1;
     H2D(e, &p.ctl->need_rebuild, &one, sizeof(int));
+    e->dist_resizes += 1;
+    if (!first) return 0;   // (a migration follows, and the re-sort that merges what it brings)
     may_resort(e, 0.f);
     launch_rebuild(e);
     D2H(e, &c, p.ctl, sizeof(Ctl));
@@ -1564,11 +1625,50 @@ int mpm_dist_init(mpm_handle_t e, const mpm_dist_config_t* cfg) {
     REQUIRE(cfg->world >= 1 && cfg->rank >= 0 && cfg->rank < cfg->world, "bad rank / world");
     REQUIRE(cfg->own_lo_block >= 0 && cfg->own_lo_block < cfg->own_hi_block && cfg->own_hi_block <= nb,
             "bad slab: need 0 <= own_lo_block < own_hi_block <= blocks per axis");
-    REQUIRE(cfg->zone_blocks >= 1 && cfg->ghost_cells >= 1 && cfg->ghost_margin_cells >= 1,
-            "zone_blocks, ghost_cells and ghost_margin_cells must be positive");
+    const bool auto_bands = cfg->ghost_cells == 0 && cfg->ghost_margin_cells == 0;
+    REQUIRE(cfg->zone_blocks >= 1 && (auto_bands || (cfg->ghost_cells >= 1 && cfg->ghost_margin_cells >= 1)),
+            "zone_blocks must be positive; ghost_cells and ghost_margin_cells both positive, or both 0 (bands from the mesh)");
     // a ghost vertex may sit ghost_cells + ghost_margin_cells beyond the cut and its stencil reaches 2 nodes further
-    REQUIRE(cfg->zone_blocks * 4 >= cfg->ghost_cells + cfg->ghost_margin_cells + 2,
+    REQUIRE(auto_bands || cfg->zone_blocks * 4 >= cfg->ghost_cells + cfg->ghost_margin_cells + 2,
             "zone too shallow for the ghost band: need 4 * zone_blocks >= ghost_cells + ghost_margin_cells + 2");
+    // Reach of a face: how far a corner vertex can be from the face particle (the centroid), in cells -- 2/3 of a
+    // median, bounded by 0.75 x the longest edge of the mesh as it was handed over (a cloth stretches by per cent).
+    float longest_edge = 0.f;
+    for (size_t f = 0; f < e->nf; ++f)
+        for (int k = 0; k < 3; ++k) {
+            const float* A = &e->h_pos[(size_t)e->h_idx[f * 3 + k] * 3];
+            const float* B = &e->h_pos[(size_t)e->h_idx[f * 3 + (k + 1) % 3] * 3];
+            longest_edge = std::max(longest_edge, std::sqrt((A[0] - B[0]) * (A[0] - B[0]) + (A[1] - B[1]) * (A[1] - B[1]) +
+                                                            (A[2] - B[2]) * (A[2] - B[2])));
+        }
+    longest_edge *= e->dp.dxinv;
+    const float reach = .75f * longest_edge;
+    // Drift budget.  Between two migrations nothing joins or leaves a rank, so what a rank holds must cover what its
+    // owned particles need even after every particle has drifted `delta` cells along x:
+    //   an owned vertex needs its adjacent faces:  ghost_w >= reach + 2 delta   (both may have moved)
+    //   a face needs its corners:                  vert_w  >= ghost_w + reach   (holds at the migration, nothing leaves after)
+    //   a ghost's stencil stays inside the zone:   vert_w + delta <= 4 zone_blocks - 2
+    //   an owned particle's stencil does:          delta <= 4 zone_blocks - 3
+    // bands from the mesh (ghost_cells = ghost_margin_cells = 0): the widths that make delta largest; given widths:
+    // the delta they allow (0: migrate with every substep).
+    // (with the hysteresis h of ownership and band membership, Dist::hyst: an owned particle may sit h beyond a cut and a
+    // held ghost h beyond its band when the drift starts)
+    //   ghost_w >= reach + 2 delta + h;  vert_w >= ghost_w + reach;  vert_w + h + delta <= 4 zone_blocks - 2;
+    //   h + delta <= 4 zone_blocks - 3
+    const float zone_room = (float)(4 * cfg->zone_blocks - 2);
+    float ghost_w, vert_w, delta, hyst = .125f;
+    if (auto_bands) {
+        delta = std::min((zone_room - 2.f * reach - 2.f * hyst) / 3.f, zone_room - 1.f - hyst);
+        REQUIRE(delta > .05f, "mpm_dist_init: the exchanged zone is too shallow for this mesh (4 zone_blocks - 2 must exceed 1.5 x "
+                              "the longest mesh edge in cells): use more zone_blocks or a finer mesh");
+        ghost_w = reach + 2.f * delta + hyst;
+        vert_w = ghost_w + reach;
+    } else {
+        ghost_w = (float)cfg->ghost_cells;
+        vert_w = (float)(cfg->ghost_cells + cfg->ghost_margin_cells);
+        if (zone_room - vert_w < 2.f * hyst) hyst = 0.f;   // (bands that fill the zone: no room for it)
+        delta = std::max(0.f, std::min({(ghost_w - reach - hyst) * .5f, zone_room - vert_w - hyst, zone_room - 1.f - hyst}));
+    }
     const bool has_left = cfg->rank > 0, has_right = cfg->rank < cfg->world - 1;
     // the zones of the two cuts must not overlap (a block is shared by at most two ranks)
     REQUIRE(!(has_left && has_right) || cfg->own_hi_block - cfg->own_lo_block >= 2 * cfg->zone_blocks,
@@ -1583,10 +1683,15 @@ int mpm_dist_init(mpm_handle_t e, const mpm_dist_config_t* cfg) {
     d.nbr_lo = has_left ? (cfg->rank > 1 ? cfg->left_lo_block * 4 : 0) : 0;
     d.nbr_hi = has_right ? (cfg->rank < cfg->world - 2 ? cfg->right_hi_block * 4 : nb * 4) : nb * 4;
     d.has_left = has_left; d.has_right = has_right;
-    d.ghost_cells = cfg->ghost_cells;
-    d.vert_cells = cfg->ghost_cells + cfg->ghost_margin_cells;
+    d.ghost_w = ghost_w;
+    d.vert_w = vert_w;
+    d.hyst = hyst;
     d.zone_cells = cfg->zone_blocks * 4;
+    d.mig_delta = delta;
+    d.mig_reach = vert_w + 2.f * reach + 1.f;
+    e->dist_longest_edge = longest_edge;
     if (int rc = e->dalloc(&d.prev, e->np, true)) return rc;
+    if (int rc = e->dalloc(&d.mig_min, 32 * 32, true)) return rc;
     // per-slot topology by original id, for every particle at first (nobody has been released yet)
     for (int s = 0; s < 2; ++s) {
         if (int rc = e->dalloc(&e->dp.fg[s], e->nf, false)) return rc;
@@ -1616,8 +1721,44 @@ int mpm_dist_init(mpm_handle_t e, const mpm_dist_config_t* cfg) {
         if (int rc = recover_slab_overflow(e, c)) return rc;
     }
     // the rank keeps its share: the particle arrays shrink to it, the whole scene's topology tables go
-    if (int rc = dist_shrink(e)) return rc;
+    {
+        Ctl c;
+        D2H(e, &c, e->dp.ctl, sizeof(Ctl));
+        if (int rc = dist_resize(e, dist_slot_capacity(e, (size_t)c.nfa, (size_t)e->dp.Nf),
+                                 dist_slot_capacity(e, (size_t)c.nva, (size_t)e->dp.Nv), true))
+            return rc;
+    }
     return mpm_sync(e);
+}
+
+int mpm_dist_set_headroom(mpm_handle_t e, float factor) {
+    REQUIRE(e, "null handle");
+    REQUIRE(!e->dp.dist.on, "mpm_dist_set_headroom must precede mpm_dist_init");
+    REQUIRE(factor == 0.f || factor >= 1.f, "headroom must be 0 (keep the whole scene's size) or >= 1");
+    e->dist_headroom = factor;
+    return 0;
+}
+
+int mpm_dist_get_geometry(mpm_handle_t e, mpm_dist_geometry_t* out) {
+    READY_NO_SETTLE(e);
+    REQUIRE(out, "null output");
+    REQUIRE(e->dp.dist.on, "mpm_dist_init first");
+    const Dist& d = e->dp.dist;
+    out->face_band_cells = d.ghost_w;
+    out->vertex_band_cells = d.vert_w;
+    out->drift_budget_cells = d.mig_delta;
+    out->longest_edge_cells = e->dist_longest_edge;
+    out->slot_resizes = e->dist_resizes;
+    out->migrations = e->dist_migrations;
+    return 0;
+}
+
+int mpm_dist_migration_quiet_time(mpm_handle_t e, float* seconds_out) {
+    READY(e);
+    REQUIRE(seconds_out, "null output");
+    REQUIRE(e->dp.dist.on, "mpm_dist_init first");
+    D2H(e, seconds_out, &e->dp.ctl->mig_quiet, sizeof(float));
+    return 0;
 }
 
 size_t mpm_dist_migration_buffer_bytes(size_t capacity_particles) { return 16 + capacity_particles * DIST_REC_F4 * 16; }
@@ -1630,12 +1771,41 @@ int mpm_dist_migrate_pack(mpm_handle_t e, void* send_left, void* send_right, siz
     HIP_TRY(hipMemsetAsync(send_right, 0, 16, e->stream));
     hipLaunchKernelGGL(k_dist_classify, dim3(std::min(e->g_np, 2048u)), dim3(256), 0, e->stream, e->dp,
                        static_cast<float4*>(send_left), static_cast<float4*>(send_right), (unsigned)capacity_particles);
+    // (the time until the next migration is due, as far as this rank can tell: Ctl::mig_quiet)
+    hipLaunchKernelGGL(k_dist_mig_reduce, dim3(1), dim3(64), 0, e->stream, e->dp);
+    e->dist_migrations += 1;
     return 0;
 }
 
 int mpm_dist_migrate_apply(mpm_handle_t e, const void* recv_left, const void* recv_right, size_t capacity_particles) {
     READY(e);
     REQUIRE(e->dp.dist.on, "mpm_dist_init first");
+    // A migration is a synchronisation point: the host reads how many particles arrive and what the rank holds, and
+    // re-allocates the slot space first if they would not fit (a cloth that slides across a cut, an uneven split).
+    {
+        DP& p = e->dp;
+        uint32_t hdr[2][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
+        Ctl c;
+        HIP_TRY(hipMemcpyAsync(&c, p.ctl, sizeof(Ctl), hipMemcpyDeviceToHost, e->stream));
+        const void* bufs[2] = {recv_left, recv_right};
+        for (int k = 0; k < 2; ++k)
+            if (bufs[k]) HIP_TRY(hipMemcpyAsync(hdr[k], bufs[k], 16, hipMemcpyDeviceToHost, e->stream));
+        HIP_TRY(hipStreamSynchronize(e->stream));
+        size_t in_f = 0, in_v = 0;
+        for (int k = 0; k < 2; ++k) {
+            const size_t n = std::min<size_t>(hdr[k][0], capacity_particles), nf = std::min<size_t>(hdr[k][1], n);
+            in_f += nf;
+            in_v += n - nf;
+        }
+        // (every arriving record counted as a new particle -- promotions of ghosts the rank already holds need no
+        // slot --, but never more than the scene has: a particle has one slot)
+        const size_t need_f = std::min(e->nf, (size_t)(c.nfa + c.add_f) + in_f), need_v = std::min(e->nv, (size_t)(c.nva + c.add_v) + in_v);
+        if (need_f > (size_t)p.Nf || need_v > (size_t)p.Nv) {
+            const size_t want_f = std::max((size_t)p.Nf, dist_slot_capacity(e, need_f, e->nf));
+            const size_t want_v = std::max((size_t)p.Nv, dist_slot_capacity(e, need_v, e->nv));
+            if (int rc = dist_resize(e, want_f, want_v, false)) return rc;
+        }
+    }
     for (const void* b : {recv_left, recv_right})
         if (b)
             hipLaunchKernelGGL(k_dist_apply, dim3(256), dim3(256), 0, e->stream, e->dp, static_cast<const float4*>(b),

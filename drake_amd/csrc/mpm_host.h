@@ -91,7 +91,9 @@ struct mpm_engine {
         size_t cap = 0, bytes = 0;
         void *send_l = nullptr, *send_r = nullptr, *recv_l = nullptr, *recv_r = nullptr;
         // partitioned domain: migration records every mig_every substeps
-        int mig_every = 0;
+        int mig_every = 0;         // 0 with mig_cap > 0: adaptive (see mpm_chain_substeps)
+        float mig_budget = 0.f, mig_elapsed = 0.f;   // adaptive cadence: seconds until the next migration / since the last
+        float* mig_quiet_all = nullptr;              // device: the ranks' common estimate (ncclMin)
         size_t mig_cap = 0, mig_bytes = 0;
         void *mig_send_l = nullptr, *mig_send_r = nullptr, *mig_recv_l = nullptr, *mig_recv_r = nullptr;
         uint64_t steps = 0;
@@ -124,6 +126,14 @@ struct mpm_engine {
     mpm_contact_stats_t last_contact{};   // of the last mpm_update_contact
     float last_contact_dt = 0.f, last_contact_mu = 0.f, last_contact_k = 0.f, last_contact_d = 0.f;   // its parameters
     mpm_dist_config_t dist_cfg{};         // partitioned domain (mpm_dist_init)
+    // slot space of a partitioned rank = headroom x what it holds (mpm_dist_set_headroom, MPM_DIST_HEADROOM; 0 = the whole
+    // scene's size, no shrink); grown at the migration that would overflow it (dist_resize)
+    float dist_headroom = getenv("MPM_DIST_HEADROOM") ? std::max(0.f, (float)atof(getenv("MPM_DIST_HEADROOM"))) : 1.5f;
+    float dist_longest_edge = 0.f;        // cells, from the mesh handed to AddQRCloth
+    // share of the ranks' common quiet-time estimate after which they migrate again (the estimate is ballistic, elastic
+    // forces are not in it); MPM_MIG_SAFETY
+    float mig_safety = getenv("MPM_MIG_SAFETY") ? std::min(1.f, std::max(.05f, (float)atof(getenv("MPM_MIG_SAFETY")))) : .5f;
+    uint32_t dist_resizes = 0, dist_migrations = 0;
     // transport of the distributed contact solve when there is no native chain (mpm_dist_set_transport)
     mpm_exchange_fn dist_exchange = nullptr;
     mpm_allreduce_fn dist_allreduce = nullptr;

@@ -274,6 +274,7 @@ __global__ __launch_bounds__(1024) void k_rb_tables(DP p) {
     // A2: particle ranges = prefix sums of the block counts over the home list
     const unsigned hpt = (n_home + 1023u) / 1024u;
     const unsigned h0 = min(tid * hpt, n_home), h1 = min(h0 + hpt, n_home);
+    int held = 0;   // particles this engine holds after the re-sort
     {
         int cf = 0, cv = 0;
         for (unsigned h = h0; h < h1; ++h) {
@@ -284,6 +285,7 @@ __global__ __launch_bounds__(1024) void k_rb_tables(DP p) {
         int tf = 0, tv = 0;
         int rf = wg_scan_exclusive(cf, tf, s_w);
         int rv = wg_scan_exclusive(cv, tv, s_w);
+        held = tf + tv;
         if (tid == 0) {
             c->nfa_new = tf;
             c->nva_new = tv;
@@ -339,7 +341,9 @@ __global__ __launch_bounds__(1024) void k_rb_tables(DP p) {
     // longer for 8 to 12 (more slabs): items stay as large as the split for dense piles allows.
     unsigned n_items;
     {
-        const int ig = p.item_groups;
+        // (a small share -- a partitioned rank -- is cut into smaller items: scratch/share_scaling.py, an eighth of the 1M
+        // workload: k_p2g 24.9 -> 15.8 us, k_g2p 8.6 -> 5.6 us with items of 16 groups; the whole workload is fastest at 48)
+        const int ig = ((held + 63) >> 6) < p.item_small_below ? min(p.item_groups, p.item_groups_small) : p.item_groups;
         auto items_of = [&](int ng) { return (ng + ig - 1) / ig; };
         int mine_items = 0;
         for (unsigned h = h0; h < h1; ++h) {

@@ -23,8 +23,10 @@ MPM_DEV bool gated_out(const DP& p) {
 
 __global__ __launch_bounds__(256) void k_fem(DP p, float dt) {
     if (gated_out(p)) return;
-    const unsigned i = xcd_chunk(blockIdx.x, gridDim.x) * 256 + threadIdx.x;
-    if (i >= (unsigned)p.ctl->nfa) return;
+    const unsigned nfa = (unsigned)p.ctl->nfa;
+    const unsigned chunk = xcd_chunk_active(blockIdx.x, nfa);
+    const unsigned i = chunk * 256 + threadIdx.x;
+    if (chunk == 0xFFFFFFFFu || i >= nfa) return;
     const PSet& S = p.set[p.ctl->cur];
     // 104 bytes in (F 36, Dm^-1 | vol | corners 32, C 36) + the corner gathers; 116 bytes out (F 36, face x v 32,
     // tau factor a 12 -- the other one is F's normal column, see pack_F --, corner forces 36).  The face particle's own q[0] / q[1] are written, never read: its
@@ -165,8 +167,10 @@ MPM_DEV void vertex_force(const DP& p, const PSet& S, int k) {   // ... written 
 // item, see DP::fuse_vforce)
 __global__ __launch_bounds__(256) void k_vforce(DP p) {
     if (gated_out(p)) return;
-    const int k = (int)(xcd_chunk(blockIdx.x, gridDim.x) * 256 + threadIdx.x);
-    if (k >= p.ctl->nva) return;
+    const unsigned nva = (unsigned)p.ctl->nva;
+    const unsigned chunk = xcd_chunk_active(blockIdx.x, nva);
+    const int k = (int)(chunk * 256 + threadIdx.x);
+    if (chunk == 0xFFFFFFFFu || k >= (int)nva) return;
     vertex_force(p, p.set[p.ctl->cur], k);
 }
 
@@ -735,7 +739,33 @@ __global__ __launch_bounds__(256) void k_grid(DP p, GridColliders gc) {
         }
         const int* nbr = p.act_nbr_items + (size_t)a * 27;
         float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (MODE == 2) s = p.gv[(size_t)a * 64 + cell];
+        if (MODE == 2) {
+            s = p.gv[(size_t)a * 64 + cell];
+            if (p.halo_pn > 0) {
+                // chain substep: the neighbour's sums for this block, straight from the received buffer (what k_halo_add2
+                // does as a launch of its own for the public mpm_halo_add).  The buffer lists its blocks in the order its
+                // sender's atomics fell: the wave scans the ids, 64 per step (a zone holds a few hundred blocks).  own +
+                // received is the same pair of numbers on both ranks, so both compute identical node values.
+                const uint32_t myid = p.act_block[a];
+                int bx, by, bz;
+                block_coords(myid, bx, by, bz);
+                for (int k = 0; k < p.halo_pn; ++k) {
+                    if (bx < p.halo_plo[k] || bx > p.halo_phi[k]) continue;   // wave-uniform
+                    const uint32_t* buf = p.halo_pbuf[k];
+                    const unsigned n = min(buf[0], p.halo_pcap);
+                    int found = -1;
+                    for (unsigned base = 0; base < n && found < 0; base += 64) {
+                        const uint32_t id = base + (unsigned)cell < n ? buf[halo_ids_offset() + base + (unsigned)cell] : 0xFFFFFFFFu;
+                        const unsigned long long m = __ballot(id == myid);
+                        if (m) found = (int)base + __builtin_ctzll(m);
+                    }
+                    if (found >= 0) {
+                        const float4 r = (reinterpret_cast<const float4*>(buf) + halo_data_offset(p.halo_pcap))[(size_t)found * 64 + cell];
+                        s.x += r.x; s.y += r.y; s.z += r.z; s.w += r.w;
+                    }
+                }
+            }
+        }
         if (MODE != 2) {
             // Phase 1: lanes 0..26 look at one neighbour home block each and list the slabs (one per
             // work item of that block) whose stencils reached this block, in a fixed order

@@ -20,16 +20,40 @@ copies next to the cuts (mpm_dist_init); particles migrate between neighbours ev
 """
 from __future__ import annotations
 
+import math
+import os
+
 import torch
 import torch.distributed as dist
+
+
+def strong_geometry(bits: int, world: int):
+    """The partition bench.py --scaling strong uses for `world` ranks on a (1 << bits)^3 grid: the cloth stack spans
+    the x blocks nb/4 .. 3nb/4, cut into slabs of equal width (the outermost ranks extend to the walls).  The zone is
+    two blocks deep where a slab is at least four blocks wide, else one; the ghost bands come from the mesh (fractional
+    widths that leave the most room for drift, mpm_dist_init) and migrations follow the measured x velocities."""
+    nb = (1 << bits) // 4
+    lo, hi = nb // 4, 3 * nb // 4
+    if (hi - lo) % world or (hi - lo) // world < 2:
+        raise ValueError(f"the cloth's {hi - lo} blocks do not split evenly into {world} slabs of at least 2 blocks")
+    width = (hi - lo) // world
+    cuts = [0] + [lo + width * r for r in range(1, world)] + [nb]
+    return dict(cuts=cuts, zone_blocks=2 if width >= 4 else 1, ghost_cells=0, ghost_margin_cells=0, migrate_every=0)
+
+
+def migration_safety() -> float:
+    """Share of the ranks' common quiet-time estimate after which they migrate again (as the native chain's)."""
+    return min(1.0, max(0.05, float(os.environ.get("MPM_MIG_SAFETY", "0.5"))))
 
 
 class HaloChain:
     def __init__(self, engine, rank: int, world: int, cut_lo_block: int, cut_hi_block: int, pitch_blocks: int,
                  zone_blocks: int = 2, capacity_blocks: int = 512, device: torch.device | None = None,
-                 group=None, split: bool | None = None):
+                 group=None, split: bool | None = None, backend: str | None = None):
         """cut_lo_block / cut_hi_block: local x block index of the first block at/after the left /
-        right cut plane (e.g. patch x in [0.25, 0.75] on 128^3 -> 8 and 24)."""
+        right cut plane (e.g. patch x in [0.25, 0.75] on 128^3 -> 8 and 24).
+        backend: name of the transport instead of the process group's ("local": the ranks live in one process and a
+        LocalWorld moves their buffers)."""
         self.e, self.rank, self.world, self.group = engine, rank, world, group
         self.cap = capacity_blocks
         self.left = rank - 1 if rank > 0 else None
@@ -39,7 +63,9 @@ class HaloChain:
         self.pitch = pitch_blocks
         self._fast_args = None
         self._ops = None
-        backend = dist.get_backend(group) if world > 1 else "none"
+        if backend is None:
+            backend = dist.get_backend(group) if world > 1 else "none"
+        self.backend = backend
         self.staged = backend != "nccl"
         # split = update and gather what does not depend on the neighbours while the exchange is in
         # flight (mpm_substep_mid_halo).  Pays with an asynchronous transport (RCCL); with the staged
@@ -175,14 +201,23 @@ class DomainChain(HaloChain):
     def __init__(self, engine, rank: int, world: int, cuts, zone_blocks: int = 2, ghost_cells: int = 2,
                  ghost_margin_cells: int = 2, capacity_blocks: int = 512, migrate_every: int = 4,
                  migrate_capacity: int = 8192, device: torch.device | None = None, group=None,
-                 split: bool | None = None):
+                 split: bool | None = None, backend: str | None = None, headroom: float | None = None,
+                 partitioned: bool = False):
+        """migrate_every = 0: adaptive -- the ranks migrate when a share (MPM_MIG_SAFETY, default half) of the time has
+        passed in which, by their common ballistic estimate, no particle drifts further along x than the bands allow
+        (mpm_dist_migration_quiet_time).  partitioned: the engine has been through mpm_dist_init already."""
         assert len(cuts) == world + 1 and all(a < b for a, b in zip(cuts, cuts[1:]))
-        engine.dist_init(rank, world, list(cuts), zone_blocks, ghost_cells, ghost_margin_cells)
+        if not partitioned:
+            kw = {} if headroom is None else {"headroom": headroom}
+            engine.dist_init(rank, world, list(cuts), zone_blocks, ghost_cells, ghost_margin_cells, **kw)
         super().__init__(engine, rank, world, cut_lo_block=cuts[rank], cut_hi_block=cuts[rank + 1], pitch_blocks=0,
                          zone_blocks=zone_blocks, capacity_blocks=capacity_blocks, device=device, group=group,
-                         split=split)
+                         split=split, backend=backend)
         self.migrate_every, self.mig_cap = int(migrate_every), int(migrate_capacity)
         self.steps = 0
+        self.migrations = 0
+        self.mig_budget, self.mig_elapsed = 0.0, 0.0   # adaptive cadence: seconds until the next migration / since the last
+        self.last_dt = 0.0
         nbytes = engine.dist_migration_buffer_bytes(self.mig_cap)
         mk = lambda: torch.zeros(nbytes, dtype=torch.uint8, device=self.device)
         # pack always fills a left and a right buffer; a missing neighbour's stays local
@@ -251,9 +286,110 @@ class DomainChain(HaloChain):
                 w.wait()
         e.dist_migrate_apply(self.mig_recv[self.left].data_ptr() if self.left is not None else None,
                              self.mig_recv[self.right].data_ptr() if self.right is not None else None, self.mig_cap)
+        self.migrations += 1
+        if self.migrate_every == 0:
+            # the ranks agree on the smallest estimate (apply has just synchronised the stream: the read-back is cheap)
+            t = torch.tensor([e.dist_migration_quiet_time()], dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MIN, group=self.group if self.backend != "nccl" else None)
+            self.set_quiet_time(float(t.item()))
+
+    def set_quiet_time(self, t_all: float):
+        """The next migration is due after a share of the ranks' common estimate -- but the interval at most doubles from
+        one migration to the next (4 substeps after the first): the estimate is ballistic, and a change of the
+        velocities must be seen after at most as long as they have been watched (as mpm_chain_substeps does)."""
+        t_est = migration_safety() * (t_all if t_all >= 0.0 else 0.0)   # (NaN -> 0)
+        self.mig_budget = min(t_est, max(4.0 * self.last_dt, 2.0 * self.mig_elapsed))
+        self.mig_elapsed = 0.0
+
+    def migration_due(self, dt: float) -> bool:
+        self.last_dt = dt
+        if self.world == 1:
+            return False
+        if self.migrate_every > 0:
+            return self.steps > 0 and self.steps % self.migrate_every == 0
+        return not (self.mig_elapsed + dt <= self.mig_budget)
 
     def substep(self, dt: float, mpm_bc: int = -1):
-        if self.migrate_every > 0 and self.steps % self.migrate_every == 0 and self.steps > 0:
+        if self.migration_due(dt):
             self.migrate()
         self.steps += 1
+        self.mig_elapsed += dt
         super().substep(dt, mpm_bc)
+
+
+class LocalWorld:
+    """`world` ranks of ONE partitioned domain inside one process, every rank with its own engine on the same GPU: the
+    kernels, the bookkeeping and the decisions are exactly a DomainChain's, only the transport is a device-to-device
+    copy.  All engines run on torch's current stream, so the copies are ordered with their kernels without host
+    synchronisation.  For tests and rehearsals of partitions with more ranks than a box has GPUs (a GPU box admits few
+    processes per card): one process, any number of ranks."""
+
+    def __init__(self, engines, cuts, zone_blocks: int = 2, ghost_cells: int = 0, ghost_margin_cells: int = 0,
+                 capacity_blocks: int = 512, migrate_every: int = 0, migrate_capacity: int = 8192,
+                 device: torch.device | None = None, headroom: float | None = None):
+        self.world = len(engines)
+        assert len(cuts) == self.world + 1
+        device = device if device is not None else torch.device("cuda", 0)
+        # one stream of its own for all engines and all copies (the engines' own streams are non-blocking: nothing on
+        # torch's default stream is ordered with them, and a null stream handle means "the engine's own" to mpm_set_stream)
+        self.stream = torch.cuda.Stream(device)
+        self.chains = []
+        with torch.cuda.stream(self.stream):
+            for r, e in enumerate(engines):
+                e.set_stream(self.stream.cuda_stream)
+                self.chains.append(DomainChain(e, r, self.world, cuts, zone_blocks, ghost_cells, ghost_margin_cells,
+                                               capacity_blocks, migrate_every, migrate_capacity, device=device,
+                                               backend="local", headroom=headroom))
+        self.stream.synchronize()
+        self.migrations = 0
+
+    def _move(self, send_of, recv_of):
+        for c in self.chains:
+            for n in (c.left, c.right):
+                if n is not None:
+                    recv_of(self.chains[n])[c.rank].copy_(send_of(c, n), non_blocking=True)
+
+    def migrate(self):
+        with torch.cuda.stream(self.stream):
+            self._migrate()
+
+    def substep(self, dt: float, mpm_bc: int = -1):
+        with torch.cuda.stream(self.stream):
+            self._substep(dt, mpm_bc)
+
+    def _migrate(self):
+        for c in self.chains:
+            c.e.dist_migrate_pack(c.mig_send["l"].data_ptr(), c.mig_send["r"].data_ptr(), c.mig_cap)
+        self._move(lambda c, n: c.mig_send["l" if n == c.left else "r"], lambda c: c.mig_recv)
+        for c in self.chains:
+            c.e.dist_migrate_apply(c.mig_recv[c.left].data_ptr() if c.left is not None else None,
+                                   c.mig_recv[c.right].data_ptr() if c.right is not None else None, c.mig_cap)
+            c.migrations += 1
+        self.migrations += 1
+        if self.chains[0].migrate_every == 0:
+            t = min(c.e.dist_migration_quiet_time() for c in self.chains)
+            for c in self.chains:
+                c.set_quiet_time(t)
+
+    def _substep(self, dt: float, mpm_bc: int = -1):
+        if self.world > 1 and all([c.migration_due(dt) for c in self.chains]):
+            self._migrate()
+        for c in self.chains:
+            c.steps += 1
+            c.mig_elapsed += dt
+            if c._fast_args is None:
+                zones = c._zones()
+                c._fast_args = (c.e.halo_zone_args([z[:3] for z in zones], [c.send[z[3]].data_ptr() for z in zones]),
+                                c.e.halo_buffer_args([c.recv[n].data_ptr() for n in c.recv]))
+            c.e.substep_begin_halo(dt, c._fast_args[0], c.cap)
+        self._move(lambda c, n: c.send[n], lambda c: c.recv)
+        for c in self.chains:
+            c.e.substep_end_halo(dt, mpm_bc, c._fast_args[1], c.cap)
+
+    def run_substeps(self, n: int, dt: float, mpm_bc: int = -1):
+        for _ in range(n):
+            self.substep(dt, mpm_bc)
+
+    def sync(self):
+        for c in self.chains:
+            c.e.gpu_sync()

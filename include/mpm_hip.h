@@ -417,7 +417,8 @@ MPM_API int mpm_chain_init(mpm_handle_t h, const char id[128], int rank, int wor
                            int pitch_blocks, int zone_blocks, size_t capacity_blocks, int periodic);
 MPM_API int mpm_chain_substeps(mpm_handle_t h, int n_substeps, float dt, int mpm_bc);
 /* Partitioned domain (mpm_dist_init + mpm_chain_init with pitch_blocks = 0): mpm_chain_substeps also
- * swaps migration records with the neighbours every `every` substeps (mpm_dist_migrate_pack / _apply). */
+ * swaps migration records with the neighbours every `every` substeps (mpm_dist_migrate_pack / _apply);
+ * every = 0: when the ranks' common quiet-time estimate says so (mpm_dist_migration_quiet_time). */
 MPM_API int mpm_chain_enable_migration(mpm_handle_t h, int every, size_t capacity_particles);
 MPM_API int mpm_chain_destroy(mpm_handle_t h);
 
@@ -453,6 +454,31 @@ typedef struct {
                                                mesh edge), so that a ghost face always has its corners */
 } mpm_dist_config_t;
 MPM_API int mpm_dist_init(mpm_handle_t h, const mpm_dist_config_t *config);
+/* ghost_cells = ghost_margin_cells = 0 selects BANDS FROM THE MESH: fractional widths (in cells, measured on x / dx - 0.5)
+ * chosen so that the drift every particle may accumulate along x between two migrations is as large as the zone allows:
+ *   reach = 0.75 x longest mesh edge (cells);   drift = (4 zone_blocks - 2 - 2 reach) / 3;
+ *   face band = reach + 2 drift;   vertex band = 2 reach + 2 drift.
+ * (zone_blocks = 2 and 0.62-cell edges: drift 1.7 cells against 0.8 for the integer bands 2 + 2; zone_blocks = 1, the
+ * only depth a slab two blocks wide allows: 0.36 cells, where integer bands 1 + 1 leave none.)  Given integer bands
+ * allow drift = min((ghost_cells - reach) / 2, 4 zone_blocks - 2 - ghost_cells - ghost_margin_cells). */
+typedef struct {
+    float face_band_cells, vertex_band_cells;   /* as in use */
+    float drift_budget_cells;                   /* what a particle may drift along x between two migrations */
+    float longest_edge_cells;
+    uint32_t slot_resizes;                      /* re-allocations of the rank's slot space (1 = mpm_dist_init's own) */
+    uint32_t migrations;                        /* mpm_dist_migrate_pack calls so far */
+} mpm_dist_geometry_t;
+MPM_API int mpm_dist_get_geometry(mpm_handle_t h, mpm_dist_geometry_t *out);
+/* Slot space of a partitioned rank = factor x what it holds after the partition (default 1.5, or MPM_DIST_HEADROOM;
+ * 0 = keep the whole scene's size).  Before mpm_dist_init.  Whatever the factor, a migration that would overflow
+ * the slot space re-allocates it first (mpm_dist_migrate_apply), up to the whole scene's size. */
+MPM_API int mpm_dist_set_headroom(mpm_handle_t h, float factor);
+/* Adaptive migration cadence.  mpm_dist_migrate_pack also estimates how long no particle this rank holds can drift
+ * further along x than drift_budget_cells if all keep moving ballistically (a particle far from both cuts has to get
+ * near one first); this call waits for the stream and returns that time (seconds, may be infinity).  The ranks take
+ * the minimum over all of them and migrate again when a share of it has passed (mpm_chain_enable_migration with
+ * every = 0 does exactly that: ncclAllReduce(min), half of the common estimate). */
+MPM_API int mpm_dist_migration_quiet_time(mpm_handle_t h, float *seconds_out);
 MPM_API size_t mpm_dist_migration_buffer_bytes(size_t capacity_particles);
 /* send_left / send_right: device buffers of mpm_dist_migration_buffer_bytes(capacity) each (both
  * required; a rank without that neighbour gets an empty one).  recv_*: what the neighbours packed, or NULL. */

@@ -178,15 +178,18 @@ class FakeDomainEngine(FakeEngine):
         self.calls.append("end")
 
 
-def _domain_worker(rank, world, cuts, port, q):
+def _domain_worker(rank, world, cuts, port, q, migrate_every=3):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
+    os.environ.pop("MPM_MIG_SAFETY", None)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from drake_amd.dist import DomainChain
     eng = FakeDomainEngine(300, cuts[-1])
+    # adaptive cadence: every rank has its own estimate of how long the bands hold; the smallest one counts
+    eng.dist_migration_quiet_time = lambda: (rank + 2) * 3.0e-3
     chain = DomainChain(eng, rank, world, cuts, zone_blocks=2, ghost_cells=2, ghost_margin_cells=2, capacity_blocks=16,
-                        migrate_every=3, migrate_capacity=128)
+                        migrate_every=migrate_every, migrate_capacity=128)
     start = set(eng.owned)
     for _ in range(12):
         chain.substep(1e-3, -1)
@@ -195,12 +198,14 @@ def _domain_worker(rank, world, cuts, port, q):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,cuts", [(2, [0, 8, 16]), (3, [0, 6, 10, 16])])
-def test_domain_chain_migrates_particles_between_neighbours(world, cuts):
+@pytest.mark.parametrize("world,cuts,migrate_every", [(2, [0, 8, 16], 3), (3, [0, 6, 10, 16], 3), (3, [0, 6, 10, 16], 0)])
+def test_domain_chain_migrates_particles_between_neighbours(world, cuts, migrate_every):
+    """migrate_every = 0: the adaptive cadence -- a migration before the first substep (it yields the first estimate), then
+    whenever half of the ranks' smallest estimate (6 ms here: rank 0's) has passed: before substeps 0, 3, 6, 9 of 1 ms."""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29800 + world + (os.getpid() % 200)
-    procs = [ctx.Process(target=_domain_worker, args=(r, world, cuts, port, q)) for r in range(world)]
+    port = 29800 + world + (os.getpid() % 200) + (40 if migrate_every == 0 else 0)
+    procs = [ctx.Process(target=_domain_worker, args=(r, world, cuts, port, q, migrate_every)) for r in range(world)]
     for p in procs:
         p.start()
     got = {}
@@ -221,10 +226,11 @@ def test_domain_chain_migrates_particles_between_neighbours(world, cuts):
         lo = cuts[r] * 4 if r > 0 else -1e9
         hi = cuts[r + 1] * 4 if r < world - 1 else 1e9
         assert all(lo <= x[g] < hi + 3 * 0.7 for g in owned)
-        # cadence: a migration round (pack, apply) before substeps 3, 6, 9 and no other
-        assert calls.count("pack") == 3 and calls.count("apply") == 3
+        # cadence: a migration round (pack, apply) before substeps 3, 6, 9 and no other (adaptive: also before substep 0)
+        want = [3, 6, 9] if migrate_every else [0, 3, 6, 9]
+        assert calls.count("pack") == len(want) and calls.count("apply") == len(want)
         begins = [i for i, c in enumerate(calls) if c == "begin"]
         packs = [i for i, c in enumerate(calls) if c == "pack"]
-        assert [sum(1 for b in begins if b < pk) for pk in packs] == [3, 6, 9]
+        assert [sum(1 for b in begins if b < pk) for pk in packs] == want
         # the zones straddle this rank's cuts in global block coordinates
         assert zones == ((cuts[r] - 2, cuts[r] + 1), (cuts[r + 1] - 2, cuts[r + 1] + 1))

@@ -1,0 +1,191 @@
+"""Partitions with more ranks than a GPU box admits processes: `world` ranks of ONE domain inside one process
+(drake_amd/dist.py: LocalWorld -- the same kernels, bookkeeping and decisions as the process-per-GPU DomainChain, the
+transport is a device-to-device copy).  Covered here:
+
+* the geometry `bench.py --gpus 4` / `--gpus 8` picks on the 128^3 grid (dist.strong_geometry: at 8 ranks slabs of two
+  blocks, zone ONE block deep, ghost bands from the mesh, adaptive migration cadence), against a single engine, with
+  the assertions of tests/test_domain_gpu.py;
+* the adaptive cadence: a slow scene migrates (and therefore re-sorts) rarely, a fast one often, both stay correct;
+* a cloth that slides across a cut: the receiving rank's slot space grows at the migration that would overflow it
+  (it used to end in MPM_ERR_CAPACITY).
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+DT = 1e-3
+
+
+def _populate(g, sheets):
+    from drake_amd import scenes
+    scenes.populate(g, [(p.copy(), v.copy(), i.copy()) for p, v, i in sheets])
+    return g
+
+
+def _run_world(bits, sheets, geo, steps, capacity_blocks=1024, migrate_capacity=1 << 16, headroom=None, **over):
+    """-> (per-rank results, LocalWorld).  Every rank is finalised with the whole scene, like a process per GPU would."""
+    import torch
+    from drake_amd import GpuMpm
+    from drake_amd.dist import LocalWorld
+    geo = dict(geo, **over)
+    world = len(geo["cuts"]) - 1
+    engines = [_populate(GpuMpm(bits), sheets) for _ in range(world)]
+    w = LocalWorld(engines, geo["cuts"], geo["zone_blocks"], geo["ghost_cells"], geo["ghost_margin_cells"],
+                   capacity_blocks=capacity_blocks, migrate_every=geo["migrate_every"], migrate_capacity=migrate_capacity,
+                   device=torch.device("cuda", 0), headroom=headroom)
+    roles0 = [e.dist_roles() for e in engines]
+    w.run_substeps(steps, DT, -1)
+    w.sync()
+    return roles0, w
+
+
+def _collect(w, roles0, n, nf):
+    """union of what the ranks own (positions, velocities, F), with the ownership checks of test_domain_gpu"""
+    from drake_amd import ARR
+    owners = np.zeros(n, np.int32)
+    owners0 = np.zeros(n, np.int32)
+    pos, vel = np.full((n, 3), np.nan, np.float32), np.full((n, 3), np.nan, np.float32)
+    F = np.full((nf, 9), np.nan, np.float32)
+    per_rank = []
+    for r, c in enumerate(w.chains):
+        g = c.e
+        st = g.stats()
+        assert st["error_flags"] == 0, (r, st)
+        roles = g.dist_roles()
+        p_r, v_r, F_r = g.download(ARR.POSITIONS), g.download(ARR.VELOCITIES), g.download(ARR.DEFORMATION_GRADIENTS)
+        own = roles == 1
+        owners += own
+        owners0 += roles0[r] == 1
+        pos[own], vel[own] = p_r[own], v_r[own]
+        F[own[:nf]] = F_r[own[:nf]]
+        per_rank.append((roles, p_r, v_r, st))
+    assert np.all(owners0 == 1) and np.all(owners == 1)   # exactly one owner per particle, before and after
+    for roles, p_r, v_r, _ in per_rank:
+        gh = roles == 2
+        assert gh.any()
+        # a ghost copy is the same particle advanced redundantly: bit-identical to its owner's
+        assert np.array_equal(p_r[gh], pos[gh]) and np.array_equal(v_r[gh], vel[gh])
+    return pos, vel, F, per_rank
+
+
+def _bench_like_scene(bits, layers, res, vx):
+    from drake_amd import scenes
+    sheets = scenes.cloth_stack(layers, res, bits, seed=1234)
+    for pos, vel, idx in sheets:
+        vel[:, 0] += vx
+    return sheets
+
+
+@pytest.mark.parametrize("world,vx,steps", [(8, 0.8, 36), (4, 0.8, 36), (8, 0.0, 25)])
+def test_bench_partition_geometry_matches_single_engine(world, vx, steps):
+    """The partition bench.py picks for `world` GPUs on the 128^3 grid (8 ranks: two-block slabs, zone 1, fractional
+    ghost bands with 0.36 cells of drift budget; 4 ranks: zone 2) holding a quarter-density copy of the benchmark's
+    cloth stack, drifting 0.1 cells per substep along x (vx = 0.8: dozens of migrations) or at the benchmark's own
+    jitter velocities (vx = 0: the cadence the timed run sees)."""
+    from drake_amd import ARR, GpuMpm
+    from drake_amd.dist import strong_geometry
+    from tests.helpers import close
+    bits = 7
+    sheets = _bench_like_scene(bits, 4, 145, vx)
+    ref = _populate(GpuMpm(bits), sheets)
+    x0 = ref.download(ARR.POSITIONS)
+    ref.run_substeps(steps, DT, -1)
+    ref.gpu_sync()
+    rp, rv, rF = ref.download(ARR.POSITIONS), ref.download(ARR.VELOCITIES), ref.download(ARR.DEFORMATION_GRADIENTS)
+    n, nf = ref.n_particles, ref.n_faces
+    # The yardstick: what a different division of the SAME single-engine run into work items does (node sums are exact
+    # per work item and float-added across items, so the grouping decides the rounding -- and a partition is a different
+    # grouping).  On the 128^3 grid one ulp of F is dt E / (rho dx) x 1.2e-7 = 3e-6 m/s of nodal velocity per substep and
+    # the stiff explicit update compounds it: 36 substeps of rounding alone move F by ~1e-4.
+    import os
+    os.environ["MPM_ITEM_GROUPS"] = "7"
+    try:
+        ref2 = _populate(GpuMpm(bits), sheets)
+    finally:
+        del os.environ["MPM_ITEM_GROUPS"]
+    ref2.run_substeps(steps, DT, -1)
+    ref2.gpu_sync()
+    noise_v = float(np.abs(ref2.download(ARR.VELOCITIES) - rv).max())
+    noise_F = float(np.abs(ref2.download(ARR.DEFORMATION_GRADIENTS) - rF).max())
+    ref2.destroy()
+
+    geo = strong_geometry(bits, world)
+    assert geo["zone_blocks"] == (1 if world == 8 else 2) and geo["migrate_every"] == 0 and geo["ghost_cells"] == 0
+    roles0, w = _run_world(bits, sheets, geo, steps)
+    dg = w.chains[1].e.dist_geometry()
+    # bands from the mesh: 0.44-cell lattice -> edges of 0.62 cells, reach 0.47; zone 1 leaves (2 - 0.93) / 3 cells of drift
+    assert 0.55 < dg["longest_edge_cells"] < 0.70, dg
+    if world == 8:
+        # (0.125 cells of hysteresis on either side of the vertex band)
+        assert 0.18 < dg["drift_budget_cells"] < 0.32 and dg["vertex_band_cells"] + 0.125 + dg["drift_budget_cells"] <= 2.0 + 1e-5, dg
+    else:
+        assert 1.4 < dg["drift_budget_cells"] < 1.8, dg
+    pos, vel, F, per_rank = _collect(w, roles0, n, nf)
+    vs = max(float(np.abs(rv).max()), 1.0)
+    close(pos, rp, scale=1.0, rtol=1e-5, what=f"world x{world} (vx {vx}): positions vs single engine")
+    # (within 3 x what regrouping the single engine's own work items does, floor 1e-4 as in tests/test_domain_gpu.py)
+    close(vel, rv, scale=vs, rtol=max(1e-4, 3 * noise_v / vs), what=f"world x{world} (vx {vx}): velocities vs single engine")
+    close(F, rF, scale=1.0, rtol=max(1e-4, 3 * noise_F), what=f"world x{world} (vx {vx}): F vs single engine")
+    print(f"world x{world} vx {vx}: regrouping noise v {noise_v:.2e} F {noise_F:.2e}; migrations {w.migrations}; "
+          f"bands {dg}")
+    if vx > 0:
+        # ownership followed the motion: 3.6 cells in 36 substeps, slabs of 8 or 16 cells
+        cell0 = np.minimum((x0[:, 0] * (1 << bits) - 0.5).astype(np.int64), (1 << bits) - 3)
+        start_owner = np.searchsorted(np.array(geo["cuts"][1:-1]) * 4, cell0, side="right")
+        end_owner = np.argmax(np.stack([pr[0] == 1 for pr in per_rank]), axis=0)
+        assert np.count_nonzero(end_owner != start_owner) > n // 50
+        # 0.1 cells per substep against a budget of 0.36 / 1.7 cells, half of it trusted
+        assert (w.migrations >= steps // 3) if world == 8 else (2 <= w.migrations <= steps // 4), w.migrations
+    else:
+        # the benchmark's jitter velocities (0.01 m/s = 0.0013 cells per substep): the estimate allows hundreds of
+        # substeps, the interval doubles from 4 (before substeps 0, 4, 12, 28 ...) -- and the cloth's vibration about the
+        # cuts and band edges stays inside the hysteresis, so no migration moves anything and none forces a re-sort
+        # (6 re-sorts in 25 substeps)
+        assert w.migrations == 3, w.migrations
+        for _, _, _, st in per_rank:
+            assert st["rebuilds"] <= 4, st   # Finalize, the partition, the shrink (+ at most one of the free fall)
+
+
+def test_cloth_crossing_a_cut_grows_the_slot_space():
+    """Most of a cloth slides from rank 0 to rank 1: rank 1's slot space (1.5 x what it held after the
+    partition: a sliver) overflows and is re-allocated at the migration that would overflow it; the run stays equal to a
+    single engine's."""
+    from drake_amd import ARR, GpuMpm, scenes
+    from tests.helpers import close
+    bits, steps = 6, 72
+    sheets = scenes.cloth_stack(2, 40, bits, z0=0.5, side=0.25, seed=5, vel_amp=0.2, center=(0.36, 0.5))
+    for pos, vel, idx in sheets:
+        vel[:, 0] += 3.0      # 0.19 cells per substep: 14 cells over the run; the cloth spans cells 15..31, the cut is at 32
+    ref = _populate(GpuMpm(bits), sheets)
+    ref.run_substeps(steps, DT, -1)
+    ref.gpu_sync()
+    rp, rv = ref.download(ARR.POSITIONS), ref.download(ARR.VELOCITIES)
+    n, nf = ref.n_particles, ref.n_faces
+    geo = dict(cuts=[0, 8, 16], zone_blocks=2, ghost_cells=0, ghost_margin_cells=0, migrate_every=0)
+    roles0, w = _run_world(bits, sheets, geo, steps, capacity_blocks=512, migrate_capacity=8192)
+    held0 = [int(np.count_nonzero(r == 1)) for r in roles0]
+    assert held0[1] < n // 20 and held0[0] > n * 0.9, held0     # it starts on rank 0
+    pos, vel, F, per_rank = _collect(w, roles0, n, nf)
+    held1 = [int(np.count_nonzero(pr[0] == 1)) for pr in per_rank]
+    assert held1[1] > n * 0.7, (held0, held1)                    # ... and ends on rank 1
+    g1 = w.chains[1].e.dist_geometry()
+    assert g1["slot_resizes"] >= 2, g1                           # mpm_dist_init's own + at least one growth
+    st1 = per_rank[1][3]
+    assert st1["face_slots"] >= st1["active_faces"] and st1["vertex_slots"] >= st1["active_vertices"]
+    vs = max(float(np.abs(rv).max()), 1.0)
+    close(pos, rp, scale=1.0, rtol=1e-5, what="cloth across a cut: positions vs single engine")
+    close(vel, rv, scale=vs, rtol=1e-4, what="cloth across a cut: velocities vs single engine")
+
+
+def test_no_shrink_keeps_the_whole_scene_size():
+    """headroom 0: a rank keeps slot space for the whole scene (no re-allocation can ever be needed)."""
+    from drake_amd import GpuMpm, scenes
+    bits = 6
+    sheets = scenes.cloth_stack(2, 40, bits, z0=0.5, side=0.4, seed=7)
+    whole = _populate(GpuMpm(bits), sheets).stats()
+    geo = dict(cuts=[0, 8, 16], zone_blocks=2, ghost_cells=2, ghost_margin_cells=2, migrate_every=4)
+    roles0, w = _run_world(bits, sheets, geo, 6, capacity_blocks=512, migrate_capacity=4096, headroom=0.0)
+    for c in w.chains:
+        st = c.e.stats()
+        assert st["error_flags"] == 0
+        assert st["face_slots"] == whole["face_slots"] and st["vertex_slots"] == whole["vertex_slots"], (st, whole)
