@@ -1658,7 +1658,10 @@ int mpm_dist_init(mpm_handle_t e, const mpm_dist_config_t* cfg) {
     const float zone_room = (float)(4 * cfg->zone_blocks - 2);
     float ghost_w, vert_w, delta, hyst = .125f;
     if (auto_bands) {
-        delta = std::min((zone_room - 2.f * reach - 2.f * hyst) / 3.f, zone_room - 1.f - hyst);
+        // (as much drift as the zone allows, but no more than dist_drift_target: every cell of band is a cell of ghost
+        // particles that FEM and GridToParticle advance with every substep -- with slabs of 16 cells the widest bands
+        // of a two-block zone, 3.8 / 4.3 cells, are half as many ghosts as owned particles)
+        delta = std::min({(zone_room - 2.f * reach - 2.f * hyst) / 3.f, zone_room - 1.f - hyst, e->dist_drift_target});
         REQUIRE(delta > .05f, "mpm_dist_init: the exchanged zone is too shallow for this mesh (4 zone_blocks - 2 must exceed 1.5 x "
                               "the longest mesh edge in cells): use more zone_blocks or a finer mesh");
         ghost_w = reach + 2.f * delta + hyst;

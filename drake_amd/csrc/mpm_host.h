@@ -129,6 +129,9 @@ struct mpm_engine {
     // slot space of a partitioned rank = headroom x what it holds (mpm_dist_set_headroom, MPM_DIST_HEADROOM; 0 = the whole
     // scene's size, no shrink); grown at the migration that would overflow it (dist_resize)
     float dist_headroom = getenv("MPM_DIST_HEADROOM") ? std::max(0.f, (float)atof(getenv("MPM_DIST_HEADROOM"))) : 1.5f;
+    // bands from the mesh: the drift (cells along x) between two migrations that the ghost bands are sized for, if the
+    // zone allows that much (MPM_DIST_DRIFT).  Wider bands: fewer migrations, more ghost particles to advance.
+    float dist_drift_target = getenv("MPM_DIST_DRIFT") ? std::max(.06f, (float)atof(getenv("MPM_DIST_DRIFT"))) : .5f;
     float dist_longest_edge = 0.f;        // cells, from the mesh handed to AddQRCloth
     // share of the ranks' common quiet-time estimate after which they migrate again (the estimate is ballistic, elastic
     // forces are not in it); MPM_MIG_SAFETY

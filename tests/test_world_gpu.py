@@ -119,7 +119,8 @@ def test_bench_partition_geometry_matches_single_engine(world, vx, steps):
         # (0.125 cells of hysteresis on either side of the vertex band)
         assert 0.18 < dg["drift_budget_cells"] < 0.32 and dg["vertex_band_cells"] + 0.125 + dg["drift_budget_cells"] <= 2.0 + 1e-5, dg
     else:
-        assert 1.4 < dg["drift_budget_cells"] < 1.8, dg
+        # (the zone of two blocks would allow 1.6 cells; the bands are sized for MPM_DIST_DRIFT = 0.5 by default)
+        assert abs(dg["drift_budget_cells"] - 0.5) < 1e-5 and dg["vertex_band_cells"] < 2.3, dg
     pos, vel, F, per_rank = _collect(w, roles0, n, nf)
     vs = max(float(np.abs(rv).max()), 1.0)
     close(pos, rp, scale=1.0, rtol=1e-5, what=f"world x{world} (vx {vx}): positions vs single engine")
@@ -134,8 +135,8 @@ def test_bench_partition_geometry_matches_single_engine(world, vx, steps):
         start_owner = np.searchsorted(np.array(geo["cuts"][1:-1]) * 4, cell0, side="right")
         end_owner = np.argmax(np.stack([pr[0] == 1 for pr in per_rank]), axis=0)
         assert np.count_nonzero(end_owner != start_owner) > n // 50
-        # 0.1 cells per substep against a budget of 0.36 / 1.7 cells, half of it trusted
-        assert (w.migrations >= steps // 3) if world == 8 else (2 <= w.migrations <= steps // 4), w.migrations
+        # 0.1 cells per substep (more where the jittered lattice relaxes) against a budget of 0.24 / 0.5 cells, half of it trusted
+        assert w.migrations >= steps // 3, w.migrations
     else:
         # the benchmark's jitter velocities (0.01 m/s = 0.0013 cells per substep): the estimate allows hundreds of
         # substeps, the interval doubles from 4 (before substeps 0, 4, 12, 28 ...) -- and the cloth's vibration about the
