@@ -386,7 +386,9 @@ static int update_contact(mpm_engine* e, int frame, int substep, float dt, float
             return fail(MPM_ERR_HIP, "contact sort failed");
     }
     hipLaunchKernelGGL(k_ct_prepare, dim3(gc), dim3(256), 0, s, p, c);
-    const bool dist = p.dist.on && p.dist.world > 1;
+    // (MPM_CT_FORCE_DIST=1, tests: a partitioned engine of ONE rank takes the distributed paths too -- split direction
+    // kernels, sums through the all-reduce -- so that they can run on a box with one GPU)
+    const bool dist = p.dist.on && (p.dist.world > 1 || e->ct_force_dist);
     if (dist) {
         // a node in a zone may be reached by the neighbour's contacts only: both ranks need it listed
         hipLaunchKernelGGL(k_ct_flags_to_field, dim3(512), dim3(256), 0, s, p, c, 0);
@@ -459,18 +461,35 @@ static int update_contact(mpm_engine* e, int frame, int substep, float dt, float
         if (!eager) hipLaunchKernelGGL(k_ct_apply, dim3(CT_ROWS), dim3(CT_WG), 0, s, p, c, 2);
         iters = st.iters;
         residual = st.residual;
-    } else if (!dist) {
+    } else if (!dist || (e->chain.comm && rccl_rt::api()->all_reduce)) {
         // Exact line search, device resident: a fixed pattern of launches per Newton iteration --
         // direction, PROBES x (energies at st->alpha_probe, one-thread state machine = root finder of
         // mpm_rootfind.h), apply, close -- whose kernels skip themselves according to the state: a search
         // that needs more probes continues in the next pattern (direction skipped), patterns after
         // convergence are idle.  One read-back per batch instead of one per probe.
+        // Partitioned domain with the native chain: the same pattern; the sums of a probe go through ncclAllReduce ON
+        // THE ENGINE'S STREAM between the two halves of the decision (k_ct_decide phase 1: this rank's sums; phase 2:
+        // the state machine, on the global sums -- identical on every rank, so all ranks walk the same states and
+        // every collective of the pattern is entered by all of them), the direction through the zone exchange.  No
+        // host loop per probe: the root finder is inherently sequential (every probe is placed by the one before), so
+        // one all-reduce per probe is the floor; what goes is the host round trip around each of them.
         const int PROBES = 6;
+        int rc_pattern = 0;
         auto pattern = [&](int index) {
-            launch_dir(index == 0, 0);
+            if (!dist) {
+                launch_dir(index == 0, 0);
+            } else if (int rc = newton_direction(index == 0)) {
+                rc_pattern = rc;
+            }
             for (int k = 0; k < PROBES; ++k) {
                 hipLaunchKernelGGL(k_ct_ls, dim3(n_con_wg + n_grid_wg), dim3(CT_WG), 0, s, p, c, n_con_wg, 2, 0.f);
-                hipLaunchKernelGGL(k_ct_decide, dim3(1), dim3(1024), 0, s, c, n_dir_wg, n_con_wg, n_grid_wg, 2, 0);
+                if (!dist) {
+                    hipLaunchKernelGGL(k_ct_decide, dim3(1), dim3(1024), 0, s, c, n_dir_wg, n_con_wg, n_grid_wg, 2, 0);
+                } else {
+                    hipLaunchKernelGGL(k_ct_decide, dim3(1), dim3(1024), 0, s, c, n_dir_wg, n_con_wg, n_grid_wg, 2, 1);
+                    if (int rc = dist_allreduce(e, b.st->red, 32)) rc_pattern = rc;
+                    hipLaunchKernelGGL(k_ct_decide, dim3(1), dim3(1024), 0, s, c, n_dir_wg, n_con_wg, n_grid_wg, 2, 2);
+                }
             }
             hipLaunchKernelGGL(k_ct_apply, dim3(CT_ROWS), dim3(CT_WG), 0, s, p, c, 1);
             hipLaunchKernelGGL(k_ct_exact_finish, dim3(1), dim3(64), 0, s, c);
@@ -481,6 +500,7 @@ static int update_contact(mpm_engine* e, int frame, int substep, float dt, float
         if (int rc = run_batches(e, pattern, ct_batch(e, 0, 1), ct_batch(e, 1, 1), max_iters, &st,
                                  (200 / PROBES + 2) * max_iters + 64))
             return rc;
+        if (rc_pattern) return rc_pattern;
         iters = st.iters;
         residual = st.residual;
         s_alpha_last = st.alpha;
@@ -496,8 +516,9 @@ static int update_contact(mpm_engine* e, int frame, int substep, float dt, float
             }
         }
     } else {
-        // exact line search: Newton with bisection fallback on dE/dalpha, driven from the host
-        // exactly like cuda_mpm_solver.cu:383-471 (itself a clone of Drake's
+        // exact line search on a partitioned domain whose transport is a pair of host callbacks
+        // (mpm_dist_set_transport): every all-reduce is a host round trip anyway, so the search is driven from the
+        // host, probe by probe, exactly like cuda_mpm_solver.cu:383-471 (itself a clone of Drake's
         // DoNewtonWithBisectionFallback)
         auto probe = [&](float alpha, std::tuple<float, float, float>* out) -> int {
             hipLaunchKernelGGL(k_ct_ls, dim3(n_con_wg + n_grid_wg), dim3(CT_WG), 0, s, p, c, n_con_wg, 1, alpha);

@@ -164,6 +164,7 @@ struct mpm_engine {
     // MPM_CT_BATCH="first,next": Newton iterations enqueued per batch of the contact solve (measurements)
     int ct_batch[2] = {0, 0};
     bool ct_debug = getenv("MPM_CT_DEBUG") != nullptr;
+    bool ct_force_dist = getenv("MPM_CT_FORCE_DIST") != nullptr;   // (tests, see update_contact)
     mpm_engine() {
         if (const char* t = getenv("MPM_CT_BATCH")) sscanf(t, "%d,%d", &ct_batch[0], &ct_batch[1]);
     }

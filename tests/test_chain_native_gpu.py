@@ -57,3 +57,56 @@ def test_ring_of_one_equals_device_copies():
     np.testing.assert_allclose(v_nat, v_ref, rtol=0, atol=2e-6)
     np.testing.assert_allclose(g.download(ARR.POSITIONS), ref.download(ARR.POSITIONS), rtol=0, atol=1e-7)
     g.chain_destroy()
+
+
+def test_partitioned_exact_line_search_is_device_resident_over_rccl(monkeypatch):
+    """UpdateContact with the exact line search on a partitioned engine whose transport is the native chain (VERDICT r3,
+    item 7): the device-resident pattern of the single-GPU solve, with ncclAllReduce on the engine's stream between the two
+    halves of every decision and the zone exchange inside the direction -- no host loop per probe.  One GPU is all the box
+    has and RCCL refuses two ranks on one device, so the partition has ONE rank (MPM_CT_FORCE_DIST: it takes the
+    distributed paths all the same -- split direction kernels, sums through the all-reduce); the result must be the
+    single engine's."""
+    from drake_amd import ARR, Collider, GpuMpm, scenes
+    floor_z = 0.5
+
+    def engine(partitioned):
+        if partitioned:
+            monkeypatch.setenv("MPM_CT_FORCE_DIST", "1")
+        else:
+            monkeypatch.delenv("MPM_CT_FORCE_DIST", raising=False)
+        g = GpuMpm(BITS)
+        g.set_deterministic(True)
+        sheets = scenes.cloth_stack(2, 36, BITS, z0=floor_z - 0.004, side=0.4, seed=33, vel_amp=0.3)
+        for pos, vel, idx in sheets:
+            vel[:, 2] -= 0.5
+        scenes.populate(g, sheets)
+        if partitioned:
+            nb = (1 << BITS) // 4
+            g.dist_init(0, 1, [0, nb], 2, 2, 2)
+            g.chain_init(GpuMpm.chain_unique_id(), 0, 1, 0, nb, 0, 2, 256)
+        return g
+
+    out = []
+    for partitioned in (False, True):
+        g = engine(partitioned)
+        res = []
+        for _ in range(3):
+            g.reallocate_external_bodies(1)
+            g.rebuild_mapping(False)
+            g.calc_fem_state_and_force(DT)
+            g.particle_to_grid(DT)
+            g.update_grid(-1)
+            n = g.generate_contact_pairs([Collider(0, body=0, p_WB=(0.5, 0.5, floor_z))])
+            r = g.update_contact(DT, 0.5, 1e5, 1e-3, exact_line_search=True)
+            res.append((n, r["iterations"], g.contact_stats()["line_search_evals"]))
+            g.grid_to_particle(DT)
+        g.gpu_sync()
+        assert g.stats()["error_flags"] == 0
+        out.append((res, g.download(ARR.VELOCITIES), g.download(ARR.POSITIONS)))
+        if partitioned:
+            g.chain_destroy()
+    (res_a, v_a, x_a), (res_b, v_b, x_b) = out
+    assert all(n > 20 and it >= 2 for n, it, _ in res_a), res_a
+    assert res_a == res_b, (res_a, res_b)     # same contacts, Newton iterations and probes
+    np.testing.assert_allclose(v_b, v_a, rtol=0, atol=2e-6)
+    np.testing.assert_allclose(x_b, x_a, rtol=0, atol=1e-7)

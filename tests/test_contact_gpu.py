@@ -238,8 +238,8 @@ def test_single_newton_iteration_matches_oracle(exact, params, mu, scene):
     close(f_g, o.F_f, scale=float(np.abs(o.F_f).max()), rtol=10 * rt, what="1-iteration body impulse")
 
 
-@pytest.mark.parametrize("exact", [False, True])
-def test_five_newton_iterations_match_oracle(exact):
+@pytest.mark.parametrize("exact,iters", [(False, 5), (True, 5)])
+def test_five_newton_iterations_match_oracle(exact, iters):
     """max_newton_iterations = 5 on both sides, config-3 parameters, the dense scene: the
     solver's stopping tolerance still plays no role, but unlike the single iteration this goes through the lazy update
     (k_ct_tile reading v - alpha D, k_ct_node_dir writing it back), the batched / pipelined loop and, for the exact
@@ -261,31 +261,81 @@ def test_five_newton_iterations_match_oracle(exact):
     assert cp[0].size > 5000
     o.copy_contact_pairs(orc.ContactPairs(*cp))
     g.copy_contact_pairs(*cp)
-    ro = o.update_contact(DT, 1.0, stiffness, damping, exact_line_search=exact, max_iters=5)
-    rg = g.update_contact(DT, 1.0, stiffness, damping, exact_line_search=exact, max_newton_iterations=5)
+    ro = o.update_contact(DT, 1.0, stiffness, damping, exact_line_search=exact, max_iters=iters)
+    rg = g.update_contact(DT, 1.0, stiffness, damping, exact_line_search=exact, max_newton_iterations=iters)
     cs = g.contact_stats()
-    assert ro["iterations"] == rg["iterations"] == cs["iterations"] == 5
+    assert ro["iterations"] == rg["iterations"] == cs["iterations"] == iters
     # Backtracking: 1e-4 (measured 2e-6 .. 7e-6 per iteration: the two paths do not drift apart).  Exact search: the
     # root finder works on dE/dalpha, a float sum that is noise below ~1e-6 of its terms; with x_tol = 3e-9 it ends
     # after its 200 evaluations (or earlier, when the noise happens to cross |f'| < 1e-8) wherever the noise leaves it
     # -- on BOTH sides, cuda_mpm_solver.cu:383-471 -- so alpha agrees to ~5e-5 and five iterations compound to ~3e-4
     rt = 1e-3 if exact else 1e-4
-    close(g.download(A.GRID_DIR), o.g_D, rtol=rt, what="5-iteration Dir")
+    close(g.download(A.GRID_DIR), o.g_D, rtol=rt, what=f"{iters}-iteration Dir")
     assert cs["dofs"] == ro["dofs"] > 0
-    close([cs["norm_dir_sq"]], [ro["norm_dir_sq"]], rtol=rt, what="5-iteration |Dir|^2")
-    close([rg["residual"]], [ro["residual"]], rtol=rt, what="5-iteration residual")
-    close([cs["E0"]], [ro["E0"]], rtol=rt, what="5-iteration E(0)")
-    close([cs["energy"]], [ro["E1"]], scale=abs(ro["E0"]), rtol=rt, what="5-iteration E(alpha)")
+    close([cs["norm_dir_sq"]], [ro["norm_dir_sq"]], rtol=rt, what=f"{iters}-iteration |Dir|^2")
+    close([rg["residual"]], [ro["residual"]], rtol=rt, what=f"{iters}-iteration residual")
+    close([cs["E0"]], [ro["E0"]], rtol=rt, what=f"{iters}-iteration E(0)")
+    close([cs["energy"]], [ro["E1"]], scale=abs(ro["E0"]), rtol=rt, what=f"{iters}-iteration E(alpha)")
     if exact:
-        close([cs["alpha"]], [ro["alpha"]], scale=1.0, rtol=2e-4, what="5-iteration alpha (exact search)")
+        close([cs["alpha"]], [ro["alpha"]], scale=1.0, rtol=2e-4, what=f"{iters}-iteration alpha (exact search)")
     else:
         assert cs["alpha"] == ro["alpha"]
     sc = natural_scales(o, DT)
     wgt = (o.g_m / o.g_m.max())[:, None]
-    close(g.download(A.GRID_MOMENTUM) * wgt, o.g_mv * wgt, scale=sc["vel"], rtol=rt, what="5-iteration grid v")
-    close(g.download(A.CONTACT_VEL), o.c_vel, scale=sc["vel"], rtol=rt, what="5-iteration contact vel")
+    close(g.download(A.GRID_MOMENTUM) * wgt, o.g_mv * wgt, scale=sc["vel"], rtol=rt, what=f"{iters}-iteration grid v")
+    close(g.download(A.CONTACT_VEL), o.c_vel, scale=sc["vel"], rtol=rt, what=f"{iters}-iteration contact vel")
     tau_g, f_g = g.external_body_force_to_host()
-    close(f_g, o.F_f, scale=float(np.abs(o.F_f).max()), rtol=10 * rt, what="5-iteration body impulse")
+    close(f_g, o.F_f, scale=float(np.abs(o.F_f).max()), rtol=10 * rt, what=f"{iters}-iteration body impulse")
+
+
+def test_twenty_newton_iterations_against_the_float_noise_of_the_iteration():
+    """VERDICT r3, item 6 asked for the 5-iteration test at 20 iterations with the same tolerances.  Measured
+    (scratch/ct20.py, this scene): the relaxed Jacobi iteration with config 3's stiffness is not contractive over these
+    iterations -- a perturbation of the direction field grows about threefold per iteration (engine vs float oracle:
+    3.6e-6 after 5 iterations, 1e-4 after 7, 1e-3 after 10, 2e-1 after 16) while every DECISION stays the same (step
+    lengths, residuals to three digits).  That is the iteration, not an implementation: the float and the double build of
+    the ORACLE part ways at the same rate.  So at 20 iterations the yardstick is that distance: the engine must sit as
+    close to the float oracle as the double oracle does (factor 3), and take the same decisions."""
+    from drake_amd import ARR as A
+    from oracle import oracle as orc
+    from tests.helpers import oracle_copy
+    stiffness, damping, DT = CONTACT_PARAMS["config3"]
+    iters = 20
+    o, g = build_pair(layers=4, res=40, side=0.15, z0=Z_FLOOR - 0.02, vel_amp=0.3)
+    o.vel[:, 2] -= 0.5
+    o.vel[:, 0] += 0.3
+    g.upload_particle_state(o.pos, o.vel, o.C, None, o.F)
+    for s in (o, g):
+        s.reallocate_external_bodies(1)
+        s.rebuild_mapping(False)
+        s.calc_fem_state_and_force(DT)
+        s.particle_to_grid(DT)
+        s.update_grid(-1)
+    cp = floor_contacts(g.sync_particle_state_to_cpu())
+    o64 = oracle_copy(o, np.float64)
+    for s in (o, o64):
+        s.copy_contact_pairs(orc.ContactPairs(*cp))
+    g.copy_contact_pairs(*cp)
+    ro = o.update_contact(DT, 1.0, stiffness, damping, max_iters=iters)
+    r64 = o64.update_contact(DT, 1.0, stiffness, damping, max_iters=iters)
+    rg = g.update_contact(DT, 1.0, stiffness, damping, max_newton_iterations=iters)
+    cs = g.contact_stats()
+    assert ro["iterations"] == rg["iterations"] == r64["iterations"] == iters
+    # the same decisions: last step length, residual and energies to the digits the three share
+    assert cs["alpha"] == ro["alpha"]
+    # (scratch/ct20.py: residuals 0.02959 / 0.02968, energies -3.49211 / -3.49208 for oracle / engine)
+    close([rg["residual"]], [ro["residual"]], rtol=6e-2, what="20-iteration residual")
+    close([cs["energy"]], [ro["E1"]], rtol=2e-3, what="20-iteration E(alpha)")
+    wgt = (o.g_m / o.g_m.max())[:, None]
+    scale_D = float(np.abs(o.g_D).max())
+    noise_D = float(np.abs(o64.g_D - o.g_D).max())
+    noise_v = float(np.abs((o64.g_mv - o.g_mv) * wgt).max())
+    err_D = float(np.abs(g.download(A.GRID_DIR) - o.g_D).max())
+    err_v = float(np.abs((g.download(A.GRID_MOMENTUM) - o.g_mv) * wgt).max())
+    print(f"20 iterations: |Dir| {scale_D:.3g}; float oracle vs double oracle: Dir {noise_D:.2e}, grid v {noise_v:.2e}; "
+          f"engine vs float oracle: Dir {err_D:.2e}, grid v {err_v:.2e}")
+    assert noise_D > 1e-3 * scale_D          # (the premise: rounding alone has grown this far)
+    assert err_D <= 3.0 * noise_D and err_v <= 3.0 * noise_v, (err_D, noise_D, err_v, noise_v)
 
 
 def test_config3_full_size_against_the_oracle():
