@@ -308,6 +308,19 @@ MPM_DEV unsigned tile_reach_mask(int rx, int ry, int rz) {
 #ifndef MPM_P2G_WAVES
 #define MPM_P2G_WAVES 8
 #endif
+#ifndef MPM_P2G_DESC_AHEAD
+#define MPM_P2G_DESC_AHEAD 0   // 1 (experiment, no effect measured): the group descriptor alone fetched a group ahead
+#endif
+#ifndef MPM_P2G_PIPE2
+#define MPM_P2G_PIPE2 0      // 1 (experiment): MFMA operands fetched two steps ahead in two named register sets
+#endif
+#ifndef MPM_P2G_PREFETCH
+// 0 (what ships since round 4): a group's records are loaded when its turn comes.  Rounds 1-3 fetched them one group
+// ahead; with four waves per SIMD the other waves cover the two round trips anyway, and the 25 registers the prefetched
+// records occupied through the contraction cost more than the wait: 128 VGPRs + 12 bytes of scratch -> 103, none;
+// k_p2g 51.6 -> 49.4 us (event time), 20-substep window 105.0 -> 101.5 us (same-box A/B, scratch/ab_run.py).
+#define MPM_P2G_PREFETCH 0
+#endif
 constexpr int P2G_WAVES = MPM_P2G_WAVES, P2G_THREADS = 64 * P2G_WAVES;
 // two workgroups per CU: 8 waves each at <= 128 VGPRs (4 per SIMD), or 10 at <= 96 (5 per SIMD; -DMPM_P2G_WAVES=10)
 __global__ __launch_bounds__(P2G_THREADS) __attribute__((amdgpu_waves_per_eu(P2G_WAVES / 2, P2G_WAVES / 2))) void k_p2g(DP p, float dt) {
@@ -479,16 +492,27 @@ __global__ __launch_bounds__(P2G_THREADS) __attribute__((amdgpu_waves_per_eu(P2G
         unsigned mymask = 0;
         bool halo_bad = false;
         unsigned out_worst = 0, fix_worst = 0;   // error conditions, collected as integers in vector registers
-        if (wv < ngroups) {
+        if (MPM_P2G_PREFETCH && wv < ngroups) {
             cur = load_raw(desc_of(wv));
             gd_next = desc_of(wv + P2G_WAVES);
         }
+        // (without the record prefetch only the group DESCRIPTOR is fetched a group ahead: four registers, and the
+        // records' loads no longer wait for a dependent round trip)
+        if (!MPM_P2G_PREFETCH && MPM_P2G_DESC_AHEAD && wv < ngroups) gd_next = desc_of(wv);
         const bool prof = (diag_flags(p) & 4) != 0 && wv == 0;
         unsigned long long tq[3] = {0, 0, 0}, pc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         if (prof && lane == 0) atomicAdd(&p.dbgbuf[14], (unsigned long long)__builtin_readcyclecounter() - tb0);   // prologue
         for (int g = wv; g < ngroups; g += P2G_WAVES) {
             // ---- 1. one particle per lane (its raw state was prefetched) ----------
             if (prof) tq[0] = __builtin_readcyclecounter();
+            if (!MPM_P2G_PREFETCH) {
+                if (MPM_P2G_DESC_AHEAD) {
+                    cur = load_raw(gd_next);
+                    gd_next = desc_of(g + P2G_WAVES);
+                } else {
+                    cur = load_raw(desc_of(g));
+                }
+            }
             const bool act = cur.act, is_face = cur.is_face;
             const Stencil st = make_stencil(p, cur.x[0], cur.x[1], cur.x[2], ox, oy, oz);
             // partitioned domain: a ghost copy (vol < 0) scatters nothing, its owner does
@@ -534,7 +558,7 @@ __global__ __launch_bounds__(P2G_THREADS) __attribute__((amdgpu_waves_per_eu(P2G
             }
             // the raw registers are dead now: start the next group's loads, they complete while this
             // group goes through the LDS / matrix-pipe phases below (which never wait on vmcnt)
-            if (g + P2G_WAVES < ngroups) {
+            if (MPM_P2G_PREFETCH && g + P2G_WAVES < ngroups) {
                 cur = load_raw(gd_next);
                 gd_next = desc_of(g + 2 * P2G_WAVES);
             }
@@ -580,6 +604,49 @@ __global__ __launch_bounds__(P2G_THREADS) __attribute__((amdgpu_waves_per_eu(P2G
             // ---- 4. per-cell contraction on the matrix pipe ----------------------
             unsigned long long todo = actmask;
             int s0 = 0;
+#if MPM_P2G_PIPE2
+            // Operands two steps deep: set A feeds step s, set B step s + 4; A is re-loaded (for s + 8) while B's step
+            // computes and the other way round, so every LDS read has a whole step of arithmetic to arrive in.  The
+            // two sets are named, not rotated: no moves.  Rows beyond the staged ones are clamped to the last row
+            // (they are masked in the B operand anyway).
+            float afx, afy, afz, ay, bfx, bfy, bfz, by;
+            auto ld = [&](int row, float& fx_, float& fy_, float& fz_, float& y_) {
+                const float* sn = stage + min(row + g4, 64 + 8 - 1) * STG;
+                fx_ = sn[STG_FX]; fy_ = sn[STG_FX + 1]; fz_ = sn[STG_FX + 2]; y_ = sn[j16];
+            };
+            ld(0, afx, afy, afz, ay);
+            ld(4, bfx, bfy, bfz, by);
+            if (prof) tq[1] = __builtin_readcyclecounter();
+            __builtin_amdgcn_s_setprio(2);
+            while (todo) {
+                const int ckey = __builtin_amdgcn_readlane(key, __builtin_ctzll(todo));
+                const unsigned long long same = __ballot(key == ckey) & todo;
+                todo &= ~same;
+                const int s1 = s0 + (int)__popcll(same);
+                f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+                if (prof) { pc[4] += 1; pc[5] += (unsigned)((s1 - s0 + 3) >> 2); tq[2] = __builtin_readcyclecounter(); }
+                auto step = [&](int s, float fx, float fy, float fz, float y) {
+                    const bool ok = s + g4 < s1;
+                    const f32x2 fx2 = {fx, fx}, fy2 = {fy, fy}, fz2 = {fz, fz};
+                    const f32x2 w01 = __builtin_elementwise_fma(__builtin_elementwise_fma(cx2, fx2, cx1), fx2, cx0) *
+                                      __builtin_elementwise_fma(__builtin_elementwise_fma(cy2, fy2, cy1), fy2, cy0) *
+                                      __builtin_elementwise_fma(__builtin_elementwise_fma(cz2, fz2, cz1), fz2, cz0);
+                    if (!ok) y = 0.f;
+                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(w01.x, y, acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(w01.y, y, acc1, 0, 0, 0);
+                };
+                for (int s = s0; s < s1; s += 8) {
+                    step(s, afx, afy, afz, ay);
+                    if (s + 8 < s1) ld(s + 8, afx, afy, afz, ay);
+                    if (s + 4 < s1) {
+                        step(s + 4, bfx, bfy, bfz, by);
+                        if (s + 12 < s1) ld(s + 12, bfx, bfy, bfz, by);
+                    }
+                }
+                // the next cell starts at s1: its first two steps' operands arrive during this cell's epilogue
+                ld(s1, afx, afy, afz, ay);
+                ld(s1 + 4, bfx, bfy, bfz, by);
+#else
             float nfx, nfy, nfz, ny;
             {
                 const float* sn = stage + g4 * STG;
@@ -626,6 +693,7 @@ __global__ __launch_bounds__(P2G_THREADS) __attribute__((amdgpu_waves_per_eu(P2G
                     const float* sn = stage + (s1 + g4) * STG;
                     nfx = sn[STG_FX]; nfy = sn[STG_FX + 1]; nfz = sn[STG_FX + 2]; ny = sn[j16];
                 }
+#endif
                 if (prof) { asm volatile("" :: "v"(acc0), "v"(acc1)); const unsigned long long tm = __builtin_readcyclecounter(); pc[2] += tm - tq[2]; tq[2] = tm; }
                 s0 = s1;
                 // rows = nodes, columns = (component d, term tt): fold the 4 terms of each component

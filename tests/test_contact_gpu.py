@@ -410,6 +410,7 @@ def test_backtracking_beyond_the_first_candidates_matches_oracle(monkeypatch):
     from drake_amd import ARR as A
     from oracle import oracle as orc
     stiffness, damping, DT = CONTACT_PARAMS["soft"]
+    monkeypatch.setenv("MPM_CT_RELAX", "40")   # (read per handle, when the engine is created)
     o, g = build_pair(layers=2, res=24, z0=Z_FLOOR - 0.004, vel_amp=0.3)
     o.vel[:, 2] -= 0.5
     g.upload_particle_state(o.pos, o.vel, o.C, None, o.F)
@@ -422,7 +423,6 @@ def test_backtracking_beyond_the_first_candidates_matches_oracle(monkeypatch):
     cp = floor_contacts(g.sync_particle_state_to_cpu())
     o.copy_contact_pairs(orc.ContactPairs(*cp))
     g.copy_contact_pairs(*cp)
-    monkeypatch.setenv("MPM_CT_RELAX", "40")
     o.set_contact_relax(40.0)
     try:
         ro = o.update_contact(DT, 0.5, stiffness, damping, exact_line_search=False, max_iters=1)
