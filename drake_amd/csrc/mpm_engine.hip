@@ -1138,22 +1138,42 @@ int mpm_chain_substeps(mpm_handle_t e, int n, float dt, int bc) {
             else due = !(c.mig_elapsed + dt <= c.mig_budget);
         }
         if (due) {
-            // particles change hands (mpm_dist.h): records to / from both neighbours, same pairing as below
+            // particles change hands (mpm_dist.h): records to / from both neighbours, same pairing as below.  In two
+            // rounds: the 16-byte headers first (record counts), then exactly the records that exist -- a RCCL
+            // send needs its size when it is enqueued, and the buffers are sized for the worst case (9 MB for 65536
+            // records) while a migration of a cloth at rest moves none.  The host reads the counts in between; a
+            // migration is a synchronisation point anyway (mpm_dist_migrate_apply).
             if (int rc = mpm_dist_migrate_pack(e, c.mig_send_l, c.mig_send_r, c.mig_cap)) return rc;
-            RCCL_TRY(a->group_start());
-            int rc_g = 0;
-            if (!rc_g && c.left >= 0) rc_g = a->send(c.mig_send_l, c.mig_bytes, 0, c.left, c.comm, e->stream);
-            if (!rc_g && c.right >= 0) rc_g = a->send(c.mig_send_r, c.mig_bytes, 0, c.right, c.comm, e->stream);
-            if (!rc_g && c.right >= 0) rc_g = a->recv(c.mig_recv_r, c.mig_bytes, 0, c.right, c.comm, e->stream);
-            if (!rc_g && c.left >= 0) rc_g = a->recv(c.mig_recv_l, c.mig_bytes, 0, c.left, c.comm, e->stream);
-            const int rc_e = a->group_end();   // (always closes the group, also after a failed call)
-            RCCL_TRY(rc_g);
-            RCCL_TRY(rc_e);
+            auto exchange = [&](size_t out_l, size_t out_r, size_t in_l, size_t in_r, size_t offset) -> int {
+                RCCL_TRY(a->group_start());
+                int rc_g = 0;
+                if (!rc_g && c.left >= 0 && out_l) rc_g = a->send((char*)c.mig_send_l + offset, out_l, 0, c.left, c.comm, e->stream);
+                if (!rc_g && c.right >= 0 && out_r) rc_g = a->send((char*)c.mig_send_r + offset, out_r, 0, c.right, c.comm, e->stream);
+                if (!rc_g && c.right >= 0 && in_r) rc_g = a->recv((char*)c.mig_recv_r + offset, in_r, 0, c.right, c.comm, e->stream);
+                if (!rc_g && c.left >= 0 && in_l) rc_g = a->recv((char*)c.mig_recv_l + offset, in_l, 0, c.left, c.comm, e->stream);
+                const int rc_e = a->group_end();   // (always closes the group, also after a failed call)
+                RCCL_TRY(rc_g);
+                RCCL_TRY(rc_e);
+                return 0;
+            };
+            if (int rc = exchange(16, 16, 16, 16, 0)) return rc;
             if (c.mig_every == 0) {
-                // the ranks agree on the smallest estimate (one float, ncclMin), read back at the synchronisation
-                // point that mpm_dist_migrate_apply is anyway
+                // the ranks agree on the smallest estimate (one float, ncclMin), read back with the headers
                 RCCL_TRY(a->all_reduce(&e->dp.ctl->mig_quiet, c.mig_quiet_all, 1, 7 /* ncclFloat32 */, 3 /* ncclMin */, c.comm,
                                        e->stream));
+            }
+            {
+                uint32_t h[4][4] = {};
+                void* bufs[4] = {c.mig_send_l, c.mig_send_r, c.mig_recv_l, c.mig_recv_r};
+                for (int k = 0; k < 4; ++k) HIP_TRY(hipMemcpyAsync(h[k], bufs[k], 16, hipMemcpyDeviceToHost, e->stream));
+                HIP_TRY(hipStreamSynchronize(e->stream));
+                auto bytes = [&](int k, bool there) {
+                    return there ? (size_t)std::min<size_t>(h[k][0], c.mig_cap) * DIST_REC_F4 * 16 : (size_t)0;
+                };
+                // (a ring of one or two ranks pairs the k-th send with the k-th receive: what goes left arrives "from the
+                // right" over there -- the received headers say how much comes from each side)
+                if (int rc = exchange(bytes(0, c.left >= 0), bytes(1, c.right >= 0), bytes(2, c.left >= 0), bytes(3, c.right >= 0), 16))
+                    return rc;
             }
             if (int rc = mpm_dist_migrate_apply(e, c.left >= 0 ? c.mig_recv_l : nullptr, c.right >= 0 ? c.mig_recv_r : nullptr,
                                                 c.mig_cap))

@@ -308,6 +308,9 @@ MPM_DEV unsigned tile_reach_mask(int rx, int ry, int rz) {
 #ifndef MPM_P2G_WAVES
 #define MPM_P2G_WAVES 8
 #endif
+#ifndef MPM_P2G_DYNAMIC
+#define MPM_P2G_DYNAMIC 0   // 1 (experiment): the waves of a workgroup take the item's groups from an LDS counter
+#endif
 #ifndef MPM_P2G_DESC_AHEAD
 #define MPM_P2G_DESC_AHEAD 0   // 1 (experiment, no effect measured): the group descriptor alone fetched a group ahead
 #endif
@@ -331,6 +334,9 @@ __global__ __launch_bounds__(P2G_THREADS) __attribute__((amdgpu_waves_per_eu(P2G
     // wave-private staging: 64 particles (+8 slack rows touched by the operand prefetch)
     __shared__ __attribute__((aligned(16))) float stage_all[P2G_WAVES][(64 + 8) * STG];
     __shared__ unsigned s_mask;
+#if MPM_P2G_DYNAMIC
+    __shared__ int s_next;   // next unclaimed group of the item (waves take groups as they finish, not round robin)
+#endif
 #if MPM_P2G_LDSF
     __shared__ float s_frc[LDSF_CAP * 3];
     static_assert(sizeof(long long) * TILE_N * 4 + sizeof(float) * P2G_WAVES * (64 + 8) * STG + sizeof(float) * LDSF_CAP * 3 + 4 <= 81920,
@@ -397,6 +403,9 @@ __global__ __launch_bounds__(P2G_THREADS) __attribute__((amdgpu_waves_per_eu(P2G
         const unsigned long long tb0 = (diag_flags(p) & 4) ? __builtin_readcyclecounter() : 0ull;
         for (int n = tid; n < TILE_N * 4; n += P2G_THREADS) tile[n] = 0;
         if (tid == 0) s_mask = 0;
+#if MPM_P2G_DYNAMIC
+        if (tid == 0) s_next = P2G_WAVES;
+#endif
         int bx, by, bz;
         block_coords((uint32_t)fa.z, bx, by, bz);
         const int ox = bx * 4 - FREE_ZONE, oy = by * 4 - FREE_ZONE, oz = bz * 4 - FREE_ZONE;
@@ -502,7 +511,17 @@ __global__ __launch_bounds__(P2G_THREADS) __attribute__((amdgpu_waves_per_eu(P2G
         const bool prof = (diag_flags(p) & 4) != 0 && wv == 0;
         unsigned long long tq[3] = {0, 0, 0}, pc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         if (prof && lane == 0) atomicAdd(&p.dbgbuf[14], (unsigned long long)__builtin_readcyclecounter() - tb0);   // prologue
+#if MPM_P2G_DYNAMIC
+        static_assert(!MPM_P2G_PREFETCH, "dynamic group assignment has no place for a prefetched group");
+        auto next_group = [&]() {
+            int n = 0;
+            if (lane == 0) n = atomicAdd(&s_next, 1);
+            return __builtin_amdgcn_readfirstlane(n);
+        };
+        for (int g = wv; g < ngroups; g = next_group()) {
+#else
         for (int g = wv; g < ngroups; g += P2G_WAVES) {
+#endif
             // ---- 1. one particle per lane (its raw state was prefetched) ----------
             if (prof) tq[0] = __builtin_readcyclecounter();
             if (!MPM_P2G_PREFETCH) {

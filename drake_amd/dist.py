@@ -261,28 +261,42 @@ class DomainChain(HaloChain):
         e.dist_migrate_pack(self.mig_send["l"].data_ptr(), self.mig_send["r"].data_ptr(), self.mig_cap)
         pairs = [(self.left, self.mig_send["l"]), (self.right, self.mig_send["r"])]
         pairs = [(n, b) for n, b in pairs if n is not None]
+        cuda = self.device.type == "cuda"
+        if cuda:
+            torch.cuda.synchronize()
+        # Two rounds, like mpm_chain_substeps: the record counts first, then exactly the records that exist (the
+        # buffers are sized for the worst case: 9 MB for 65536 records; a migration of a cloth at rest moves none).
+        rec = e.dist_migration_buffer_bytes(1) - 16
+        size_out = {n: 16 + rec * min(int(b[:4].cpu().view(torch.int32)[0]), self.mig_cap) for n, b in pairs}
+        size_in, reqs = {}, []
+        count_group = None if self.backend == "nccl" else self.group   # (CPU tensors: the default, gloo, group)
+        for n, _ in pairs:
+            size_in[n] = torch.zeros(1, dtype=torch.int64)
+            reqs.append(dist.isend(torch.tensor([size_out[n]], dtype=torch.int64), n, group=count_group))
+            reqs.append(dist.irecv(size_in[n], n, group=count_group))
+        for r in reqs:
+            r.wait()
+        size_in = {n: int(t[0]) for n, t in size_in.items()}
+        self.mig_bytes_sent = dict(size_out)
         if self.staged:
-            cuda = self.device.type == "cuda"
-            if cuda:
-                torch.cuda.synchronize()
             reqs, hosts = [], {}
             for n, b in pairs:
-                hosts[n] = torch.empty(b.numel(), dtype=torch.uint8)
-                reqs.append(dist.isend(b.cpu() if cuda else b, n, group=self.group))
+                hosts[n] = torch.empty(size_in[n], dtype=torch.uint8)
+                out = b[:size_out[n]]
+                reqs.append(dist.isend(out.cpu() if cuda else out, n, group=self.group))
                 reqs.append(dist.irecv(hosts[n], n, group=self.group))
             for r in reqs:
                 r.wait()
             for n in hosts:
-                self.mig_recv[n].copy_(hosts[n])
+                self.mig_recv[n][:size_in[n]].copy_(hosts[n])
             if cuda:
                 torch.cuda.synchronize()
         else:
-            if self._mig_ops is None:
-                self._mig_ops = []
-                for n, b in pairs:
-                    self._mig_ops.append(dist.P2POp(dist.isend, b, n, group=self.group))
-                    self._mig_ops.append(dist.P2POp(dist.irecv, self.mig_recv[n], n, group=self.group))
-            for w in dist.batch_isend_irecv(self._mig_ops):
+            ops = []
+            for n, b in pairs:
+                ops.append(dist.P2POp(dist.isend, b[:size_out[n]], n, group=self.group))
+                ops.append(dist.P2POp(dist.irecv, self.mig_recv[n][:size_in[n]], n, group=self.group))
+            for w in dist.batch_isend_irecv(ops):
                 w.wait()
         e.dist_migrate_apply(self.mig_recv[self.left].data_ptr() if self.left is not None else None,
                              self.mig_recv[self.right].data_ptr() if self.right is not None else None, self.mig_cap)
