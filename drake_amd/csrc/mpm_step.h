@@ -308,6 +308,9 @@ MPM_DEV unsigned tile_reach_mask(int rx, int ry, int rz) {
 #ifndef MPM_P2G_WAVES
 #define MPM_P2G_WAVES 8
 #endif
+#ifndef MPM_P2G_SETPRIO
+#define MPM_P2G_SETPRIO 1
+#endif
 #ifndef MPM_P2G_DYNAMIC
 #define MPM_P2G_DYNAMIC 0   // 1 (experiment): the waves of a workgroup take the item's groups from an LDS counter
 #endif
@@ -672,7 +675,7 @@ __global__ __launch_bounds__(P2G_THREADS) __attribute__((amdgpu_waves_per_eu(P2G
                 nfx = sn[STG_FX]; nfy = sn[STG_FX + 1]; nfz = sn[STG_FX + 2]; ny = sn[j16];
             }
             if (prof) tq[1] = __builtin_readcyclecounter();
-            __builtin_amdgcn_s_setprio(2);   // (waves in the contraction keep the matrix pipe fed: ahead of waves that derive / group)
+            if (MPM_P2G_SETPRIO) __builtin_amdgcn_s_setprio(2);   // (waves in the contraction keep the matrix pipe fed: ahead of waves that derive / group)
             while (todo) {
                 const int ckey = __builtin_amdgcn_readlane(key, __builtin_ctzll(todo));
                 const unsigned long long same = __ballot(key == ckey) & todo;
