@@ -1093,21 +1093,16 @@ __global__ __launch_bounds__(CT_WG) __attribute__((amdgpu_waves_per_eu(4, 4))) v
 // st->red[0..31] (the host all-reduces them); 2 = decide from the global sums put back into st->red.
 // The decision of a Newton iteration from the partial sums (one workgroup of NT threads: the kernel
 // below, or the last workgroup of k_ct_ls to finish).
+// this thread's share of the partial rows: v = its entry of its rows, (d0, d1) = its (|Dir|^2, DoFs) records.  Every
+// load is issued before the first is waited for (one round trip; the rows hold numbers in any state of the solve, so
+// k_ct_decide calls this BEFORE it knows whether the solve is over or which pass this is, see there)
 template <int NT>
-MPM_DEV void ct_decide(const ContactDev& c, int n_dir_wg, int n_con_wg, int n_grid_wg, int exact, int phase,
-                       double (*s_sum)[CT_PART], double (*s_dir)[2]) {
-    ContactState* st = c.st;
-    // entries 0..28: energies; 29: norm_dir; 30: dofs
-    double v = 0;
-    if (phase == 2) {
-        if (threadIdx.x >= 64) return;
-        v = threadIdx.x < 32 ? st->red[threadIdx.x] : 0.0;
-    } else {
+MPM_DEV void ct_thread_sums(const ContactDev& c, int n_dir_wg, int n_con_wg, int n_grid_wg, int exact, bool deep_pass, double& v,
+                            double& d0, double& d1) {
     // Only the entries this pass decides on are summed (the others hold sums of an earlier pass):
     // 4 candidates + E(0) in the shallow pass, 24 in the deep one, (E, dE, d2E) for the exact search.
     // Thread (slot, r) adds the slot's entry of rows r, r + RG, ... (contact rows first, then node
     // rows), 16 loads in flight at a time; wave 0 adds the RG row groups in order and decides.
-    const bool deep_pass = !exact && st->ls_phase == 4;
     const int lgNE = exact ? 2 : (deep_pass ? 5 : 3);
     const int NE = 1 << lgNE, RG = NT >> lgNE;
     const int slot = threadIdx.x & (NE - 1), r = threadIdx.x >> lgNE;
@@ -1115,7 +1110,19 @@ MPM_DEV void ct_decide(const ContactDev& c, int n_dir_wg, int n_con_wg, int n_gr
     if (exact) e = slot < 3 ? slot : -1;
     else if (deep_pass) e = slot >= LS_SHALLOW && slot < LS_CAND ? slot : -1;
     else e = slot < LS_SHALLOW ? slot : (slot == LS_SHALLOW ? LS_CAND : -1);
-    double* s_flat = &s_sum[0][0];   // NT doubles
+    // the (|Dir|^2, DoFs) records of k_ct_node_dir: thread t adds records t, t + NT, ...
+    d0 = 0; d1 = 0;
+    double dq[2][2] = {{0, 0}, {0, 0}};
+    static_assert(CT_DIR_WG <= 2 * 1024, "two records per thread at most");
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const int w = (int)threadIdx.x + k * NT;
+        if (w < n_dir_wg) {
+            dq[k][0] = c.part_dir[(size_t)w * 2];
+            dq[k][1] = c.part_dir[(size_t)w * 2 + 1];
+        }
+    }
+    v = 0;
     if (e >= 0) {
         const int rows = n_con_wg + n_grid_wg;
         for (int k0 = r; k0 < rows; k0 += 16 * RG) {
@@ -1130,15 +1137,43 @@ MPM_DEV void ct_decide(const ContactDev& c, int n_dir_wg, int n_con_wg, int n_gr
             for (int k = 0; k < 16; ++k) v += t[k];
         }
     }
+    for (int w = (int)threadIdx.x + 2 * NT; w < n_dir_wg; w += NT) {   // (never with today's CT_DIR_WG)
+        dq[0][0] += c.part_dir[(size_t)w * 2];
+        dq[0][1] += c.part_dir[(size_t)w * 2 + 1];
+    }
+    d0 = dq[0][0] + dq[1][0];
+    d1 = dq[0][1] + dq[1][1];
+}
+
+template <int NT>
+MPM_DEV void ct_decide_from(const ContactDev& c, int exact, int phase, bool deep_pass, double v, double d0, double d1,
+                            double (*s_sum)[CT_PART], double (*s_dir)[2]);
+
+template <int NT>
+MPM_DEV void ct_decide(const ContactDev& c, int n_dir_wg, int n_con_wg, int n_grid_wg, int exact, int phase,
+                       double (*s_sum)[CT_PART], double (*s_dir)[2]) {
+    ContactState* st = c.st;
+    double v = 0, d0 = 0, d1 = 0;
+    const bool deep_pass = !exact && st->ls_phase == 4;
+    if (phase != 2) ct_thread_sums<NT>(c, n_dir_wg, n_con_wg, n_grid_wg, exact, deep_pass, v, d0, d1);
+    ct_decide_from<NT>(c, exact, phase, deep_pass, v, d0, d1, s_sum, s_dir);
+}
+
+template <int NT>
+MPM_DEV void ct_decide_from(const ContactDev& c, int exact, int phase, bool deep_pass, double v, double d0, double d1,
+                            double (*s_sum)[CT_PART], double (*s_dir)[2]) {
+    ContactState* st = c.st;
+    // entries 0..28: energies; 29: norm_dir; 30: dofs
+    if (phase == 2) {
+        if (threadIdx.x >= 64) return;
+        v = threadIdx.x < 32 ? st->red[threadIdx.x] : 0.0;
+    } else {
+    const int lgNE = exact ? 2 : (deep_pass ? 5 : 3);
+    const int RG = NT >> lgNE;
+    double* s_flat = &s_sum[0][0];   // NT doubles
     s_flat[threadIdx.x] = v;   // [r][slot]
-    // the (|Dir|^2, DoFs) records of k_ct_node_dir: thread t adds records t, t + NT, ..., then a
-    // fixed tree over the workgroup
+    // fixed tree over the workgroup for the direction records
     {
-        double d0 = 0, d1 = 0;
-        for (int w = threadIdx.x; w < n_dir_wg; w += NT) {
-            d0 += c.part_dir[(size_t)w * 2];
-            d1 += c.part_dir[(size_t)w * 2 + 1];
-        }
 #pragma unroll
         for (int d = 32; d >= 1; d >>= 1) {
             d0 += __shfl_down(d0, d);
@@ -1242,13 +1277,21 @@ __global__ __launch_bounds__(1024) void k_ct_decide(ContactDev c, int n_dir_wg, 
     __shared__ double s_sum[32][CT_PART];
     __shared__ double s_dir[16][2];
     ContactState* st = c.st;
-    if (st->done && !c.force) {
+    // One workgroup, nothing but dependent round trips: the state, then the rows, then the direction records.  So the
+    // rows are read BEFORE the state has arrived, as if this were the usual pass (not finished, not the deep pass of
+    // the backtracking): the loads are harmless in any state, and the rare other case reads again.
+    const int done = st->done, ls_phase = st->ls_phase;
+    double v = 0, d0 = 0, d1 = 0;
+    if (phase != 2) ct_thread_sums<1024>(c, n_dir_wg, n_con_wg, n_grid_wg, exact, false, v, d0, d1);
+    if (done && !c.force) {
         // "finish after this update" becomes "finished" once that update (k_ct_apply of the
         // previous iteration) has run
-        if (threadIdx.x == 0 && st->done == 2) st->done = 1;
+        if (threadIdx.x == 0 && done == 2) st->done = 1;
         return;
     }
-    ct_decide<1024>(c, n_dir_wg, n_con_wg, n_grid_wg, exact, phase, s_sum, s_dir);
+    const bool deep_pass = !exact && ls_phase == 4;
+    if (deep_pass && phase != 2) ct_thread_sums<1024>(c, n_dir_wg, n_con_wg, n_grid_wg, exact, true, v, d0, d1);
+    ct_decide_from<1024>(c, exact, phase, deep_pass, v, d0, d1, s_sum, s_dir);
 }
 
 // G3: v -= alpha Dir (cuda_mpm_kernels.cuh:1591-1614); only nodes that see contacts have a direction

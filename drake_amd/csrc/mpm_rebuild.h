@@ -114,41 +114,46 @@ __global__ __launch_bounds__(256) void k_rb_count(DP p) {
     const int t = ii >= p.Nf;
     const uint32_t key = cell_key(bx, by, bz);
     const int lane = threadIdx.x & 63;
-    // A wave straddles at most two types; handle them one after the other.  The atomics of all
-    // groups are issued back to back and their results are collected once, after the loops, so a
-    // wave pays one memory round trip instead of one per distinct cell.
-    int ret_cell = 0, ret_blk = 1, my_lead = lane;
-    unsigned long long my_same = 0ull;
-    bool blk_lead = false;
-    for (int ty = 0; ty < 2; ++ty) {
-        unsigned long long todo = __ballot(valid && t == ty);
+    // The lanes of a wave are merged by (type, cell) and by (type, block) with ballots, and then ALL group leaders
+    // issue their atomic in ONE wave instruction per histogram (different addresses in different lanes).  Round 1-3 issued
+    // one single-lane atomic instruction per distinct cell and block from inside the ballot loops: a CU retires a
+    // memory-side atomic instruction every ~50 ns whatever its active lanes (MI355X_MICROARCH.md, global float
+    // atomics: a wave instruction with 64 scattered lanes takes 17 of those, 13 ns per request), so ~7 instructions per
+    // wave were 0.35 us per wave and the kernel's bound; now 2.
+    int ret_cell = 0, ret_blk = 1, my_lead = lane, blk_leader = lane;
+    unsigned long long my_same = 0ull, blk_same = 0ull;
+    {
+        const uint32_t ckey = valid ? (key | ((uint32_t)t << 31)) : 0xFFFFFFFFu;   // (type in the top bit: one pass for both)
+        unsigned long long todo = __ballot(valid);
         while (todo) {
             const int lead = __builtin_ctzll(todo);
-            const uint32_t lk = (uint32_t)__shfl((int)key, lead);
-            const unsigned long long same = __ballot(key == lk) & todo;
-            if (lane == lead) ret_cell = atomicAdd(&p.cellcnt[ty][lk], (int)__popcll(same));
+            const uint32_t lk = (uint32_t)__shfl((int)ckey, lead);
+            const unsigned long long same = __ballot(ckey == lk) & todo;
             if (same & (1ull << lane)) {
                 my_lead = lead;
                 my_same = same;
             }
             todo &= ~same;
         }
-        // block histogram, merged per wave in the same way
-        todo = __ballot(valid && t == ty);
+        const uint32_t bkey = valid ? ((key >> 6) | ((uint32_t)t << 31)) : 0xFFFFFFFFu;
+        todo = __ballot(valid);
         while (todo) {
             const int lead = __builtin_ctzll(todo);
-            const uint32_t lb = (uint32_t)__shfl((int)(key >> 6), lead);
-            const unsigned long long same = __ballot((key >> 6) == lb) & todo;
-            if (lane == lead) {
-                ret_blk = atomicAdd(&p.blkcnt[ty][lb], (int)__popcll(same));
-                blk_lead = true;
+            const uint32_t lb = (uint32_t)__shfl((int)bkey, lead);
+            const unsigned long long same = __ballot(bkey == lb) & todo;
+            if (same & (1ull << lane)) {
+                blk_leader = lead;
+                blk_same = same;
             }
             todo &= ~same;
         }
     }
+    const bool cell_lead = valid && lane == my_lead, blk_lead = valid && lane == blk_leader;
+    if (cell_lead) ret_cell = atomicAdd(&p.cellcnt[t][key], (int)__popcll(my_same));
+    if (blk_lead) ret_blk = atomicAdd(&p.blkcnt[t][key >> 6], (int)__popcll(blk_same));
     // same-address device atomics serialise at ~30 ns each: only the first arrival of a
     // (type, block) pair touches the non-empty bitmap
-    if (blk_lead && ret_blk == 0) atomicOr(&p.home_bits[key >> 11], 1u << ((key >> 6) & 31u));
+    if (blk_lead && ret_blk == 0) atomicOr(&p.home_bits[key >> 11], 1u << ((key >> 6) & 31u));   // (one instruction too)
     const uint32_t rank = (uint32_t)__shfl(ret_cell, my_lead) + (uint32_t)__popcll(my_same & ((1ull << lane) - 1ull));
     if (listed) {
         p.pkey[i] = valid ? key : 0xFFFFFFFFu;

@@ -8,6 +8,13 @@
 #pragma once
 #include "mpm_device.h"
 
+#ifndef MPM_FEM_SETPRIO
+#define MPM_FEM_SETPRIO 1    // (A/B switch, round 4: no difference measured)
+#endif
+#ifndef MPM_G2P_PREFETCH
+#define MPM_G2P_PREFETCH 1   // 0 (experiment): a particle's position is loaded when its turn comes
+#endif
+
 namespace mpm {
 
 // ---------------------------------------------------------------------------
@@ -52,7 +59,7 @@ __global__ __launch_bounds__(256) void k_fem(DP p, float dt) {
     // partitioned domain: the sign of q[0].w is the particle's role (ghost copies are negative) and changes
     // with migration; a single-domain engine never looks at the face particle's own record
     const float volw = p.dist.on ? S.q[0][i].w : f2.w;
-    __builtin_amdgcn_s_setprio(2);   // (a wave that has its data computes and stores ahead of waves still issuing loads)
+    if (MPM_FEM_SETPRIO) __builtin_amdgcn_s_setprio(2);   // (a wave that has its data computes and stores ahead of waves still issuing loads)
     const float x0[3] = {xa.x, xa.y, xa.z}, x1[3] = {xb.x, xb.y, xb.z}, x2[3] = {xc.x, xc.y, xc.z};
     // the face particle sits at the centroid and moves with the mean velocity (:203-207);
     // vol and C8 ride along unchanged
@@ -1151,10 +1158,14 @@ __global__ __launch_bounds__(G2P_THREADS) __attribute__((amdgpu_waves_per_eu(MPM
         const int ox = bx * 4 - FREE_ZONE, oy = by * 4 - FREE_ZONE, oz = bz * 4 - FREE_ZONE;
 #pragma unroll 1
         for (; u < total; u += G2P_THREADS * G2P_SPLIT) {
+            if (!MPM_G2P_PREFETCH) {
+                i = slot_of(u);
+                pq = S.q[0][i];
+            }
             const unsigned ci = i;
             const float4 c = pq;
             const int un = u + G2P_THREADS * G2P_SPLIT;
-            if (un < total) {
+            if (MPM_G2P_PREFETCH && un < total) {
                 i = slot_of(un);
                 pq = S.q[0][i];
             }
