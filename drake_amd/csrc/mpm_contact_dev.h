@@ -608,10 +608,13 @@ MPM_DEV void wg_reduce_store(double* vals, double* out) {
 
 // Segments of a tile of sorted contacts: a segment = the contacts of one cell inside the tile.  Wave 0
 // fills s_seg[0..nseg] (first contact of every segment, then cnt) and s_cseg[contact] (its segment).
-MPM_DEV void tile_segments(const ContactDev& c, int lo, int cnt, int* s_seg, int* s_cseg, int* s_nseg) {
+// (`key`: this lane's contact key, loaded by the caller -- tile_key -- so that the load can be in flight early)
+MPM_DEV uint32_t tile_key(const ContactDev& c, int lo, int cnt) {
+    return threadIdx.x < 64 ? c.key[lo + min((int)threadIdx.x, cnt - 1)] : 0u;
+}
+MPM_DEV void tile_segments(uint32_t key, int cnt, int* s_seg, int* s_cseg, int* s_nseg) {
     const int tid = threadIdx.x;
     if (tid >= 64) return;
-    const uint32_t key = c.key[lo + min(tid, cnt - 1)];
     const uint32_t prev = __shfl_up(key, 1);
     const bool head = tid < cnt && (tid == 0 || key != prev);
     const unsigned long long m = __ballot(head);
@@ -640,7 +643,14 @@ MPM_DEV void tile_segments(const ContactDev& c, int lo, int cnt, int* s_seg, int
 // lazy: the step of the previous Newton iteration has not been added to the grid yet (k_ct_node_dir does
 // that, after this kernel): velocities are read as v - alpha D.
 __global__ __launch_bounds__(256) void k_ct_tile(DP p, ContactDev c, int first, int lazy) {
-    if (!c.force && (c.st->done || c.st->ls_phase != 0)) return;   // (line search of the previous direction still running)
+    // (the first tile's keys are requested together with the solver state: one round trip instead of two before the
+    // kernel knows what to do -- the state was written by a single workgroup of the previous kernel and is a miss in
+    // seven of the eight L2s)
+    const int n_tiles = (c.n + CT_TILE - 1) / CT_TILE;
+    uint32_t key_next = (int)blockIdx.x < n_tiles ? tile_key(c, (int)blockIdx.x * CT_TILE, min(CT_TILE, c.n - (int)blockIdx.x * CT_TILE)) : 0u;
+    const int st_done = c.st->done, st_phase = c.st->ls_phase;
+    const float st_alpha = c.st->alpha;
+    if (!c.force && (st_done || st_phase != 0)) return;   // (line search of the previous direction still running)
     __shared__ float s_part[8][CT_SEG_F];
     __shared__ __attribute__((aligned(16))) float4 s_rec[CT_TILE * 3];
     __shared__ __attribute__((aligned(16))) float4 s_nv[CT_STAGE * 27];
@@ -648,17 +658,32 @@ __global__ __launch_bounds__(256) void k_ct_tile(DP p, ContactDev c, int first, 
     __shared__ int s_seg[CT_TILE + 1];
     __shared__ int s_cseg[CT_TILE];
     __shared__ int s_nseg;
-    const int n_tiles = (c.n + CT_TILE - 1) / CT_TILE;
-    const float al = lazy ? c.st->alpha : 0.f;
+    const float al = lazy ? st_alpha : 0.f;
     const int tid = threadIdx.x, lc = tid >> 2, part = tid & 3;
     const ContactParams cp = {c.dt, c.mu, c.k, c.d, c.epsv};
     for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
         const int lo = tile * CT_TILE, cnt = min(CT_TILE, c.n - lo);
-        tile_segments(c, lo, cnt, s_seg, s_cseg, &s_nseg);
-        __syncthreads();
-        const int nseg = s_nseg;
+        const uint32_t key = key_next;
+        if (tile + (int)gridDim.x < n_tiles) {
+            const int lo2 = (tile + (int)gridDim.x) * CT_TILE;
+            key_next = tile_key(c, lo2, min(CT_TILE, c.n - lo2));
+        }
         const int jc = min(lc, cnt - 1);   // (lanes past the end repeat the last contact and store nothing)
         const int j = lo + jc;
+        // this contact's constants: requested here, used after the stencil nodes have been staged (the loads ride on the
+        // staging's round trips instead of following them)
+        float R[9], v0[3], crv[3];
+#pragma unroll
+        for (int t = 0; t < 9; ++t) R[t] = c.cR[t * c.n + j];
+#pragma unroll
+        for (int t = 0; t < 3; ++t) {
+            v0[t] = c.cv0[t * c.n + j];
+            crv[t] = c.crv[t * c.n + j];
+        }
+        const float phi0_j = c.cphi0[j], mass = c.cmass[j];
+        tile_segments(key, cnt, s_seg, s_cseg, &s_nseg);
+        __syncthreads();
+        const int nseg = s_nseg;
         float wx[3], wy[3], wz[3];
         bspline3(c.cfx[j], wx);
         bspline3(c.cfx[c.n + j], wy);
@@ -707,16 +732,11 @@ __global__ __launch_bounds__(256) void k_ct_tile(DP p, ContactDev c, int first, 
                 v[t] += __shfl_xor(v[t], 2);
             }
         }
-        float R[9], v0[3];
-#pragma unroll
-        for (int t = 0; t < 9; ++t) R[t] = c.cR[t * c.n + j];
-#pragma unroll
-        for (int t = 0; t < 3; ++t) v0[t] = c.cv0[t * c.n + j];
-        const float vr[3] = {v[0] - c.crv[j], v[1] - c.crv[c.n + j], v[2] - c.crv[2 * c.n + j]};
+        const float vr[3] = {v[0] - crv[0], v[1] - crv[1], v[2] - crv[2]};
         float vl[3];
         mulv3(R, vr, vl);
         float CH[9], CG[3];
-        contact_grad_hess(cp, c.cphi0[j], v0, vl, CH, CG);
+        contact_grad_hess(cp, phi0_j, v0, vl, CH, CG);
         // world frame: R^T G and R^T H R, with the zeros of the contact-frame Hessian (its tangential 2 x 2
         // block and the normal entry are all there is) left out of the products
         float tm[9];   // R^T H
@@ -726,7 +746,6 @@ __global__ __launch_bounds__(256) void k_ct_tile(DP p, ContactDev c, int first, 
             tm[i * 3 + 1] = R[i] * CH[1] + R[3 + i] * CH[4];
             tm[i * 3 + 2] = R[6 + i] * CH[8];
         }
-        const float mass = c.cmass[j];
         float hs[6];   // xx xy xz yy yz zz
         {
             const int ii[6] = {0, 0, 0, 1, 1, 2}, jj2[6] = {0, 1, 2, 1, 2, 2};
@@ -901,12 +920,18 @@ __global__ __launch_bounds__(CT_WG) void k_ct_node_dir(DP p, ContactDev c, int l
 // host; 2 = the same at st->alpha_probe, the device-resident search (skipped once the step is decided)
 __global__ __launch_bounds__(CT_WG) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_ct_ls(DP p, ContactDev c, int n_con_wg, int exact,
                                                                                              float alpha_probe) {
-    if (c.st->done && !c.force) return;   // k_ct_decide does not read the records of a finished solve
+    // (as in k_ct_tile: the first tile's keys are requested together with the solver state)
+    const int n_tiles = (c.n + CT_TILE - 1) / CT_TILE;
+    uint32_t key_next = (int)blockIdx.x < n_con_wg && (int)blockIdx.x < n_tiles
+                            ? tile_key(c, (int)blockIdx.x * CT_TILE, min(CT_TILE, c.n - (int)blockIdx.x * CT_TILE)) : 0u;
+    const int st_done = c.st->done, st_phase = c.st->ls_phase;
+    const float st_probe = c.st->alpha_probe;
+    if (st_done && !c.force) return;   // k_ct_decide does not read the records of a finished solve
     if (exact == 2) {
-        if (c.st->ls_phase == 3) return;
-        alpha_probe = c.st->alpha_probe;
+        if (st_phase == 3) return;
+        alpha_probe = st_probe;
     }
-    const bool deep = !exact && c.st->ls_phase == 4;
+    const bool deep = !exact && st_phase == 4;
     if ((int)blockIdx.x < n_con_wg) {
         // A tile of CT_TILE sorted contacts at a time, 4 lanes per contact: the stencil nodes of every
         // segment are staged in LDS once (see k_ct_tile), each lane adds up 9 of the 27 and evaluates its
@@ -921,11 +946,15 @@ __global__ __launch_bounds__(CT_WG) __attribute__((amdgpu_waves_per_eu(4, 4))) v
         const int part = threadIdx.x & 3, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
         const ContactParams cp = {c.dt, c.mu, c.k, c.d, c.epsv};
         double acc[6] = {0, 0, 0, 0, 0, 0}, e0 = 0;
-        const int n_tiles = (c.n + CT_TILE - 1) / CT_TILE;
         for (int tile = blockIdx.x; tile < n_tiles; tile += n_con_wg) {
             const int lo = tile * CT_TILE, cnt = min(CT_TILE, c.n - lo);
+            const uint32_t key = key_next;
+            if (tile + n_con_wg < n_tiles) {
+                const int lo2 = (tile + n_con_wg) * CT_TILE;
+                key_next = tile_key(c, lo2, min(CT_TILE, c.n - lo2));
+            }
             __syncthreads();   // the previous tile's tables are no longer read
-            tile_segments(c, lo, cnt, s_seg, s_cseg, &s_nseg);
+            tile_segments(key, cnt, s_seg, s_cseg, &s_nseg);
             __syncthreads();
             const int nseg = s_nseg;
             const int jc = min(lc, cnt - 1), j = lo + jc;
