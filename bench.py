@@ -409,8 +409,7 @@ def main():
                     g.chain_substeps(1, dt, -1)
                     g.gpu_sync()
                 except Exception as exc:  # noqa: BLE001
-                    print(f"[bench] rank {rank}: native RCCL chain failed: {exc} (RCCL's own diagnosis is on stderr above: "
-                          "NCCL_DEBUG=WARN)", file=sys.stderr, flush=True)
+                    print(f"[bench] rank {rank}: native RCCL chain failed: {exc}", file=sys.stderr, flush=True)
                     ok = False
             native = all_ok(ok)
             if native:

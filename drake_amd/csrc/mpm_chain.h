@@ -26,6 +26,7 @@ using Send = int (*)(const void*, size_t, int, int, Comm, hipStream_t);
 using Recv = int (*)(void*, size_t, int, int, Comm, hipStream_t);
 using AllReduce = int (*)(const void*, void*, size_t, int, int, Comm, hipStream_t);
 using GetErrorString = const char* (*)(int);
+using GetLastError = const char* (*)(Comm);
 struct Api {
     void* lib = nullptr;
     GetUniqueId get_unique_id = nullptr;
@@ -37,6 +38,7 @@ struct Api {
     Recv recv = nullptr;
     AllReduce all_reduce = nullptr;
     GetErrorString error_string = nullptr;
+    GetLastError last_error = nullptr;   // ncclGetLastError: RCCL's own words for what went wrong (optional symbol)
 };
 // The process may already hold an RCCL (PyTorch ships one): use that instance, never a second one --
 // two copies of RCCL's dependencies (rocm_smi) in one process end in a double free at exit.  A process
@@ -64,6 +66,7 @@ static const Api* api() {
     a.recv = (Recv)dlsym(a.lib, "ncclRecv");
     a.all_reduce = (AllReduce)dlsym(a.lib, "ncclAllReduce");
     a.error_string = (GetErrorString)dlsym(a.lib, "ncclGetErrorString");
+    a.last_error = (GetLastError)dlsym(a.lib, "ncclGetLastError");
     if (!a.get_unique_id || !a.comm_init_rank || !a.comm_destroy || !a.group_start || !a.group_end || !a.send || !a.recv) {
         a.lib = nullptr;
         return nullptr;
@@ -77,7 +80,9 @@ static const Api* api() {
         const int rc_ = (expr);                                                                     \
         if (rc_ != 0) {                                                                             \
             const rccl_rt::Api* a_ = rccl_rt::api();                                                \
+            const char* why_ = a_ && a_->last_error ? a_->last_error(nullptr) : nullptr;            \
             return fail(MPM_ERR_HIP, std::string("RCCL: ") + #expr + ": " +                        \
-                                         (a_ && a_->error_string ? a_->error_string(rc_) : "error")); \
+                                         (a_ && a_->error_string ? a_->error_string(rc_) : "error") + \
+                                         (why_ && *why_ ? std::string(" -- ") + why_ : std::string())); \
         }                                                                                           \
     } while (0)

@@ -247,6 +247,18 @@ MPM_DEV float quad_perm(float v) {
 // infinity have the largest patterns of all): the caller compares it with 2^62 once, at the end -- a
 // boolean per call lives in a scalar register pair and costs scalar instructions in every loop.
 MPM_DEV void lds_add_fixed(long long* a, float q, unsigned& worst) {   // q = value * scale
+#if MPM_P2G_FIXBITS <= 50
+    // |q| < 2^51 (the scales leave 50 bits below the total mass): adding 1.5 * 2^52 in double leaves the integer
+    // nearest to q (ties to even) in the low mantissa bits, two's complement included -- four instructions instead of
+    // twelve.  Quantum = total mass * 2^-50: a contribution keeps 24 bits while it is larger than 2^-27 of the total
+    // mass, smaller ones are rounded to the quantum (unbiased), i.e. errors of 1e-15 of the total mass.
+    const double x = (double)q + 0x1.8p52;
+    const long long fxs = __double_as_longlong(x) - __double_as_longlong(0x1.8p52);
+    __hip_atomic_fetch_add(reinterpret_cast<unsigned long long*>(a), (unsigned long long)fxs, __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_WORKGROUP);
+    worst = max(worst, __float_as_uint(fabsf(q)));
+    return;
+#endif
     const float aq = fabsf(q);
     const float h = floorf(aq * 0x1p-32f);
     const unsigned lo = (unsigned)rintf(fmaf(-h, 0x1p32f, aq));
@@ -314,6 +326,12 @@ MPM_DEV unsigned tile_reach_mask(int rx, int ry, int rz) {
 
 #ifndef MPM_P2G_WAVES
 #define MPM_P2G_WAVES 8
+#endif
+#ifndef MPM_P2G_PEEL
+#define MPM_P2G_PEEL 0
+#endif
+#ifndef MPM_P2G_FIXBITS
+#define MPM_P2G_FIXBITS 61   // bits of the fixed-point tile below the total mass (50: conversion through a double, see lds_add_fixed)
 #endif
 #ifndef MPM_P2G_SETPRIO
 #define MPM_P2G_SETPRIO 1
@@ -692,7 +710,7 @@ __global__ __launch_bounds__(P2G_THREADS) __attribute__((amdgpu_waves_per_eu(P2G
                 if (prof) { pc[4] += 1; pc[5] += (unsigned)((s1 - s0 + 3) >> 2); tq[2] = __builtin_readcyclecounter(); }
                 // operands of a step are fetched one step ahead (the first step's during the previous
                 // cell's epilogue), so the LDS latency hides behind the MFMAs
-                for (int s = (diag_flags(p) & 8) ? s1 : s0; s < s1; s += 4) {
+                auto one_step = [&](int s, bool first_step) {
                     const bool ok = s + g4 < s1;
                     const float fx = nfx, fy = nfy, fz = nfz;
                     float y = ny;
@@ -712,10 +730,24 @@ __global__ __launch_bounds__(P2G_THREADS) __attribute__((amdgpu_waves_per_eu(P2G
                     if (diag_flags(p) & 64) {
                         acc0[0] = fmaf(w0, y, acc0[0]);
                         acc1[0] = fmaf(w1, y, acc1[0]);
+                    } else if (MPM_P2G_PEEL && first_step) {
+                        // (the first step of a cell accumulates onto the constant 0 -- an inline operand of the MFMA --
+                        // instead of onto eight registers that have to be cleared first)
+                        const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+                        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(w0, y, zero, 0, 0, 0);
+                        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(w1, y, zero, 0, 0, 0);
                     } else {
                         acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(w0, y, acc0, 0, 0, 0);
                         acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(w1, y, acc1, 0, 0, 0);
                     }
+                };
+                {
+                    int s = (diag_flags(p) & 8) ? s1 : s0;
+                    if (MPM_P2G_PEEL && s < s1) {   // (a cell has at least one particle: s0 < s1)
+                        one_step(s, true);
+                        s += 4;
+                    }
+                    for (; s < s1; s += 4) one_step(s, false);
                 }
                 // the loop leaves row block (last step + 4) preloaded; the next cell starts at s1
                 if (((s1 - s0) & 3) != 0 || (diag_flags(p) & 8)) {
@@ -762,7 +794,7 @@ __global__ __launch_bounds__(P2G_THREADS) __attribute__((amdgpu_waves_per_eu(P2G
             for (int q = 0; q < 8; ++q) atomicAdd(&p.dbgbuf[q], pc[q]);
         if (mymask && lane == 0) atomicOr(&s_mask, mymask);
         if (__ballot(out_worst > (unsigned)(TILE_W - 3)) && lane == 0) atomicOr(&ctl->error, ERR_DRIFT);
-        if (__ballot(fix_worst >= __float_as_uint(0x1p62f)) && lane == 0) atomicOr(&ctl->error, ERR_RANGE);
+        if (__ballot(fix_worst >= __float_as_uint(MPM_P2G_FIXBITS <= 50 ? 0x1p50f : 0x1p62f)) && lane == 0) atomicOr(&ctl->error, ERR_RANGE);
         if (p.dist.on && __ballot(halo_bad) && lane == 0) atomicOr(&ctl->error, ERR_HALO);
         __syncthreads();
         if (prof && lane == 0) atomicAdd(&p.dbgbuf[15], (unsigned long long)__builtin_readcyclecounter() - tb0 - pc[7]);   // wave 0 at the closing barrier
