@@ -228,7 +228,7 @@ static int set_fixed_point_scales(mpm_engine* e) {
     double mass = 0;
     for (size_t i = 0; i < slots; ++i) mass += std::fabs((double)q0[i * 4 + 3]) * p.M.density;
     if (!(mass > 0) || !std::isfinite(mass)) mass = 1.0;
-    const int k = MPM_P2G_FIXBITS - (int)std::ceil(std::log2(mass));
+    const int k = 61 - (int)std::ceil(std::log2(mass));
     p.fix_m = std::ldexp(1.0, k);
     p.fix_p = std::ldexp(1.0, k - 14);
     p.unfix_m = 1.0 / p.fix_m;

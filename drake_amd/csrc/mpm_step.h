@@ -8,6 +8,10 @@
 #pragma once
 #include "mpm_device.h"
 
+// (A/B switches used before their kernels are defined: all at the top, an undefined macro in an #if reads as 0)
+#ifndef MPM_P2G_PEEL
+#define MPM_P2G_PEEL 0
+#endif
 #ifndef MPM_FEM_SETPRIO
 #define MPM_FEM_SETPRIO 1    // (A/B switch, round 4: no difference measured)
 #endif
@@ -247,18 +251,6 @@ MPM_DEV float quad_perm(float v) {
 // infinity have the largest patterns of all): the caller compares it with 2^62 once, at the end -- a
 // boolean per call lives in a scalar register pair and costs scalar instructions in every loop.
 MPM_DEV void lds_add_fixed(long long* a, float q, unsigned& worst) {   // q = value * scale
-#if MPM_P2G_FIXBITS <= 50
-    // |q| < 2^51 (the scales leave 50 bits below the total mass): adding 1.5 * 2^52 in double leaves the integer
-    // nearest to q (ties to even) in the low mantissa bits, two's complement included -- four instructions instead of
-    // twelve.  Quantum = total mass * 2^-50: a contribution keeps 24 bits while it is larger than 2^-27 of the total
-    // mass, smaller ones are rounded to the quantum (unbiased), i.e. errors of 1e-15 of the total mass.
-    const double x = (double)q + 0x1.8p52;
-    const long long fxs = __double_as_longlong(x) - __double_as_longlong(0x1.8p52);
-    __hip_atomic_fetch_add(reinterpret_cast<unsigned long long*>(a), (unsigned long long)fxs, __ATOMIC_RELAXED,
-                           __HIP_MEMORY_SCOPE_WORKGROUP);
-    worst = max(worst, __float_as_uint(fabsf(q)));
-    return;
-#endif
     const float aq = fabsf(q);
     const float h = floorf(aq * 0x1p-32f);
     const unsigned lo = (unsigned)rintf(fmaf(-h, 0x1p32f, aq));
@@ -326,12 +318,6 @@ MPM_DEV unsigned tile_reach_mask(int rx, int ry, int rz) {
 
 #ifndef MPM_P2G_WAVES
 #define MPM_P2G_WAVES 8
-#endif
-#ifndef MPM_P2G_PEEL
-#define MPM_P2G_PEEL 0
-#endif
-#ifndef MPM_P2G_FIXBITS
-#define MPM_P2G_FIXBITS 61   // bits of the fixed-point tile below the total mass (50: conversion through a double, see lds_add_fixed)
 #endif
 #ifndef MPM_P2G_SETPRIO
 #define MPM_P2G_SETPRIO 1
@@ -794,7 +780,7 @@ __global__ __launch_bounds__(P2G_THREADS) __attribute__((amdgpu_waves_per_eu(P2G
             for (int q = 0; q < 8; ++q) atomicAdd(&p.dbgbuf[q], pc[q]);
         if (mymask && lane == 0) atomicOr(&s_mask, mymask);
         if (__ballot(out_worst > (unsigned)(TILE_W - 3)) && lane == 0) atomicOr(&ctl->error, ERR_DRIFT);
-        if (__ballot(fix_worst >= __float_as_uint(MPM_P2G_FIXBITS <= 50 ? 0x1p50f : 0x1p62f)) && lane == 0) atomicOr(&ctl->error, ERR_RANGE);
+        if (__ballot(fix_worst >= __float_as_uint(0x1p62f)) && lane == 0) atomicOr(&ctl->error, ERR_RANGE);
         if (p.dist.on && __ballot(halo_bad) && lane == 0) atomicOr(&ctl->error, ERR_HALO);
         __syncthreads();
         if (prof && lane == 0) atomicAdd(&p.dbgbuf[15], (unsigned long long)__builtin_readcyclecounter() - tb0 - pc[7]);   // wave 0 at the closing barrier
