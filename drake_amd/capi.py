@@ -87,7 +87,8 @@ class DistConfig(C.Structure):
 
 class DistGeometry(C.Structure):
     _fields_ = [("face_band_cells", C.c_float), ("vertex_band_cells", C.c_float), ("drift_budget_cells", C.c_float),
-                ("longest_edge_cells", C.c_float), ("slot_resizes", C.c_uint32), ("migrations", C.c_uint32)]
+                ("longest_edge_cells", C.c_float), ("slot_resizes", C.c_uint32), ("migrations", C.c_uint32),
+                ("retunes", C.c_uint32)]
 
 
 class Stats(C.Structure):
@@ -125,7 +126,7 @@ SYMBOLS = [
     "mpm_dist_migrate_pack", "mpm_dist_migrate_apply", "mpm_dist_roles", "mpm_chain_enable_migration",
     "mpm_dist_set_transport", "mpm_device_synchronize", "mpm_debug_owed_substeps",
     "mpm_memcpy_d2h", "mpm_memcpy_h2d", "mpm_profile_contact_iteration", "mpm_contact_frame", "mpm_halo_zone_blocks",
-    "mpm_dist_get_geometry", "mpm_dist_set_headroom", "mpm_dist_migration_quiet_time",
+    "mpm_dist_get_geometry", "mpm_dist_set_headroom", "mpm_dist_migration_quiet_time", "mpm_dist_retune",
 ]
 
 EXCHANGE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t)
@@ -239,6 +240,7 @@ def load_library(build: bool = True):
         "mpm_dist_get_geometry": [vp, P(DistGeometry)],
         "mpm_dist_set_headroom": [vp, f],
         "mpm_dist_migration_quiet_time": [vp, P(f)],
+        "mpm_dist_retune": [vp, f, f, P(i)],
         "mpm_chain_enable_migration": [vp, i, sz],
         "mpm_dist_set_transport": [vp, EXCHANGE_FN, ALLREDUCE_FN, vp, sz],
         "mpm_grid_collider_preset": [i, f, vp, sz, P(sz)],
@@ -587,6 +589,12 @@ class GpuMpm:
         t = C.c_float(0.0)
         self._ck(self.lib.mpm_dist_migration_quiet_time(self.h, C.byref(t)))
         return float(t.value)
+
+    def dist_retune(self, quiet_time_all: float, dt: float) -> bool:
+        """Re-sizes bands that came from the mesh for the speed the ranks' common estimate implies (mpm_dist_retune)."""
+        changed = C.c_int(0)
+        self._ck(self.lib.mpm_dist_retune(self.h, float(quiet_time_all), float(dt), C.byref(changed)))
+        return bool(changed.value)
 
     def dist_migration_buffer_bytes(self, capacity_particles: int) -> int:
         return int(self.lib.mpm_dist_migration_buffer_bytes(capacity_particles))

@@ -1187,6 +1187,7 @@ int mpm_chain_substeps(mpm_handle_t e, int n, float dt, int bc) {
                 const float t_est = e->mig_safety * (t >= 0.f ? t : 0.f);   // (NaN -> 0: migrate again next substep)
                 c.mig_budget = std::min(t_est, std::max(4.f * dt, 2.f * c.mig_elapsed));
                 c.mig_elapsed = 0.f;
+                if (int rc = mpm_dist_retune(e, t, dt, nullptr)) return rc;   // (band widths for the migrations to come)
             }
         }
         c.mig_elapsed += dt;
@@ -1713,6 +1714,10 @@ int mpm_dist_init(mpm_handle_t e, const mpm_dist_config_t* cfg) {
     d.mig_delta = delta;
     d.mig_reach = vert_w + 2.f * reach + 1.f;
     e->dist_longest_edge = longest_edge;
+    e->dist_auto = auto_bands;
+    e->dist_reach = reach;
+    e->dist_hyst = hyst;
+    e->dist_delta_max = std::min((zone_room - 2.f * reach - 2.f * hyst) / 3.f, zone_room - 1.f - hyst);
     if (int rc = e->dalloc(&d.prev, e->np, true)) return rc;
     if (int rc = e->dalloc(&d.mig_min, 32 * 32, true)) return rc;
     // per-slot topology by original id, for every particle at first (nobody has been released yet)
@@ -1773,6 +1778,43 @@ int mpm_dist_get_geometry(mpm_handle_t e, mpm_dist_geometry_t* out) {
     out->longest_edge_cells = e->dist_longest_edge;
     out->slot_resizes = e->dist_resizes;
     out->migrations = e->dist_migrations;
+    out->retunes = e->dist_retunes;
+    return 0;
+}
+
+int mpm_dist_retune(mpm_handle_t e, float quiet_time_all, float dt, int* changed_out) {
+    REQUIRE(e, "null handle");
+    REQUIRE(e->dp.dist.on, "mpm_dist_init first");
+    if (changed_out) *changed_out = 0;
+    if (!e->dist_auto || !e->dist_retune || !(dt > 0.f)) return 0;
+    Dist& d = e->dp.dist;
+    // The ranks' common estimate says the fastest relevant particle uses up the CURRENT budget in quiet_time_all: that
+    // is a speed.  The budget that makes a migration due every dist_target_interval substeps at that speed (half of
+    // the estimate is trusted), in steps of an eighth of a cell so that it does not flutter, within what the zone allows:
+    float want = e->dist_delta_max;   // (an estimate of 0 or NaN: as wide as the zone allows)
+    if (quiet_time_all > 0.f && std::isfinite(quiet_time_all)) {
+        const float speed = d.mig_delta / quiet_time_all;   // cells per second
+        want = speed * dt * e->dist_target_interval / e->mig_safety;
+        want = std::ceil(want * 8.f) * .125f;
+    } else if (quiet_time_all > 0.f) {
+        want = .125f;   // (an infinite estimate -- nothing moves along x --: the narrowest bands)
+    }
+    want = std::min(std::max(want, .125f), e->dist_delta_max);
+    if (!(want > .05f) || std::fabs(want - d.mig_delta) < .06f) return 0;
+    // Every rank computes this from the same numbers at the same migration, so all switch together.  The new widths
+    // take effect at the NEXT migration's classification (particles newly inside a wider band are sent then, ghosts
+    // outside a narrower one are released then); the interval up to it was budgeted with the old widths.
+    d.mig_delta = want;
+    d.ghost_w = e->dist_reach + 2.f * want + e->dist_hyst;
+    d.vert_w = d.ghost_w + e->dist_reach;
+    d.mig_reach = d.vert_w + 2.f * e->dist_reach + 1.f;
+    e->dist_retunes += 1;
+    drop_step_graph(e);
+    for (auto& kg : e->halo_graph) {   // (captured launches carry the Dist by value)
+        if (kg.exec) (void)hipGraphExecDestroy(kg.exec);
+        kg.exec = nullptr;
+    }
+    if (changed_out) *changed_out = 1;
     return 0;
 }
 

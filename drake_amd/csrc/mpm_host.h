@@ -133,6 +133,14 @@ struct mpm_engine {
     // zone allows that much (MPM_DIST_DRIFT).  Wider bands: fewer migrations, more ghost particles to advance.
     float dist_drift_target = getenv("MPM_DIST_DRIFT") ? std::max(.06f, (float)atof(getenv("MPM_DIST_DRIFT"))) : .5f;
     float dist_longest_edge = 0.f;        // cells, from the mesh handed to AddQRCloth
+    // bands from the mesh are RE-TUNED at migrations (mpm_dist_retune): the drift budget follows the speed the ranks
+    // measure, so that a migration is due every dist_target_interval substeps or so -- wide bands for a cloth that moves
+    // along x, narrow ones (few ghosts) for one that does not.  MPM_DIST_RETUNE=0 keeps the bands of mpm_dist_init.
+    bool dist_auto = false;               // the bands came from the mesh
+    bool dist_retune = getenv("MPM_DIST_RETUNE") ? atoi(getenv("MPM_DIST_RETUNE")) != 0 : true;
+    float dist_reach = 0.f, dist_hyst = 0.f, dist_delta_max = 0.f;   // cells: a face's reach, the hysteresis, the zone's limit
+    float dist_target_interval = getenv("MPM_DIST_INTERVAL") ? std::max(2.f, (float)atof(getenv("MPM_DIST_INTERVAL"))) : 16.f;
+    uint32_t dist_retunes = 0;
     // share of the ranks' common quiet-time estimate after which they migrate again (the estimate is ballistic, elastic
     // forces are not in it); MPM_MIG_SAFETY
     float mig_safety = getenv("MPM_MIG_SAFETY") ? std::min(1.f, std::max(.05f, (float)atof(getenv("MPM_MIG_SAFETY")))) : .5f;

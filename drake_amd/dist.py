@@ -314,6 +314,8 @@ class DomainChain(HaloChain):
         t_est = migration_safety() * (t_all if t_all >= 0.0 else 0.0)   # (NaN -> 0)
         self.mig_budget = min(t_est, max(4.0 * self.last_dt, 2.0 * self.mig_elapsed))
         self.mig_elapsed = 0.0
+        if hasattr(self.e, "dist_retune"):   # (band widths for the migrations to come; the same on every rank)
+            self.e.dist_retune(t_all, self.last_dt)
 
     def migration_due(self, dt: float) -> bool:
         self.last_dt = dt

@@ -467,6 +467,7 @@ typedef struct {
     float longest_edge_cells;
     uint32_t slot_resizes;                      /* re-allocations of the rank's slot space (1 = mpm_dist_init's own) */
     uint32_t migrations;                        /* mpm_dist_migrate_pack calls so far */
+    uint32_t retunes;                           /* times mpm_dist_retune changed the band widths */
 } mpm_dist_geometry_t;
 MPM_API int mpm_dist_get_geometry(mpm_handle_t h, mpm_dist_geometry_t *out);
 /* Slot space of a partitioned rank = factor x what it holds after the partition (default 1.5, or MPM_DIST_HEADROOM;
@@ -479,6 +480,13 @@ MPM_API int mpm_dist_set_headroom(mpm_handle_t h, float factor);
  * the minimum over all of them and migrate again when a share of it has passed (mpm_chain_enable_migration with
  * every = 0 does exactly that: ncclAllReduce(min), half of the common estimate). */
 MPM_API int mpm_dist_migration_quiet_time(mpm_handle_t h, float *seconds_out);
+/* Bands from the mesh follow the motion: called by every rank with the ranks' COMMON estimate right after a migration
+ * (mpm_chain_substeps does it itself), this re-sizes the bands so that at the speed that estimate implies a migration is
+ * due every ~16 substeps (MPM_DIST_INTERVAL): wide bands for a cloth that moves along x, the narrowest (0.125 cells of
+ * drift: fewest ghost particles) for one that does not; within what the zone allows, in steps of an eighth of a cell.
+ * All ranks compute the same widths from the same numbers; they take effect at the next migration.  No-op for given
+ * integer bands or with MPM_DIST_RETUNE=0. */
+MPM_API int mpm_dist_retune(mpm_handle_t h, float quiet_time_all, float dt, int *changed_out);
 MPM_API size_t mpm_dist_migration_buffer_bytes(size_t capacity_particles);
 /* send_left / send_right: device buffers of mpm_dist_migration_buffer_bytes(capacity) each (both
  * required; a rank without that neighbour gets an empty one).  recv_*: what the neighbours packed, or NULL. */

@@ -44,6 +44,7 @@ def _run_world(bits, sheets, geo, steps, capacity_blocks=1024, migrate_capacity=
                    capacity_blocks=capacity_blocks, migrate_every=geo["migrate_every"], migrate_capacity=migrate_capacity,
                    device=torch.device("cuda", 0), headroom=headroom)
     roles0 = [e.dist_roles() for e in engines]
+    w.geometry_at_init = engines[min(1, world - 1)].dist_geometry()
     w.run_substeps(steps, DT, -1)
     w.sync()
     return roles0, w
@@ -122,15 +123,24 @@ def test_bench_partition_geometry_matches_single_engine(world, vx, steps):
     geo = strong_geometry(bits, world)
     assert geo["zone_blocks"] == (1 if world == 8 else 2) and geo["migrate_every"] == 0 and geo["ghost_cells"] == 0
     roles0, w = _run_world(bits, sheets, geo, steps)
-    dg = w.chains[1].e.dist_geometry()
-    # bands from the mesh: 0.44-cell lattice -> edges of 0.62 cells, reach 0.47; zone 1 leaves (2 - 0.93) / 3 cells of drift
-    assert 0.55 < dg["longest_edge_cells"] < 0.70, dg
+    dg0, dg = w.geometry_at_init, w.chains[1].e.dist_geometry()
+    # bands from the mesh: 0.44-cell lattice -> edges of 0.68 cells with the jitter, reach 0.51; a zone of one block leaves
+    # (2 - 1.02 - 0.25) / 3 cells of drift
+    assert 0.55 < dg0["longest_edge_cells"] < 0.70, dg0
     if world == 8:
         # (0.125 cells of hysteresis on either side of the vertex band)
-        assert 0.18 < dg["drift_budget_cells"] < 0.32 and dg["vertex_band_cells"] + 0.125 + dg["drift_budget_cells"] <= 2.0 + 1e-5, dg
+        assert 0.18 < dg0["drift_budget_cells"] < 0.32 and dg0["vertex_band_cells"] + 0.125 + dg0["drift_budget_cells"] <= 2.0 + 1e-5, dg0
     else:
-        # (the zone of two blocks would allow 1.6 cells; the bands are sized for MPM_DIST_DRIFT = 0.5 by default)
-        assert abs(dg["drift_budget_cells"] - 0.5) < 1e-5 and dg["vertex_band_cells"] < 2.3, dg
+        # (the zone of two blocks would allow 1.6 cells; the bands start out sized for MPM_DIST_DRIFT = 0.5)
+        assert abs(dg0["drift_budget_cells"] - 0.5) < 1e-5 and dg0["vertex_band_cells"] < 2.3, dg0
+    # ... and follow the motion (mpm_dist_retune): as wide as the zone allows for the cloth that drifts 0.1 cells per
+    # substep, the narrowest (an eighth of a cell of drift, fewest ghosts) for the one that only falls
+    if vx > 0:
+        assert dg["drift_budget_cells"] >= dg0["drift_budget_cells"] - 1e-6 and dg["retunes"] >= (0 if world == 8 else 1), (dg0, dg)
+        if world == 4:
+            assert dg["drift_budget_cells"] > 1.4, dg
+    else:
+        assert dg["retunes"] >= 1 and dg["drift_budget_cells"] <= 0.25 + 1e-6, (dg0, dg)
     pos, vel, F, per_rank = _collect(w, roles0, n, nf)
     vs = max(float(np.abs(rv).max()), 1.0)
     close(pos, rp, scale=1.0, rtol=1e-5, what=f"world x{world} (vx {vx}): positions vs single engine")
@@ -146,7 +156,7 @@ def test_bench_partition_geometry_matches_single_engine(world, vx, steps):
         end_owner = np.argmax(np.stack([pr[0] == 1 for pr in per_rank]), axis=0)
         assert np.count_nonzero(end_owner != start_owner) > n // 50
         # 0.1 cells per substep (more where the jittered lattice relaxes) against a budget of 0.24 / 0.5 cells, half of it trusted
-        assert w.migrations >= steps // 3, w.migrations
+        assert w.migrations >= (steps // 3 if world == 8 else 3), w.migrations
     else:
         # the benchmark's jitter velocities (0.01 m/s = 0.0013 cells per substep): the estimate allows hundreds of
         # substeps, the interval doubles from 4 (before substeps 0, 4, 12, 28 ...) -- and the cloth's vibration about the
@@ -154,7 +164,8 @@ def test_bench_partition_geometry_matches_single_engine(world, vx, steps):
         # (6 re-sorts in 25 substeps)
         assert w.migrations == 3, w.migrations
         for _, _, _, st in per_rank:
-            assert st["rebuilds"] <= 4, st   # Finalize, the partition, the shrink (+ at most one of the free fall)
+            # Finalize, the partition, the shrink, ONE for the ghosts that the narrower bands release (+ at most one of the free fall)
+            assert st["rebuilds"] <= 5, st
 
 
 def test_cloth_crossing_a_cut_grows_the_slot_space():
