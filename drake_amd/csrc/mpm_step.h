@@ -15,6 +15,13 @@
 #ifndef MPM_FEM_SETPRIO
 #define MPM_FEM_SETPRIO 1    // (A/B switch, round 4: no difference measured)
 #endif
+#ifndef MPM_P2G_LAZYF
+// 1 (what ships since round 4): a vertex lane gathers its force from the corner records when its group's turn comes.
+// 0: rounds 2-3, the forces of all vertices of an item in a prologue of their own (two dependent round trips and a
+// barrier that all workgroups of the launch walk through at the same time: ~6 us in which nothing else happens).
+// Same-box A/B (scratch/ab_run.py): k_p2g 48.9 -> 46.0 us (event time), with the group descriptor a group ahead 45.0.
+#define MPM_P2G_LAZYF 1
+#endif
 #ifndef MPM_G2P_PREFETCH
 #define MPM_G2P_PREFETCH 1   // 0 (experiment): a particle's position is loaded when its turn comes
 #endif
@@ -123,10 +130,9 @@ __global__ __launch_bounds__(256) void k_fem(DP p, float dt) {
 // kept per vertex slot (refreshed at every rebuild) so that a vertex needs one coalesced index
 // load and one 16-byte gather per adjacent face.
 // the force on vertex `k` (slot p.Nf + k) from the corner records of its adjacent faces
-MPM_DEV void vertex_force_value(const DP& p, const PSet& S, int k, float& f0, float& f1, float& f2) {
+MPM_DEV void vertex_force_from(const DP& p, const PSet& S, int k, int4 r0, int4 r1, float& f0, float& f1, float& f2) {
     const int s = p.Nf + k;
     f0 = f1 = f2 = 0.f;
-    const int4 r0 = S.va[0][k], r1 = S.va[1][k];
     const int rec[8] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w};
     if (p.dist.on) {
         // a face next to this vertex is missing on this rank (-3): fine for a ghost vertex, whose force
@@ -164,6 +170,36 @@ MPM_DEV void vertex_force_value(const DP& p, const PSet& S, int k, float& f0, fl
             f2 += -g.z;
         }
     }
+}
+// The same for the lanes of a wave of k_p2g, without branches in the common case: every lane gathers eight records
+// (a lane that is not a vertex comes with the adjacency of vertex 0: valid records, shared lines, result unused; an
+// empty entry reads record 0 and adds -0, which changes nothing: the sums are those of vertex_force_from to the bit).
+// Valence above 8 and faces missing on this rank take the general routine, per lane.
+MPM_DEV void vertex_force_wave(const DP& p, const PSet& S, bool vert, int k, int4 r0, int4 r1, float& f0, float& f1, float& f2) {
+    f0 = f1 = f2 = 0.f;
+    if (p.Nf <= 0) return;   // (uniform: no faces, no records)
+    const int rec[8] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w};
+    float3 g[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) g[q] = p.G3[max(rec[q], 0)];
+    bool special = rec[0] == -2;
+    if (p.dist.on) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) special |= rec[q] == -3;
+    }
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        const bool on = rec[q] >= 0;
+        f0 += on ? -g[q].x : -0.f;
+        f1 += on ? -g[q].y : -0.f;
+        f2 += on ? -g[q].z : -0.f;
+    }
+    if (__ballot(vert && special)) {
+        if (vert && special) vertex_force_from(p, S, k, r0, r1, f0, f1, f2);
+    }
+}
+MPM_DEV void vertex_force_value(const DP& p, const PSet& S, int k, float& f0, float& f1, float& f2) {
+    vertex_force_from(p, S, k, S.va[0][k], S.va[1][k], f0, f1, f2);
 }
 MPM_DEV void vertex_force(const DP& p, const PSet& S, int k) {   // ... written to p.f
     float f0, f1, f2;
@@ -326,7 +362,9 @@ MPM_DEV unsigned tile_reach_mask(int rx, int ry, int rz) {
 #define MPM_P2G_DYNAMIC 0   // 1 (experiment): the waves of a workgroup take the item's groups from an LDS counter
 #endif
 #ifndef MPM_P2G_DESC_AHEAD
-#define MPM_P2G_DESC_AHEAD 0   // 1 (experiment, no effect measured): the group descriptor alone fetched a group ahead
+// the group descriptor alone fetched a group ahead (4 registers): nothing with the vertex forces in a prologue (49.2 vs
+// 49.3 us); with the lazy forces a group's chain is descriptor -> adjacency -> corner records, and it is worth 1 us
+#define MPM_P2G_DESC_AHEAD 1
 #endif
 #ifndef MPM_P2G_PIPE2
 #define MPM_P2G_PIPE2 0      // 1 (experiment): MFMA operands fetched two steps ahead in two named register sets
@@ -446,7 +484,7 @@ __global__ __launch_bounds__(P2G_THREADS) __attribute__((amdgpu_waves_per_eu(P2G
         };
         // the force on a vertex particle from wherever the prologue left it (fused mode), or from k_vforce's p.f
         auto force_of = [&](unsigned ii, float* f) {
-#if MPM_P2G_LDSF
+#if MPM_P2G_LDSF && !MPM_P2G_LAZYF
             if (f_lds) {
                 // (face lanes come with a slot that is not a vertex of the item: any entry will do, they do not use it)
                 const unsigned k = min(ii - (unsigned)v0_item, (unsigned)(LDSF_CAP - 1));
@@ -470,6 +508,12 @@ __global__ __launch_bounds__(P2G_THREADS) __attribute__((amdgpu_waves_per_eu(P2G
             // unsigned index: lets the loads use the scalar-base + 32-bit-offset addressing form
             const unsigned any_slot = (unsigned)(nfb ? rg.x : rg.z);   // (a particle of the item: always valid)
             const unsigned ii = r.act ? (unsigned)(r.is_face ? gr.x + lane : gr.z + (lane - gf)) : any_slot;
+            // (the head of the longest chain first: adjacency -> corner records)
+            int4 va0 = make_int4(0, 0, 0, 0), va1 = va0;
+            if (MPM_P2G_LAZYF && p.fuse_vforce) {
+                const unsigned kv = r.act && !r.is_face ? ii - (unsigned)p.Nf : 0u;   // (any valid entry for the other lanes)
+                va0 = S.va[0][kv]; va1 = S.va[1][kv];
+            }
             // (one base pointer and a stride for the four planes: see DP::q_stride)
             const float4* qb = S.q[0] + ii;
             const float4 q0 = qb[0], q1 = qb[p.q_stride], q2 = qb[2 * (size_t)p.q_stride], q3 = qb[3 * (size_t)p.q_stride];
@@ -486,12 +530,21 @@ __global__ __launch_bounds__(P2G_THREADS) __attribute__((amdgpu_waves_per_eu(P2G
                 const float3 a = p.ta[fi];
                 const float3 b = *reinterpret_cast<const float3*>(&S.fq[0][fi]);   // F[:,2], see pack_F
                 r.ta[0] = a.x; r.ta[1] = a.y; r.ta[2] = a.z; r.tb[0] = b.x; r.tb[1] = b.y; r.tb[2] = b.z;
-                force_of(vi, r.frc);
+                if (MPM_P2G_LAZYF && p.fuse_vforce) {
+                    const bool vert = r.act && !r.is_face;
+                    vertex_force_wave(p, S, vert, (int)ii - p.Nf, va0, va1, r.frc[0], r.frc[1], r.frc[2]);
+                    // (p.f is what a caller downloads as the forces: between the substeps of one batch nobody can)
+                    if (vert && !p.lean_g2p) {
+                        p.f[0][ii] = r.frc[0]; p.f[1][ii] = r.frc[1]; p.f[2][ii] = r.frc[2];
+                    }
+                } else {
+                    force_of(vi, r.frc);
+                }
             }
             return r;
         };
         Raw cur;
-        if (p.fuse_vforce && fa.w > 0) {
+        if (!MPM_P2G_LAZYF && p.fuse_vforce && fa.w > 0) {
             // the vertex forces of this item (k_vforce's job: one launch less per substep), handed to the particle
             // loop below in LDS -- the barrier orders the two; vertices beyond the LDS array go through p.f
             for (int sv = v0_item + tid; sv < irg.w; sv += P2G_THREADS) {
