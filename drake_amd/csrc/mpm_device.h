@@ -41,6 +41,7 @@ constexpr unsigned ERR_SLABS = 32u;     // the re-sort made more work items than
 //   fq[3] = (0, v0, v1, v2)   v* = slots of the three corner vertices (int bits)
 //   c8    = C8 of the face particle as GridToParticle left it: k_fem reads it here instead of fetching
 //           the 16-byte record q[1] for 4 useful bytes (q[1].w carries the same value for ParticleToGrid)
+constexpr unsigned VF_MARK = 0x7FB0A5C3u;   // (a NaN pattern: see DP::VF)
 struct PSet {
     float4* q[4];
     int* pid;      // slot -> original particle id ([faces | verts] order of Finalize)
@@ -155,7 +156,6 @@ struct DP {
     int dbg;               // MPM_DBG environment variable (kernel ablation switches, 0 in production)
     float dx, dxinv, Dinv;
     unsigned q_stride, f_stride;   // distance (elements) between the planes PSet::q[0..3] and f[0..2] (one allocation each)
-    int fuse_vforce;       // 1: k_p2g computes the vertex forces of its work items itself (no k_vforce launch)
     int gated;             // bit 0: this substep was enqueued without the re-sort launches and returns at once when it finds a
                            // re-sort pending; bit 1: it returns at once when the slab pool has overflowed (every substep
                            // of mpm_run_substeps; the phase-by-phase calls cannot be repeated by the engine).  Either way it
@@ -182,6 +182,18 @@ struct DP {
                            // floats of fq[0] (see pack_F)
     float3* G3;            // faces: G3[face slot * 3 + c] = force triple the face exerts on corner c (negated when
                            // applied); 12-byte records: 36 B written per face and one dwordx3 gather per adjacency
+    // Single-domain engines: the same triples where the VERTEX looks for them, VF[(j * vf_stride + vertex slot - Nf) * 3 ..],
+    // j = the rank of the face among the faces around that vertex (ascending original face id: the order of the sum).
+    // j is a property of the mesh: the three corners' ranks ride in fq[3].x (4 bits each, 15 = this corner's vertex has
+    // more than 8 faces: the triple goes to G3 and the vertex walks the CSR).  k_fem scatters 3 x 12 bytes per face; a
+    // vertex reads its eight triples in ONE round trip of loads that coalesce over the vertex lanes of a wave (through
+    // va and G3 it was two dependent round trips and eight scattered gathers).  Eight planes by rank, not one 96-byte row
+    // per vertex: neighbouring faces then write neighbouring 12-byte entries of the same plane (rows cost k_fem +6 us,
+    // planes +0.8; k_p2g -3.2 either way).  Entries past a vertex's valence hold zeros (written at every re-sort: adding
+    // -0 changes nothing); VF_MARK in the first word of plane 0 = "walk the CSR".  A partitioned domain keeps va + G3
+    // (its faces come and go).
+    float* VF;
+    unsigned vf_stride;    // entries per plane (the vertex slot capacity)
     float* f[3];           // vertices: internal force
     // topology (original ids)
     const int* idx_orig[3];  // face -> original particle ids of its corners

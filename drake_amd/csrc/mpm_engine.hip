@@ -185,19 +185,27 @@ static void launch_fem(mpm_engine* e, float dt) {
     launch_fem_faces(e, dt);
     launch_fem_vertices(e);
 }
-static void launch_p2g(mpm_engine* e, float dt) {
-    TraceRange tr(e->dp.fuse_vforce ? "mpm:ParticleToGrid (+ vertex forces)" : "mpm:ParticleToGrid");
-    hipLaunchKernelGGL(k_p2g, dim3(e->g_tile), dim3(P2G_THREADS), 0, e->stream, e->dp, dt);
+// `forces`: where k_p2g's vertex lanes find the force on their vertex (the kernel's template parameter: 0 = in p.f,
+// k_vforce ran; 1 / 2 = summed inside the kernel)
+static void launch_p2g(mpm_engine* e, float dt, int forces = 0) {
+    TraceRange tr(forces ? "mpm:ParticleToGrid (+ vertex forces)" : "mpm:ParticleToGrid");
+    const dim3 g(e->g_tile), b(P2G_THREADS);
+    if (forces == 1) hipLaunchKernelGGL(k_p2g<1>, g, b, 0, e->stream, e->dp, dt);
+    else if (forces == 2) hipLaunchKernelGGL(k_p2g<2>, g, b, 0, e->stream, e->dp, dt);
+    else hipLaunchKernelGGL(k_p2g<0>, g, b, 0, e->stream, e->dp, dt);
     e->last_tile_kernel = 1;
 }
+// the vertex forces inside k_p2g: from the vertices' rows of DP::VF in a single-domain engine, through va + G3 in a
+// partitioned one; a mesh with a vertex of more than eight faces keeps the k_vforce launch
+static int fused_forces(const mpm_engine* e) { return e->dp.dist.on ? 2 : (e->max_valence <= 8 ? 1 : 0); }
 // FEM faces, then P2G with the vertex forces of every work item computed inside it (no k_vforce launch): the
 // batched substeps use this; the phase-by-phase calls keep the two FEM kernels, whose forces a caller may read
 static void launch_fem_p2g(mpm_engine* e, float dt) {
     e->last_dt = dt;
     launch_fem_faces(e, dt);
-    e->dp.fuse_vforce = 1;
-    launch_p2g(e, dt);
-    e->dp.fuse_vforce = 0;
+    const int forces = fused_forces(e);
+    if (!forces) launch_fem_vertices(e);
+    launch_p2g(e, dt, forces);
 }
 // (`p` may carry a halo class restriction)
 static void launch_g2p_with(mpm_engine* e, DP p, float dt) {
@@ -305,6 +313,8 @@ int mpm_finalize(mpm_handle_t e) {
     }
     ALLOC(p.ta, std::max<size_t>(nf, 1), true);   // (k_p2g's vertex lanes read element 0 when an item has no face)
     ALLOC(p.G3, 3 * nf, true);
+    ALLOC(p.VF, 24 * std::max<size_t>(nv, 1), true);   // (k_p2g's face lanes read row 0)
+    p.vf_stride = (unsigned)std::max<size_t>(nv, 1);
     {
         float* base = nullptr;
         ALLOC(base, 3 * (size_t)p.f_stride, true);
@@ -382,13 +392,10 @@ int mpm_finalize(mpm_handle_t e) {
         for (size_t f = 0; f < nf; ++f) col[f] = e->h_idx[f * 3 + d] + (int)nf;
         H2D(e, idx_orig[d], col.data(), nf * 4);
     }
-    if (nf) {
-        // corner vertex slots ride in fq[3].yzw (slot == original id before the first sort)
-        std::vector<int> f3(nf * 4, 0);
-        for (size_t f = 0; f < nf; ++f)
-            for (int d = 0; d < 3; ++d) f3[f * 4 + 1 + d] = e->h_idx[f * 3 + d] + (int)nf;
-        H2D(e, S0.fq[3], f3.data(), nf * 16);
-    }
+    // corner vertex slots ride in fq[3].yzw (slot == original id before the first sort)
+    std::vector<int> f3(nf * 4, 0);
+    for (size_t f = 0; f < nf; ++f)
+        for (int d = 0; d < 3; ++d) f3[f * 4 + 1 + d] = e->h_idx[f * 3 + d] + (int)nf;
     // vertex -> (face, corner) adjacency, ascending face id
     std::vector<int> off(nv + 1, 0), fc(3 * nf);
     for (size_t k = 0; k < 3 * nf; ++k) off[e->h_idx[k] + 1]++;
@@ -396,8 +403,18 @@ int mpm_finalize(mpm_handle_t e) {
     {
         std::vector<int> fill(off.begin(), off.end() - 1);
         for (size_t f = 0; f < nf; ++f)
-            for (int c = 0; c < 3; ++c) fc[fill[e->h_idx[f * 3 + c]]++] = (int)(f << 2) | c;
+            for (int c = 0; c < 3; ++c) {
+                const int v = e->h_idx[f * 3 + c];
+                const int at = fill[v]++;
+                fc[at] = (int)(f << 2) | c;
+                // the face's rank around this corner's vertex (DP::VF), 15 = the vertex has more than eight faces
+                const int rank = off[v + 1] - off[v] <= 8 ? at - off[v] : 15;
+                f3[f * 4] |= rank << (4 * c);
+            }
     }
+    if (nf) H2D(e, S0.fq[3], f3.data(), nf * 16);
+    e->max_valence = 0;
+    for (size_t v = 0; v < nv; ++v) e->max_valence = std::max(e->max_valence, off[v + 1] - off[v]);
     H2D(e, adj_off, off.data(), (nv + 1) * 4);
     if (nf) H2D(e, adj_fc, fc.data(), 3 * nf * 4);
 
@@ -432,7 +449,7 @@ int mpm_finalize(mpm_handle_t e) {
     }
     if (p.dbg) {
         int a = 0, b = 0, c = 0;
-        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, k_p2g, P2G_THREADS, 0);
+        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, k_p2g<1>, P2G_THREADS, 0);
         (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, k_g2p, G2P_THREADS, 0);
         (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&c, k_fem, 256, 0);
         std::fprintf(stderr, "[mpm_hip] resident workgroups per CU: p2g %d, g2p %d, fem %d\n", a, b, c);
@@ -1343,9 +1360,11 @@ int mpm_profile_substeps(mpm_handle_t e, int n, float dt, int bc, float* phase_m
         // (as in mpm_run_substeps: the vertex forces are part of k_p2g; this phase is empty)
         HIP_TRY(hipEventRecord(q[3], e->stream));
         e->dp.lean_g2p = s + 1 < n && !e->dp.dist.on;   // (as in mpm_run_substeps)
-        e->dp.fuse_vforce = 1;
-        launch_p2g(e, dt);
-        e->dp.fuse_vforce = 0;
+        {
+            const int forces = fused_forces(e);
+            if (!forces) launch_fem_vertices(e);
+            launch_p2g(e, dt, forces);
+        }
         HIP_TRY(hipEventRecord(q[4], e->stream));
         launch_grid(e, gc);
         HIP_TRY(hipEventRecord(q[5], e->stream));

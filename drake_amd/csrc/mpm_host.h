@@ -118,6 +118,7 @@ struct mpm_engine {
         hipGraphExec_t exec = nullptr;
         std::vector<uint64_t> key;
     } halo_graph[2];
+    int max_valence = 0;       // most faces around one vertex of the mesh (Finalize): above 8, k_vforce stays (see fused_forces)
     int last_tile_kernel = 0;  // 1 = P2G, 2 = G2P (see launch_p2g)
     // launch geometry
     unsigned g_np = 0, g_nf = 0, g_nv = 0, g_tile = 0, g_grid = 0;

@@ -38,7 +38,7 @@ __global__ __launch_bounds__(256) void k_init_faces(DP p) {
     pack_F(Q, S.fq[0][i], S.fq[1][i], S.f8[i]);
     S.c8[i] = 0.f;
     S.fq[2][i] = make_float4(Di[0], Di[1], Di[3], v4);   // (Di[2] = -0 / det: Dm is upper triangular)
-    S.fq[3][i] = make_float4(0.f, f3.y, f3.z, f3.w);
+    S.fq[3][i] = f3;   // (.x: the corners' ranks around their vertices, see DP::VF)
     const_cast<float4*>(p.dm_orig)[i] = make_float4(Di[0], Di[1], Di[2], Di[3]);
     p.G3[(size_t)i * 3].x = v4;
 }
@@ -58,7 +58,10 @@ __global__ __launch_bounds__(256) void k_init_vertex_adjacency(DP p) {
             rec[q] = (fc >> 2) * 3 + (fc & 3);
         }
     }
-    if (e1 - e0 > 8) rec[0] = -2;
+    if (e1 - e0 > 8) {
+        rec[0] = -2;
+        p.VF[(size_t)k * 3] = __uint_as_float(VF_MARK);
+    }
     p.set[0].va[0][k] = make_int4(rec[0], rec[1], rec[2], rec[3]);
     p.set[0].va[1][k] = make_int4(rec[4], rec[5], rec[6], rec[7]);
 }

@@ -605,6 +605,15 @@ __global__ __launch_bounds__(256) void k_rb_finish(DP p) {
             }
             D.va[0][j - p.Nf] = r0;
             D.va[1][j - p.Nf] = r1;
+            // the row of force triples at the new slot: zeros where this vertex has no face (k_fem rewrites the others
+            // before anything reads them), or the mark that sends the vertex to the CSR (DP::VF)
+            {
+                const size_t kk = (size_t)(j - p.Nf);
+                const float3 z = make_float3(0.f, 0.f, 0.f);
+                *reinterpret_cast<float3*>(p.VF + kk * 3) = r0.x == -2 ? make_float3(__uint_as_float(VF_MARK), 0.f, 0.f) : z;
+#pragma unroll
+                for (int q = 1; q < 8; ++q) *reinterpret_cast<float3*>(p.VF + ((size_t)q * p.vf_stride + kk) * 3) = z;
+            }
         } else {
             // (face slot * 3 + corner) of the adjacent faces, ascending original face id; -3 = a face
             // that is not on this rank (legal around a ghost vertex, an error around an owned one)

@@ -15,13 +15,6 @@
 #ifndef MPM_FEM_SETPRIO
 #define MPM_FEM_SETPRIO 1    // (A/B switch, round 4: no difference measured)
 #endif
-#ifndef MPM_P2G_LAZYF
-// 1 (what ships since round 4): a vertex lane gathers its force from the corner records when its group's turn comes.
-// 0: rounds 2-3, the forces of all vertices of an item in a prologue of their own (two dependent round trips and a
-// barrier that all workgroups of the launch walk through at the same time: ~6 us in which nothing else happens).
-// Same-box A/B (scratch/ab_run.py): k_p2g 48.9 -> 46.0 us (event time), with the group descriptor a group ahead 45.0.
-#define MPM_P2G_LAZYF 1
-#endif
 #ifndef MPM_G2P_PREFETCH
 #define MPM_G2P_PREFETCH 1   // 0 (experiment): a particle's position is loaded when its turn comes
 #endif
@@ -120,9 +113,34 @@ __global__ __launch_bounds__(256) void k_fem(DP p, float dt) {
         Gm[d * 3 + 1] = a * g01 + b * g11;
         Gm[d * 3 + 2] = b * g12;
     }
-    // one 12-byte record per corner: a vertex fetches its triple with a single dwordx3 load
+    // one 12-byte record per corner, at its place among the vertex's entries (DP::VF) -- or, in a partitioned domain and for
+    // a vertex with more than eight faces, in the face's own triple of G3
+    const unsigned jb = (unsigned)__float_as_int(f3.x);
+    const unsigned sc[3] = {s0, s1, s2};
 #pragma unroll
-    for (int c = 0; c < 3; ++c) p.G3[(size_t)i * 3 + c] = make_float3(Gm[c], Gm[3 + c], Gm[6 + c]);
+    for (int c = 0; c < 3; ++c) {
+        const float3 rec = make_float3(Gm[c], Gm[3 + c], Gm[6 + c]);
+        const unsigned j = (jb >> (4 * c)) & 15u;
+        if (!p.dist.on && j < 8u)
+            *reinterpret_cast<float3*>(p.VF + ((size_t)j * p.vf_stride + (sc[c] - (unsigned)p.Nf)) * 3u) = rec;
+        else
+            p.G3[(size_t)i * 3 + c] = rec;
+    }
+}
+
+// the force on vertex k from its entries of DP::VF; false = they say "walk the CSR" (nothing usable summed)
+MPM_DEV bool vertex_force_vf(const DP& p, int k, float& f0, float& f1, float& f2) {
+    float3 g[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) g[j] = *reinterpret_cast<const float3*>(p.VF + ((size_t)j * p.vf_stride + (size_t)k) * 3);
+    f0 = f1 = f2 = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {   // (ascending original face id, as vertex_force_from; an empty entry adds -0)
+        f0 += -g[j].x;
+        f1 += -g[j].y;
+        f2 += -g[j].z;
+    }
+    return __float_as_uint(g[0].x) != VF_MARK;
 }
 
 // Vertex force = - sum over adjacent (face, corner) of that corner's force triple, summed in
@@ -171,10 +189,10 @@ MPM_DEV void vertex_force_from(const DP& p, const PSet& S, int k, int4 r0, int4 
         }
     }
 }
-// The same for the lanes of a wave of k_p2g, without branches in the common case: every lane gathers eight records
-// (a lane that is not a vertex comes with the adjacency of vertex 0: valid records, shared lines, result unused; an
-// empty entry reads record 0 and adds -0, which changes nothing: the sums are those of vertex_force_from to the bit).
-// Valence above 8 and faces missing on this rank take the general routine, per lane.
+// The same for the lanes of a wave of k_p2g (partitioned domain), without branches in the common case: every lane gathers
+// eight records (a lane that is not a vertex comes with the adjacency of vertex 0: valid records, shared lines, result
+// unused; an empty entry reads record 0 and adds -0, which changes nothing: the sums are those of vertex_force_from to the
+// bit).  Valence above 8 and faces missing on this rank take the general routine, per lane.
 MPM_DEV void vertex_force_wave(const DP& p, const PSet& S, bool vert, int k, int4 r0, int4 r1, float& f0, float& f1, float& f2) {
     f0 = f1 = f2 = 0.f;
     if (p.Nf <= 0) return;   // (uniform: no faces, no records)
@@ -199,6 +217,7 @@ MPM_DEV void vertex_force_wave(const DP& p, const PSet& S, bool vert, int k, int
     }
 }
 MPM_DEV void vertex_force_value(const DP& p, const PSet& S, int k, float& f0, float& f1, float& f2) {
+    if (!p.dist.on && vertex_force_vf(p, k, f0, f1, f2)) return;
     vertex_force_from(p, S, k, S.va[0][k], S.va[1][k], f0, f1, f2);
 }
 MPM_DEV void vertex_force(const DP& p, const PSet& S, int k) {   // ... written to p.f
@@ -211,7 +230,7 @@ MPM_DEV void vertex_force(const DP& p, const PSet& S, int k) {   // ... written 
 }
 
 // (the phase-by-phase API and the partitioned-domain chains; mpm_run_substeps lets k_p2g do this per work
-// item, see DP::fuse_vforce)
+// item, see k_p2g's FORCES)
 __global__ __launch_bounds__(256) void k_vforce(DP p) {
     if (gated_out(p)) return;
     const unsigned nva = (unsigned)p.ctl->nva;
@@ -253,20 +272,12 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 #ifndef MPM_P2G_STG16
 #define MPM_P2G_STG16 1
 #endif
-#ifndef MPM_P2G_LDSF
-#define MPM_P2G_LDSF 1   // vertex forces handed over in LDS: 8 MB less traffic per substep for 0.3 us (measured)
-#endif
 #if MPM_P2G_STG16
 // staged floats per particle: the 13 columns of Y that carry numbers, then fx, fy, fz in the three columns of the
 // mass component that Y leaves empty (their products are discarded by a zero in `fac`)
 constexpr int STG = 16, STG_FX = 13;
 #else
 constexpr int STG = 20, STG_FX = 16;  // 16 columns of Y, fx, fy, fz, pad
-#endif
-#if MPM_P2G_LDSF
-// vertex forces of a work item handed from its prologue to its particle loop in LDS (12 bytes per vertex; an item
-// with more vertices than this keeps the rest in p.f): what is left of the 80 KB that let two workgroups share a CU
-constexpr int LDSF_CAP = 1080;
 #endif
 
 template <int CTRL>
@@ -378,6 +389,15 @@ MPM_DEV unsigned tile_reach_mask(int rx, int ry, int rz) {
 #endif
 constexpr int P2G_WAVES = MPM_P2G_WAVES, P2G_THREADS = 64 * P2G_WAVES;
 // two workgroups per CU: 8 waves each at <= 128 VGPRs (4 per SIMD), or 10 at <= 96 (5 per SIMD; -DMPM_P2G_WAVES=10)
+// FORCES: where a vertex lane finds the internal force on its vertex.
+//   0  in p.f (k_vforce ran before this kernel: the phase-by-phase API, meshes with a vertex of more than eight faces)
+//   1  in the eight planes of DP::VF, summed here (single-domain engines: one round trip of coalesced loads)
+//   2  through va + G3, summed here (partitioned domain: two dependent round trips, eight gathers)
+// 1 and 2 save the k_vforce launch of every substep.  Rounds 2-3 computed the forces of ALL vertices of an item in a
+// prologue of their own (two dependent round trips and a barrier that every workgroup of the launch walks through at
+// the same time: ~6 us in which nothing else happens); now each vertex lane fetches them with its particle records:
+// k_p2g 48.9 -> 45.3 us (event time, same box), -> 43.9 with the group descriptor a group ahead, -> 41 with the vertex-side records (DP::VF).
+template <int FORCES>
 __global__ __launch_bounds__(P2G_THREADS) __attribute__((amdgpu_waves_per_eu(P2G_WAVES / 2, P2G_WAVES / 2))) void k_p2g(DP p, float dt) {
     if (gated_out(p)) return;
     // chain substep: the entry counters of the halo send buffers, which the k_grid<0> behind this kernel fills
@@ -389,11 +409,8 @@ __global__ __launch_bounds__(P2G_THREADS) __attribute__((amdgpu_waves_per_eu(P2G
 #if MPM_P2G_DYNAMIC
     __shared__ int s_next;   // next unclaimed group of the item (waves take groups as they finish, not round robin)
 #endif
-#if MPM_P2G_LDSF
-    __shared__ float s_frc[LDSF_CAP * 3];
-    static_assert(sizeof(long long) * TILE_N * 4 + sizeof(float) * P2G_WAVES * (64 + 8) * STG + sizeof(float) * LDSF_CAP * 3 + 4 <= 81920,
+    static_assert(sizeof(long long) * TILE_N * 4 + sizeof(float) * P2G_WAVES * (64 + 8) * STG + 4 <= 81920,
                   "two workgroups per CU need <= 80 KB of LDS each");
-#endif
     Ctl* ctl = p.ctl;
     const PSet& S = p.set[ctl->cur];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -468,13 +485,6 @@ __global__ __launch_bounds__(P2G_THREADS) __attribute__((amdgpu_waves_per_eu(P2G
         // at the last rebuild: a group usually spans two base cells.
         const int ngroups = fa.w;
         const int4* groups = p.home_groups + fb.w;
-        const int4 irg = p.item_rng[q];
-        const int v0_item = irg.z;   // first vertex slot of the item
-#if MPM_P2G_LDSF
-        // (uniform over the workgroup: an item with more vertices than the LDS array holds -- a mesh with far more
-        // vertices than faces -- hands all its forces over through p.f)
-        const bool f_lds = p.fuse_vforce && irg.w - irg.z <= LDSF_CAP;
-#endif
         struct Raw {
             float x[3], v[3], vol, C[9];
             // tau factors a, b (faces) and force (vertices) in separate registers: merging them
@@ -482,16 +492,8 @@ __global__ __launch_bounds__(P2G_THREADS) __attribute__((amdgpu_waves_per_eu(P2G
             float ta[3], tb[3], frc[3];
             bool act, is_face;
         };
-        // the force on a vertex particle from wherever the prologue left it (fused mode), or from k_vforce's p.f
+        // the force on a vertex particle from k_vforce's p.f
         auto force_of = [&](unsigned ii, float* f) {
-#if MPM_P2G_LDSF && !MPM_P2G_LAZYF
-            if (f_lds) {
-                // (face lanes come with a slot that is not a vertex of the item: any entry will do, they do not use it)
-                const unsigned k = min(ii - (unsigned)v0_item, (unsigned)(LDSF_CAP - 1));
-                f[0] = s_frc[k * 3]; f[1] = s_frc[k * 3 + 1]; f[2] = s_frc[k * 3 + 2];
-                return;
-            }
-#endif
             const float* fbase = p.f[0] + ii;
 #pragma unroll
             for (int d = 0; d < 3; ++d) f[d] = fbase[(size_t)d * p.f_stride];
@@ -510,7 +512,7 @@ __global__ __launch_bounds__(P2G_THREADS) __attribute__((amdgpu_waves_per_eu(P2G
             const unsigned ii = r.act ? (unsigned)(r.is_face ? gr.x + lane : gr.z + (lane - gf)) : any_slot;
             // (the head of the longest chain first: adjacency -> corner records)
             int4 va0 = make_int4(0, 0, 0, 0), va1 = va0;
-            if (MPM_P2G_LAZYF && p.fuse_vforce) {
+            if (FORCES == 2) {
                 const unsigned kv = r.act && !r.is_face ? ii - (unsigned)p.Nf : 0u;   // (any valid entry for the other lanes)
                 va0 = S.va[0][kv]; va1 = S.va[1][kv];
             }
@@ -530,40 +532,22 @@ __global__ __launch_bounds__(P2G_THREADS) __attribute__((amdgpu_waves_per_eu(P2G
                 const float3 a = p.ta[fi];
                 const float3 b = *reinterpret_cast<const float3*>(&S.fq[0][fi]);   // F[:,2], see pack_F
                 r.ta[0] = a.x; r.ta[1] = a.y; r.ta[2] = a.z; r.tb[0] = b.x; r.tb[1] = b.y; r.tb[2] = b.z;
-                if (MPM_P2G_LAZYF && p.fuse_vforce) {
-                    const bool vert = r.act && !r.is_face;
+                const bool vert = r.act && !r.is_face;
+                if (FORCES == 1) {
+                    vertex_force_vf(p, vert ? (int)ii - p.Nf : 0, r.frc[0], r.frc[1], r.frc[2]);   // (vertex 0 for the other lanes: valid memory)
+                } else if (FORCES == 2) {
                     vertex_force_wave(p, S, vert, (int)ii - p.Nf, va0, va1, r.frc[0], r.frc[1], r.frc[2]);
-                    // (p.f is what a caller downloads as the forces: between the substeps of one batch nobody can)
-                    if (vert && !p.lean_g2p) {
-                        p.f[0][ii] = r.frc[0]; p.f[1][ii] = r.frc[1]; p.f[2][ii] = r.frc[2];
-                    }
                 } else {
                     force_of(vi, r.frc);
+                }
+                // (p.f is what a caller downloads as the forces: between the substeps of one batch nobody can)
+                if (FORCES != 0 && vert && !p.lean_g2p) {
+                    p.f[0][ii] = r.frc[0]; p.f[1][ii] = r.frc[1]; p.f[2][ii] = r.frc[2];
                 }
             }
             return r;
         };
         Raw cur;
-        if (!MPM_P2G_LAZYF && p.fuse_vforce && fa.w > 0) {
-            // the vertex forces of this item (k_vforce's job: one launch less per substep), handed to the particle
-            // loop below in LDS -- the barrier orders the two; vertices beyond the LDS array go through p.f
-            for (int sv = v0_item + tid; sv < irg.w; sv += P2G_THREADS) {
-#if MPM_P2G_LDSF
-                float f0, f1, f2;
-                vertex_force_value(p, S, sv - p.Nf, f0, f1, f2);
-                const int k = sv - v0_item;
-                if (f_lds) {
-                    s_frc[k * 3] = f0; s_frc[k * 3 + 1] = f1; s_frc[k * 3 + 2] = f2;
-                }
-                // (p.f is what a caller downloads as the forces: between the substeps of one batch nobody can)
-                if (!f_lds || !p.lean_g2p) {
-                    p.f[0][sv] = f0; p.f[1][sv] = f1; p.f[2][sv] = f2;
-                }
-#else
-                vertex_force(p, S, sv - p.Nf);
-#endif
-            }
-        }
         __syncthreads();
         unsigned mymask = 0;
         bool halo_bad = false;

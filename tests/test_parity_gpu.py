@@ -141,6 +141,81 @@ def test_trajectory_with_sorts_and_rebuilds():
     assert np.array_equal(im[pid_g], np.arange(pid_g.size))
 
 
+def _fan_sheet(n_rim, radius, centre, z, seed):
+    """A disc of n_rim triangles around a hub vertex: the hub has n_rim faces around it."""
+    ang = 2.0 * np.pi * np.arange(n_rim) / n_rim
+    pos = np.zeros((n_rim + 1, 3), np.float32)
+    pos[0] = (centre[0], centre[1], z)
+    pos[1:, 0] = centre[0] + radius * np.cos(ang)
+    pos[1:, 1] = centre[1] + radius * np.sin(ang)
+    pos[1:, 2] = z
+    idx = np.stack([np.zeros(n_rim, np.int32), 1 + np.arange(n_rim, dtype=np.int32),
+                    1 + (np.arange(n_rim, dtype=np.int32) + 1) % n_rim], -1).reshape(-1)
+    rng = np.random.default_rng(seed)
+    vel = (0.3 * rng.standard_normal(pos.shape)).astype(np.float32)
+    return pos, vel, idx
+
+
+def test_vertex_with_more_than_eight_faces():
+    """The vertex-force gather keeps eight adjacent (face, corner) records per vertex; a vertex with more walks the
+    adjacency CSR (vertex_force_from).  Such a mesh also takes a different route through a batched substep: the forces
+    of its vertices are not summed inside k_p2g from the per-vertex records k_fem scatters (DP::VF), k_vforce is launched
+    (fused_forces, mpm_engine.hip), and the faces around the hub write their triples to G3.  A fan of 12 faces next to a
+    regular sheet, against the oracle, phase by phase and batched, across re-sorts."""
+    from drake_amd import scenes
+    A = _A()
+    dx = 1.0 / 64
+
+    def sheets():
+        reg = scenes.cloth_stack(1, 14, 6, z0=0.5, side=0.2, seed=3, vel_amp=0.3)
+        return list(reg) + [_fan_sheet(12, 0.9 * dx, (0.5, 0.5), 0.5 + 3 * dx, 5), _fan_sheet(8, 0.8 * dx, (0.42, 0.55), 0.5 + 3 * dx, 6)]
+
+    o, g1 = build_pair(sheets=sheets())
+    _, g2 = build_pair(sheets=sheets())
+    vel = o.vel.copy()
+    vel[:, 0] += 6.0           # a cell every third substep: re-sorts on the way
+    o.vel[:] = vel
+    for g in (g1, g2):
+        g.upload_particle_state(None, vel)
+    n = 9
+    for _ in range(n):
+        o.substep(DT, -1, sort=False)
+        g2.rebuild_mapping(False)
+        g2.calc_fem_state_and_force(DT)
+        g2.particle_to_grid(DT)
+        g2.update_grid(-1)
+        g2.grid_to_particle(DT)
+    g1.run_substeps(4, DT, -1)
+    g1.run_substeps(n - 4, DT, -1)
+    so = o.state_in_original_order()
+    sc = natural_scales(o, DT)
+    for g, what in ((g1, "batched"), (g2, "phase calls")):
+        st = g.stats()
+        assert st["error_flags"] == 0 and st["rebuilds"] >= 2, st
+        pid = g.download(A.PIDS)
+        x, v = np.empty_like(so["pos"]), np.empty_like(so["vel"])
+        x[pid], v[pid] = g.download(A.POSITIONS), g.download(A.VELOCITIES)
+        close(x, so["pos"], scale=1.0, what=f"fan mesh, {what}: pos")
+        close(v, so["vel"], scale=max(sc["vel"], 6.0), rtol=3 * RTOL, what=f"fan mesh, {what}: vel")
+    # the forces a caller downloads after CalcFemStateAndForce, hub and rim, on a state one substep old
+    # (one substep in: the rest state has no forces to compare)
+    o3, g3 = build_pair(sheets=sheets())
+    o3.substep(DT, -1, sort=False)
+    g3.substep(DT, -1)
+    o3.rebuild_mapping(False)
+    o3.calc_fem_state_and_force(DT)
+    g3.rebuild_mapping(False)
+    g3.calc_fem_state_and_force(DT)
+    pid = g3.download(A.PIDS)
+    f = np.empty_like(o3.forces)
+    f[pid] = g3.download(A.FORCES)
+    fo = np.empty_like(o3.forces)
+    fo[o3.pids] = o3.forces
+    assert np.abs(fo).max() > 0
+    # (the natural scale of a nodal force is vol * E / edge -- unit strain --, as in test_phase_by_phase)
+    close(f, fo, scale=max(float(np.abs(fo).max()), float(np.max(o3.vol)) * 4e5 * 64), what="fan mesh: vertex forces")
+
+
 def test_substep_equals_phase_calls():
     A = _A()
     o, g1 = build_pair(seed=11)
