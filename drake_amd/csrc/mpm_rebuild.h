@@ -559,10 +559,8 @@ __global__ __launch_bounds__(256) void k_rb_finish(DP p) {
     const PSet& S = p.set[c->cur];
     const PSet& D = p.set[c->cur ^ 1];
     // move the particle records into their sorted slots (16-byte gathers, coalesced 16-byte stores);
-    // every slot reference inside a record (face -> corner vertices, vertex -> adjacent face
-    // corners) is translated through dst_of, whose accesses stay local because mesh neighbours
-    // were neighbours in the old order too
-    auto moved = [&](int rec) { return rec < 0 ? rec : p.dst_of[(unsigned)rec / 3u] * 3 + (int)((unsigned)rec % 3u); };
+    // the slot references inside a face's record (its corner vertices) are translated through dst_of, whose
+    // accesses stay local because mesh neighbours were neighbours in the old order too
     const int nf_out = c->nfa_new, total_out = nf_out + c->nva_new;
     for (unsigned idx = i0; idx < (unsigned)total_out; idx += gs) {
         const unsigned j = (unsigned)active_slot(p, (int)idx, nf_out);
@@ -598,19 +596,16 @@ __global__ __launch_bounds__(256) void k_rb_finish(DP p) {
             D.f8[j] = S.f8[i];
             D.c8[j] = S.c8[i];
         } else if (!p.dist.on) {
-            int4 r0 = S.va[0][i - p.Nf], r1 = S.va[1][i - p.Nf];
-            if (r0.x != -2) {
-                r0 = make_int4(moved(r0.x), moved(r0.y), moved(r0.z), moved(r0.w));
-                r1 = make_int4(moved(r1.x), moved(r1.y), moved(r1.z), moved(r1.w));
-            }
-            D.va[0][j - p.Nf] = r0;
-            D.va[1][j - p.Nf] = r1;
-            // the row of force triples at the new slot: zeros where this vertex has no face (k_fem rewrites the others
-            // before anything reads them), or the mark that sends the vertex to the CSR (DP::VF)
+            // A single-domain engine finds the forces on its vertices in DP::VF and has no use for va (a partitioned
+            // one rebuilds it from the topology by original id, below).  The vertex's entries at the new slot: zeros
+            // where it has no face (k_fem rewrites the others before anything reads them), or the mark that sends a
+            // vertex with more than eight faces to the CSR.
+            const int vo = pid - p.NfG;
+            const bool many = p.adj_off[vo + 1] - p.adj_off[vo] > 8;
             {
                 const size_t kk = (size_t)(j - p.Nf);
                 const float3 z = make_float3(0.f, 0.f, 0.f);
-                *reinterpret_cast<float3*>(p.VF + kk * 3) = r0.x == -2 ? make_float3(__uint_as_float(VF_MARK), 0.f, 0.f) : z;
+                *reinterpret_cast<float3*>(p.VF + kk * 3) = many ? make_float3(__uint_as_float(VF_MARK), 0.f, 0.f) : z;
 #pragma unroll
                 for (int q = 1; q < 8; ++q) *reinterpret_cast<float3*>(p.VF + ((size_t)q * p.vf_stride + kk) * 3) = z;
             }

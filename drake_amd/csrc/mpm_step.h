@@ -143,6 +143,22 @@ MPM_DEV bool vertex_force_vf(const DP& p, int k, float& f0, float& f1, float& f2
     return __float_as_uint(g[0].x) != VF_MARK;
 }
 
+// more than 8 faces around vertex k: walk the original adjacency (the triples of these faces' corners are in G3)
+MPM_DEV void vertex_force_csr(const DP& p, const PSet& S, int k, float& f0, float& f1, float& f2) {
+    const int s = p.Nf + k;
+    f0 = f1 = f2 = 0.f;
+    const int vo = S.pid[s] - p.NfG;
+    for (int e = p.adj_off[vo]; e < p.adj_off[vo + 1]; ++e) {
+        const int fc = p.adj_fc[e];
+        const int fs = p.imap[fc >> 2];
+        const float3 g = fs >= 0 ? p.G3[(size_t)fs * 3 + (fc & 3)]
+                                 : make_float3(S.q[0][s].w > 0.f ? __int_as_float(0x7FC00000) : 0.f, 0.f, 0.f);
+        f0 += -g.x;
+        f1 += -g.y;
+        f2 += -g.z;
+    }
+}
+
 // Vertex force = - sum over adjacent (face, corner) of that corner's force triple, summed in
 // ascending original face id (the order sequential atomics would produce).  The adjacency is
 // kept per vertex slot (refreshed at every rebuild) so that a vertex needs one coalesced index
@@ -176,17 +192,7 @@ MPM_DEV void vertex_force_from(const DP& p, const PSet& S, int k, int4 r0, int4 
             }
         }
     } else {
-        // more than 8 faces around this vertex: walk the original adjacency
-        const int vo = S.pid[s] - p.NfG;
-        for (int e = p.adj_off[vo]; e < p.adj_off[vo + 1]; ++e) {
-            const int fc = p.adj_fc[e];
-            const int fs = p.imap[fc >> 2];
-            const float3 g = fs >= 0 ? p.G3[(size_t)fs * 3 + (fc & 3)]
-                                     : make_float3(S.q[0][s].w > 0.f ? __int_as_float(0x7FC00000) : 0.f, 0.f, 0.f);
-            f0 += -g.x;
-            f1 += -g.y;
-            f2 += -g.z;
-        }
+        vertex_force_csr(p, S, k, f0, f1, f2);
     }
 }
 // The same for the lanes of a wave of k_p2g (partitioned domain), without branches in the common case: every lane gathers
@@ -217,7 +223,10 @@ MPM_DEV void vertex_force_wave(const DP& p, const PSet& S, bool vert, int k, int
     }
 }
 MPM_DEV void vertex_force_value(const DP& p, const PSet& S, int k, float& f0, float& f1, float& f2) {
-    if (!p.dist.on && vertex_force_vf(p, k, f0, f1, f2)) return;
+    if (!p.dist.on) {   // (a single-domain engine does not keep va: DP::VF, k_rb_finish)
+        if (!vertex_force_vf(p, k, f0, f1, f2)) vertex_force_csr(p, S, k, f0, f1, f2);
+        return;
+    }
     vertex_force_from(p, S, k, S.va[0][k], S.va[1][k], f0, f1, f2);
 }
 MPM_DEV void vertex_force(const DP& p, const PSet& S, int k) {   // ... written to p.f
