@@ -38,10 +38,10 @@ def test_committed_pmc_summary_feeds_the_roofline_traffic():
         assert rec["hbm_bytes_per_launch"] > 0 and rec["launches"] > 0
         assert abs(rec["hbm_bytes_per_launch"] - (rec["read_bytes"] + rec["write_bytes"])) < 1.0
         assert b.measured_traffic(k, "cloth_1m") == rec["hbm_bytes_per_launch"]
-    assert b.measured_traffic("mpm::k_p2g", "some_other_config") is None
+    assert b.measured_traffic(b.KERNEL_OF["p2g"], "some_other_config") is None
     # the dominant kernel must not move (much) more than its algorithmic bytes
     ab = b.algorithmic_bytes(999952, 663552, 336400, 64 * 972)
-    assert t["kernels"]["mpm::k_p2g"]["hbm_bytes_per_launch"] < 1.2 * (ab["p2g"] + ab["vforce"])
+    assert t["kernels"][b.KERNEL_OF["p2g"]]["hbm_bytes_per_launch"] < 1.2 * (ab["p2g"] + ab["vforce"])
 
 
 def test_gpus_flag_launches_that_many_ranks():
