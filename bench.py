@@ -33,7 +33,7 @@ KERNEL_OF = dict(fem="mpm::k_fem", vforce="mpm::k_vforce", p2g="mpm::k_p2g<1>", 
 def algorithmic_bytes(np_, nf, nv, ncells):
     """bytes one substep has to move, fp32, one pass per phase.
     The reference's FEM kernel (200 B/face + 36 B/vertex) is two kernels here (k_fem, and k_vforce or -- in
-    mpm_run_substeps -- the prologue of k_p2g's work items)."""
+    mpm_run_substeps -- the vertex lanes of k_p2g, which sum the triples k_fem left them)."""
     fem = 200 * nf
     vforce = 36 * nv
     p2g = 116 * np_ + 16 * ncells
@@ -588,7 +588,7 @@ def main():
                     substep_frac=job_bytes / (el / args.steps) / 1e9 / (HBM_PEAK_GBS * world), phase_ms=phases,
                     phase_note="separate pass with HIP events around every phase (mpm_profile_substeps); it launches the "
                                "re-sort kernels with every substep, the timed run with every fourth (gated substeps); "
-                               "the vertex-force slot is empty (k_p2g does that work per work item): its interval is "
+                               "the vertex-force slot is empty (the vertex lanes of k_p2g do that work): its interval is "
                                "the cost of an event pair; phase_ms are raw intervals")
 
     if rank == 0:
