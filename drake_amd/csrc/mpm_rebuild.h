@@ -210,6 +210,12 @@ constexpr int MAX_BITMAP_WORDS = 8192;  // 2^18 blocks = 256^3 cells
 __global__ __launch_bounds__(1024) void k_rb_tables(DP p) {
     Ctl* c = p.ctl;
     if (!c->need_rebuild) return;
+#if MPM_DIAG
+    const unsigned long long tk0 = __builtin_readcyclecounter();
+    auto stamp = [&](int k) { if (threadIdx.x == 0 && (diag_flags(p) & 512)) p.dbgbuf[k] = __builtin_readcyclecounter() - tk0; };
+#else
+    auto stamp = [&](int) {};
+#endif
     if (blockIdx.x > 0) {
         // B (all other workgroups, concurrently with workgroup 0): per non-empty block and type,
         // exclusive prefix of its 64 cell counters, in place.  16 lanes per row (one int4 each).
@@ -236,6 +242,7 @@ __global__ __launch_bounds__(1024) void k_rb_tables(DP p) {
             const int s0 = inc - tot;
             *cc = make_int4(s0, s0 + q.x, s0 + q.x + q.y, s0 + q.x + q.y + q.z);
         }
+        if (blockIdx.x == 1) stamp(15);
         return;
     }
     __shared__ int s_w[16];
@@ -250,6 +257,7 @@ __global__ __launch_bounds__(1024) void k_rb_tables(DP p) {
     for (unsigned k = tid; k < c->n_home; k += 1024) p.lut_home[p.home_block[k]] = -1;
     for (unsigned k = tid; k < c->n_active; k += 1024) p.lut_act[p.act_block[k]] = -1;
     __syncthreads();
+    stamp(0);
 
     // A: home list = set bits of the non-empty bitmap, in ascending order
     int mine = 0;
@@ -275,6 +283,7 @@ __global__ __launch_bounds__(1024) void k_rb_tables(DP p) {
     }
     for (unsigned w = tid; w < words; w += 1024) s_bits[w] = 0;
     __syncthreads();
+    stamp(1);
 
     // A2: particle ranges = prefix sums of the block counts over the home list
     const unsigned hpt = (n_home + 1023u) / 1024u;
@@ -306,12 +315,21 @@ __global__ __launch_bounds__(1024) void k_rb_tables(DP p) {
         }
     }
 
+    stamp(2);
     // C: union of the 27-neighbourhoods in an LDS bitmap
-    for (unsigned w = tid; w < n_home * 27; w += 1024) {
-        const int nbid = neighbor_block(p.home_block[w / 27], (int)(w % 27), p.nb);
-        if (nbid >= 0) atomicOr(&s_bits[nbid >> 5], 1u << (nbid & 31));
+    // (a thread per home block, its 27 neighbours in a row: ONE global load in front of the LDS atomics -- a thread per
+    // (block, neighbour) pair put a dependent load in front of every atomic, 15 round trips in sequence per thread:
+    // 21k of this workgroup's 58k cycles at 1M particles)
+    for (unsigned h = tid; h < n_home; h += 1024) {
+        const uint32_t hb = p.home_block[h];
+#pragma unroll
+        for (int o = 0; o < 27; ++o) {
+            const int nbid = neighbor_block(hb, o, p.nb);
+            if (nbid >= 0) atomicOr(&s_bits[nbid >> 5], 1u << (nbid & 31));
+        }
     }
     __syncthreads();
+    stamp(3);
 
     // D: active list = set bits, ascending
     mine = 0;
@@ -337,6 +355,7 @@ __global__ __launch_bounds__(1024) void k_rb_tables(DP p) {
     }
     if (tid < 64) s_bucket[tid] = 0;
     __syncthreads();
+    stamp(4);
 
     // F: work items.  A home block with more than item_groups wave groups is split evenly into
     // several items (so a dense pile still spreads over the CUs); the static round-robin order is
@@ -379,6 +398,7 @@ __global__ __launch_bounds__(1024) void k_rb_tables(DP p) {
             n_items = p.capS;
         }
         __syncthreads();
+        stamp(5);
         auto bucket_of = [&](unsigned w) {
             const int4 d = p.item_desc[w];
             return 63 - min(d.z - d.y, 63);  // descending group count
@@ -396,6 +416,7 @@ __global__ __launch_bounds__(1024) void k_rb_tables(DP p) {
         __syncthreads();
         for (unsigned w = tid; w < n_items; w += 1024) p.item_order[atomicAdd(&s_bucket[bucket_of(w)], 1)] = w;
         __syncthreads();
+        stamp(6);
         // the same, flattened in processing order (see DP::item_flat)
         for (unsigned q = tid; q < n_items; q += 1024) {
             const unsigned w = p.item_order[q];
@@ -408,6 +429,7 @@ __global__ __launch_bounds__(1024) void k_rb_tables(DP p) {
         }
     }
 
+    stamp(7);
     if (tid == 0) {
         c->n_home = n_home;
         c->n_active = n_active;
