@@ -317,15 +317,25 @@ __global__ __launch_bounds__(1024) void k_rb_tables(DP p) {
 
     stamp(2);
     // C: union of the 27-neighbourhoods in an LDS bitmap
-    // (a thread per home block, its 27 neighbours in a row: ONE global load in front of the LDS atomics -- a thread per
-    // (block, neighbour) pair put a dependent load in front of every atomic, 15 round trips in sequence per thread:
-    // 21k of this workgroup's 58k cycles at 1M particles)
+    // (a thread per home block, its 27 neighbours in a row: ONE global load, ONE Morton decode and nine bit spreads per
+    // block.  A thread per (block, neighbour) pair put a dependent load in front of every LDS atomic and decoded and
+    // encoded a Morton id per pair -- ~80 vector instructions each: 21k of this workgroup's 58k cycles at 1M particles)
     for (unsigned h = tid; h < n_home; h += 1024) {
-        const uint32_t hb = p.home_block[h];
+        int bx, by, bz;
+        block_coords(p.home_block[h], bx, by, bz);
+        uint32_t sx[3], sy[3], sz[3];
+        bool vx[3], vy[3], vz[3];
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            const int x = bx + d - 1, y = by + d - 1, z = bz + d - 1;
+            vx[d] = x >= 0 && x < p.nb; vy[d] = y >= 0 && y < p.nb; vz[d] = z >= 0 && z < p.nb;
+            sx[d] = spread3((uint32_t)x) * 4u; sy[d] = spread3((uint32_t)y) * 2u; sz[d] = spread3((uint32_t)z);
+        }
 #pragma unroll
         for (int o = 0; o < 27; ++o) {
-            const int nbid = neighbor_block(hb, o, p.nb);
-            if (nbid >= 0) atomicOr(&s_bits[nbid >> 5], 1u << (nbid & 31));
+            const int a = o / 9, b = (o / 3) % 3, cz = o % 3;
+            const uint32_t nbid = sx[a] + sy[b] + sz[cz];   // (= neighbor_block(home_block[h], o, nb))
+            if (vx[a] && vy[b] && vz[cz]) atomicOr(&s_bits[nbid >> 5], 1u << (nbid & 31));
         }
     }
     __syncthreads();
@@ -478,37 +488,47 @@ __global__ __launch_bounds__(256) void k_rb_scatter(DP p) {
                 const int nf = rg.y - rg.x, nv = rg.w - rg.z, total = nf + nv;
                 const int ng = (total + 63) >> 6;
                 int4* out = p.home_groups + group_pool_offset(p, rg, h);
-                // split of merged position m into (faces before it, vertices before it)
+                // split of merged position m into (faces before it, vertices before it).  The 64 cell prefixes of the
+                // block sit in the lanes of the wave (lane = cell): the binary search walks registers (six shuffles)
+                // instead of memory (six dependent round trips per boundary -- the waves that build groups were this
+                // kernel's critical path).  Every lane of the wave calls it.
+                const int pf = cf[lane], pv = cv[lane], ps = pf + pv;
                 auto split = [&](int m, int& f, int& v) {
-                    if (m >= total) { f = nf; v = nv; return; }
                     int lo = 0, hi = 63;                       // last cell whose start is <= m
-                    while (lo < hi) {
+#pragma unroll
+                    for (int it = 0; it < 6; ++it) {
                         const int mid = (lo + hi + 1) >> 1;
-                        if (cf[mid] + cv[mid] <= m) lo = mid; else hi = mid - 1;
+                        const int s_mid = __shfl(ps, mid);
+                        if (lo < hi) { if (s_mid <= m) lo = mid; else hi = mid - 1; }
                     }
-                    const int fs = cf[lo], vs = cv[lo];
-                    const int fe = lo < 63 ? cf[lo + 1] : nf;
+                    const int fs = __shfl(pf, lo), vs = __shfl(pv, lo);
+                    const int fnext = __shfl(pf, min(lo + 1, 63));
+                    const int fe = lo < 63 ? fnext : nf;
                     const int r = m - (fs + vs);
                     if (r < fe - fs) { f = fs + r; v = vs; } else { f = fe; v = vs + (r - (fe - fs)); }
+                    if (m >= total) { f = nf; v = nv; }
                 };
-                for (int g = (int)lane; g < ng; g += 64) {
+                for (int g0 = 0; g0 < ng; g0 += 64) {
+                    const int g = g0 + (int)lane;
                     int f0, v0, f1, v1;
                     split(g * 64, f0, v0);
                     split(g * 64 + 64, f1, v1);
-                    out[g] = make_int4(rg.x + f0, rg.x + f1, rg.z + v0, rg.z + v1);
+                    if (g < ng) out[g] = make_int4(rg.x + f0, rg.x + f1, rg.z + v0, rg.z + v1);
                 }
                 if (lane == 0) p.home_ngroups[h] = ng;
                 // the slot ranges of the block's work items (what the tile kernels would otherwise fetch from the
                 // first and the last group of the item, behind one more dependent load)
                 const int2 hi = p.home_items[h];
-                for (int k = (int)lane; k < hi.y; k += 64) {
+                const unsigned n_items = p.ctl->n_items;
+                for (int k0 = 0; k0 < hi.y; k0 += 64) {
+                    const int k = k0 + (int)lane;
                     const unsigned it = (unsigned)(hi.x + k);
-                    if (it >= p.ctl->n_items) continue;   // (slab pool exhausted: the item is not scheduled)
-                    const int4 d = p.item_desc[it];
+                    const bool on = k < hi.y && it < n_items;   // (slab pool exhausted: the item is not scheduled)
+                    const int4 d = on ? p.item_desc[it] : make_int4(0, 0, 0, 0);
                     int f0, v0, f1, v1;
                     split(d.y * 64, f0, v0);
                     split(d.z * 64, f1, v1);
-                    p.item_rng[p.item_pos[it]] = make_int4(rg.x + f0, rg.x + f1, rg.z + v0, rg.z + v1);
+                    if (on) p.item_rng[p.item_pos[it]] = make_int4(rg.x + f0, rg.x + f1, rg.z + v0, rg.z + v1);
                 }
             }
         }
@@ -623,13 +643,16 @@ __global__ __launch_bounds__(256) void k_rb_finish(DP p) {
             // where it has no face (k_fem rewrites the others before anything reads them), or the mark that sends a
             // vertex with more than eight faces to the CSR.
             const int vo = pid - p.NfG;
-            const bool many = p.adj_off[vo + 1] - p.adj_off[vo] > 8;
+            const int valence = p.adj_off[vo + 1] - p.adj_off[vo];
             {
                 const size_t kk = (size_t)(j - p.Nf);
                 const float3 z = make_float3(0.f, 0.f, 0.f);
-                *reinterpret_cast<float3*>(p.VF + kk * 3) = many ? make_float3(__uint_as_float(VF_MARK), 0.f, 0.f) : z;
+                if (valence > 8) *reinterpret_cast<float3*>(p.VF + kk * 3) = make_float3(__uint_as_float(VF_MARK), 0.f, 0.f);
+                // (entries below the valence are k_fem's to write, before anything reads them: for the inner vertices
+                // of a cloth only planes 6 and 7 are touched here)
 #pragma unroll
-                for (int q = 1; q < 8; ++q) *reinterpret_cast<float3*>(p.VF + ((size_t)q * p.vf_stride + kk) * 3) = z;
+                for (int q = 0; q < 8; ++q)
+                    if (q >= valence) *reinterpret_cast<float3*>(p.VF + ((size_t)q * p.vf_stride + kk) * 3) = z;
             }
         } else {
             // (face slot * 3 + corner) of the adjacent faces, ascending original face id; -3 = a face
