@@ -42,6 +42,12 @@ constexpr unsigned ERR_SLABS = 32u;     // the re-sort made more work items than
 //   c8    = C8 of the face particle as GridToParticle left it: k_fem reads it here instead of fetching
 //           the 16-byte record q[1] for 4 useful bytes (q[1].w carries the same value for ParticleToGrid)
 constexpr unsigned VF_MARK = 0x7FB0A5C3u;   // (a NaN pattern: see DP::VF)
+// entry (rank j, vertex k) of DP::VF, in units of 12-byte entries: vertices in chunks of 32, a chunk's eight rank planes
+// next to each other (8 x 384 bytes = 24 full 128-byte lines)
+constexpr unsigned VF_CHUNK = 32;
+__host__ __device__ inline size_t vf_entry(unsigned k, unsigned j) {
+    return (size_t)(k / VF_CHUNK) * (8u * VF_CHUNK) + j * VF_CHUNK + (k % VF_CHUNK);
+}
 struct PSet {
     float4* q[4];
     int* pid;      // slot -> original particle id ([faces | verts] order of Finalize)
@@ -182,18 +188,19 @@ struct DP {
                            // floats of fq[0] (see pack_F)
     float3* G3;            // faces: G3[face slot * 3 + c] = force triple the face exerts on corner c (negated when
                            // applied); 12-byte records: 36 B written per face and one dwordx3 gather per adjacency
-    // Single-domain engines: the same triples where the VERTEX looks for them, VF[(j * vf_stride + vertex slot - Nf) * 3 ..],
+    // Single-domain engines: the same triples where the VERTEX looks for them, VF[vf_entry(vertex slot - Nf, j) * 3 ..],
     // j = the rank of the face among the faces around that vertex (ascending original face id: the order of the sum).
     // j is a property of the mesh: the three corners' ranks ride in fq[3].x (4 bits each, 15 = this corner's vertex has
     // more than 8 faces: the triple goes to G3 and the vertex walks the CSR).  k_fem scatters 3 x 12 bytes per face; a
     // vertex reads its eight triples in ONE round trip of loads that coalesce over the vertex lanes of a wave (through
-    // va and G3 it was two dependent round trips and eight scattered gathers).  Eight planes by rank, not one 96-byte row
-    // per vertex: neighbouring faces then write neighbouring 12-byte entries of the same plane (rows cost k_fem +6 us,
-    // planes +0.8; k_p2g -3.2 either way).  Entries past a vertex's valence hold zeros (written at every re-sort: adding
-    // -0 changes nothing); VF_MARK in the first word of plane 0 = "walk the CSR".  A partitioned domain keeps va + G3
-    // (its faces come and go).
+    // va and G3 it was two dependent round trips and eight scattered gathers).  Layout: chunks of 32 vertices, in a
+    // chunk eight planes by rank of 32 entries each (vf_entry): neighbouring faces write neighbouring entries of the
+    // same plane, a vertex's eight entries are 384 bytes apart (immediate offsets of one address).  One 96-byte row per
+    // vertex cost k_fem +6 us (a store instruction touching 64 rows), eight planes over the whole vertex range the
+    // same +0.7 as this.  Entries past a vertex's valence hold zeros (written at every re-sort: adding -0 changes
+    // nothing); VF_MARK in the first word of plane 0 = "walk the CSR".  A partitioned domain keeps va + G3 (its faces
+    // come and go).
     float* VF;
-    unsigned vf_stride;    // entries per plane (the vertex slot capacity)
     float* f[3];           // vertices: internal force
     // topology (original ids)
     const int* idx_orig[3];  // face -> original particle ids of its corners

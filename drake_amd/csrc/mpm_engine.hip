@@ -313,8 +313,7 @@ int mpm_finalize(mpm_handle_t e) {
     }
     ALLOC(p.ta, std::max<size_t>(nf, 1), true);   // (k_p2g's vertex lanes read element 0 when an item has no face)
     ALLOC(p.G3, 3 * nf, true);
-    ALLOC(p.VF, 24 * std::max<size_t>(nv, 1), true);   // (k_p2g's face lanes read row 0)
-    p.vf_stride = (unsigned)std::max<size_t>(nv, 1);
+    ALLOC(p.VF, 3 * vf_entry((unsigned)nv + VF_CHUNK, 0), true);   // (whole chunks; k_p2g's face lanes read vertex 0's entries)
     {
         float* base = nullptr;
         ALLOC(base, 3 * (size_t)p.f_stride, true);

@@ -60,7 +60,7 @@ __global__ __launch_bounds__(256) void k_init_vertex_adjacency(DP p) {
     }
     if (e1 - e0 > 8) {
         rec[0] = -2;
-        p.VF[(size_t)k * 3] = __uint_as_float(VF_MARK);
+        p.VF[vf_entry((unsigned)k, 0) * 3] = __uint_as_float(VF_MARK);
     }
     p.set[0].va[0][k] = make_int4(rec[0], rec[1], rec[2], rec[3]);
     p.set[0].va[1][k] = make_int4(rec[4], rec[5], rec[6], rec[7]);

@@ -647,12 +647,12 @@ __global__ __launch_bounds__(256) void k_rb_finish(DP p) {
             {
                 const size_t kk = (size_t)(j - p.Nf);
                 const float3 z = make_float3(0.f, 0.f, 0.f);
-                if (valence > 8) *reinterpret_cast<float3*>(p.VF + kk * 3) = make_float3(__uint_as_float(VF_MARK), 0.f, 0.f);
+                if (valence > 8) *reinterpret_cast<float3*>(p.VF + vf_entry((unsigned)kk, 0) * 3) = make_float3(__uint_as_float(VF_MARK), 0.f, 0.f);
                 // (entries below the valence are k_fem's to write, before anything reads them: for the inner vertices
                 // of a cloth only planes 6 and 7 are touched here)
 #pragma unroll
                 for (int q = 0; q < 8; ++q)
-                    if (q >= valence) *reinterpret_cast<float3*>(p.VF + ((size_t)q * p.vf_stride + kk) * 3) = z;
+                    if (q >= valence) *reinterpret_cast<float3*>(p.VF + vf_entry((unsigned)kk, (unsigned)q) * 3) = z;
             }
         } else {
             // (face slot * 3 + corner) of the adjacent faces, ascending original face id; -3 = a face

@@ -122,7 +122,7 @@ __global__ __launch_bounds__(256) void k_fem(DP p, float dt) {
         const float3 rec = make_float3(Gm[c], Gm[3 + c], Gm[6 + c]);
         const unsigned j = (jb >> (4 * c)) & 15u;
         if (!p.dist.on && j < 8u)
-            *reinterpret_cast<float3*>(p.VF + (size_t)(j * p.vf_stride + (sc[c] - (unsigned)p.Nf)) * 3u) = rec;   // (8 x slots < 2^32)
+            *reinterpret_cast<float3*>(p.VF + vf_entry(sc[c] - (unsigned)p.Nf, j) * 3u) = rec;
         else
             p.G3[(size_t)i * 3 + c] = rec;
     }
@@ -130,13 +130,11 @@ __global__ __launch_bounds__(256) void k_fem(DP p, float dt) {
 
 // the force on vertex k from its entries of DP::VF; false = they say "walk the CSR" (nothing usable summed)
 MPM_DEV bool vertex_force_vf(const DP& p, int k, float& f0, float& f1, float& f2) {
-    // (plane bases are uniform: scalar registers; one 32-bit byte offset for all eight loads)
-    const char* base = reinterpret_cast<const char*>(p.VF);
-    const size_t plane = (size_t)p.vf_stride * 12u;
-    const unsigned off = (unsigned)k * 12u;
+    // (one address for all eight loads: the planes of a chunk are 384 bytes apart, an immediate offset)
+    const float* e0 = p.VF + vf_entry((unsigned)k, 0) * 3;
     float3 g[8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) g[j] = *reinterpret_cast<const float3*>(base + (size_t)j * plane + off);
+    for (int j = 0; j < 8; ++j) g[j] = *reinterpret_cast<const float3*>(e0 + (size_t)j * VF_CHUNK * 3);
     f0 = f1 = f2 = 0.f;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {   // (ascending original face id, as vertex_force_from; an empty entry adds -0)
