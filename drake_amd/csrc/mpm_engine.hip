@@ -1423,7 +1423,7 @@ int mpm_get_stats(mpm_handle_t e, mpm_stats_t* out) {
             for (int d = 0; d < 4; ++d) pb += e->bytes_of(S.fq[d]);
             for (int d = 0; d < 2; ++d) pb += e->bytes_of(S.va[d]) + e->bytes_of(p.vg[s][d]);
         }
-        pb += e->bytes_of(p.ta) + e->bytes_of(p.G3) + e->bytes_of(p.f[0]) + e->bytes_of(p.pkey) +
+        pb += e->bytes_of(p.ta) + e->bytes_of(p.G3) + e->bytes_of(p.VF) + e->bytes_of(p.f[0]) + e->bytes_of(p.pkey) +
               e->bytes_of(p.prank) + e->bytes_of(p.src_of) + e->bytes_of(p.dst_of) + e->bytes_of(p.home_groups);
         sb += e->bytes_of(p.imap) + e->bytes_of(e->d_pids_api) + e->bytes_of(e->d_apimap) + e->bytes_of(p.dist.prev);
         for (int d = 0; d < 3; ++d) sb += e->bytes_of(p.idx_orig[d]);
@@ -1634,6 +1634,8 @@ static int dist_resize(mpm_engine* e, size_t new_nf, size_t new_nv, bool first) 
         float4* dm = const_cast<float4*>(p.dm_orig);
         e->dfree(a); e->dfree(b); e->dfree(dm);
         p.adj_off = nullptr; p.adj_fc = nullptr; p.dm_orig = nullptr;
+        e->dfree(p.VF);   // (a partitioned domain finds its vertex forces through va + G3: DP::VF)
+        p.VF = nullptr;
     }
     p.Np = (int)new_np; p.Nf = (int)new_nf; p.Nv = (int)new_nv;
     p.q_stride = new_q_stride;
