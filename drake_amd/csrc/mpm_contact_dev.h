@@ -1174,9 +1174,17 @@ MPM_DEV void ct_thread_sums(const ContactDev& c, int n_dir_wg, int n_con_wg, int
     d1 = dq[0][1] + dq[1][1];
 }
 
+// the fields of the solver state the backtracking decision reads and updates, fetched once at the start of the kernel
+// (read where they are used, each is one more dependent round trip of the single workgroup that decides)
+struct CtSnap {
+    int ls_phase, iters, ls_total;
+    float E0;
+};
+MPM_DEV CtSnap ct_snapshot(const ContactState* st) { return CtSnap{st->ls_phase, st->iters, st->ls_total, st->E0}; }
+
 template <int NT>
 MPM_DEV void ct_decide_from(const ContactDev& c, int exact, int phase, bool deep_pass, double v, double d0, double d1,
-                            double (*s_sum)[CT_PART], double (*s_dir)[2]);
+                            double (*s_sum)[CT_PART], double (*s_dir)[2], CtSnap sn);
 
 template <int NT>
 MPM_DEV void ct_decide(const ContactDev& c, int n_dir_wg, int n_con_wg, int n_grid_wg, int exact, int phase,
@@ -1185,12 +1193,12 @@ MPM_DEV void ct_decide(const ContactDev& c, int n_dir_wg, int n_con_wg, int n_gr
     double v = 0, d0 = 0, d1 = 0;
     const bool deep_pass = !exact && st->ls_phase == 4;
     if (phase != 2) ct_thread_sums<NT>(c, n_dir_wg, n_con_wg, n_grid_wg, exact, deep_pass, v, d0, d1);
-    ct_decide_from<NT>(c, exact, phase, deep_pass, v, d0, d1, s_sum, s_dir);
+    ct_decide_from<NT>(c, exact, phase, deep_pass, v, d0, d1, s_sum, s_dir, ct_snapshot(st));
 }
 
 template <int NT>
 MPM_DEV void ct_decide_from(const ContactDev& c, int exact, int phase, bool deep_pass, double v, double d0, double d1,
-                            double (*s_sum)[CT_PART], double (*s_dir)[2]) {
+                            double (*s_sum)[CT_PART], double (*s_dir)[2], CtSnap sn) {
     ContactState* st = c.st;
     // entries 0..28: energies; 29: norm_dir; 30: dofs
     if (phase == 2) {
@@ -1273,8 +1281,8 @@ MPM_DEV void ct_decide_from(const ContactDev& c, int exact, int phase, bool deep
         return;
     }
     const float en = (float)v;
-    const bool deep = st->ls_phase == 4;
-    const float E0 = deep ? st->E0 : __shfl(en, LS_CAND);
+    const bool deep = sn.ls_phase == 4;
+    const float E0 = deep ? sn.E0 : __shfl(en, LS_CAND);
     const int lo = deep ? LS_SHALLOW : 0, hi = deep ? LS_CAND : LS_SHALLOW;
     const unsigned long long ok = __ballot(lane >= lo && lane < hi && en <= E0);
     if (!ok && !deep) {
@@ -1294,10 +1302,11 @@ MPM_DEV void ct_decide_from(const ContactDev& c, int exact, int phase, bool deep
         st->alpha = ldexpf(1.f, -j);
         st->energy = Ej;
         st->E0 = E0;
-        st->ls_total += j + 1;
-        st->iters += 1;
-        st->residual = sqrtf(nd) / dofs;   // NaN when there is no DoF: the loop stops, as in the reference
-        if (!(st->residual > c.tol) || st->iters >= c.max_iters) st->done = 2;  // finish after this update
+        st->ls_total = sn.ls_total + j + 1;
+        st->iters = sn.iters + 1;
+        const float res = sqrtf(nd) / dofs;   // NaN when there is no DoF: the loop stops, as in the reference
+        st->residual = res;
+        if (!(res > c.tol) || sn.iters + 1 >= c.max_iters) st->done = 2;  // finish after this update
     }
 }
 
@@ -1309,7 +1318,9 @@ __global__ __launch_bounds__(1024) void k_ct_decide(ContactDev c, int n_dir_wg, 
     // One workgroup, nothing but dependent round trips: the state, then the rows, then the direction records.  So the
     // rows are read BEFORE the state has arrived, as if this were the usual pass (not finished, not the deep pass of
     // the backtracking): the loads are harmless in any state, and the rare other case reads again.
-    const int done = st->done, ls_phase = st->ls_phase;
+    const int done = st->done;
+    const CtSnap sn = ct_snapshot(st);
+    const int ls_phase = sn.ls_phase;
     double v = 0, d0 = 0, d1 = 0;
     if (phase != 2) ct_thread_sums<1024>(c, n_dir_wg, n_con_wg, n_grid_wg, exact, false, v, d0, d1);
     if (done && !c.force) {
@@ -1320,7 +1331,7 @@ __global__ __launch_bounds__(1024) void k_ct_decide(ContactDev c, int n_dir_wg, 
     }
     const bool deep_pass = !exact && ls_phase == 4;
     if (deep_pass && phase != 2) ct_thread_sums<1024>(c, n_dir_wg, n_con_wg, n_grid_wg, exact, true, v, d0, d1);
-    ct_decide_from<1024>(c, exact, phase, deep_pass, v, d0, d1, s_sum, s_dir);
+    ct_decide_from<1024>(c, exact, phase, deep_pass, v, d0, d1, s_sum, s_dir, sn);
 }
 
 // G3: v -= alpha Dir (cuda_mpm_kernels.cuh:1591-1614); only nodes that see contacts have a direction
