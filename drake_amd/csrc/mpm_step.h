@@ -1138,10 +1138,12 @@ MPM_DEV int g2p_particle(const DP& p, const PSet& S, const float4* tile, unsigne
                     // instruction's operand select instead of by a move each (the compiler loads 12 bytes per node and
                     // then has no pair to select from)
                     const f32x2 z0 = {g0.z, g0.w}, z1 = {g1.z, g1.w}, z2 = {g2.z, g2.w};
-                    f32x2 t;
-                    asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(t) : "v"(W0), "v"(z0));
-                    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[1,0,1]" : "=v"(t) : "v"(W1), "v"(z1), "v"(t));
-                    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[1,0,1]" : "=v"(AA) : "v"(W2), "v"(z2), "v"(t));
+                    // (one block with its own wait states between the dependent packed operations: the compiler puts an
+                    // s_nop between its own, and must not be relied on to know what is inside an asm statement)
+                    asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]\n\ts_nop 0\n\t"
+                        "v_pk_fma_f32 %0, %3, %4, %0 op_sel_hi:[1,0,1]\n\ts_nop 0\n\t"
+                        "v_pk_fma_f32 %0, %5, %6, %0 op_sel_hi:[1,0,1]"
+                        : "=&v"(AA) : "v"(W0), "v"(z0), "v"(W1), "v"(z1), "v"(W2), "v"(z2));
                 } else {
                     const f32x2 s0 = {c0[r], c0[r]}, s1 = {c1[r], c1[r]}, s2 = {c2[r], c2[r]};
                     AA = __builtin_elementwise_fma(W2, s2, __builtin_elementwise_fma(W1, s1, W0 * s0));
