@@ -1176,7 +1176,9 @@ MPM_DEV int g2p_particle(const DP& p, const PSet& S, const float4* tile, unsigne
 #pragma unroll
     for (int r = 0; r < 3; ++r)
 #pragma unroll
-        for (int c = 0; c < 3; ++c) Cn[r * 3 + c] = ca * (sc * nC[r * 3 + c]) + cb * (sc * nC[c * 3 + r]);
+        // (an explicit fused multiply-add: left to the compiler, WHICH of the two products is fused changes from build to
+        // build with the scheduling of the code around it, and C with it in the last bit)
+        for (int c = 0; c < 3; ++c) Cn[r * 3 + c] = fmaf(ca, sc * nC[r * 3 + c], cb * (sc * nC[c * 3 + r]));
     // four 16-byte stores per particle (in this order: it keeps the kernel at 126 VGPRs without scratch)
     const float xn = x + nv[0] * dt, yn = y + nv[1] * dt, zn = z + nv[2] * dt;
     // A face particle's position and velocity are only looked at from outside (downloads): CalcFemStateAndForce
