@@ -25,8 +25,11 @@ MPM_DEV float time_to_travel(float d, float v, float a) {
     if (!(d > 0.f)) return 0.f;
     const float disc = v * v + 2.f * a * d;
     if (!(disc >= 0.f)) return __int_as_float(0x7F800000);   // turns around before it gets there
-    const float den = v + sqrtf(disc);
-    return den > 0.f ? 2.f * d / den : __int_as_float(0x7F800000);
+    // (the hardware's square root and reciprocal, one instruction and one ulp each: this is an ESTIMATE that the host
+    // halves before it uses it, computed six times per particle -- with IEEE sqrtf and division it was a third of the
+    // vector instructions of k_rb_count)
+    const float den = v + __builtin_amdgcn_sqrtf(disc);
+    return den > 0.f ? 2.f * d * __builtin_amdgcn_rcpf(den) : __int_as_float(0x7F800000);
 }
 
 __global__ __launch_bounds__(256) void k_rb_count(DP p) {
@@ -36,6 +39,15 @@ __global__ __launch_bounds__(256) void k_rb_count(DP p) {
     // the particles to sort: the active ones and what a migration appended behind them
     const int nf_in = p.ctl->nfa + p.ctl->add_f, total = nf_in + p.ctl->nva + p.ctl->add_v;
     // grid-stride over 256-particle chunks: a small fixed grid keeps the idle launches cheap
+#if MPM_DIAG
+    const unsigned long long tc0 = __builtin_readcyclecounter();
+    int stamp_it = 0;
+    auto cstamp = [&](int k) {
+        if (blockIdx.x == 1000 && threadIdx.x == 0 && (diag_flags(p) & 1024) && stamp_it < 2) p.dbgbuf[stamp_it * 4 + k] = __builtin_readcyclecounter() - tc0;
+    };
+#else
+    auto cstamp = [&](int) {};
+#endif
     for (int base = blockIdx.x * 256; base < total; base += gridDim.x * 256) {
     const int idx = base + threadIdx.x;
     const bool listed = idx < total;
@@ -56,8 +68,11 @@ __global__ __launch_bounds__(256) void k_rb_count(DP p) {
         const int s0 = __float_as_int(f3.y), s1 = __float_as_int(f3.z), s2 = __float_as_int(f3.w);
         const float4 xa = S.q[0][s0], xb = S.q[0][s1], xc = S.q[0][s2];
         const float4 a = S.q[1][s0], b = S.q[1][s1], c = S.q[1][s2];
-        xq = make_float4((xa.x + xb.x + xc.x) / 3.f, (xa.y + xb.y + xc.y) / 3.f, (xa.z + xb.z + xc.z) / 3.f, 1.f);
-        vx = (a.x + b.x + c.x) / 3.f; vy = (a.y + b.y + c.y) / 3.f; vz = (a.z + b.z + c.z) / 3.f;
+        // (the centroid as k_fem forms it -- a third as a product in the product build: an IEEE division is ten vector
+        // instructions, and there were six)
+        auto mean3 = [](float u, float v, float w) { return MPM_FEM_IEEE ? (u + v + w) / 3.f : (u + v + w) * (1.f / 3.f); };
+        xq = make_float4(mean3(xa.x, xb.x, xc.x), mean3(xa.y, xb.y, xc.y), mean3(xa.z, xb.z, xc.z), 1.f);
+        vx = mean3(a.x, b.x, c.x); vy = mean3(a.y, b.y, c.y); vz = mean3(a.z, b.z, c.z);
     } else {
         xq = S.q[0][ii];
         if (!p.dist.on) {   // (a partitioned domain bins by position and checks with every substep)
@@ -66,6 +81,9 @@ __global__ __launch_bounds__(256) void k_rb_count(DP p) {
         }
     }
     const bool valid = listed && xq.w != 0.f;   // volume 0: released by the migration, dropped here
+#if MPM_DIAG
+    if (diag_flags(p) & 1024) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); cstamp(0); }
+#endif
     // Anticipatory binning: a particle may sit up to FREE_ZONE cells outside its home block, on either side.
     // Binned by where it will be a few substeps from now (at most 1.75 cells ahead, which leaves it
     // >= 0.25 cells inside the upstream free zone today), it has up to 2 + 4 + 2 cells to travel before
@@ -123,31 +141,26 @@ __global__ __launch_bounds__(256) void k_rb_count(DP p) {
     int ret_cell = 0, ret_blk = 1, my_lead = lane, blk_leader = lane;
     unsigned long long my_same = 0ull, blk_same = 0ull;
     {
+        // Merged by RUNS of equal keys in lane order (one shuffle, one ballot), not by distinct keys (a ballot loop with
+        // one trip per distinct cell and block of the wave: 5.6k cycles per pass with eight waves per SIMD taking turns,
+        // scratch/count_diag.py).  The particles come in the order of the last sort, so a cell is one run unless its
+        // particles have moved apart; a cell in two runs gets two atomics and two rank ranges -- any unique rank inside
+        // the cell will do (the canonical order of deterministic mode is established afterwards, k_rb_canon).
+        auto runs = [&](uint32_t k, int& lead, unsigned long long& same) {
+            const uint32_t prev = (uint32_t)__shfl_up((int)k, 1);
+            const unsigned long long heads = __ballot(lane == 0 || k != prev);
+            const unsigned long long upto = heads & ((2ull << lane) - 1ull);          // heads at or below this lane
+            lead = 63 - (int)__builtin_clzll(upto);                                    // (lane 0 is a head: never zero)
+            const unsigned long long above = lane < 63 ? heads & ~((2ull << lane) - 1ull) : 0ull;
+            const int next = above ? (int)__builtin_ctzll(above) : 64;
+            same = (next == 64 ? ~0ull : ((1ull << next) - 1ull)) & ~((1ull << lead) - 1ull);
+        };
         const uint32_t ckey = valid ? (key | ((uint32_t)t << 31)) : 0xFFFFFFFFu;   // (type in the top bit: one pass for both)
-        unsigned long long todo = __ballot(valid);
-        while (todo) {
-            const int lead = __builtin_ctzll(todo);
-            const uint32_t lk = (uint32_t)__shfl((int)ckey, lead);
-            const unsigned long long same = __ballot(ckey == lk) & todo;
-            if (same & (1ull << lane)) {
-                my_lead = lead;
-                my_same = same;
-            }
-            todo &= ~same;
-        }
+        runs(ckey, my_lead, my_same);
         const uint32_t bkey = valid ? ((key >> 6) | ((uint32_t)t << 31)) : 0xFFFFFFFFu;
-        todo = __ballot(valid);
-        while (todo) {
-            const int lead = __builtin_ctzll(todo);
-            const uint32_t lb = (uint32_t)__shfl((int)bkey, lead);
-            const unsigned long long same = __ballot(bkey == lb) & todo;
-            if (same & (1ull << lane)) {
-                blk_leader = lead;
-                blk_same = same;
-            }
-            todo &= ~same;
-        }
+        runs(bkey, blk_leader, blk_same);
     }
+    cstamp(1);
     const bool cell_lead = valid && lane == my_lead, blk_lead = valid && lane == blk_leader;
     if (cell_lead) ret_cell = atomicAdd(&p.cellcnt[t][key], (int)__popcll(my_same));
     if (blk_lead) ret_blk = atomicAdd(&p.blkcnt[t][key >> 6], (int)__popcll(blk_same));
@@ -155,10 +168,16 @@ __global__ __launch_bounds__(256) void k_rb_count(DP p) {
     // (type, block) pair touches the non-empty bitmap
     if (blk_lead && ret_blk == 0) atomicOr(&p.home_bits[key >> 11], 1u << ((key >> 6) & 31u));   // (one instruction too)
     const uint32_t rank = (uint32_t)__shfl(ret_cell, my_lead) + (uint32_t)__popcll(my_same & ((1ull << lane) - 1ull));
+#if MPM_DIAG
+    if (diag_flags(p) & 1024) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); cstamp(2); }
+#endif
     if (listed) {
         p.pkey[i] = valid ? key : 0xFFFFFFFFu;
         p.prank[i] = rank;
     }
+#if MPM_DIAG
+    if (diag_flags(p) & 1024) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); cstamp(3); ++stamp_it; }
+#endif
     }
     if (!p.dist.on) {
         // minimum over the workgroup, then over 32 slots, 128 bytes apart (same-address device atomics serialise at the
