@@ -651,6 +651,14 @@ __global__ __launch_bounds__(256) void k_ct_tile(DP p, ContactDev c, int first, 
     const int st_done = c.st->done, st_phase = c.st->ls_phase;
     const float st_alpha = c.st->alpha;
     if (!c.force && (st_done || st_phase != 0)) return;   // (line search of the previous direction still running)
+#if MPM_DIAG
+    const unsigned long long tt0 = __builtin_readcyclecounter();
+    auto tstamp = [&](int k) {
+        if (blockIdx.x == 100 && threadIdx.x == 0 && (diag_flags(p) & 2048)) atomicAdd(&p.dbgbuf[k], (unsigned long long)__builtin_readcyclecounter() - tt0);
+    };
+#else
+    auto tstamp = [&](int) {};
+#endif
     __shared__ float s_part[8][CT_SEG_F];
     __shared__ __attribute__((aligned(16))) float4 s_rec[CT_TILE * 3];
     __shared__ __attribute__((aligned(16))) float4 s_nv[CT_STAGE * 27];
@@ -683,6 +691,7 @@ __global__ __launch_bounds__(256) void k_ct_tile(DP p, ContactDev c, int first, 
         const float phi0_j = c.cphi0[j], mass = c.cmass[j];
         tile_segments(key, cnt, s_seg, s_cseg, &s_nseg);
         __syncthreads();
+        tstamp(0);
         const int nseg = s_nseg;
         float wx[3], wy[3], wz[3];
         bspline3(c.cfx[j], wx);
@@ -732,6 +741,7 @@ __global__ __launch_bounds__(256) void k_ct_tile(DP p, ContactDev c, int first, 
                 v[t] += __shfl_xor(v[t], 2);
             }
         }
+        tstamp(1);
         const float vr[3] = {v[0] - crv[0], v[1] - crv[1], v[2] - crv[2]};
         float vl[3];
         mulv3(R, vr, vl);
@@ -762,6 +772,7 @@ __global__ __launch_bounds__(256) void k_ct_tile(DP p, ContactDev c, int first, 
         else piece = make_float4(WG[2], 0.f, 0.f, 0.f);
         if (lc < cnt && part < 3) s_rec[lc * 3 + part] = piece;
         __syncthreads();
+        tstamp(2);
         // ---- sums per segment: S subsets per segment, 8 / S segments at a time ----------------
         int S = 8, lgS = 3;
         while (S > 1 && nseg * S > 8) {
@@ -803,6 +814,8 @@ __global__ __launch_bounds__(256) void k_ct_tile(DP p, ContactDev c, int first, 
             }
             __syncthreads();
         }
+        tstamp(3);
+        if (blockIdx.x == 100 && threadIdx.x == 0 && (diag_flags(p) & 2048)) atomicAdd(&p.dbgbuf[15], 1ull);
     }
 }
 
