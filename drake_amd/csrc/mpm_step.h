@@ -1225,7 +1225,9 @@ __global__ __launch_bounds__(G2P_THREADS) __attribute__((amdgpu_waves_per_eu(MPM
             block_coords((uint32_t)fa.z, hx, hy, hz);
             if (!halo_item_selected(p, hx)) continue;
         }
-        const bool prof = (diag_flags(p) & 4) != 0;
+        // (bit 2: every wave of every workgroup, which perturbs the kernel; bit 12: wave 0 of eight workgroups spread over
+        // the heaviest-first order, which does not)
+        const bool prof = (diag_flags(p) & 4) != 0 || ((diag_flags(p) & 4096) != 0 && (blockIdx.x & 63u) == 5u && threadIdx.x < 64);
         unsigned long long t0 = 0, t1 = 0;
         if (prof) t0 = __builtin_readcyclecounter();
         const int4 rg = p.item_rng[q];   // the item's particles: face slots [x, y), vertex slots [z, w)
