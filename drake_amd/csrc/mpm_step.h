@@ -1071,7 +1071,7 @@ __global__ __launch_bounds__(256) void k_grid(DP p, GridColliders gc) {
 #endif
 constexpr int G2P_THREADS = MPM_G2P_THREADS, G2P_SPLIT = MPM_G2P_SPLIT;
 constexpr int LOAD_TILE_NQ = (TILE_N + G2P_THREADS - 1) / G2P_THREADS;
-MPM_DEV void load_tile(const DP& p, unsigned h, float4* tile, const float4* field, int nthreads) {
+MPM_DEV void load_tile(const DP& p, unsigned h, float4* tile, const float4* field, int nthreads, unsigned long long* stamps = nullptr) {
     const int* nbr = p.home_nbr_act + (size_t)h * 27;
     // NQ nodes per thread (TILE_N <= NQ * nthreads), branch-free and in three sweeps so that the
     // table loads and then the node loads of all are in flight together
@@ -1085,9 +1085,11 @@ MPM_DEV void load_tile(const DP& p, unsigned h, float4* tile, const float4* fiel
         a[q] = nbr[(qx >> 2) * 9 + (qy >> 2) * 3 + (qz >> 2)];
         cell[q] = ((qx & 3) << 4) + ((qy & 3) << 2) + (qz & 3);
     }
+    if (MPM_DIAG && stamps) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); stamps[0] = __builtin_readcyclecounter(); }
     float4 v[NQ];
 #pragma unroll
     for (int q = 0; q < NQ; ++q) v[q] = field[(size_t)max(a[q], 0) * 64 + cell[q]];
+    if (MPM_DIAG && stamps) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); stamps[1] = __builtin_readcyclecounter(); }
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
         const int n = (int)threadIdx.x + q * nthreads;
@@ -1240,9 +1242,14 @@ __global__ __launch_bounds__(G2P_THREADS) __attribute__((amdgpu_waves_per_eu(MPM
         int left = 0;
         unsigned i = slot_of(u < total ? u : 0);
         float4 pq = S.q[0][i];
-        load_tile(p, h, tile, p.gv, G2P_THREADS);
+        unsigned long long ts[2] = {0, 0};
+        load_tile(p, h, tile, p.gv, G2P_THREADS, prof ? ts : nullptr);
         __syncthreads();
         if (prof) t1 = __builtin_readcyclecounter();
+        if (prof && (threadIdx.x & 63) == 0 && (diag_flags(p) & 4096)) {
+            atomicAdd(&p.dbgbuf[12], ts[0] - t0);   // item descriptor + neighbour table arrived
+            atomicAdd(&p.dbgbuf[13], ts[1] - ts[0]);   // node values arrived
+        }
         int bx, by, bz;
         block_coords((uint32_t)fa.z, bx, by, bz);
         const int ox = bx * 4 - FREE_ZONE, oy = by * 4 - FREE_ZONE, oz = bz * 4 - FREE_ZONE;

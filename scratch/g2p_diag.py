@@ -13,6 +13,6 @@ n = 20
 g.run_substeps(n, 1e-3, -1)
 c = g.debug_counters()
 k = max(c[11], 1)
-print("items stamped", c[11], "per item: staging %d cycles, particle loop %d cycles, %.2f particles per thread" % (c[8] // k, c[9] // k, c[10] / k), flush=True)
+print("items stamped", c[11], "per item: staging %d cycles (descriptor + neighbour table %d, node values %d, rest = LDS writes + barrier), particle loop %d cycles, %.2f particles per thread" % (c[8] // k, c[12] // k, c[13] // k, c[9] // k, c[10] / k), flush=True)
 ph, tot = g.profile_substeps(40, 1e-3, -1)
 print("g2p event time with the stamps on: %.1f us" % (ph["g2p"] * 1e3))
