@@ -195,7 +195,7 @@ static void launch_p2g(mpm_engine* e, float dt, int forces = 0) {
     else hipLaunchKernelGGL(k_p2g<0>, g, b, 0, e->stream, e->dp, dt);
     e->last_tile_kernel = 1;
 }
-// the vertex forces inside k_p2g: from the vertices' rows of DP::VF in a single-domain engine, through va + G3 in a
+// the vertex forces inside k_p2g: from the vertices' entries of DP::VF in a single-domain engine, through va + G3 in a
 // partitioned one; a mesh with a vertex of more than eight faces keeps the k_vforce launch
 static int fused_forces(const mpm_engine* e) { return e->dp.dist.on ? 2 : (e->max_valence <= 8 ? 1 : 0); }
 // FEM faces, then P2G with the vertex forces of every work item computed inside it (no k_vforce launch): the
