@@ -190,9 +190,17 @@ static void launch_fem(mpm_engine* e, float dt) {
 static void launch_p2g(mpm_engine* e, float dt, int forces = 0) {
     TraceRange tr(forces ? "mpm:ParticleToGrid (+ vertex forces)" : "mpm:ParticleToGrid");
     const dim3 g(e->g_tile), b(P2G_THREADS);
-    if (forces == 1) hipLaunchKernelGGL(k_p2g<1>, g, b, 0, e->stream, e->dp, dt);
-    else if (forces == 2) hipLaunchKernelGGL(k_p2g<2>, g, b, 0, e->stream, e->dp, dt);
-    else hipLaunchKernelGGL(k_p2g<0>, g, b, 0, e->stream, e->dp, dt);
+    // (deterministic mode accumulates in fixed point: exact sums whatever the order of arrival, see k_p2g's EXACT)
+    const bool exact = e->deterministic || e->p2g_fixed_point;
+#define MPM_P2G_LAUNCH(F)                                                                          \
+    do {                                                                                           \
+        if (exact) hipLaunchKernelGGL((k_p2g<F, 1>), g, b, 0, e->stream, e->dp, dt);               \
+        else hipLaunchKernelGGL((k_p2g<F, 0>), g, b, 0, e->stream, e->dp, dt);                     \
+    } while (0)
+    if (forces == 1) MPM_P2G_LAUNCH(1);
+    else if (forces == 2) MPM_P2G_LAUNCH(2);
+    else MPM_P2G_LAUNCH(0);
+#undef MPM_P2G_LAUNCH
     e->last_tile_kernel = 1;
 }
 // the vertex forces inside k_p2g: from the vertices' entries of DP::VF in a single-domain engine, through va + G3 in a
@@ -448,7 +456,7 @@ int mpm_finalize(mpm_handle_t e) {
     }
     if (p.dbg) {
         int a = 0, b = 0, c = 0;
-        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, k_p2g<1>, P2G_THREADS, 0);
+        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, k_p2g<1, 0>, P2G_THREADS, 0);
         (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, k_g2p, G2P_THREADS, 0);
         (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&c, k_fem, 256, 0);
         std::fprintf(stderr, "[mpm_hip] resident workgroups per CU: p2g %d, g2p %d, fem %d\n", a, b, c);

@@ -83,6 +83,7 @@ struct mpm_engine {
     int* d_iota = nullptr;     // identity map, created on first use (views in original order)
     bool api_identity = true;
     bool deterministic = getenv("MPM_DETERMINISTIC") != nullptr;  // see mpm_set_deterministic
+    bool p2g_fixed_point = getenv("MPM_P2G_FIXED") != nullptr;    // the fixed-point LDS tile of k_p2g outside deterministic mode too (A/B)
     // native chain (mpm_chain_*): communicator, neighbours, device buffers
     struct Chain {
         void* comm = nullptr;

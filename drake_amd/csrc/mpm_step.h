@@ -414,12 +414,22 @@ constexpr int P2G_WAVES = MPM_P2G_WAVES, P2G_THREADS = 64 * P2G_WAVES;
 // prologue of their own (two dependent round trips and a barrier that every workgroup of the launch walks through at
 // the same time: ~6 us in which nothing else happens); now each vertex lane fetches them with its particle records:
 // k_p2g 48.9 -> 45.3 us (event time, same box), -> 43.9 with the group descriptor a group ahead, -> 41 with the vertex-side records (DP::VF).
-template <int FORCES>
+// EXACT: how the node sums of a work item are accumulated in its LDS tile.
+//   1  64-bit fixed point (lds_add_fixed): integer sums, exact, independent of the order in which the waves' atomics
+//      arrive -- what makes a trajectory reproducible to the bit in deterministic mode (mpm_set_deterministic), at 13
+//      vector instructions per value and cell for the conversion (a third of the per-cell epilogue);
+//   0  double precision (ds_add_f64: native on gfx950, 17-21 cycles per wave instruction, scratch/lds_atomic_bench.hip --
+//      ds_add_f32 is the one that takes 194): one conversion instruction per value.  The sum of the <= ~100 float
+//      contributions to a node is exact in double, hence independent of the order, as long as they span less than 2^29
+//      in magnitude; beyond that its LAST bit (2^-53 of the sum, rounded to float afterwards) may depend on the order.
+//      The default: without the canonical particle order of deterministic mode the order INSIDE a cell already
+//      differs from run to run at float level.
+template <int FORCES, int EXACT>
 __global__ __launch_bounds__(P2G_THREADS) __attribute__((amdgpu_waves_per_eu(P2G_WAVES / 2, P2G_WAVES / 2))) void k_p2g(DP p, float dt) {
     if (gated_out(p)) return;
     // chain substep: the entry counters of the halo send buffers, which the k_grid<0> behind this kernel fills
     if (blockIdx.x == 0 && threadIdx.x < 2 && p.halo_hdr[threadIdx.x]) p.halo_hdr[threadIdx.x][0] = 0u;
-    __shared__ long long tile[TILE_N * 4];  // (mvx, mvy, mvz, m) per node, fixed point
+    __shared__ long long tile[TILE_N * 4];  // (mvx, mvy, mvz, m) per node: fixed point, or the bits of doubles (EXACT)
     // wave-private staging: 64 particles (+8 slack rows touched by the operand prefetch)
     __shared__ __attribute__((aligned(16))) float stage_all[P2G_WAVES][(64 + 8) * STG];
     __shared__ unsigned s_mask;
@@ -467,7 +477,7 @@ __global__ __launch_bounds__(P2G_THREADS) __attribute__((amdgpu_waves_per_eu(P2G
         delta[t] = n < 27 ? (((n / 9) * TILE_W + (n / 3) % 3) * TILE_W + n % 3) * 4 + dcomp : -1;
     }
     {
-        const float fscale = (float)(dcomp == 3 ? p.fix_m : p.fix_p);
+        const float fscale = EXACT ? (float)(dcomp == 3 ? p.fix_m : p.fix_p) : 1.f;
 #pragma unroll
         for (int t = 0; t < 2; ++t)
 #pragma unroll
@@ -814,7 +824,10 @@ __global__ __launch_bounds__(P2G_THREADS) __attribute__((amdgpu_waves_per_eu(P2G
                     const float ua = (b0 ? x1 : x0) + quad_perm<0xB1>(b0 ? x0 : x1);   // row b0, lanes l and l ^ 1
                     const float ub = (b0 ? x3 : x2) + quad_perm<0xB1>(b0 ? x2 : x3);   // row 2 + b0
                     const float val = (b1 ? ub : ua) + quad_perm<0x4E>(b1 ? ua : ub);
-                    if (delta[t] >= 0 && !(diag_flags(p) & 16)) lds_add_fixed(tb + delta[t], val, fix_worst);
+                    if (delta[t] >= 0 && !(diag_flags(p) & 16)) {
+                        if (EXACT) lds_add_fixed(tb + delta[t], val, fix_worst);
+                        else __hip_atomic_fetch_add(reinterpret_cast<double*>(tb + delta[t]), (double)val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    }
                 }
                 if (prof) pc[3] += __builtin_readcyclecounter() - tq[2];
             }
@@ -834,16 +847,27 @@ __global__ __launch_bounds__(P2G_THREADS) __attribute__((amdgpu_waves_per_eu(P2G
             for (int q = 0; q < 8; ++q) atomicAdd(&p.dbgbuf[q], pc[q]);
         if (mymask && lane == 0) atomicOr(&s_mask, mymask);
         if (__ballot(out_worst > (unsigned)(TILE_W - 3)) && lane == 0) atomicOr(&ctl->error, ERR_DRIFT);
-        if (__ballot(fix_worst >= __float_as_uint(0x1p62f)) && lane == 0) atomicOr(&ctl->error, ERR_RANGE);
+        if (EXACT && __ballot(fix_worst >= __float_as_uint(0x1p62f)) && lane == 0) atomicOr(&ctl->error, ERR_RANGE);
         if (p.dist.on && __ballot(halo_bad) && lane == 0) atomicOr(&ctl->error, ERR_HALO);
         __syncthreads();
         if (prof && lane == 0) atomicAdd(&p.dbgbuf[15], (unsigned long long)__builtin_readcyclecounter() - tb0 - pc[7]);   // wave 0 at the closing barrier
         float4* out = p.slab + (size_t)item * TILE_N;
+        bool not_finite = false;
         for (int n = tid; n < TILE_N; n += P2G_THREADS) {
             const long long* q = tile + n * 4;
-            out[n] = make_float4((float)((double)q[0] * p.unfix_p), (float)((double)q[1] * p.unfix_p),
-                                 (float)((double)q[2] * p.unfix_p), (float)((double)q[3] * p.unfix_m));
+            float4 o;
+            if (EXACT) {
+                o = make_float4((float)((double)q[0] * p.unfix_p), (float)((double)q[1] * p.unfix_p),
+                                (float)((double)q[2] * p.unfix_p), (float)((double)q[3] * p.unfix_m));
+            } else {
+                const double* d = reinterpret_cast<const double*>(q);
+                o = make_float4((float)d[0], (float)d[1], (float)d[2], (float)d[3]);
+                // (NaN or infinity in a sum: what the fixed-point conversion reports per contribution)
+                not_finite |= !(fabsf(o.x) + fabsf(o.y) + fabsf(o.z) + fabsf(o.w) < __int_as_float(0x7F800000));
+            }
+            out[n] = o;
         }
+        if (!EXACT && __ballot(not_finite) && lane == 0) atomicOr(&ctl->error, ERR_RANGE);
         if (tid == 0) p.slab_mask[item] = s_mask;
         if ((diag_flags(p) & 4) && tid == 0) {
             atomicAdd(&p.dbgbuf[12], (unsigned long long)__builtin_readcyclecounter() - tb0);

@@ -16,6 +16,7 @@ __global__ __launch_bounds__(512) void k(float* out, int iters, int stride) {
         if (MODE == 2) { float t = buf[idx]; buf[idx] = t + v; }
         if (MODE == 3) __hip_atomic_fetch_add(reinterpret_cast<unsigned long long*>(buf) + ((idx & 8191) >> 1), (unsigned long long)lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         if (MODE == 4) buf[idx] = v;
+        if (MODE == 5) __hip_atomic_fetch_add(reinterpret_cast<double*>(buf) + ((idx & 8191) >> 1), (double)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         idx = (idx + 64 * stride + 4) & 8191;
     }
     __syncthreads();
@@ -43,6 +44,7 @@ int main() {
         run<2>("ds_read+add+ds_write", stride);
         run<3>("ds_add_u64", stride);
         run<4>("ds_write_b32", stride);
+        run<5>("ds_add_f64", stride);
     }
     return 0;
 }
