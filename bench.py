@@ -27,7 +27,7 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
 # kernel names as rocprofv3 prints them, per phase of mpm_profile_substeps
-KERNEL_OF = dict(fem="mpm::k_fem", vforce="mpm::k_vforce", p2g="mpm::k_p2g<1>", grid="mpm::k_grid<1>", g2p="mpm::k_g2p")
+KERNEL_OF = dict(fem="mpm::k_fem", vforce="mpm::k_vforce", p2g="mpm::k_p2g<1, 0>", grid="mpm::k_grid<1>", g2p="mpm::k_g2p")
 
 
 def algorithmic_bytes(np_, nf, nv, ncells):
