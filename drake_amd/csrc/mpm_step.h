@@ -619,11 +619,13 @@ __global__ __launch_bounds__(P2G_THREADS) __attribute__((amdgpu_waves_per_eu(P2G
             {
                 float B[9];
                 float fext[3] = {0.f, 0.f, 0.f};
+                // (explicit fused multiply-adds where a sum of products could be fused in more than one way: left to the
+                // compiler, the choice -- and the last bit of the result -- changes from build to build with the code around it)
                 if (is_face) {
 #pragma unroll
                     for (int r = 0; r < 3; ++r)
 #pragma unroll
-                        for (int c = 0; c < 3; ++c) B[r * 3 + c] = sdt * (cur.ta[r] * cur.tb[c]) + cur.C[r * 3 + c] * m;
+                        for (int c = 0; c < 3; ++c) B[r * 3 + c] = fmaf(sdt, cur.ta[r] * cur.tb[c], cur.C[r * 3 + c] * m);
                 } else {
 #pragma unroll
                     for (int r = 0; r < 9; ++r) B[r] = cur.C[r] * m;
@@ -632,10 +634,10 @@ __global__ __launch_bounds__(P2G_THREADS) __attribute__((amdgpu_waves_per_eu(P2G
                 }
 #pragma unroll
                 for (int r = 0; r < 3; ++r) {
-                    float qq = cur.v[r] * m;
-                    if (r == p.M.gravity_axis) qq += m * gdt;
+                    float qq = r == p.M.gravity_axis ? fmaf(cur.v[r], m, m * gdt) : cur.v[r] * m;
                     qq += fext[r];
-                    qq -= (B[r * 3] * st.fx[0] + B[r * 3 + 1] * st.fx[1] + B[r * 3 + 2] * st.fx[2]) * p.dx;
+                    const float dot = fmaf(B[r * 3 + 2], st.fx[2], fmaf(B[r * 3], st.fx[0], B[r * 3 + 1] * st.fx[1]));
+                    qq = fmaf(-p.dx, dot, qq);
                     Y[r * 4 + 0] = qq;
                     Y[r * 4 + 1] = B[r * 3 + 0] * p.dx;
                     Y[r * 4 + 2] = B[r * 3 + 1] * p.dx;
