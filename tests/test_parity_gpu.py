@@ -216,6 +216,35 @@ def test_vertex_with_more_than_eight_faces():
     close(f, fo, scale=max(float(np.abs(fo).max()), float(np.max(o3.vol)) * 4e5 * 64), what="fan mesh: vertex forces")
 
 
+def test_double_and_fixed_point_tiles_of_p2g_agree(monkeypatch):
+    """ParticleToGrid accumulates the node sums of a work item in LDS in double precision (the default) or in 64-bit
+    fixed point (deterministic mode; MPM_P2G_FIXED=1 selects it alone).  Both sum the float contributions of the waves
+    exactly and round once.  (The contributions themselves are float sums over the particles of a cell in the order the
+    re-sort left them, which differs between two engines outside deterministic mode: that is the rounding noise the
+    comparison allows for.)"""
+    from drake_amd import GpuMpm, scenes
+    A = _A()
+
+    def grid(fixed):
+        if fixed:
+            monkeypatch.setenv("MPM_P2G_FIXED", "1")
+        else:
+            monkeypatch.delenv("MPM_P2G_FIXED", raising=False)
+        g = GpuMpm(6)
+        scenes.populate(g, scenes.cloth_stack(3, 40, 6, z0=0.5, side=0.5, seed=21, vel_amp=1.0))
+        g.rebuild_mapping(False)
+        g.calc_fem_state_and_force(DT)
+        g.particle_to_grid(DT)
+        g.gpu_sync()
+        assert g.stats()["error_flags"] == 0
+        return g.download(A.GRID_MASSES), g.download(A.GRID_MOMENTUM)
+
+    (m_d, p_d), (m_f, p_f) = grid(False), grid(True)
+    assert float(m_d.sum()) > 0
+    for a, b, what in ((m_d, m_f, "mass"), (p_d, p_f, "momentum")):
+        close(a, b, rtol=2e-6, what=f"double vs fixed-point tile: grid {what}")
+
+
 def test_substep_equals_phase_calls():
     A = _A()
     o, g1 = build_pair(seed=11)
