@@ -127,6 +127,7 @@ SYMBOLS = [
     "mpm_dist_set_transport", "mpm_device_synchronize", "mpm_debug_owed_substeps",
     "mpm_memcpy_d2h", "mpm_memcpy_h2d", "mpm_profile_contact_iteration", "mpm_contact_frame", "mpm_halo_zone_blocks",
     "mpm_dist_get_geometry", "mpm_dist_set_headroom", "mpm_dist_migration_quiet_time", "mpm_dist_retune",
+    "mpm_dist_plan_migration", "mpm_debug_throw", "mpm_debug_fail_alloc",
 ]
 
 EXCHANGE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t)
@@ -241,6 +242,9 @@ def load_library(build: bool = True):
         "mpm_dist_set_headroom": [vp, f],
         "mpm_dist_migration_quiet_time": [vp, P(f)],
         "mpm_dist_retune": [vp, f, f, P(i)],
+        "mpm_dist_plan_migration": [vp, vp, sz, sz, sz, sz, sz, sz, sz, f, P(sz)],
+        "mpm_debug_throw": [i],
+        "mpm_debug_fail_alloc": [vp, i],
         "mpm_chain_enable_migration": [vp, i, sz],
         "mpm_dist_set_transport": [vp, EXCHANGE_FN, ALLREDUCE_FN, vp, sz],
         "mpm_grid_collider_preset": [i, f, vp, sz, P(sz)],
@@ -607,6 +611,10 @@ class GpuMpm:
         self._ck(self.lib.mpm_dist_migrate_apply(self.h, C.c_void_p(recv_left_ptr) if recv_left_ptr else None,
                                                  C.c_void_p(recv_right_ptr) if recv_right_ptr else None,
                                                  capacity_particles))
+
+    def debug_fail_alloc(self, nth: int):
+        """tests: the engine's nth device allocation from now fails like an exhausted device (0 = off)"""
+        self._ck(self.lib.mpm_debug_fail_alloc(self.h, int(nth)))
 
     def dist_set_transport(self, exchange, allreduce, zone_capacity_blocks: int = 1024):
         """Transport callbacks of the distributed contact solve (see mpm_dist_set_transport):

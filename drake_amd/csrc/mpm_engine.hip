@@ -13,6 +13,7 @@
 #include <mutex>
 #include <numeric>
 #include <string>
+#include <thread>
 #include <type_traits>
 #include <vector>
 
@@ -32,7 +33,7 @@ extern "C" {
 
 const char* mpm_last_error(void) { return g_last_error.c_str(); }
 
-int mpm_default_material(mpm_material_t* m) {
+int mpm_default_material(mpm_material_t* m) try {
     REQUIRE(m, "null material");
     m->youngs_modulus = 400000.f;
     m->poisson_ratio = .3f;
@@ -47,9 +48,9 @@ int mpm_default_material(mpm_material_t* m) {
     m->gravity_axis = 2;
     m->wall_cells = 3;
     return 0;
-}
+} MPM_CATCH_ALL
 
-int mpm_create(int domain_bits, const mpm_material_t* material, int device, mpm_handle_t* out) {
+int mpm_create(int domain_bits, const mpm_material_t* material, int device, mpm_handle_t* out) try {
     REQUIRE(out, "null handle pointer");
     REQUIRE(domain_bits >= 4 && domain_bits <= 8, "domain_bits must be in [4,8] (16^3 .. 256^3 cells)");
     int ndev = 0;
@@ -81,10 +82,10 @@ int mpm_create(int domain_bits, const mpm_material_t* material, int device, mpm_
     }
     *out = e;
     return 0;
-}
+} MPM_CATCH_ALL
 
 int mpm_add_qr_cloth(mpm_handle_t e, const float* pos, const float* vel, size_t n_verts, const int32_t* indices,
-                     size_t n_faces) {
+                     size_t n_faces) try {
     REQUIRE(e, "null handle");
     REQUIRE(!e->finalized, "AddQRCloth after Finalize");
     REQUIRE(pos && vel && (indices || n_faces == 0), "null input array");
@@ -98,7 +99,7 @@ int mpm_add_qr_cloth(mpm_handle_t e, const float* pos, const float* vel, size_t 
     e->nf += n_faces;
     e->np = e->nv + e->nf;
     return 0;
-}
+} MPM_CATCH_ALL
 
 // ---- analytic colliders of the grid update ---------------------------------------------------
 // The reference's compile-time scenes (cuda_mpm_kernels.cuh:673-774) as tables; MPM_BC_TABLE selects
@@ -259,7 +260,7 @@ static int set_fixed_point_scales(mpm_engine* e) {
     return 0;
 }
 
-int mpm_finalize(mpm_handle_t e) {
+int mpm_finalize(mpm_handle_t e) try {
     REQUIRE(e, "null handle");
     REQUIRE(!e->finalized, "Finalize called twice");
     REQUIRE(e->np > 0, "no particles: call mpm_add_qr_cloth first");
@@ -470,14 +471,15 @@ int mpm_finalize(mpm_handle_t e) {
         e->quiet_left = c.error || c.need_rebuild ? 0.f : c.quiet_time;
     }
     return 0;
-}
+} MPM_CATCH_ALL
 
-int mpm_destroy(mpm_handle_t e) {
+int mpm_destroy(mpm_handle_t e) try {
     if (!e) return 0;
     {
         std::lock_guard<std::mutex> lock(g_live_mutex);
         g_live.erase(std::remove(g_live.begin(), g_live.end(), e), g_live.end());
     }
+    while (e->pins.load() > 0) std::this_thread::yield();   // (a GpuSync() of another thread is settling this engine)
     hipSetDevice(e->device);
     if (e->own_stream) hipStreamSynchronize(e->own_stream);
     (void)mpm_chain_destroy(e);
@@ -492,19 +494,19 @@ int mpm_destroy(mpm_handle_t e) {
     if (e->own_stream) hipStreamDestroy(e->own_stream);
     delete e;
     return 0;
-}
+} MPM_CATCH_ALL
 
-int mpm_counts(mpm_handle_t e, size_t* nv, size_t* nf, size_t* np) {
+int mpm_counts(mpm_handle_t e, size_t* nv, size_t* nf, size_t* np) try {
     REQUIRE(e, "null handle");
     if (nv) *nv = e->nv;
     if (nf) *nf = e->nf;
     if (np) *np = e->np;
     return 0;
-}
+} MPM_CATCH_ALL
 
 static int settle(mpm_engine* e, Ctl* fresh = nullptr);
 
-int mpm_set_deterministic(mpm_handle_t e, int on) {
+int mpm_set_deterministic(mpm_handle_t e, int on) try {
     REQUIRE(e, "null handle");
     if (e->finalized) {
         if (int rc = use(e)) return rc;
@@ -513,9 +515,9 @@ int mpm_set_deterministic(mpm_handle_t e, int on) {
     if (e->deterministic != (on != 0)) drop_step_graph(e);   // the captured substep has one kernel more or less
     e->deterministic = on != 0;
     return 0;
-}
+} MPM_CATCH_ALL
 
-int mpm_set_stream(mpm_handle_t e, void* s) {
+int mpm_set_stream(mpm_handle_t e, void* s) try {
     REQUIRE(e, "null handle");
     if (int rc = use(e)) return rc;
     if (e->finalized)
@@ -523,7 +525,7 @@ int mpm_set_stream(mpm_handle_t e, void* s) {
     HIP_TRY(hipStreamSynchronize(e->stream));
     e->stream = s ? static_cast<hipStream_t>(s) : e->own_stream;
     return 0;
-}
+} MPM_CATCH_ALL
 
 // The stream is idle and `c` is the current control block: double the slab pool when the work items
 // fill more than half of it.  Slabs only live from ParticleToGrid to UpdateGrid, so between substeps
@@ -576,7 +578,7 @@ static void note_quiet_time(mpm_engine* e, const Ctl& c) {
     e->quiet_left = c.skipped || c.need_rebuild || c.error ? 0.f : std::max(0.f, c.quiet_time - c.time_since_resort);
 }
 
-int mpm_sync(mpm_handle_t e) {
+int mpm_sync(mpm_handle_t e) try {
     REQUIRE(e, "null handle");
     if (int rc = use(e)) return rc;
     Ctl c;
@@ -613,7 +615,7 @@ int mpm_sync(mpm_handle_t e) {
                     "grown at synchronisation points: call mpm_sync more often while a cloth spreads out, or set "
                     "MPM_SLAB_CAPACITY --, slabs over one block, halo or migration buffers)");
     return 0;
-}
+} MPM_CATCH_ALL
 
 // ---- the solver calls -----------------------------------------------------
 static void launch_substep(mpm_engine* e, float dt, const GridColliders& gc, bool allow_gate, bool lean = false);
@@ -685,7 +687,7 @@ static int settle_owed(mpm_engine* e, Ctl* fresh) {
     READY_NO_SETTLE(e);  \
     if (int rc2__ = settle(e)) return rc2__
 
-int mpm_halo_zone_blocks(mpm_handle_t e, int bx_lo, int bx_hi, uint32_t* count_out) {
+int mpm_halo_zone_blocks(mpm_handle_t e, int bx_lo, int bx_hi, uint32_t* count_out) try {
     READY(e);
     REQUIRE(count_out, "null output");
     HIP_TRY(hipStreamSynchronize(e->stream));
@@ -708,46 +710,46 @@ int mpm_halo_zone_blocks(mpm_handle_t e, int bx_lo, int bx_hi, uint32_t* count_o
     }
     *count_out = n;
     return 0;
-}
+} MPM_CATCH_ALL
 
-int mpm_contact_frame(const float u[3], float J[9]) {
+int mpm_contact_frame(const float u[3], float J[9]) try {
     REQUIRE(u && J, "null argument");
     frame_from_normal(u, J);
     return 0;
-}
+} MPM_CATCH_ALL
 
-int mpm_profile_contact_iteration(mpm_handle_t e, int reps, float kernel_ms[4]) {
+int mpm_profile_contact_iteration(mpm_handle_t e, int reps, float kernel_ms[4]) try {
     READY(e);
     REQUIRE(kernel_ms && reps > 0 && reps <= 1000, "bad arguments");
     return profile_contact_iteration(e, reps, kernel_ms);
-}
+} MPM_CATCH_ALL
 
-int mpm_memcpy_d2h(mpm_handle_t e, void* dst_host, const void* src_device, size_t bytes) {
+int mpm_memcpy_d2h(mpm_handle_t e, void* dst_host, const void* src_device, size_t bytes) try {
     REQUIRE(e, "null handle");
     REQUIRE(bytes == 0 || (dst_host && src_device), "null pointer");
     if (int rc = use(e)) return rc;
     if (bytes) D2H(e, dst_host, src_device, bytes);
     return 0;
-}
+} MPM_CATCH_ALL
 
-int mpm_memcpy_h2d(mpm_handle_t e, void* dst_device, const void* src_host, size_t bytes) {
+int mpm_memcpy_h2d(mpm_handle_t e, void* dst_device, const void* src_host, size_t bytes) try {
     REQUIRE(e, "null handle");
     REQUIRE(bytes == 0 || (dst_device && src_host), "null pointer");
     if (int rc = use(e)) return rc;
     if (bytes) H2D(e, dst_device, src_host, bytes);
     return 0;
-}
+} MPM_CATCH_ALL
 
-int mpm_debug_owed_substeps(mpm_handle_t e, uint32_t* out) {
+int mpm_debug_owed_substeps(mpm_handle_t e, uint32_t* out) try {
     READY_NO_SETTLE(e);
     REQUIRE(out, "null output");
     unsigned owed = 0;
     D2H(e, &owed, &e->dp.ctl->skipped, sizeof(unsigned));
     *out = owed;
     return 0;
-}
+} MPM_CATCH_ALL
 
-int mpm_device_synchronize(void) {
+int mpm_device_synchronize(void) try {
     // The reference's GpuSync() is a plain cudaDeviceSynchronize (cuda_mpm_solver.cu:164-166): it completes the work
     // of the device and says nothing about the state of any simulation.  Here "the work" includes substeps that
     // mpm_run_substeps deferred, so every engine of the device is settled and flushed first; the sticky SIMULATION
@@ -758,21 +760,29 @@ int mpm_device_synchronize(void) {
     HIP_TRY(hipGetDevice(&dev));
     int first = 0;
     std::string first_msg;
+    //  the engines of this device are PINNED under the lock and settled outside it: mpm_create / mpm_destroy of
+    // other threads do not stall behind a GPU drain, and mpm_destroy of a pinned engine waits for the pin to go
+    std::vector<mpm_engine*> mine;
     {
         std::lock_guard<std::mutex> lock(g_live_mutex);
-        for (mpm_engine* e : g_live) {
-            if (e->device != dev) continue;
-            const int rc = mpm_sync(e);
-            if (rc == MPM_ERR_HIP && !first) {
-                first = rc;
-                first_msg = g_last_error;
+        for (mpm_engine* e : g_live)
+            if (e->device == dev) {
+                e->pins.fetch_add(1);
+                mine.push_back(e);
             }
+    }
+    for (mpm_engine* e : mine) {
+        const int rc = mpm_sync(e);
+        if ((rc == MPM_ERR_HIP || rc == MPM_ERR_NOMEM || rc == MPM_ERR_INTERNAL) && !first) {
+            first = rc;
+            first_msg = g_last_error;
         }
+        e->pins.fetch_sub(1);
     }
     HIP_TRY(hipSetDevice(dev));
     HIP_TRY(hipDeviceSynchronize());
     return first ? fail(first, first_msg) : 0;
-}
+} MPM_CATCH_ALL
 
 // The reference's five calls per substep (cuda_mpm_test.cc:64-72, deformable_driver.h:244-258), taken one by one, are
 // nine launches with the re-sort check in front of every substep and the vertex forces as a kernel of their own.
@@ -806,7 +816,7 @@ static int flush_phases(mpm_engine* e) {
     return 0;
 }
 
-int mpm_rebuild_mapping(mpm_handle_t e, int sort) {
+int mpm_rebuild_mapping(mpm_handle_t e, int sort) try {
     if (e && can_defer(e) && !sort && e->pend.n == 0) {
         READY_NO_SETTLE(e);
         e->pend.n = 1;
@@ -820,9 +830,9 @@ int mpm_rebuild_mapping(mpm_handle_t e, int sort) {
         return api_sort(e);
     }
     return 0;
-}
+} MPM_CATCH_ALL
 
-int mpm_calc_fem_state_and_force(mpm_handle_t e, float dt) {
+int mpm_calc_fem_state_and_force(mpm_handle_t e, float dt) try {
     if (e && can_defer(e) && e->pend.n == 1) {
         READY_NO_SETTLE(e);
         e->pend.n = 2;
@@ -832,9 +842,9 @@ int mpm_calc_fem_state_and_force(mpm_handle_t e, float dt) {
     READY(e);
     launch_fem(e, dt);
     return 0;
-}
+} MPM_CATCH_ALL
 
-int mpm_particle_to_grid(mpm_handle_t e, float dt) {
+int mpm_particle_to_grid(mpm_handle_t e, float dt) try {
     if (e && can_defer(e) && e->pend.n == 2 && dt == e->pend.dt) {
         READY_NO_SETTLE(e);
         e->pend.n = 3;
@@ -844,9 +854,9 @@ int mpm_particle_to_grid(mpm_handle_t e, float dt) {
     launch_p2g(e, dt);
     e->grid_state = 1;
     return 0;
-}
+} MPM_CATCH_ALL
 
-int mpm_update_grid(mpm_handle_t e, int bc) {
+int mpm_update_grid(mpm_handle_t e, int bc) try {
     if (e && can_defer(e) && e->pend.n == 3) {
         READY_NO_SETTLE(e);
         GridColliders probe;
@@ -862,19 +872,19 @@ int mpm_update_grid(mpm_handle_t e, int bc) {
     launch_grid(e, gc);
     e->grid_state = 2;
     return 0;
-}
+} MPM_CATCH_ALL
 
-int mpm_grid_gather(mpm_handle_t e) {
+int mpm_grid_gather(mpm_handle_t e) try {
     READY(e);
     REQUIRE(e->grid_state >= 1, "grid gather before ParticleToGrid");
     hipLaunchKernelGGL(k_grid<0>, dim3(e->g_grid), dim3(256), 0, e->stream, e->dp, GridColliders{});
     e->grid_state = 3;  // raw sums in gv
     return 0;
-}
+} MPM_CATCH_ALL
 
 size_t mpm_halo_buffer_bytes(size_t cap) { return (((4 + cap) * 4 + 15) / 16) * 16 + cap * 64 * 16; }
 
-int mpm_halo_pack(mpm_handle_t e, int bx_lo, int bx_hi, int shift_bx, void* dev_buf, size_t cap) {
+int mpm_halo_pack(mpm_handle_t e, int bx_lo, int bx_hi, int shift_bx, void* dev_buf, size_t cap) try {
     READY(e);
     REQUIRE(e->grid_state == 3, "halo pack needs mpm_grid_gather first");
     REQUIRE(dev_buf && cap > 0 && cap < (1u << 24), "bad halo buffer");
@@ -884,9 +894,9 @@ int mpm_halo_pack(mpm_handle_t e, int bx_lo, int bx_hi, int shift_bx, void* dev_
     z.buf[0] = static_cast<uint32_t*>(dev_buf);
     hipLaunchKernelGGL(k_halo_pack2, dim3(e->g_grid, 1), dim3(256), 0, e->stream, e->dp, z, (unsigned)cap);
     return 0;
-}
+} MPM_CATCH_ALL
 
-int mpm_halo_add(mpm_handle_t e, const void* dev_buf, size_t cap) {
+int mpm_halo_add(mpm_handle_t e, const void* dev_buf, size_t cap) try {
     READY(e);
     REQUIRE(e->grid_state == 3, "halo add needs mpm_grid_gather first");
     REQUIRE(dev_buf && cap > 0, "bad halo buffer");
@@ -894,9 +904,9 @@ int mpm_halo_add(mpm_handle_t e, const void* dev_buf, size_t cap) {
     hb.buf[0] = static_cast<const uint32_t*>(dev_buf);
     hipLaunchKernelGGL(k_halo_add2, dim3(64, 1), dim3(256), 0, e->stream, e->dp, hb, (unsigned)cap);
     return 0;
-}
+} MPM_CATCH_ALL
 
-int mpm_update_grid_from_sums(mpm_handle_t e, int bc) {
+int mpm_update_grid_from_sums(mpm_handle_t e, int bc) try {
     READY(e);
     REQUIRE(e->grid_state == 3, "needs mpm_grid_gather first");
     GridColliders gc;
@@ -904,9 +914,9 @@ int mpm_update_grid_from_sums(mpm_handle_t e, int bc) {
     hipLaunchKernelGGL(k_grid<2>, dim3(e->g_grid), dim3(256), 0, e->stream, e->dp, gc);
     e->grid_state = 2;
     return 0;
-}
+} MPM_CATCH_ALL
 
-int mpm_substep_begin(mpm_handle_t e, float dt) {
+int mpm_substep_begin(mpm_handle_t e, float dt) try {
     READY(e);
     may_resort(e, dt);
     launch_rebuild(e);
@@ -914,9 +924,9 @@ int mpm_substep_begin(mpm_handle_t e, float dt) {
     hipLaunchKernelGGL(k_grid<0>, dim3(e->g_grid), dim3(256), 0, e->stream, e->dp, GridColliders{});
     e->grid_state = 3;
     return 0;
-}
+} MPM_CATCH_ALL
 
-int mpm_substep_end(mpm_handle_t e, float dt, int bc) {
+int mpm_substep_end(mpm_handle_t e, float dt, int bc) try {
     READY(e);
     REQUIRE(e->grid_state == 3, "mpm_substep_end without mpm_substep_begin");
     GridColliders gc;
@@ -926,7 +936,7 @@ int mpm_substep_end(mpm_handle_t e, float dt, int bc) {
     launch_g2p(e, dt);
     e->substeps += 1;
     return 0;
-}
+} MPM_CATCH_ALL
 
 // Replays `body` (a sequence of launches on e->stream) from a graph cached under `key`.
 static int replay_keyed(mpm_engine* e, mpm_engine::KeyedGraph& kg, const std::vector<uint64_t>& key,
@@ -949,7 +959,7 @@ static int replay_keyed(mpm_engine* e, mpm_engine::KeyedGraph& kg, const std::ve
 static uint64_t bits_of(float f) { uint32_t u; std::memcpy(&u, &f, 4); return u; }
 
 int mpm_substep_begin_halo(mpm_handle_t e, float dt, int n, const int* bx_lo, const int* bx_hi, const int* shift_bx,
-                           void* const* send_bufs, size_t cap) {
+                           void* const* send_bufs, size_t cap) try {
     READY(e);
     may_resort(e, dt);
     REQUIRE(n >= 0 && n <= 2 && (n == 0 || (bx_lo && bx_hi && shift_bx && send_bufs)), "bad halo zone list");
@@ -990,11 +1000,11 @@ int mpm_substep_begin_halo(mpm_handle_t e, float dt, int n, const int* bx_lo, co
     e->halo_nz = n;
     for (int i = 0; i < n; ++i) { e->halo_zlo[i] = bx_lo[i]; e->halo_zhi[i] = bx_hi[i]; }
     return 0;
-}
+} MPM_CATCH_ALL
 
 // Between begin and end: the part of the grid update and of G2P that does not depend on the
 // neighbours' sums, to be overlapped with the exchange.  Zones = the ranges given to begin.
-int mpm_substep_mid_halo(mpm_handle_t e, float dt, int bc) {
+int mpm_substep_mid_halo(mpm_handle_t e, float dt, int bc) try {
     READY(e);
     REQUIRE(e->grid_state == 3 && !e->halo_mid_done, "mpm_substep_mid_halo needs mpm_substep_begin_halo first");
     GridColliders gc;
@@ -1007,9 +1017,9 @@ int mpm_substep_mid_halo(mpm_handle_t e, float dt, int bc) {
     launch_g2p_with(e, p, dt);
     e->halo_mid_done = true;
     return 0;
-}
+} MPM_CATCH_ALL
 
-int mpm_substep_end_halo(mpm_handle_t e, float dt, int bc, int n, const void* const* recv_bufs, size_t cap) {
+int mpm_substep_end_halo(mpm_handle_t e, float dt, int bc, int n, const void* const* recv_bufs, size_t cap) try {
     READY(e);
     REQUIRE(n >= 0 && n <= 2 && (n == 0 || recv_bufs), "bad halo buffer list");
     REQUIRE(e->grid_state == 3, "mpm_substep_end_halo without mpm_substep_begin_halo");
@@ -1058,9 +1068,9 @@ int mpm_substep_end_halo(mpm_handle_t e, float dt, int bc, int n, const void* co
     e->grid_state = 2;
     e->substeps += 1;
     return 0;
-}
+} MPM_CATCH_ALL
 
-int mpm_chain_unique_id(char id_out[128]) {
+int mpm_chain_unique_id(char id_out[128]) try {
     REQUIRE(id_out, "null argument");
     const rccl_rt::Api* a = rccl_rt::api();
     if (!a) return fail(MPM_ERR_HIP, "RCCL (librccl.so) is not available in this process");
@@ -1068,9 +1078,9 @@ int mpm_chain_unique_id(char id_out[128]) {
     RCCL_TRY(a->get_unique_id(&id));
     std::memcpy(id_out, id.internal, rccl_rt::kIdBytes);
     return 0;
-}
+} MPM_CATCH_ALL
 
-int mpm_chain_destroy(mpm_handle_t e) {
+int mpm_chain_destroy(mpm_handle_t e) try {
     REQUIRE(e, "null handle");
     mpm_engine::Chain& c = e->chain;
     if (int rc = use(e)) return rc;
@@ -1084,9 +1094,9 @@ int mpm_chain_destroy(mpm_handle_t e) {
         if (q) (void)hipFree(q);
     c = mpm_engine::Chain();
     return 0;
-}
+} MPM_CATCH_ALL
 
-int mpm_chain_enable_migration(mpm_handle_t e, int every, size_t capacity_particles) {
+int mpm_chain_enable_migration(mpm_handle_t e, int every, size_t capacity_particles) try {
     READY(e);
     mpm_engine::Chain& c = e->chain;
     REQUIRE(c.comm, "mpm_chain_init first");
@@ -1111,10 +1121,10 @@ int mpm_chain_enable_migration(mpm_handle_t e, int every, size_t capacity_partic
     }
     HIP_TRY(hipStreamSynchronize(e->stream));
     return 0;
-}
+} MPM_CATCH_ALL
 
 int mpm_chain_init(mpm_handle_t e, const char id[128], int rank, int world, int cut_lo_block, int cut_hi_block,
-                   int pitch_blocks, int zone_blocks, size_t capacity_blocks, int periodic) {
+                   int pitch_blocks, int zone_blocks, size_t capacity_blocks, int periodic) try {
     READY(e);
     REQUIRE(id && world >= 1 && rank >= 0 && rank < world, "bad rank / world");
     REQUIRE(zone_blocks >= 1 && capacity_blocks > 0 && capacity_blocks < (1u << 24), "bad halo geometry");
@@ -1137,9 +1147,9 @@ int mpm_chain_init(mpm_handle_t e, const char id[128], int rank, int world, int 
     std::memcpy(uid.internal, id, rccl_rt::kIdBytes);
     RCCL_TRY(a->comm_init_rank(&c.comm, world, uid, rank));
     return 0;
-}
+} MPM_CATCH_ALL
 
-int mpm_chain_substeps(mpm_handle_t e, int n, float dt, int bc) {
+int mpm_chain_substeps(mpm_handle_t e, int n, float dt, int bc) try {
     READY(e);
     mpm_engine::Chain& c = e->chain;
     REQUIRE(c.comm, "mpm_chain_init first");
@@ -1241,9 +1251,9 @@ int mpm_chain_substeps(mpm_handle_t e, int n, float dt, int bc) {
     }
     HIP_TRY(hipGetLastError());
     return 0;
-}
+} MPM_CATCH_ALL
 
-int mpm_grid_to_particle(mpm_handle_t e, float dt) {
+int mpm_grid_to_particle(mpm_handle_t e, float dt) try {
     if (e && can_defer(e) && e->pend.n == 4 && dt == e->pend.dt) {
         // the substep is complete: one gated substep, as mpm_run_substeps(1) enqueues it
         e->pend.n = 0;
@@ -1254,9 +1264,9 @@ int mpm_grid_to_particle(mpm_handle_t e, float dt) {
     launch_g2p(e, dt);
     e->substeps += 1;
     return 0;
-}
+} MPM_CATCH_ALL
 
-int mpm_substep(mpm_handle_t e, float dt, int bc) { return mpm_run_substeps(e, 1, dt, bc); }
+int mpm_substep(mpm_handle_t e, float dt, int bc) try { return mpm_run_substeps(e, 1, dt, bc); } MPM_CATCH_ALL
 
 // allow_gate: the substep may go without the re-sort launches (mpm_run_substeps outside graphs)
 // lean: another substep follows in the same batch, GridToParticle need not refresh what only a download reads
@@ -1316,7 +1326,7 @@ static int step_graph_for(mpm_engine* e, float dt, int bc, const GridColliders& 
     return 0;
 }
 
-int mpm_run_substeps(mpm_handle_t e, int n, float dt, int bc) {
+int mpm_run_substeps(mpm_handle_t e, int n, float dt, int bc) try {
     READY_NO_SETTLE(e);
     // owed substeps are run with the parameters they were enqueued with: settle before these change (and before phase
     // calls that were held back, which come first)
@@ -1346,9 +1356,9 @@ int mpm_run_substeps(mpm_handle_t e, int n, float dt, int bc) {
     e->substeps += (uint64_t)std::max(n, 0);
     HIP_TRY(hipGetLastError());
     return 0;
-}
+} MPM_CATCH_ALL
 
-int mpm_profile_substeps(mpm_handle_t e, int n, float dt, int bc, float* phase_ms, float* total_ms) {
+int mpm_profile_substeps(mpm_handle_t e, int n, float dt, int bc, float* phase_ms, float* total_ms) try {
     READY(e);
     REQUIRE(n > 0 && n <= 4096, "n out of range");
     GridColliders gc;
@@ -1399,9 +1409,9 @@ int mpm_profile_substeps(mpm_handle_t e, int n, float dt, int bc, float* phase_m
         for (int k = 0; k < MPM_PHASE_COUNT; ++k) phase_ms[k] = (float)(acc[k] / n);
     if (total_ms) *total_ms = (float)(tot / n);
     return 0;
-}
+} MPM_CATCH_ALL
 
-int mpm_get_stats(mpm_handle_t e, mpm_stats_t* out) {
+int mpm_get_stats(mpm_handle_t e, mpm_stats_t* out) try {
     READY(e);
     REQUIRE(out, "null stats");
     HIP_TRY(hipStreamSynchronize(e->stream));
@@ -1446,36 +1456,36 @@ int mpm_get_stats(mpm_handle_t e, mpm_stats_t* out) {
         out->touched_blocks = cnt;
     }
     return 0;
-}
+} MPM_CATCH_ALL
 
-int mpm_grid_touched_cnt(mpm_handle_t e, uint32_t* out) {
+int mpm_grid_touched_cnt(mpm_handle_t e, uint32_t* out) try {
     READY(e);
     REQUIRE(out, "null output");
     *out = 0;
     if (e->grid_state < 1) return 0;
     return touched_flags(e, nullptr, out);
-}
+} MPM_CATCH_ALL
 
-int mpm_download_array(mpm_handle_t e, int which, void* out, size_t bytes, size_t* written) {
+int mpm_download_array(mpm_handle_t e, int which, void* out, size_t bytes, size_t* written) try {
     READY(e);
     REQUIRE(out, "null output");
     return download_array(e, which, out, bytes, written);
-}
+} MPM_CATCH_ALL
 
 int mpm_upload_particle_state(mpm_handle_t e, const float* pos, const float* vel, const float* affine,
-                              const float* volumes, const float* deformation_gradients) {
+                              const float* volumes, const float* deformation_gradients) try {
     READY(e);
     if (int rc = upload_state(e, pos, vel, affine, volumes, deformation_gradients)) return rc;
     return volumes ? set_fixed_point_scales(e) : 0;
-}
+} MPM_CATCH_ALL
 
-int mpm_sync_particle_state_to_cpu(mpm_handle_t e, float* pos_out) {
+int mpm_sync_particle_state_to_cpu(mpm_handle_t e, float* pos_out) try {
     READY(e);
     REQUIRE(pos_out, "null output");
     return download_array(e, MPM_ARR_POSITIONS, pos_out, e->np * 12, nullptr);
-}
+} MPM_CATCH_ALL
 
-int mpm_dump_cpu_state(mpm_handle_t e, float* pos_out, int32_t* idx_out) {
+int mpm_dump_cpu_state(mpm_handle_t e, float* pos_out, int32_t* idx_out) try {
     READY(e);
     if (pos_out) {
         // original vertex order = original ids nf..np (cuda_mpm_model.cu:257-260)
@@ -1483,9 +1493,9 @@ int mpm_dump_cpu_state(mpm_handle_t e, float* pos_out, int32_t* idx_out) {
     }
     if (idx_out) std::copy(e->h_idx.begin(), e->h_idx.end(), idx_out);
     return 0;
-}
+} MPM_CATCH_ALL
 
-int mpm_dump_obj(mpm_handle_t e, const char* filename) {
+int mpm_dump_obj(mpm_handle_t e, const char* filename) try {
     READY(e);
     REQUIRE(filename, "null filename");
     std::vector<float> pos(e->nv * 3);
@@ -1496,38 +1506,38 @@ int mpm_dump_obj(mpm_handle_t e, const char* filename) {
     for (size_t f = 0; f < e->nf; ++f)
         obj << "f " << e->h_idx[f * 3] + 1 << " " << e->h_idx[f * 3 + 1] + 1 << " " << e->h_idx[f * 3 + 2] + 1 << "\n";
     return 0;
-}
+} MPM_CATCH_ALL
 
-int mpm_debug_counters(mpm_handle_t e, uint64_t* out16, int reset) {
+int mpm_debug_counters(mpm_handle_t e, uint64_t* out16, int reset) try {
     READY(e);
     HIP_TRY(hipStreamSynchronize(e->stream));
     if (out16) D2H(e, out16, e->dp.dbgbuf, 16 * 8);
     if (reset) HIP_TRY(hipMemsetAsync(e->dp.dbgbuf, 0, 16 * 8, e->stream));
     HIP_TRY(hipStreamSynchronize(e->stream));
     return 0;
-}
+} MPM_CATCH_ALL
 
-int mpm_set_dump_dir(mpm_handle_t e, const char* dir) {
+int mpm_set_dump_dir(mpm_handle_t e, const char* dir) try {
     REQUIRE(e && dir, "null argument");
     e->dump_dir = dir;
     return 0;
-}
+} MPM_CATCH_ALL
 
-int mpm_reallocate_external_bodies(mpm_handle_t e, size_t n) {
+int mpm_reallocate_external_bodies(mpm_handle_t e, size_t n) try {
     READY(e);
     if (e->cb.resize_bodies(n, e->stream))
         return fail(MPM_ERR_HIP, "ReallocateExternelBodies: device allocation or reset failed");
     return 0;
-}
+} MPM_CATCH_ALL
 
-int mpm_external_body_force_to_host(mpm_handle_t e, float* tau_out, float* f_out) {
+int mpm_external_body_force_to_host(mpm_handle_t e, float* tau_out, float* f_out) try {
     READY(e);
     HIP_TRY(hipStreamSynchronize(e->stream));
     if (e->cb.n_bodies == 0) return 0;
     if (tau_out) D2H(e, tau_out, e->cb.body_tau, e->cb.n_bodies * 12);
     if (f_out) D2H(e, f_out, e->cb.body_f, e->cb.n_bodies * 12);
     return 0;
-}
+} MPM_CATCH_ALL
 
 // ---- partitioned domain ----------------------------------------------------------------------
 namespace mpm {
@@ -1560,76 +1570,110 @@ static size_t dist_slot_capacity(const mpm_engine* e, size_t held, size_t all) {
     if (!(e->dist_headroom > 0.f)) return all;   // (0: keep the whole scene's size)
     return std::min(all, std::max<size_t>((size_t)((double)held * std::max(1.f, e->dist_headroom)) + 256, 1024));
 }
+// TWO-PHASE: phase 1 allocates every new array and touches nothing of the engine -- a failure there (device
+// memory exhausted) frees what phase 1 got and returns with the engine exactly as it was, still usable at its old size;
+// phase 2 (copies, swaps, frees) cannot fail for lack of memory.
 static int dist_resize(mpm_engine* e, size_t new_nf, size_t new_nv, bool first) {
     DP& p = e->dp;
     HIP_TRY(hipStreamSynchronize(e->stream));
     Ctl c;
     D2H(e, &c, p.ctl, sizeof(Ctl));
     // (what a migration appended behind the active particles and the re-sort has not merged yet is kept too)
-    const size_t nfa = (size_t)(c.nfa + c.add_f), nva = (size_t)(c.nva + c.add_v);
+    REQUIRE(c.nfa >= 0 && c.nva >= 0 && c.add_f >= 0 && c.add_v >= 0, "dist_resize: corrupt control block");
+    const size_t nfa = (size_t)c.nfa + (size_t)c.add_f, nva = (size_t)c.nva + (size_t)c.add_v;
     const size_t old_nf = (size_t)p.Nf;
+    REQUIRE(nfa <= old_nf && nva <= (size_t)p.Nv, "dist_resize: the control block counts more particles than the slot space holds");
     REQUIRE(new_nf >= nfa && new_nv >= nva, "dist_resize: smaller than what the rank holds");
+    REQUIRE(new_nf + new_nv < ((size_t)1 << 30), "dist_resize: too many particle slots");
     const size_t new_np = new_nf + new_nv;
     const int cur = c.cur & 1;
+    const unsigned new_q_stride = (unsigned)((new_np + 63) & ~(size_t)63);
+
+    // ---- phase 1: allocate ----------------------------------------------------------------------------------------
+    struct Copy { size_t dst_off, src_off, bytes; };
+    struct Plan {
+        void** owner;             // where the engine keeps the allocation's base pointer
+        void* fresh;              // its replacement
+        std::vector<Copy> keep;   // byte ranges carried over (old base -> fresh)
+    };
+    std::vector<Plan> plans;
+    plans.reserve(64);
+    const size_t allocs_before = e->allocs.size();
+    auto rollback = [&]() {
+        for (Plan& pl : plans) {
+            void* q = pl.fresh;
+            if (q) e->dfree(q);
+        }
+        (void)allocs_before;
+    };
     int rc = 0;
-    // one array: allocate n_new elements, keep `keep` elements from old[from_old ...] at new[to_new ...]
-    auto move = [&](auto*& ptr, size_t n_new, size_t keep, size_t from_old, size_t to_new) -> int {
+    auto plan = [&](auto*& ptr, size_t n_new, std::vector<Copy> keep_elems) -> int {
         using T = std::remove_pointer_t<std::remove_reference_t<decltype(ptr)>>;
         T* fresh = nullptr;
         if (int r = e->dalloc(&fresh, n_new, true)) return r;
-        if (keep) HIP_TRY(hipMemcpyAsync(fresh + to_new, ptr + from_old, keep * sizeof(T), hipMemcpyDeviceToDevice, e->stream));
-        HIP_TRY(hipStreamSynchronize(e->stream));
-        e->dfree(ptr);
-        ptr = fresh;
+        Plan pl;
+        pl.owner = (void**)(&ptr);
+        pl.fresh = (void*)fresh;
+        for (Copy k : keep_elems)
+            if (k.bytes) pl.keep.push_back(Copy{k.dst_off * sizeof(T), k.src_off * sizeof(T), k.bytes * sizeof(T)});
+        plans.push_back(std::move(pl));
         return 0;
     };
-    const unsigned new_q_stride = (unsigned)((new_np + 63) & ~(size_t)63);
-    for (int s = 0; s < 2; ++s) {
+    float4* q_base[2] = {p.set[0].q[0], p.set[1].q[0]};   // (the four planes of a set are one allocation)
+    float* f_base = p.f[0];
+    for (int s = 0; s < 2 && !rc; ++s) {
         PSet& S = p.set[s];
         const bool live = s == cur;
-        {   // the four planes of one allocation
-            float4* base = nullptr;
-            if ((rc = e->dalloc(&base, 4 * (size_t)new_q_stride, true))) return rc;
-            if (live)
-                for (int d = 0; d < 4; ++d) {
-                    if (nfa) HIP_TRY(hipMemcpyAsync(base + (size_t)d * new_q_stride, S.q[d], nfa * 16, hipMemcpyDeviceToDevice, e->stream));
-                    if (nva) HIP_TRY(hipMemcpyAsync(base + (size_t)d * new_q_stride + new_nf, S.q[d] + old_nf, nva * 16,
-                                                    hipMemcpyDeviceToDevice, e->stream));
-                }
-            HIP_TRY(hipStreamSynchronize(e->stream));
-            float4* old_base = S.q[0];
-            e->dfree(old_base);
-            for (int d = 0; d < 4; ++d) S.q[d] = base + (size_t)d * new_q_stride;
+        std::vector<Copy> planes;
+        if (live)
+            for (int d = 0; d < 4; ++d) {
+                planes.push_back(Copy{(size_t)d * new_q_stride, (size_t)d * p.q_stride, nfa});
+                planes.push_back(Copy{(size_t)d * new_q_stride + new_nf, (size_t)d * p.q_stride + old_nf, nva});
+            }
+        rc = plan(q_base[s], 4 * (size_t)new_q_stride, planes);
+        if (!rc) rc = plan(S.pid, new_np, live ? std::vector<Copy>{{0, 0, nfa}, {new_nf, old_nf, nva}} : std::vector<Copy>{});
+        const std::vector<Copy> kf = live ? std::vector<Copy>{{0, 0, nfa}} : std::vector<Copy>{};
+        const std::vector<Copy> kv = live ? std::vector<Copy>{{0, 0, nva}} : std::vector<Copy>{};
+        for (int d = 0; d < 4 && !rc; ++d) rc = plan(S.fq[d], new_nf, kf);
+        if (!rc) rc = plan(S.f8, new_nf, kf);
+        if (!rc) rc = plan(S.c8, new_nf, kf);
+        if (!rc) rc = plan(p.fg[s], new_nf, kf);
+        for (int d = 0; d < 2 && !rc; ++d) {
+            rc = plan(S.va[d], new_nv, kv);
+            if (!rc) rc = plan(p.vg[s][d], new_nv, kv);
         }
-        {   // pid: faces then vertices
-            int* fresh = nullptr;
-            if ((rc = e->dalloc(&fresh, new_np, true))) return rc;
-            if (live && nfa) HIP_TRY(hipMemcpyAsync(fresh, S.pid, nfa * 4, hipMemcpyDeviceToDevice, e->stream));
-            if (live && nva) HIP_TRY(hipMemcpyAsync(fresh + new_nf, S.pid + old_nf, nva * 4, hipMemcpyDeviceToDevice, e->stream));
-            HIP_TRY(hipStreamSynchronize(e->stream));
-            e->dfree(S.pid);
-            S.pid = fresh;
-        }
-        for (int d = 0; d < 4; ++d)
-            if ((rc = move(S.fq[d], new_nf, live ? nfa : 0, 0, 0))) return rc;
-        if ((rc = move(S.f8, new_nf, live ? nfa : 0, 0, 0)) || (rc = move(S.c8, new_nf, live ? nfa : 0, 0, 0))) return rc;
-        if ((rc = move(p.fg[s], new_nf, live ? nfa : 0, 0, 0))) return rc;
-        for (int d = 0; d < 2; ++d)
-            if ((rc = move(S.va[d], new_nv, live ? nva : 0, 0, 0)) || (rc = move(p.vg[s][d], new_nv, live ? nva : 0, 0, 0))) return rc;
     }
     // per-substep outputs and re-sort scratch: nothing to keep
-    if ((rc = move(p.ta, new_nf, 0, 0, 0)) || (rc = move(p.G3, 3 * new_nf, 0, 0, 0))) return rc;
-    {
-        float* base = nullptr;
-        if ((rc = e->dalloc(&base, 3 * (size_t)new_q_stride, true))) return rc;
-        float* old_base = p.f[0];
-        e->dfree(old_base);
-        for (int d = 0; d < 3; ++d) p.f[d] = base + (size_t)d * new_q_stride;
+    if (!rc) rc = plan(p.ta, new_nf, {});
+    if (!rc) rc = plan(p.G3, 3 * new_nf, {});
+    if (!rc) rc = plan(f_base, 3 * (size_t)new_q_stride, {});
+    if (!rc) rc = plan(p.pkey, new_np, {});
+    if (!rc) rc = plan(p.prank, new_np, {});
+    if (!rc) rc = plan(p.src_of, new_np, {});
+    if (!rc) rc = plan(p.dst_of, new_np, {});
+    if (!rc) rc = plan(p.home_groups, new_np / 64 + p.capH + 2, {});
+    if (rc) {
+        const std::string why = g_last_error;
+        rollback();
+        (void)hipStreamSynchronize(e->stream);
+        return fail(rc, "dist_resize: " + why + " -- the rank keeps its slot space of " + std::to_string(p.Nf) + " + " +
+                            std::to_string(p.Nv) + " slots and stays usable");
     }
-    if ((rc = move(p.pkey, new_np, 0, 0, 0)) || (rc = move(p.prank, new_np, 0, 0, 0)) || (rc = move(p.src_of, new_np, 0, 0, 0)) ||
-        (rc = move(p.dst_of, new_np, 0, 0, 0)))
-        return rc;
-    if ((rc = move(p.home_groups, new_np / 64 + p.capH + 2, 0, 0, 0))) return rc;
+
+    // ---- phase 2: copy, swap, free (no allocation from here on) ------------------------------------------------------
+    for (Plan& pl : plans)
+        for (const Copy& k : pl.keep)
+            HIP_TRY(hipMemcpyAsync((char*)pl.fresh + k.dst_off, (const char*)*pl.owner + k.src_off, k.bytes,
+                                   hipMemcpyDeviceToDevice, e->stream));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    for (Plan& pl : plans) {
+        void* old = *pl.owner;
+        e->dfree(old);
+        *pl.owner = pl.fresh;
+    }
+    for (int s = 0; s < 2; ++s)
+        for (int d = 0; d < 4; ++d) p.set[s].q[d] = q_base[s] + (size_t)d * new_q_stride;
+    for (int d = 0; d < 3; ++d) p.f[d] = f_base + (size_t)d * new_q_stride;
     if (first) {
         // the whole scene's topology tables
         for (int d = 0; d < 3; ++d) {
@@ -1665,12 +1709,15 @@ static int dist_resize(mpm_engine* e, size_t new_nf, size_t new_nv, bool first) 
     return recover_slab_overflow(e, c);
 }
 
-int mpm_dist_init(mpm_handle_t e, const mpm_dist_config_t* cfg) {
+int mpm_dist_init(mpm_handle_t e, const mpm_dist_config_t* cfg) try {
     READY(e);
     REQUIRE(cfg, "null configuration");
     REQUIRE(!e->dp.dist.on, "mpm_dist_init called twice");
     REQUIRE(e->api_identity, "mpm_dist_init must precede RebuildMapping(sort = true)");
     const int nb = e->dp.nb;
+    // (known on the host since Finalize: refused before anything is allocated or launched -- ADVICE r4)
+    REQUIRE(e->max_valence <= 8, "mpm_dist_init: a vertex with more than eight adjacent faces is not supported in a "
+                                 "partitioned domain");
     REQUIRE(cfg->world >= 1 && cfg->rank >= 0 && cfg->rank < cfg->world, "bad rank / world");
     REQUIRE(cfg->own_lo_block >= 0 && cfg->own_lo_block < cfg->own_hi_block && cfg->own_hi_block <= nb,
             "bad slab: need 0 <= own_lo_block < own_hi_block <= blocks per axis");
@@ -1755,14 +1802,6 @@ int mpm_dist_init(mpm_handle_t e, const mpm_dist_config_t* cfg) {
             if (int rc = e->dalloc(&e->dp.vg[s][k], e->nv, false)) return rc;
     }
     hipLaunchKernelGGL(k_dist_build_topology, dim3(std::min(e->g_np, 2048u)), dim3(256), 0, e->stream, e->dp);
-    {
-        // (read here, before the re-sort: table overflows of the re-sort raise the same bit and are a different story)
-        unsigned err = 0;
-        D2H(e, &err, &e->dp.ctl->error, sizeof(unsigned));
-        if (err & ERR_CAPACITY)
-            return fail(MPM_ERR_INVALID, "mpm_dist_init: a vertex with more than eight adjacent faces is not supported "
-                                         "in a partitioned domain");
-    }
     e->dp.dist = d;
     e->dist_cfg = *cfg;
     drop_step_graph(e);
@@ -1785,17 +1824,17 @@ int mpm_dist_init(mpm_handle_t e, const mpm_dist_config_t* cfg) {
             return rc;
     }
     return mpm_sync(e);
-}
+} MPM_CATCH_ALL
 
-int mpm_dist_set_headroom(mpm_handle_t e, float factor) {
+int mpm_dist_set_headroom(mpm_handle_t e, float factor) try {
     REQUIRE(e, "null handle");
     REQUIRE(!e->dp.dist.on, "mpm_dist_set_headroom must precede mpm_dist_init");
     REQUIRE(factor == 0.f || factor >= 1.f, "headroom must be 0 (keep the whole scene's size) or >= 1");
     e->dist_headroom = factor;
     return 0;
-}
+} MPM_CATCH_ALL
 
-int mpm_dist_get_geometry(mpm_handle_t e, mpm_dist_geometry_t* out) {
+int mpm_dist_get_geometry(mpm_handle_t e, mpm_dist_geometry_t* out) try {
     READY_NO_SETTLE(e);
     REQUIRE(out, "null output");
     REQUIRE(e->dp.dist.on, "mpm_dist_init first");
@@ -1808,9 +1847,9 @@ int mpm_dist_get_geometry(mpm_handle_t e, mpm_dist_geometry_t* out) {
     out->migrations = e->dist_migrations;
     out->retunes = e->dist_retunes;
     return 0;
-}
+} MPM_CATCH_ALL
 
-int mpm_dist_retune(mpm_handle_t e, float quiet_time_all, float dt, int* changed_out) {
+int mpm_dist_retune(mpm_handle_t e, float quiet_time_all, float dt, int* changed_out) try {
     REQUIRE(e, "null handle");
     REQUIRE(e->dp.dist.on, "mpm_dist_init first");
     if (changed_out) *changed_out = 0;
@@ -1844,19 +1883,19 @@ int mpm_dist_retune(mpm_handle_t e, float quiet_time_all, float dt, int* changed
     }
     if (changed_out) *changed_out = 1;
     return 0;
-}
+} MPM_CATCH_ALL
 
-int mpm_dist_migration_quiet_time(mpm_handle_t e, float* seconds_out) {
+int mpm_dist_migration_quiet_time(mpm_handle_t e, float* seconds_out) try {
     READY(e);
     REQUIRE(seconds_out, "null output");
     REQUIRE(e->dp.dist.on, "mpm_dist_init first");
     D2H(e, seconds_out, &e->dp.ctl->mig_quiet, sizeof(float));
     return 0;
-}
+} MPM_CATCH_ALL
 
 size_t mpm_dist_migration_buffer_bytes(size_t capacity_particles) { return 16 + capacity_particles * DIST_REC_F4 * 16; }
 
-int mpm_dist_migrate_pack(mpm_handle_t e, void* send_left, void* send_right, size_t capacity_particles) {
+int mpm_dist_migrate_pack(mpm_handle_t e, void* send_left, void* send_right, size_t capacity_particles) try {
     READY(e);
     REQUIRE(e->dp.dist.on, "mpm_dist_init first");
     REQUIRE(send_left && send_right && capacity_particles > 0 && capacity_particles < (1u << 28), "bad migration buffers");
@@ -1868,46 +1907,131 @@ int mpm_dist_migrate_pack(mpm_handle_t e, void* send_left, void* send_right, siz
     hipLaunchKernelGGL(k_dist_mig_reduce, dim3(1), dim3(64), 0, e->stream, e->dp);
     e->dist_migrations += 1;
     return 0;
+} MPM_CATCH_ALL
+
+// What a migration brings, from the two 16-byte headers of the received buffers ([0] records, [1] how many of them are
+// faces, [2..3] zero), and the slot space it needs.  Host arithmetic on numbers that came out of BUFFERS (another rank
+// wrote them, a transport carried them): nothing is sized from them before they have been checked against the
+// buffers' capacity and against the scene -- a header that fails the checks is an error code, never an allocation.
+struct MigrationPlan {
+    size_t in_f = 0, in_v = 0;       // arriving records: faces, vertices
+    size_t need_f = 0, need_v = 0;   // slots the rank must have before k_dist_apply runs
+    size_t want_f = 0, want_v = 0;   // slot space to re-allocate to (= the current one when it suffices)
+};
+static int plan_migration(const uint32_t* hdr_left, const uint32_t* hdr_right, size_t capacity, size_t scene_f, size_t scene_v,
+                          size_t held_f, size_t held_v, size_t slots_f, size_t slots_v, float headroom, MigrationPlan* out) {
+    REQUIRE(capacity > 0 && capacity < ((size_t)1 << 28), "migration: bad buffer capacity");
+    REQUIRE(scene_f + scene_v < ((size_t)1 << 30), "migration: bad scene size");
+    if (held_f > slots_f || held_v > slots_v || slots_f > scene_f || slots_v > scene_v)
+        return fail(MPM_ERR_INTERNAL, "migration: the rank's own counts are inconsistent (holds " + std::to_string(held_f) + " + " +
+                                          std::to_string(held_v) + " particles in " + std::to_string(slots_f) + " + " +
+                                          std::to_string(slots_v) + " slots of a scene of " + std::to_string(scene_f) + " + " +
+                                          std::to_string(scene_v) + ")");
+    MigrationPlan m;
+    const uint32_t* hdrs[2] = {hdr_left, hdr_right};
+    for (int k = 0; k < 2; ++k) {
+        const uint32_t* h = hdrs[k];
+        if (!h) continue;
+        const char* side = k ? "right" : "left";
+        // (a sender whose buffer overflowed keeps counting: it raises MPM_ERR_CAPACITY on its side, and the records
+        // beyond the capacity were never written -- applying the rest would lose particles silently)
+        if (h[0] > capacity)
+            return fail(MPM_ERR_CAPACITY, std::string("migration: the ") + side + " neighbour packed " + std::to_string(h[0]) +
+                                              " records into buffers of " + std::to_string(capacity) +
+                                              " (mpm_chain_enable_migration / DomainChain: raise capacity_particles)");
+        if (h[1] > h[0] || h[2] != 0 || h[3] != 0)
+            return fail(MPM_ERR_INVALID, std::string("migration: corrupt header from the ") + side + " neighbour (" +
+                                             std::to_string(h[0]) + " records, " + std::to_string(h[1]) + " faces, " +
+                                             std::to_string(h[2]) + ", " + std::to_string(h[3]) + ")");
+        m.in_f += h[1];
+        m.in_v += h[0] - h[1];
+    }
+    // (every arriving record counted as a new particle -- promotions of ghosts the rank already holds need no slot --,
+    // but never more than the scene has: a particle has one slot)
+    m.need_f = std::min(scene_f, held_f + m.in_f);
+    m.need_v = std::min(scene_v, held_v + m.in_v);
+    auto capacity_for = [&](size_t held, size_t all) {
+        if (!(headroom > 0.f)) return all;   // (0: keep the whole scene's size)
+        return std::min(all, std::max<size_t>((size_t)((double)held * std::max(1.f, headroom)) + 256, 1024));
+    };
+    m.want_f = slots_f;
+    m.want_v = slots_v;
+    if (m.need_f > slots_f || m.need_v > slots_v) {
+        m.want_f = std::max(slots_f, capacity_for(m.need_f, scene_f));
+        m.want_v = std::max(slots_v, capacity_for(m.need_v, scene_v));
+    }
+    *out = m;
+    return 0;
 }
 
-int mpm_dist_migrate_apply(mpm_handle_t e, const void* recv_left, const void* recv_right, size_t capacity_particles) {
+int mpm_dist_plan_migration(const uint32_t* hdr_left, const uint32_t* hdr_right, size_t capacity_particles, size_t scene_faces,
+                            size_t scene_vertices, size_t held_faces, size_t held_vertices, size_t face_slots,
+                            size_t vertex_slots, float headroom, size_t out6[6]) try {
+    REQUIRE(out6, "null output");
+    MigrationPlan m;
+    if (int rc = plan_migration(hdr_left, hdr_right, capacity_particles, scene_faces, scene_vertices, held_faces, held_vertices,
+                                face_slots, vertex_slots, headroom, &m))
+        return rc;
+    out6[0] = m.in_f; out6[1] = m.in_v; out6[2] = m.need_f; out6[3] = m.need_v; out6[4] = m.want_f; out6[5] = m.want_v;
+    return 0;
+} MPM_CATCH_ALL
+
+int mpm_dist_migrate_apply(mpm_handle_t e, const void* recv_left, const void* recv_right, size_t capacity_particles) try {
     READY(e);
     REQUIRE(e->dp.dist.on, "mpm_dist_init first");
+    REQUIRE(capacity_particles > 0 && capacity_particles < (1u << 28), "bad migration buffers");
     // A migration is a synchronisation point: the host reads how many particles arrive and what the rank holds, and
     // re-allocates the slot space first if they would not fit (a cloth that slides across a cut, an uneven split).
     {
         DP& p = e->dp;
         uint32_t hdr[2][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
+        // (pinned landing places are not needed: the copies are followed by a synchronisation at once)
         Ctl c;
         HIP_TRY(hipMemcpyAsync(&c, p.ctl, sizeof(Ctl), hipMemcpyDeviceToHost, e->stream));
         const void* bufs[2] = {recv_left, recv_right};
         for (int k = 0; k < 2; ++k)
             if (bufs[k]) HIP_TRY(hipMemcpyAsync(hdr[k], bufs[k], 16, hipMemcpyDeviceToHost, e->stream));
         HIP_TRY(hipStreamSynchronize(e->stream));
-        size_t in_f = 0, in_v = 0;
-        for (int k = 0; k < 2; ++k) {
-            const size_t n = std::min<size_t>(hdr[k][0], capacity_particles), nf = std::min<size_t>(hdr[k][1], n);
-            in_f += nf;
-            in_v += n - nf;
-        }
-        // (every arriving record counted as a new particle -- promotions of ghosts the rank already holds need no
-        // slot --, but never more than the scene has: a particle has one slot)
-        const size_t need_f = std::min(e->nf, (size_t)(c.nfa + c.add_f) + in_f), need_v = std::min(e->nv, (size_t)(c.nva + c.add_v) + in_v);
-        if (need_f > (size_t)p.Nf || need_v > (size_t)p.Nv) {
-            const size_t want_f = std::max((size_t)p.Nf, dist_slot_capacity(e, need_f, e->nf));
-            const size_t want_v = std::max((size_t)p.Nv, dist_slot_capacity(e, need_v, e->nv));
-            if (int rc = dist_resize(e, want_f, want_v, false)) return rc;
-        }
+        REQUIRE(c.nfa >= 0 && c.nva >= 0 && c.add_f >= 0 && c.add_v >= 0, "migration: corrupt control block");
+        MigrationPlan m;
+        if (int rc = plan_migration(recv_left ? hdr[0] : nullptr, recv_right ? hdr[1] : nullptr, capacity_particles, e->nf, e->nv,
+                                    (size_t)c.nfa + (size_t)c.add_f, (size_t)c.nva + (size_t)c.add_v, (size_t)p.Nf, (size_t)p.Nv,
+                                    e->dist_headroom, &m))
+            return rc;
+        if (m.want_f != (size_t)p.Nf || m.want_v != (size_t)p.Nv)
+            if (int rc = dist_resize(e, m.want_f, m.want_v, false)) return rc;
     }
     for (const void* b : {recv_left, recv_right})
         if (b)
             hipLaunchKernelGGL(k_dist_apply, dim3(256), dim3(256), 0, e->stream, e->dp, static_cast<const float4*>(b),
                                (unsigned)capacity_particles);
     return 0;
-}
+} MPM_CATCH_ALL
+
+// Tests of the exception barrier and of the allocation-failure paths.  mpm_debug_throw raises a C++ exception of the given
+// kind INSIDE an entry point (0: std::bad_alloc, 1: std::length_error via a container asked for an absurd size, 2: a
+// non-std exception) and must come back as MPM_ERR_NOMEM / MPM_ERR_INTERNAL; host code only.  mpm_debug_fail_alloc makes the
+// engine's n-th device allocation from now fail as if the device were out of memory (0 = off).
+int mpm_debug_throw(int kind) try {
+    if (kind == 0) throw std::bad_alloc();
+    if (kind == 1) {
+        std::vector<float> v;
+        v.resize(v.max_size() + 1);   // (what an unchecked count from a buffer does to a container)
+        return (int)v.size();
+    }
+    if (kind == 2) throw 42;
+    return fail(MPM_ERR_INVALID, "mpm_debug_throw: kind must be 0, 1 or 2");
+} MPM_CATCH_ALL
+
+int mpm_debug_fail_alloc(mpm_handle_t e, int nth) try {
+    REQUIRE(e, "null handle");
+    REQUIRE(nth >= 0, "nth must not be negative");
+    e->fail_alloc_countdown = nth;
+    return 0;
+} MPM_CATCH_ALL
 
 int mpm_dist_set_transport(mpm_handle_t e, mpm_exchange_fn exchange, mpm_allreduce_fn allreduce, void* user,
-                           size_t zone_capacity_blocks) {
+                           size_t zone_capacity_blocks) try {
     REQUIRE(e, "null handle");
     REQUIRE(zone_capacity_blocks > 0 && zone_capacity_blocks < (1u << 24), "bad zone capacity");
     e->dist_exchange = exchange;
@@ -1915,9 +2039,9 @@ int mpm_dist_set_transport(mpm_handle_t e, mpm_exchange_fn exchange, mpm_allredu
     e->dist_user = user;
     e->dist_zone_cap = zone_capacity_blocks;
     return 0;
-}
+} MPM_CATCH_ALL
 
-int mpm_dist_roles(mpm_handle_t e, uint8_t* out) {
+int mpm_dist_roles(mpm_handle_t e, uint8_t* out) try {
     READY(e);
     REQUIRE(out, "null output");
     if (int rc = e->stage(e->np)) return rc;
@@ -1926,9 +2050,9 @@ int mpm_dist_roles(mpm_handle_t e, uint8_t* out) {
     HIP_TRY(hipMemcpyAsync(out, e->d_stage, e->np, hipMemcpyDeviceToHost, e->stream));
     HIP_TRY(hipStreamSynchronize(e->stream));
     return 0;
-}
+} MPM_CATCH_ALL
 
-int mpm_set_grid_colliders(mpm_handle_t e, size_t n, const mpm_grid_collider_t* colliders) {
+int mpm_set_grid_colliders(mpm_handle_t e, size_t n, const mpm_grid_collider_t* colliders) try {
     static_assert(sizeof(GridCollider) == sizeof(mpm_grid_collider_t), "grid collider layouts differ");
     REQUIRE(e, "null handle");
     REQUIRE(n <= (size_t)MAX_GRID_COLLIDERS, "too many grid colliders (at most 16)");
@@ -1955,9 +2079,9 @@ int mpm_set_grid_colliders(mpm_handle_t e, size_t n, const mpm_grid_collider_t* 
     e->grid_colliders = gc;
     e->grid_colliders_version += 1;
     return 0;
-}
+} MPM_CATCH_ALL
 
-int mpm_grid_collider_preset(int mpm_bc, float sdf_friction, mpm_grid_collider_t* out, size_t capacity, size_t* n_out) {
+int mpm_grid_collider_preset(int mpm_bc, float sdf_friction, mpm_grid_collider_t* out, size_t capacity, size_t* n_out) try {
     REQUIRE(n_out, "null argument");
     GridColliders gc{};
     if (grid_collider_preset(mpm_bc, sdf_friction, &gc)) return fail(MPM_ERR_INVALID, "mpm_bc must be -1, 0, 1, 2 or 3");
@@ -1965,9 +2089,9 @@ int mpm_grid_collider_preset(int mpm_bc, float sdf_friction, mpm_grid_collider_t
     REQUIRE((size_t)gc.n <= capacity && (gc.n == 0 || out), "output array too small");
     for (int k = 0; k < gc.n; ++k) std::memcpy(&out[k], &gc.c[k], sizeof(GridCollider));
     return 0;
-}
+} MPM_CATCH_ALL
 
-int mpm_finalize_external_contact_forces(mpm_handle_t e, float dt, float* tau_out, float* f_out) {
+int mpm_finalize_external_contact_forces(mpm_handle_t e, float dt, float* tau_out, float* f_out) try {
     READY(e);
     REQUIRE(dt > 0.f, "dt must be positive");
     if (int rc = mpm_external_body_force_to_host(e, tau_out, f_out)) return rc;
@@ -1977,50 +2101,50 @@ int mpm_finalize_external_contact_forces(mpm_handle_t e, float dt, float* tau_ou
         if (f_out) f_out[i] /= dt;
     }
     return 0;
-}
+} MPM_CATCH_ALL
 
-int mpm_spatial_force_shift(size_t n, const float* tau, const float* f, const float* offset, float* tau_out) {
+int mpm_spatial_force_shift(size_t n, const float* tau, const float* f, const float* offset, float* tau_out) try {
     REQUIRE(n == 0 || (tau && f && offset && tau_out), "null argument");
     spatial_force_shift(n, tau, f, offset, tau_out);
     return 0;
-}
+} MPM_CATCH_ALL
 
 int mpm_external_forces_at_body_origin(size_t n, const float* R_WB, const float* p_BoBq_B, const float* tau,
-                                       const float* f, float* tau_Bo_out) {
+                                       const float* f, float* tau_Bo_out) try {
     REQUIRE(n == 0 || (R_WB && p_BoBq_B && tau && f && tau_Bo_out), "null argument");
     forces_at_body_origin(n, R_WB, p_BoBq_B, tau, f, tau_Bo_out);
     return 0;
-}
+} MPM_CATCH_ALL
 
 int mpm_copy_contact_pairs(mpm_handle_t e, size_t n, const uint32_t* particle, const uint32_t* body, const float* dist,
-                           const float* normal, const float* pos, const float* rigid_v, const float* rigid_p_WB) {
+                           const float* normal, const float* pos, const float* rigid_v, const float* rigid_p_WB) try {
     READY(e);
     REQUIRE(n == 0 || (particle && body && dist && normal && pos && rigid_v && rigid_p_WB), "null contact array");
     return copy_contacts(e, n, particle, body, dist, normal, pos, rigid_v, rigid_p_WB);
-}
+} MPM_CATCH_ALL
 
-int mpm_generate_contact_pairs(mpm_handle_t e, size_t n_colliders, const mpm_collider_t* colliders, size_t* n_out) {
+int mpm_generate_contact_pairs(mpm_handle_t e, size_t n_colliders, const mpm_collider_t* colliders, size_t* n_out) try {
     READY(e);
     REQUIRE(n_colliders == 0 || colliders, "null collider array");
     REQUIRE(n_colliders <= 1024, "too many colliders");
     return generate_contacts(e, n_colliders, colliders, n_out);
-}
+} MPM_CATCH_ALL
 
 int mpm_download_contact_pairs(mpm_handle_t e, uint32_t* particle, uint32_t* body, float* dist, float* normal,
-                               float* pos, float* rigid_v, float* p_WB) {
+                               float* pos, float* rigid_v, float* p_WB) try {
     READY(e);
     return download_contacts(e, particle, body, dist, normal, pos, rigid_v, p_WB);
-}
+} MPM_CATCH_ALL
 
-int mpm_get_contact_stats(mpm_handle_t e, mpm_contact_stats_t* out) {
+int mpm_get_contact_stats(mpm_handle_t e, mpm_contact_stats_t* out) try {
     READY(e);
     REQUIRE(out, "null stats");
     *out = e->last_contact;
     return 0;
-}
+} MPM_CATCH_ALL
 
 int mpm_update_contact(mpm_handle_t e, int frame, int substep, float dt, float mu, float stiffness, float damping,
-                       int dump, int exact, int max_iters, int* iters_out, float* residual_out) {
+                       int dump, int exact, int max_iters, int* iters_out, float* residual_out) try {
     READY(e);
     if (iters_out) *iters_out = 0;
     if (residual_out) *residual_out = 0.f;
@@ -2029,12 +2153,12 @@ int mpm_update_contact(mpm_handle_t e, int frame, int substep, float dt, float m
     REQUIRE(e->grid_state == 2, "UpdateContact before UpdateGrid");
     return update_contact(e, frame, substep, dt, mu, stiffness, damping, dump, exact, max_iters, iters_out,
                           residual_out);
-}
+} MPM_CATCH_ALL
 
 // The root finder of the exact line search behind a C callback, for the known-answer tests
 // (host code only: no device is touched).
 int mpm_newton_bisect_f64(mpm_rootfind_fn fn, void* user, double x_lo, double x_hi, double guess, double x_tol,
-                          double f_tol, int max_evals, int flags, double* root_out, int* evals_out) {
+                          double f_tol, int max_evals, int flags, double* root_out, int* evals_out) try {
     REQUIRE(fn && root_out && evals_out, "null argument");
     REQUIRE(x_lo < x_hi && x_lo <= guess && guess <= x_hi && x_tol > 0 && f_tol > 0, "bad bracket / tolerances");
     double f_lo, f_hi, d;
@@ -2050,10 +2174,10 @@ int mpm_newton_bisect_f64(mpm_rootfind_fn fn, void* user, double x_lo, double x_
     *root_out = rf.root;
     *evals_out = rf.evals;
     return rf.status == 1 ? 0 : 1;
-}
+} MPM_CATCH_ALL
 
 int mpm_newton_bisect_f32(mpm_rootfind_fn fn, void* user, float x_lo, float x_hi, float guess, float x_tol,
-                          float f_tol, int max_evals, int flags, float* root_out, int* evals_out) {
+                          float f_tol, int max_evals, int flags, float* root_out, int* evals_out) try {
     REQUIRE(fn && root_out && evals_out, "null argument");
     REQUIRE(x_lo < x_hi && x_lo <= guess && guess <= x_hi && x_tol > 0 && f_tol > 0, "bad bracket / tolerances");
     double f_lo, f_hi, d;
@@ -2069,6 +2193,6 @@ int mpm_newton_bisect_f32(mpm_rootfind_fn fn, void* user, float x_lo, float x_hi
     *root_out = rf.root;
     *evals_out = rf.evals;
     return rf.status == 1 ? 0 : 1;
-}
+} MPM_CATCH_ALL
 
 }  // extern "C"

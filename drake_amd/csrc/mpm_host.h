@@ -3,6 +3,10 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
+#include <exception>
+#include <new>
+#include <stdexcept>
 #include <string>
 #include <vector>
 
@@ -17,16 +21,54 @@ using namespace mpm;
 
 static thread_local std::string g_last_error;
 
-static int fail(int code, const std::string& msg) {
-    g_last_error = msg;
+// (never throws: the message of a failure must not become a second failure -- the catch-all of the C ABI calls this)
+static int fail(int code, const std::string& msg) noexcept {
+    try {
+        g_last_error = msg;
+    } catch (...) {
+        g_last_error.clear();
+    }
     return code;
 }
+static int fail(int code, const char* msg) noexcept {
+    try {
+        g_last_error = msg;
+    } catch (...) {
+        g_last_error.clear();
+    }
+    return code;
+}
+
+// The exception barrier of the C ABI (include/mpm_hip.h: "errors never kill the caller", the reference's
+// settings.h:11-25 contract turned round: CUDA_SAFE_CALL throws only in DEBUG builds, nothing else does).  Every
+// extern "C" entry point is a function-try-block that ends in MPM_CATCH_ALL: a C++ exception raised anywhere below it
+// (std::bad_alloc / std::length_error from a container sized by a count that came off the device or out of a buffer, a
+// std::function that is empty, an ofstream failure with exceptions on ...) becomes a status code and a message instead
+// of std::terminate -- which, inside Drake, would take the whole simulation process down.
+static int exception_to_status() noexcept {
+    try {
+        throw;
+    } catch (const std::bad_alloc&) {
+        return fail(MPM_ERR_NOMEM, "host memory exhausted (std::bad_alloc) inside the engine");
+    } catch (const std::exception& ex) {
+        try {
+            return fail(MPM_ERR_INTERNAL, std::string("C++ exception inside the engine: ") + ex.what());
+        } catch (...) {
+            return fail(MPM_ERR_INTERNAL, "C++ exception inside the engine");
+        }
+    } catch (...) {
+        return fail(MPM_ERR_INTERNAL, "unknown C++ exception inside the engine");
+    }
+}
+#define MPM_CATCH_ALL \
+    catch (...) { return exception_to_status(); }
 
 #define HIP_TRY(expr)                                                                                   \
     do {                                                                                                \
         hipError_t e__ = (expr);                                                                        \
         if (e__ != hipSuccess)                                                                          \
-            return fail(MPM_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e__));               \
+            return fail(e__ == hipErrorOutOfMemory ? MPM_ERR_NOMEM : MPM_ERR_HIP,                       \
+                        std::string(#expr) + ": " + hipGetErrorString(e__));                            \
     } while (0)
 
 #define REQUIRE(cond, msg)                                   \
@@ -35,6 +77,7 @@ static int fail(int code, const std::string& msg) {
     } while (0)
 
 struct mpm_engine {
+    std::atomic<int> pins{0};   // mpm_device_synchronize of another thread is working on this engine (mpm_destroy waits)
     int device = 0;
     int bits = 7;
     mpm_material_t mat{};
@@ -178,10 +221,14 @@ struct mpm_engine {
     mpm_engine() {
         if (const char* t = getenv("MPM_CT_BATCH")) sscanf(t, "%d,%d", &ct_batch[0], &ct_batch[1]);
     }
+    // tests (mpm_debug_fail_alloc): the n-th dalloc from now reports hipErrorOutOfMemory without asking the runtime
+    int fail_alloc_countdown = 0;
     template <class T>
     int dalloc(T** out, size_t n, bool zero) {
         void* ptr = nullptr;
         const size_t bytes = std::max<size_t>(n, 1) * sizeof(T);
+        if (fail_alloc_countdown > 0 && --fail_alloc_countdown == 0)
+            return fail(MPM_ERR_NOMEM, "device allocation failed (injected by mpm_debug_fail_alloc)");
         HIP_TRY(hipMalloc(&ptr, bytes));
         allocs.push_back(ptr);
         alloc_bytes.push_back(bytes);

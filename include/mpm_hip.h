@@ -10,7 +10,10 @@
  * Conventions
  *   - plain pointers and sizes only; host buffers are caller-owned
  *   - every call returns 0 on success or a negative mpm_status; the message
- *     for the calling thread's last failure is mpm_last_error()
+ *     for the calling thread's last failure is mpm_last_error().  No call throws and no call
+ *     terminates the process: every entry point ends in a catch-all that turns a C++ exception
+ *     raised below it into MPM_ERR_NOMEM / MPM_ERR_INTERNAL (the reference's contract --
+ *     settings.h:11-25: errors never kill the caller outside DEBUG builds)
  *   - one handle <-> one HIP device; calls on one handle must be serialised
  *     by the caller (the reference is single-threaded per state as well)
  *   - "slot order" is the reference's current particle order: [faces | verts]
@@ -49,7 +52,10 @@ typedef enum {
     MPM_ERR_NO_DEVICE = -5,   /* no usable GPU: there is no CPU fallback       */
     MPM_ERR_DOMAIN = -6,      /* a particle left the grid (the reference: undefined behaviour) */
     MPM_ERR_RANGE = -7,       /* a ParticleToGrid node sum was not finite / out of the accumulators' range */
-    MPM_ERR_HALO = -8         /* partitioned domain: a particle left the zone shared with the neighbour rank */
+    MPM_ERR_HALO = -8,        /* partitioned domain: a particle left the zone shared with the neighbour rank */
+    MPM_ERR_NOMEM = -9,       /* host or device memory exhausted (std::bad_alloc / hipErrorOutOfMemory)        */
+    MPM_ERR_INTERNAL = -10    /* a C++ exception reached the C boundary and was caught there: a bug in the engine,
+                                 reported instead of terminating the calling process                         */
 } mpm_status;
 
 /* Runtime form of the compile-time constants in settings.h:36-127. */
@@ -498,6 +504,28 @@ MPM_API int mpm_dist_migrate_pack(mpm_handle_t h, void *send_left, void *send_ri
 MPM_API int mpm_dist_migrate_apply(mpm_handle_t h, const void *recv_left, const void *recv_right,
                                    size_t capacity_particles);
 MPM_API int mpm_dist_roles(mpm_handle_t h, uint8_t *roles_out /* n_particles */);
+/* What mpm_dist_migrate_apply decides from the two 16-byte headers of the received buffers ([0] records, [1] how many of
+ * them are faces, [2..3] zero; NULL = no such neighbour) before it sizes anything: the headers are CHECKED against the
+ * buffers' capacity and the scene (more records than the buffers hold: MPM_ERR_CAPACITY, the sender overflowed; more
+ * faces than records or non-zero padding: MPM_ERR_INVALID, a corrupt header; inconsistent own counts:
+ * MPM_ERR_INTERNAL), then out6 = {arriving faces, arriving vertices, face slots needed, vertex slots needed, face
+ * slots to re-allocate to, vertex slots to re-allocate to} (the last two equal the current slot space when it
+ * suffices; never more than the scene has).  Host arithmetic only: works without a GPU (tests/test_error_paths.py). */
+MPM_API int mpm_dist_plan_migration(const uint32_t *hdr_left, const uint32_t *hdr_right, size_t capacity_particles,
+                                    size_t scene_faces, size_t scene_vertices, size_t held_faces, size_t held_vertices,
+                                    size_t face_slots, size_t vertex_slots, float headroom, size_t out6[6]);
+/* Re-allocation of a partitioned rank's slot space is TWO-PHASE: every new array is allocated before anything of the
+ * engine is touched, so a failed allocation (MPM_ERR_NOMEM) leaves the handle exactly as it was -- usable, at its old
+ * size, with the arriving records not applied (the caller may free memory and call mpm_dist_migrate_apply again with
+ * the same buffers). */
+
+/* Tests of the error contract.  mpm_debug_throw raises a C++ exception inside an entry point (kind 0: std::bad_alloc,
+ * 1: std::length_error from a container asked for an absurd size, 2: a non-std exception) and returns what the
+ * boundary's catch-all made of it: MPM_ERR_NOMEM / MPM_ERR_INTERNAL, message in mpm_last_error(); host code only.
+ * mpm_debug_fail_alloc: the engine's nth device allocation from now fails as if the device were out of memory
+ * (0 = off). */
+MPM_API int mpm_debug_throw(int kind);
+MPM_API int mpm_debug_fail_alloc(mpm_handle_t h, int nth);
 
 /* UpdateContact on a partitioned domain.  Every rank solves for the grid nodes it holds with the
  * contacts of the particles it OWNS (pass only those to mpm_copy_contact_pairs;
