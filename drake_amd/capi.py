@@ -127,7 +127,7 @@ SYMBOLS = [
     "mpm_dist_set_transport", "mpm_device_synchronize", "mpm_debug_owed_substeps",
     "mpm_memcpy_d2h", "mpm_memcpy_h2d", "mpm_profile_contact_iteration", "mpm_contact_frame", "mpm_halo_zone_blocks",
     "mpm_dist_get_geometry", "mpm_dist_set_headroom", "mpm_dist_migration_quiet_time", "mpm_dist_retune",
-    "mpm_dist_plan_migration", "mpm_debug_throw", "mpm_debug_fail_alloc",
+    "mpm_dist_plan_migration", "mpm_debug_throw", "mpm_debug_fail_alloc", "mpm_set_fast_math", "mpm_get_fast_math",
 ]
 
 EXCHANGE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t)
@@ -220,6 +220,8 @@ def load_library(build: bool = True):
         "mpm_generate_contact_pairs": [vp, sz, vp, P(sz)],
         "mpm_download_contact_pairs": [vp, vp, vp, vp, vp, vp, vp, vp],
         "mpm_set_deterministic": [vp, i],
+        "mpm_set_fast_math": [vp, i],
+        "mpm_get_fast_math": [vp, P(i)],
         "mpm_substep_begin_halo": [vp, f, i, P(C.c_int), P(C.c_int), P(C.c_int), P(C.c_void_p), sz],
         "mpm_substep_end_halo": [vp, f, i, i, P(C.c_void_p), sz],
         "mpm_substep_mid_halo": [vp, f, i],
@@ -684,6 +686,17 @@ class GpuMpm:
 
     def set_deterministic(self, on: bool = True):
         self._ck(self.lib.mpm_set_deterministic(self.h, 1 if on else 0))
+
+    def set_fast_math(self, on: bool = True):
+        """CalcFemStateAndForce's divisions / square roots: correctly rounded (default) or hardware approximation + one
+        Newton step (mpm_set_fast_math)."""
+        self._ck(self.lib.mpm_set_fast_math(self.h, 1 if on else 0))
+
+    @property
+    def fast_math(self) -> bool:
+        v = C.c_int()
+        self._ck(self.lib.mpm_get_fast_math(self.h, C.byref(v)))
+        return bool(v.value)
 
     def set_stream(self, stream_handle: int | None):
         self._ck(self.lib.mpm_set_stream(self.h, C.c_void_p(stream_handle) if stream_handle else None))

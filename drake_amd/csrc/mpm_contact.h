@@ -15,9 +15,10 @@
 
 // (the poison switch of the engine whose buffers are being grown: set by the callers of grow() from their handle)
 static thread_local bool g_grow_poison = false;
-struct GrowPoison {
-    explicit GrowPoison(const mpm_engine* e) { g_grow_poison = e->poison(); }
-    ~GrowPoison() { g_grow_poison = false; }
+struct GrowPoison {   // (nests: generate_contacts -> ensure_contact_capacity; the outer setting comes back -- ADVICE r4)
+    bool before;
+    explicit GrowPoison(const mpm_engine* e) : before(g_grow_poison) { g_grow_poison = e->poison(); }
+    ~GrowPoison() { g_grow_poison = before; }
 };
 template <class T>
 static int grow(T** ptr, size_t n) {

@@ -171,6 +171,7 @@ struct DP {
     int lean_g2p;          // 1: another substep of the same mpm_run_substeps batch follows, nobody can look at the state
                            // in between: k_g2p leaves the x / v records of the face particles alone (see g2p_particle),
                            // k_p2g keeps the vertex forces of its work items in LDS only; per substep
+    int fem_fast;          // mpm_set_fast_math: k_fem<1> runs (the re-sort forms a face's centroid the way k_fem will)
     float anticip;         // re-sort: cells a particle is binned ahead per unit of velocity (0 = by position), see k_rb_count
     // fixed-point scales of the LDS tile accumulators (powers of two), see k_p2g
     double fix_m, fix_p, unfix_m, unfix_p;

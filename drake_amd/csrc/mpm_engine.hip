@@ -175,7 +175,9 @@ static void drop_step_graph(mpm_engine* e) {
 
 static void launch_fem_faces(mpm_engine* e, float dt) {
     TraceRange tr("mpm:CalcFemStateAndForce (faces)");
-    if (e->nf) hipLaunchKernelGGL(k_fem, dim3((e->g_nf + 7u) & ~7u), dim3(256), 0, e->stream, e->dp, dt);
+    if (!e->nf) return;
+    if (e->fast_math) hipLaunchKernelGGL(k_fem<1>, dim3((e->g_nf + 7u) & ~7u), dim3(256), 0, e->stream, e->dp, dt);
+    else hipLaunchKernelGGL(k_fem<0>, dim3((e->g_nf + 7u) & ~7u), dim3(256), 0, e->stream, e->dp, dt);
 }
 static void launch_fem_vertices(mpm_engine* e) {
     TraceRange tr("mpm:CalcFemStateAndForce (vertex forces)");
@@ -278,6 +280,7 @@ int mpm_finalize(mpm_handle_t e) try {
     p.capH = (unsigned)std::min<size_t>(p.nblocks, np);
     p.capA = (unsigned)std::min<size_t>(p.nblocks, (size_t)27 * p.capH);
     p.halo_cls = -1;
+    p.fem_fast = e->fast_math ? 1 : 0;
     p.item_groups = getenv("MPM_ITEM_GROUPS") ? std::max(1, atoi(getenv("MPM_ITEM_GROUPS"))) : 48;
     p.item_groups_small = getenv("MPM_ITEM_GROUPS_SMALL") ? std::max(1, atoi(getenv("MPM_ITEM_GROUPS_SMALL"))) : 16;
     p.item_small_below = getenv("MPM_ITEM_SMALL_BELOW") ? atoi(getenv("MPM_ITEM_SMALL_BELOW")) : 6500;
@@ -459,7 +462,7 @@ int mpm_finalize(mpm_handle_t e) try {
         int a = 0, b = 0, c = 0;
         (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, k_p2g<1, 0>, P2G_THREADS, 0);
         (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, k_g2p, G2P_THREADS, 0);
-        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&c, k_fem, 256, 0);
+        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&c, k_fem<0>, 256, 0);
         std::fprintf(stderr, "[mpm_hip] resident workgroups per CU: p2g %d, g2p %d, fem %d\n", a, b, c);
     }
     e->finalized = true;
@@ -514,6 +517,30 @@ int mpm_set_deterministic(mpm_handle_t e, int on) try {
     }
     if (e->deterministic != (on != 0)) drop_step_graph(e);   // the captured substep has one kernel more or less
     e->deterministic = on != 0;
+    return 0;
+} MPM_CATCH_ALL
+
+int mpm_set_fast_math(mpm_handle_t e, int on) try {
+    REQUIRE(e, "null handle");
+    if (e->finalized) {
+        if (int rc = use(e)) return rc;
+        if (int rc = settle(e)) return rc;   // (owed substeps run with the arithmetic they were enqueued with)
+    }
+    if (e->fast_math != (on != 0)) {
+        drop_step_graph(e);   // captured launches name the kernel
+        for (auto& kg : e->halo_graph) {
+            if (kg.exec) (void)hipGraphExecDestroy(kg.exec);
+            kg.exec = nullptr;
+        }
+    }
+    e->fast_math = on != 0;
+    e->dp.fem_fast = e->fast_math ? 1 : 0;
+    return 0;
+} MPM_CATCH_ALL
+
+int mpm_get_fast_math(mpm_handle_t e, int* on_out) try {
+    REQUIRE(e && on_out, "null argument");
+    *on_out = e->fast_math ? 1 : 0;
     return 0;
 } MPM_CATCH_ALL
 

@@ -126,6 +126,9 @@ struct mpm_engine {
     int* d_iota = nullptr;     // identity map, created on first use (views in original order)
     bool api_identity = true;
     bool deterministic = getenv("MPM_DETERMINISTIC") != nullptr;  // see mpm_set_deterministic
+    // mpm_set_fast_math / MPM_FAST_MATH=1: k_fem's divisions and square roots by the hardware approximation + one Newton
+    // step (mpm_math.h, FM = 1) instead of correctly rounded (the default)
+    bool fast_math = getenv("MPM_FAST_MATH") != nullptr && atoi(getenv("MPM_FAST_MATH")) != 0;
     bool p2g_fixed_point = getenv("MPM_P2G_FIXED") != nullptr;    // the fixed-point LDS tile of k_p2g outside deterministic mode too (A/B)
     // native chain (mpm_chain_*): communicator, neighbours, device buffers
     struct Chain {

@@ -15,50 +15,49 @@ struct Material {
     int gravity_axis, wall;
 };
 
-// Reciprocal, square root and reciprocal square root of the constitutive update.  k_fem issues ~1000 vector
-// instructions per face, of which an IEEE-correct division costs ten (v_div_scale x2, v_rcp, four fma, v_div_fmas,
-// v_div_fixup) and a correctly rounded sqrtf eight: with 19 divisions and 10 square roots per face the kernel was as
-// close to the vector ALU's limit (84 % busy at 6 waves per SIMD) as to the memory system's.  The hardware
-// approximations (1 ulp each) followed by ONE Newton step in fused multiply-adds (2 - 3 instructions) give results
-// within ~0.6 ulp without the scaling / fix-up instructions: 3 - 4 instructions instead of 8 - 10.  (The bare
-// approximations were measured too: 44 instructions fewer still, but the stress -- a difference of nearly equal
-// numbers, 2 mu (F - R) -- came out 6x noisier than with correctly rounded operations, more than a float evaluation's
-// own distance from a double one allows, tests/test_precision_gpu.py.)  -DMPM_FEM_MATH=0 restores the correctly rounded forms,
-// =2 the bare approximations (A/B measurements).
-#ifndef MPM_FEM_MATH
-#define MPM_FEM_MATH 1
-#endif
-#define MPM_FEM_IEEE (MPM_FEM_MATH == 0)
-#if MPM_FEM_MATH == 0
-MPM_DEV float f_rcp(float x) { return 1.f / x; }
-MPM_DEV float f_sqrt(float x) { return sqrtf(x); }
-MPM_DEV float f_rsqrt(float x) { return 1.f / sqrtf(x); }
-#elif MPM_FEM_MATH == 2
-MPM_DEV float f_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
-MPM_DEV float f_sqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
-MPM_DEV float f_rsqrt(float x) { return __builtin_amdgcn_rsqf(x); }
-#else
+// Reciprocal, square root and reciprocal square root of the constitutive update, in three arithmetics selected by a
+// template parameter FM that runs from the kernel (k_fem<FM>) down through every helper of this file:
+//   FM = 0  correctly rounded division and square root (what the reference's expressions mean; an IEEE division is ten
+//           vector instructions -- v_div_scale x2, v_rcp, four fma, v_div_fmas, v_div_fixup --, sqrtf eight).  THE DEFAULT
+//           since round 5: with it one substep agrees with the oracle at north_star's plain 1e-5
+//           wherever float arithmetic can deliver that (tests/test_ieee_variant_gpu.py, tests/helpers.py); every other
+//           user of these helpers (Finalize's k_init_faces, the 3x3 solve of the contact direction) always runs it.
+//   FM = 1  the hardware approximations (1 ulp each) followed by ONE Newton step in fused multiply-adds: 3 - 4
+//           instructions instead of 8 - 10, results within ~0.6 ulp; with 19 divisions and 10 square roots per face
+//           k_fem drops from ~910 to ~630 vector instructions per face, 2.4 us per substep at 1M particles.  The
+//           caller's choice: mpm_set_fast_math(h, 1) / MPM_FAST_MATH=1.
+//   FM = 2  the bare approximations (measurements only: the stress -- a difference of nearly equal numbers,
+//           2 mu (F - R) -- comes out 6x noisier than with correctly rounded operations, tests/test_precision_gpu.py).
+template <int FM>
 MPM_DEV float f_rcp(float x) {
+    if (FM == 0) return 1.f / x;
     const float r = __builtin_amdgcn_rcpf(x);
+    if (FM == 2) return r;
     return fmaf(fmaf(-x, r, 1.f), r, r);                 // r + r (1 - x r)
 }
+template <int FM>
 MPM_DEV float f_rsqrt(float x) {
+    if (FM == 0) return 1.f / sqrtf(x);
     const float y = __builtin_amdgcn_rsqf(x);
+    if (FM == 2) return y;
     const float e = fmaf(-x * y, y, 1.f);                // 1 - x y^2
     return fmaf(.5f * y, e, y);                          // y + y e / 2
 }
+template <int FM>
 MPM_DEV float f_sqrt(float x) {
+    if (FM == 0) return sqrtf(x);
+    if (FM == 2) return __builtin_amdgcn_sqrtf(x);
     const float y = __builtin_amdgcn_rsqf(x);
     const float s = x * y;
     return x > 0.f ? fmaf(fmaf(-s, s, x), .5f * y, s) : 0.f;   // s + (x - s^2) y / 2
 }
-#endif
 
 // ---- 2x2 ------------------------------------------------------------------
 MPM_DEV float det2(const float* m) { return m[0] * m[3] - m[1] * m[2]; }
 
+template <int FM = 0>
 MPM_DEV void inv2(const float* m, float* o) {  // math_tools.cuh:142-149
-    const float di = f_rcp(det2(m));
+    const float di = f_rcp<FM>(det2(m));
     o[0] = m[3] * di;
     o[1] = -m[1] * di;
     o[2] = -m[2] * di;
@@ -67,6 +66,7 @@ MPM_DEV void inv2(const float* m, float* o) {  // math_tools.cuh:142-149
 
 // Rotation factor of the polar decomposition of a 2x2 matrix and the symmetric
 // factor S (math_tools.cuh:512-549).
+template <int FM = 0>
 MPM_DEV void polar2(const float* A, float* U, float* S) {
     U[0] = 1.f; U[1] = 0.f; U[2] = 0.f; U[3] = 1.f;
     S[0] = A[0]; S[1] = A[1]; S[2] = A[2]; S[3] = A[3];
@@ -79,7 +79,7 @@ MPM_DEV void polar2(const float* A, float* U, float* S) {
     } else {
         B0 = A[0] + A[3]; B1 = A[1] - A[2]; B2 = A[2] - A[1]; B3 = A[3] + A[0];
     }
-    const float k = f_rsqrt(fabsf(B0 * B3 - B1 * B2));
+    const float k = f_rsqrt<FM>(fabsf(B0 * B3 - B1 * B2));
     U[0] = B0 * k; U[1] = B1 * k; U[2] = B2 * k; U[3] = B3 * k;
     S[0] = (A[0] * A[0] + A[2] * A[2] + adet) * k;
     S[1] = (A[0] * A[1] + A[2] * A[3]) * k;
@@ -92,17 +92,18 @@ MPM_DEV void polar2(const float* A, float* U, float* S) {
 // reference builds it through its Jacobi SVD, so the same branches are kept to
 // reproduce its column/sign choices (they cancel in U V^T, but only up to
 // rounding).
+template <int FM = 0>
 MPM_DEV void svd2_rotation(const float* A, float* R) {
     float P[4], S[4];
-    polar2(A, P, S);
+    polar2<FM>(A, P, S);
     float c, s, s1, s2;
     if (fabsf(S[1]) < 1e-5f) {
         c = 1.f; s = 0.f; s1 = S[0]; s2 = S[3];
     } else {
         const float tao = .5f * (S[0] - S[3]);
-        const float w = f_sqrt(tao * tao + S[1] * S[1]);
-        const float t = S[1] * f_rcp(tao > 0.f ? tao + w : tao - w);
-        c = f_rsqrt(t * t + 1.f);
+        const float w = f_sqrt<FM>(tao * tao + S[1] * S[1]);
+        const float t = S[1] * f_rcp<FM>(tao > 0.f ? tao + w : tao - w);
+        c = f_rsqrt<FM>(t * t + 1.f);
         s = -t * c;
         s1 = c * c * S[0] - 2.f * c * s * S[1] + s * s * S[3];
         s2 = s * s * S[0] + 2.f * c * s * S[1] + c * c * S[3];
@@ -126,11 +127,12 @@ MPM_DEV void svd2_rotation(const float* A, float* R) {
 }
 
 // 2D fixed-corotated first Piola-Kirchhoff stress (cuda_mpm_kernels.cuh:72-86)
+template <int FM = 0>
 MPM_DEV void pk1_fixed_corotated_2d(const Material& M, const float* F, float* P) {
     float R[4], Fi[4];
-    svd2_rotation(F, R);
+    svd2_rotation<FM>(F, R);
     const float J = det2(F);
-    inv2(F, Fi);
+    inv2<FM>(F, Fi);
     const float a = 2.f * M.mu, b = M.lambda * (J - 1.f) * J;
     P[0] = a * (F[0] - R[0]) + b * Fi[0];
     P[1] = a * (F[1] - R[1]) + b * Fi[2];
@@ -158,10 +160,11 @@ MPM_DEV void mulv3(const float* a, const float* x, float* y) {
 }
 MPM_DEV float dot3(const float* a, const float* b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
 
+template <int FM = 0>
 MPM_DEV void inv33(const float* m, float* o) {  // math_tools.cuh:113-134
     const float det = m[0] * (m[4] * m[8] - m[7] * m[5]) - m[3] * (m[1] * m[8] - m[7] * m[2]) +
                       m[6] * (m[1] * m[5] - m[4] * m[2]);
-    const float di = f_rcp(det);
+    const float di = f_rcp<FM>(det);
     o[0] = (m[4] * m[8] - m[5] * m[7]) * di;
     o[3] = (m[5] * m[6] - m[3] * m[8]) * di;
     o[6] = (m[3] * m[7] - m[4] * m[6]) * di;
@@ -175,13 +178,13 @@ MPM_DEV void inv33(const float* m, float* o) {  // math_tools.cuh:113-134
 
 // One Givens rotation zeroing the lower entry of column `col` between rows
 // (ri, rk) of R (COLS wide), applied to the rows of Qt (3 wide) as well.
-template <int COLS>
+template <int COLS, int FM = 0>
 MPM_DEV void givens_step(float* R, float* Qt, int ri, int rk, int col) {
     const float a = R[ri * COLS + col], b = R[rk * COLS + col];
     const float q2 = a * a + b * b;
     float c = 1.f, s = 0.f;
     if (q2 > 0.f) {
-        const float t = f_rsqrt(q2);
+        const float t = f_rsqrt<FM>(q2);
         c = a * t;
         s = -b * t;
     }
@@ -201,14 +204,14 @@ MPM_DEV void givens_step(float* R, float* Qt, int ri, int rk, int col) {
 
 // QR of a 3xCOLS matrix by Givens rotations in the elimination order of
 // math_tools.cuh:456-510 (column by column, bottom row upwards).
-template <int COLS>
+template <int COLS, int FM = 0>
 MPM_DEV void givens_qr3(const float* A, float* Q, float* R) {
     float Qt[9] = {1.f, 0.f, 0.f, 0.f, 1.f, 0.f, 0.f, 0.f, 1.f};
 #pragma unroll
     for (int i = 0; i < 3 * COLS; ++i) R[i] = A[i];
-    givens_step<COLS>(R, Qt, 1, 2, 0);
-    givens_step<COLS>(R, Qt, 0, 1, 0);
-    givens_step<COLS>(R, Qt, 1, 2, 1);
+    givens_step<COLS, FM>(R, Qt, 1, 2, 0);
+    givens_step<COLS, FM>(R, Qt, 0, 1, 0);
+    givens_step<COLS, FM>(R, Qt, 1, 2, 1);
 #pragma unroll
     for (int i = 0; i < 3; ++i)
 #pragma unroll
@@ -216,9 +219,10 @@ MPM_DEV void givens_qr3(const float* A, float* Q, float* R) {
 }
 
 // Return mapping of the cloth model (cuda_mpm_kernels.cuh:146-181).
+template <int FM = 0>
 MPM_DEV void project_strain(const Material& M, float* F) {
     float Q[9], R[9];
-    givens_qr3<3>(F, Q, R);
+    givens_qr3<3, FM>(F, Q, R);
     if (M.gamma == 0.f || R[8] > 1.f) {
         R[8] = fminf(R[8], 1.f);
         R[2] = 0.f;
@@ -243,12 +247,13 @@ MPM_DEV void project_strain(const Material& M, float* F) {
 
 // dPsi/dF of the anisotropic cloth energy (cuda_mpm_kernels.cuh:88-144):
 // in-plane fixed corotated on R[0:2,0:2], shear gamma, normal penalty K.
+template <int FM = 0>
 MPM_DEV void cloth_dphi_dF(const Material& M, const float* F, float* out) {
     float Q[9], R[9];
-    givens_qr3<3>(F, Q, R);
+    givens_qr3<3, FM>(F, Q, R);
     const float Rh[4] = {R[0], R[1], R[3], R[4]};
     float P2[4];
-    pk1_fixed_corotated_2d(M, Rh, P2);
+    pk1_fixed_corotated_2d<FM>(M, Rh, P2);
     // Q * [P2 0; 0 0]
     float Pp[9];
 #pragma unroll
@@ -271,7 +276,7 @@ MPM_DEV void cloth_dphi_dF(const Material& M, const float* F, float* out) {
     A[6] = A[2];
     A[7] = A[5];
     float Ri[9], QA[9], Pn[9];
-    inv33(R, Ri);
+    inv33<FM>(R, Ri);
     mul33(Q, A, QA);
     mul33T(QA, Ri, Pn);
 #pragma unroll

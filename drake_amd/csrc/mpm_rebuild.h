@@ -68,9 +68,10 @@ __global__ __launch_bounds__(256) void k_rb_count(DP p) {
         const int s0 = __float_as_int(f3.y), s1 = __float_as_int(f3.z), s2 = __float_as_int(f3.w);
         const float4 xa = S.q[0][s0], xb = S.q[0][s1], xc = S.q[0][s2];
         const float4 a = S.q[1][s0], b = S.q[1][s1], c = S.q[1][s2];
-        // (the centroid as k_fem forms it -- a third as a product in the product build: an IEEE division is ten vector
-        // instructions, and there were six)
-        auto mean3 = [](float u, float v, float w) { return MPM_FEM_IEEE ? (u + v + w) / 3.f : (u + v + w) * (1.f / 3.f); };
+        // (the centroid as k_fem forms it: a division, or -- fast math, DP::fem_fast -- a third as a product: an IEEE
+        // division is ten vector instructions, and there are six)
+        const bool fast = p.fem_fast != 0;
+        auto mean3 = [fast](float u, float v, float w) { return fast ? (u + v + w) * (1.f / 3.f) : (u + v + w) / 3.f; };
         xq = make_float4(mean3(xa.x, xb.x, xc.x), mean3(xa.y, xb.y, xc.y), mean3(xa.z, xb.z, xc.z), 1.f);
         vx = mean3(a.x, b.x, c.x); vy = mean3(a.y, b.y, c.y); vz = mean3(a.z, b.z, c.z);
     } else {

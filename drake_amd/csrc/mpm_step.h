@@ -38,6 +38,9 @@ MPM_DEV bool gated_out(const DP& p) {
     return ((p.gated & 1) && p.ctl->need_rebuild) || ((p.gated & 2) && (p.ctl->error & ERR_SLABS));
 }
 
+// FM: the arithmetic of the divisions and square roots (mpm_math.h: 0 = correctly rounded, the default; 1 = hardware
+// approximation + one Newton step, mpm_set_fast_math)
+template <int FM>
 __global__ __launch_bounds__(256) void k_fem(DP p, float dt) {
     if (gated_out(p)) return;
     const unsigned nfa = (unsigned)p.ctl->nfa;
@@ -74,8 +77,8 @@ __global__ __launch_bounds__(256) void k_fem(DP p, float dt) {
     // the face particle sits at the centroid and moves with the mean velocity (:203-207);
     // vol and C8 ride along unchanged
     // (a third as a product: an IEEE division costs ten vector instructions, see f_rcp in mpm_math.h)
-    const float third = MPM_FEM_IEEE ? 0.f : (1.f / 3.f);
-    auto mean3 = [&](float a, float b, float c) { return MPM_FEM_IEEE ? (a + b + c) / 3.f : (a + b + c) * third; };
+    const float third = FM == 0 ? 0.f : (1.f / 3.f);
+    auto mean3 = [&](float a, float b, float c) { return FM == 0 ? (a + b + c) / 3.f : (a + b + c) * third; };
     S.q[0][i] = make_float4(mean3(xa.x, xb.x, xc.x), mean3(xa.y, xb.y, xc.y), mean3(xa.z, xb.z, xc.z), volw);
     S.q[1][i] = make_float4(mean3(va.x, vb.x, vc.x), mean3(va.y, vb.y, vc.y), mean3(va.z, vb.z, vc.z), C8);
     float F[9];
@@ -92,7 +95,7 @@ __global__ __launch_bounds__(256) void k_fem(DP p, float dt) {
     cF[5] = dt * C[3] * F[2] + (1.f + dt * C[4]) * F[5] + dt * C[5] * F[8];
     cF[6] = F[6]; cF[7] = F[7];
     cF[8] = dt * C[6] * F[2] + dt * C[7] * F[5] + (1.f + dt * C[8]) * F[8];
-    project_strain(p.M, cF);
+    project_strain<FM>(p.M, cF);
     // in-plane columns from the deformed edges (:230-250); the Dm^-1[2] = 0 terms are left out
 #pragma unroll
     for (int d = 0; d < 3; ++d) {
@@ -103,7 +106,7 @@ __global__ __launch_bounds__(256) void k_fem(DP p, float dt) {
     pack_F(cF, S.fq[0][i], S.fq[1][i], S.f8[i]);
 
     float P[9];
-    cloth_dphi_dF(p.M, cF, P);
+    cloth_dphi_dF<FM>(p.M, cF, P);
 #pragma unroll
     for (int d = 0; d < 9; ++d) P[d] *= vol;
     // tau = (V P[:,2]) (x) F[:,2]  (:265-267), kept factored: the second factor is in fq[0] already

@@ -268,15 +268,30 @@ class DomainChain(HaloChain):
         # buffers are sized for the worst case: 9 MB for 65536 records; a migration of a cloth at rest moves none).
         rec = e.dist_migration_buffer_bytes(1) - 16
         size_out = {n: 16 + rec * min(int(b[:4].cpu().view(torch.int32)[0]), self.mig_cap) for n, b in pairs}
-        size_in, reqs = {}, []
-        count_group = None if self.backend == "nccl" else self.group   # (CPU tensors: the default, gloo, group)
+        # The record counts travel over THIS CHAIN'S group, as tensors of the kind that group carries (with the
+        # "nccl" backend they used to go as CPU tensors through the DEFAULT group, which only works when that one happens
+        # to be gloo, as in bench.py; a program whose only group is NCCL -- the usual torchrun setup -- raised).  Device
+        # tensors in one batch for RCCL, CPU tensors for gloo / the in-process transport.
+        size_in = {}
+        cdev = self.device if self.backend == "nccl" else torch.device("cpu")
+        outs = {n: torch.tensor([size_out[n]], dtype=torch.int64, device=cdev) for n, _ in pairs}
         for n, _ in pairs:
-            size_in[n] = torch.zeros(1, dtype=torch.int64)
-            reqs.append(dist.isend(torch.tensor([size_out[n]], dtype=torch.int64), n, group=count_group))
-            reqs.append(dist.irecv(size_in[n], n, group=count_group))
-        for r in reqs:
-            r.wait()
-        size_in = {n: int(t[0]) for n, t in size_in.items()}
+            size_in[n] = torch.zeros(1, dtype=torch.int64, device=cdev)
+        if self.backend == "nccl":
+            ops = []
+            for n, _ in pairs:
+                ops.append(dist.P2POp(dist.isend, outs[n], n, group=self.group))
+                ops.append(dist.P2POp(dist.irecv, size_in[n], n, group=self.group))
+            for w in dist.batch_isend_irecv(ops):
+                w.wait()
+        else:
+            reqs = []
+            for n, _ in pairs:
+                reqs.append(dist.isend(outs[n], n, group=self.group))
+                reqs.append(dist.irecv(size_in[n], n, group=self.group))
+            for r in reqs:
+                r.wait()
+        size_in = {n: int(t.cpu()[0]) for n, t in size_in.items()}
         self.mig_bytes_sent = dict(size_out)
         if self.staged:
             reqs, hosts = [], {}
@@ -303,8 +318,10 @@ class DomainChain(HaloChain):
         self.migrations += 1
         if self.migrate_every == 0:
             # the ranks agree on the smallest estimate (apply has just synchronised the stream: the read-back is cheap)
-            t = torch.tensor([e.dist_migration_quiet_time()], dtype=torch.float64)
-            dist.all_reduce(t, op=dist.ReduceOp.MIN, group=self.group if self.backend != "nccl" else None)
+            # (over this chain's group as well: a device tensor for RCCL)
+            t = torch.tensor([e.dist_migration_quiet_time()], dtype=torch.float64,
+                             device=self.device if self.backend == "nccl" else torch.device("cpu"))
+            dist.all_reduce(t, op=dist.ReduceOp.MIN, group=self.group)
             self.set_quiet_time(float(t.item()))
 
     def set_quiet_time(self, t_all: float):

@@ -302,6 +302,22 @@ MPM_API int mpm_debug_owed_substeps(mpm_handle_t h, uint32_t *out);
  * 2^29 in magnitude, in which case their last bit, 2^-53 of the sum, depends on the order). */
 MPM_API int mpm_set_deterministic(mpm_handle_t h, int on);
 
+/* The arithmetic of CalcFemStateAndForce's 19 divisions and 10 square roots per face (the QR / polar / SVD steps of
+ * cuda_mpm_kernels.cuh:72-181 through math_tools.cuh:456-597).
+ *   on = 0 (default): correctly rounded, as the reference's expressions read.  One substep then agrees with a plain-C
+ *     restatement of the reference at north_star's "float state within 1e-5 relative" wherever float arithmetic can
+ *     deliver that (tests/test_ieee_variant_gpu.py).
+ *   on = 1: the hardware's 1-ulp reciprocal / reciprocal square root followed by one Newton step (results within
+ *     ~0.6 ulp): 2.4 us per substep less at 1M particles (k_fem 910 -> 630 vector instructions per face); the
+ *     velocities of one substep then differ from the strict path's by about the float rounding noise of that substep
+ *     (1.4 x the distance between a float and a double evaluation; 1.0 - 1.7e-5 of max|v| on the parity scenes).
+ *     The reference itself is built with -use_fast_math (tools/skylark/cuda.bzl:66-80), i.e. with CUDA's
+ *     approximate division and square root: this switch is the closer analogue of what the reference RUNS, the default
+ *     of what its source SAYS.
+ * Also MPM_FAST_MATH=1 in the environment at mpm_create.  May be changed between substeps. */
+MPM_API int mpm_set_fast_math(mpm_handle_t h, int on);
+MPM_API int mpm_get_fast_math(mpm_handle_t h, int *on_out);
+
 /* GpuMpmSolver::SyncParticleStateToCpu (cuda_mpm_solver.cu:185-191):
  * pos_out: float[3*n_particles] in slot order (the reference fills
  * positions_host()). */

@@ -234,3 +234,61 @@ def test_domain_chain_migrates_particles_between_neighbours(world, cuts, migrate
         assert [sum(1 for b in begins if b < pk) for pk in packs] == want
         # the zones straddle this rank's cuts in global block coordinates
         assert zones == ((cuts[r] - 2, cuts[r] + 1), (cuts[r + 1] - 2, cuts[r + 1] + 1))
+
+
+def _nccl_shaped_worker(rank, world, cuts, port, q):
+    """A DomainChain told that its transport is "nccl" must talk over ITS group only, never over the default group
+    (an NCCL-only program has no gloo default group to fall back on).  RCCL itself needs one GPU per rank,
+    so here the chain's group is a gloo subgroup standing in for it (device = cpu) and the DEFAULT group is poisoned:
+    any collective or point-to-point call without an explicit group fails the test."""
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.pop("MPM_MIG_SAFETY", None)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    group = dist.new_group(backend="gloo")
+    from drake_amd import dist as mdist
+    seen = []
+    # (isend / irecv themselves cannot be wrapped: P2POp checks their identity; in this mode the chain uses them only
+    # inside batch_isend_irecv, whose ops carry their group)
+    for name in ("all_reduce", "batch_isend_irecv"):
+        real = getattr(dist, name)
+
+        def guarded(*a, _real=real, _name=name, **kw):
+            if _name == "batch_isend_irecv":
+                assert all(op.group is group for op in a[0]), "a point-to-point op outside the chain's group"
+            else:
+                assert kw.get("group") is group, f"dist.{_name} on the default group"
+            seen.append(_name)
+            return _real(*a, **kw)
+        setattr(mdist.dist, name, guarded)
+    eng = FakeDomainEngine(300, cuts[-1])
+    eng.dist_migration_quiet_time = lambda: (rank + 2) * 3.0e-3
+    chain = mdist.DomainChain(eng, rank, world, cuts, zone_blocks=2, ghost_cells=2, ghost_margin_cells=2, capacity_blocks=16,
+                              migrate_every=0, migrate_capacity=128, group=group, backend="nccl", split=False)
+    assert not chain.staged
+    for _ in range(8):
+        chain.substep(1e-3, -1)
+    q.put((rank, set(eng.owned), sorted(set(seen))))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_a_chain_on_an_nccl_group_never_touches_the_default_group():
+    world, cuts = 2, [0, 8, 16]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29900 + (os.getpid() % 200)
+    procs = [ctx.Process(target=_nccl_shaped_worker, args=(r, world, cuts, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = {}
+    for _ in range(world):
+        item = q.get(timeout=120)
+        got[item[0]] = item[1:]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert sorted(g for r in range(world) for g in got[r][0]) == list(range(300))
+    for r in range(world):
+        assert "all_reduce" in got[r][1] and "batch_isend_irecv" in got[r][1]
