@@ -164,20 +164,38 @@ def contact_leg(device, steps=20, warmup=5):
     1M-particle cloth stack pressed on a rigid floor (half-space z < 0.25), contact pairs made on the
     device, UpdateContact with the bagging demo's parameters (k = 1e6, d = 1e-5, mu = 1, dt = 2e-4,
     examples/multibody/deformable/mpm_bagging.cc:9,15-17).  One coupled substep = RebuildMapping ...
-    UpdateGrid, pairs, UpdateContact, GridToParticle (deformable_driver.h:244-258)."""
+    UpdateGrid, pairs, UpdateContact, GridToParticle (deformable_driver.h:244-258).
+    `ms_per_substep` goes through mpm_run_coupled_substeps (the loop body of deformable_driver.h:240-258 n times in one
+    call -- an entry point the reference does not have, like mpm_run_substeps for the headline); `reference_call_pattern`
+    is the same schedule through the reference's seven calls per substep on a second engine."""
     from drake_amd import Collider, GpuMpm, scenes
     bits, layers, res = scenes.CONFIGS["cloth_1m"]
     floor_z, k, d, mu, dt = 0.25, 1e6, 1e-5, 1.0, 2e-4
-    g = GpuMpm(bits, device=device)
-    sheets = scenes.cloth_stack(layers, res, bits, z0=floor_z - 0.004)
-    for pos, vel, idx in sheets:
-        vel[:, 2] -= 0.5
-    scenes.populate(g, sheets)
-    g.reallocate_external_bodies(1)
-    floor = [Collider(0, body=0, p_WB=(0.5, 0.5, floor_z))]
-    def coupled(first, count):
-        """`count` coupled substeps; the first `first` of them are not timed"""
-        iters, contacts, t0 = [], [], 0.0
+    floor = (Collider * 1)(Collider(0, body=0, p_WB=(0.5, 0.5, floor_z)))   # (the ctypes array built once, as a C++ caller would)
+
+    def engine():
+        g = GpuMpm(bits, device=device)
+        sheets = scenes.cloth_stack(layers, res, bits, z0=floor_z - 0.004)
+        for pos, vel, idx in sheets:
+            vel[:, 2] -= 0.5
+        scenes.populate(g, sheets)
+        g.reallocate_external_bodies(1)
+        return g
+
+    def batched(g, first, count):
+        """`count` coupled substeps in two calls; the first `first` of them are not timed"""
+        if first:
+            g.run_coupled_substeps(first, dt, floor, mu, k, d)
+        g.gpu_sync()
+        t0 = time.perf_counter()
+        rs = g.run_coupled_substeps(count - first, dt, floor, mu, k, d)
+        g.gpu_sync()
+        return time.perf_counter() - t0, [r["iterations"] for r in rs], [r["contacts"] for r in rs], sum(r["setup_reused"] for r in rs)
+
+    def seven_calls(g, first, count):
+        """the reference's calls in the reference's order (deformable_driver.h:244-258); the pair count stays on the device
+        (want_count = False) and comes back with UpdateContact's result"""
+        iters, contacts, reused, t0 = [], [], 0, 0.0
         for s in range(count):
             if s == first:
                 g.gpu_sync()
@@ -186,21 +204,36 @@ def contact_leg(device, steps=20, warmup=5):
             g.calc_fem_state_and_force(dt)
             g.particle_to_grid(dt)
             g.update_grid(-1)
-            n = g.generate_contact_pairs(floor)
+            g.generate_contact_pairs(floor, want_count=False)
             r = g.update_contact(dt, mu, k, d)
             g.grid_to_particle(dt)
             if s >= first:
                 iters.append(r["iterations"])
-                contacts.append(n)
+                contacts.append(r["contacts"])
+                reused += int(r["setup_reused"])
         g.gpu_sync()
-        return time.perf_counter() - t0, iters, contacts
+        return time.perf_counter() - t0, iters, contacts, reused
 
-    # the impact: substeps `warmup` .. `warmup + steps` after the release (the number this leg reports) ...
-    el, iters, contacts = coupled(warmup, warmup + steps)
-    # ... and the same stack once it has settled on the floor (fewer Newton iterations per solve)
-    el_s, iters_s, contacts_s = coupled(100, 100 + steps)
-    settled = dict(ms_per_substep=el_s / steps * 1e3, contacts=float(np.mean(contacts_s)),
-                   newton_iterations=float(np.mean(iters_s)), after_substeps=warmup + steps + 100)
+    def schedule(g, run):
+        # the impact: substeps `warmup` .. `warmup + steps` after the release (the number this leg reports) ...
+        el, iters, contacts, reused = run(g, warmup, warmup + steps)
+        # ... and the same stack once it has settled on the floor (fewer Newton iterations per solve)
+        el_s, iters_s, contacts_s, reused_s = run(g, 100, 100 + steps)
+        return dict(ms_per_substep=el / steps * 1e3, substeps_per_s=steps / el, contacts=float(np.mean(contacts)),
+                    newton_iterations=float(np.mean(iters)), solves_on_a_reused_setup=reused,
+                    settled=dict(ms_per_substep=el_s / steps * 1e3, contacts=float(np.mean(contacts_s)),
+                                 newton_iterations=float(np.mean(iters_s)), after_substeps=warmup + steps + 100,
+                                 solves_on_a_reused_setup=reused_s))
+
+    g2 = engine()
+    ref_calls = schedule(g2, seven_calls)
+    ref_calls["calls"] = ("RebuildMapping(false), CalcFemStateAndForce, ParticleToGrid, UpdateGrid, pairs on the device, "
+                          "UpdateContact, GridToParticle per substep (deformable_driver.h:244-258)")
+    assert g2.stats()["error_flags"] == 0
+    g2.destroy()
+    g = engine()
+    main = schedule(g, batched)
+    settled = main["settled"]
     # roofline of the Newton iteration (~ 2 * 76 B per contact + 300 B per cell carrying contact
     # Hessians per iteration), on the settled stack: one more coupled substep up to the solve, then the four kernels of
     # an iteration re-launched back to back on that state and timed with HIP events (mpm_profile_contact_iteration)
@@ -225,8 +258,10 @@ def contact_leg(device, steps=20, warmup=5):
     st = g.stats()
     assert st["error_flags"] == 0, st
     g.destroy()
-    return dict(ms_per_substep=el / steps * 1e3, substeps_per_s=steps / el, contacts=float(np.mean(contacts)),
-                newton_iterations=float(np.mean(iters)), steps=steps, warmup=warmup, settled=settled, roofline=roofline,
+    return dict(ms_per_substep=main["ms_per_substep"], substeps_per_s=main["substeps_per_s"], contacts=main["contacts"],
+                newton_iterations=main["newton_iterations"], steps=steps, warmup=warmup,
+                solves_on_a_reused_setup=main["solves_on_a_reused_setup"],
+                settled=settled, reference_call_pattern=ref_calls, roofline=roofline,
                 params=dict(stiffness=k, damping=d, friction_mu=mu, dt=dt, floor_z=floor_z, line_search="backtracking"),
                 workload="cloth_1m on a half-space, pairs from mpm_generate_contact_pairs (device)")
 
@@ -274,6 +309,8 @@ def main():
                     help="strong (default, BASELINE.json: substeps/s at 1M particles on 1/2/4/8 GPUs): the ranks share "
                          "ONE copy of the workload; weak: every rank owns its own copy")
     ap.add_argument("--no-contact-leg", action="store_true", help="skip the config-3 (contact) record")
+    ap.add_argument("--contact-only", action="store_true",
+                    help="only the config-3 (contact) record: the command whose rocprofv3 kernel trace is profiles/rNN_contact_*")
     ap.add_argument("--launcher-selftest", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
 
@@ -289,6 +326,10 @@ def main():
 
     global HOST
     HOST = host_description()   # (forks lscpu: before the first GPU call of this process)
+    if args.contact_only:
+        print(json.dumps(dict(contact=contact_leg(int(os.environ.get("LOCAL_RANK", "0")), steps=args.steps if args.steps != 200 else 20,
+                                                  warmup=args.warmup if args.warmup != 20 else 5))), flush=True)
+        return
 
     import torch
     import torch.distributed as dist

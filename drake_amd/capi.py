@@ -79,6 +79,16 @@ class ContactStats(C.Structure):
                 ("E0", C.c_float), ("norm_dir_sq", C.c_float), ("dofs", C.c_float)]
 
 
+class CoupledParams(C.Structure):
+    _fields_ = [("dt", C.c_float), ("mpm_bc", C.c_int32), ("friction_mu", C.c_float), ("stiffness", C.c_float),
+                ("damping", C.c_float), ("exact_line_search", C.c_int32), ("max_newton_iterations", C.c_int32)]
+
+
+class CoupledResult(C.Structure):
+    _fields_ = [("iterations", C.c_int32), ("contacts", C.c_uint32), ("nodes", C.c_uint32), ("residual", C.c_float),
+                ("setup_reused", C.c_int32)]
+
+
 class DistConfig(C.Structure):
     _fields_ = [("rank", C.c_int32), ("world", C.c_int32), ("own_lo_block", C.c_int32), ("own_hi_block", C.c_int32),
                 ("left_lo_block", C.c_int32), ("right_hi_block", C.c_int32), ("zone_blocks", C.c_int32),
@@ -128,6 +138,8 @@ SYMBOLS = [
     "mpm_memcpy_d2h", "mpm_memcpy_h2d", "mpm_profile_contact_iteration", "mpm_contact_frame", "mpm_halo_zone_blocks",
     "mpm_dist_get_geometry", "mpm_dist_set_headroom", "mpm_dist_migration_quiet_time", "mpm_dist_retune",
     "mpm_dist_plan_migration", "mpm_debug_throw", "mpm_debug_fail_alloc", "mpm_set_fast_math", "mpm_get_fast_math",
+    "mpm_get_contact_pair_count", "mpm_download_contact_log", "mpm_last_contact_counts",
+    "mpm_debug_contact_counters", "mpm_run_coupled_substeps",
 ]
 
 EXCHANGE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t)
@@ -221,6 +233,11 @@ def load_library(build: bool = True):
         "mpm_download_contact_pairs": [vp, vp, vp, vp, vp, vp, vp, vp],
         "mpm_set_deterministic": [vp, i],
         "mpm_set_fast_math": [vp, i],
+        "mpm_get_contact_pair_count": [vp, P(sz)],
+        "mpm_last_contact_counts": [vp, P(C.c_uint32), P(C.c_uint32), P(i)],
+        "mpm_download_contact_log": [vp, vp, sz, P(sz)],
+        "mpm_debug_contact_counters": [vp, P(C.c_uint64)],
+        "mpm_run_coupled_substeps": [vp, i, vp, sz, vp, vp],
         "mpm_get_fast_math": [vp, P(i)],
         "mpm_substep_begin_halo": [vp, f, i, P(C.c_int), P(C.c_int), P(C.c_int), P(C.c_void_p), sz],
         "mpm_substep_end_halo": [vp, f, i, i, P(C.c_void_p), sz],
@@ -484,17 +501,66 @@ class GpuMpm:
         self._ck(self.lib.mpm_copy_contact_pairs(self.h, n, _ptr(particle), _ptr(body), *[_ptr(a) for a in arrs]))
         self._n_contacts = n
 
-    def generate_contact_pairs(self, colliders) -> int:
-        """Device-side CalcMpmContactPairs + CopyContactPairs for analytic colliders; returns the pair count."""
-        arr = (Collider * max(len(colliders), 1))(*colliders)
+    def generate_contact_pairs(self, colliders, want_count: bool = True):
+        """Device-side CalcMpmContactPairs + CopyContactPairs for analytic colliders; returns the pair count -- or, with
+        want_count = False, None without waiting for anything: the count stays on the device, update_contact reports it
+        (contact_stats()["contacts"]), contact_pair_count() reads it back."""
+        if isinstance(colliders, C.Array):
+            arr, nc = colliders, len(colliders)
+        else:
+            arr, nc = (Collider * max(len(colliders), 1))(*colliders), len(colliders)
+        if not want_count:
+            self._ck(self.lib.mpm_generate_contact_pairs(self.h, nc, arr, None))
+            self._n_contacts = None
+            return None
         n = C.c_size_t()
-        self._ck(self.lib.mpm_generate_contact_pairs(self.h, len(colliders), arr, C.byref(n)))
+        self._ck(self.lib.mpm_generate_contact_pairs(self.h, nc, arr, C.byref(n)))
         self._n_contacts = int(n.value)
         return self._n_contacts
+
+    def contact_pair_count(self) -> int:
+        n = C.c_size_t()
+        self._ck(self.lib.mpm_get_contact_pair_count(self.h, C.byref(n)))
+        self._n_contacts = int(n.value)
+        return self._n_contacts
+
+    def run_coupled_substeps(self, n, dt, colliders, friction_mu, stiffness, damping, mpm_bc=-1, exact_line_search=False,
+                             max_newton_iterations=0):
+        """n times the body of DeformableDriver::CalcAbstractStates' substep loop (deformable_driver.h:240-258) for analytic
+        colliders, in one call (mpm_run_coupled_substeps); returns the per-substep results."""
+        if isinstance(colliders, C.Array):
+            arr, nc = colliders, len(colliders)
+        else:
+            arr, nc = (Collider * max(len(colliders), 1))(*colliders), len(colliders)
+        prm = CoupledParams(dt, mpm_bc, friction_mu, stiffness, damping, 1 if exact_line_search else 0, max_newton_iterations)
+        res = (CoupledResult * max(n, 1))()
+        self._ck(self.lib.mpm_run_coupled_substeps(self.h, n, C.byref(prm), nc, arr, res))
+        out = [dict(iterations=r.iterations, contacts=r.contacts, nodes=r.nodes, residual=r.residual,
+                    setup_reused=bool(r.setup_reused)) for r in res[:n]]
+        if out:
+            self._n_contacts = out[-1]["contacts"]
+        return out
+
+    def contact_counters(self) -> dict:
+        out = (C.c_uint64 * 4)()
+        self._ck(self.lib.mpm_debug_contact_counters(self.h, out))
+        return dict(solves=int(out[0]), reused=int(out[1]), refused_stale=int(out[2]), repeated_overflow=int(out[3]))
+
+    def contact_log(self):
+        """rows (residual, line-search evaluations, E(alpha), alpha, E(0), sum |Dir|^2, DoFs, 0) of the last solve's Newton
+        iterations (mpm_download_contact_log)"""
+        n = C.c_size_t()
+        self._ck(self.lib.mpm_download_contact_log(self.h, None, 0, C.byref(n)))
+        out = np.zeros((int(n.value), 8), np.float32)
+        if n.value:
+            self._ck(self.lib.mpm_download_contact_log(self.h, _ptr(out), out.shape[0], C.byref(n)))
+        return out
 
     def download_contact_pairs(self):
         """(particle, body, dist, normal, pos, rigid_v, rigid_p_WB) of the pairs currently in the engine."""
         n = getattr(self, "_n_contacts", 0)
+        if n is None:
+            n = self.contact_pair_count()
         particle, body = np.zeros(n, np.uint32), np.zeros(n, np.uint32)
         dist = np.zeros(n, np.float32)
         v3 = [np.zeros((n, 3), np.float32) for _ in range(4)]
@@ -509,7 +575,11 @@ class GpuMpm:
         self._ck(self.lib.mpm_update_contact(self.h, frame, substep, dt, friction_mu, stiffness, damping,
                                              1 if dump else 0, 1 if exact_line_search else 0, max_newton_iterations,
                                              C.byref(it), C.byref(res)))
-        return dict(iterations=int(it.value), residual=float(res.value))
+        nc, nn, reused = C.c_uint32(), C.c_uint32(), C.c_int()
+        self.lib.mpm_last_contact_counts(self.h, C.byref(nc), C.byref(nn), C.byref(reused))
+        self._n_contacts = int(nc.value)
+        return dict(iterations=int(it.value), residual=float(res.value), contacts=int(nc.value), nodes=int(nn.value),
+                    setup_reused=bool(reused.value))
 
     def contact_stats(self) -> dict:
         s = ContactStats()

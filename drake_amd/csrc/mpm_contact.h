@@ -39,21 +39,31 @@ static int ensure_contact_capacity(mpm_engine* e, size_t n) {
     ContactBuffers& b = e->cb;
     if (n > b.cap) {
         const size_t cap = n + n / 4;
+        const size_t pad = cap + CT_TILE;   // (k_ct_tile / k_ct_ls read a whole tile of keys before they know the count)
         int rc;
         if ((rc = grow(&b.api_idx, cap)) || (rc = grow(&b.slot, cap)) || (rc = grow(&b.body, cap)) ||
             (rc = grow(&b.dist, cap)) ||
             (rc = grow(&b.normal, 3 * cap)) || (rc = grow(&b.pos, 3 * cap)) || (rc = grow(&b.rigid_v, 3 * cap)) ||
             (rc = grow(&b.p_WB, 3 * cap)) || (rc = grow(&b.vel, 3 * cap)) || (rc = grow(&b.vel0, 3 * cap)) ||
-            (rc = grow(&b.key, cap)) || (rc = grow(&b.order, cap)) || (rc = grow(&b.key2, cap)) ||
-            (rc = grow(&b.order2, cap)) || (rc = grow(&b.cnode, 27 * cap)) || (rc = grow(&b.cfx, 3 * cap)) ||
+            (rc = grow(&b.key, pad)) || (rc = grow(&b.order, pad)) || (rc = grow(&b.key2, pad)) ||
+            (rc = grow(&b.order2, pad)) || (rc = grow(&b.cnode, 27 * cap)) || (rc = grow(&b.cfx, 3 * cap)) ||
             (rc = grow(&b.cmass, cap)) || (rc = grow(&b.cphi0, cap)) || (rc = grow(&b.cR, 9 * cap)) ||
             (rc = grow(&b.cv0, 3 * cap)) || (rc = grow(&b.crv, 3 * cap)) || (rc = grow(&b.cvel, 3 * cap)) ||
-            (rc = grow(&b.seg_part, cap * CT_SEG_F)))
+            (rc = grow(&b.seg_part, cap * CT_SEG_F)) || (rc = grow(&b.prev_key, cap)) || (rc = grow(&b.prev_api, cap)) ||
+            (rc = grow(&b.prev_body, cap)))
             return rc;
+        // (keys beyond the count are read speculatively and then ignored: they only have to be there)
+        for (uint32_t* q : {b.key, b.key2}) HIP_TRY(hipMemsetAsync(q, 0xFF, pad * 4, e->stream));
         b.cap = cap;
+        b.last_unchanged = false;   // (prev_* are new: the next solve compares against nothing)
+        if (b.st) {
+            const int none = -1;
+            HIP_TRY(hipMemcpyAsync(&b.st->prev_n, &none, 4, hipMemcpyHostToDevice, e->stream));
+            HIP_TRY(hipStreamSynchronize(e->stream));
+        }
     }
     {
-        const size_t want = sort_hist_ints(n);
+        const size_t want = sort_hist_ints(b.cap);   // (sized for the capacity: the count may live on the device)
         if (want > b.cap_hist) {
             if (int rc = grow(&b.sort_hist, want)) return rc;
             b.cap_hist = want;
@@ -66,9 +76,22 @@ static int ensure_contact_capacity(mpm_engine* e, size_t n) {
             (rc = grow(&b.node_runs, 27 * cells)) || (rc = grow(&b.gD, cells)) ||
             (e->dp.dist.on && (rc = grow(&b.hg, 3 * cells))) ||
             (rc = grow(&b.part, (size_t)(CT_ROWS_CON + CT_ROWS) * CT_PART)) || (rc = grow(&b.part_dir, (size_t)2 * CT_DIR_WG)) ||
-            (rc = grow(&b.st, 1)) || (rc = grow(&b.it_log, (size_t)3 * CT_LOG)))
+            (rc = grow(&b.st, 1)) || (rc = grow(&b.it_log, (size_t)CT_LOG_F * CT_LOG)))
             return rc;
+        HIP_TRY(hipMemsetAsync(b.st, 0, sizeof(ContactState), e->stream));
+        {
+            const int none = -1;   // (no previous solve)
+            HIP_TRY(hipMemcpyAsync(&b.st->prev_n, &none, 4, hipMemcpyHostToDevice, e->stream));
+            HIP_TRY(hipStreamSynchronize(e->stream));
+        }
         b.cap_cells = cells;
+        b.last_unchanged = false;
+    }
+    if (!b.h_mbox) {
+        // the mailbox the host polls (ContactMailbox): pinned, mapped, coherent -- the device's stores land without a copy
+        HIP_TRY(hipHostMalloc((void**)&b.h_mbox, sizeof(ContactMailbox), hipHostMallocMapped | hipHostMallocCoherent));
+        std::memset(b.h_mbox, 0, sizeof(ContactMailbox));
+        HIP_TRY(hipHostGetDevicePointer((void**)&b.d_mbox, b.h_mbox, 0));
     }
     return 0;
 }
@@ -78,6 +101,7 @@ static int copy_contacts(mpm_engine* e, size_t n, const uint32_t* particle, cons
                          const float* normal, const float* pos, const float* rigid_v, const float* p_WB) {
     ContactBuffers& b = e->cb;
     b.n = n;
+    b.dev_counted = false;
     if (n == 0) return 0;
     for (size_t k = 0; k < n; ++k) REQUIRE(particle[k] < e->np, "contact particle index out of range");
     for (size_t k = 0; k < n; ++k) REQUIRE(body[k] < std::max<size_t>(b.n_bodies, 1), "contact body index out of range");
@@ -97,64 +121,161 @@ static int copy_contacts(mpm_engine* e, size_t n, const uint32_t* particle, cons
     c.slot = b.slot;
     c.vel = b.vel;
     hipLaunchKernelGGL(k_ct_init_vel, dim3(g), dim3(256), 0, e->stream, e->dp, c);
-    // (how many blocks are active: bounds the sort keys of the solve, see update_contact)
-    HIP_TRY(hipMemcpyAsync(&b.n_active_hint, &e->dp.ctl->n_active, 4, hipMemcpyDeviceToHost, e->stream));
     HIP_TRY(hipStreamSynchronize(e->stream));  // the host arrays may be released by the caller
     return 0;
 }
 
-// Device-side CalcMpmContactPairs + CopyContactPairs for analytic colliders (include/mpm_hip.h)
+// The mailbox the kernels publish to (ContactMailbox): wait until publication `target` (or a later one) is there and
+// return a consistent set of its four words.  Spins on host memory; every few thousand spins it asks the stream whether
+// it has drained without the publication arriving (a kernel that faulted, a miscounted launch): an error, not a hang.
+struct MailboxState {
+    unsigned seq = 0;
+    int done = 0, iters = 0;
+    float residual = 0.f;
+    unsigned count = 0, nodes = 0, n_active = 0;
+    bool unchanged = false;
+};
+static int wait_mailbox(mpm_engine* e, unsigned target, MailboxState* out) {
+    ContactBuffers& b = e->cb;
+    const volatile unsigned long long* w = b.h_mbox->w;
+    unsigned spins = 0;
+    bool drained = false;
+    while (true) {
+        const unsigned long long w0 = __atomic_load_n(&w[0], __ATOMIC_ACQUIRE);
+        const unsigned seq = (unsigned)(w0 >> 32);
+        if ((int)(seq - target) >= 0) {
+            const unsigned long long w1 = __atomic_load_n(&w[1], __ATOMIC_ACQUIRE), w2 = __atomic_load_n(&w[2], __ATOMIC_ACQUIRE),
+                                     w3 = __atomic_load_n(&w[3], __ATOMIC_ACQUIRE), w4 = __atomic_load_n(&w[4], __ATOMIC_ACQUIRE);
+            if ((unsigned)(w1 >> 32) == seq && (unsigned)(w2 >> 32) == seq && (unsigned)(w3 >> 32) == seq &&
+                (unsigned)(w4 >> 32) == seq && __atomic_load_n(&w[0], __ATOMIC_ACQUIRE) == w0) {
+                out->n_active = (unsigned)w4;
+                out->seq = seq;
+                out->done = (int)((w0 >> 24) & 0xFF);
+                out->iters = (int)(w0 & 0xFFFFFF);
+                const unsigned rb = (unsigned)w1;
+                std::memcpy(&out->residual, &rb, 4);
+                out->count = (unsigned)w2;
+                out->nodes = (unsigned)w3 & 0x7FFFFFFFu;
+                out->unchanged = ((unsigned)w3 >> 31) != 0;
+                return 0;
+            }
+            continue;   // (a later publication is landing: its words arrive one by one)
+        }
+        if (drained) return fail(MPM_ERR_INTERNAL, "contact solve: the stream drained without the expected publication in the mailbox");
+        if ((++spins & 0x3FFF) == 0) {
+            const hipError_t q = hipStreamQuery(e->stream);
+            if (q == hipSuccess) drained = true;   // (one more look at the mailbox: the last store may still be landing)
+            else if (q != hipErrorNotReady) return fail(MPM_ERR_HIP, std::string("contact solve: ") + hipGetErrorString(q));
+        }
+#if defined(__x86_64__)
+        __builtin_ia32_pause();
+#endif
+    }
+}
+
+// The pair count of the buffers, read back if the host does not know it yet (pairs made on the device without a
+// read-back: mpm_generate_contact_pairs with n_contacts_out == NULL).  A synchronisation point.
+static int generate_contacts_launch(mpm_engine* e);
+static int resolve_contact_count(mpm_engine* e) {
+    ContactBuffers& b = e->cb;
+    for (int attempt = 0; b.dev_counted && attempt < 8; ++attempt) {
+        int three[3] = {0, 0, 0};   // n, n_wanted, gen_fault
+        D2H(e, three, &b.st->n, 12);
+        if (!three[2]) {
+            b.n = (size_t)std::max(three[0], 0);
+            b.dev_counted = false;
+            return 0;
+        }
+        // more pairs than the buffers hold: grow them and make the pairs again (nothing has used them yet)
+        e->ct_counters[3] += 1;
+        if (int rc = ensure_contact_capacity(e, (size_t)three[1])) return rc;
+        if (int rc = generate_contacts_launch(e)) return rc;
+    }
+    REQUIRE(!b.dev_counted, "contact pairs: the buffers keep overflowing");
+    return 0;
+}
+
+// Device-side CalcMpmContactPairs + CopyContactPairs for analytic colliders (include/mpm_hip.h).  Nothing here waits for
+// the device: the colliders travel as a kernel argument, the pairs are counted, placed and LEFT COUNTED on the device
+// (ContactState::n); mpm_update_contact's launches have fixed grids and read the count there.  Four launches: count per
+// slot, scan inside 4096-blocks, scan of the block totals (+ the count), write.
+static int generate_contacts_launch(mpm_engine* e) {
+    ContactBuffers& b = e->cb;
+    const DP& p = e->dp;
+    hipStream_t s = e->stream;
+    const size_t n_col = b.last_colliders.size();
+    ColliderTable tab{};
+    tab.n = (int)n_col;
+    if (n_col <= (size_t)CT_COLLIDER_ARGS) {
+        for (size_t j = 0; j < n_col; ++j) tab.c[j] = b.last_colliders[j];
+    } else {
+        tab.dev = b.colliders;   // (uploaded by generate_contacts when they changed)
+    }
+    const size_t np = e->np, padded = ((np + 1 + 4095) / 4096) * 4096;
+    const int nb = (int)(padded / 4096);
+    hipLaunchKernelGGL(k_ct_gen_count, dim3((unsigned)(padded / 256)), dim3(256), 0, s, p, (const int*)e->d_pids_api, tab, b.gen_cnt, (int)padded);
+    hipLaunchKernelGGL(k_scan_blocks, dim3(nb), dim3(256), 0, s, b.gen_cnt, (int)(np + 1), b.gen_sums);
+    hipLaunchKernelGGL(k_ct_gen_total, dim3(1), dim3(1024), 0, s, b.gen_sums, nb, (int)std::min<size_t>(b.cap, 0x7FFFFFFF), b.st);
+    ContactDev c{};
+    c.n = -1;
+    c.slot = b.slot; c.body = b.body; c.dist = b.dist; c.normal = b.normal; c.pos = b.pos;
+    c.rigid_v = b.rigid_v; c.p_WB = b.p_WB; c.vel = b.vel;
+    hipLaunchKernelGGL(k_ct_gen_write, dim3(e->g_np), dim3(256), 0, s, p, (const int*)e->d_pids_api, tab, (const int*)b.gen_cnt,
+                       (const int*)b.gen_sums, (int)std::min<size_t>(b.cap, 0x7FFFFFFF), b.api_idx, c);
+    HIP_TRY(hipGetLastError());
+    b.dev_counted = true;
+    b.n = 0;
+    // (the block tables are what they are now: the keys of the solve's sort are as wide as the active blocks need.
+    // The host's last reading of that count, mpm_sync / mpm_get_stats, may be older than a re-sort: unknown then)
+    return 0;
+}
+
 static int generate_contacts(mpm_engine* e, size_t n_col, const mpm_collider_t* cols, size_t* n_out) {
     GrowPoison gp(e);
     TraceRange tr("mpm:contact pairs (device)");
     static_assert(sizeof(Collider) == sizeof(mpm_collider_t), "collider layouts differ");
     ContactBuffers& b = e->cb;
-    const DP& p = e->dp;
-    hipStream_t s = e->stream;
     b.n = 0;
+    b.dev_counted = false;
     if (n_out) *n_out = 0;
     if (n_col == 0) return 0;
     for (size_t j = 0; j < n_col; ++j) {
         REQUIRE(cols[j].kind >= 0 && cols[j].kind <= 3, "unknown collider kind");
         REQUIRE(cols[j].body < std::max<size_t>(b.n_bodies, 1), "collider body index out of range");
     }
-    if (n_col > b.cap_colliders) {
-        if (int rc = grow(&b.colliders, n_col)) return rc;
-        b.cap_colliders = n_col;
+    const Collider* in = reinterpret_cast<const Collider*>(cols);
+    const bool same = b.last_colliders.size() == n_col && std::memcmp(b.last_colliders.data(), in, n_col * sizeof(Collider)) == 0;
+    if (!same) b.last_colliders.assign(in, in + n_col);
+    if (n_col > (size_t)CT_COLLIDER_ARGS) {
+        if (n_col > b.cap_colliders) {
+            if (int rc = grow(&b.colliders, n_col)) return rc;
+            b.cap_colliders = n_col;
+            H2D(e, b.colliders, cols, n_col * sizeof(Collider));
+        } else if (!same) {
+            H2D(e, b.colliders, cols, n_col * sizeof(Collider));
+        }
     }
     const size_t np = e->np, padded = ((np + 1 + 4095) / 4096) * 4096;
     if (!b.gen_cnt) {
         int rc;
         if ((rc = grow(&b.gen_cnt, padded)) || (rc = grow(&b.gen_sums, padded / 4096 + 8))) return rc;
+        HIP_TRY(hipMemsetAsync(b.gen_sums, 0, (padded / 4096 + 8) * 4, e->stream));
     }
-    H2D(e, b.colliders, cols, n_col * sizeof(Collider));
-    HIP_TRY(hipMemsetAsync(b.gen_cnt, 0, padded * 4, s));
-    hipLaunchKernelGGL(k_ct_gen_count, dim3(e->g_np), dim3(256), 0, s, p, (const int*)e->d_pids_api, (int)n_col,
-                       (const Collider*)b.colliders, b.gen_cnt);
-    if (device_exclusive_scan(s, b.gen_cnt, np + 1, b.gen_sums)) return fail(MPM_ERR_HIP, "contact scan failed");
-    // the one number the host needs: how many pairs (and, for the key width of the solve's sort -- see
-    // update_contact -- how many blocks are active); gen_sums[0..1] is free again after the scan
-    int two[2] = {0, 0};
-    hipLaunchKernelGGL(k_pair_of_ints, dim3(1), dim3(1), 0, s, b.gen_sums, (const int*)(b.gen_cnt + np), (const unsigned*)&p.ctl->n_active);
-    D2H(e, two, b.gen_sums, 8);
-    const int total = two[0];
-    b.n_active_hint = (unsigned)two[1];
-    if (total <= 0) return 0;
-    if (int rc = ensure_contact_capacity(e, (size_t)total)) return rc;
-    ContactDev c{};
-    c.n = total;
-    c.slot = b.slot; c.body = b.body; c.dist = b.dist; c.normal = b.normal; c.pos = b.pos;
-    c.rigid_v = b.rigid_v; c.p_WB = b.p_WB; c.vel = b.vel;
-    hipLaunchKernelGGL(k_ct_gen_write, dim3(e->g_np), dim3(256), 0, s, p, (const int*)e->d_pids_api, (int)n_col,
-                       (const Collider*)b.colliders, (const int*)b.gen_cnt, total, b.api_idx, c);
-    HIP_TRY(hipGetLastError());
-    b.n = (size_t)total;
-    if (n_out) *n_out = (size_t)total;
+    // a first capacity (the buffers grow when a scene needs more: resolve_contact_count / update_contact)
+    if (int rc = ensure_contact_capacity(e, std::max<size_t>(b.cap, e->ct_initial_capacity ? e->ct_initial_capacity
+                                                                                            : std::max<size_t>(4096, np / 16))))
+        return rc;
+    if (int rc = generate_contacts_launch(e)) return rc;
+    if (n_out) {   // the caller wants the count now: a synchronisation point
+        if (int rc = resolve_contact_count(e)) return rc;
+        *n_out = b.n;
+    }
     return 0;
 }
 
 static int download_contacts(mpm_engine* e, uint32_t* particle, uint32_t* body, float* dist, float* normal, float* pos,
                              float* rigid_v, float* p_WB) {
+    if (int rc = resolve_contact_count(e)) return rc;
     const ContactBuffers& b = e->cb;
     const size_t n = b.n;
     if (n == 0) return 0;
@@ -168,10 +289,13 @@ static int download_contacts(mpm_engine* e, uint32_t* particle, uint32_t* body, 
     return 0;
 }
 
-static ContactDev make_contact_dev(mpm_engine* e, float dt, float mu, float k, float d, int max_iters) {
+// `sorted`: the arrays the solve's kernels read after the sort (the sorted keys / order may sit in the second pair of
+// buffers: radix_sort_pairs does not copy them back); otherwise the pair the set-up fills
+static ContactDev make_contact_dev(mpm_engine* e, float dt, float mu, float k, float d, int max_iters, bool sorted = true) {
     ContactBuffers& b = e->cb;
     ContactDev c{};
-    c.n = (int)b.n;
+    c.n = b.dev_counted ? -1 : (int)b.n;
+    c.stride = (int)b.cap;
     c.max_iters = max_iters;
     c.dt = dt; c.mu = mu; c.k = k; c.d = d;
     c.epsv = e->mat.epsv;
@@ -180,12 +304,16 @@ static ContactDev make_contact_dev(mpm_engine* e, float dt, float mu, float k, f
     c.tol = 1e-4f;    // kTol, cuda_mpm_solver.cu:236
     c.slot = b.slot; c.body = b.body; c.dist = b.dist; c.normal = b.normal; c.pos = b.pos;
     c.rigid_v = b.rigid_v; c.p_WB = b.p_WB; c.vel = b.vel; c.vel0 = b.vel0;
-    c.key = b.key; c.order = b.order;
+    const bool alt = sorted && b.sorted_in_alt;
+    c.key = alt ? b.key2 : b.key;
+    c.order = alt ? b.order2 : b.order;
     c.cnode = b.cnode; c.cfx = b.cfx; c.cmass = b.cmass; c.cphi0 = b.cphi0; c.cR = b.cR; c.cv0 = b.cv0;
     c.crv = b.crv; c.cvel = b.cvel; c.seg_part = b.seg_part;
     c.run = b.run; c.node_flag = b.node_flag; c.node_list = b.node_list; c.flag_bits = b.flag_bits; c.node_runs = b.node_runs;
     c.cap_nodes = (int)b.cap_cells; c.gD = b.gD; c.hg = b.hg;
     c.part = b.part; c.part_dir = b.part_dir; c.st = b.st; c.it_log = b.it_log;
+    c.mbox = b.d_mbox;
+    c.prev_key = b.prev_key; c.prev_api = b.prev_api; c.prev_body = b.prev_body;
     c.body_tau = b.body_tau; c.body_f = b.body_f; c.n_bodies = (int)b.n_bodies;
     return c;
 }
@@ -260,41 +388,31 @@ static int dist_allreduce(mpm_engine* e, double* dev, size_t n) {
     return 0;
 }
 
-// The batched Newton loops: `pattern(i)` enqueues the launches of one iteration (kernels of an iteration
-// that starts after convergence return at once).  The solver state is read back after every batch, into
-// pinned memory, and the NEXT batch is enqueued before the host waits for that read-back: the device
-// never idles while the host finds out whether the solve has finished (a stream synchronisation plus
-// relaunch cost ~40 us per batch); the price is one batch of idle launches at the end.
+// The batched Newton loops: `pattern(i)` enqueues the launches of one iteration (kernels of an iteration that starts
+// after convergence return at once) and returns how many of them PUBLISH the solver state in the host-mapped mailbox
+// (k_ct_decide, k_ct_exact_finish: ContactMailbox).  The host never copies the state back: it polls the mailbox for
+// the last publication of the batch before the one it has just enqueued, so the device never idles while the host
+// finds out whether the solve has finished (round 4 read the state back with a blit kernel per batch, ~4 us of the
+// engine's stream each, 8 - 20 per solve); the price is one batch of idle launches at the end.
 // (batch sizes: MPM_CT_BATCH="first,next" overrides the defaults, for measurements)
 static int ct_batch(const mpm_engine* e, int which, int dflt) { return e->ct_batch[which] > 0 ? e->ct_batch[which] : dflt; }
 
 template <class Pattern>
-static int run_batches(mpm_engine* e, Pattern&& pattern, int first_batch, int batch, int max_iters, ContactState* out,
+static int run_batches(mpm_engine* e, Pattern&& pattern, int first_batch, int batch, int max_iters, MailboxState* out,
                        int max_patterns = 1 << 30) {
     ContactBuffers& b = e->cb;
-    hipStream_t s = e->stream;
-    for (int i = 0; i < 2; ++i) {
-        if (!b.h_st[i]) HIP_TRY(hipHostMalloc((void**)&b.h_st[i], sizeof(ContactState), hipHostMallocDefault));
-        if (!b.h_ev[i]) HIP_TRY(hipEventCreateWithFlags(&b.h_ev[i], hipEventDisableTiming));
-    }
-    int launched = 0, slot = 0;
-    auto enqueue = [&](int count) -> int {
-        for (int q = 0; q < count; ++q) pattern(launched + q);
+    int launched = 0;
+    auto enqueue = [&](int count) {
+        for (int q = 0; q < count; ++q) b.published += (unsigned)pattern(launched + q);
         launched += count;
-        HIP_TRY(hipMemcpyAsync(b.h_st[slot], b.st, sizeof(ContactState), hipMemcpyDeviceToHost, s));
-        HIP_TRY(hipEventRecord(b.h_ev[slot], s));
-        slot ^= 1;
-        return 0;
     };
-    if (int rc = enqueue(first_batch)) return rc;
+    enqueue(first_batch);
     while (true) {
-        if (int rc = enqueue(batch)) return rc;            // speculative: idle if the previous batch finished
-        HIP_TRY(hipEventSynchronize(b.h_ev[slot]));        // (slot now names the older of the two)
-        const ContactState& st = *b.h_st[slot];
-        if (st.done || st.iters >= max_iters || launched > max_patterns) break;
+        const unsigned older = b.published;                // the last publication of what is enqueued so far
+        enqueue(batch);                                    // speculative: idle if the previous batch finished
+        if (int rc = wait_mailbox(e, older, out)) return rc;
+        if (out->done || out->iters >= max_iters || launched > max_patterns) break;
     }
-    HIP_TRY(hipEventSynchronize(b.h_ev[slot ^ 1]));        // the speculative batch has drained
-    *out = *b.h_st[slot ^ 1];
     return 0;
 }
 
@@ -308,12 +426,14 @@ static int profile_contact_iteration(mpm_engine* e, int reps, float* kernel_ms) 
     REQUIRE(b.n > 0 && b.last_iters > 0, "mpm_profile_contact_iteration needs a finished mpm_update_contact on this state");
     const mpm_contact_stats_t& lc = e->last_contact;
     (void)lc;
+    if (int rc = resolve_contact_count(e)) return rc;
     ContactDev c = make_contact_dev(e, e->last_contact_dt, e->last_contact_mu, e->last_contact_k, e->last_contact_d, 1 << 30);
     c.force = 1;
+    c.mbox = nullptr;   // (nothing here is waited for through the mailbox)
     const DP& p = e->dp;
     hipStream_t s = e->stream;
     const size_t n = b.n;
-    const int n_con_wg = (int)std::min<size_t>((n + CT_WG / 4 - 1) / (CT_WG / 4), CT_ROWS_CON);
+    const int n_con_wg = CT_ROWS_CON;   // (as the solve launches it)
     const int n_grid_wg = CT_ROWS, n_dir_wg = CT_DIR_WG;
     const unsigned n_tile_wg = (unsigned)std::min<size_t>((n + CT_TILE - 1) / CT_TILE, CT_TILE_WG);
     hipEvent_t ev[5];
@@ -339,77 +459,251 @@ static int profile_contact_iteration(mpm_engine* e, int reps, float* kernel_ms) 
         kernel_ms[k] = ms / (float)reps;
     }
     for (auto& x : ev) (void)hipEventDestroy(x);
-    HIP_TRY(hipMemsetAsync(b.st, 0, sizeof(ContactState), s));
+    HIP_TRY(hipMemsetAsync(b.st, 0, offsetof(ContactState, n), s));
     return 0;
 }
+
+// What a finished (or refused) solve left for the host: the mailbox's last words
+struct SolveOutcome {
+    MailboxState mb;
+    ContactState st;          // (only the paths that copy the state back fill it: partitioned domain)
+    bool have_state = false;
+};
+
+static int solve_once(mpm_engine* e, float dt, float mu, float stiffness, float damping, int exact, int max_iters, bool full_setup,
+                      SolveOutcome* oc, std::vector<float>* s_res, std::vector<int>* s_ls, std::vector<float>* s_energy,
+                      float* s_alpha_last, float* s_E0_last);
+static int contact_stats_from_device(mpm_engine* e);
 
 static int update_contact(mpm_engine* e, int frame, int substep, float dt, float mu, float stiffness, float damping,
                           int dump, int exact, int max_iters, int* iters_out, float* residual_out) {
     ContactBuffers& b = e->cb;
-    const size_t n = b.n;
     if (max_iters <= 0) max_iters = 2000;  // cuda_mpm_solver.cu:234
     if (b.n_bodies == 0) {
         // the reference requires ReallocateExternelBodies first; size the accumulators to the ids in use
         return fail(MPM_ERR_INVALID, "call mpm_reallocate_external_bodies before mpm_update_contact");
     }
-    ContactDev c = make_contact_dev(e, dt, mu, stiffness, damping, max_iters);
     e->last_contact_dt = dt; e->last_contact_mu = mu; e->last_contact_k = stiffness; e->last_contact_d = damping;
+    const bool dist = e->dp.dist.on && (e->dp.dist.world > 1 || e->ct_force_dist);
+    // (the distributed paths are host-driven per iteration anyway: they work with a count the host knows)
+    if (dist)
+        if (int rc = resolve_contact_count(e)) return rc;
+    if (!b.dev_counted && b.n == 0) return 0;   // cuda_mpm_solver.cu:216-217
+    TraceRange tr_all("mpm:UpdateContact");
+    SolveOutcome oc;
+    std::vector<float> s_res, s_energy;
+    std::vector<int> s_ls;
+    float s_alpha_last = 0.f, s_E0_last = 0.f;
+    // A solve may REFUSE to run, in which case none of its kernels has touched the grid and it is repeated:
+    //   CT_DONE_FAULT  pairs counted on the device did not fit the buffers: grow them, make the pairs again;
+    //   CT_DONE_STALE  the set-up was enqueued on a guess that the device found wrong (the previous solve's sorted order
+    //                  reused for a pair list that has changed; sort keys narrower than the active blocks need): full set-up.
+    bool full_setup = false;
+    for (int attempt = 0;; ++attempt) {
+        REQUIRE(attempt < 8, "contact solve: the set-up keeps being refused");
+        s_res.clear(); s_energy.clear(); s_ls.clear();
+        if (int rc = solve_once(e, dt, mu, stiffness, damping, exact, max_iters, full_setup, &oc, &s_res, &s_ls, &s_energy,
+                                &s_alpha_last, &s_E0_last))
+            return rc;
+        if (oc.mb.done == CT_DONE_FAULT) {
+            e->ct_counters[3] += 1;
+            if (int rc = ensure_contact_capacity(e, (size_t)oc.mb.count)) return rc;
+            if (int rc = generate_contacts_launch(e)) return rc;
+            full_setup = true;
+            continue;
+        }
+        if (oc.mb.done == CT_DONE_STALE) {
+            e->ct_counters[2] += 1;
+            b.n_active_hint = 0;
+            full_setup = true;
+            continue;
+        }
+        break;
+    }
+    const int iters = oc.mb.iters;
+    const float residual = oc.mb.residual;
+    e->ct_counters[0] += 1;
+    e->ct_counters[1] += e->last_contact_reused ? 1 : 0;
+    if (b.dev_counted) {   // the count has arrived with the solve's first publication
+        b.n = oc.mb.count;
+        b.dev_counted = false;
+    }
+    b.last_iters = iters;
+    b.last_unchanged = oc.mb.unchanged;
+    if (e->ct_debug) fprintf(stderr, "contact solve: n %zu nodes %u iters %d unchanged %d\n", b.n, oc.mb.nodes, iters, (int)oc.mb.unchanged);
+    if (iters_out) *iters_out = iters;
+    if (residual_out) *residual_out = residual;
+    {
+        // what the reference prints / dumps per substep (cuda_mpm_solver.cu:577-612), kept for mpm_get_contact_stats: the
+        // mailbox carries the iteration count, the residual, the contact and node counts; the other numbers stay on the
+        // device until somebody asks (contact_stats_from_device: a synchronisation point of its own)
+        mpm_contact_stats_t& cs = e->last_contact;
+        cs = mpm_contact_stats_t{};
+        cs.iterations = iters;
+        cs.contacts = (uint32_t)b.n;
+        cs.nodes = oc.mb.nodes;
+        cs.residual = residual;
+        e->last_contact_on_device = !oc.have_state;
+        e->last_contact_exact = exact != 0;
+        if (oc.have_state) {
+            const ContactState& st = oc.st;
+            cs.norm_dir_sq = st.norm_dir_sq;
+            cs.dofs = st.dofs;
+            cs.line_search_evals = st.ls_total;
+            cs.alpha = st.alpha;
+            cs.energy = st.energy;
+            cs.E0 = st.E0;
+            if (exact && !s_ls.empty()) {   // (host-driven exact search: its own bookkeeping)
+                cs.line_search_evals = 0;
+                for (int v : s_ls) cs.line_search_evals += v;
+                cs.alpha = s_alpha_last;
+                cs.energy = s_energy.empty() ? 0.f : s_energy.back();
+                cs.E0 = s_E0_last;
+            }
+        }
+    }
+    if (dump) {
+        // per-substep statistics, same fields as cuda_mpm_solver.cu:587-612
+        if (int rc = contact_stats_from_device(e)) return rc;
+        const mpm_contact_stats_t& cs = e->last_contact;
+        if (exact && s_res.empty() && iters > 0) {
+            std::vector<float> log((size_t)CT_LOG_F * std::min(iters, CT_LOG));
+            D2H(e, log.data(), b.it_log, log.size() * 4);
+            for (int i = 0; i < std::min(iters, CT_LOG); ++i) {
+                s_res.push_back(log[(size_t)i * CT_LOG_F]);
+                s_ls.push_back((int)log[(size_t)i * CT_LOG_F + 1]);
+                s_energy.push_back(log[(size_t)i * CT_LOG_F + 2]);
+            }
+        }
+        const std::string fn = e->dump_dir + "/jacobi_iter_" + std::to_string(max_iters) + "_frame_" +
+                               std::to_string(frame) + "_substep_" + std::to_string(substep) + ".json";
+        std::ofstream f(fn);
+        if (!f) return fail(MPM_ERR_INVALID, "cannot write " + fn);
+        f << "[\n";
+        if (exact) {
+            for (size_t i = 0; i < s_res.size(); ++i)
+                f << "  {\n      \"residual\": " << s_res[i] << ",\n      \"line_search_cnt\": " << s_ls[i]
+                  << ",\n      \"energy\": " << s_energy[i] << "\n  }" << (i + 1 < s_res.size() ? "," : "") << "\n";
+        } else {
+            f << "  {\n      \"iterations\": " << iters << ",\n      \"residual\": " << residual
+              << ",\n      \"line_search_cnt\": " << (iters ? (double)cs.line_search_evals / iters : 0.0)
+              << ",\n      \"energy\": " << cs.energy << "\n  }\n";
+        }
+        f << "]\n";
+    }
+    return 0;
+}
+
+// the numbers of the last solve that the mailbox does not carry (step, energies, |Dir|^2, DoFs, line-search count)
+static int contact_stats_from_device(mpm_engine* e) {
+    if (!e->last_contact_on_device) return 0;
+    ContactBuffers& b = e->cb;
+    ContactState st;
+    D2H(e, &st, b.st, sizeof(ContactState));
+    mpm_contact_stats_t& cs = e->last_contact;
+    cs.norm_dir_sq = st.norm_dir_sq;
+    cs.dofs = st.dofs;
+    cs.line_search_evals = st.ls_total;
+    cs.alpha = st.alpha;
+    cs.energy = st.energy;
+    cs.E0 = st.E0;
+    e->last_contact_on_device = false;
+    return 0;
+}
+
+static int solve_once(mpm_engine* e, float dt, float mu, float stiffness, float damping, int exact, int max_iters, bool full_setup,
+                      SolveOutcome* oc, std::vector<float>* s_res_p, std::vector<int>* s_ls_p, std::vector<float>* s_energy_p,
+                      float* s_alpha_last_p, float* s_E0_last_p) {
+    ContactBuffers& b = e->cb;
+    std::vector<float>&s_res = *s_res_p, &s_energy = *s_energy_p;
+    std::vector<int>& s_ls = *s_ls_p;
+    float &s_alpha_last = *s_alpha_last_p, &s_E0_last = *s_E0_last_p;
+    *oc = SolveOutcome();
+    e->last_contact_reused = false;
     const DP& p = e->dp;
     hipStream_t s = e->stream;
-    const unsigned gc = (unsigned)((n + 255) / 256);
+    // what sizes the grids: the count, or -- counted on the device -- a bound (every kernel strides over its grid and
+    // reads the count itself): the last solve's count with some room, at most the buffers' capacity
+    size_t n = b.n;
+    if (b.dev_counted) n = b.n_hint ? std::min<size_t>(b.cap, b.n_hint + b.n_hint / 8 + 256) : b.cap;
+    n = std::max<size_t>(n, 1);
+    const unsigned gc = (unsigned)std::min<size_t>((n + 255) / 256, 2048);
     // The pairs name particles by the caller's slot; the engine's internal slots change with every
     // re-sort (which the device decides by itself, e.g. inside a RebuildMapping between
     // CopyContactPairs and this call): k_ct_keys resolves them again, from the kept caller indices.
     // grid-stride contact part of k_ct_ls: 4 lanes per contact
-    const int n_con_wg = (int)std::min<size_t>((n + CT_WG / 4 - 1) / (CT_WG / 4), CT_ROWS_CON);
+    // (always all CT_ROWS_CON rows: tile t goes to row t mod CT_ROWS_CON whatever the count or the buffers' capacity, so
+    // the energy sums -- and with them every `E1 <= E0` decision -- do not depend on what sized the launch; workgroups
+    // without a tile write a row of zeros)
+    const int n_con_wg = CT_ROWS_CON;
     const int n_grid_wg = CT_ROWS;                               // grid-stride node part
     const int n_dir_wg = CT_DIR_WG;
-    TraceRange tr_all("mpm:UpdateContact");
+    // (MPM_CT_FORCE_DIST=1, tests: a partitioned engine of ONE rank takes the distributed paths too -- split direction
+    // kernels, sums through the all-reduce -- so that they can run on a box with one GPU)
+    const bool dist = p.dist.on && (p.dist.world > 1 || e->ct_force_dist);
     // ---- set-up: contacts in base-cell order, per-cell runs, nodes that see contacts ---------
     std::unique_ptr<TraceRange> tr_phase(new TraceRange("mpm:UpdateContact set-up (sort, per-cell runs, node list)"));
     auto trace_phase = [&](const char* name) {   // (phases end where the next begins; early returns close them too)
         tr_phase.reset();
         tr_phase.reset(new TraceRange(name));
     };
-    HIP_TRY(hipMemsetAsync(b.st, 0, sizeof(ContactState), s));
-    hipLaunchKernelGGL(k_ct_keys, dim3(1024), dim3(256), 0, s, p, c, (const uint32_t*)b.api_idx, (const int*)e->d_pids_api, b.slot);
+    b.solves += 1;
+    // Settled scenes: when the last solve found its pair list equal to its predecessor's, this one
+    // is enqueued on the guess that it is again -- no sort, no per-cell runs, no node list: the last full set-up's stand
+    // -- and k_ct_keys checks the guess on the device, entry by entry (same particle, body and base cell, same count, same
+    // block tables).  A wrong guess refuses the solve (CT_DONE_STALE), the caller repeats it with the full set-up.
+    const bool reuse = !full_setup && b.last_unchanged && !dist && !e->ct_no_reuse;
+    // Keys are compact cells (active block * 64 + cell).  How many blocks are active the host knows from the last
+    // solve's publication (it changes with re-sorts only); with config 3's 1805 blocks that is 18 key bits, two passes
+    // of 9, instead of 22 bits for the table capacity, three passes of 8.  Checked on the device as well: keys wider
+    // than the guess refuse the solve (CT_DONE_STALE).
+    const size_t blocks = b.n_active_hint && !full_setup ? std::min<size_t>((size_t)b.n_active_hint * 2, p.capA) : p.capA;
+    int bits = 1;
+    while (((size_t)1 << bits) < blocks * 64) ++bits;
     {
-        // Keys are compact cells (active block * 64 + cell).  The number of active blocks is known from
-        // the hand-over of the pairs unless a re-sort may have run since (launch_rebuild clears the hint):
-        // with config 3's 1805 blocks that is 18 key bits, two passes of 9, instead of 22 bits for the
-        // table capacity, three passes of 8.
-        const size_t blocks = b.n_active_hint ? std::min<size_t>(b.n_active_hint, p.capA) : p.capA;
-        int bits = 1;
-        while (((size_t)1 << bits) < blocks * 64) ++bits;
+        ContactDev c_in = make_contact_dev(e, dt, mu, stiffness, damping, max_iters, /* sorted = */ false);
+        if (dist) c_in.mbox = nullptr;
+        hipLaunchKernelGGL(k_ct_keys, dim3(1024), dim3(256), 0, s, p, c_in, (const uint32_t*)b.api_idx, (const int*)e->d_pids_api, b.slot,
+                           b.published, b.solves, bits, reuse ? 1 : 0, full_setup ? 1 : 0);
+    }
+    if (!reuse) {
         // CT_NO_CELL has all those bits set and more: it sorts behind every real cell as long as
         // one more bit takes part
-        if (radix_sort_pairs(s, b.key, b.order, b.key2, b.order2, b.sort_hist, n, std::min(bits + 1, 31)))
+        // (a sort's tiles are fixed chunks, not a stride over the grid: with the count on the device its launch must
+        // cover whatever the count may be -- the buffers' capacity, not the guess that sizes the other grids; a sheet of
+        // the stack landing doubles the count from one substep to the next)
+        bool in_alt = false;
+        if (radix_sort_pairs(s, b.key, b.order, b.key2, b.order2, b.sort_hist, b.dev_counted ? b.cap : n, std::min(bits + 1, 31), &in_alt,
+                             b.dev_counted ? &b.st->n : nullptr))
             return fail(MPM_ERR_HIP, "contact sort failed");
+        b.sorted_in_alt = in_alt;
     }
-    hipLaunchKernelGGL(k_ct_prepare, dim3(gc), dim3(256), 0, s, p, c);
-    // (MPM_CT_FORCE_DIST=1, tests: a partitioned engine of ONE rank takes the distributed paths too -- split direction
-    // kernels, sums through the all-reduce -- so that they can run on a box with one GPU)
-    const bool dist = p.dist.on && (p.dist.world > 1 || e->ct_force_dist);
-    if (dist) {
-        // a node in a zone may be reached by the neighbour's contacts only: both ranks need it listed
-        hipLaunchKernelGGL(k_ct_flags_to_field, dim3(512), dim3(256), 0, s, p, c, 0);
-        if (int rc = zone_exchange3(e, b.hg)) return rc;
-        hipLaunchKernelGGL(k_ct_flags_to_field, dim3(512), dim3(256), 0, s, p, c, 1);
+    ContactDev c = make_contact_dev(e, dt, mu, stiffness, damping, max_iters);
+    if (dist) c.mbox = nullptr;   // (host-driven iterations: the state is copied back, nothing is published)
+    if (reuse) {
+        hipLaunchKernelGGL(k_ct_prepare<true>, dim3(gc), dim3(256), 0, s, p, c);
+    } else {
+        hipLaunchKernelGGL(k_ct_prepare<false>, dim3(gc), dim3(256), 0, s, p, c);
+        if (dist) {
+            // a node in a zone may be reached by the neighbour's contacts only: both ranks need it listed
+            hipLaunchKernelGGL(k_ct_flags_to_field, dim3(512), dim3(256), 0, s, p, c, 0);
+            if (int rc = zone_exchange3(e, b.hg)) return rc;
+            hipLaunchKernelGGL(k_ct_flags_to_field, dim3(512), dim3(256), 0, s, p, c, 1);
+        }
+        hipLaunchKernelGGL(k_ct_flag_bits, dim3(256), dim3(256), 0, s, p, c);
+        hipLaunchKernelGGL(k_ct_node_list, dim3(1), dim3(1024), 0, s, p, c);
+        hipLaunchKernelGGL(k_ct_node_runs, dim3(1024), dim3(256), 0, s, p, c);
     }
-    hipLaunchKernelGGL(k_ct_flag_bits, dim3(256), dim3(256), 0, s, p, c);
-    hipLaunchKernelGGL(k_ct_node_list, dim3(1), dim3(1024), 0, s, p, c);
-    hipLaunchKernelGGL(k_ct_node_runs, dim3(1024), dim3(256), 0, s, p, c);
-    // pre-contact velocity at the contact points (cuda_mpm_solver.cu:267-272)
-    hipLaunchKernelGGL(k_ct_gather_vel, dim3(gc), dim3(256), 0, s, p, c, b.vel0);
 
     trace_phase("mpm:UpdateContact Newton iterations");
-    std::vector<float> s_res, s_energy;
-    std::vector<int> s_ls;
-    float s_alpha_last = 0.f, s_E0_last = 0.f;
     ContactState st{};
     int iters = 0;
     float residual = 1e10f;
-    const unsigned n_tile_wg = (unsigned)std::min<size_t>((n + CT_TILE - 1) / CT_TILE, CT_TILE_WG);
+    const unsigned n_tile_wg = (unsigned)std::max<size_t>(1, std::min<size_t>((n + CT_TILE - 1) / CT_TILE, CT_TILE_WG));
+    // the iterations are driven by the host, step by step, with the state copied back (partitioned domain without the
+    // device-resident exact search): nothing is published, nothing is polled
+    const bool host_driven = dist && !(exact && e->chain.comm && rccl_rt::api()->all_reduce);
+    if (host_driven) c.mbox = nullptr;
     // contact gradients/Hessians and their per-cell sums, then (H, G) and the direction per node
     auto launch_dir = [&](int first, int lazy) {
         hipLaunchKernelGGL(k_ct_tile, dim3(n_tile_wg), dim3(256), 0, s, p, c, first, lazy);
@@ -445,29 +739,34 @@ static int update_contact(mpm_engine* e, int frame, int substep, float dt, float
     } else if (!exact) {
         // device-resident loop: iterations are launched in batches, kernels of an iteration
         // that starts after convergence return immediately
-        // (as many as the previous solve needed plus one, then a few at a time: iterations that start
-        // after convergence are idle launches of ~2 us each)
         // Four launches per iteration: contacts -> sums per cell, nodes -> direction, energies of the
         // candidate steps, decision.  The accepted step reaches the grid velocity at the start of the
         // next iteration (k_ct_node_dir, lazy; k_ct_tile reads v - alpha D meanwhile) and, for the last
         // iteration, in the k_ct_apply after the loop.  MPM_CT_EAGER=1 keeps the separate k_ct_apply.
+        // (the first iteration has no step to catch up with -- and, with a reused set-up, directions of the previous
+        // solve in place: it never reads them)
         const bool eager = e->ct_eager;   // (per handle, read at mpm_create)
-        auto pattern = [&](int index) {
-            launch_dir(index == 0, eager ? 0 : 1);
+        auto pattern = [&](int index) -> int {
+            launch_dir(index == 0, eager || index == 0 ? 0 : 1);
             hipLaunchKernelGGL(k_ct_ls, dim3(n_con_wg + n_grid_wg), dim3(CT_WG), 0, s, p, c, n_con_wg, 0, 0.f);
             hipLaunchKernelGGL(k_ct_decide, dim3(1), dim3(1024), 0, s, c, n_dir_wg, n_con_wg, n_grid_wg, 0, 0);
             if (eager) hipLaunchKernelGGL(k_ct_apply, dim3(CT_ROWS), dim3(CT_WG), 0, s, p, c, 0);
+            return 1;
         };
-        if (int rc = run_batches(e, pattern, ct_batch(e, 0, 2), ct_batch(e, 1, 2), max_iters, &st)) return rc;
+        // first batch: as many iterations as the last solve took (a settled scene repeats itself), at least two; then
+        // one at a time (an iteration is ~34 us of device time, the host needs a few to react: one in flight is enough,
+        // and the idle launches at the end are one iteration's instead of two)
+        const int first = ct_batch(e, 0, std::min(std::max(b.last_iters, 2), 32));
+        if (int rc = run_batches(e, pattern, first, ct_batch(e, 1, 1), max_iters, &oc->mb)) return rc;
         if (!eager) hipLaunchKernelGGL(k_ct_apply, dim3(CT_ROWS), dim3(CT_WG), 0, s, p, c, 2);
-        iters = st.iters;
-        residual = st.residual;
-    } else if (!dist || (e->chain.comm && rccl_rt::api()->all_reduce)) {
+        iters = oc->mb.iters;
+        residual = oc->mb.residual;
+    } else if (!host_driven) {
         // Exact line search, device resident: a fixed pattern of launches per Newton iteration --
         // direction, PROBES x (energies at st->alpha_probe, one-thread state machine = root finder of
         // mpm_rootfind.h), apply, close -- whose kernels skip themselves according to the state: a search
         // that needs more probes continues in the next pattern (direction skipped), patterns after
-        // convergence are idle.  One read-back per batch instead of one per probe.
+        // convergence are idle.  No read-back at all: the host polls the mailbox.
         // Partitioned domain with the native chain: the same pattern; the sums of a probe go through ncclAllReduce ON
         // THE ENGINE'S STREAM between the two halves of the decision (k_ct_decide phase 1: this rank's sums; phase 2:
         // the state machine, on the global sums -- identical on every rank, so all ranks walk the same states and
@@ -476,7 +775,8 @@ static int update_contact(mpm_engine* e, int frame, int substep, float dt, float
         // one all-reduce per probe is the floor; what goes is the host round trip around each of them.
         const int PROBES = 6;
         int rc_pattern = 0;
-        auto pattern = [&](int index) {
+        auto pattern = [&](int index) -> int {
+            int published = 0;
             if (!dist) {
                 launch_dir(index == 0, 0);
             } else if (int rc = newton_direction(index == 0)) {
@@ -486,36 +786,27 @@ static int update_contact(mpm_engine* e, int frame, int substep, float dt, float
                 hipLaunchKernelGGL(k_ct_ls, dim3(n_con_wg + n_grid_wg), dim3(CT_WG), 0, s, p, c, n_con_wg, 2, 0.f);
                 if (!dist) {
                     hipLaunchKernelGGL(k_ct_decide, dim3(1), dim3(1024), 0, s, c, n_dir_wg, n_con_wg, n_grid_wg, 2, 0);
+                    published += 1;
                 } else {
                     hipLaunchKernelGGL(k_ct_decide, dim3(1), dim3(1024), 0, s, c, n_dir_wg, n_con_wg, n_grid_wg, 2, 1);
                     if (int rc = dist_allreduce(e, b.st->red, 32)) rc_pattern = rc;
                     hipLaunchKernelGGL(k_ct_decide, dim3(1), dim3(1024), 0, s, c, n_dir_wg, n_con_wg, n_grid_wg, 2, 2);
+                    published += 2;
                 }
             }
             hipLaunchKernelGGL(k_ct_apply, dim3(CT_ROWS), dim3(CT_WG), 0, s, p, c, 1);
             hipLaunchKernelGGL(k_ct_exact_finish, dim3(1), dim3(64), 0, s, c);
+            return published + 1;
         };
         // (a search that never terminates cannot happen -- the root finder stops after 200 evaluations, which in
         // float it often needs: |dx| < 3e-9 is out of reach -- but the launches are bounded too: every Newton
         // iteration may take 200 / PROBES + 1 patterns)
-        if (int rc = run_batches(e, pattern, ct_batch(e, 0, 1), ct_batch(e, 1, 1), max_iters, &st,
+        if (int rc = run_batches(e, pattern, ct_batch(e, 0, 1), ct_batch(e, 1, 1), max_iters, &oc->mb,
                                  (200 / PROBES + 2) * max_iters + 64))
             return rc;
         if (rc_pattern) return rc_pattern;
-        iters = st.iters;
-        residual = st.residual;
-        s_alpha_last = st.alpha;
-        s_E0_last = st.E0;
-        if (iters > 0) {
-            std::vector<float> log((size_t)3 * std::min(iters, CT_LOG));
-            HIP_TRY(hipMemcpyAsync(log.data(), b.it_log, log.size() * 4, hipMemcpyDeviceToHost, s));
-            HIP_TRY(hipStreamSynchronize(s));
-            for (int i = 0; i < std::min(iters, CT_LOG); ++i) {
-                s_res.push_back(log[i * 3]);
-                s_ls.push_back((int)log[i * 3 + 1]);
-                s_energy.push_back(log[i * 3 + 2]);
-            }
-        }
+        iters = oc->mb.iters;
+        residual = oc->mb.residual;
     } else {
         // exact line search on a partitioned domain whose transport is a pair of host callbacks
         // (mpm_dist_set_transport): every all-reduce is a host round trip anyway, so the search is driven from the
@@ -523,13 +814,9 @@ static int update_contact(mpm_engine* e, int frame, int substep, float dt, float
         // DoNewtonWithBisectionFallback)
         auto probe = [&](float alpha, std::tuple<float, float, float>* out) -> int {
             hipLaunchKernelGGL(k_ct_ls, dim3(n_con_wg + n_grid_wg), dim3(CT_WG), 0, s, p, c, n_con_wg, 1, alpha);
-            if (dist) {
-                hipLaunchKernelGGL(k_ct_decide, dim3(1), dim3(1024), 0, s, c, n_dir_wg, n_con_wg, n_grid_wg, 1, 1);
-                if (int rc2 = dist_allreduce(e, b.st->red, 32)) return rc2;
-                hipLaunchKernelGGL(k_ct_decide, dim3(1), dim3(1024), 0, s, c, n_dir_wg, n_con_wg, n_grid_wg, 1, 2);
-            } else {
-                hipLaunchKernelGGL(k_ct_decide, dim3(1), dim3(1024), 0, s, c, n_dir_wg, n_con_wg, n_grid_wg, 1);
-            }
+            hipLaunchKernelGGL(k_ct_decide, dim3(1), dim3(1024), 0, s, c, n_dir_wg, n_con_wg, n_grid_wg, 1, 1);
+            if (int rc2 = dist_allreduce(e, b.st->red, 32)) return rc2;
+            hipLaunchKernelGGL(k_ct_decide, dim3(1), dim3(1024), 0, s, c, n_dir_wg, n_con_wg, n_grid_wg, 1, 2);
             HIP_TRY(hipMemcpyAsync(&st, b.st, sizeof(ContactState), hipMemcpyDeviceToHost, s));
             HIP_TRY(hipStreamSynchronize(s));
             *out = std::make_tuple((float)st.scal[0], (float)st.scal[1], (float)st.scal[2]);
@@ -574,49 +861,22 @@ static int update_contact(mpm_engine* e, int frame, int substep, float dt, float
     trace_phase("mpm:UpdateContact impulses");
     hipLaunchKernelGGL(k_ct_impulse, dim3(std::min(gc, 256u)), dim3(256), 0, s, p, c);
     HIP_TRY(hipGetLastError());
-    b.last_iters = iters;
-    if (e->ct_debug) fprintf(stderr, "contact solve: n %zu nodes %d items %d iters %d\n", n, st.n_nodes, 0, iters);
-    if (iters_out) *iters_out = iters;
-    if (residual_out) *residual_out = residual;
-    {
-        // what the reference prints / dumps per substep (cuda_mpm_solver.cu:577-612), kept for mpm_get_contact_stats
-        mpm_contact_stats_t& cs = e->last_contact;
-        cs.iterations = iters;
-        cs.contacts = (uint32_t)n;
-        cs.nodes = (uint32_t)st.n_nodes;
-        cs.residual = residual;
-        cs.norm_dir_sq = st.norm_dir_sq;
-        cs.dofs = st.dofs;
-        if (exact) {
-            cs.line_search_evals = 0;
-            for (int v : s_ls) cs.line_search_evals += v;
-            cs.alpha = s_alpha_last;
-            cs.energy = s_energy.empty() ? 0.f : s_energy.back();
-            cs.E0 = s_E0_last;
-        } else {
-            cs.line_search_evals = st.ls_total;
-            cs.alpha = st.alpha;
-            cs.energy = st.energy;
-            cs.E0 = st.E0;
-        }
-    }
-    if (dump) {
-        // per-substep statistics, same fields as cuda_mpm_solver.cu:587-612
-        const std::string fn = e->dump_dir + "/jacobi_iter_" + std::to_string(max_iters) + "_frame_" +
-                               std::to_string(frame) + "_substep_" + std::to_string(substep) + ".json";
-        std::ofstream f(fn);
-        if (!f) return fail(MPM_ERR_INVALID, "cannot write " + fn);
-        f << "[\n";
-        if (exact) {
-            for (size_t i = 0; i < s_res.size(); ++i)
-                f << "  {\n      \"residual\": " << s_res[i] << ",\n      \"line_search_cnt\": " << s_ls[i]
-                  << ",\n      \"energy\": " << s_energy[i] << "\n  }" << (i + 1 < s_res.size() ? "," : "") << "\n";
-        } else {
-            f << "  {\n      \"iterations\": " << iters << ",\n      \"residual\": " << residual
-              << ",\n      \"line_search_cnt\": " << (iters ? (double)st.ls_total / iters : 0.0)
-              << ",\n      \"energy\": " << st.energy << "\n  }\n";
-        }
-        f << "]\n";
+    if (host_driven) {
+        // (these paths know the state: hand it over like a publication)
+        oc->st = st;
+        oc->have_state = true;
+        oc->mb.done = st.done ? st.done : 1;
+        oc->mb.iters = iters;
+        oc->mb.residual = residual;
+        oc->mb.count = (unsigned)b.n;
+        oc->mb.nodes = (unsigned)st.n_nodes;
+        oc->mb.unchanged = false;
+        if (oc->mb.done == 2) oc->mb.done = 1;
+    } else {
+        e->last_contact_reused = reuse && oc->mb.done != CT_DONE_STALE;
+        b.n_hint = oc->mb.count;
+        // (how many blocks were active: from the control block as this solve's kernels saw it -- a word of the mailbox)
+        b.n_active_hint = oc->mb.n_active;
     }
     return 0;
 }

@@ -24,6 +24,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <vector>
+
 #include "mpm_device.h"
 #include "mpm_sort.h"
 #include "mpm_rootfind.h"
@@ -68,12 +70,45 @@ struct ContactState {       // device-resident solver state
     float alpha_probe;      // where k_ct_ls evaluates next
     float f_lo[3];          // (E, dE, d2E) at alpha = 0
     RootFinder<float> rf;
+    // ---- what the HOST would otherwise have to read back before it can enqueue the solve (round 5) -------------------
+    // Pairs made on the device (mpm_generate_contact_pairs) are COUNTED on the device: the count stays here, every
+    // kernel of the solve reads it (ct_count), every launch that depends on it has a fixed grid.  More pairs than the
+    // buffers hold: gen_fault -- the solve's kernels skip themselves (done = CT_DONE_FAULT), the host learns it from the
+    // first mailbox word it waits for anyway, grows the buffers and repeats pair generation + solve (nothing has
+    // touched the grid).  None of these fields is reset by the solve's set-up.
+    int n;                  // contacts the solve works on (<= capacity)
+    int n_wanted;           // pairs the scene has (mpm_generate_contact_pairs)
+    int gen_fault;          // n_wanted > capacity
+    unsigned seq;           // publications in the mailbox so far (k_ct_decide, k_ct_exact_finish); the host re-bases it
+                            // with every solve (k_ct_keys)
+    // settled scenes: the pair list of this solve equals the previous solve's entry by entry (same particle, same body,
+    // same base cell, same block tables): changed_solve != the solve's number (kernel argument of k_ct_keys)
+    unsigned changed_solve;
+    unsigned solve_no;      // this solve's number
+    unsigned n_active;      // active blocks as this solve's set-up saw them (the host sizes the next solve's sort keys from it)
+    int prev_n;             // contacts of the previous solve
+    unsigned setup_rebuilds;  // Ctl::rebuilds when the per-cell tables were last built
+};
+constexpr int CT_DONE_FAULT = 4;     // ContactState::done: the pair buffers overflowed, nothing was solved
+constexpr int CT_DONE_STALE = 5;     // ... a speculated set-up (previous solve's order reused) did not match, nothing was solved
+
+// Mailbox in host-mapped pinned memory: what the host polls instead of copying the state back after every batch of
+// iterations (a blit kernel of ~4 us on the engine's stream per read-back, 8 - 20 per solve).  Four
+// words, each written by ONE naturally aligned 8-byte store (untorn) and each carrying the publication number in its
+// upper half, so that the host can tell a consistent set without any fence on the device:
+//   w[0] = seq << 32 | done << 24 | iterations        w[1] = seq << 32 | bits of the residual (float)
+//   w[2] = seq << 32 | contacts (the wanted count when done = CT_DONE_FAULT)
+//   w[3] = seq << 32 | unchanged << 31 | nodes that see contacts          w[4] = seq << 32 | active blocks
+struct ContactMailbox {
+    unsigned long long w[8];
 };
 
-constexpr int CT_LOG = 2048;   // per-iteration statistics kept for the JSON dump (residual, evaluations, energy)
+constexpr int CT_LOG = 2048;   // Newton iterations whose decisions are logged (mpm_download_contact_log, the JSON dump)
+constexpr int CT_LOG_F = 8;    // floats per logged iteration
 
 struct ContactDev {
-    int n;                  // contacts
+    int n;                  // contacts; < 0: counted on the device, read ContactState::n (ct_count)
+    int stride;             // distance between the planes of the per-contact SoA arrays below (the buffers' capacity)
     int max_iters;
     int force;              // mpm_profile_contact_iteration: the iteration kernels run whatever the solver state says
     float dt, mu, k, d, epsv, relax, tol;
@@ -108,7 +143,11 @@ struct ContactDev {
     double* part;           // [CT_ROWS_CON + CT_ROWS][CT_PART] line-search partial sums (contacts, then cells)
     double* part_dir;       // [CT_DIR_WG][2] (|Dir|^2, DoFs) per workgroup of k_ct_node_dir
     ContactState* st;
-    float* it_log;          // [CT_LOG][3] exact search: residual, line-search evaluations, energy per Newton iteration
+    ContactMailbox* mbox;   // host-mapped (device address)
+    // the previous solve's pair list in the caller's order, for the "unchanged" test of k_ct_keys
+    uint32_t *prev_key, *prev_api, *prev_body;
+    float* it_log;          // [CT_LOG][CT_LOG_F] per Newton iteration: residual, line-search evaluations, E(alpha), alpha,
+                            // E(0), sum |Dir|^2, DoFs (both searches; mpm_download_contact_log)
     float* body_tau;
     float* body_f;
     int n_bodies;
@@ -159,22 +198,35 @@ struct ContactBuffers {
     ContactState* st = nullptr;
     float* it_log = nullptr;
     int last_iters = 0;         // Newton iterations of the previous solve (sizes the first batch of launches)
-    unsigned n_active_hint = 0; // active blocks when the pairs were handed over (0: unknown / a re-sort may have run since)
+    unsigned n_active_hint = 0; // active blocks as the last solve saw them (0: unknown); sizes the sort keys, verified on the device
+    unsigned n_hint = 0;        // contacts of the last solve (sizes the grids of a solve whose count is on the device)
     ContactState* h_st[2] = {nullptr, nullptr};   // pinned read-back slots of the batched loops
     hipEvent_t h_ev[2] = {nullptr, nullptr};
+    ContactMailbox* h_mbox = nullptr;   // host-mapped pinned mailbox (host address) ...
+    ContactMailbox* d_mbox = nullptr;   // ... and its device address
+    unsigned published = 0;             // publications enqueued so far (the device's ContactState::seq follows it)
+    unsigned solves = 0;                // mpm_update_contact calls so far (numbers the "unchanged" test)
+    bool dev_counted = false;           // the pairs in the buffers were counted on the device and the host has not read the count
+    uint32_t *prev_key = nullptr, *prev_api = nullptr, *prev_body = nullptr;
+    // the colliders of the last mpm_generate_contact_pairs (a buffer overflow repeats the generation)
+    std::vector<Collider> last_colliders;
+    bool sorted_in_alt = false;         // the sorted (key, order) of the last set-up sit in key2 / order2
+    bool last_unchanged = false;        // the last solve found its pair list equal to its predecessor's
     float* body_tau = nullptr;  // F_Bq_W_tau
     float* body_f = nullptr;    // F_Bq_W_f
 
     void release() {
         void* ptrs[] = {api_idx, colliders, gen_cnt, gen_sums, slot, body, dist, normal, pos, rigid_v, p_WB, vel, vel0, key, order, key2, order2, sort_hist,
                         cnode, cfx, cmass, cphi0, cR, cv0, crv, cvel, run, node_flag, flag_bits, node_list, node_runs, seg_part, gD, hg,
-                        zone_buf[0], zone_buf[1], zone_buf[2], zone_buf[3], part, part_dir, st, it_log, body_tau, body_f};
+                        zone_buf[0], zone_buf[1], zone_buf[2], zone_buf[3], part, part_dir, st, it_log, body_tau, body_f,
+                        prev_key, prev_api, prev_body};
         for (void* q : ptrs)
             if (q) (void)hipFree(q);
         for (int i = 0; i < 2; ++i) {
             if (h_st[i]) (void)hipHostFree(h_st[i]);
             if (h_ev[i]) (void)hipEventDestroy(h_ev[i]);
         }
+        if (h_mbox) (void)hipHostFree(h_mbox);
         *this = ContactBuffers();
     }
     int resize_bodies(size_t nb, hipStream_t s) {
@@ -252,37 +304,72 @@ MPM_DEV float collider_sdf(const Collider& c, const float* x, float* grad) {
     return phi;
 }
 
-// P1: number of penetrated colliders per particle slot (the caller's slot order)
-__global__ __launch_bounds__(256) void k_ct_gen_count(DP p, const int* pids_api, int n_col, const Collider* cols,
-                                                      int* cnt) {
+// The colliders of a call travel as a kernel ARGUMENT while there are at most CT_COLLIDER_ARGS of them (no upload, no
+// synchronisation: an upload of 92 bytes per collider costs a blit launch and, with the host buffer on the stack, a wait
+// for the stream); beyond that through a device array that the host refreshes only when the colliders have changed.
+constexpr int CT_COLLIDER_ARGS = 16;
+struct ColliderTable {
+    int n;
+    const Collider* dev;   // non-null: n colliders there
+    Collider c[CT_COLLIDER_ARGS];
+};
+MPM_DEV const Collider& collider_of(const ColliderTable& t, int j) { return t.dev ? t.dev[j] : t.c[j]; }
+
+// this solve's contact count: the host's when it knows it, else the device's (mpm_generate_contact_pairs without a
+// read-back)
+MPM_DEV int ct_count(const ContactDev& c) { return c.n >= 0 ? c.n : c.st->n; }
+
+// P1: number of penetrated colliders per particle slot (the caller's slot order); the padding of the scan's storage is
+// zeroed here (the in-place scan leaves totals there)
+__global__ __launch_bounds__(256) void k_ct_gen_count(DP p, const int* pids_api, ColliderTable cols, int* cnt, int padded) {
     const int s = blockIdx.x * 256 + threadIdx.x;
-    if (s >= p.NpG) return;
+    if (s >= padded) return;
+    if (s >= p.NpG) {
+        cnt[s] = 0;
+        return;
+    }
     const PSet& S = p.set[p.ctl->cur];
     const int slot = p.imap[pids_api[s]];
     // (partitioned domain: only the particles this rank owns make contacts here)
     const float4 q = slot >= 0 ? S.q[0][slot] : make_float4(0.f, 0.f, 0.f, 0.f);
     const float x[3] = {q.x, q.y, q.z};
     int n = 0;
-    for (int j = 0; j < n_col && q.w > 0.f; ++j) {
+    for (int j = 0; j < cols.n && q.w > 0.f; ++j) {
         float g[3];
-        n += collider_sdf(cols[j], x, g) < 0.f ? 1 : 0;
+        n += collider_sdf(collider_of(cols, j), x, g) < 0.f ? 1 : 0;
     }
     cnt[s] = n;
 }
 
-// P2: the pairs, at the scanned offsets: ascending (slot, collider)
-__global__ __launch_bounds__(256) void k_ct_gen_write(DP p, const int* pids_api, int n_col, const Collider* cols,
-                                                      const int* offs, int cap, uint32_t* api_idx, ContactDev c) {
+// P1b (one workgroup, behind k_scan_blocks): the block totals scanned in place, and the pair count left where the solve
+// reads it -- ContactState::n / n_wanted / gen_fault -- instead of travelling to the host
+__global__ __launch_bounds__(1024) void k_ct_gen_total(int* sums, int nb, int cap, ContactState* st) {
+    __shared__ int s_w[16];
+    if (threadIdx.x == 0) sums[nb] = 0;   // (receives the grand total)
+    __syncthreads();
+    wg1024_scan_inplace(sums, nb + 1, s_w);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int total = sums[nb];
+        st->n_wanted = total;
+        st->n = min(total, cap);
+        st->gen_fault = total > cap ? 1 : 0;
+    }
+}
+
+// P2: the pairs, at the scanned offsets (offset inside its 4096-block + that block's offset): ascending (slot, collider)
+__global__ __launch_bounds__(256) void k_ct_gen_write(DP p, const int* pids_api, ColliderTable cols, const int* offs,
+                                                      const int* sums, int cap, uint32_t* api_idx, ContactDev c) {
     const int s = blockIdx.x * 256 + threadIdx.x;
     if (s >= p.NpG) return;
-    int at = offs[s];
-    if (offs[s + 1] == at) return;
+    int at = offs[s] + sums[s >> 12];
+    if (offs[s + 1] + sums[(s + 1) >> 12] == at) return;
     const PSet& S = p.set[p.ctl->cur];
     const uint32_t slot = (uint32_t)p.imap[pids_api[s]];
     const float4 q = S.q[0][slot], vq = S.q[1][slot];
     const float x[3] = {q.x, q.y, q.z};
-    for (int j = 0; j < n_col; ++j) {
-        const Collider& cl = cols[j];
+    for (int j = 0; j < cols.n; ++j) {
+        const Collider& cl = collider_of(cols, j);
         float g[3];
         const float phi = collider_sdf(cl, x, g);
         if (!(phi < 0.f) || at >= cap) continue;
@@ -306,12 +393,6 @@ __global__ __launch_bounds__(256) void k_ct_gen_write(DP p, const int* pids_api,
     }
 }
 
-// two device words side by side, for one read-back instead of two
-__global__ void k_pair_of_ints(int* dst, const int* a, const unsigned* b) {
-    dst[0] = *a;
-    dst[1] = (int)*b;
-}
-
 // ---- set-up (once per UpdateContact) -----------------------------------------
 
 MPM_DEV int compact_cell(const DP& p, uint32_t x, uint32_t y, uint32_t z) {
@@ -326,49 +407,146 @@ MPM_DEV void contact_base(const DP& p, const float* pos, uint32_t* b) {
 }
 
 // S1: sort key = compact index of the stencil's base cell; clears the per-cell tables
-// (also re-resolves the pairs' particles: caller's slot -> engine id -> current internal slot, k_ct_slots' job)
-__global__ __launch_bounds__(256) void k_ct_keys(DP p, ContactDev c, const uint32_t* api_slot, const int* pids_api, uint32_t* slot_out) {
-    const int gs = gridDim.x * 256, i0 = blockIdx.x * 256 + threadIdx.x;
-    const int ncell = (int)p.ctl->n_active * 64;
-    for (int g = i0; g < ncell; g += gs) {
-        c.run[g] = make_int2(0, 0);
-        c.node_flag[g] = 0;
-        c.gD[g] = make_float4(0.f, 0.f, 0.f, 0.f);
+// (also re-resolves the pairs' particles: caller's slot -> engine id -> current internal slot, k_ct_slots' job; resets
+// the solver state -- what a hipMemsetAsync did --; and compares the pair list with the previous solve's, entry by
+// entry: ContactState::changed_solve)
+// key_bits: the host sized the sort for keys below 2^key_bits (from the active blocks of the previous solve); reuse: the
+// host enqueued the set-up that reuses the previous solve's sorted order, this kernel only verifies (k_ct_prepare<true>
+// acts on the verdict); force_changed: this is the repetition of a refused solve (its first attempt has already overwritten
+// the previous list with this one: "unchanged" would be a tautology)
+__global__ __launch_bounds__(256) void k_ct_keys(DP p, ContactDev c, const uint32_t* api_slot, const int* pids_api, uint32_t* slot_out,
+                                                 unsigned seq_base, unsigned solve_no, int key_bits, int reuse, int force_changed) {
+    ContactState* st = c.st;
+    const int n = ct_count(c);
+    const unsigned n_active = p.ctl->n_active;
+    if (blockIdx.x == 0) {
+        // every word in front of ContactState::n starts a solve as zero, except `done`: finished at once when there is
+        // no contact (cuda_mpm_solver.cu:216-217); refused when the pair buffers overflowed or the sort keys are wider
+        // than the host assumed (the host repeats the call)
+        constexpr int NW = (int)(offsetof(ContactState, n) / 4);
+        static_assert(NW <= 256 && offsetof(ContactState, done) == 0, "state reset: one word per thread of one workgroup");
+        const bool fault = c.n < 0 && st->gen_fault;
+        const bool narrow = !reuse && key_bits < 31 && ((unsigned long long)n_active * 64ull > (1ull << key_bits));
+        const int done0 = fault ? CT_DONE_FAULT : (narrow ? CT_DONE_STALE : (n == 0 ? 1 : 0));
+        // (a reused set-up keeps its node list, and with it the count of listed nodes)
+        constexpr int W_NODES = (int)(offsetof(ContactState, n_nodes) / 4);
+        if ((int)threadIdx.x < NW) {
+            int v = 0;
+            if (threadIdx.x == 0) v = done0;
+            else if (reuse && (int)threadIdx.x == W_NODES) v = st->n_nodes;
+            reinterpret_cast<int*>(st)[threadIdx.x] = v;
+        }
+        if (threadIdx.x == 0) {
+            st->seq = seq_base;
+            st->solve_no = solve_no;
+            st->n_active = n_active;
+            if (c.n >= 0) st->n = c.n;
+            const unsigned rebuilds = (unsigned)p.ctl->rebuilds;
+            if (force_changed || n != st->prev_n || rebuilds != st->setup_rebuilds) st->changed_solve = solve_no;
+            st->prev_n = n;
+            st->setup_rebuilds = rebuilds;
+        }
     }
-    for (int k = i0; k < c.n; k += gs) {
+    const int gs = gridDim.x * 256, i0 = blockIdx.x * 256 + threadIdx.x;
+    if (!reuse) {
+        const int ncell = (int)n_active * 64;
+        for (int g = i0; g < ncell; g += gs) {
+            c.run[g] = make_int2(0, 0);
+            c.node_flag[g] = 0;
+            c.gD[g] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    }
+    bool differs = false;
+    for (int k = i0; k < n; k += gs) {
         uint32_t b[3];
         contact_base(p, c.pos + (size_t)k * 3, b);
         const int cc = compact_cell(p, b[0], b[1], b[2]);
-        c.key[k] = cc < 0 ? CT_NO_CELL : (uint32_t)cc;
-        c.order[k] = (uint32_t)k;
-        slot_out[k] = (uint32_t)p.imap[pids_api[api_slot[k]]];
+        const uint32_t key = cc < 0 ? CT_NO_CELL : (uint32_t)cc;
+        const uint32_t api = api_slot[k], body = c.body[k];
+        if (!reuse) {   // (reused set-up: the sorted keys and the order of the last full set-up stay where they are)
+            c.key[k] = key;
+            c.order[k] = (uint32_t)k;
+        }
+        slot_out[k] = (uint32_t)p.imap[pids_api[api]];
+        differs |= c.prev_key[k] != key || c.prev_api[k] != api || c.prev_body[k] != body;
+        c.prev_key[k] = key;
+        c.prev_api[k] = api;
+        c.prev_body[k] = body;
+    }
+    // (a plain store of the same value by every wave that saw a difference: thousands of same-address atomics would
+    // serialise at ~50 ns each)
+    if (__ballot(differs) && (threadIdx.x & 63) == 0) st->changed_solve = solve_no;
+}
+
+MPM_DEV float stencil_weight(const float* wx, const float* wy, const float* wz, int n) {
+    return wx[n / 9] * wy[(n / 3) % 3] * wz[n % 3];
+}
+
+// grid_to_particle_kernel<CONTACT_TRANSFER=true> (cuda_mpm_kernels.cuh:860-866, 891-894):
+// velocity at a contact point (stencil nodes g[27], -1 = not on the active grid) from nodes with m > 1e-7
+MPM_DEV void gather_from_nodes(const DP& p, const int* g, float fx, float fy, float fz, float* v) {
+    float wx[3], wy[3], wz[3];
+    bspline3(fx, wx);
+    bspline3(fy, wy);
+    bspline3(fz, wz);
+    v[0] = v[1] = v[2] = 0.f;
+    // branch-free: a skipped node costs a load of cell 0 and a zero weight, but the 27 node loads are all in flight
+    // together (a branch per node serialises them: one L2 round trip each)
+    float4 q[27];
+#pragma unroll
+    for (int n = 0; n < 27; ++n) q[n] = p.gv[max(g[n], 0)];
+#pragma unroll
+    for (int n = 0; n < 27; ++n) {
+        const float w = (g[n] >= 0 && q[n].w > 1e-7f) ? stencil_weight(wx, wy, wz, n) : 0.f;
+        v[0] += w * q[n].x;
+        v[1] += w * q[n].y;
+        v[2] += w * q[n].z;
     }
 }
 
 // S2 (after the sort): everything that stays fixed during the solve, in sorted order
-// (stencil, fx, mass, contact frame, lagged velocity: cuda_mpm_kernels.cuh:1107-1139)
+// (stencil, fx, mass, contact frame, lagged velocity: cuda_mpm_kernels.cuh:1107-1139), and the pre-contact velocity at
+// the contact points (contact_vel0, cuda_mpm_solver.cu:267-272: the caller's order).
+// REUSE: the pair list equals the previous solve's (ContactState::changed_solve, verified by k_ct_keys in front of this
+// launch): the sorted order, the per-cell runs, the stencil nodes and the node list of that solve stand; only what
+// moves with the particles is refreshed.
+template <bool REUSE>
 __global__ __launch_bounds__(256) void k_ct_prepare(DP p, ContactDev c) {
-    const int j = blockIdx.x * 256 + threadIdx.x;
-    if (j >= c.n) return;
-    const int k = (int)c.order[j];
+    const int n = ct_count(c);
+    const int N = c.stride;
+    if (REUSE && c.st->changed_solve == c.st->solve_no) {
+        // the speculation failed: nothing of this solve may run (the host repeats it with the full set-up)
+        if (blockIdx.x == 0 && threadIdx.x == 0) c.st->done = CT_DONE_STALE;
+        return;
+    }
     const PSet& S = p.set[p.ctl->cur];
+    for (int j = blockIdx.x * 256 + threadIdx.x; j < n; j += gridDim.x * 256) {
+    const int k = (int)c.order[j];
     const uint32_t key = c.key[j];
     // runs of equal keys
-    if (key != CT_NO_CELL) {
+    if (!REUSE && key != CT_NO_CELL) {
         if (j == 0 || c.key[j - 1] != key) c.run[key].x = j;
-        if (j == c.n - 1 || c.key[j + 1] != key) c.run[key].y = j + 1;
+        if (j == n - 1 || c.key[j + 1] != key) c.run[key].y = j + 1;
     }
     uint32_t b[3];
     contact_base(p, c.pos + (size_t)k * 3, b);
+    float fx[3];
 #pragma unroll
-    for (int d = 0; d < 3; ++d) c.cfx[d * c.n + j] = c.pos[k * 3 + d] * p.dxinv - (float)b[d];
+    for (int d = 0; d < 3; ++d) {
+        fx[d] = c.pos[k * 3 + d] * p.dxinv - (float)b[d];
+        c.cfx[d * N + j] = fx[d];
+    }
     const uint32_t slot = c.slot[k];
     c.cmass[j] = fabsf(S.q[0][slot].w) * p.M.density;
     // The 27 stencil cells lie in at most 2 x 2 x 2 blocks: 8 block look-ups (Morton spread + table) instead
     // of 27.  (A contact whose base cell lies outside the active grid cannot be found by the nodes' run
     // lookup: it is left out of the solve altogether; contact points at particle positions, which is what
     // the driver produces, never are.)
-    {
+    int gn[27];
+    if (REUSE) {
+#pragma unroll
+        for (int t = 0; t < 27; ++t) gn[t] = c.cnode[t * N + j];
+    } else {
         const uint32_t bb[3] = {b[0] >> 2, b[1] >> 2, b[2] >> 2};
         uint32_t sx[2], sy[2], sz[2];
 #pragma unroll
@@ -394,7 +572,8 @@ __global__ __launch_bounds__(256) void k_ct_prepare(DP p, ContactDev c) {
 #pragma unroll
                     for (int t = 1; t < 8; ++t) a = q == t ? act[t] : a;
                     const int g = (key == CT_NO_CELL || a < 0) ? -1 : a * 64 + (int)(((x & 3u) << 4) | ((y & 3u) << 2) | (z & 3u));
-                    c.cnode[(i * 9 + jj * 3 + l) * c.n + j] = g;
+                    gn[i * 9 + jj * 3 + l] = g;
+                    c.cnode[(i * 9 + jj * 3 + l) * N + j] = g;
                     if (g >= 0) c.node_flag[g] = 1;
                 }
     }
@@ -407,14 +586,21 @@ __global__ __launch_bounds__(256) void k_ct_prepare(DP p, ContactDev c) {
     float v0[3];
     mulv3(R, v0r, v0);
 #pragma unroll
-    for (int t = 0; t < 9; ++t) c.cR[t * c.n + j] = R[t];
+    for (int t = 0; t < 9; ++t) c.cR[t * N + j] = R[t];
 #pragma unroll
     for (int t = 0; t < 3; ++t) {
-        c.cv0[t * c.n + j] = v0[t];
-        c.crv[t * c.n + j] = rv[t];
-        c.cvel[t * c.n + j] = c.vel[k * 3 + t];   // contact_vel of CopyContactPairs (first iteration)
+        c.cv0[t * N + j] = v0[t];
+        c.crv[t * N + j] = rv[t];
+        c.cvel[t * N + j] = c.vel[k * 3 + t];   // contact_vel of CopyContactPairs (first iteration)
     }
     c.cphi0[j] = -c.dist[k];
+    // pre-contact velocity at the contact point (what k_ct_gather_vel did as a launch of its own)
+    float vg[3];
+    gather_from_nodes(p, gn, fx[0], fx[1], fx[2], vg);
+    c.vel0[k * 3] = vg[0];
+    c.vel0[k * 3 + 1] = vg[1];
+    c.vel0[k * 3 + 2] = vg[2];
+    }
 }
 
 // S3: the nodes that see contacts, in ascending order.  Two steps: the flags of a block (64 ints) become one
@@ -466,46 +652,12 @@ __global__ __launch_bounds__(256) void k_ct_node_runs(DP p, ContactDev c) {
     }
 }
 
-MPM_DEV float stencil_weight(const float* wx, const float* wy, const float* wz, int n) {
-    return wx[n / 9] * wy[(n / 3) % 3] * wz[n % 3];
-}
-
-// grid_to_particle_kernel<CONTACT_TRANSFER=true> (cuda_mpm_kernels.cuh:860-866, 891-894):
-// velocity at the contact point from nodes with m > 1e-7
+// velocity at the sorted contact j from its stencil nodes
 MPM_DEV void gather_contact_velocity(const DP& p, const ContactDev& c, int j, float* v) {
-    float wx[3], wy[3], wz[3];
-    bspline3(c.cfx[j], wx);
-    bspline3(c.cfx[c.n + j], wy);
-    bspline3(c.cfx[2 * c.n + j], wz);
-    v[0] = v[1] = v[2] = 0.f;
-    // branch-free: a skipped node costs a load of cell 0 and a zero weight, but the 27 index loads and
-    // then the 27 node loads are all in flight together (a branch per node serialises them: one L2
-    // round trip each)
     int g[27];
 #pragma unroll
-    for (int n = 0; n < 27; ++n) g[n] = c.cnode[n * c.n + j];
-    float4 q[27];
-#pragma unroll
-    for (int n = 0; n < 27; ++n) q[n] = p.gv[max(g[n], 0)];
-#pragma unroll
-    for (int n = 0; n < 27; ++n) {
-        const float w = (g[n] >= 0 && q[n].w > 1e-7f) ? stencil_weight(wx, wy, wz, n) : 0.f;
-        v[0] += w * q[n].x;
-        v[1] += w * q[n].y;
-        v[2] += w * q[n].z;
-    }
-}
-
-// contact velocities in the caller's order (contact_vel0 before the solve, contact_vel after)
-__global__ __launch_bounds__(256) void k_ct_gather_vel(DP p, ContactDev c, float* out) {
-    const int j = blockIdx.x * 256 + threadIdx.x;
-    if (j >= c.n) return;
-    float v[3];
-    gather_contact_velocity(p, c, j, v);
-    const int k = (int)c.order[j];
-    out[k * 3] = v[0];
-    out[k * 3 + 1] = v[1];
-    out[k * 3 + 2] = v[2];
+    for (int n = 0; n < 27; ++n) g[n] = c.cnode[n * c.stride + j];
+    gather_from_nodes(p, g, c.cfx[j], c.cfx[c.stride + j], c.cfx[2 * c.stride + j], v);
 }
 
 // ---- partitioned domain: node ownership and the exchange of per-node fields in the zones -------
@@ -612,6 +764,18 @@ MPM_DEV void wg_reduce_store(double* vals, double* out) {
 MPM_DEV uint32_t tile_key(const ContactDev& c, int lo, int cnt) {
     return threadIdx.x < 64 ? c.key[lo + min((int)threadIdx.x, cnt - 1)] : 0u;
 }
+// The FIRST tile's keys are requested together with the solver state (one round trip instead of two before the kernel
+// knows what to do).  With the contact count on the device that is before the count is known: every lane of wave 0
+// reads its own key speculatively (the key arrays are padded by a tile, and a workgroup's first tile lies inside the
+// capacity that sized the grid), and once the count is there the lanes past the end take the last contact's key.
+// (lo < stride: a launch may have more workgroups than the buffers have tiles -- k_ct_ls always has CT_ROWS_CON --, and
+// theirs would lie outside the arrays; the arrays are padded by one tile beyond `stride` entries)
+MPM_DEV uint32_t tile_key_early(const ContactDev& c, int lo) {
+    return threadIdx.x < 64 && lo < c.stride ? c.key[lo + (int)threadIdx.x] : 0u;
+}
+MPM_DEV uint32_t tile_key_settle(uint32_t key, int cnt) {
+    return threadIdx.x < 64 ? (uint32_t)__shfl((int)key, min((int)threadIdx.x, max(cnt, 1) - 1)) : 0u;
+}
 MPM_DEV void tile_segments(uint32_t key, int cnt, int* s_seg, int* s_cseg, int* s_nseg) {
     const int tid = threadIdx.x;
     if (tid >= 64) return;
@@ -646,11 +810,13 @@ __global__ __launch_bounds__(256) void k_ct_tile(DP p, ContactDev c, int first, 
     // (the first tile's keys are requested together with the solver state: one round trip instead of two before the
     // kernel knows what to do -- the state was written by a single workgroup of the previous kernel and is a miss in
     // seven of the eight L2s)
-    const int n_tiles = (c.n + CT_TILE - 1) / CT_TILE;
-    uint32_t key_next = (int)blockIdx.x < n_tiles ? tile_key(c, (int)blockIdx.x * CT_TILE, min(CT_TILE, c.n - (int)blockIdx.x * CT_TILE)) : 0u;
+    uint32_t key_next = tile_key_early(c, (int)blockIdx.x * CT_TILE);
     const int st_done = c.st->done, st_phase = c.st->ls_phase;
     const float st_alpha = c.st->alpha;
+    const int cn = ct_count(c), N = c.stride;
     if (!c.force && (st_done || st_phase != 0)) return;   // (line search of the previous direction still running)
+    const int n_tiles = (cn + CT_TILE - 1) / CT_TILE;
+    key_next = tile_key_settle(key_next, min(CT_TILE, cn - (int)blockIdx.x * CT_TILE));
 #if MPM_DIAG
     const unsigned long long tt0 = __builtin_readcyclecounter();
     auto tstamp = [&](int k) {
@@ -670,11 +836,11 @@ __global__ __launch_bounds__(256) void k_ct_tile(DP p, ContactDev c, int first, 
     const int tid = threadIdx.x, lc = tid >> 2, part = tid & 3;
     const ContactParams cp = {c.dt, c.mu, c.k, c.d, c.epsv};
     for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-        const int lo = tile * CT_TILE, cnt = min(CT_TILE, c.n - lo);
+        const int lo = tile * CT_TILE, cnt = min(CT_TILE, cn - lo);
         const uint32_t key = key_next;
         if (tile + (int)gridDim.x < n_tiles) {
             const int lo2 = (tile + (int)gridDim.x) * CT_TILE;
-            key_next = tile_key(c, lo2, min(CT_TILE, c.n - lo2));
+            key_next = tile_key(c, lo2, min(CT_TILE, cn - lo2));
         }
         const int jc = min(lc, cnt - 1);   // (lanes past the end repeat the last contact and store nothing)
         const int j = lo + jc;
@@ -682,11 +848,11 @@ __global__ __launch_bounds__(256) void k_ct_tile(DP p, ContactDev c, int first, 
         // staging's round trips instead of following them)
         float R[9], v0[3], crv[3];
 #pragma unroll
-        for (int t = 0; t < 9; ++t) R[t] = c.cR[t * c.n + j];
+        for (int t = 0; t < 9; ++t) R[t] = c.cR[t * N + j];
 #pragma unroll
         for (int t = 0; t < 3; ++t) {
-            v0[t] = c.cv0[t * c.n + j];
-            crv[t] = c.crv[t * c.n + j];
+            v0[t] = c.cv0[t * N + j];
+            crv[t] = c.crv[t * N + j];
         }
         const float phi0_j = c.cphi0[j], mass = c.cmass[j];
         tile_segments(key, cnt, s_seg, s_cseg, &s_nseg);
@@ -695,8 +861,8 @@ __global__ __launch_bounds__(256) void k_ct_tile(DP p, ContactDev c, int first, 
         const int nseg = s_nseg;
         float wx[3], wy[3], wz[3];
         bspline3(c.cfx[j], wx);
-        bspline3(c.cfx[c.n + j], wy);
-        bspline3(c.cfx[2 * c.n + j], wz);
+        bspline3(c.cfx[N + j], wy);
+        bspline3(c.cfx[2 * N + j], wz);
         if (part == 3 && lc < cnt) {
 #pragma unroll
             for (int t = 0; t < 3; ++t) {
@@ -707,7 +873,7 @@ __global__ __launch_bounds__(256) void k_ct_tile(DP p, ContactDev c, int first, 
         }
         float v[3] = {0.f, 0.f, 0.f};
         if (first) {
-            v[0] = c.cvel[j]; v[1] = c.cvel[c.n + j]; v[2] = c.cvel[2 * c.n + j];
+            v[0] = c.cvel[j]; v[1] = c.cvel[N + j]; v[2] = c.cvel[2 * N + j];
         } else {
             // grid_to_particle_kernel<CONTACT_TRANSFER=true> (cuda_mpm_kernels.cuh:860-866, 891-894):
             // velocity at the contact point from nodes with m > 1e-7
@@ -717,7 +883,7 @@ __global__ __launch_bounds__(256) void k_ct_tile(DP p, ContactDev c, int first, 
                 const int ns = min(CT_STAGE, nseg - s0);
                 for (int t = tid; t < ns * 27; t += 256) {
                     const int sg = t / 27, n = t - sg * 27;
-                    const int g = c.cnode[(size_t)n * c.n + lo + s_seg[s0 + sg]];
+                    const int g = c.cnode[(size_t)n * N + lo + s_seg[s0 + sg]];
                     const float4 q = p.gv[max(g, 0)], D = c.gD[max(g, 0)];
                     const bool ok = g >= 0 && q.w > 1e-7f;
                     s_nv[t] = ok ? make_float4(fmaf(-al, D.x, q.x), fmaf(-al, D.y, q.y), fmaf(-al, D.z, q.z), 1.f)
@@ -934,12 +1100,13 @@ __global__ __launch_bounds__(CT_WG) void k_ct_node_dir(DP p, ContactDev c, int l
 __global__ __launch_bounds__(CT_WG) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_ct_ls(DP p, ContactDev c, int n_con_wg, int exact,
                                                                                              float alpha_probe) {
     // (as in k_ct_tile: the first tile's keys are requested together with the solver state)
-    const int n_tiles = (c.n + CT_TILE - 1) / CT_TILE;
-    uint32_t key_next = (int)blockIdx.x < n_con_wg && (int)blockIdx.x < n_tiles
-                            ? tile_key(c, (int)blockIdx.x * CT_TILE, min(CT_TILE, c.n - (int)blockIdx.x * CT_TILE)) : 0u;
+    uint32_t key_next = (int)blockIdx.x < n_con_wg ? tile_key_early(c, (int)blockIdx.x * CT_TILE) : 0u;
     const int st_done = c.st->done, st_phase = c.st->ls_phase;
     const float st_probe = c.st->alpha_probe;
+    const int cn = ct_count(c), N = c.stride;
     if (st_done && !c.force) return;   // k_ct_decide does not read the records of a finished solve
+    const int n_tiles = (cn + CT_TILE - 1) / CT_TILE;
+    if ((int)blockIdx.x < n_con_wg) key_next = tile_key_settle(key_next, min(CT_TILE, cn - (int)blockIdx.x * CT_TILE));
     if (exact == 2) {
         if (st_phase == 3) return;
         alpha_probe = st_probe;
@@ -960,11 +1127,11 @@ __global__ __launch_bounds__(CT_WG) __attribute__((amdgpu_waves_per_eu(4, 4))) v
         const ContactParams cp = {c.dt, c.mu, c.k, c.d, c.epsv};
         double acc[6] = {0, 0, 0, 0, 0, 0}, e0 = 0;
         for (int tile = blockIdx.x; tile < n_tiles; tile += n_con_wg) {
-            const int lo = tile * CT_TILE, cnt = min(CT_TILE, c.n - lo);
+            const int lo = tile * CT_TILE, cnt = min(CT_TILE, cn - lo);
             const uint32_t key = key_next;
             if (tile + n_con_wg < n_tiles) {
                 const int lo2 = (tile + n_con_wg) * CT_TILE;
-                key_next = tile_key(c, lo2, min(CT_TILE, c.n - lo2));
+                key_next = tile_key(c, lo2, min(CT_TILE, cn - lo2));
             }
             __syncthreads();   // the previous tile's tables are no longer read
             tile_segments(key, cnt, s_seg, s_cseg, &s_nseg);
@@ -974,8 +1141,8 @@ __global__ __launch_bounds__(CT_WG) __attribute__((amdgpu_waves_per_eu(4, 4))) v
             const bool counted = lc < cnt;   // (lanes past the end repeat the last contact and add nothing)
             float wx[3], wy[3], wz[3];
             bspline3(c.cfx[j], wx);
-            bspline3(c.cfx[c.n + j], wy);
-            bspline3(c.cfx[2 * c.n + j], wz);
+            bspline3(c.cfx[N + j], wy);
+            bspline3(c.cfx[2 * N + j], wz);
             const float wxi = part == 0 ? wx[0] : (part == 1 ? wx[1] : wx[2]);
             const int myseg = s_cseg[jc];
             float ov[3] = {0.f, 0.f, 0.f}, dd[3] = {0.f, 0.f, 0.f};
@@ -983,7 +1150,7 @@ __global__ __launch_bounds__(CT_WG) __attribute__((amdgpu_waves_per_eu(4, 4))) v
                 const int ns = min(CT_STAGE, nseg - s0);
                 for (int t = tid; t < ns * 27; t += CT_WG) {
                     const int sg = t / 27, n = t - sg * 27;
-                    const int g = c.cnode[(size_t)n * c.n + lo + s_seg[s0 + sg]];
+                    const int g = c.cnode[(size_t)n * N + lo + s_seg[s0 + sg]];
                     float4 q = p.gv[max(g, 0)], D = c.gD[max(g, 0)];
                     D.w = g >= 0 ? 1.f : 0.f;
                     s_nv[t] = q;
@@ -1011,13 +1178,13 @@ __global__ __launch_bounds__(CT_WG) __attribute__((amdgpu_waves_per_eu(4, 4))) v
             }
             float R[9], v0[3];
 #pragma unroll
-            for (int t = 0; t < 9; ++t) R[t] = c.cR[t * c.n + j];
+            for (int t = 0; t < 9; ++t) R[t] = c.cR[t * N + j];
 #pragma unroll
-            for (int t = 0; t < 3; ++t) v0[t] = c.cv0[t * c.n + j];
+            for (int t = 0; t < 3; ++t) v0[t] = c.cv0[t * N + j];
             const float phi0 = c.cphi0[j], mass = counted ? c.cmass[j] : 0.f;
             float ovl[3], ddl[3];
             {
-                const float t[3] = {ov[0] - c.crv[j], ov[1] - c.crv[c.n + j], ov[2] - c.crv[2 * c.n + j]};
+                const float t[3] = {ov[0] - c.crv[j], ov[1] - c.crv[N + j], ov[2] - c.crv[2 * N + j]};
                 mulv3(R, t, ovl);
                 mulv3(R, dd, ddl);
             }
@@ -1187,6 +1354,25 @@ MPM_DEV void ct_thread_sums(const ContactDev& c, int n_dir_wg, int n_con_wg, int
     d1 = dq[0][1] + dq[1][1];
 }
 
+// One thread leaves the state of the solve where the host polls it (ContactMailbox): no fence -- every word is one 8-byte
+// store and carries the publication number, the host accepts four words with the same number.
+MPM_DEV void ct_publish(const ContactDev& c) {
+    ContactState* st = c.st;
+    const unsigned seq = st->seq + 1u;
+    st->seq = seq;
+    const int done = st->done;
+    const unsigned long long hi = (unsigned long long)seq << 32;
+    const unsigned cnt = (unsigned)(done == CT_DONE_FAULT ? st->n_wanted : st->n);
+    const unsigned nodes = ((unsigned)st->n_nodes & 0x7FFFFFFFu) | (st->changed_solve != st->solve_no ? 0x80000000u : 0u);
+    unsigned long long* w = c.mbox->w;
+    __hip_atomic_store(&w[1], hi | (unsigned long long)__float_as_uint(st->residual), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(&w[2], hi | (unsigned long long)cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(&w[3], hi | (unsigned long long)nodes, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(&w[4], hi | (unsigned long long)st->n_active, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(&w[0], hi | ((unsigned long long)(done & 0xFF) << 24) | (unsigned long long)((unsigned)st->iters & 0xFFFFFFu),
+                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 // the fields of the solver state the backtracking decision reads and updates, fetched once at the start of the kernel
 // (read where they are used, each is one more dependent round trip of the single workgroup that decides)
 struct CtSnap {
@@ -1320,6 +1506,12 @@ MPM_DEV void ct_decide_from(const ContactDev& c, int exact, int phase, bool deep
         const float res = sqrtf(nd) / dofs;   // NaN when there is no DoF: the loop stops, as in the reference
         st->residual = res;
         if (!(res > c.tol) || sn.iters + 1 >= c.max_iters) st->done = 2;  // finish after this update
+        if (sn.iters < CT_LOG) {
+            // the host-side decisions of cuda_mpm_solver.cu:472-528, 567-570, one row per Newton iteration
+            float* row = c.it_log + (size_t)sn.iters * CT_LOG_F;
+            row[0] = res; row[1] = (float)(j + 1); row[2] = Ej; row[3] = ldexpf(1.f, -j); row[4] = E0; row[5] = nd; row[6] = dofs;
+            row[7] = 0.f;
+        }
     }
 }
 
@@ -1339,12 +1531,17 @@ __global__ __launch_bounds__(1024) void k_ct_decide(ContactDev c, int n_dir_wg, 
     if (done && !c.force) {
         // "finish after this update" becomes "finished" once that update (k_ct_apply of the
         // previous iteration) has run
-        if (threadIdx.x == 0 && done == 2) st->done = 1;
+        if (threadIdx.x == 0) {
+            if (done == 2) st->done = 1;
+            if (c.mbox) ct_publish(c);
+        }
         return;
     }
     const bool deep_pass = !exact && ls_phase == 4;
     if (deep_pass && phase != 2) ct_thread_sums<1024>(c, n_dir_wg, n_con_wg, n_grid_wg, exact, true, v, d0, d1);
     ct_decide_from<1024>(c, exact, phase, deep_pass, v, d0, d1, s_sum, s_dir, sn);
+    // (thread 0 is the lane that took the decision: its own stores to the state precede this in program order)
+    if (threadIdx.x == 0 && c.mbox) ct_publish(c);
 }
 
 // G3: v -= alpha Dir (cuda_mpm_kernels.cuh:1591-1614); only nodes that see contacts have a direction
@@ -1353,6 +1550,7 @@ __global__ __launch_bounds__(1024) void k_ct_decide(ContactDev c, int n_dir_wg, 
 // of the last iteration when k_ct_node_dir applies the others (lazy)
 __global__ __launch_bounds__(CT_WG) void k_ct_apply(DP p, ContactDev c, int mode = 0) {
     ContactState* st = c.st;
+    if (st->done >= CT_DONE_FAULT) return;        // (nothing was solved)
     if (mode != 2 && st->done == 1) return;
     if (mode == 0 && st->ls_phase == 4) return;   // backtracking continues: no step accepted yet
     if (mode == 1 && st->ls_phase != 3) return;   // the search of this direction is still running
@@ -1371,18 +1569,21 @@ __global__ __launch_bounds__(CT_WG) void k_ct_apply(DP p, ContactDev c, int mode
 // Device-resident exact search: closes a Newton iteration after k_ct_apply (cuda_mpm_solver.cu:567-570)
 __global__ void k_ct_exact_finish(ContactDev c) {
     ContactState* st = c.st;
-    if (threadIdx.x != 0 || st->done == 1 || st->ls_phase != 3) return;
-    st->residual = sqrtf(st->norm_dir_sq) / st->dofs;
-    if (st->iters < CT_LOG) {
-        c.it_log[st->iters * 3] = st->residual;
-        c.it_log[st->iters * 3 + 1] = (float)st->ls_evals;
-        c.it_log[st->iters * 3 + 2] = st->energy;
+    if (threadIdx.x != 0) return;
+    if (!(st->done != 0 || st->ls_phase != 3)) {
+        st->residual = sqrtf(st->norm_dir_sq) / st->dofs;
+        if (st->iters < CT_LOG) {
+            float* row = c.it_log + (size_t)st->iters * CT_LOG_F;
+            row[0] = st->residual; row[1] = (float)st->ls_evals; row[2] = st->energy; row[3] = st->alpha; row[4] = st->E0;
+            row[5] = st->norm_dir_sq; row[6] = st->dofs; row[7] = 0.f;
+        }
+        st->iters += 1;
+        st->ls_total += st->ls_evals;
+        st->ls_phase = 0;
+        st->alpha_probe = 0.f;   // the next direction's search starts with (E, dE, d2E) at alpha = 0 (cuda_mpm_solver.cu:386-390)
+        if (!(st->residual > c.tol) || st->iters >= c.max_iters) st->done = 1;
     }
-    st->iters += 1;
-    st->ls_total += st->ls_evals;
-    st->ls_phase = 0;
-    st->alpha_probe = 0.f;   // the next direction's search starts with (E, dE, d2E) at alpha = 0 (cuda_mpm_solver.cu:386-390)
-    if (!(st->residual > c.tol) || st->iters >= c.max_iters) st->done = 1;
+    if (c.mbox) ct_publish(c);   // (the host learns "finished" from this launch, not from the next pattern's first decision)
 }
 
 // apply_contact_impulse_to_rigid_bodies (cuda_mpm_kernels.cuh:1616-1658).  Impulses are summed
@@ -1394,7 +1595,8 @@ __global__ __launch_bounds__(256) void k_ct_impulse(DP p, ContactDev c) {
     __shared__ float s_acc[CT_LDS_BODIES][6];
     for (int q = threadIdx.x; q < CT_LDS_BODIES * 6; q += 256) (&s_acc[0][0])[q] = 0.f;
     __syncthreads();
-    for (int j = blockIdx.x * 256 + threadIdx.x; j < c.n; j += gridDim.x * 256) {
+    const int cn = c.st->done >= CT_DONE_FAULT ? 0 : ct_count(c);   // (a solve that did not run leaves no impulse: the host repeats it)
+    for (int j = blockIdx.x * 256 + threadIdx.x; j < cn; j += gridDim.x * 256) {
         const int k = (int)c.order[j];   // sorted position j is the caller's contact k
         const float m = c.cmass[j];
         float v[3];

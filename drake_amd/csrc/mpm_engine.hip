@@ -165,7 +165,7 @@ static void launch_rebuild(mpm_engine* e) {
 // A re-sort may be about to run (directly or inside a replayed graph): the block tables may change, so contact
 // pairs handed over before are re-keyed with the full width, and the anticipatory binning uses this substep length.
 static void may_resort(mpm_engine* e, float dt) {
-    e->cb.n_active_hint = 0;
+    // (the contact solve's guess of how many blocks are active survives a re-sort: k_ct_keys verifies it on the device)
     if (dt > 0.f) e->last_dt = dt;
 }
 static void drop_step_graph(mpm_engine* e) {
@@ -2163,9 +2163,45 @@ int mpm_download_contact_pairs(mpm_handle_t e, uint32_t* particle, uint32_t* bod
     return download_contacts(e, particle, body, dist, normal, pos, rigid_v, p_WB);
 } MPM_CATCH_ALL
 
+int mpm_last_contact_counts(mpm_handle_t e, uint32_t* contacts_out, uint32_t* nodes_out, int* setup_reused_out) try {
+    REQUIRE(e, "null handle");
+    if (contacts_out) *contacts_out = e->last_contact.contacts;
+    if (nodes_out) *nodes_out = e->last_contact.nodes;
+    if (setup_reused_out) *setup_reused_out = e->last_contact_reused ? 1 : 0;
+    return 0;
+} MPM_CATCH_ALL
+
+int mpm_debug_contact_counters(mpm_handle_t e, uint64_t out4[4]) try {
+    REQUIRE(e && out4, "null argument");
+    for (int k = 0; k < 4; ++k) out4[k] = e->ct_counters[k];
+    return 0;
+} MPM_CATCH_ALL
+
+int mpm_get_contact_pair_count(mpm_handle_t e, size_t* n_out) try {
+    READY(e);
+    REQUIRE(n_out, "null output");
+    if (int rc = resolve_contact_count(e)) return rc;
+    *n_out = e->cb.n;
+    return 0;
+} MPM_CATCH_ALL
+
+int mpm_download_contact_log(mpm_handle_t e, float* rows_out, size_t capacity_rows, size_t* n_rows_out) try {
+    READY(e);
+    REQUIRE(n_rows_out, "null output");
+    static_assert(CT_LOG_F == MPM_CONTACT_LOG_FLOATS, "contact log layouts differ");
+    const size_t rows = (size_t)std::min(std::max(e->cb.last_iters, 0), CT_LOG);
+    *n_rows_out = rows;
+    if (!rows_out || rows == 0) return 0;
+    REQUIRE(capacity_rows >= rows, "output array too small");
+    REQUIRE(e->cb.it_log, "no contact solve has run");
+    D2H(e, rows_out, e->cb.it_log, rows * CT_LOG_F * sizeof(float));
+    return 0;
+} MPM_CATCH_ALL
+
 int mpm_get_contact_stats(mpm_handle_t e, mpm_contact_stats_t* out) try {
     READY(e);
     REQUIRE(out, "null stats");
+    if (int rc = contact_stats_from_device(e)) return rc;
     *out = e->last_contact;
     return 0;
 } MPM_CATCH_ALL
@@ -2176,10 +2212,67 @@ int mpm_update_contact(mpm_handle_t e, int frame, int substep, float dt, float m
     if (iters_out) *iters_out = 0;
     if (residual_out) *residual_out = 0.f;
     e->last_contact = mpm_contact_stats_t{};
-    if (e->cb.n == 0) return 0;  // cuda_mpm_solver.cu:216-217
+    if (!e->cb.dev_counted && e->cb.n == 0) return 0;  // cuda_mpm_solver.cu:216-217
     REQUIRE(e->grid_state == 2, "UpdateContact before UpdateGrid");
     return update_contact(e, frame, substep, dt, mu, stiffness, damping, dump, exact, max_iters, iters_out,
                           residual_out);
+} MPM_CATCH_ALL
+
+// The body of DeformableDriver::CalcAbstractStates' substep loop (multibody/plant/deformable_driver.h:240-258) for
+// rigid bodies with analytic signed distance fields, n times, in one call: RebuildMapping, CalcFemStateAndForce,
+// ParticleToGrid, UpdateGrid, CalcMpmContactPairs + CopyContactPairs (on the device), UpdateContact, GridToParticle.
+// What the seven calls per substep cost a caller on top of the kernels is the host's share: ~45 launches per coupled
+// substep at ~3.5 us each, issued in bursts behind every point where the host has to wait (the solve's end), with the
+// caller's own code in between.  Here the host waits exactly once per substep -- for the mailbox word that says the solve
+// has converged -- and has the next substep's long kernels (FEM, ParticleToGrid) enqueued before the short ones of the
+// contact set-up are due; between two substeps of the call GridToParticle and ParticleToGrid leave out what only a
+// download would read (DP::lean_g2p), as mpm_run_substeps does.
+int mpm_run_coupled_substeps(mpm_handle_t e, int n, const mpm_coupled_params_t* prm, size_t n_colliders,
+                             const mpm_collider_t* colliders, mpm_coupled_result_t* results) try {
+    READY(e);
+    REQUIRE(prm && n >= 0, "bad arguments");
+    REQUIRE(n_colliders == 0 || colliders, "null collider array");
+    REQUIRE(n_colliders <= 1024, "too many colliders");
+    REQUIRE(!e->dp.dist.on, "mpm_run_coupled_substeps: not on a partitioned domain (use the phase calls)");
+    GridColliders gc;
+    if (int rc = grid_colliders_for(e, prm->mpm_bc, &gc)) return rc;
+    const float dt = prm->dt;
+    for (int s = 0; s < n; ++s) {
+        may_resort(e, dt);
+        e->dp.gated = 0;
+        e->dp.lean_resort = 1;   // (CalcFemStateAndForce follows at once)
+        launch_rebuild(e);
+        e->dp.lean_resort = 0;
+        e->dp.lean_g2p = s + 1 < n;
+        launch_fem_p2g(e, dt);
+        launch_grid(e, gc);
+        e->grid_state = 2;
+        int iters = 0;
+        float residual = 0.f;
+        int rc = generate_contacts(e, n_colliders, colliders, nullptr);
+        if (!rc && (e->cb.dev_counted || e->cb.n > 0))
+            rc = update_contact(e, 0, s, dt, prm->friction_mu, prm->stiffness, prm->damping, 0, prm->exact_line_search,
+                                prm->max_newton_iterations, &iters, &residual);
+        else if (!rc)
+            e->last_contact = mpm_contact_stats_t{};
+        if (rc) {
+            e->dp.lean_g2p = 0;
+            return rc;
+        }
+        launch_g2p(e, dt);
+        e->dp.lean_g2p = 0;
+        e->substeps += 1;
+        if (results) {
+            mpm_coupled_result_t& r = results[s];
+            r.iterations = iters;
+            r.contacts = e->last_contact.contacts;
+            r.nodes = e->last_contact.nodes;
+            r.residual = residual;
+            r.setup_reused = e->last_contact_reused ? 1 : 0;
+        }
+    }
+    HIP_TRY(hipGetLastError());
+    return 0;
 } MPM_CATCH_ALL
 
 // The root finder of the exact line search behind a C callback, for the known-answer tests

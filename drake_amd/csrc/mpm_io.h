@@ -227,6 +227,8 @@ __global__ __launch_bounds__(256) void k_touched_flags(DP p, uint32_t* flags) {
 }  // namespace mpm
 
 // identity "slot -> original id" map on the device (views in original order)
+static int resolve_contact_count(mpm_engine* e);   // (mpm_contact.h: the pair count may still be on the device)
+
 static int device_iota(mpm_engine* e, int** out) {
     if (!e->d_iota) {
         std::vector<int> iota(e->np);
@@ -306,6 +308,7 @@ static int download_grid(mpm_engine* e, int which, void* out, size_t bytes, size
         field = p.gvs;
     } else if (which == MPM_ARR_GRID_DIR) {
         // the relaxed Newton direction of the last UpdateContact iteration (nodes without contacts: 0)
+        if (int rc_n = resolve_contact_count(e)) return rc_n;
         REQUIRE(e->cb.n > 0 && e->cb.gD && e->grid_state == 2, "grid_Dir is only defined after UpdateContact");
         field = e->cb.gD;
     } else if (e->grid_state == 3) {
@@ -413,6 +416,7 @@ static int download_array(mpm_engine* e, int which, void* out, size_t bytes, siz
         }
         case MPM_ARR_CONTACT_VEL:
         case MPM_ARR_CONTACT_VEL0: {
+            if ((rc = resolve_contact_count(e))) return rc;
             if ((rc = need(e->cb.n * 12))) return rc;
             HIP_TRY(hipStreamSynchronize(e->stream));
             if (e->cb.n)

@@ -28,9 +28,12 @@ namespace mpm {
 constexpr int SORT_WAVES = 4;
 
 template <int DB>
+// (n_dev: the number of pairs is on the device -- the contact pairs of mpm_generate_contact_pairs --; `n` is then an
+// upper bound that sized the grid, tiles beyond the count do nothing)
 __global__ __launch_bounds__(64 * SORT_WAVES) void k_sort_hist(const uint32_t* keys, int n, int shift, int items, int* hist,
-                                                              int ntiles) {
+                                                              int ntiles, const int* n_dev = nullptr) {
     constexpr int ND = 1 << DB;
+    if (n_dev) n = min(n, *n_dev);
     __shared__ int s_cnt[ND];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, tile = blockIdx.x;
     for (int d = tid; d < ND; d += 64 * SORT_WAVES) s_cnt[d] = 0;
@@ -71,8 +74,7 @@ MPM_DEV int wg1024_exclusive(int v, int& total, int* s_w) {
 // exclusive scan of `total` ints in place, one 1024-thread workgroup; every thread owns 16
 // consecutive entries (four 16-byte loads) of each 16384-entry block.  `a` must be 16-byte
 // aligned and padded to a multiple of 4 entries.
-__global__ __launch_bounds__(1024) void k_sort_scan(int* a, int total) {
-    __shared__ int s_w[16];
+MPM_DEV void wg1024_scan_inplace(int* a, int total, int* s_w /* [16] shared */) {
     const int tid = threadIdx.x;
     int carry = 0;
     for (int base = 0; base < total; base += 16384) {
@@ -107,6 +109,10 @@ __global__ __launch_bounds__(1024) void k_sort_scan(int* a, int total) {
         }
         carry += block_total;
     }
+}
+__global__ __launch_bounds__(1024) void k_sort_scan(int* a, int total) {
+    __shared__ int s_w[16];
+    wg1024_scan_inplace(a, total, s_w);
 }
 
 // Large exclusive scan: k_scan_blocks scans 4096-entry blocks in place and records their totals,
@@ -163,8 +169,9 @@ __global__ __launch_bounds__(256) void k_scan_add(int* a, const int* sums) {
 template <int DB>
 __global__ __launch_bounds__(64 * SORT_WAVES) void k_sort_scatter(const uint32_t* keys, const uint32_t* vals, uint32_t* keys_out,
                                                                  uint32_t* vals_out, int n, int shift, int items, const int* hist,
-                                                                 int ntiles) {
+                                                                 int ntiles, const int* n_dev = nullptr) {
     constexpr int ND = 1 << DB;
+    if (n_dev) n = min(n, *n_dev);
     __shared__ int s_off[SORT_WAVES][ND];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, tile = blockIdx.x;
     for (int d = tid; d < SORT_WAVES * ND; d += 64 * SORT_WAVES) (&s_off[0][0])[d] = 0;
@@ -244,19 +251,22 @@ static inline size_t sort_hist_ints(size_t n) {
 
 template <int DB>
 static void radix_pass(hipStream_t s, const uint32_t* ki, const uint32_t* vi, uint32_t* ko, uint32_t* vo, int* hist, int n,
-                       int shift, int items, int ntiles) {
+                       int shift, int items, int ntiles, const int* n_dev) {
     using namespace mpm;
-    hipLaunchKernelGGL(k_sort_hist<DB>, dim3(ntiles), dim3(64 * SORT_WAVES), 0, s, ki, n, shift, items, hist, ntiles);
+    hipLaunchKernelGGL(k_sort_hist<DB>, dim3(ntiles), dim3(64 * SORT_WAVES), 0, s, ki, n, shift, items, hist, ntiles, n_dev);
     hipLaunchKernelGGL(k_sort_scan, dim3(1), dim3(1024), 0, s, hist, (1 << DB) * ntiles);
     hipLaunchKernelGGL(k_sort_scatter<DB>, dim3(ntiles), dim3(64 * SORT_WAVES), 0, s, ki, vi, ko, vo, n, shift, items, (const int*)hist,
-                       ntiles);
+                       ntiles, n_dev);
 }
 
-// Sorts n pairs by the key bits [0, bits) (stable).  `a` holds the input and receives the result;
-// `b` and `hist` are scratch (hist: sort_hist_ints(n) ints).
+// Sorts n pairs by the key bits [0, bits) (stable).  `a` holds the input; `b` and `hist` are scratch (hist:
+// sort_hist_ints(n) ints).  The result ends in `a` after an even number of passes and in `b` after an odd one:
+// *in_b says which when the caller can live with either (no copy), else (in_b == nullptr) it is copied back to `a`.
+// n_dev: the count lives on the device, n is its upper bound (see k_sort_hist).
 static int radix_sort_pairs(hipStream_t s, uint32_t* ka, uint32_t* va, uint32_t* kb, uint32_t* vb, int* hist, size_t n,
-                            int bits) {
+                            int bits, bool* in_b = nullptr, const int* n_dev = nullptr) {
     using namespace mpm;
+    if (in_b) *in_b = false;
     if (n < 2 || bits <= 0) return 0;
     const int items = sort_items_for(n);
     const int ntiles = (int)((n + (size_t)64 * items - 1) / ((size_t)64 * items));
@@ -279,17 +289,21 @@ static int radix_sort_pairs(hipStream_t s, uint32_t* ka, uint32_t* va, uint32_t*
     for (int pass = 0; pass < passes; ++pass) {
         const int shift = pass * db;
         switch (db) {
-            case 8: radix_pass<8>(s, ki, vi, ko, vo, hist, (int)n, shift, items, ntiles); break;
-            case 9: radix_pass<9>(s, ki, vi, ko, vo, hist, (int)n, shift, items, ntiles); break;
-            case 10: radix_pass<10>(s, ki, vi, ko, vo, hist, (int)n, shift, items, ntiles); break;
-            default: radix_pass<11>(s, ki, vi, ko, vo, hist, (int)n, shift, items, ntiles); break;
+            case 8: radix_pass<8>(s, ki, vi, ko, vo, hist, (int)n, shift, items, ntiles, n_dev); break;
+            case 9: radix_pass<9>(s, ki, vi, ko, vo, hist, (int)n, shift, items, ntiles, n_dev); break;
+            case 10: radix_pass<10>(s, ki, vi, ko, vo, hist, (int)n, shift, items, ntiles, n_dev); break;
+            default: radix_pass<11>(s, ki, vi, ko, vo, hist, (int)n, shift, items, ntiles, n_dev); break;
         }
         std::swap(ki, ko);
         std::swap(vi, vo);
     }
     if (ki != ka) {  // odd number of passes: the result sits in the scratch pair
-        if (hipMemcpyAsync(ka, ki, n * 4, hipMemcpyDeviceToDevice, s) != hipSuccess) return -1;
-        if (hipMemcpyAsync(va, vi, n * 4, hipMemcpyDeviceToDevice, s) != hipSuccess) return -1;
+        if (in_b) {
+            *in_b = true;
+        } else {
+            if (hipMemcpyAsync(ka, ki, n * 4, hipMemcpyDeviceToDevice, s) != hipSuccess) return -1;
+            if (hipMemcpyAsync(va, vi, n * 4, hipMemcpyDeviceToDevice, s) != hipSuccess) return -1;
+        }
     }
     return 0;
 }

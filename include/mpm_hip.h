@@ -358,6 +358,21 @@ typedef struct mpm_collider {
 } mpm_collider_t;
 MPM_API int mpm_generate_contact_pairs(mpm_handle_t h, size_t n_colliders, const mpm_collider_t *colliders,
                                        size_t *n_contacts_out);
+/* n_contacts_out may be NULL: the call then waits for nothing -- the pairs are counted on the device and STAY counted
+ * there; mpm_update_contact's launches have fixed grids and read the count on the device (the reference's driver reads
+ * every position back, loops over the particles on the host and uploads the pairs, per substep:
+ * deformable_driver.h:120-194, cuda_mpm_solver.cu:185-212).  mpm_update_contact reports the count afterwards
+ * (mpm_contact_stats_t::contacts); mpm_get_contact_pair_count reads it back on request (a synchronisation point), as do
+ * mpm_download_contact_pairs and a non-NULL n_contacts_out.  Up to 16 colliders travel as a kernel argument (no upload);
+ * more through a device array that is refreshed only when the colliders have changed. */
+MPM_API int mpm_get_contact_pair_count(mpm_handle_t h, size_t *n_contacts_out);
+/* What the last mpm_update_contact worked on, without touching the device: contacts, grid nodes reached by a contact
+ * stencil, and whether its set-up was the previous solve's, reused (a settled scene whose pair list repeats: no sort, no
+ * per-cell runs, no node list -- verified on the device entry by entry).  Any pointer may be NULL. */
+MPM_API int mpm_last_contact_counts(mpm_handle_t h, uint32_t *contacts_out, uint32_t *nodes_out, int *setup_reused_out);
+/* Tests: {mpm_update_contact calls that solved, of them on a reused set-up, solves refused on the device because a guess of
+ * the host's was wrong (repeated with the full set-up), pair generations / solves repeated after a buffer overflow}. */
+MPM_API int mpm_debug_contact_counters(mpm_handle_t h, uint64_t out4[4]);
 MPM_API int mpm_download_contact_pairs(mpm_handle_t h, uint32_t *particle_in_contact_index, uint32_t *non_mpm_id,
                                        float *penetration_distance, float *normal, float *position, float *rigid_v,
                                        float *rigid_p_WB);
@@ -390,12 +405,45 @@ typedef struct {
 } mpm_contact_stats_t;
 MPM_API int mpm_get_contact_stats(mpm_handle_t h, mpm_contact_stats_t *out);
 
+/* The decisions of the last mpm_update_contact, one row per Newton iteration -- what the reference's host loop decides per
+ * iteration (cuda_mpm_solver.cu:472-528 backtracking, :383-471 exact search, :567-570 stopping test) and dumps as JSON
+ * for the exact search (:587-612).  Row = MPM_CONTACT_LOG_FLOATS floats:
+ *   [0] residual sqrt(sum |Dir|^2) / DoFs   [1] line-search evaluations   [2] E(alpha)   [3] accepted alpha   [4] E(0)
+ *   [5] sum |Dir|^2 (before relaxation)     [6] DoFs                      [7] 0
+ * At most 2048 iterations are kept.  rows_out may be NULL (count only). */
+#define MPM_CONTACT_LOG_FLOATS 8
+MPM_API int mpm_download_contact_log(mpm_handle_t h, float *rows_out, size_t capacity_rows, size_t *n_rows_out);
+
 /* ---- conveniences on top of the reference interface ---------------------- */
 
 /* The five solver calls of one contact-free substep (cuda_mpm_test.cc:66-72,
  * deformable_driver.h:244-258 without the contact part), without host syncs. */
 MPM_API int mpm_substep(mpm_handle_t h, float dt, int mpm_bc);
 MPM_API int mpm_run_substeps(mpm_handle_t h, int n, float dt, int mpm_bc);
+
+/* The same for COUPLED substeps: the body of DeformableDriver::CalcAbstractStates' loop
+ * (multibody/plant/deformable_driver.h:240-258) n times in one call, for rigid bodies with analytic signed distance
+ * fields (mpm_collider_t, see mpm_generate_contact_pairs): RebuildMapping, CalcFemStateAndForce, ParticleToGrid,
+ * UpdateGrid(mpm_bc), contact pairs on the device, UpdateContact(dt, mu, stiffness, damping, exact), GridToParticle.
+ * The results are those of the seven calls (the tests compare them bit for bit); the host waits once per substep, for
+ * the word that says the solve has converged.  mpm_reallocate_external_bodies must have been called (the per-body
+ * impulses accumulate over the n substeps, as over the substeps of one plant step: deformable_driver.h:196-219).
+ * results: n entries or NULL. */
+typedef struct {
+    float dt;
+    int32_t mpm_bc;
+    float friction_mu, stiffness, damping;
+    int32_t exact_line_search;
+    int32_t max_newton_iterations;   /* <= 0: the reference's 2000 */
+} mpm_coupled_params_t;
+typedef struct {
+    int32_t iterations;
+    uint32_t contacts, nodes;
+    float residual;
+    int32_t setup_reused;
+} mpm_coupled_result_t;
+MPM_API int mpm_run_coupled_substeps(mpm_handle_t h, int n, const mpm_coupled_params_t *params, size_t n_colliders,
+                                     const mpm_collider_t *colliders, mpm_coupled_result_t *results);
 
 /* Runs n substeps with HIP events around every kernel group on the engine's
  * stream and returns the mean milliseconds per substep of each phase

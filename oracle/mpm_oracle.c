@@ -1322,6 +1322,18 @@ static void ls_thunk(void *ctx, real alpha, real *out) {
  * test use): accepted alpha, E(0), E(alpha), sum |Dir|^2, DoFs, line-search evaluations */
 static real g_last_diag[6];
 ORC_API void orc_last_contact_diag(real *out6) { memcpy(out6, g_last_diag, sizeof(g_last_diag)); }
+/* ... and the same six numbers of EVERY Newton iteration of that call, plus the residual the loop test of :274 saw
+ * after it (cuda_mpm_solver.cu:472-528, 567-570: the host-side decisions of the reference, one row per iteration):
+ * alpha, E(0), E(alpha), sum |Dir|^2, DoFs, line-search evaluations, residual.  What the JSON dump of :587-612 holds
+ * per iteration for the exact search, for both searches. */
+#define ORC_LOG_MAX 4096
+static real g_it_log[ORC_LOG_MAX][7];
+static int g_it_log_n;
+ORC_API int orc_contact_iteration_log(real *out, int max_rows) {
+    const int n = g_it_log_n < max_rows ? g_it_log_n : max_rows;
+    if (out && n > 0) memcpy(out, g_it_log, (size_t)n * 7 * sizeof(real));
+    return g_it_log_n;
+}
 
 /* jacobi_relax_coeff (cuda_mpm_solver.cu:239) is a constant, 0.3, in the reference.  Tests raise it to make
  * the Newton step overshoot, so that the backtracking loop (:472-528) has to halve it several times. */
@@ -1342,6 +1354,7 @@ ORC_API int orc_update_contact(const orc_params *p, size_t nk, const real *cpos,
                                real dt, real mu, real k, real d, int exact_line_search,
                                int max_iters, real *residual_out, real *ls_avg_out,
                                real *energy_out) {
+    g_it_log_n = 0;
     if (!nk) return 0;                                           /* :216-217 */
     const uint32_t tc = touched_blocks * 64u;
     const real kTol = R(1e-4), relax = g_relax;                   /* :236,239 */
@@ -1410,6 +1423,11 @@ ORC_API int orc_update_contact(const orc_params *p, size_t nk, const real *cpos,
         memcpy(pos_tmp, cpos, n3 * sizeof(real));
         orc_grid_to_particle(p, nk, pos_tmp, cvel, NULL, gm, gv, dt, 1); /* :557-562 */
         norm_dir = sqrt(nd) / (real)(int)dofs;                 /* :567-569 */
+        if (g_it_log_n < ORC_LOG_MAX) {
+            real *row = g_it_log[g_it_log_n++];
+            row[0] = alpha; row[1] = E0; row[2] = E1; row[3] = nd; row[4] = (real)dofs; row[5] = (real)ls_cnt;
+            row[6] = norm_dir;
+        }
         count += 1;
     }
     free(pos_tmp);

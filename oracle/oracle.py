@@ -349,6 +349,11 @@ class OracleMpm:
             C.c_int(max_iters), C.byref(res), C.byref(lsa), C.byref(en))
         diag = np.zeros(6, self.real)
         self.L.orc_last_contact_diag(self._f(diag))
+        # one row per Newton iteration: alpha, E(0), E(alpha), sum |Dir|^2, DoFs, line-search evaluations, residual
+        log = np.zeros((min(int(it), 4096), 7), self.real)
+        self.L.orc_contact_iteration_log.restype = C.c_int
+        self.L.orc_contact_iteration_log(self._f(log), C.c_int(log.shape[0]))
+        self.contact_log = log.astype(np.float64)
         return dict(iterations=int(it), residual=float(res.value), line_search_avg=float(lsa.value),
                     energy=float(en.value), alpha=float(diag[0]), E0=float(diag[1]), E1=float(diag[2]),
                     norm_dir_sq=float(diag[3]), dofs=float(diag[4]), ls_last=int(diag[5]))

@@ -89,11 +89,15 @@ def float_noise_of_a_substep(o, dt, bc=-1):
 
 
 # |engine - float oracle| allowed on a one-substep velocity comparison, in units of the MEASURED float noise of that
-# substep (float vs double build of the oracle), where that exceeds 1e-5 of max|v|.  Round 5: the engine's default
-# arithmetic is the correctly rounded one (mpm_set_fast_math off), and with it 2 noises suffice on every parity scene
-# (rounds 3 - 4, fast math: 6); on the scenes that move at O(1 m/s) -- the 256^3 scene, the bagging and the
-# material-friction scenes -- the floor is then BELOW 1e-5 of max|v| and north_star's plain tolerance is what is tested.
-NOISE_FLOOR = 2.0
+# substep (max over the particles of |float oracle - double oracle|), where that exceeds 1e-5 of max|v|.  By the triangle
+# inequality engine and float oracle are within (1 + k) noises of each other when the engine is within k noises of the
+# double build; tests/test_precision_gpu.py REQUIRES k <= 2 field by field on configs 1 and 2 (60k and 1M particles) and
+# finds 0.5 - 1.4; on the parity scenes of a few thousand particles the maxima of two noise fields spread further.
+# Measured with the correctly rounded default of round 5: the worst scene (64^3, four pin spheres, max|v| = 0.14 m/s) 3.03
+# noises, every other one below 2.6 -- hence 4 (rounds 3 - 4, fast math the only arithmetic: 4.3 measured, 6 allowed).  On
+# the scenes that move at O(1 m/s) -- the 256^3 scene, the bagging and the material-friction scenes -- the floor is BELOW
+# 1e-5 of max|v| and north_star's plain tolerance is what is tested (natural_scales()["floor_decides"]).
+NOISE_FLOOR = 4.0
 NOISE_FLOOR_FAST_MATH = 6.0
 
 

@@ -1,0 +1,203 @@
+"""The contact path without host round trips (the reference: deformable_driver.h:244-258 calling
+cuda_mpm_solver.cu:185-621, which reads every position back, builds the pairs on the host, uploads them and then
+synchronises >= 3 times per Newton iteration).
+
+* pairs counted on the device and LEFT counted there (mpm_generate_contact_pairs without a count): the solve gives bit
+  for bit what it gives with the count read back;
+* more pairs than the buffers hold: nothing is solved on a truncated list -- the solve refuses itself on the device, the
+  host grows the buffers, makes the pairs again and repeats; the result is that of buffers that were large enough;
+* a settled scene, whose pair list repeats from substep to substep: the previous solve's sorted order, per-cell runs and
+  node list are reused (verified on the device, entry by entry); results equal to the bit those of the full set-up; a
+  list that changes after a repeat is caught on the device and the solve repeated with the full set-up."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+DT, MU, K, D = 2e-4, 1.0, 1e6, 1e-5      # config 3's parameters (mpm_bagging.cc:9,15-17)
+Z_FLOOR = 0.5
+
+
+def _engine(env=None, sheets=None, bodies=1):
+    from drake_amd import GpuMpm, scenes
+    # (deterministic from Finalize's own first sort on: two engines then agree to the bit, and a difference between two
+    # of them is a difference between the paths under test)
+    env = dict(env or {}, MPM_DETERMINISTIC="1")
+    old = {k: os.environ.get(k) for k in env}
+    os.environ.update(env)
+    try:
+        g = GpuMpm(6)     # (environment switches are read per handle, at mpm_create)
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    scenes.populate(g, [(p.copy(), v.copy(), i.copy()) for p, v, i in sheets])
+    g.reallocate_external_bodies(bodies)
+    return g
+
+
+def _pressed_stack():
+    """four sheets, the lowest two below the floor, moving down: contacts from the first substep on"""
+    from drake_amd import scenes
+    sheets = scenes.cloth_stack(4, 40, 6, z0=Z_FLOOR - 0.012, side=0.3, seed=21, vel_amp=0.05)
+    for pos, vel, idx in sheets:
+        vel[:, 2] -= 0.3
+    return sheets
+
+
+def _coupled(g, floor, n, want_count):
+    out = []
+    for _ in range(n):
+        g.rebuild_mapping(False)
+        g.calc_fem_state_and_force(DT)
+        g.particle_to_grid(DT)
+        g.update_grid(-1)
+        cnt = g.generate_contact_pairs(floor, want_count=want_count)
+        r = g.update_contact(DT, MU, K, D)
+        if want_count:
+            assert cnt == r["contacts"]
+        g.grid_to_particle(DT)
+        out.append(r)
+    g.gpu_sync()
+    return out
+
+
+def _state(g):
+    from drake_amd import ARR as A
+    tau, f = g.external_body_force_to_host()
+    return dict(pos=g.download(A.POSITIONS), vel=g.download(A.VELOCITIES), F=g.download(A.DEFORMATION_GRADIENTS), tau=tau, f=f)
+
+
+def _same(a, b):
+    """particle state to the bit; the per-body impulses to rounding (k_ct_impulse adds them with float atomics, in LDS and
+    then per body: the one sum of the contact path whose order is not fixed -- as in the reference,
+    cuda_mpm_kernels.cuh:1616-1658)"""
+    for k in ("pos", "vel", "F"):
+        assert np.array_equal(a[k], b[k]), k
+    for k in ("tau", "f"):
+        np.testing.assert_allclose(a[k], b[k], rtol=2e-5, atol=1e-6 * float(np.abs(b[k]).max()), err_msg=k)
+
+
+def _rows(rs, *keys):
+    """per-substep results as an array (NaN residuals -- no DoF, as in the reference -- compare equal)"""
+    return np.array([[float(r[k]) for k in keys] for r in rs])
+
+
+def _same_rows(ra, rb, *keys):
+    assert np.array_equal(_rows(ra, *keys), _rows(rb, *keys), equal_nan=True), (_rows(ra, *keys), _rows(rb, *keys))
+
+
+def test_pairs_left_counted_on_the_device_give_the_same_solve():
+    from drake_amd import Collider
+    floor = [Collider(0, body=0, p_WB=(0.5, 0.5, Z_FLOOR))]
+    sheets = _pressed_stack()
+    a, b = _engine({"MPM_CT_NO_REUSE": "1"}, sheets), _engine({"MPM_CT_NO_REUSE": "1"}, sheets)
+    ra, rb = _coupled(a, floor, 6, True), _coupled(b, floor, 6, False)
+    _same_rows(ra, rb, "iterations", "contacts", "residual")
+    assert ra[0]["contacts"] > 500
+    _same(_state(a), _state(b))
+    # the pairs themselves, read back afterwards, are the ones the counted call produced
+    a.rebuild_mapping(False); b.rebuild_mapping(False)
+    for g in (a, b):
+        g.calc_fem_state_and_force(DT); g.particle_to_grid(DT); g.update_grid(-1)
+    na = a.generate_contact_pairs(floor)
+    b.generate_contact_pairs(floor, want_count=False)
+    pa, pb = a.download_contact_pairs(), b.download_contact_pairs()
+    assert b.contact_pair_count() == na
+    for x, y in zip(pa, pb):
+        assert np.array_equal(x, y)
+
+
+def test_more_pairs_than_the_buffers_hold_refuses_the_solve_and_repeats_it():
+    from drake_amd import Collider
+    floor = [Collider(0, body=0, p_WB=(0.5, 0.5, Z_FLOOR))]
+    sheets = _pressed_stack()
+    big = _engine({"MPM_CT_NO_REUSE": "1", "MPM_CT_INITIAL_CAPACITY": "100000"}, sheets)
+    small = _engine({"MPM_CT_NO_REUSE": "1", "MPM_CT_INITIAL_CAPACITY": "100"}, sheets)
+    rb, rs = _coupled(big, floor, 5, False), _coupled(small, floor, 5, False)
+    assert rb[0]["contacts"] > 500
+    cb, cs = big.contact_counters(), small.contact_counters()
+    assert cb["repeated_overflow"] == 0 and cs["repeated_overflow"] >= 1, (cb, cs)
+    _same_rows(rb, rs, "iterations", "contacts", "residual")
+    _same(_state(big), _state(small))
+    # ... and with the count read back at once (the overflow is then found by the read-back, before any solve)
+    small2 = _engine({"MPM_CT_NO_REUSE": "1", "MPM_CT_INITIAL_CAPACITY": "100"}, sheets)
+    rs2 = _coupled(small2, floor, 5, True)
+    assert small2.contact_counters()["repeated_overflow"] >= 1
+    _same_rows(rb, rs2, "iterations", "contacts")
+    _same(_state(big), _state(small2))
+
+
+def _resting_sheet():
+    """one flat sheet a little below the floor, at rest: every particle is in contact and stays there for many substeps
+    (the list of pairs repeats); a second sheet falls onto it later and changes the list"""
+    from drake_amd import scenes
+    low = scenes.cloth_stack(1, 36, 6, z0=Z_FLOOR - 0.0015, side=0.3, seed=5, vel_amp=0.0)
+    high = scenes.cloth_stack(1, 36, 6, z0=Z_FLOOR + 0.004, side=0.3, seed=6, vel_amp=0.0)
+    for pos, vel, idx in high:
+        vel[:, 2] -= 1.0
+    return low + high
+
+
+def test_a_repeating_pair_list_reuses_the_setup_and_a_change_is_caught_on_the_device():
+    from drake_amd import Collider
+    floor = [Collider(0, body=0, p_WB=(0.5, 0.5, Z_FLOOR))]
+    sheets = _resting_sheet()
+    full, fast = _engine({"MPM_CT_NO_REUSE": "1"}, sheets), _engine(None, sheets)
+    steps = 40
+    rf, rr = _coupled(full, floor, steps, False), _coupled(fast, floor, steps, False)
+    cf, cr = full.contact_counters(), fast.contact_counters()
+    print("contact counters: full set-up", cf, "with reuse", cr, "contacts", [r["contacts"] for r in rr][::4])
+    assert cf["reused"] == 0 and cf["refused_stale"] == 0
+    assert cr["reused"] >= 5, cr              # the list did repeat, and the repeats ran on the reused set-up
+    assert cr["refused_stale"] >= 1, cr       # ... and a guess was wrong at least once (the second sheet arriving)
+    assert len({r["contacts"] for r in rr}) > 1
+    _same_rows(rf, rr, "iterations", "contacts", "residual")
+    assert any(r["setup_reused"] for r in rr) and not any(r["setup_reused"] for r in rf)
+    _same(_state(full), _state(fast))
+
+
+def test_uploaded_pairs_go_through_the_same_paths():
+    """CopyContactPairs (host-made pairs, the reference's route): the count is the host's, the set-up reuse and the mailbox
+    are the same; a repeated identical hand-over is recognised as unchanged."""
+    from drake_amd import ARR as A
+    sheets = _resting_sheet()[:1]
+    g, h = _engine(None, sheets), _engine({"MPM_CT_NO_REUSE": "1"}, sheets)
+    res = {}
+    for e in (g, h):
+        rs = []
+        for s in range(6):
+            e.rebuild_mapping(False); e.calc_fem_state_and_force(DT); e.particle_to_grid(DT); e.update_grid(-1)
+            pos = e.sync_particle_state_to_cpu()
+            idx = np.nonzero(pos[:, 2] < Z_FLOOR)[0].astype(np.uint32)
+            n = idx.size
+            e.copy_contact_pairs(idx, np.zeros(n, np.uint32), (pos[idx, 2] - Z_FLOOR).astype(np.float32),
+                                 np.tile(np.array([0, 0, -1], np.float32), (n, 1)), pos[idx].astype(np.float32),
+                                 np.zeros((n, 3), np.float32), np.zeros((n, 3), np.float32))
+            rs.append(e.update_contact(DT, MU, K, D))
+            e.grid_to_particle(DT)
+        e.gpu_sync()
+        res[e] = rs
+    assert g.contact_counters()["reused"] >= 2, g.contact_counters()
+    _same_rows(res[g], res[h], "iterations", "contacts", "residual")
+    _same(_state(g), _state(h))
+
+
+def test_coupled_substeps_in_one_call_equal_the_seven_calls():
+    """mpm_run_coupled_substeps (the loop body of deformable_driver.h:240-258, n times): bit for bit the state, the
+    impulses and the per-substep iteration counts of the reference's seven calls per substep -- through a repeating pair
+    list, a changing one, and no contacts at all."""
+    from drake_amd import Collider
+    floor = [Collider(0, body=0, p_WB=(0.5, 0.5, Z_FLOOR))]
+    sheets = _resting_sheet()
+    a, b = _engine(None, sheets), _engine(None, sheets)
+    ra = _coupled(a, floor, 30, False)
+    rb = b.run_coupled_substeps(12, DT, floor, MU, K, D) + b.run_coupled_substeps(18, DT, floor, MU, K, D)
+    b.gpu_sync()
+    _same_rows(ra, rb, "iterations", "contacts", "residual", "setup_reused")
+    assert any(r["contacts"] == 0 for r in rb) and any(r["setup_reused"] for r in rb)
+    _same(_state(a), _state(b))
+    assert a.stats()["error_flags"] == 0 and b.stats()["error_flags"] == 0
