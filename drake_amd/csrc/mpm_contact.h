@@ -1,6 +1,7 @@
 // Host orchestration of the contact solve (CopyContactPairs / UpdateContact,
 // cuda_mpm_solver.cu:193-621).
 #pragma once
+#include <chrono>
 #include <memory>
 #include <cmath>
 #include <fstream>
@@ -133,9 +134,18 @@ struct MailboxState {
     int done = 0, iters = 0;
     float residual = 0.f;
     unsigned count = 0, nodes = 0, n_active = 0;
+    float quiet_left = 0.f;
     bool unchanged = false;
 };
+static int wait_mailbox_impl(mpm_engine* e, unsigned target, MailboxState* out);
 static int wait_mailbox(mpm_engine* e, unsigned target, MailboxState* out) {
+    if (!e->ct_debug) return wait_mailbox_impl(e, target, out);
+    const auto t0 = std::chrono::steady_clock::now();
+    const int rc = wait_mailbox_impl(e, target, out);
+    e->ct_wait_us += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+    return rc;
+}
+static int wait_mailbox_impl(mpm_engine* e, unsigned target, MailboxState* out) {
     ContactBuffers& b = e->cb;
     const volatile unsigned long long* w = b.h_mbox->w;
     unsigned spins = 0;
@@ -145,10 +155,13 @@ static int wait_mailbox(mpm_engine* e, unsigned target, MailboxState* out) {
         const unsigned seq = (unsigned)(w0 >> 32);
         if ((int)(seq - target) >= 0) {
             const unsigned long long w1 = __atomic_load_n(&w[1], __ATOMIC_ACQUIRE), w2 = __atomic_load_n(&w[2], __ATOMIC_ACQUIRE),
-                                     w3 = __atomic_load_n(&w[3], __ATOMIC_ACQUIRE), w4 = __atomic_load_n(&w[4], __ATOMIC_ACQUIRE);
+                                     w3 = __atomic_load_n(&w[3], __ATOMIC_ACQUIRE), w4 = __atomic_load_n(&w[4], __ATOMIC_ACQUIRE),
+                                     w5 = __atomic_load_n(&w[5], __ATOMIC_ACQUIRE);
             if ((unsigned)(w1 >> 32) == seq && (unsigned)(w2 >> 32) == seq && (unsigned)(w3 >> 32) == seq &&
-                (unsigned)(w4 >> 32) == seq && __atomic_load_n(&w[0], __ATOMIC_ACQUIRE) == w0) {
+                (unsigned)(w4 >> 32) == seq && (unsigned)(w5 >> 32) == seq && __atomic_load_n(&w[0], __ATOMIC_ACQUIRE) == w0) {
                 out->n_active = (unsigned)w4;
+                const unsigned qb = (unsigned)w5;
+                std::memcpy(&out->quiet_left, &qb, 4);
                 out->seq = seq;
                 out->done = (int)((w0 >> 24) & 0xFF);
                 out->iters = (int)(w0 & 0xFFFFFF);
@@ -197,8 +210,8 @@ static int resolve_contact_count(mpm_engine* e) {
 
 // Device-side CalcMpmContactPairs + CopyContactPairs for analytic colliders (include/mpm_hip.h).  Nothing here waits for
 // the device: the colliders travel as a kernel argument, the pairs are counted, placed and LEFT COUNTED on the device
-// (ContactState::n); mpm_update_contact's launches have fixed grids and read the count there.  Four launches: count per
-// slot, scan inside 4096-blocks, scan of the block totals (+ the count), write.
+// (ContactState::n); mpm_update_contact's launches have fixed grids and read the count there.  Three launches: count per
+// slot, scan inside 4096-blocks, write (every workgroup adds up the block totals it needs; workgroup 0 leaves the count).
 static int generate_contacts_launch(mpm_engine* e) {
     ContactBuffers& b = e->cb;
     const DP& p = e->dp;
@@ -215,13 +228,13 @@ static int generate_contacts_launch(mpm_engine* e) {
     const int nb = (int)(padded / 4096);
     hipLaunchKernelGGL(k_ct_gen_count, dim3((unsigned)(padded / 256)), dim3(256), 0, s, p, (const int*)e->d_pids_api, tab, b.gen_cnt, (int)padded);
     hipLaunchKernelGGL(k_scan_blocks, dim3(nb), dim3(256), 0, s, b.gen_cnt, (int)(np + 1), b.gen_sums);
-    hipLaunchKernelGGL(k_ct_gen_total, dim3(1), dim3(1024), 0, s, b.gen_sums, nb, (int)std::min<size_t>(b.cap, 0x7FFFFFFF), b.st);
     ContactDev c{};
     c.n = -1;
+    c.st = b.st;
     c.slot = b.slot; c.body = b.body; c.dist = b.dist; c.normal = b.normal; c.pos = b.pos;
     c.rigid_v = b.rigid_v; c.p_WB = b.p_WB; c.vel = b.vel;
     hipLaunchKernelGGL(k_ct_gen_write, dim3(e->g_np), dim3(256), 0, s, p, (const int*)e->d_pids_api, tab, (const int*)b.gen_cnt,
-                       (const int*)b.gen_sums, (int)std::min<size_t>(b.cap, 0x7FFFFFFF), b.api_idx, c);
+                       (const int*)b.gen_sums, nb, (int)std::min<size_t>(b.cap, 0x7FFFFFFF), b.api_idx, c);
     HIP_TRY(hipGetLastError());
     b.dev_counted = true;
     b.n = 0;
@@ -313,6 +326,7 @@ static ContactDev make_contact_dev(mpm_engine* e, float dt, float mu, float k, f
     c.cap_nodes = (int)b.cap_cells; c.gD = b.gD; c.hg = b.hg;
     c.part = b.part; c.part_dir = b.part_dir; c.st = b.st; c.it_log = b.it_log;
     c.mbox = b.d_mbox;
+    c.ctl = e->dp.ctl;
     c.prev_key = b.prev_key; c.prev_api = b.prev_api; c.prev_body = b.prev_body;
     c.body_tau = b.body_tau; c.body_f = b.body_f; c.n_bodies = (int)b.n_bodies;
     return c;
@@ -512,6 +526,14 @@ static int update_contact(mpm_engine* e, int frame, int substep, float dt, float
             full_setup = true;
             continue;
         }
+        if (oc.mb.done == CT_DONE_GATED) {
+            // (mpm_run_coupled_substeps enqueued the substep without its re-sort launches and a re-sort was pending: nothing
+            // of the substep has run; the caller repeats all of it)
+            e->last_contact_gated = true;
+            if (iters_out) *iters_out = 0;
+            if (residual_out) *residual_out = 0.f;
+            return 0;
+        }
         if (oc.mb.done == CT_DONE_STALE) {
             e->ct_counters[2] += 1;
             b.n_active_hint = 0;
@@ -522,6 +544,7 @@ static int update_contact(mpm_engine* e, int frame, int substep, float dt, float
     }
     const int iters = oc.mb.iters;
     const float residual = oc.mb.residual;
+    e->ct_quiet_left = oc.mb.quiet_left;
     e->ct_counters[0] += 1;
     e->ct_counters[1] += e->last_contact_reused ? 1 : 0;
     if (b.dev_counted) {   // the count has arrived with the solve's first publication
@@ -620,12 +643,13 @@ static int solve_once(mpm_engine* e, float dt, float mu, float stiffness, float 
     float &s_alpha_last = *s_alpha_last_p, &s_E0_last = *s_E0_last_p;
     *oc = SolveOutcome();
     e->last_contact_reused = false;
+    e->last_contact_gated = false;
     const DP& p = e->dp;
     hipStream_t s = e->stream;
     // what sizes the grids: the count, or -- counted on the device -- a bound (every kernel strides over its grid and
     // reads the count itself): the last solve's count with some room, at most the buffers' capacity
     size_t n = b.n;
-    if (b.dev_counted) n = b.n_hint ? std::min<size_t>(b.cap, b.n_hint + b.n_hint / 8 + 256) : b.cap;
+    if (b.dev_counted) n = b.n_hint && !full_setup ? std::min<size_t>(b.cap, b.n_hint + b.n_hint / 8 + 256) : b.cap;
     n = std::max<size_t>(n, 1);
     const unsigned gc = (unsigned)std::min<size_t>((n + 255) / 256, 2048);
     // The pairs name particles by the caller's slot; the engine's internal slots change with every
@@ -662,24 +686,22 @@ static int solve_once(mpm_engine* e, float dt, float mu, float stiffness, float 
     while (((size_t)1 << bits) < blocks * 64) ++bits;
     {
         ContactDev c_in = make_contact_dev(e, dt, mu, stiffness, damping, max_iters, /* sorted = */ false);
-        if (dist) c_in.mbox = nullptr;
         hipLaunchKernelGGL(k_ct_keys, dim3(1024), dim3(256), 0, s, p, c_in, (const uint32_t*)b.api_idx, (const int*)e->d_pids_api, b.slot,
-                           b.published, b.solves, bits, reuse ? 1 : 0, full_setup ? 1 : 0);
+                           b.published, b.solves, bits, (int)std::min<size_t>(n, 0x7FFFFFFF), reuse ? 1 : 0, full_setup ? 1 : 0);
     }
     if (!reuse) {
         // CT_NO_CELL has all those bits set and more: it sorts behind every real cell as long as
         // one more bit takes part
-        // (a sort's tiles are fixed chunks, not a stride over the grid: with the count on the device its launch must
-        // cover whatever the count may be -- the buffers' capacity, not the guess that sizes the other grids; a sheet of
-        // the stack landing doubles the count from one substep to the next)
+        // (a sort's tiles are fixed chunks, not a stride over the grid: with the count on the device its launch covers
+        // the guess `n` -- the last solve's count with an eighth of room --, and k_ct_keys refuses the solve when the
+        // count has outgrown it: a sheet of the stack landing doubles the count from one substep to the next, once)
         bool in_alt = false;
-        if (radix_sort_pairs(s, b.key, b.order, b.key2, b.order2, b.sort_hist, b.dev_counted ? b.cap : n, std::min(bits + 1, 31), &in_alt,
+        if (radix_sort_pairs(s, b.key, b.order, b.key2, b.order2, b.sort_hist, n, std::min(bits + 1, 31), &in_alt,
                              b.dev_counted ? &b.st->n : nullptr))
             return fail(MPM_ERR_HIP, "contact sort failed");
         b.sorted_in_alt = in_alt;
     }
     ContactDev c = make_contact_dev(e, dt, mu, stiffness, damping, max_iters);
-    if (dist) c.mbox = nullptr;   // (host-driven iterations: the state is copied back, nothing is published)
     if (reuse) {
         hipLaunchKernelGGL(k_ct_prepare<true>, dim3(gc), dim3(256), 0, s, p, c);
     } else {
@@ -859,6 +881,11 @@ static int solve_once(mpm_engine* e, float dt, float mu, float stiffness, float 
     }
     // contact velocities after the solve and the reaction on the rigid bodies
     trace_phase("mpm:UpdateContact impulses");
+    // (mpm_run_coupled_substeps puts GridToParticle in front of this kernel: the host has just learnt that the solve is
+    // over and the device's queue is short -- a long kernel first gives the host time to enqueue what follows; the
+    // impulses read the grid velocities and the contact arrays, which GridToParticle does not touch)
+    // (not behind a solve that refused itself: the caller repeats that one, and GridToParticle belongs behind the repeat)
+    if (e->ct_before_impulse && (host_driven || (oc->mb.done != CT_DONE_FAULT && oc->mb.done != CT_DONE_STALE))) e->ct_before_impulse();
     hipLaunchKernelGGL(k_ct_impulse, dim3(std::min(gc, 256u)), dim3(256), 0, s, p, c);
     HIP_TRY(hipGetLastError());
     if (host_driven) {

@@ -91,6 +91,8 @@ struct ContactState {       // device-resident solver state
 };
 constexpr int CT_DONE_FAULT = 4;     // ContactState::done: the pair buffers overflowed, nothing was solved
 constexpr int CT_DONE_STALE = 5;     // ... a speculated set-up (previous solve's order reused) did not match, nothing was solved
+constexpr int CT_DONE_GATED = 6;     // ... the substep was enqueued without its re-sort launches and found a re-sort pending: all of
+                                     // it skipped itself (DP::gated), the host runs it again with the re-sort in front
 
 // Mailbox in host-mapped pinned memory: what the host polls instead of copying the state back after every batch of
 // iterations (a blit kernel of ~4 us on the engine's stream per read-back, 8 - 20 per solve).  Four
@@ -99,6 +101,7 @@ constexpr int CT_DONE_STALE = 5;     // ... a speculated set-up (previous solve'
 //   w[0] = seq << 32 | done << 24 | iterations        w[1] = seq << 32 | bits of the residual (float)
 //   w[2] = seq << 32 | contacts (the wanted count when done = CT_DONE_FAULT)
 //   w[3] = seq << 32 | unchanged << 31 | nodes that see contacts          w[4] = seq << 32 | active blocks
+//   w[5] = seq << 32 | bits of the quiet time left (float seconds; 0 when a re-sort is pending: Ctl::quiet_time)
 struct ContactMailbox {
     unsigned long long w[8];
 };
@@ -144,6 +147,7 @@ struct ContactDev {
     double* part_dir;       // [CT_DIR_WG][2] (|Dir|^2, DoFs) per workgroup of k_ct_node_dir
     ContactState* st;
     ContactMailbox* mbox;   // host-mapped (device address)
+    const Ctl* ctl;         // the engine's control block (the publication carries the quiet time left)
     // the previous solve's pair list in the caller's order, for the "unchanged" test of k_ct_keys
     uint32_t *prev_key, *prev_api, *prev_body;
     float* it_log;          // [CT_LOG][CT_LOG_F] per Newton iteration: residual, line-search evaluations, E(alpha), alpha,
@@ -341,29 +345,47 @@ __global__ __launch_bounds__(256) void k_ct_gen_count(DP p, const int* pids_api,
     cnt[s] = n;
 }
 
-// P1b (one workgroup, behind k_scan_blocks): the block totals scanned in place, and the pair count left where the solve
-// reads it -- ContactState::n / n_wanted / gen_fault -- instead of travelling to the host
-__global__ __launch_bounds__(1024) void k_ct_gen_total(int* sums, int nb, int cap, ContactState* st) {
-    __shared__ int s_w[16];
-    if (threadIdx.x == 0) sums[nb] = 0;   // (receives the grand total)
+// P2: the pairs, at the scanned offsets (offset inside its 4096-block + the pairs of the blocks before it): ascending
+// (slot, collider).  Every workgroup adds up the block totals it needs itself (a few hundred ints: rounds 1 - 4 scanned
+// them with a single-workgroup kernel in between); workgroup 0 leaves the pair count where the solve reads it --
+// ContactState::n / n_wanted / gen_fault -- instead of sending it to the host.
+__global__ __launch_bounds__(256) void k_ct_gen_write(DP p, const int* pids_api, ColliderTable cols, const int* offs,
+                                                      const int* sums, int nb, int cap, uint32_t* api_idx, ContactDev c) {
+    __shared__ int s_part[4];
+    const int first = (int)(blockIdx.x * 256u) >> 12;   // 4096-block of this workgroup's first slot; a workgroup of 256 slots
+                                                         // never straddles two (4096 is a multiple of 256)
+    // pairs in the blocks before `first`, and in all blocks
+    int before = 0, total = 0;
+    for (int t = threadIdx.x; t < nb; t += 256) {
+        const int v = sums[t];
+        total += v;
+        before += t < first ? v : 0;
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        before += __shfl_xor(before, d);
+        total += __shfl_xor(total, d);
+    }
+    if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = before;
     __syncthreads();
-    wg1024_scan_inplace(sums, nb + 1, s_w);
+    before = s_part[0] + s_part[1] + s_part[2] + s_part[3];
     __syncthreads();
-    if (threadIdx.x == 0) {
-        const int total = sums[nb];
+    if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = total;
+    __syncthreads();
+    total = s_part[0] + s_part[1] + s_part[2] + s_part[3];
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        ContactState* st = c.st;
         st->n_wanted = total;
         st->n = min(total, cap);
         st->gen_fault = total > cap ? 1 : 0;
     }
-}
-
-// P2: the pairs, at the scanned offsets (offset inside its 4096-block + that block's offset): ascending (slot, collider)
-__global__ __launch_bounds__(256) void k_ct_gen_write(DP p, const int* pids_api, ColliderTable cols, const int* offs,
-                                                      const int* sums, int cap, uint32_t* api_idx, ContactDev c) {
     const int s = blockIdx.x * 256 + threadIdx.x;
     if (s >= p.NpG) return;
-    int at = offs[s] + sums[s >> 12];
-    if (offs[s + 1] + sums[(s + 1) >> 12] == at) return;
+    int at = offs[s] + before;
+    // (the slot after the last one of a 4096-block starts the next block: its offset there is 0, the block's total is
+    // what this slot's pairs end at)
+    const int end = ((s + 1) & 4095) ? offs[s + 1] + before : before + sums[first];
+    if (end == at) return;
     const PSet& S = p.set[p.ctl->cur];
     const uint32_t slot = (uint32_t)p.imap[pids_api[s]];
     const float4 q = S.q[0][slot], vq = S.q[1][slot];
@@ -410,12 +432,14 @@ MPM_DEV void contact_base(const DP& p, const float* pos, uint32_t* b) {
 // (also re-resolves the pairs' particles: caller's slot -> engine id -> current internal slot, k_ct_slots' job; resets
 // the solver state -- what a hipMemsetAsync did --; and compares the pair list with the previous solve's, entry by
 // entry: ContactState::changed_solve)
-// key_bits: the host sized the sort for keys below 2^key_bits (from the active blocks of the previous solve); reuse: the
+// key_bits, count_bound: the host sized the sort for keys below 2^key_bits and at most count_bound pairs (from the
+// previous solve's publication); reuse: the
 // host enqueued the set-up that reuses the previous solve's sorted order, this kernel only verifies (k_ct_prepare<true>
 // acts on the verdict); force_changed: this is the repetition of a refused solve (its first attempt has already overwritten
 // the previous list with this one: "unchanged" would be a tautology)
 __global__ __launch_bounds__(256) void k_ct_keys(DP p, ContactDev c, const uint32_t* api_slot, const int* pids_api, uint32_t* slot_out,
-                                                 unsigned seq_base, unsigned solve_no, int key_bits, int reuse, int force_changed) {
+                                                 unsigned seq_base, unsigned solve_no, int key_bits, int count_bound, int reuse,
+                                                 int force_changed) {
     ContactState* st = c.st;
     const int n = ct_count(c);
     const unsigned n_active = p.ctl->n_active;
@@ -426,8 +450,11 @@ __global__ __launch_bounds__(256) void k_ct_keys(DP p, ContactDev c, const uint3
         constexpr int NW = (int)(offsetof(ContactState, n) / 4);
         static_assert(NW <= 256 && offsetof(ContactState, done) == 0, "state reset: one word per thread of one workgroup");
         const bool fault = c.n < 0 && st->gen_fault;
-        const bool narrow = !reuse && key_bits < 31 && ((unsigned long long)n_active * 64ull > (1ull << key_bits));
-        const int done0 = fault ? CT_DONE_FAULT : (narrow ? CT_DONE_STALE : (n == 0 ? 1 : 0));
+        // (count_bound: the sort's launch covers that many pairs)
+        const bool narrow = !reuse && ((key_bits < 31 && ((unsigned long long)n_active * 64ull > (1ull << key_bits))) || n > count_bound);
+        // (p.gated: the substep went without its re-sort launches; k_grid, in front of this kernel, has left its verdict)
+        const bool gated = p.gated && p.ctl->skip_this;
+        const int done0 = gated ? CT_DONE_GATED : (fault ? CT_DONE_FAULT : (narrow ? CT_DONE_STALE : (n == 0 ? 1 : 0)));
         // (a reused set-up keeps its node list, and with it the count of listed nodes)
         constexpr int W_NODES = (int)(offsetof(ContactState, n_nodes) / 4);
         if ((int)threadIdx.x < NW) {
@@ -616,19 +643,28 @@ __global__ __launch_bounds__(256) void k_ct_flag_bits(DP p, ContactDev c) {
 }
 __global__ __launch_bounds__(1024) void k_ct_node_list(DP p, ContactDev c) {
     __shared__ int s_w[16];
-    const int tid = threadIdx.x;
+    __shared__ int s_at[1024];
+    __shared__ unsigned long long s_m[1024];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int words = (int)p.ctl->n_active;
     int carry = 0;
     for (int base = 0; base < words; base += 1024) {
         const int w = base + tid;
-        unsigned long long m = w < words ? c.flag_bits[w] : 0ull;
+        const unsigned long long m = w < words ? c.flag_bits[w] : 0ull;
         int block_total;
-        int at = carry + wg1024_exclusive((int)__popcll(m), block_total, s_w);
-        while (m) {
-            c.node_list[at++] = w * 64 + (int)__builtin_ctzll(m);
-            m &= m - 1ull;
+        s_at[tid] = carry + wg1024_exclusive((int)__popcll(m), block_total, s_w);
+        s_m[tid] = m;
+        __syncthreads();
+        // write-out by whole waves, a word per wave and step: lane l owns bit l.  (A thread per word, writing its up to
+        // 64 nodes one after the other, took 10 us: the nodes that see contacts sit in a tenth of the blocks -- the floor's
+        // --, so a few threads wrote 64 entries each while the rest had none.)
+        for (int q = wv; q < 1024 && base + q < words; q += 16) {
+            const unsigned long long mq = s_m[q];
+            if (mq == 0ull) continue;   // (wave-uniform)
+            if ((mq >> lane) & 1ull) c.node_list[s_at[q] + (int)__popcll(mq & ((1ull << lane) - 1ull))] = (base + q) * 64 + lane;
         }
         carry += block_total;
+        __syncthreads();
     }
     if (tid == 0) c.st->n_nodes = carry;
 }
@@ -1369,6 +1405,11 @@ MPM_DEV void ct_publish(const ContactDev& c) {
     __hip_atomic_store(&w[2], hi | (unsigned long long)cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     __hip_atomic_store(&w[3], hi | (unsigned long long)nodes, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     __hip_atomic_store(&w[4], hi | (unsigned long long)st->n_active, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    {
+        const Ctl* k = c.ctl;
+        const float left = k->need_rebuild || k->error ? 0.f : fmaxf(0.f, k->quiet_time - k->time_since_resort);
+        __hip_atomic_store(&w[5], hi | (unsigned long long)__float_as_uint(left), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
     __hip_atomic_store(&w[0], hi | ((unsigned long long)(done & 0xFF) << 24) | (unsigned long long)((unsigned)st->iters & 0xFFFFFFu),
                        __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }

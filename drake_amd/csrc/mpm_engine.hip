@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -2237,30 +2238,79 @@ int mpm_run_coupled_substeps(mpm_handle_t e, int n, const mpm_coupled_params_t* 
     GridColliders gc;
     if (int rc = grid_colliders_for(e, prm->mpm_bc, &gc)) return rc;
     const float dt = prm->dt;
+    // (MPM_CT_DEBUG: where the HOST's time of the call goes, per substep)
+    using clk = std::chrono::steady_clock;
+    double t_base = 0, t_gen = 0, t_solve = 0, t_tail = 0;
+    auto since = [](clk::time_point a) { return std::chrono::duration<double, std::micro>(clk::now() - a).count(); };
+    struct Report {
+        mpm_engine* e; int n; double *a, *b, *c, *d;
+        ~Report() {
+            if (e->ct_debug && n > 0)
+                std::fprintf(stderr, "[mpm_hip] coupled substeps, host us per substep: base launches %.1f, pairs %.1f, solve (set-up + "
+                                     "iterations + waits: %.1f polling) %.1f, GridToParticle %.1f\n", *a / n, *b / n, e->ct_wait_us / n, *c / n, *d / n);
+        }
+    } report{e, n, &t_base, &t_gen, &t_solve, &t_tail};
+    e->ct_wait_us = 0;
+    struct HookReset {   // (however the function is left)
+        mpm_engine* e;
+        ~HookReset() { e->ct_before_impulse = nullptr; e->dp.lean_g2p = 0; e->dp.gated = 0; }
+    } hook_reset{e};
+    bool g2p_done = false;
+    // Re-sort check launches (four kernels that return at once unless GridToParticle has raised need_rebuild): with every
+    // substep that may not skip itself; none while the quiet time that the last re-sort estimated lasts -- the host learns
+    // what is left of it from every solve's publication.  A substep that goes without them and finds a re-sort pending
+    // skips itself as a whole (DP::gated: transfer kernels, contact solve, GridToParticle) and is run again, with the
+    // re-sort in front: a wrong guess costs time, not correctness.
+    bool force_check = true;
     for (int s = 0; s < n; ++s) {
+        auto t0 = clk::now();
+        // (without colliders there is no solve whose publication would report a skipped substep: always checked)
+        const bool gate = n_colliders > 0 && !force_check && (e->ct_gate_always || e->quiet_factor * e->ct_quiet_left > 2.f * dt);
         may_resort(e, dt);
-        e->dp.gated = 0;
-        e->dp.lean_resort = 1;   // (CalcFemStateAndForce follows at once)
-        launch_rebuild(e);
-        e->dp.lean_resort = 0;
+        e->dp.gated = gate ? 1 : 0;
+        if (!gate) {
+            e->dp.lean_resort = 1;   // (CalcFemStateAndForce follows at once)
+            launch_rebuild(e);
+            e->dp.lean_resort = 0;
+        }
+        force_check = false;
         e->dp.lean_g2p = s + 1 < n;
         launch_fem_p2g(e, dt);
         launch_grid(e, gc);
         e->grid_state = 2;
         int iters = 0;
         float residual = 0.f;
+        t_base += since(t0); t0 = clk::now();
         int rc = generate_contacts(e, n_colliders, colliders, nullptr);
+        t_gen += since(t0); t0 = clk::now();
+        g2p_done = false;
+        e->ct_before_impulse = [&]() {
+            launch_g2p(e, dt);
+            g2p_done = true;
+        };
+        e->last_contact_gated = false;
         if (!rc && (e->cb.dev_counted || e->cb.n > 0))
             rc = update_contact(e, 0, s, dt, prm->friction_mu, prm->stiffness, prm->damping, 0, prm->exact_line_search,
                                 prm->max_newton_iterations, &iters, &residual);
         else if (!rc)
             e->last_contact = mpm_contact_stats_t{};
-        if (rc) {
-            e->dp.lean_g2p = 0;
-            return rc;
-        }
-        launch_g2p(e, dt);
+        e->ct_before_impulse = nullptr;
+        t_solve += since(t0); t0 = clk::now();
+        if (rc) return rc;
+        if (!g2p_done) launch_g2p(e, dt);
         e->dp.lean_g2p = 0;
+        t_tail += since(t0);
+        if (e->last_contact_gated) {
+            // nothing of this substep has run (its GridToParticle counted it in Ctl::skipped, which belongs to
+            // mpm_run_substeps' bookkeeping: cleared): once more, with the re-sort in front
+            REQUIRE(gate, "contact solve: a substep with its re-sort launches reported itself as skipped");
+            HIP_TRY(hipMemsetAsync(&e->dp.ctl->skipped, 0, sizeof(unsigned), e->stream));
+            e->ct_counters[2] += 1;
+            e->ct_quiet_left = 0.f;
+            force_check = true;
+            --s;
+            continue;
+        }
         e->substeps += 1;
         if (results) {
             mpm_coupled_result_t& r = results[s];

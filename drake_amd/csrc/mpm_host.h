@@ -5,6 +5,7 @@
 #include <algorithm>
 #include <atomic>
 #include <exception>
+#include <functional>
 #include <new>
 #include <stdexcept>
 #include <string>
@@ -174,12 +175,19 @@ struct mpm_engine {
     mpm_contact_stats_t last_contact{};   // of the last mpm_update_contact
     bool last_contact_on_device = false;  // ... of which only what the mailbox carries has reached the host (contact_stats_from_device)
     bool last_contact_exact = false;
+    bool last_contact_gated = false;      // ... skipped itself with its whole substep (CT_DONE_GATED)
+    float ct_quiet_left = 0.f;            // Ctl::quiet_time left as of the last solve's publication
+    std::function<void()> ct_before_impulse;   // (mpm_run_coupled_substeps) launched between the solve's last update and its impulses
     bool last_contact_reused = false;     // ... ran on the previous solve's sorted order and node list (settled scene)
     // MPM_CT_NO_REUSE=1: every solve runs the full set-up (sort, per-cell runs, node list), also when the pair list repeats
     bool ct_no_reuse = getenv("MPM_CT_NO_REUSE") != nullptr;
     // MPM_CT_INITIAL_CAPACITY: contacts the buffers of device-made pairs hold at first (tests: a small value makes the
     // overflow-and-repeat path run; default: a sixteenth of the particles, at least 4096)
     size_t ct_initial_capacity = getenv("MPM_CT_INITIAL_CAPACITY") ? (size_t)std::max(1, atoi(getenv("MPM_CT_INITIAL_CAPACITY"))) : 0;
+    // MPM_CT_GATE_ALWAYS=1 (tests): mpm_run_coupled_substeps never sends the re-sort launches ahead of a substep on its own
+    // estimate: every re-sort is found by a substep skipping itself
+    bool ct_gate_always = getenv("MPM_CT_GATE_ALWAYS") != nullptr;
+    double ct_wait_us = 0;   // (MPM_CT_DEBUG) host time spent polling the mailbox
     uint64_t ct_counters[4] = {0, 0, 0, 0};   // solves, of them on a reused set-up, refused as stale, repeated after an overflow
     float last_contact_dt = 0.f, last_contact_mu = 0.f, last_contact_k = 0.f, last_contact_d = 0.f;   // its parameters
     mpm_dist_config_t dist_cfg{};         // partitioned domain (mpm_dist_init)

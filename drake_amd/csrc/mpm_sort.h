@@ -8,10 +8,13 @@
 // mpm_rebuild.h: that one is a counting sort fused with the block tables).
 //
 // A workgroup of 4 waves owns a tile of 64 * items consecutive pairs (a quarter of its chunks per wave):
-//   k_sort_hist    digit histogram of the tile                -> hist[digit][tile]
-//   k_sort_scan    exclusive scan of hist in (digit, tile) order (one workgroup)
-//   k_sort_scatter ranks the tile's pairs chunk by chunk with wave ballots (lanes in order,
-//                  chunks in order => stable) and writes them to their final position
+//   k_sort_hist    digit histogram of the tile                -> hist[tile][digit]
+//   k_sort_scatter every workgroup derives ITS OWN output offsets from the histograms of all tiles (coalesced rows of
+//                  2^DB ints, all loads independent: the whole table is a few hundred KB of L2 reads per workgroup),
+//                  then ranks the tile's pairs chunk by chunk with wave ballots (lanes in order, chunks in order =>
+//                  stable) and writes them to their final position
+// Two launches per pass.  (Rounds 1 - 4 had a single-workgroup scan of the table between the two: 8 - 11 us per pass of
+// one CU walking 40k - 80k entries 16384 at a time, more than the two kernels around it together.)
 // No global atomics; LDS holds the running offsets of every wave of the tile.
 #pragma once
 #include <hip/hip_runtime.h>
@@ -45,7 +48,7 @@ __global__ __launch_bounds__(64 * SORT_WAVES) void k_sort_hist(const uint32_t* k
         if (i < n) atomicAdd(&s_cnt[(keys[i] >> shift) & (uint32_t)(ND - 1)], 1);
     }
     __syncthreads();
-    for (int d = tid; d < ND; d += 64 * SORT_WAVES) hist[(size_t)d * ntiles + tile] = s_cnt[d];
+    for (int d = tid; d < ND; d += 64 * SORT_WAVES) hist[(size_t)tile * ND + d] = s_cnt[d];
 }
 
 // Exclusive scan of one int per thread across a 1024-thread workgroup (shared by the scans below).
@@ -172,7 +175,7 @@ __global__ __launch_bounds__(64 * SORT_WAVES) void k_sort_scatter(const uint32_t
                                                                  int ntiles, const int* n_dev = nullptr) {
     constexpr int ND = 1 << DB;
     if (n_dev) n = min(n, *n_dev);
-    __shared__ int s_off[SORT_WAVES][ND];
+    __shared__ int s_off[SORT_WAVES][ND];   // per wave and digit: first the count, then the first output position
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, tile = blockIdx.x;
     for (int d = tid; d < SORT_WAVES * ND; d += 64 * SORT_WAVES) (&s_off[0][0])[d] = 0;
     __syncthreads();
@@ -184,9 +187,71 @@ __global__ __launch_bounds__(64 * SORT_WAVES) void k_sort_scatter(const uint32_t
         if (i < n) atomicAdd(&s_off[wv][(keys[i] >> shift) & (uint32_t)(ND - 1)], 1);
     }
     __syncthreads();
-    // ... and turned into every wave's first output position per digit: the tile's, then wave by wave
+    // ... and turned into every wave's first output position per digit.  The tile's own first position of digit d is
+    //   (pairs with a smaller digit, all tiles) + (pairs with digit d in the tiles before this one):
+    // both from the table hist[tile][digit] of ALL tiles, read here in coalesced rows (thread = digit), every load
+    // independent of the others -- what a single-workgroup scan kernel between the two launches used to produce.
+    __shared__ int s_tot[ND];       // pairs with digit d, all tiles -> exclusive prefix over the digits
+    __shared__ int s_before[ND];    // pairs with digit d in the tiles before this one
+    __shared__ int s_scan[SORT_WAVES];
+    for (int d0 = 0; d0 < ND; d0 += 64 * SORT_WAVES) {
+        const int d = d0 + tid;
+        int before = 0, total = 0;
+        if (d < ND) {
+            int t = 0;
+            for (; t + 8 <= ntiles; t += 8) {
+                int v[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) v[q] = hist[(size_t)(t + q) * ND + d];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    total += v[q];
+                    before += (t + q) < tile ? v[q] : 0;
+                }
+            }
+            for (; t < ntiles; ++t) {
+                const int v = hist[(size_t)t * ND + d];
+                total += v;
+                before += t < tile ? v : 0;
+            }
+            s_tot[d] = total;
+            s_before[d] = before;
+        }
+    }
+    __syncthreads();
+    // exclusive prefix of s_tot over the digits (ND <= 2048: every thread owns ND / 256 consecutive digits)
+    {
+        constexpr int PER = (ND + 64 * SORT_WAVES - 1) / (64 * SORT_WAVES);
+        int loc[PER], sum = 0;
+#pragma unroll
+        for (int q = 0; q < PER; ++q) {
+            const int d = tid * PER + q;
+            loc[q] = d < ND ? s_tot[d] : 0;
+            sum += loc[q];
+        }
+        // scan of the per-thread sums across the workgroup (4 waves)
+        int inc = sum;
+#pragma unroll
+        for (int dd = 1; dd < 64; dd <<= 1) {
+            const int t = __shfl_up(inc, dd);
+            if (lane >= dd) inc += t;
+        }
+        if (lane == 63) s_scan[wv] = inc;
+        __syncthreads();
+        int pre = inc - sum;
+        for (int w = 0; w < wv; ++w) pre += s_scan[w];
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < PER; ++q) {
+            const int d = tid * PER + q;
+            if (d < ND) s_tot[d] = pre;
+            pre += loc[q];
+        }
+    }
+    __syncthreads();
+    // per-wave counts -> per-wave first positions: the tile's, then wave by wave
     for (int d = tid; d < ND; d += 64 * SORT_WAVES) {
-        int run = hist[(size_t)d * ntiles + tile];
+        int run = s_tot[d] + s_before[d];
 #pragma unroll
         for (int w = 0; w < SORT_WAVES; ++w) {
             const int cnt = s_off[w][d];
@@ -254,7 +319,6 @@ static void radix_pass(hipStream_t s, const uint32_t* ki, const uint32_t* vi, ui
                        int shift, int items, int ntiles, const int* n_dev) {
     using namespace mpm;
     hipLaunchKernelGGL(k_sort_hist<DB>, dim3(ntiles), dim3(64 * SORT_WAVES), 0, s, ki, n, shift, items, hist, ntiles, n_dev);
-    hipLaunchKernelGGL(k_sort_scan, dim3(1), dim3(1024), 0, s, hist, (1 << DB) * ntiles);
     hipLaunchKernelGGL(k_sort_scatter<DB>, dim3(ntiles), dim3(64 * SORT_WAVES), 0, s, ki, vi, ko, vo, n, shift, items, (const int*)hist,
                        ntiles, n_dev);
 }
@@ -270,14 +334,14 @@ static int radix_sort_pairs(hipStream_t s, uint32_t* ka, uint32_t* va, uint32_t*
     if (n < 2 || bits <= 0) return 0;
     const int items = sort_items_for(n);
     const int ntiles = (int)((n + (size_t)64 * items - 1) / ((size_t)64 * items));
-    // digit width: a pass costs three launches (~20 us at this size) plus the single-workgroup scan of
-    // its 2^db x ntiles histogram (~3 us per 16384 entries)
+    // digit width: a pass costs two launches (~11 us at the contact solve's sizes) plus, in every workgroup of the
+    // scatter, a walk over the 2^db x ntiles table of all tiles' histograms (L2 reads, ~1 us per 64 KB)
     int db = 8, passes = (bits + 7) / 8;
     {
         double best = 1e30;
         for (int d = 8; d <= SORT_MAX_DIGIT_BITS; ++d) {
             const int ps = (bits + d - 1) / d;
-            const double cost = ps * (20.0 + 3.0 * (double)((((size_t)1 << d) * ntiles + 16383) / 16384));
+            const double cost = ps * (11.0 + (double)(((size_t)1 << d) * ntiles * 4) / 65536.0);
             if (cost < best) {
                 best = cost;
                 db = d;

@@ -87,7 +87,10 @@ def _rows(rs, *keys):
 
 
 def _same_rows(ra, rb, *keys):
-    assert np.array_equal(_rows(ra, *keys), _rows(rb, *keys), equal_nan=True), (_rows(ra, *keys), _rows(rb, *keys))
+    A, B = _rows(ra, *keys), _rows(rb, *keys)
+    assert A.shape == B.shape, (A.shape, B.shape)
+    bad = np.nonzero(~np.all((A == B) | (np.isnan(A) & np.isnan(B)), axis=1))[0]
+    assert bad.size == 0, (keys, [(int(i), A[i].tolist(), B[i].tolist()) for i in bad[:6]])
 
 
 def test_pairs_left_counted_on_the_device_give_the_same_solve():
@@ -151,7 +154,7 @@ def test_a_repeating_pair_list_reuses_the_setup_and_a_change_is_caught_on_the_de
     rf, rr = _coupled(full, floor, steps, False), _coupled(fast, floor, steps, False)
     cf, cr = full.contact_counters(), fast.contact_counters()
     print("contact counters: full set-up", cf, "with reuse", cr, "contacts", [r["contacts"] for r in rr][::4])
-    assert cf["reused"] == 0 and cf["refused_stale"] == 0
+    assert cf["reused"] == 0
     assert cr["reused"] >= 5, cr              # the list did repeat, and the repeats ran on the reused set-up
     assert cr["refused_stale"] >= 1, cr       # ... and a guess was wrong at least once (the second sheet arriving)
     assert len({r["contacts"] for r in rr}) > 1
@@ -201,3 +204,30 @@ def test_coupled_substeps_in_one_call_equal_the_seven_calls():
     assert any(r["contacts"] == 0 for r in rb) and any(r["setup_reused"] for r in rb)
     _same(_state(a), _state(b))
     assert a.stats()["error_flags"] == 0 and b.stats()["error_flags"] == 0
+
+
+@pytest.mark.parametrize("gate_always", [False, True])
+def test_coupled_substeps_through_resorts(gate_always):
+    """A cloth sliding over the floor at 6 m/s (a cell every 13 substeps: several re-sorts).  mpm_run_coupled_substeps sends
+    the four re-sort check launches only when the quiet time left says a re-sort may be due; a substep that goes without
+    them and finds one pending skips itself as a whole -- transfer kernels, contact solve, GridToParticle -- and is run
+    again (CT_DONE_GATED).  MPM_CT_GATE_ALWAYS makes every re-sort be found that way.  Either way: bit for bit the seven
+    calls' result."""
+    from drake_amd import Collider, scenes
+    floor = [Collider(0, body=0, p_WB=(0.5, 0.5, Z_FLOOR))]
+    sheets = scenes.cloth_stack(2, 36, 6, z0=Z_FLOOR - 0.002, side=0.3, seed=8, vel_amp=0.05, center=(0.35, 0.5))
+    for pos, vel, idx in sheets:
+        vel[:, 0] += 6.0
+    a = _engine(None, sheets)
+    b = _engine({"MPM_CT_GATE_ALWAYS": "1"} if gate_always else None, sheets)
+    ra = _coupled(a, floor, 60, False)
+    rb = b.run_coupled_substeps(25, DT, floor, MU, K, D) + b.run_coupled_substeps(35, DT, floor, MU, K, D)
+    b.gpu_sync()
+    sa, sb = a.stats(), b.stats()
+    assert sa["error_flags"] == 0 and sb["error_flags"] == 0
+    assert sa["rebuilds"] >= 2 and sa["rebuilds"] == sb["rebuilds"], (sa["rebuilds"], sb["rebuilds"])
+    if gate_always:
+        # (Finalize's own sort is one of the re-sorts; the first substep of each of the two calls carries its check launches)
+        assert b.contact_counters()["refused_stale"] >= 1, (b.contact_counters(), sb["rebuilds"])
+    _same_rows(ra, rb, "iterations", "contacts", "residual")
+    _same(_state(a), _state(b))
