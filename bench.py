@@ -26,8 +26,14 @@ import numpy as np  # noqa: E402
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
-# kernel names as rocprofv3 prints them, per phase of mpm_profile_substeps
-KERNEL_OF = dict(fem="mpm::k_fem", vforce="mpm::k_vforce", p2g="mpm::k_p2g<1, 0>", grid="mpm::k_grid<1>", g2p="mpm::k_g2p")
+def kernel_names(fast_math, partitioned):
+    """kernel names as rocprofv3 prints them, per phase of mpm_profile_substeps: the instantiations THIS run launches
+    (the table used to hard-code the single-engine, non-deterministic ones).  k_fem<FM>: 0 correctly rounded
+    (default), 1 mpm_set_fast_math; k_p2g<FORCES, EXACT>: the vertex forces from the vertex-side records (1) or, on a
+    partitioned domain, through the adjacency (2); EXACT = 1 with the fixed-point tile (MPM_DETERMINISTIC / MPM_P2G_FIXED)."""
+    exact = 1 if (os.environ.get("MPM_DETERMINISTIC") is not None or os.environ.get("MPM_P2G_FIXED") is not None) else 0
+    return dict(fem=f"mpm::k_fem<{1 if fast_math else 0}>", vforce="mpm::k_vforce", p2g=f"mpm::k_p2g<{2 if partitioned else 1}, {exact}>",
+                grid="mpm::k_grid<1>", g2p="mpm::k_g2p")
 
 
 def algorithmic_bytes(np_, nf, nv, ncells):
@@ -40,6 +46,23 @@ def algorithmic_bytes(np_, nf, nv, ncells):
     grid = 40 * ncells
     g2p = 72 * np_ + 12 * ncells
     return dict(fem=fem, vforce=vforce, p2g=p2g, grid=grid, g2p=g2p, total=fem + vforce + p2g + grid + g2p)
+
+
+def measured_sq(kernel, config):
+    """SQ counters per launch of `kernel` from the committed rocprofv3 PMC pass of this same command
+    (profiles/sq_counters.json, written by scripts/sq_summary.py), or None."""
+    path = os.path.join(ROOT, "profiles", "sq_counters.json")
+    try:
+        with open(path) as f:
+            t = json.load(f)
+        if t.get("config") != config:
+            return None
+        for rec in t["kernels"]:
+            if rec["kernel"] == kernel:
+                return rec["counters"]
+    except (OSError, KeyError, ValueError):
+        pass
+    return None
 
 
 def measured_traffic(kernel, config):
@@ -577,8 +600,10 @@ def main():
         for _ in range(frames):
             frame()
         el_r = time.perf_counter() - ts
+        st_r = g.stats()
+        assert st_r["error_flags"] == 0, st_r   # (GpuSync() reports no simulation errors: ADVICE r4)
         ref_pattern = dict(ms_per_step=el_r / (40 * frames) * 1e3, substeps_per_s=40 * frames / el_r, frames=frames,
-                           substeps_per_frame=40, warmup_substeps=20, rebuilds=g.stats()["rebuilds"] - r0,
+                           substeps_per_frame=40, warmup_substeps=20, rebuilds=st_r["rebuilds"] - r0,
                            calls="RebuildMapping(false), CalcFemStateAndForce, ParticleToGrid, UpdateGrid, GridToParticle per "
                                  "substep; GpuSync() per frame (cuda_mpm_test.cc:64-74)")
 
@@ -595,12 +620,15 @@ def main():
     g.gpu_sync()
     st = g.stats()
     ncells = 64 * st["touched_blocks"]
+    KERNEL_OF = kernel_names(g.fast_math, strong)
     # the particles this rank's kernels worked on (all of them unless the domain is partitioned)
     ab = algorithmic_bytes(st["active_faces"] + st["active_vertices"], st["active_faces"], st["active_vertices"], ncells)
+    # mpm_run_substeps / mpm_profile_substeps: k_p2g also sums the vertex forces of its work items (no k_vforce launch).
+    # Its algorithmic bytes stay the P2G row of SURVEY 8(d), 116 B per particle + 16 B per cell: the vertices' x, v and f
+    # are IN those 116 bytes (rounds 3 - 4 added the 36 B per vertex of the FEM row on top, which counted the
+    # vertices' x, v twice -- the PMC traffic came out BELOW the "algorithmic" figure).  The old figure is kept beside it.
+    p2g_with_vertex_row = ab["p2g"] + ab["vforce"]
     if world == 1:
-        # mpm_run_substeps / mpm_profile_substeps: k_p2g also gathers the vertex forces of its work items (no
-        # k_vforce launch), so its algorithmic bytes are both rows of SURVEY 8(d)
-        ab["p2g"] += ab["vforce"]
         ab["vforce"] = 0
     dom = max(KERNEL_OF, key=lambda k: phases[k])
     # An interval between two events holds the kernel AND the two event packets' own processing.  `achieved` / `frac`
@@ -617,8 +645,19 @@ def main():
     copies = 1 if (strong or world == 1) else world
     # (cells: rank 0's count; a partitioned domain has about `world` times as many, a 1% term)
     job_bytes = copies * algorithmic_bytes(npart, nf, nv, ncells * world if strong else ncells)["total"]
+    # which bound the dominant kernel sits on, from the committed SQ counters of this command: vector instructions per
+    # launch x 4 cycles (one wave's issue cost, MI355X_MICROARCH.md) / 1024 SIMDs / 2.4 GHz = the time the vector ALUs
+    # need for them if all 1024 issue all the time
+    sq = measured_sq(KERNEL_OF[dom], args.config) if world == 1 else None
+    valu_issue_ms = sq["SQ_INSTS_VALU"] * 4.0 / 1024.0 / 2.4e9 * 1e3 if sq and sq.get("SQ_INSTS_VALU") else None
     roofline = dict(bound="hbm", kernel=KERNEL_OF[dom], achieved=ach, peak=HBM_PEAK_GBS, unit="GB/s",
                     frac=ach / HBM_PEAK_GBS, traffic=measured_traffic(KERNEL_OF[dom], args.config) if world == 1 else None,
+                    valu_issue_ms=valu_issue_ms,
+                    valu_issue_note="SQ_INSTS_VALU of profiles/sq_counters.json (replayed) x 4 cycles / 1024 SIMDs / 2.4 GHz: "
+                                    "against kernel_ms it says how much of the kernel is vector-instruction issue -- k_p2g is "
+                                    "issue-bound on its ~800 vector instructions per 64 particles, not HBM-bound, although the "
+                                    "path's roofline is HBM's",
+                    algorithmic_bytes_per_launch_with_vertex_row=p2g_with_vertex_row if dom == "p2g" else None,
                     traffic_source="profiles/pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this "
                                    "command, collected by scripts/collect_profiles.sh and committed (replayed, not "
                                    "measured in this run)",
@@ -628,7 +667,9 @@ def main():
                     substep_achieved=job_bytes / (el / args.steps) / 1e9,
                     substep_frac=job_bytes / (el / args.steps) / 1e9 / (HBM_PEAK_GBS * world), phase_ms=phases,
                     phase_note="separate pass with HIP events around every phase (mpm_profile_substeps); it launches the "
-                               "re-sort kernels with every substep, the timed run with every fourth (gated substeps); "
+                               "re-sort kernels with every substep; the timed run launches none while the quiet time of the "
+                               "last re-sort lasts (the stats() call in front of the window re-arms it: normally no check "
+                               "launch in a 20-substep window), then with every fourth substep (gated substeps); "
                                "the vertex-force slot is empty (the vertex lanes of k_p2g do that work): its interval is "
                                "the cost of an event pair; phase_ms are raw intervals")
 
@@ -645,6 +686,9 @@ def main():
                    n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=el / args.steps * 1e3,
                    higher_is_better=True, scaling="strong" if strong or world == 1 and args.scaling == "strong" else "weak",
                    vs_baseline=None, dtype="f32", data="synthetic",
+                   arithmetic=("fast math (mpm_set_fast_math: hardware reciprocal / rsqrt + one Newton step in k_fem)" if g.fast_math
+                               else "correctly rounded divisions and square roots in k_fem (the default; MPM_FAST_MATH=1 / "
+                                    "mpm_set_fast_math select the approximations, 2.4 us per substep less)"),
                    config=dict(workload=f"{args.config}: {npart} particles ({nf} faces + {nv} vertices), "
                                         f"{1 << bits}^3 grid, corotated cloth, no contact, dt={dt}",
                                particles_total=npart * copies, particles_rank0=st["active_faces"] + st["active_vertices"],

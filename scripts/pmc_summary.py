@@ -64,7 +64,7 @@ def main():
             f.write(",".join(str(x) for x in r) + "\n")
     with open(os.path.join(ROOT, "profiles", "pmc_traffic.json"), "w") as f:
         json.dump(dict(config=config, source=f"profiles/{tag}_pmc_traffic.csv", correction="hbm = 2*FETCH_SIZE + WRITE_SIZE (KiB)",
-                       kernels=out), f, indent=1)
+                       head=os.environ.get("MPM_PROFILE_HEAD"), kernels=out), f, indent=1)
     for r in rows:
         print(r)
 

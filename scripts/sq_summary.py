@@ -39,6 +39,10 @@ def main():
         out.append(rec)
     with open(os.path.join(ROOT, "profiles", f"{tag}_sq_counters.json"), "w") as f:
         json.dump(out, f, indent=1)
+    # what bench.py replays into roofline.valu_issue_ms
+    config = sys.argv[3] if len(sys.argv) > 3 else "cloth_1m"
+    with open(os.path.join(ROOT, "profiles", "sq_counters.json"), "w") as f:
+        json.dump(dict(config=config, source=f"profiles/{tag}_sq_counters.json", head=os.environ.get("MPM_PROFILE_HEAD"), kernels=out), f, indent=1)
     for r in out:
         print(r["kernel"], {k: round(v) for k, v in r["counters"].items()})
 
