@@ -139,7 +139,7 @@ SYMBOLS = [
     "mpm_dist_get_geometry", "mpm_dist_set_headroom", "mpm_dist_migration_quiet_time", "mpm_dist_retune",
     "mpm_dist_plan_migration", "mpm_debug_throw", "mpm_debug_fail_alloc", "mpm_set_fast_math", "mpm_get_fast_math",
     "mpm_get_contact_pair_count", "mpm_download_contact_log", "mpm_last_contact_counts",
-    "mpm_debug_contact_counters", "mpm_run_coupled_substeps",
+    "mpm_debug_contact_counters", "mpm_run_coupled_substeps", "mpm_chain_direct_prepare", "mpm_chain_direct_connect",
 ]
 
 EXCHANGE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t)
@@ -246,6 +246,8 @@ def load_library(build: bool = True):
         "mpm_chain_init": [vp, vp, i, i, i, i, i, i, sz, i],
         "mpm_chain_substeps": [vp, i, f, i],
         "mpm_chain_destroy": [vp],
+        "mpm_chain_direct_prepare": [vp, vp],
+        "mpm_chain_direct_connect": [vp, vp, vp],
         "mpm_debug_counters": [vp, P(C.c_uint64), i],
         "mpm_download_array": [vp, i, vp, sz, P(sz)],
         "mpm_upload_particle_state": [vp, vp, vp, vp, vp, vp],
@@ -722,6 +724,10 @@ class GpuMpm:
     # ---- native chain: RCCL point-to-point on the engine's stream (mpm_chain_*) -----
     @staticmethod
     def chain_unique_id() -> bytes:
+        try:   # (PyTorch's RCCL and its dependencies are bound once per process: torch first, see csrc/mpm_chain.h)
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         buf = C.create_string_buffer(128)
         lib = load_library()
         rc = lib.mpm_chain_unique_id(buf)
@@ -729,11 +735,22 @@ class GpuMpm:
             raise MpmError(rc, (lib.mpm_last_error() or b"").decode())
         return buf.raw
 
-    def chain_init(self, unique_id: bytes, rank: int, world: int, cut_lo_block: int, cut_hi_block: int,
+    def chain_init(self, unique_id: bytes | None, rank: int, world: int, cut_lo_block: int, cut_hi_block: int,
                    pitch_blocks: int, zone_blocks: int = 2, capacity_blocks: int = 512, periodic: bool = False):
-        assert len(unique_id) == 128
-        self._ck(self.lib.mpm_chain_init(self.h, C.c_char_p(unique_id), rank, world, cut_lo_block, cut_hi_block,
-                                         pitch_blocks, zone_blocks, capacity_blocks, 1 if periodic else 0))
+        """unique_id = None: the geometry alone, no RCCL communicator (for the direct transport)"""
+        assert unique_id is None or len(unique_id) == 128
+        self._ck(self.lib.mpm_chain_init(self.h, C.c_char_p(unique_id) if unique_id is not None else None, rank, world,
+                                         cut_lo_block, cut_hi_block, pitch_blocks, zone_blocks, capacity_blocks,
+                                         1 if periodic else 0))
+
+    def chain_direct_prepare(self) -> bytes:
+        """allocates this rank's receive buffers of the direct halo exchange; returns their 64-byte IPC handle"""
+        buf = C.create_string_buffer(64)
+        self._ck(self.lib.mpm_chain_direct_prepare(self.h, buf))
+        return buf.raw
+
+    def chain_direct_connect(self, left: bytes | None, right: bytes | None):
+        self._ck(self.lib.mpm_chain_direct_connect(self.h, C.c_char_p(left) if left else None, C.c_char_p(right) if right else None))
 
     def chain_enable_migration(self, every: int, capacity_particles: int):
         self._ck(self.lib.mpm_chain_enable_migration(self.h, every, capacity_particles))

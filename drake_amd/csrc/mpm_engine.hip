@@ -1120,6 +1120,9 @@ int mpm_chain_destroy(mpm_handle_t e) try {
     for (void* q : {c.send_l, c.send_r, c.recv_l, c.recv_r, c.mig_send_l, c.mig_send_r, c.mig_recv_l, c.mig_recv_r,
                     (void*)c.mig_quiet_all})
         if (q) (void)hipFree(q);
+    for (int k = 0; k < 2; ++k)
+        if (c.peer_mapped[k] && c.peer_base[k] && !(k == 1 && c.peer_base[1] == c.peer_base[0])) (void)hipIpcCloseMemHandle(c.peer_base[k]);
+    if (c.direct_base) (void)hipFree(c.direct_base);
     c = mpm_engine::Chain();
     return 0;
 } MPM_CATCH_ALL
@@ -1154,10 +1157,11 @@ int mpm_chain_enable_migration(mpm_handle_t e, int every, size_t capacity_partic
 int mpm_chain_init(mpm_handle_t e, const char id[128], int rank, int world, int cut_lo_block, int cut_hi_block,
                    int pitch_blocks, int zone_blocks, size_t capacity_blocks, int periodic) try {
     READY(e);
-    REQUIRE(id && world >= 1 && rank >= 0 && rank < world, "bad rank / world");
+    REQUIRE(world >= 1 && rank >= 0 && rank < world, "bad rank / world");
     REQUIRE(zone_blocks >= 1 && capacity_blocks > 0 && capacity_blocks < (1u << 24), "bad halo geometry");
-    const rccl_rt::Api* a = rccl_rt::api();
-    if (!a) return fail(MPM_ERR_HIP, "RCCL (librccl.so) is not available in this process");
+    // (id == NULL: the geometry only, no RCCL communicator -- for the direct transport, mpm_chain_direct_prepare)
+    const rccl_rt::Api* a = id ? rccl_rt::api() : nullptr;
+    if (id && !a) return fail(MPM_ERR_HIP, "RCCL (librccl.so) is not available in this process");
     if (int rc = mpm_chain_destroy(e)) return rc;
     mpm_engine::Chain& c = e->chain;
     c.rank = rank; c.world = world; c.pitch = pitch_blocks; c.cap = capacity_blocks;
@@ -1171,17 +1175,93 @@ int mpm_chain_init(mpm_handle_t e, const char id[128], int rank, int world, int 
         HIP_TRY(hipMemsetAsync(*q, 0, c.bytes, e->stream));
     }
     HIP_TRY(hipStreamSynchronize(e->stream));
-    rccl_rt::UniqueId uid;
-    std::memcpy(uid.internal, id, rccl_rt::kIdBytes);
-    RCCL_TRY(a->comm_init_rank(&c.comm, world, uid, rank));
+    if (id) {
+        rccl_rt::UniqueId uid;
+        std::memcpy(uid.internal, id, rccl_rt::kIdBytes);
+        RCCL_TRY(a->comm_init_rank(&c.comm, world, uid, rank));
+    }
+    return 0;
+} MPM_CATCH_ALL
+
+// ---- direct halo: peer-to-peer stores + sequence flags -------------------------------------------
+static size_t direct_slot_bytes(const mpm_engine::Chain& c) { return (c.bytes + 255) & ~(size_t)255; }
+static size_t direct_total_bytes(const mpm_engine::Chain& c) { return 4 * direct_slot_bytes(c) + 256; }
+// [side 0 = from the left neighbour, 1 = from the right][parity] inside an allocation laid out as above
+static void* direct_buffer(const mpm_engine::Chain& c, void* base, int side, int parity) {
+    return (char*)base + (size_t)(side * 2 + parity) * direct_slot_bytes(c);
+}
+static uint32_t* direct_flag(const mpm_engine::Chain& c, void* base, int side) {
+    return reinterpret_cast<uint32_t*>((char*)base + 4 * direct_slot_bytes(c)) + side * 16;   // (64 bytes apart)
+}
+
+int mpm_chain_direct_prepare(mpm_handle_t e, char handle_out[64]) try {
+    READY(e);
+    mpm_engine::Chain& c = e->chain;
+    REQUIRE(handle_out, "null argument");
+    REQUIRE(c.cap > 0, "mpm_chain_init first (with a NULL id for the geometry alone)");
+    static_assert(sizeof(hipIpcMemHandle_t) == 64, "IPC handle size");
+    if (!c.direct_base) {
+        const size_t bytes = direct_total_bytes(c);
+        // fine-grained: a peer's stores into it are not shadowed by stale lines of this device's L2
+        if (hipExtMallocWithFlags(&c.direct_base, bytes, hipDeviceMallocFinegrained) != hipSuccess) {
+            (void)hipGetLastError();
+            HIP_TRY(hipMalloc(&c.direct_base, bytes));
+        }
+        HIP_TRY(hipMemsetAsync(c.direct_base, 0, bytes, e->stream));
+        HIP_TRY(hipStreamSynchronize(e->stream));
+    }
+    hipIpcMemHandle_t h;
+    HIP_TRY(hipIpcGetMemHandle(&h, c.direct_base));
+    std::memcpy(handle_out, &h, 64);
+    if (const char* t = getenv("MPM_HALO_TIMEOUT_S")) c.direct_timeout_s = std::max(.001f, (float)atof(t));
+    c.direct_mute = getenv("MPM_HALO_DEBUG_MUTE") != nullptr;   // (tests: this rank never signals)
+    return 0;
+} MPM_CATCH_ALL
+
+int mpm_chain_direct_connect(mpm_handle_t e, const char left_handle[64], const char right_handle[64]) try {
+    READY(e);
+    mpm_engine::Chain& c = e->chain;
+    REQUIRE(c.direct_base, "mpm_chain_direct_prepare first");
+    const char* hs[2] = {left_handle, right_handle};
+    const int nbr[2] = {c.left, c.right};
+    for (int k = 0; k < 2; ++k) {
+        if (c.peer_mapped[k] && c.peer_base[k] && !(k == 1 && c.peer_base[1] == c.peer_base[0])) (void)hipIpcCloseMemHandle(c.peer_base[k]);
+        c.peer_base[k] = nullptr;
+        c.peer_mapped[k] = false;
+    }
+    for (int k = 0; k < 2; ++k) {
+        if (nbr[k] < 0) continue;
+        if (nbr[k] == c.rank) {   // a ring of one: the neighbour is this rank, no mapping
+            c.peer_base[k] = c.direct_base;
+            continue;
+        }
+        REQUIRE(hs[k], "missing IPC handle of a neighbour");
+        if (k == 1 && c.left == c.right && c.peer_base[0]) {   // a ring of two: both neighbours are the same rank
+            c.peer_base[1] = c.peer_base[0];
+            c.peer_mapped[1] = c.peer_mapped[0];
+            continue;
+        }
+        hipIpcMemHandle_t h;
+        std::memcpy(&h, hs[k], 64);
+        const hipError_t err = hipIpcOpenMemHandle(&c.peer_base[k], h, hipIpcMemLazyEnablePeerAccess);
+        if (err != hipSuccess) {
+            (void)hipGetLastError();   // (not sticky: the engine stays usable, with RCCL or without neighbours)
+            c.peer_base[k] = nullptr;
+            return fail(MPM_ERR_HIP, std::string("hipIpcOpenMemHandle: ") + hipGetErrorString(err) +
+                                         " (the neighbour's buffers cannot be mapped: another node, or a handle of this very process)");
+        }
+        c.peer_mapped[k] = true;
+    }
+    c.direct = true;
     return 0;
 } MPM_CATCH_ALL
 
 int mpm_chain_substeps(mpm_handle_t e, int n, float dt, int bc) try {
     READY(e);
     mpm_engine::Chain& c = e->chain;
-    REQUIRE(c.comm, "mpm_chain_init first");
-    const rccl_rt::Api* a = rccl_rt::api();
+    REQUIRE(c.comm || c.direct, "mpm_chain_init first");
+    const rccl_rt::Api* a = c.comm ? rccl_rt::api() : nullptr;
+    REQUIRE(c.comm || c.mig_cap == 0, "migration needs the RCCL communicator (mpm_chain_init with an id)");
     struct LeanReset {   // (whatever way this function is left)
         mpm_engine* e;
         ~LeanReset() { e->chain_lean = 0; }
@@ -1255,6 +1335,39 @@ int mpm_chain_substeps(mpm_handle_t e, int n, float dt, int bc) try {
         c.mig_elapsed += dt;
         c.steps += 1;
         e->chain_lean = s + 1 < n;   // (reset below; the two calls are public entry points of their own as well)
+        if (c.direct && nz > 0) {
+            // DIRECT: the pack kernel stores into the neighbours' receive buffers of this substep's parity (two in
+            // rotation: a neighbour may still be reading the other one -- it cannot be reading this one: its read of
+            // substep s - 2 precedes its signal of s - 1, which this rank's update of s - 1 has waited for), a one-thread
+            // kernel raises the flags over there, a one-wave kernel waits for this rank's.
+            const int parity = (int)(c.steps & 1u);
+            const uint32_t seq = (uint32_t)c.steps;
+            void *dsb[2], *drb[2];
+            uint32_t *sig[2] = {nullptr, nullptr}, *mine[2] = {nullptr, nullptr};
+            int k = 0;
+            if (c.left >= 0) {   // my left zone goes to the left neighbour's "from the right" buffer
+                dsb[k] = direct_buffer(c, c.peer_base[0], 1, parity);
+                drb[k] = direct_buffer(c, c.direct_base, 0, parity);
+                sig[0] = direct_flag(c, c.peer_base[0], 1);
+                mine[0] = direct_flag(c, c.direct_base, 0);
+                ++k;
+            }
+            if (c.right >= 0) {
+                dsb[k] = direct_buffer(c, c.peer_base[1], 0, parity);
+                drb[k] = direct_buffer(c, c.direct_base, 1, parity);
+                sig[1] = direct_flag(c, c.peer_base[1], 0);
+                mine[1] = direct_flag(c, c.direct_base, 1);
+                ++k;
+            }
+            if (int rc = mpm_substep_begin_halo(e, dt, nz, lo, hi, sh, dsb, c.cap)) return rc;
+            if (!c.direct_mute) hipLaunchKernelGGL(k_halo_signal, dim3(1), dim3(64), 0, e->stream, sig[0], sig[1], seq);
+            hipLaunchKernelGGL(k_halo_wait, dim3(1), dim3(64), 0, e->stream, (const uint32_t*)mine[0], (const uint32_t*)mine[1], seq,
+                               (unsigned long long)((double)c.direct_timeout_s * 1e8), e->dp.ctl);
+            const int rc_end = mpm_substep_end_halo(e, dt, bc, nz, drb, c.cap);
+            e->chain_lean = 0;
+            if (rc_end) return rc_end;
+            continue;
+        }
         if (int rc = mpm_substep_begin_halo(e, dt, nz, lo, hi, sh, sb, c.cap)) {
             e->chain_lean = 0;
             return rc;

@@ -145,6 +145,16 @@ struct mpm_engine {
         size_t mig_cap = 0, mig_bytes = 0;
         void *mig_send_l = nullptr, *mig_send_r = nullptr, *mig_recv_l = nullptr, *mig_recv_r = nullptr;
         uint64_t steps = 0;
+        // DIRECT halo (mpm_chain_direct_*): the pack kernel stores the zone sums straight into the NEIGHBOUR's receive
+        // buffer (peer memory mapped through an IPC handle), a one-thread kernel raises a sequence flag over there, the
+        // receiver's one-workgroup kernel waits for it: no RCCL kernel, no staging copy on the per-substep path.
+        // One allocation per rank: [from-left parity 0 | from-left parity 1 | from-right 0 | from-right 1 | flags].
+        bool direct = false;
+        void* direct_base = nullptr;            // this rank's allocation (fine-grained device memory)
+        void* peer_base[2] = {nullptr, nullptr};   // the left / right neighbour's, as mapped here
+        bool peer_mapped[2] = {false, false};      // ... through hipIpcOpenMemHandle (else: this rank itself)
+        float direct_timeout_s = 5.f;
+        bool direct_mute = false;   // MPM_HALO_DEBUG_MUTE (tests): the signal kernel is left out
     } chain;
     bool halo_mid_done = false;   // mpm_substep_mid_halo ran in this substep
     int halo_nz = 0, halo_zlo[2] = {0, 0}, halo_zhi[2] = {0, 0};

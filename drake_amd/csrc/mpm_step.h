@@ -1350,6 +1350,37 @@ __global__ __launch_bounds__(256) void k_halo_pack2(DP p, HaloZones z, unsigned 
 struct HaloBufs {
     const uint32_t* buf[2];
 };
+
+// ---- DIRECT halo (peer-to-peer stores + sequence flags) ---------------------------------------------------------------
+// k_grid<0> of substep s has stored the zone sums into the neighbours' receive buffers (its halo_pbuf point into peer
+// memory).  This one-thread kernel, behind it on the same stream, tells the neighbours: the kernel boundary in front of
+// it has made those stores complete; the system-scope fence and release store order the flag behind them for an observer
+// on another device.  (Cross-device ordering cannot be observed on a box with one GPU: the protocol, not its memory
+// model, is what the one-GPU tests exercise -- DESIGN.md section 5.)
+__global__ void k_halo_signal(uint32_t* flag_a, uint32_t* flag_b, uint32_t seq) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    __threadfence_system();
+    if (flag_a) __hip_atomic_store(flag_a, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (flag_b) __hip_atomic_store(flag_b, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+// ... and this one, one wave, waits until both neighbours have said so for substep `seq` (sequence numbers only grow:
+// signed difference), BOUNDED: after `timeout_ticks` of the 100 MHz wall clock it gives up and raises ERR_HALO, so that a
+// neighbour that never arrives is an error code, not a hung device.  The kernel boundary behind it is the acquire for
+// k_grid<2>, which then reads the received sums (fine-grained memory: not held in this device's L2).
+__global__ void k_halo_wait(const uint32_t* flag_a, const uint32_t* flag_b, uint32_t seq, unsigned long long timeout_ticks, Ctl* ctl) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const unsigned long long t0 = wall_clock64();
+    while (true) {
+        const bool a = !flag_a || (int)(__hip_atomic_load(flag_a, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) - seq) >= 0;
+        const bool b = !flag_b || (int)(__hip_atomic_load(flag_b, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) - seq) >= 0;
+        if (a && b) return;
+        if (wall_clock64() - t0 > timeout_ticks) {
+            atomicOr(&ctl->error, ERR_HALO);
+            return;
+        }
+        __builtin_amdgcn_s_sleep(20);
+    }
+}
 // (a block lies in one zone only, so the two buffers of a launch touch disjoint cells)
 __global__ __launch_bounds__(256) void k_halo_add2(DP p, HaloBufs b, unsigned cap) {
     const uint32_t* buf = b.buf[blockIdx.y];

@@ -485,7 +485,8 @@ MPM_API int mpm_substep_begin_halo(mpm_handle_t h, float dt, int n_zones, const 
  * Rank r's local frame is shifted by r * pitch_blocks blocks along x; cut_lo / cut_hi are the local
  * x block indices of the left / right cut planes, zone_blocks the halo depth either side of a cut.
  * periodic != 0 closes the chain into a ring (rank world-1's right neighbour is rank 0): used to
- * exercise the transport with a single rank, whose neighbours are then itself. */
+ * exercise the transport with a single rank, whose neighbours are then itself.  id == NULL: the geometry only, without
+ * an RCCL communicator (for the direct transport below). */
 MPM_API int mpm_chain_unique_id(char id_out[128]);
 MPM_API int mpm_chain_init(mpm_handle_t h, const char id[128], int rank, int world, int cut_lo_block, int cut_hi_block,
                            int pitch_blocks, int zone_blocks, size_t capacity_blocks, int periodic);
@@ -495,6 +496,23 @@ MPM_API int mpm_chain_substeps(mpm_handle_t h, int n_substeps, float dt, int mpm
  * every = 0: when the ranks' common quiet-time estimate says so (mpm_dist_migration_quiet_time). */
 MPM_API int mpm_chain_enable_migration(mpm_handle_t h, int every, size_t capacity_particles);
 MPM_API int mpm_chain_destroy(mpm_handle_t h);
+/* DIRECT halo exchange (round 5; the reference has no multi-GPU path, settings.h:40): instead of RCCL send / recv -- a
+ * kernel of its own plus a staging copy, ~21 us of every chain substep on this stack -- the kernel that gathers a rank's
+ * zone sums stores them straight into the NEIGHBOUR's receive buffer (device memory of the peer, mapped through a HIP IPC
+ * handle; xGMI on one node), a one-thread kernel raises a sequence flag over there, and a one-wave kernel on the
+ * receiving side waits for it (bounded: MPM_HALO_TIMEOUT_S, default 5 s, then MPM_ERR_HALO) before the grid update reads
+ * the sums.  Receive buffers alternate between two parities, so nobody overwrites what a neighbour may still read.
+ *   mpm_chain_init(h, NULL, rank, world, ...)     the geometry alone (no RCCL communicator; or with an id: RCCL stays
+ *                                                 available for the rare exchanges -- migration, the contact solve)
+ *   mpm_chain_direct_prepare(h, handle_out)       allocates this rank's receive buffers, returns their IPC handle
+ *   (the caller hands every rank its neighbours' 64 bytes, by any means)
+ *   mpm_chain_direct_connect(h, left, right)      maps the neighbours' buffers (NULL where there is no neighbour; a rank
+ *                                                 that is its own neighbour -- a ring of one -- needs no handle)
+ * mpm_chain_substeps then uses the direct path for the per-substep halo.  Validated on one GPU only (two processes
+ * sharing it; the ring of one): the protocol, the indexing and the time-out -- NOT the ordering of peer stores across
+ * two devices, which this build has never run on. */
+MPM_API int mpm_chain_direct_prepare(mpm_handle_t h, char handle_out[64]);
+MPM_API int mpm_chain_direct_connect(mpm_handle_t h, const char left_handle[64], const char right_handle[64]);
 
 /* ---- multi-GPU, ONE domain cut into x slabs (strong scaling) ------------------------------
  * Every rank is created and finalised with the WHOLE scene (same mpm_add_qr_cloth calls: replicated
