@@ -362,6 +362,7 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     assert torch.cuda.is_available(), "bench.py needs a GPU (the engine has no CPU fallback)"
     # Multi-GPU transports, tried in this order (the JSON line names the one that was measured):
+    #   0. only with MPM_BENCH_TRANSPORT=direct, on top of 1: peer stores + flags for the per-substep halo (mpm_chain_direct_*),
     #   1. the library's own chain: RCCL send/recv on the engine's stream (mpm_chain_*),
     #   2. torch.distributed point-to-point over RCCL ("nccl" backend, drake_amd/dist.py),
     #   3. host-staged gloo (what the one-GPU tests exercise).
@@ -482,6 +483,33 @@ def main():
                 transport = "RCCL send/recv on the engine stream (mpm_chain)"
             else:
                 g.chain_destroy()
+            if os.environ.get("MPM_BENCH_TRANSPORT") == "direct" and (native or not strong):
+                # 0. (opt-in: never run across two devices) the per-substep halo as peer stores into the
+                # neighbours' IPC-mapped buffers + flags.  On top of the RCCL chain, which keeps the migrations; without
+                # RCCL (ranks sharing a GPU: a rehearsal) only where nothing migrates (weak scaling).  All ranks or none.
+                ok = True
+                try:
+                    if not native:
+                        g.chain_init(None, rank, world, **chain_args)
+                    handles = [None] * world
+                    dist.all_gather_object(handles, g.chain_direct_prepare())
+                    g.chain_direct_connect(handles[rank - 1] if rank > 0 else None, handles[rank + 1] if rank < world - 1 else None)
+                except Exception as exc:  # noqa: BLE001
+                    print(f"[bench] rank {rank}: direct halo exchange not available: {exc}", file=sys.stderr, flush=True)
+                    ok = False
+                if all_ok(ok):
+                    g.chain_substeps(2, dt, -1)   # (both parities; a neighbour that never signals is MPM_ERR_HALO after 5 s)
+                    g.gpu_sync()
+                    transport = ("peer stores into IPC-mapped buffers + flags (mpm_chain_direct)" +
+                                 ("; migrations over RCCL" if native else ", no RCCL"))
+                    native = True
+                elif native:
+                    try:
+                        g.chain_direct_connect(None, None)   # (off on every rank: one transport for all)
+                    except Exception:  # noqa: BLE001
+                        pass
+                else:
+                    g.chain_destroy()
 
         def python_chain(group):
             if strong:

@@ -1229,6 +1229,11 @@ int mpm_chain_direct_connect(mpm_handle_t e, const char left_handle[64], const c
         c.peer_base[k] = nullptr;
         c.peer_mapped[k] = false;
     }
+    const bool foreign = (c.left >= 0 && c.left != c.rank) || (c.right >= 0 && c.right != c.rank);
+    if (foreign && !left_handle && !right_handle) {   // switched off again: the chain is RCCL's (or nobody's) once more
+        c.direct = false;
+        return 0;
+    }
     for (int k = 0; k < 2; ++k) {
         if (nbr[k] < 0) continue;
         if (nbr[k] == c.rank) {   // a ring of one: the neighbour is this rank, no mapping

@@ -507,7 +507,10 @@ MPM_API int mpm_chain_destroy(mpm_handle_t h);
  *   mpm_chain_direct_prepare(h, handle_out)       allocates this rank's receive buffers, returns their IPC handle
  *   (the caller hands every rank its neighbours' 64 bytes, by any means)
  *   mpm_chain_direct_connect(h, left, right)      maps the neighbours' buffers (NULL where there is no neighbour; a rank
- *                                                 that is its own neighbour -- a ring of one -- needs no handle)
+ *                                                 that is its own neighbour -- a ring of one -- needs no handle);
+ *                                                 both NULL on a rank that HAS neighbours: the direct path is switched
+ *                                                 off again (what a caller does on every rank when one of them could
+ *                                                 not map its neighbour: all ranks must use the same transport)
  * mpm_chain_substeps then uses the direct path for the per-substep halo.  Validated on one GPU only (two processes
  * sharing it; the ring of one): the protocol, the indexing and the time-out -- NOT the ordering of peer stores across
  * two devices, which this build has never run on. */
