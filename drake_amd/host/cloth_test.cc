@@ -68,9 +68,11 @@ int main(int argc, char** argv) {
         solver.Dump(state, "/tmp/mpm_cloth_test.obj");
         state.Destroy();
     }
-    for (int device_pairs = 0; device_pairs < 2; ++device_pairs) {
+    double z_of_mode[3][2];
+    for (int device_pairs = 0; device_pairs < 3; ++device_pairs) {
         // cloth dropped on a rigid floor at z = 0.4 (config 3 in miniature): once with the contact pairs
-        // made on the host like DeformableDriver does, once with mpm_generate_contact_pairs
+        // made on the host like DeformableDriver does, once with mpm_generate_contact_pairs, once with the
+        // substeps of a plant step in one call (mpm_run_coupled_substeps)
         GpuMpmState<T> state;
         std::vector<Vec3<T>> pos, vel;
         std::vector<int> idx;
@@ -84,6 +86,7 @@ int main(int argc, char** argv) {
         cfg.contact_friction_mu = T(1.0);
         drake_amd::MpmDriver driver(&state, cfg);
         driver.device_contact_pairs = device_pairs != 0;
+        driver.coupled_batch = device_pairs == 2;
         drake_amd::RigidBody floor;
         floor.origin = {0, 0, T(0.4)};
         driver.bodies().push_back(floor);
@@ -98,12 +101,15 @@ int main(int argc, char** argv) {
         double zmin = 1, zmax = 0;
         for (const auto& q : std::get<0>(dumped)) { zmin = std::min<double>(zmin, q[2]); zmax = std::max<double>(zmax, q[2]); }
         std::printf("floor drop (%s pairs): z in [%.4f, %.4f], max contacts=%zu, peak force on floor z=%.4g, newton iterations=%d\n",
-                    device_pairs ? "device" : "host", zmin, zmax, max_contacts, fz, state.total_contact_iteration_count);
+                    device_pairs == 2 ? "device, batched" : device_pairs ? "device" : "host", zmin, zmax, max_contacts, fz, state.total_contact_iteration_count);
         CHECK(zmin > 0.39 && zmax < 0.42);   // caught by the floor, not tunnelling
         CHECK(max_contacts > 0);
         CHECK(fz < 0);                        // the cloth pushed the floor down
+        z_of_mode[device_pairs][0] = zmin; z_of_mode[device_pairs][1] = zmax;
         state.Destroy();
     }
+    // the batched call is the seven calls (bit for bit in deterministic mode: tests/test_contact_noroundtrip_gpu.py)
+    CHECK(std::fabs(z_of_mode[2][0] - z_of_mode[1][0]) < 1e-4 && std::fabs(z_of_mode[2][1] - z_of_mode[1][1]) < 1e-4);
     std::printf("cloth_test ok\n");
     return 0;
 }

@@ -86,6 +86,25 @@ class MpmDriver {
             if (origins.empty()) origins.push_back({0, 0, 0});
             drake::multibody::gmpm::InitalizeExternalContactForces(state_, origins);
         }
+        if (coupled_batch) {
+            // the whole loop below as ONE call per run of equal substeps (mpm_run_coupled_substeps): the host waits once
+            // per substep, for the word that says the solve is over
+            std::vector<mpm_collider_t> cols;
+            for (size_t b = 0; b < bodies_.size(); ++b) cols.push_back(bodies_[b].collider(uint32_t(b)));
+            while (dt_left > 0) {
+                const float ddt = std::min(dt_left, config_.substep_dt);
+                int n = 0;
+                while (dt_left > 0 && std::min(dt_left, config_.substep_dt) == ddt) { dt_left -= ddt; ++n; }
+                const auto r = solver_.RunCoupledSubsteps(state_, n, ddt, config_.mpm_bc, config_.contact_friction_mu,
+                                                          config_.contact_stiffness, config_.contact_damping,
+                                                          config_.exact_line_search, cols);
+                n_pairs_last_ = r.back().contacts;
+                substep += n;
+            }
+            drake::multibody::gmpm::FinalizeExternalContactForces(state_, dt);
+            last_contacts_ = n_pairs_last_;
+            return substep;
+        }
         MpmParticleContactPairs<float> pairs;
         while (dt_left > 0) {
             const float ddt = std::min(dt_left, config_.substep_dt);
@@ -118,6 +137,7 @@ class MpmDriver {
     }
     size_t last_contacts() const { return last_contacts_; }
     bool device_contact_pairs = false;  // true: mpm_generate_contact_pairs instead of the host loop
+    bool coupled_batch = false;         // true: mpm_run_coupled_substeps for the substeps of a plant step
 
   private:
     GpuMpmState<float>* state_;

@@ -177,6 +177,35 @@ class GpuMpmSolver {
         s->n_contacts_ = n;
         return n;
     }
+    // The same without the count: nothing at all travels to the host, UpdateContact works from the device's count
+    // (mpm_hip.h, mpm_generate_contact_pairs with n_out = NULL).
+    void GenerateContactPairsOnDevice(GpuMpmState<T>* s, const std::vector<mpm_collider_t>& colliders) const {
+        mpm_check(mpm_generate_contact_pairs(s->h_, colliders.size(), colliders.data(), nullptr));
+    }
+    size_t ContactPairCount(GpuMpmState<T>* s) const {
+        size_t n = 0;
+        mpm_check(mpm_get_contact_pair_count(s->h_, &n));
+        s->n_contacts_ = n;
+        return n;
+    }
+    // Extension: the body of DeformableDriver::CalcAbstractStates' loop (deformable_driver.h:240-258) n times in one
+    // call, for bodies with analytic signed distance fields: RebuildMapping, CalcFemStateAndForce, ParticleToGrid,
+    // UpdateGrid, pairs on the device, UpdateContact, GridToParticle.  Same results as the seven calls.
+    std::vector<mpm_coupled_result_t> RunCoupledSubsteps(GpuMpmState<T>* s, int n, const T& dt, int mpm_bc, const T& friction_mu,
+                                                         const T& stiffness, const T& damping, bool exact_line_search,
+                                                         const std::vector<mpm_collider_t>& colliders) const {
+        mpm_coupled_params_t p{};
+        p.dt = dt; p.mpm_bc = mpm_bc; p.friction_mu = friction_mu; p.stiffness = stiffness; p.damping = damping;
+        p.exact_line_search = exact_line_search ? 1 : 0;
+        p.max_newton_iterations = 0;
+        std::vector<mpm_coupled_result_t> r(n > 0 ? size_t(n) : 0);
+        mpm_check(mpm_run_coupled_substeps(s->h_, n, &p, colliders.size(), colliders.data(), r.data()));
+        for (const auto& q : r) s->total_contact_iteration_count += q.iterations;
+        if (!r.empty()) s->n_contacts_ = r.back().contacts;
+        return r;
+    }
+    // Extension: the arithmetic of CalcFemStateAndForce (correctly rounded by default, like the reference's build).
+    void SetFastMath(GpuMpmState<T>* s, bool on) const { mpm_check(mpm_set_fast_math(s->h_, on ? 1 : 0)); }
     void DownloadContactPairs(const GpuMpmState<T>& s, MpmParticleContactPairs<T>* c) const {
         const size_t n = s.n_contacts_;
         c->particle_in_contact_index.resize(n); c->non_mpm_id.resize(n); c->penetration_distance.resize(n);
