@@ -929,6 +929,26 @@ __global__ __launch_bounds__(256) void k_grid(DP p, GridColliders gc) {
     const int cx = cell >> 4, cy = (cell >> 2) & 3, cz = cell & 3;
     // the multi-GPU path packs halo buffers right after this kernel: reset their entry counters here
     if (MODE == 0 && blockIdx.x == 0 && tid < 2 && p.halo_hdr[tid]) p.halo_hdr[tid][0] = 0u;
+    if (MODE == 2 && p.halo_pn > 0 && tid < 64 && blockIdx.x * 64u < p.halo_pcap) {
+        // Diagnostics of the received lists (what k_halo_add2 reports for the public mpm_halo_add): the add
+        // below looks a zone block up in ITS zone's buffer, so a received block that lies in this rank's grid but outside
+        // the zone its buffer belongs to would be dropped without a trace.  The first few workgroups look at 64 ids each.
+        for (int k = 0; k < p.halo_pn; ++k) {
+            const uint32_t* buf = p.halo_pbuf[k];
+            const unsigned n = min(buf[0], p.halo_pcap);
+            for (unsigned e = blockIdx.x * 64u + (unsigned)tid; e < n; e += gridDim.x * 64u) {
+                const uint32_t id = buf[halo_ids_offset() + e];
+                if (id >= p.nblocks) {   // (no sender writes such an id: the buffer is not a halo buffer of this grid)
+                    atomicOr(&p.ctl->error, ERR_HALO);
+                    continue;
+                }
+                if (p.lut_act[id] < 0) continue;   // nothing of ours reaches that block
+                int hx, hy, hz;
+                block_coords(id, hx, hy, hz);
+                if (hx < p.halo_plo[k] || hx > p.halo_phi[k]) atomicOr(&p.ctl->error, ERR_CAPACITY);
+            }
+        }
+    }
     for (unsigned a = blockIdx.x * 4 + (tid >> 6); a < n_active; a += gridDim.x * 4) {
         if (MODE == 2 && p.halo_cls >= 0) {   // split update around the halo exchange (wave-uniform)
             int hx, hy, hz;

@@ -59,6 +59,47 @@ def test_ring_of_one_equals_device_copies():
     g.chain_destroy()
 
 
+def test_a_received_block_outside_its_zone_raises_a_flag():
+    """The grid update of a chain substep looks every zone block up in ITS zone's received buffer (the add folded into
+    k_grid<2>); a received list that names a block of this rank's grid outside that zone must not be dropped without a
+    trace (k_halo_add2 reported it, the folded add did not).  The left buffer gets the right buffer's ids."""
+    import torch
+    cut_lo, cut_hi, pitch, zone, cap = 6, 10, 4, 2, 256
+    MPM_ERR_CAPACITY_BIT, MPM_ERR_HALO_BIT = 2, 16   # (mpm_device.h: ERR_CAPACITY, ERR_HALO)
+
+    def run(tamper):
+        g = _engine()
+        nbytes = g.halo_buffer_bytes(cap)
+        dev = torch.device("cuda", 0)
+        send_l, send_r, recv_l, recv_r = (torch.zeros(nbytes, dtype=torch.uint8, device=dev) for _ in range(4))
+        zones = [(cut_lo - zone, cut_lo + zone - 1, +pitch), (cut_hi - zone, cut_hi + zone - 1, -pitch)]
+        za = g.halo_zone_args(zones, [send_l.data_ptr(), send_r.data_ptr()])
+        ra = g.halo_buffer_args([recv_l.data_ptr(), recv_r.data_ptr()])
+        stream = torch.cuda.Stream()
+        g.set_stream(stream.cuda_stream)
+        with torch.cuda.stream(stream):
+            g.substep_begin_halo(DT, za, cap)
+            recv_r.copy_(send_l, non_blocking=True)
+            recv_l.copy_(send_r, non_blocking=True)
+            if tamper == "zone":      # ids (and count) of the other zone's list: blocks 8..11 in the buffer of zone 4..7
+                words = 4 + cap
+                recv_l.view(torch.int32)[:words].copy_(recv_r.view(torch.int32)[:words])
+            elif tamper == "corrupt":  # an id no sender writes
+                recv_l.view(torch.int32)[4] = 0x7FFFFFF0
+            g.substep_end_halo(DT, -1, ra, cap)
+        try:
+            g.gpu_sync()
+        except Exception:  # noqa: BLE001  (the sticky flag is what is looked at)
+            pass
+        flags = g.stats()["error_flags"]
+        g.destroy()
+        return flags
+
+    assert run(None) == 0
+    assert run("zone") & MPM_ERR_CAPACITY_BIT
+    assert run("corrupt") & MPM_ERR_HALO_BIT
+
+
 def test_partitioned_exact_line_search_is_device_resident_over_rccl(monkeypatch):
     """UpdateContact with the exact line search on a partitioned engine whose transport is the native chain (VERDICT r3,
     item 7): the device-resident pattern of the single-GPU solve, with ncclAllReduce on the engine's stream between the two
