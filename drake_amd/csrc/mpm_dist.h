@@ -248,8 +248,8 @@ __global__ __launch_bounds__(256) void k_dist_roles(DP p, const int* pids_api, u
 }
 
 // mpm_dist_init: per-slot topology by original id for the particles this rank keeps, from the tables of the whole
-// scene that Finalize built (which are released afterwards).  A vertex with more than eight adjacent faces is not
-// supported in a partitioned domain (ERR_CAPACITY; cloth meshes have six).
+// scene that Finalize built (which are released afterwards -- except the adjacency of a mesh that has a vertex with more
+// than eight adjacent faces: that vertex's record is a mark, and its force is summed over the scene's adjacency).
 __global__ __launch_bounds__(256) void k_dist_build_topology(DP p) {
     const Ctl* c = p.ctl;
     const PSet& S = p.set[c->cur];
@@ -264,7 +264,11 @@ __global__ __launch_bounds__(256) void k_dist_build_topology(DP p) {
             int rec[8];
 #pragma unroll
             for (int q = 0; q < 8; ++q) rec[q] = e0 + q < e1 ? p.adj_fc[e0 + q] : -1;
-            if (e1 - e0 > 8) atomicOr(&p.ctl->error, ERR_CAPACITY);
+            if (e1 - e0 > 8) {   // the record holds eight: the mark sends this vertex to the scene's adjacency, which stays
+                rec[0] = -2;     // resident on every rank for such a mesh (dist_resize)
+#pragma unroll
+                for (int q = 1; q < 8; ++q) rec[q] = -1;
+            }
             p.vg[cs][0][slot - p.Nf] = make_int4(rec[0], rec[1], rec[2], rec[3]);
             p.vg[cs][1][slot - p.Nf] = make_int4(rec[4], rec[5], rec[6], rec[7]);
         }

@@ -1827,11 +1827,18 @@ static int dist_resize(mpm_engine* e, size_t new_nf, size_t new_nv, bool first) 
             e->dfree(t);
             p.idx_orig[d] = nullptr;
         }
-        int* a = const_cast<int*>(p.adj_off);
-        int* b = const_cast<int*>(p.adj_fc);
         float4* dm = const_cast<float4*>(p.dm_orig);
-        e->dfree(a); e->dfree(b); e->dfree(dm);
-        p.adj_off = nullptr; p.adj_fc = nullptr; p.dm_orig = nullptr;
+        e->dfree(dm);
+        p.dm_orig = nullptr;
+        if (e->max_valence <= 8) {
+            int* a = const_cast<int*>(p.adj_off);
+            int* b = const_cast<int*>(p.adj_fc);
+            e->dfree(a); e->dfree(b);
+            p.adj_off = nullptr; p.adj_fc = nullptr;
+        }
+        // (a mesh with a vertex of more than eight faces keeps the scene's adjacency -- 4 bytes per vertex and 12 per face
+        // on every rank: such a vertex's record holds a mark instead of face ids, and its force walks the adjacency by
+        // original id through the id -> slot map, wherever the vertex migrates: vertex_force_csr)
         e->dfree(p.VF);   // (a partitioned domain finds its vertex forces through va + G3: DP::VF)
         p.VF = nullptr;
     }
@@ -1861,9 +1868,6 @@ int mpm_dist_init(mpm_handle_t e, const mpm_dist_config_t* cfg) try {
     REQUIRE(!e->dp.dist.on, "mpm_dist_init called twice");
     REQUIRE(e->api_identity, "mpm_dist_init must precede RebuildMapping(sort = true)");
     const int nb = e->dp.nb;
-    // (known on the host since Finalize: refused before anything is allocated or launched -- ADVICE r4)
-    REQUIRE(e->max_valence <= 8, "mpm_dist_init: a vertex with more than eight adjacent faces is not supported in a "
-                                 "partitioned domain");
     REQUIRE(cfg->world >= 1 && cfg->rank >= 0 && cfg->rank < cfg->world, "bad rank / world");
     REQUIRE(cfg->own_lo_block >= 0 && cfg->own_lo_block < cfg->own_hi_block && cfg->own_hi_block <= nb,
             "bad slab: need 0 <= own_lo_block < own_hi_block <= blocks per axis");

@@ -690,6 +690,7 @@ __global__ __launch_bounds__(256) void k_rb_finish(DP p) {
                     rec[q] = fs < 0 ? -3 : fs * 3 + (fcs[q] & 3);
                 }
             }
+            if (fcs[0] == -2) rec[0] = -2;   // more than eight faces: the scene's adjacency (vertex_force_csr)
             D.va[0][j - p.Nf] = make_int4(rec[0], rec[1], rec[2], rec[3]);
             D.va[1][j - p.Nf] = make_int4(rec[4], rec[5], rec[6], rec[7]);
         }

@@ -534,8 +534,9 @@ MPM_API int mpm_chain_direct_connect(mpm_handle_t h, const char left_handle[64],
  * face that misses a corner vertex (mesh edge longer than ghost_margin_cells), raises MPM_ERR_HALO.
  * Arrays downloaded from a rank hold NaN / -1 for particles it does not have; mpm_dist_roles tells
  * which are owned (1), ghosts (2) or absent (0), per slot.  The reference has no multi-GPU path.
- * Limits: a vertex with more than eight adjacent faces is refused (MPM_ERR_INVALID: the per-slot
- * topology holds eight; cloth meshes have six).  After the call a rank's particle arrays are sized for
+ * Meshes: any valence.  The per-slot topology that migrates with a vertex holds eight (face, corner) ids (cloth meshes
+ * have six faces around a vertex); a mesh with a vertex of more keeps the scene's adjacency (4 bytes per vertex + 12 per
+ * face) on every rank, and such a vertex sums its force over it.  After the call a rank's particle arrays are sized for
  * slot_headroom x what it holds (default 1.5; MPM_DIST_HEADROOM, 0 = keep the whole scene's size); a rank whose share
  * outgrows that is re-allocated at the migration that would overflow it (the stream is idle there), up to
  * the whole scene's size. */

@@ -242,3 +242,45 @@ def test_no_shrink_keeps_the_whole_scene_size():
         st = c.e.stats()
         assert st["error_flags"] == 0
         assert st["face_slots"] == whole["face_slots"] and st["vertex_slots"] == whole["vertex_slots"], (st, whole)
+
+
+def test_vertex_with_more_than_eight_faces_crosses_a_cut():
+    """A partitioned domain keeps eight (face, corner) ids per vertex record; a vertex with more faces around it carries a
+    mark instead, and its force is summed over the scene's adjacency, which a mesh like that keeps resident on every rank
+    ("partitioned domains for general meshes": mpm_dist_init used to refuse such a mesh).  A fan of 12 faces
+    and a fan of 9 next to a regular sheet slide across the cut between two ranks -- the hubs migrate, their faces arrive
+    before and after them -- against a single engine."""
+    from drake_amd import ARR, GpuMpm, scenes
+    from tests.helpers import close
+    from tests.test_parity_gpu import _fan_sheet
+    bits, steps = 6, 48
+    dx = 1.0 / (1 << bits)
+
+    def sheets():
+        reg = scenes.cloth_stack(1, 24, bits, z0=0.5, side=0.2, seed=3, vel_amp=0.2, center=(0.42, 0.5))
+        out = list(reg) + [_fan_sheet(12, 0.9 * dx, (0.47, 0.45), 0.5 + 3 * dx, 5), _fan_sheet(9, 0.8 * dx, (0.45, 0.57), 0.5 + 3 * dx, 6),
+                           _fan_sheet(12, 0.9 * dx, (0.55, 0.5), 0.5 + 3 * dx, 7)]
+        for pos, vel, idx in out:
+            vel[:, 0] += 3.0      # 0.19 cells per substep: 9 cells over the run; the cut is at x = 0.5
+        return out
+
+    sh = sheets()
+    ref = _populate(GpuMpm(bits), sh)
+    ref.run_substeps(steps, DT, -1)
+    ref.gpu_sync()
+    assert ref.stats()["error_flags"] == 0
+    rp, rv, rF = ref.download(ARR.POSITIONS), ref.download(ARR.VELOCITIES), ref.download(ARR.DEFORMATION_GRADIENTS)
+    n, nf = ref.n_particles, ref.n_faces
+    geo = dict(cuts=[0, 8, 16], zone_blocks=2, ghost_cells=0, ghost_margin_cells=0, migrate_every=0)
+    roles0, w = _run_world(bits, sh, geo, steps, capacity_blocks=512, migrate_capacity=8192)
+    pos, vel, F, per_rank = _collect(w, roles0, n, nf)
+    # the first fan's hub (the vertex right behind the regular sheet's) started on rank 0 and ends on rank 1
+    hub = nf + 24 * 24
+    assert roles0[0][hub] == 1 and per_rank[1][0][hub] == 1, (roles0[0][hub], per_rank[1][0][hub])
+    assert w.migrations >= 4
+    # (the scene's adjacency stays on the ranks of such a mesh: part of scene_index_bytes)
+    assert per_rank[0][3]["scene_index_bytes"] > 4 * (n - nf) + 12 * nf
+    vs = max(float(np.abs(rv).max()), 1.0)
+    close(pos, rp, scale=1.0, rtol=1e-5, what="fan mesh across a cut: positions vs single engine")
+    close(vel, rv, scale=vs, rtol=1e-4, what="fan mesh across a cut: velocities vs single engine")
+    close(F, rF, scale=1.0, rtol=1e-4, what="fan mesh across a cut: F vs single engine")
