@@ -29,11 +29,12 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 def kernel_names(fast_math, partitioned):
     """kernel names as rocprofv3 prints them, per phase of mpm_profile_substeps: the instantiations THIS run launches
     (the table used to hard-code the single-engine, non-deterministic ones).  k_fem<FM>: 0 correctly rounded
-    (default), 1 mpm_set_fast_math; k_p2g<FORCES, EXACT>: the vertex forces from the vertex-side records (1) or, on a
-    partitioned domain, through the adjacency (2); EXACT = 1 with the fixed-point tile (MPM_DETERMINISTIC / MPM_P2G_FIXED)."""
+    (default), 1 mpm_set_fast_math; k_p2g<FORCES, EXACT>: the vertex forces from the vertex-side records (1: single and
+    partitioned domains alike since round 5); EXACT = 1 with the fixed-point tile (MPM_DETERMINISTIC / MPM_P2G_FIXED);
+    the grid update of a partitioned rank is two kernels (k_grid<0> before the exchange, k_grid<2> after it)."""
     exact = 1 if (os.environ.get("MPM_DETERMINISTIC") is not None or os.environ.get("MPM_P2G_FIXED") is not None) else 0
-    return dict(fem=f"mpm::k_fem<{1 if fast_math else 0}>", vforce="mpm::k_vforce", p2g=f"mpm::k_p2g<{2 if partitioned else 1}, {exact}>",
-                grid="mpm::k_grid<1>", g2p="mpm::k_g2p")
+    return dict(fem=f"mpm::k_fem<{1 if fast_math else 0}>", vforce="mpm::k_vforce", p2g=f"mpm::k_p2g<1, {exact}>",
+                grid="mpm::k_grid<2>" if partitioned else "mpm::k_grid<1>", g2p="mpm::k_g2p")
 
 
 def algorithmic_bytes(np_, nf, nv, ncells):

@@ -54,7 +54,6 @@ struct PSet {
     float4* fq[4];
     float* f8;
     float* c8;
-    int4* va[2];   // vertex (slot - Nf) -> up to 8 (face slot * 3 + corner) records, -1 = none, -2 in [0].x = use the CSR
 };
 
 MPM_DEV void unpack_C(const float4& q1, const float4& q2, const float4& q3, float* C) {
@@ -183,13 +182,13 @@ struct DP {
     // partitioned domain, per-rank topology (null otherwise): what a particle needs to find its mesh neighbours by
     // ORIGINAL id, kept per slot, moved by the re-sort and carried by the migration records -- no array of the size of
     // the whole scene's topology stays on a rank
-    int4* fg[2];           // [set][face slot] original ids of the three corner vertices
+    int4* fg[2];           // [set][face slot] original ids of the three corner vertices; .w = the corners' ranks (fq[3].x)
     int4* vg[2][2];        // [set][2][vertex slot - Nf] up to eight (original face id << 2 | corner), -1 = none
     float3* ta;            // faces: tau = a (x) b with a = vol*P[:,2] (12-byte records); b = F[:,2] is the first three
                            // floats of fq[0] (see pack_F)
     float3* G3;            // faces: G3[face slot * 3 + c] = force triple the face exerts on corner c (negated when
                            // applied); 12-byte records: 36 B written per face and one dwordx3 gather per adjacency
-    // Single-domain engines: the same triples where the VERTEX looks for them, VF[vf_entry(vertex slot - Nf, j) * 3 ..],
+    // The same triples where the VERTEX looks for them, VF[vf_entry(vertex slot - Nf, j) * 3 ..],
     // j = the rank of the face among the faces around that vertex (ascending original face id: the order of the sum).
     // j is a property of the mesh: the three corners' ranks ride in fq[3].x (4 bits each, 15 = this corner's vertex has
     // more than 8 faces: the triple goes to G3 and the vertex walks the CSR).  k_fem scatters 3 x 12 bytes per face; a
@@ -199,8 +198,10 @@ struct DP {
     // same plane, a vertex's eight entries are 384 bytes apart (immediate offsets of one address).  One 96-byte row per
     // vertex cost k_fem +6 us (a store instruction touching 64 rows), eight planes over the whole vertex range the
     // same +0.7 as this.  Entries past a vertex's valence hold zeros (written at every re-sort: adding -0 changes
-    // nothing); VF_MARK in the first word of plane 0 = "walk the CSR".  A partitioned domain keeps va + G3 (its faces
-    // come and go).
+    // nothing); VF_MARK in the first word of plane 0 = "walk the CSR".  A partitioned domain works the same way since
+    // round 5: a face's three ranks are a property of the mesh, so they travel with the face (DP::fg[..].w); a face that
+    // is not on this rank leaves a stale entry in its corner's row, which only a ghost vertex can have (its force is not
+    // used) -- an OWNED vertex with a face missing is found by the re-sort that follows every migration (ERR_HALO).
     float* VF;
     float* f[3];           // vertices: internal force
     // topology (original ids)

@@ -258,7 +258,7 @@ __global__ __launch_bounds__(256) void k_dist_build_topology(DP p) {
         const int slot = active_slot(p, idx, nf);
         const int gid = S.pid[slot];
         if (slot < p.Nf) {
-            p.fg[cs][slot] = make_int4(p.idx_orig[0][gid], p.idx_orig[1][gid], p.idx_orig[2][gid], 0);
+            p.fg[cs][slot] = make_int4(p.idx_orig[0][gid], p.idx_orig[1][gid], p.idx_orig[2][gid], __float_as_int(S.fq[3][slot].x));
         } else {
             const int vo = gid - p.NfG, e0 = p.adj_off[vo], e1 = p.adj_off[vo + 1];
             int rec[8];

@@ -190,7 +190,7 @@ static void launch_fem(mpm_engine* e, float dt) {
     launch_fem_vertices(e);
 }
 // `forces`: where k_p2g's vertex lanes find the force on their vertex (the kernel's template parameter: 0 = in p.f,
-// k_vforce ran; 1 / 2 = summed inside the kernel)
+// k_vforce ran; 1 = summed inside the kernel)
 static void launch_p2g(mpm_engine* e, float dt, int forces = 0) {
     TraceRange tr(forces ? "mpm:ParticleToGrid (+ vertex forces)" : "mpm:ParticleToGrid");
     const dim3 g(e->g_tile), b(P2G_THREADS);
@@ -202,14 +202,13 @@ static void launch_p2g(mpm_engine* e, float dt, int forces = 0) {
         else hipLaunchKernelGGL((k_p2g<F, 0>), g, b, 0, e->stream, e->dp, dt);                     \
     } while (0)
     if (forces == 1) MPM_P2G_LAUNCH(1);
-    else if (forces == 2) MPM_P2G_LAUNCH(2);
     else MPM_P2G_LAUNCH(0);
 #undef MPM_P2G_LAUNCH
     e->last_tile_kernel = 1;
 }
-// the vertex forces inside k_p2g: from the vertices' entries of DP::VF in a single-domain engine, through va + G3 in a
-// partitioned one; a mesh with a vertex of more than eight faces keeps the k_vforce launch
-static int fused_forces(const mpm_engine* e) { return e->dp.dist.on ? 2 : (e->max_valence <= 8 ? 1 : 0); }
+// the vertex forces inside k_p2g, from the vertices' entries of DP::VF (single and partitioned domains alike since round
+// 5); a mesh with a vertex of more than eight faces keeps the k_vforce launch
+static int fused_forces(const mpm_engine* e) { return e->max_valence <= 8 ? 1 : 0; }
 // FEM faces, then P2G with the vertex forces of every work item computed inside it (no k_vforce launch): the
 // batched substeps use this; the phase-by-phase calls keep the two FEM kernels, whose forces a caller may read
 static void launch_fem_p2g(mpm_engine* e, float dt) {
@@ -322,7 +321,6 @@ int mpm_finalize(mpm_handle_t e) try {
         ALLOC(S.f8, nf, true);
         ALLOC(S.c8, nf, true);
         ALLOC(S.pid, np, true);
-        for (int d = 0; d < 2; ++d) ALLOC(S.va[d], nv, true);
     }
     ALLOC(p.ta, std::max<size_t>(nf, 1), true);   // (k_p2g's vertex lanes read element 0 when an item has no face)
     ALLOC(p.G3, 3 * nf, true);
@@ -1585,7 +1583,7 @@ int mpm_get_stats(mpm_handle_t e, mpm_stats_t* out) try {
             const PSet& S = p.set[s];
             pb += e->bytes_of(S.q[0]) + e->bytes_of(S.pid) + e->bytes_of(S.f8) + e->bytes_of(S.c8) + e->bytes_of(p.fg[s]);
             for (int d = 0; d < 4; ++d) pb += e->bytes_of(S.fq[d]);
-            for (int d = 0; d < 2; ++d) pb += e->bytes_of(S.va[d]) + e->bytes_of(p.vg[s][d]);
+            for (int d = 0; d < 2; ++d) pb += e->bytes_of(p.vg[s][d]);
         }
         pb += e->bytes_of(p.ta) + e->bytes_of(p.G3) + e->bytes_of(p.VF) + e->bytes_of(p.f[0]) + e->bytes_of(p.pkey) +
               e->bytes_of(p.prank) + e->bytes_of(p.src_of) + e->bytes_of(p.dst_of) + e->bytes_of(p.home_groups);
@@ -1784,14 +1782,14 @@ static int dist_resize(mpm_engine* e, size_t new_nf, size_t new_nv, bool first) 
         if (!rc) rc = plan(S.f8, new_nf, kf);
         if (!rc) rc = plan(S.c8, new_nf, kf);
         if (!rc) rc = plan(p.fg[s], new_nf, kf);
-        for (int d = 0; d < 2 && !rc; ++d) {
-            rc = plan(S.va[d], new_nv, kv);
-            if (!rc) rc = plan(p.vg[s][d], new_nv, kv);
-        }
+        for (int d = 0; d < 2 && !rc; ++d) rc = plan(p.vg[s][d], new_nv, kv);
     }
     // per-substep outputs and re-sort scratch: nothing to keep
     if (!rc) rc = plan(p.ta, new_nf, {});
     if (!rc) rc = plan(p.G3, 3 * new_nf, {});
+    // (the vertices' rows of force triples: zero-filled; the re-sort that follows writes the zeros / marks of every held
+    // vertex again and k_fem the rest before anything reads them)
+    if (!rc) rc = plan(p.VF, 3 * vf_entry((unsigned)new_nv + VF_CHUNK, 0), {});
     if (!rc) rc = plan(f_base, 3 * (size_t)new_q_stride, {});
     if (!rc) rc = plan(p.pkey, new_np, {});
     if (!rc) rc = plan(p.prank, new_np, {});
@@ -1839,8 +1837,6 @@ static int dist_resize(mpm_engine* e, size_t new_nf, size_t new_nv, bool first) 
         // (a mesh with a vertex of more than eight faces keeps the scene's adjacency -- 4 bytes per vertex and 12 per face
         // on every rank: such a vertex's record holds a mark instead of face ids, and its force walks the adjacency by
         // original id through the id -> slot map, wherever the vertex migrates: vertex_force_csr)
-        e->dfree(p.VF);   // (a partitioned domain finds its vertex forces through va + G3: DP::VF)
-        p.VF = nullptr;
     }
     p.Np = (int)new_np; p.Nf = (int)new_nf; p.Nv = (int)new_nv;
     p.q_stride = new_q_stride;

@@ -43,27 +43,13 @@ __global__ __launch_bounds__(256) void k_init_faces(DP p) {
     p.G3[(size_t)i * 3].x = v4;
 }
 
-// per vertex, the (face slot * 3 + corner) records of its adjacent faces (slot == original id
-// before the first sort); rebuilds only translate them
+// a vertex with more than eight adjacent faces: the mark in its row of DP::VF that sends it to the adjacency CSR (slot ==
+// original id before the first sort; re-sorts write it again at the vertex's new slot)
 __global__ __launch_bounds__(256) void k_init_vertex_adjacency(DP p) {
     const int k = blockIdx.x * 256 + threadIdx.x;
     if (k >= p.Nv) return;
     const int e0 = p.adj_off[k], e1 = p.adj_off[k + 1];
-    int rec[8];
-#pragma unroll
-    for (int q = 0; q < 8; ++q) {
-        rec[q] = -1;
-        if (e0 + q < e1) {
-            const int fc = p.adj_fc[e0 + q];
-            rec[q] = (fc >> 2) * 3 + (fc & 3);
-        }
-    }
-    if (e1 - e0 > 8) {
-        rec[0] = -2;
-        p.VF[vf_entry((unsigned)k, 0) * 3] = __uint_as_float(VF_MARK);
-    }
-    p.set[0].va[0][k] = make_int4(rec[0], rec[1], rec[2], rec[3]);
-    p.set[0].va[1][k] = make_int4(rec[4], rec[5], rec[6], rec[7]);
+    if (e1 - e0 > 8) p.VF[vf_entry((unsigned)k, 0) * 3] = __uint_as_float(VF_MARK);
 }
 
 // vertex volume = sum of the quarter volumes of its faces (ascending face id)

@@ -650,6 +650,7 @@ __global__ __launch_bounds__(256) void k_rb_finish(DP p) {
                 // ids (per-slot topology, carried along) through the new id -> slot map; -1 = that corner is not here
                 const int4 cg = p.fg[c->cur][i];
                 p.fg[c->cur ^ 1][j] = cg;
+                b3.x = __int_as_float(cg.w);   // (the corners' ranks around their vertices: DP::VF; a face that has just arrived has none in fq)
                 b3.y = __int_as_float(p.imap[cg.x]);
                 b3.z = __int_as_float(p.imap[cg.y]);
                 b3.w = __int_as_float(p.imap[cg.z]);
@@ -658,10 +659,8 @@ __global__ __launch_bounds__(256) void k_rb_finish(DP p) {
             D.f8[j] = S.f8[i];
             D.c8[j] = S.c8[i];
         } else if (!p.dist.on) {
-            // A single-domain engine finds the forces on its vertices in DP::VF and has no use for va (a partitioned
-            // one rebuilds it from the topology by original id, below).  The vertex's entries at the new slot: zeros
-            // where it has no face (k_fem rewrites the others before anything reads them), or the mark that sends a
-            // vertex with more than eight faces to the CSR.
+            // The vertex's entries of DP::VF at the new slot: zeros where it has no face (k_fem rewrites the others
+            // before anything reads them), or the mark that sends a vertex with more than eight faces to the CSR.
             const int vo = pid - p.NfG;
             const int valence = p.adj_off[vo + 1] - p.adj_off[vo];
             {
@@ -675,24 +674,25 @@ __global__ __launch_bounds__(256) void k_rb_finish(DP p) {
                     if (q >= valence) *reinterpret_cast<float3*>(p.VF + vf_entry((unsigned)kk, (unsigned)q) * 3) = z;
             }
         } else {
-            // (face slot * 3 + corner) of the adjacent faces, ascending original face id; -3 = a face
-            // that is not on this rank (legal around a ghost vertex, an error around an owned one)
+            // Partitioned domain: the vertex's adjacent faces by original id travel with it (ascending face id, -1 = none,
+            // -2 in the first = more than eight: the scene's adjacency, vertex_force_csr).  Its row of DP::VF at the new
+            // slot as in a single domain: zeros past the valence, or the mark.  A face that is not on this rank is legal
+            // around a ghost vertex (nobody uses its force) and an error around an owned one: particles come and go at
+            // migrations only, each of which forces this re-sort, so looking here finds every case.
             const int4 g0 = p.vg[c->cur][0][i - p.Nf], g1 = p.vg[c->cur][1][i - p.Nf];
             p.vg[c->cur ^ 1][0][j - p.Nf] = g0;
             p.vg[c->cur ^ 1][1][j - p.Nf] = g1;
             const int fcs[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
-            int rec[8];
+            const size_t kk = (size_t)(j - p.Nf);
+            const float3 z = make_float3(0.f, 0.f, 0.f);
+            bool missing = false;
 #pragma unroll
             for (int q = 0; q < 8; ++q) {
-                rec[q] = -1;
-                if (fcs[q] >= 0) {
-                    const int fs = p.imap[fcs[q] >> 2];
-                    rec[q] = fs < 0 ? -3 : fs * 3 + (fcs[q] & 3);
-                }
+                if (fcs[q] >= 0) missing |= p.imap[fcs[q] >> 2] < 0;
+                else if (!(q == 0 && fcs[0] == -2)) *reinterpret_cast<float3*>(p.VF + vf_entry((unsigned)kk, (unsigned)q) * 3) = z;
             }
-            if (fcs[0] == -2) rec[0] = -2;   // more than eight faces: the scene's adjacency (vertex_force_csr)
-            D.va[0][j - p.Nf] = make_int4(rec[0], rec[1], rec[2], rec[3]);
-            D.va[1][j - p.Nf] = make_int4(rec[4], rec[5], rec[6], rec[7]);
+            if (fcs[0] == -2) *reinterpret_cast<float3*>(p.VF + vf_entry((unsigned)kk, 0) * 3) = make_float3(__uint_as_float(VF_MARK), 0.f, 0.f);
+            if (missing && S.q[0][i].w > 0.f) atomicOr(&c->error, ERR_HALO);
         }
     }
     // every cell row of a home block holds prefix values now: clear whole rows

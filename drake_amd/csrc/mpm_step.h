@@ -122,18 +122,20 @@ __global__ __launch_bounds__(256) void k_fem(DP p, float dt) {
         Gm[d * 3 + 1] = a * g01 + b * g11;
         Gm[d * 3 + 2] = b * g12;
     }
-    // one 12-byte record per corner, at its place among the vertex's entries (DP::VF) -- or, in a partitioned domain and for
-    // a vertex with more than eight faces, in the face's own triple of G3
+    // one 12-byte record per corner, at its place among the vertex's entries (DP::VF) -- or, for a vertex with more than
+    // eight faces, in the face's own triple of G3 (a corner that is not on this rank of a partitioned domain: nowhere; that
+    // face belongs to a ghost band's outer edge, or the missing corner is an error the kernel has raised above)
     const unsigned jb = (unsigned)__float_as_int(f3.x);
     const unsigned sc[3] = {s0, s1, s2};
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
         const float3 rec = make_float3(Gm[c], Gm[3 + c], Gm[6 + c]);
         const unsigned j = (jb >> (4 * c)) & 15u;
-        if (!p.dist.on && j < 8u)
-            *reinterpret_cast<float3*>(p.VF + vf_entry(sc[c] - (unsigned)p.Nf, j) * 3u) = rec;
-        else
+        if (j < 8u) {
+            if (!p.dist.on || (int)sc[c] >= p.Nf) *reinterpret_cast<float3*>(p.VF + vf_entry(sc[c] - (unsigned)p.Nf, j) * 3u) = rec;
+        } else {
             p.G3[(size_t)i * 3 + c] = rec;
+        }
     }
 }
 
@@ -170,75 +172,11 @@ MPM_DEV void vertex_force_csr(const DP& p, const PSet& S, int k, float& f0, floa
     }
 }
 
-// Vertex force = - sum over adjacent (face, corner) of that corner's force triple, summed in
-// ascending original face id (the order sequential atomics would produce).  The adjacency is
-// kept per vertex slot (refreshed at every rebuild) so that a vertex needs one coalesced index
-// load and one 16-byte gather per adjacent face.
-// the force on vertex `k` (slot p.Nf + k) from the corner records of its adjacent faces
-MPM_DEV void vertex_force_from(const DP& p, const PSet& S, int k, int4 r0, int4 r1, float& f0, float& f1, float& f2) {
-    const int s = p.Nf + k;
-    f0 = f1 = f2 = 0.f;
-    const int rec[8] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w};
-    if (p.dist.on) {
-        // a face next to this vertex is missing on this rank (-3): fine for a ghost vertex, whose force
-        // nobody uses; for an owned one the result would be wrong, so it becomes NaN and is reported
-        bool missing = false;
-#pragma unroll
-        for (int q = 0; q < 8; ++q) missing |= rec[q] == -3;
-        if (missing) {
-            f0 = f1 = f2 = S.q[0][s].w > 0.f ? __int_as_float(0x7FC00000) : 0.f;
-            return;
-        }
-    }
-    if (rec[0] != -2) {
-        float3 g[8];
-#pragma unroll
-        for (int q = 0; q < 8; ++q) g[q] = rec[q] >= 0 ? p.G3[rec[q]] : make_float3(0.f, 0.f, 0.f);
-#pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            if (rec[q] >= 0) {
-                f0 += -g[q].x;
-                f1 += -g[q].y;
-                f2 += -g[q].z;
-            }
-        }
-    } else {
-        vertex_force_csr(p, S, k, f0, f1, f2);
-    }
-}
-// The same for the lanes of a wave of k_p2g (partitioned domain), without branches in the common case: every lane gathers
-// eight records (a lane that is not a vertex comes with the adjacency of vertex 0: valid records, shared lines, result
-// unused; an empty entry reads record 0 and adds -0, which changes nothing: the sums are those of vertex_force_from to the
-// bit).  Valence above 8 and faces missing on this rank take the general routine, per lane.
-MPM_DEV void vertex_force_wave(const DP& p, const PSet& S, bool vert, int k, int4 r0, int4 r1, float& f0, float& f1, float& f2) {
-    f0 = f1 = f2 = 0.f;
-    if (p.Nf <= 0) return;   // (uniform: no faces, no records)
-    const int rec[8] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w};
-    float3 g[8];
-#pragma unroll
-    for (int q = 0; q < 8; ++q) g[q] = p.G3[max(rec[q], 0)];
-    bool special = rec[0] == -2;
-    if (p.dist.on) {
-#pragma unroll
-        for (int q = 0; q < 8; ++q) special |= rec[q] == -3;
-    }
-#pragma unroll
-    for (int q = 0; q < 8; ++q) {
-        const bool on = rec[q] >= 0;
-        f0 += on ? -g[q].x : -0.f;
-        f1 += on ? -g[q].y : -0.f;
-        f2 += on ? -g[q].z : -0.f;
-    }
-    if (__ballot(vert && special)) {
-        if (vert && special) vertex_force_from(p, S, k, r0, r1, f0, f1, f2);
-    }
-}
+// Vertex force = - sum over adjacent (face, corner) of that corner's force triple, summed in ascending original face
+// id (the order sequential atomics would produce): the vertex's row of DP::VF, or the adjacency CSR for a vertex with
+// more than eight faces.
 MPM_DEV void vertex_force_value(const DP& p, const PSet& S, int k, float& f0, float& f1, float& f2) {
-    if (!p.dist.on) {   // (a single-domain engine does not keep va: DP::VF, k_rb_finish)
-        if (!vertex_force_vf(p, k, f0, f1, f2)) vertex_force_csr(p, S, k, f0, f1, f2);
-        return;
-    }
-    vertex_force_from(p, S, k, S.va[0][k], S.va[1][k], f0, f1, f2);
+    if (!vertex_force_vf(p, k, f0, f1, f2)) vertex_force_csr(p, S, k, f0, f1, f2);
 }
 MPM_DEV void vertex_force(const DP& p, const PSet& S, int k) {   // ... written to p.f
     float f0, f1, f2;
@@ -411,9 +349,9 @@ constexpr int P2G_WAVES = MPM_P2G_WAVES, P2G_THREADS = 64 * P2G_WAVES;
 // two workgroups per CU: 8 waves each at <= 128 VGPRs (4 per SIMD), or 10 at <= 96 (5 per SIMD; -DMPM_P2G_WAVES=10)
 // FORCES: where a vertex lane finds the internal force on its vertex.
 //   0  in p.f (k_vforce ran before this kernel: the phase-by-phase API, meshes with a vertex of more than eight faces)
-//   1  in the eight planes of DP::VF, summed here (single-domain engines: one round trip of coalesced loads)
-//   2  through va + G3, summed here (partitioned domain: two dependent round trips, eight gathers)
-// 1 and 2 save the k_vforce launch of every substep.  Rounds 2-3 computed the forces of ALL vertices of an item in a
+//   1  in the eight planes of DP::VF, summed here (one round trip of coalesced loads; a partitioned domain went through
+//      per-slot adjacency records and G3 until round 5: two dependent round trips, eight gathers)
+// 1 saves the k_vforce launch of every substep.  Rounds 2-3 computed the forces of ALL vertices of an item in a
 // prologue of their own (two dependent round trips and a barrier that every workgroup of the launch walks through at
 // the same time: ~6 us in which nothing else happens); now each vertex lane fetches them with its particle records:
 // k_p2g 48.9 -> 45.3 us (event time, same box), -> 43.9 with the group descriptor a group ahead, -> 41 with the vertex-side records (DP::VF).
@@ -540,12 +478,6 @@ __global__ __launch_bounds__(P2G_THREADS) __attribute__((amdgpu_waves_per_eu(P2G
             // unsigned index: lets the loads use the scalar-base + 32-bit-offset addressing form
             const unsigned any_slot = (unsigned)(nfb ? rg.x : rg.z);   // (a particle of the item: always valid)
             const unsigned ii = r.act ? (unsigned)(r.is_face ? gr.x + lane : gr.z + (lane - gf)) : any_slot;
-            // (the head of the longest chain first: adjacency -> corner records)
-            int4 va0 = make_int4(0, 0, 0, 0), va1 = va0;
-            if (FORCES == 2) {
-                const unsigned kv = r.act && !r.is_face ? ii - (unsigned)p.Nf : 0u;   // (any valid entry for the other lanes)
-                va0 = S.va[0][kv]; va1 = S.va[1][kv];
-            }
             // (one base pointer and a stride for the four planes: see DP::q_stride)
             const float4* qb = S.q[0] + ii;
             const float4 q0 = qb[0], q1 = qb[p.q_stride], q2 = qb[2 * (size_t)p.q_stride], q3 = qb[3 * (size_t)p.q_stride];
@@ -565,8 +497,6 @@ __global__ __launch_bounds__(P2G_THREADS) __attribute__((amdgpu_waves_per_eu(P2G
                 const bool vert = r.act && !r.is_face;
                 if (FORCES == 1) {
                     vertex_force_vf(p, vert ? (int)ii - p.Nf : 0, r.frc[0], r.frc[1], r.frc[2]);   // (vertex 0 for the other lanes: valid memory)
-                } else if (FORCES == 2) {
-                    vertex_force_wave(p, S, vert, (int)ii - p.Nf, va0, va1, r.frc[0], r.frc[1], r.frc[2]);
                 } else {
                     force_of(vi, r.frc);
                 }

@@ -284,3 +284,32 @@ def test_vertex_with_more_than_eight_faces_crosses_a_cut():
     close(pos, rp, scale=1.0, rtol=1e-5, what="fan mesh across a cut: positions vs single engine")
     close(vel, rv, scale=vs, rtol=1e-4, what="fan mesh across a cut: velocities vs single engine")
     close(F, rF, scale=1.0, rtol=1e-4, what="fan mesh across a cut: F vs single engine")
+
+
+def test_an_owned_vertex_that_misses_a_face_is_reported_by_the_resort():
+    """The guard behind the vertex-side force records of a partitioned domain (round 5): a vertex sums what its faces left
+    in its row, so a face that is not on the rank would silently be missing from an OWNED vertex's force.  Particles come
+    and go at migrations only, each followed by a re-sort, which looks: MPM_ERR_HALO.  Provoked with explicit bands that
+    are too narrow for the mesh: edges of 2.5 cells, faces kept one cell beyond the cut (their centroids reach 1.7), the
+    vertex band wide enough (3 cells) that every kept face finds its corners -- the other guard stays quiet."""
+    import torch
+    from drake_amd import GpuMpm, scenes
+    from drake_amd.capi import MpmError
+    from drake_amd.dist import LocalWorld
+    bits = 6
+    sheets = scenes.cloth_stack(1, 14, bits, z0=0.5, side=0.5, seed=2, vel_amp=0.0)
+    engines = [_populate(GpuMpm(bits), sheets) for _ in range(2)]
+    flags = 0
+    try:
+        w = LocalWorld(engines, [0, 8, 16], 2, 1, 2, capacity_blocks=512, migrate_every=8, migrate_capacity=4096,
+                       device=torch.device("cuda", 0))
+        w.run_substeps(2, DT, -1)
+        w.sync()
+    except MpmError:
+        pass
+    for g in engines:
+        flags |= g.stats()["error_flags"]
+    assert flags & 16, flags      # ERR_HALO (mpm_device.h)
+    assert not flags & 8, flags   # ... and not a NaN that ParticleToGrid found later (ERR_RANGE)
+    for g in engines:
+        g.destroy()
