@@ -108,17 +108,20 @@ def test_bench_partition_geometry_matches_single_engine(world, vx, steps):
     # per work item and float-added across items, so the grouping decides the rounding -- and a partition is a different
     # grouping).  On the 128^3 grid one ulp of F is dt E / (rho dx) x 1.2e-7 = 3e-6 m/s of nodal velocity per substep and
     # the stiff explicit update compounds it: 36 substeps of rounding alone move F by ~1e-4.
+    # (two regroupings, the larger distance: the maximum of a rounding field over a million entries is itself a draw)
     import os
-    os.environ["MPM_ITEM_GROUPS"] = "7"
-    try:
-        ref2 = _populate(GpuMpm(bits), sheets)
-    finally:
-        del os.environ["MPM_ITEM_GROUPS"]
-    ref2.run_substeps(steps, DT, -1)
-    ref2.gpu_sync()
-    noise_v = float(np.abs(ref2.download(ARR.VELOCITIES) - rv).max())
-    noise_F = float(np.abs(ref2.download(ARR.DEFORMATION_GRADIENTS) - rF).max())
-    ref2.destroy()
+    noise_v = noise_F = 0.0
+    for groups in ("7", "5"):
+        os.environ["MPM_ITEM_GROUPS"] = groups
+        try:
+            ref2 = _populate(GpuMpm(bits), sheets)
+        finally:
+            del os.environ["MPM_ITEM_GROUPS"]
+        ref2.run_substeps(steps, DT, -1)
+        ref2.gpu_sync()
+        noise_v = max(noise_v, float(np.abs(ref2.download(ARR.VELOCITIES) - rv).max()))
+        noise_F = max(noise_F, float(np.abs(ref2.download(ARR.DEFORMATION_GRADIENTS) - rF).max()))
+        ref2.destroy()
 
     geo = strong_geometry(bits, world)
     assert geo["zone_blocks"] == (1 if world == 8 else 2) and geo["migrate_every"] == 0 and geo["ghost_cells"] == 0
