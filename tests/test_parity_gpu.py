@@ -246,12 +246,19 @@ def test_double_and_fixed_point_tiles_of_p2g_agree(monkeypatch):
 
 
 def test_substep_equals_phase_calls():
+    """mpm_substep against the reference's five calls, five substeps.  Not bitwise outside deterministic mode (that
+    comparison is tests/test_run_substeps_gpu.py's): the order of the particles inside a cell comes out of atomics at
+    every re-sort, and the per-cell partial sums of ParticleToGrid are float sums in that order -- last-bit differences
+    of the grid, which stay at a few hundredths of the measured one-substep float noise for almost every particle.
+    Almost: the reference's return mapping (cuda_mpm_kernels.cuh:183-294) BRANCHES on the normal stretch, and a face
+    that sits on a branch point takes one side or the other with the last bit of its input.  scratch/substep_repeat.py,
+    40 runs of this scene: in 30 the largest difference is 0.02-0.04 noises; in 8 face 2439 flips at substep 3 and ends
+    6.3-6.9 noises apart (the same number every time: a discrete event, not a spread), in 2 face 2664 at substep 5
+    (3.6).  Hence: all but a per-mille of the particles within 0.4 noises (the bound this test always had), nobody
+    beyond 40."""
     A = _A()
     o, g1 = build_pair(seed=11)
     _, g2 = build_pair(seed=11)
-    # (not bitwise: the order of the particles inside a cell comes out of atomics at every re-sort, and the
-    # per-cell partial sums of P2G are float sums in that order -- last-bit differences of the grid,
-    # which the stiff cloth turns into a few 1e-7 m/s; same scale as every other velocity comparison)
     sc = natural_scales(o, DT)
     for _ in range(5):
         g1.substep(DT, -1)
@@ -261,7 +268,12 @@ def test_substep_equals_phase_calls():
         g2.update_grid(-1)
         g2.grid_to_particle(DT)
     close(g1.download(A.POSITIONS), g2.download(A.POSITIONS), scale=1.0, rtol=1e-6, what="substep pos")
-    close(g1.download(A.VELOCITIES), g2.download(A.VELOCITIES), scale=sc["vel"], rtol=1e-6, what="substep vel")
+    v1, v2 = g1.download(A.VELOCITIES), g2.download(A.VELOCITIES)
+    err = np.abs(v1 - v2).max(axis=1)
+    order = np.argsort(err)
+    typical = order[: len(order) - max(1, len(order) // 1000)]
+    close(v1[typical], v2[typical], scale=sc["vel"], rtol=1e-6, what="substep vel (all but a per-mille of the particles)")
+    close(v1, v2, scale=sc["vel"], rtol=1e-4, what="substep vel (every particle)")
 
 
 def test_batched_substeps_with_resorts_in_between_equal_phase_calls():
