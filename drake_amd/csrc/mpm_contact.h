@@ -210,8 +210,8 @@ static int resolve_contact_count(mpm_engine* e) {
 
 // Device-side CalcMpmContactPairs + CopyContactPairs for analytic colliders (include/mpm_hip.h).  Nothing here waits for
 // the device: the colliders travel as a kernel argument, the pairs are counted, placed and LEFT COUNTED on the device
-// (ContactState::n); mpm_update_contact's launches have fixed grids and read the count there.  Three launches: count per
-// slot, scan inside 4096-blocks, write (every workgroup adds up the block totals it needs; workgroup 0 leaves the count).
+// (ContactState::n); mpm_update_contact's launches have fixed grids and read the count there.  Two launches: count per slot
+// with the scan inside 4096-blocks, write (every workgroup adds up the block totals it needs; workgroup 0 leaves the count).
 static int generate_contacts_launch(mpm_engine* e) {
     ContactBuffers& b = e->cb;
     const DP& p = e->dp;
@@ -226,8 +226,7 @@ static int generate_contacts_launch(mpm_engine* e) {
     }
     const size_t np = e->np, padded = ((np + 1 + 4095) / 4096) * 4096;
     const int nb = (int)(padded / 4096);
-    hipLaunchKernelGGL(k_ct_gen_count, dim3((unsigned)(padded / 256)), dim3(256), 0, s, p, (const int*)e->d_pids_api, tab, b.gen_cnt, (int)padded);
-    hipLaunchKernelGGL(k_scan_blocks, dim3(nb), dim3(256), 0, s, b.gen_cnt, (int)(np + 1), b.gen_sums);
+    hipLaunchKernelGGL(k_ct_gen_count_scan, dim3(nb), dim3(1024), 0, s, p, (const int*)e->d_pids_api, tab, b.gen_cnt, b.gen_sums);
     ContactDev c{};
     c.n = -1;
     c.st = b.st;
@@ -713,7 +712,7 @@ static int solve_once(mpm_engine* e, float dt, float mu, float stiffness, float 
             hipLaunchKernelGGL(k_ct_flags_to_field, dim3(512), dim3(256), 0, s, p, c, 1);
         }
         hipLaunchKernelGGL(k_ct_flag_bits, dim3(256), dim3(256), 0, s, p, c);
-        hipLaunchKernelGGL(k_ct_node_list, dim3(1), dim3(1024), 0, s, p, c);
+        hipLaunchKernelGGL(k_ct_node_list, dim3((unsigned)((p.capA + 255) / 256)), dim3(256), 0, s, p, c);
         hipLaunchKernelGGL(k_ct_node_runs, dim3(1024), dim3(256), 0, s, p, c);
     }
 

@@ -323,26 +323,54 @@ MPM_DEV const Collider& collider_of(const ColliderTable& t, int j) { return t.de
 // read-back)
 MPM_DEV int ct_count(const ContactDev& c) { return c.n >= 0 ? c.n : c.st->n; }
 
-// P1: number of penetrated colliders per particle slot (the caller's slot order); the padding of the scan's storage is
-// zeroed here (the in-place scan leaves totals there)
-__global__ __launch_bounds__(256) void k_ct_gen_count(DP p, const int* pids_api, ColliderTable cols, int* cnt, int padded) {
-    const int s = blockIdx.x * 256 + threadIdx.x;
-    if (s >= padded) return;
-    if (s >= p.NpG) {
-        cnt[s] = 0;
-        return;
-    }
+// P1: number of penetrated colliders per particle slot (the caller's slot order), 0 in the padding of the scan's storage.
+// With the scan inside 4096-blocks in ONE launch (round 5: a kernel boundary and k_scan_blocks' 5 us less per coupled
+// substep): a workgroup of 1024 threads owns a 4096-block, a thread four consecutive slots -- their three dependent loads
+// (API slot -> original id -> slot -> position) are four independent chains --, then the exclusive scan of the block's
+// counts in place and the block's total (what a count kernel + k_scan_blocks left until then).
+__global__ __launch_bounds__(1024) void k_ct_gen_count_scan(DP p, const int* pids_api, ColliderTable cols, int* cnt, int* sums) {
+    __shared__ int s_w[16];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int base = blockIdx.x * 4096 + tid * 4;
     const PSet& S = p.set[p.ctl->cur];
-    const int slot = p.imap[pids_api[s]];
-    // (partitioned domain: only the particles this rank owns make contacts here)
-    const float4 q = slot >= 0 ? S.q[0][slot] : make_float4(0.f, 0.f, 0.f, 0.f);
-    const float x[3] = {q.x, q.y, q.z};
-    int n = 0;
-    for (int j = 0; j < cols.n && q.w > 0.f; ++j) {
-        float g[3];
-        n += collider_sdf(collider_of(cols, j), x, g) < 0.f ? 1 : 0;
+    int slot[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int s = base + k;
+        slot[k] = s < p.NpG ? p.imap[pids_api[s]] : -1;
     }
-    cnt[s] = n;
+    float4 q[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) q[k] = slot[k] >= 0 ? S.q[0][slot[k]] : make_float4(0.f, 0.f, 0.f, 0.f);
+    int n[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const float x[3] = {q[k].x, q[k].y, q[k].z};
+        n[k] = 0;
+        // (partitioned domain: only the particles this rank owns make contacts here)
+        for (int j = 0; j < cols.n && q[k].w > 0.f; ++j) {
+            float g[3];
+            n[k] += collider_sdf(collider_of(cols, j), x, g) < 0.f ? 1 : 0;
+        }
+    }
+    const int sum = n[0] + n[1] + n[2] + n[3];
+    int inc = sum;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int t = __shfl_up(inc, d);
+        if (lane >= d) inc += t;
+    }
+    if (lane == 63) s_w[w] = inc;
+    __syncthreads();
+    int run = inc - sum;
+    for (int k = 0; k < w; ++k) run += s_w[k];
+    if (tid == 1023) sums[blockIdx.x] = run + sum;
+    int4 o;
+    o.x = run; run += n[0];
+    o.y = run; run += n[1];
+    o.z = run; run += n[2];
+    o.w = run;
+    *reinterpret_cast<int4*>(cnt + base) = o;
 }
 
 // P2: the pairs, at the scanned offsets (offset inside its 4096-block + the pairs of the blocks before it): ascending
@@ -641,32 +669,62 @@ __global__ __launch_bounds__(256) void k_ct_flag_bits(DP p, ContactDev c) {
         if (lane == 0) c.flag_bits[w] = m;
     }
 }
-__global__ __launch_bounds__(1024) void k_ct_node_list(DP p, ContactDev c) {
-    __shared__ int s_w[16];
-    __shared__ int s_at[1024];
-    __shared__ unsigned long long s_m[1024];
+// The list of the nodes that see contacts, ascending (block word, bit), from the words of k_ct_flag_bits.  A workgroup
+// owns 256 words, a wave 64 of them (lane = word); how many nodes the words in front of the workgroup's hold it counts
+// itself (all words' popcounts: a few coalesced rows), so no scan kernel and no single workgroup: one workgroup walking
+// all words, a word per wave and step, took 19 us for config 3's 1805 words (64 steps per wave and chunk, most of them
+// over empty words -- the nodes that see contacts sit in a tenth of the blocks, the floor's).  Here a wave steps
+// through its NON-EMPTY words only; lane l owns bit l of the word being written.
+__global__ __launch_bounds__(256) void k_ct_node_list(DP p, ContactDev c) {
+    __shared__ int s_red[2][4];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int words = (int)p.ctl->n_active;
-    int carry = 0;
-    for (int base = 0; base < words; base += 1024) {
-        const int w = base + tid;
-        const unsigned long long m = w < words ? c.flag_bits[w] : 0ull;
-        int block_total;
-        s_at[tid] = carry + wg1024_exclusive((int)__popcll(m), block_total, s_w);
-        s_m[tid] = m;
-        __syncthreads();
-        // write-out by whole waves, a word per wave and step: lane l owns bit l.  (A thread per word, writing its up to
-        // 64 nodes one after the other, took 10 us: the nodes that see contacts sit in a tenth of the blocks -- the floor's
-        // --, so a few threads wrote 64 entries each while the rest had none.)
-        for (int q = wv; q < 1024 && base + q < words; q += 16) {
-            const unsigned long long mq = s_m[q];
-            if (mq == 0ull) continue;   // (wave-uniform)
-            if ((mq >> lane) & 1ull) c.node_list[s_at[q] + (int)__popcll(mq & ((1ull << lane) - 1ull))] = (base + q) * 64 + lane;
+    const int start = blockIdx.x * 256;
+    if (start >= words && blockIdx.x != 0) return;
+    int before = 0, total = 0;
+    for (int w0 = tid; w0 < words; w0 += 8 * 256) {   // (eight rows in flight per step)
+        unsigned long long x[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) x[q] = w0 + q * 256 < words ? c.flag_bits[w0 + q * 256] : 0ull;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int n = (int)__popcll(x[q]);
+            total += n;
+            before += w0 + q * 256 < start ? n : 0;
         }
-        carry += block_total;
-        __syncthreads();
     }
-    if (tid == 0) c.st->n_nodes = carry;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        before += __shfl_xor(before, d);
+        total += __shfl_xor(total, d);
+    }
+    if (lane == 0) { s_red[0][wv] = before; s_red[1][wv] = total; }
+    const int w = start + tid;
+    const unsigned long long m = w < words ? c.flag_bits[w] : 0ull;
+    const int cnt = (int)__popcll(m);
+    int inc = cnt;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int t = __shfl_up(inc, d);
+        if (lane >= d) inc += t;
+    }
+    __shared__ int s_wt[4];
+    if (lane == 63) s_wt[wv] = inc;
+    __syncthreads();
+    before = s_red[0][0] + s_red[0][1] + s_red[0][2] + s_red[0][3];
+    total = s_red[1][0] + s_red[1][1] + s_red[1][2] + s_red[1][3];
+    if (blockIdx.x == 0 && tid == 0) c.st->n_nodes = total;
+    int at = before + inc - cnt;
+    for (int k = 0; k < wv; ++k) at += s_wt[k];
+    unsigned long long nz = __ballot(m != 0ull);
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    while (nz) {
+        const int j = __builtin_ctzll(nz);
+        nz &= nz - 1ull;
+        const unsigned long long mj = __shfl(m, j);
+        const int aj = __shfl(at, j);
+        if ((mj >> lane) & 1ull) c.node_list[aj + (int)__popcll(mj & lt)] = (start + wv * 64 + j) * 64 + lane;
+    }
 }
 
 __global__ __launch_bounds__(256) void k_ct_node_runs(DP p, ContactDev c) {
