@@ -774,10 +774,14 @@ static int solve_once(mpm_engine* e, float dt, float mu, float stiffness, float 
             if (eager) hipLaunchKernelGGL(k_ct_apply, dim3(CT_ROWS), dim3(CT_WG), 0, s, p, c, 0);
             return 1;
         };
-        // first batch: as many iterations as the last solve took (a settled scene repeats itself), at least two; then
-        // one at a time (an iteration is ~34 us of device time, the host needs a few to react: one in flight is enough,
-        // and the idle launches at the end are one iteration's instead of two)
-        const int first = ct_batch(e, 0, std::min(std::max(b.last_iters, 2), 32));
+        // two iterations first, then one at a time: an iteration is ~34 us of device time, the host needs ~20 to see a
+        // publication and enqueue the next four launches, so one iteration in flight behind the one it waits for keeps
+        // the device busy, and what is enqueued in vain when the solve converges is one iteration's idle launches.
+        // (Round 5 first enqueued as many iterations as the LAST solve had taken: where the counts fall from solve to
+        // solve -- 64, 26, 19, 17, 12 ... after an impact -- that was 5-10 idle patterns of 8 us per solve; measured
+        // over four runs each, scratch/ct_batch_ab.sh: the time of a coupled substep beyond its iterations 0.32 -> 0.30
+        // ms in the window of the impact, unchanged once settled.)
+        const int first = ct_batch(e, 0, 2);
         if (int rc = run_batches(e, pattern, first, ct_batch(e, 1, 1), max_iters, &oc->mb)) return rc;
         if (!eager) hipLaunchKernelGGL(k_ct_apply, dim3(CT_ROWS), dim3(CT_WG), 0, s, p, c, 2);
         iters = oc->mb.iters;

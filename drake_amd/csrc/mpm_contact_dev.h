@@ -659,8 +659,7 @@ __global__ __launch_bounds__(256) void k_ct_prepare(DP p, ContactDev c) {
 }
 
 // S3: the nodes that see contacts, in ascending order.  Two steps: the flags of a block (64 ints) become one
-// 64-bit word (a ballot per wave, all CUs), then ONE workgroup scans the words' bit counts and writes the
-// set bits out (one CU reading the int flags themselves took 21 us: 460 KB through a single L1).
+// 64-bit word (a ballot per wave, all CUs), then k_ct_node_list turns the words into the list.
 __global__ __launch_bounds__(256) void k_ct_flag_bits(DP p, ContactDev c) {
     const int words = (int)p.ctl->n_active;   // one word per active block
     const int lane = threadIdx.x & 63;
