@@ -282,8 +282,12 @@ def contact_leg(device, steps=20, warmup=5):
     st = g.stats()
     assert st["error_flags"] == 0, st
     g.destroy()
+    # (the iteration counts of a window differ from run to run with the particle order -- 12 .. 15 at the impact --, and
+    # an iteration is it_ms: what a coupled substep costs BEYOND its iterations is the figure that compares between runs)
+    for leg in (main, main["settled"], ref_calls, ref_calls["settled"]):
+        leg["ms_beyond_iterations"] = leg["ms_per_substep"] - leg["newton_iterations"] * it_ms
     return dict(ms_per_substep=main["ms_per_substep"], substeps_per_s=main["substeps_per_s"], contacts=main["contacts"],
-                newton_iterations=main["newton_iterations"], steps=steps, warmup=warmup,
+                newton_iterations=main["newton_iterations"], ms_beyond_iterations=main["ms_beyond_iterations"], steps=steps, warmup=warmup,
                 solves_on_a_reused_setup=main["solves_on_a_reused_setup"],
                 settled=settled, reference_call_pattern=ref_calls, roofline=roofline,
                 params=dict(stiffness=k, damping=d, friction_mu=mu, dt=dt, floor_z=floor_z, line_search="backtracking"),
