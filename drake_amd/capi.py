@@ -456,11 +456,15 @@ class GpuMpm:
         self._ck(self.lib.mpm_grid_to_particle(self.h, dt))
 
     def gpu_sync(self):
+        """GpuSync(state): waits for this engine's stream, runs what batched calls still owe and REPORTS the simulation's
+        sticky errors (DRIFT, DOMAIN, HALO, RANGE, CAPACITY) -- the call to poll for divergence."""
         self._ck(self.lib.mpm_sync(self.h))
 
     @staticmethod
     def device_synchronize():
-        """GpuMpmSolver::GpuSync() as the reference calls it: no state argument (cuda_mpm_solver.cu:164-166)."""
+        """GpuMpmSolver::GpuSync() as the reference calls it: no state argument (cuda_mpm_solver.cu:164-166).  Like
+        cudaDeviceSynchronize it reports runtime failures only: a simulation's sticky error flags are polled per engine,
+        with gpu_sync() or stats()["error_flags"]."""
         lib = load_library()
         rc = lib.mpm_device_synchronize()
         if rc:
