@@ -206,6 +206,46 @@ def test_coupled_substeps_in_one_call_equal_the_seven_calls():
     assert a.stats()["error_flags"] == 0 and b.stats()["error_flags"] == 0
 
 
+def _coupled_with(g, colliders, n, exact):
+    out = []
+    for _ in range(n):
+        g.rebuild_mapping(False)
+        g.calc_fem_state_and_force(DT)
+        g.particle_to_grid(DT)
+        g.update_grid(-1)
+        g.generate_contact_pairs(colliders, want_count=False)
+        out.append(g.update_contact(DT, MU, K, D, exact_line_search=exact))
+        g.grid_to_particle(DT)
+    g.gpu_sync()
+    return out
+
+
+@pytest.mark.parametrize("exact", [False, True])
+def test_coupled_substeps_with_several_bodies(exact):
+    """The same equality with what a scene of Drake's has: three colliders on two bodies -- the floor, a box standing on
+    it (body 0) and a sphere (body 1) that moves and spins, so that the rigid velocity at every contact point differs --, a
+    particle inside two of them at once (two pairs), both line searches.  The impulses come back per body."""
+    from drake_amd import Collider, scenes
+    cols = [Collider(0, body=0, p_WB=(0.5, 0.5, Z_FLOOR)),
+            Collider(2, body=0, p_WB=(0.42, 0.5, Z_FLOOR + 0.004), dims=(0.03, 0.05, 0.006)),
+            Collider(1, body=1, p_WB=(0.58, 0.5, Z_FLOOR + 0.03), dims=(0.035, 0, 0), v=(0.2, 0.0, -0.4), w=(0.0, 3.0, 1.0))]
+    sheets = scenes.cloth_stack(2, 36, 6, z0=Z_FLOOR - 0.001, side=0.3, seed=12, vel_amp=0.05)
+    for pos, vel, idx in sheets:
+        vel[:, 2] -= 0.3
+    a, b = _engine(None, sheets, bodies=2), _engine(None, sheets, bodies=2)
+    ra = _coupled_with(a, cols, 16, exact)
+    rb = b.run_coupled_substeps(6, DT, cols, MU, K, D, exact_line_search=exact) + \
+        b.run_coupled_substeps(10, DT, cols, MU, K, D, exact_line_search=exact)
+    b.gpu_sync()
+    assert a.stats()["error_flags"] == 0 and b.stats()["error_flags"] == 0
+    _same_rows(ra, rb, "iterations", "contacts", "residual")
+    assert max(r["contacts"] for r in rb) > 1500 and min(r["iterations"] for r in rb) >= 1
+    sa, sb = _state(a), _state(b)
+    _same(sa, sb)
+    # both bodies were pushed, the floor-and-box body downwards
+    assert sb["f"].shape[0] == 2 and sb["f"][0, 2] < 0 and np.abs(sb["f"][1]).max() > 0
+
+
 @pytest.mark.parametrize("gate_always", [False, True])
 def test_coupled_substeps_through_resorts(gate_always):
     """A cloth sliding over the floor at 6 m/s (a cell every 13 substeps: several re-sorts).  mpm_run_coupled_substeps sends
