@@ -21,5 +21,7 @@ for k in range(n):
         v1, v2 = g1.download(A.VELOCITIES), g2.download(A.VELOCITIES)
         errs.append(float(np.abs(v1 - v2).max()) / noise)
     st1, st2 = g1.stats(), g2.stats()
-    print(k, "err/noise per substep", " ".join(f"{e:6.2f}" for e in errs), "rebuilds", st1["rebuilds"], st2["rebuilds"], "worst particle", int(np.abs(v1 - v2).max(axis=1).argmax()), flush=True)
+    e5 = np.abs(v1 - v2).max(axis=1) / noise
+    print(k, "particles beyond 0.4 / 4 noises:", int((e5 > 0.4).sum()), int((e5 > 4).sum()), "of", len(e5), end="  ")
+    print("err/noise per substep", " ".join(f"{e:6.2f}" for e in errs), "rebuilds", st1["rebuilds"], st2["rebuilds"], "worst particle", int(np.abs(v1 - v2).max(axis=1).argmax()), flush=True)
     g1.destroy(); g2.destroy()
