@@ -254,7 +254,7 @@ def test_substep_equals_phase_calls():
     that sits on a branch point takes one side or the other with the last bit of its input.  scratch/substep_repeat.py,
     40 runs of this scene: in 30 the largest difference is 0.02-0.04 noises; in 8 face 2439 flips at substep 3 and ends
     6.3-6.9 noises apart (the same number every time: a discrete event, not a spread), in 2 face 2664 at substep 5
-    (3.6).  Hence: nine in ten particles within 0.4 noises (the bound this test always had for all), all but 0.5 %
+    (3.6).  Hence: nine in ten particles within 0.4 noises (the bound this test always had for all), all but 2 %
     within 4, nobody beyond 40."""
     A = _A()
     o, g1 = build_pair(seed=11)
@@ -273,7 +273,7 @@ def test_substep_equals_phase_calls():
     # particles beyond 0.4 noises, 6 - 7 of them beyond 4, in the four runs of forty that had one)
     order = np.argsort(np.abs(v1 - v2).max(axis=1))
     n = len(order)
-    for share, rtol, what in ((0.90, 1e-6, "nine in ten particles"), (0.995, 1e-5, "all but 0.5 % of the particles"), (1.0, 1e-4, "every particle")):
+    for share, rtol, what in ((0.90, 1e-6, "nine in ten particles"), (0.98, 1e-5, "all but 2 % of the particles"), (1.0, 1e-4, "every particle")):
         sel = order[: max(1, int(n * share))]
         close(v1[sel], v2[sel], scale=sc["vel"], rtol=rtol, what=f"substep vel ({what})")
 
