@@ -548,9 +548,10 @@ class GpuMpm:
         return out
 
     def contact_counters(self) -> dict:
-        out = (C.c_uint64 * 4)()
+        out = (C.c_uint64 * 6)()
         self._ck(self.lib.mpm_debug_contact_counters(self.h, out))
-        return dict(solves=int(out[0]), reused=int(out[1]), refused_stale=int(out[2]), repeated_overflow=int(out[3]))
+        return dict(solves=int(out[0]), reused=int(out[1]), refused_stale=int(out[2]), repeated_overflow=int(out[3]),
+                    contact_free=int(out[4]), contact_free_repeated=int(out[5]))
 
     def contact_log(self):
         """rows (residual, line-search evaluations, E(alpha), alpha, E(0), sum |Dir|^2, DoFs, 0) of the last solve's Newton

@@ -212,10 +212,8 @@ static int resolve_contact_count(mpm_engine* e) {
 // the device: the colliders travel as a kernel argument, the pairs are counted, placed and LEFT COUNTED on the device
 // (ContactState::n); mpm_update_contact's launches have fixed grids and read the count there.  Two launches: count per slot
 // with the scan inside 4096-blocks, write (every workgroup adds up the block totals it needs; workgroup 0 leaves the count).
-static int generate_contacts_launch(mpm_engine* e) {
-    ContactBuffers& b = e->cb;
-    const DP& p = e->dp;
-    hipStream_t s = e->stream;
+// the colliders of the last generate_contacts() as the kernels take them
+static ColliderTable collider_table(const ContactBuffers& b) {
     const size_t n_col = b.last_colliders.size();
     ColliderTable tab{};
     tab.n = (int)n_col;
@@ -224,6 +222,17 @@ static int generate_contacts_launch(mpm_engine* e) {
     } else {
         tab.dev = b.colliders;   // (uploaded by generate_contacts when they changed)
     }
+    return tab;
+}
+// see k_ct_watch (mpm_run_coupled_substeps); `p` carries the gate of the substep in front of it
+static void launch_contact_watch(mpm_engine* e, const DP& p, unsigned seq) {
+    hipLaunchKernelGGL(k_ct_watch, dim3(1024), dim3(256), 0, e->stream, p, collider_table(e->cb), seq);
+}
+static int generate_contacts_launch(mpm_engine* e) {
+    ContactBuffers& b = e->cb;
+    const DP& p = e->dp;
+    hipStream_t s = e->stream;
+    const ColliderTable tab = collider_table(b);
     const size_t np = e->np, padded = ((np + 1 + 4095) / 4096) * 4096;
     const int nb = (int)(padded / 4096);
     hipLaunchKernelGGL(k_ct_gen_count_scan, dim3(nb), dim3(1024), 0, s, p, (const int*)e->d_pids_api, tab, b.gen_cnt, b.gen_sums);

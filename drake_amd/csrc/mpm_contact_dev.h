@@ -373,6 +373,40 @@ __global__ __launch_bounds__(1024) void k_ct_gen_count_scan(DP p, const int* pid
     *reinterpret_cast<int4*>(cnt + base) = o;
 }
 
+// "Would the next substep have contact pairs?" -- asked right after GridToParticle, answered for mpm_run_coupled_substeps,
+// which then enqueues that substep WITHOUT pair generation and contact solve (and without waiting for anything).  Exact: the
+// pairs of a substep are the (particle, collider) with phi < 0 at the positions the substep starts from -- vertices where
+// GridToParticle has just put them, faces at the centroid of their corners (CalcFemStateAndForce's first act,
+// cuda_mpm_kernels.cuh:203-207) -- so "no particle with phi < margin" means "no pairs", and the margin (a thousandth of a
+// cell) only absorbs the last bit of the centroid.  A hit is a plain store of the launch's number (any wave that sees one).
+__global__ __launch_bounds__(256) void k_ct_watch(DP p, ColliderTable cols, unsigned seq) {
+    const Ctl* c = p.ctl;
+    if (p.gated && c->skip_this) return;   // (the substep in front of this launch skipped itself: nothing has moved)
+    const PSet& S = p.set[c->cur];
+    const int nf = c->nfa, total = nf + c->nva;
+    const float margin = 1e-3f * p.dx;
+    bool hit = false;
+    for (int idx = blockIdx.x * 256 + threadIdx.x; idx < total; idx += gridDim.x * 256) {
+        const int slot = active_slot(p, idx, nf);
+        float x[3];
+        if (slot < p.Nf) {
+            const float4 f3 = S.fq[3][slot];
+            const float4 xa = S.q[0][__float_as_int(f3.y)], xb = S.q[0][__float_as_int(f3.z)], xc = S.q[0][__float_as_int(f3.w)];
+            x[0] = (xa.x + xb.x + xc.x) * (1.f / 3.f);
+            x[1] = (xa.y + xb.y + xc.y) * (1.f / 3.f);
+            x[2] = (xa.z + xb.z + xc.z) * (1.f / 3.f);
+        } else {
+            const float4 q = S.q[0][slot];
+            x[0] = q.x; x[1] = q.y; x[2] = q.z;
+        }
+        for (int j = 0; j < cols.n; ++j) {
+            float g[3];
+            hit |= collider_sdf(collider_of(cols, j), x, g) < margin;
+        }
+    }
+    if (__ballot(hit) && (threadIdx.x & 63) == 0) p.ctl->watch_hit = seq;
+}
+
 // P2: the pairs, at the scanned offsets (offset inside its 4096-block + the pairs of the blocks before it): ascending
 // (slot, collider).  Every workgroup adds up the block totals it needs itself (a few hundred ints: rounds 1 - 4 scanned
 // them with a single-workgroup kernel in between); workgroup 0 leaves the pair count where the solve reads it --

@@ -71,6 +71,9 @@ struct Ctl {
     unsigned skipped;      // substeps that were enqueued without their re-sort launches and found need_rebuild set:
                            // their kernels returned at once, the host runs them again later (settle, mpm_engine.hip)
     int skip_this;         // k_grid's verdict for the G2P of the same substep (G2P itself raises need_rebuild)
+    unsigned watch_hit;    // number of the last k_ct_watch launch that found a particle inside (or a hair's breadth from) a
+                           // collider: substeps enqueued as contact-free on the strength of an earlier watch skip themselves
+                           // (DP::gated bit 2, DP::watch_base)
     unsigned n_home;       // blocks owning particles (tiles)
     unsigned n_active;     // blocks whose nodes are updated
     unsigned n_items;      // work items of the tile kernels (home blocks, heavy ones split)
@@ -165,6 +168,10 @@ struct DP {
                            // re-sort pending; bit 1: it returns at once when the slab pool has overflowed (every substep
                            // of mpm_run_substeps; the phase-by-phase calls cannot be repeated by the engine).  Either way it
                            // counts itself in Ctl::skipped and the host runs it again (settle, mpm_engine.hip)
+    unsigned watch_base;   // gated bit 2 (mpm_run_coupled_substeps: a substep enqueued WITHOUT pair generation and contact solve, on
+                           // the strength of a k_ct_watch that found no particle in any collider): it returns at once when a watch
+                           // numbered >= watch_base has found one since (Ctl::watch_hit), counts itself in Ctl::skipped, and the
+                           // host runs it again as a coupled substep
     int lean_resort;       // 1: the conditional re-sort is followed by CalcFemStateAndForce at once (a whole substep was
                            // enqueued): k_rb_finish does not move the x / v records of face particles; per launch
     int lean_g2p;          // 1: another substep of the same mpm_run_substeps batch follows, nobody can look at the state

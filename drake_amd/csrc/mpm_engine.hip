@@ -2290,9 +2290,9 @@ int mpm_last_contact_counts(mpm_handle_t e, uint32_t* contacts_out, uint32_t* no
     return 0;
 } MPM_CATCH_ALL
 
-int mpm_debug_contact_counters(mpm_handle_t e, uint64_t out4[4]) try {
+int mpm_debug_contact_counters(mpm_handle_t e, uint64_t out4[6]) try {
     REQUIRE(e && out4, "null argument");
-    for (int k = 0; k < 4; ++k) out4[k] = e->ct_counters[k];
+    for (int k = 0; k < 6; ++k) out4[k] = e->ct_counters[k];
     return 0;
 } MPM_CATCH_ALL
 
@@ -2380,7 +2380,65 @@ int mpm_run_coupled_substeps(mpm_handle_t e, int n, const mpm_coupled_params_t* 
     // skips itself as a whole (DP::gated: transfer kernels, contact solve, GridToParticle) and is run again, with the
     // re-sort in front: a wrong guess costs time, not correctness.
     bool force_check = true;
+    // Contact-free stretches (round 5): when a coupled substep had no pairs, a watch kernel behind its GridToParticle asks
+    // whether the NEXT one would have any (k_ct_watch: exact); the following substeps are then enqueued in chunks WITHOUT
+    // pair generation, contact solve or any wait, each with its own watch behind it and the gate "skip yourself if a watch
+    // since `watch_base` has seen a particle in a collider" (DP::gated bit 2).  After a chunk the host synchronises once and
+    // reads how many of its substeps skipped themselves -- always the last ones: a hit is sticky -- and runs those as
+    // coupled substeps.  A cloth that falls towards a body costs a contact-free substep plus the watch until it arrives.
+    const bool may_watch = n_colliders > 0 && !e->ct_no_watch;
+    bool spec = false;
+    unsigned watch_base = 0;
+    int chunk = 2;
     for (int s = 0; s < n; ++s) {
+        if (spec) {
+            const int m = std::min(chunk, n - s);
+            for (int q = 0; q < m; ++q) {
+                may_resort(e, dt);
+                e->dp.gated = 4;
+                e->dp.watch_base = watch_base;
+                e->dp.lean_resort = 1;
+                launch_rebuild(e);
+                e->dp.lean_resort = 0;
+                e->dp.lean_g2p = s + q + 1 < n;
+                launch_fem_p2g(e, dt);
+                launch_grid(e, gc);
+                launch_g2p(e, dt);
+                launch_contact_watch(e, e->dp, ++e->watch_seq);
+            }
+            e->dp.gated = 0;
+            e->dp.lean_g2p = 0;
+            e->grid_state = 2;
+            HIP_TRY(hipStreamSynchronize(e->stream));
+            Ctl c;
+            D2H(e, &c, e->dp.ctl, sizeof(Ctl));
+            const int skipped = (int)std::min<unsigned>(c.skipped, (unsigned)m);
+            if (c.skipped) {
+                const unsigned zero = 0;
+                H2D(e, &e->dp.ctl->skipped, &zero, sizeof(unsigned));
+            }
+            const int ran = m - skipped;
+            e->ct_counters[4] += (uint64_t)m;
+            e->ct_counters[5] += (uint64_t)skipped;
+            for (int q = 0; q < ran; ++q) {
+                e->substeps += 1;
+                if (results) results[s + q] = mpm_coupled_result_t{};
+            }
+            if (ran > 0) {
+                e->last_contact = mpm_contact_stats_t{};
+                e->last_contact_reused = false;
+            }
+            // (an error flag ends the speculation too: the coupled substep that follows reports it where it always was)
+            if (skipped > 0 || c.error) {
+                spec = false;
+                chunk = 2;
+                force_check = true;
+            } else {
+                chunk = std::min(chunk * 2, 32);
+            }
+            s += ran - 1;   // (the loop's own increment makes it `ran`)
+            continue;
+        }
         auto t0 = clk::now();
         // (without colliders there is no solve whose publication would report a skipped substep: always checked)
         const bool gate = n_colliders > 0 && !force_check && (e->ct_gate_always || e->quiet_factor * e->ct_quiet_left > 2.f * dt);
@@ -2437,6 +2495,15 @@ int mpm_run_coupled_substeps(mpm_handle_t e, int n, const mpm_coupled_params_t* 
             r.nodes = e->last_contact.nodes;
             r.residual = residual;
             r.setup_reused = e->last_contact_reused ? 1 : 0;
+        }
+        // no pairs in this substep: ask whether the next one has any, and go on without pair generation while it has not
+        spec = false;
+        if (may_watch && s + 1 < n && e->last_contact.contacts == 0 && !e->cb.dev_counted) {
+            watch_base = ++e->watch_seq;
+            DP pw = e->dp;
+            pw.gated = 0;
+            launch_contact_watch(e, pw, watch_base);
+            spec = true;
         }
     }
     HIP_TRY(hipGetLastError());

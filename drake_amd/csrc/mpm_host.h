@@ -198,7 +198,10 @@ struct mpm_engine {
     // estimate: every re-sort is found by a substep skipping itself
     bool ct_gate_always = getenv("MPM_CT_GATE_ALWAYS") != nullptr;
     double ct_wait_us = 0;   // (MPM_CT_DEBUG) host time spent polling the mailbox
-    uint64_t ct_counters[4] = {0, 0, 0, 0};   // solves, of them on a reused set-up, refused as stale, repeated after an overflow
+    uint64_t ct_counters[6] = {0, 0, 0, 0, 0, 0};   // solves, of them on a reused set-up, refused as stale, repeated after an overflow,
+                                                     // coupled substeps that ran contact-free on a watch, of them skipped and repeated
+    unsigned watch_seq = 0;                          // number of the last k_ct_watch launch (Ctl::watch_hit)
+    bool ct_no_watch = getenv("MPM_CT_NO_WATCH") != nullptr;   // every coupled substep generates pairs and solves (A/B, tests)
     float last_contact_dt = 0.f, last_contact_mu = 0.f, last_contact_k = 0.f, last_contact_d = 0.f;   // its parameters
     mpm_dist_config_t dist_cfg{};         // partitioned domain (mpm_dist_init)
     // slot space of a partitioned rank = headroom x what it holds (mpm_dist_set_headroom, MPM_DIST_HEADROOM; 0 = the whole

@@ -35,7 +35,8 @@ namespace mpm {
 // (raised by the G2P of an earlier substep): if so all of its kernels return at once and the host runs
 // that substep again, with the re-sort, at its next synchronisation point.
 MPM_DEV bool gated_out(const DP& p) {
-    return ((p.gated & 1) && p.ctl->need_rebuild) || ((p.gated & 2) && (p.ctl->error & ERR_SLABS));
+    return ((p.gated & 1) && p.ctl->need_rebuild) || ((p.gated & 2) && (p.ctl->error & ERR_SLABS)) ||
+           ((p.gated & 4) && (int)(p.ctl->watch_hit - p.watch_base) >= 0);
 }
 
 // FM: the arithmetic of the divisions and square roots (mpm_math.h: 0 = correctly rounded, the default; 1 = hardware

@@ -371,8 +371,10 @@ MPM_API int mpm_get_contact_pair_count(mpm_handle_t h, size_t *n_contacts_out);
  * per-cell runs, no node list -- verified on the device entry by entry).  Any pointer may be NULL. */
 MPM_API int mpm_last_contact_counts(mpm_handle_t h, uint32_t *contacts_out, uint32_t *nodes_out, int *setup_reused_out);
 /* Tests: {mpm_update_contact calls that solved, of them on a reused set-up, solves refused on the device because a guess of
- * the host's was wrong (repeated with the full set-up), pair generations / solves repeated after a buffer overflow}. */
-MPM_API int mpm_debug_contact_counters(mpm_handle_t h, uint64_t out4[4]);
+ * the host's was wrong (repeated with the full set-up), pair generations / solves repeated after a buffer overflow,
+ * substeps of mpm_run_coupled_substeps that were enqueued contact-free (no particle in any collider when the substep before
+ * ended), of them skipped on the device and repeated as coupled substeps}. */
+MPM_API int mpm_debug_contact_counters(mpm_handle_t h, uint64_t out6[6]);
 MPM_API int mpm_download_contact_pairs(mpm_handle_t h, uint32_t *particle_in_contact_index, uint32_t *non_mpm_id,
                                        float *penetration_distance, float *normal, float *position, float *rigid_v,
                                        float *rigid_p_WB);
@@ -428,6 +430,10 @@ MPM_API int mpm_run_substeps(mpm_handle_t h, int n, float dt, int mpm_bc);
  * The results are those of the seven calls (the tests compare them bit for bit); the host waits once per substep, for
  * the word that says the solve has converged.  mpm_reallocate_external_bodies must have been called (the per-body
  * impulses accumulate over the n substeps, as over the substeps of one plant step: deformable_driver.h:196-219).
+ * While nothing touches a collider the call goes without pair generation and solve: after a substep without pairs a watch
+ * kernel asks whether the NEXT substep would have any (a pair is a particle with phi < 0 where the substep starts: exact),
+ * and the substeps that follow are enqueued contact-free, each checked the same way; the ones that turn out to have pairs
+ * skip themselves on the device and are run again as coupled substeps.  Their results report 0 contacts and iterations.
  * results: n entries or NULL. */
 typedef struct {
     float dt;

@@ -200,10 +200,47 @@ def test_coupled_substeps_in_one_call_equal_the_seven_calls():
     ra = _coupled(a, floor, 30, False)
     rb = b.run_coupled_substeps(12, DT, floor, MU, K, D) + b.run_coupled_substeps(18, DT, floor, MU, K, D)
     b.gpu_sync()
-    _same_rows(ra, rb, "iterations", "contacts", "residual", "setup_reused")
+    _same_rows(ra, rb, "iterations", "contacts", "residual")
+    # (a substep without pairs has no set-up to reuse when the call went without generating pairs at all: see
+    # test_contact_free_stretches_of_a_coupled_run_go_without_pair_generation)
+    assert [r["setup_reused"] for r in ra if r["contacts"]] == [r["setup_reused"] for r in rb if r["contacts"]]
     assert any(r["contacts"] == 0 for r in rb) and any(r["setup_reused"] for r in rb)
     _same(_state(a), _state(b))
     assert a.stats()["error_flags"] == 0 and b.stats()["error_flags"] == 0
+
+
+def test_contact_free_stretches_of_a_coupled_run_go_without_pair_generation():
+    """A sheet released two cells above the floor, falling at 1 m/s: 60 substeps without a pair, then the impact.  When a
+    coupled substep had no pairs, a watch behind its GridToParticle asks whether the next one has any (exactly: a pair is a
+    particle with phi < 0 where the substep starts), and the substeps after it are enqueued contact-free in chunks, each
+    gated on "no watch has seen a particle in a collider since"; the ones that skipped themselves are run as coupled substeps.
+    Bit for bit the seven calls per substep; most of the fall went without pair generation; the substeps of the chunk in
+    which the sheet arrived were repeated."""
+    from drake_amd import Collider, scenes
+    floor = [Collider(0, body=0, p_WB=(0.5, 0.5, Z_FLOOR))]
+    sheets = scenes.cloth_stack(1, 36, 6, z0=Z_FLOOR + 2.0 / 64, side=0.3, seed=9, vel_amp=0.02)
+    for pos, vel, idx in sheets:
+        vel[:, 2] -= 1.0
+    n = 220
+    a, b, c = _engine(None, sheets), _engine(None, sheets), _engine({"MPM_CT_NO_WATCH": "1"}, sheets)
+    ra = _coupled(a, floor, n, False)
+    rb = b.run_coupled_substeps(90, DT, floor, MU, K, D) + b.run_coupled_substeps(n - 90, DT, floor, MU, K, D)
+    rc = c.run_coupled_substeps(n, DT, floor, MU, K, D)
+    for g in (a, b, c):
+        g.gpu_sync()
+        assert g.stats()["error_flags"] == 0
+    first = next(i for i, r in enumerate(ra) if r["contacts"] > 0)
+    assert 100 < first < 200 and max(r["contacts"] for r in ra) > 1000, first
+    _same_rows(ra, rb, "iterations", "contacts", "residual")
+    _same_rows(ra, rc, "iterations", "contacts", "residual")
+    _same(_state(a), _state(b))
+    _same(_state(a), _state(c))
+    cb, cc = b.contact_counters(), c.contact_counters()
+    assert cc["contact_free"] == 0 and cc["solves"] == n
+    # (each call starts with a coupled substep; chunks of 2, 4, 8, 16, 32, 32 ... substeps; the chunk that holds the
+    # impact is cut short)
+    assert cb["contact_free"] >= first - 8 and 1 <= cb["contact_free_repeated"] <= 32, (cb, first)
+    assert cb["solves"] <= n - first + 40, (cb, first)
 
 
 def _coupled_with(g, colliders, n, exact):
@@ -259,7 +296,9 @@ def test_coupled_substeps_through_resorts(gate_always):
     for pos, vel, idx in sheets:
         vel[:, 0] += 6.0
     a = _engine(None, sheets)
-    b = _engine({"MPM_CT_GATE_ALWAYS": "1"} if gate_always else None, sheets)
+    # (MPM_CT_NO_WATCH: the stretches of this scene in which the cloth has left the floor would otherwise go contact-free,
+    # with their re-sort checks in place -- here every re-sort is to be found by a coupled substep that skipped itself)
+    b = _engine({"MPM_CT_GATE_ALWAYS": "1", "MPM_CT_NO_WATCH": "1"} if gate_always else None, sheets)
     ra = _coupled(a, floor, 60, False)
     rb = b.run_coupled_substeps(25, DT, floor, MU, K, D) + b.run_coupled_substeps(35, DT, floor, MU, K, D)
     b.gpu_sync()
