@@ -2387,19 +2387,28 @@ int mpm_run_coupled_substeps(mpm_handle_t e, int n, const mpm_coupled_params_t* 
     // reads how many of its substeps skipped themselves -- always the last ones: a hit is sticky -- and runs those as
     // coupled substeps.  A cloth that falls towards a body costs a contact-free substep plus the watch until it arrives.
     const bool may_watch = n_colliders > 0 && !e->ct_no_watch;
-    bool spec = false;
+    bool spec = false, spec_check = true;
+    float spec_quiet_left = 0.f;
     unsigned watch_base = 0;
     int chunk = 2;
     for (int s = 0; s < n; ++s) {
         if (spec) {
             const int m = std::min(chunk, n - s);
+            // (the re-sort checks of a chunk: none while the quiet time lasts that the last look at the control block left
+            // -- a substep that meets a pending re-sort then skips itself like one that meets a hit, and the chunk's tail is
+            // repeated with the checks --, else with every substep)
+            float quiet = spec_check ? 0.f : e->quiet_factor * spec_quiet_left;
             for (int q = 0; q < m; ++q) {
+                const bool unchecked = quiet > 2.f * dt;
+                quiet -= dt;
                 may_resort(e, dt);
-                e->dp.gated = 4;
+                e->dp.gated = 4 | (unchecked ? 1 : 0);
                 e->dp.watch_base = watch_base;
-                e->dp.lean_resort = 1;
-                launch_rebuild(e);
-                e->dp.lean_resort = 0;
+                if (!unchecked) {
+                    e->dp.lean_resort = 1;
+                    launch_rebuild(e);
+                    e->dp.lean_resort = 0;
+                }
                 e->dp.lean_g2p = s + q + 1 < n;
                 launch_fem_p2g(e, dt);
                 launch_grid(e, gc);
@@ -2418,6 +2427,7 @@ int mpm_run_coupled_substeps(mpm_handle_t e, int n, const mpm_coupled_params_t* 
                 H2D(e, &e->dp.ctl->skipped, &zero, sizeof(unsigned));
             }
             const int ran = m - skipped;
+            const bool hit = (int)(c.watch_hit - watch_base) >= 0;
             e->ct_counters[4] += (uint64_t)m;
             e->ct_counters[5] += (uint64_t)skipped;
             for (int q = 0; q < ran; ++q) {
@@ -2428,11 +2438,15 @@ int mpm_run_coupled_substeps(mpm_handle_t e, int n, const mpm_coupled_params_t* 
                 e->last_contact = mpm_contact_stats_t{};
                 e->last_contact_reused = false;
             }
+            spec_quiet_left = c.need_rebuild || c.error ? 0.f : std::max(0.f, c.quiet_time - c.time_since_resort);
+            spec_check = skipped > 0;   // (whatever made them skip: the repeated ones carry their checks)
             // (an error flag ends the speculation too: the coupled substep that follows reports it where it always was)
-            if (skipped > 0 || c.error) {
+            if (hit || c.error) {
                 spec = false;
                 chunk = 2;
                 force_check = true;
+            } else if (skipped > 0) {
+                chunk = 2;           // a re-sort was pending: the tail of the chunk again, contact-free, with its checks
             } else {
                 chunk = std::min(chunk * 2, 32);
             }
@@ -2504,6 +2518,8 @@ int mpm_run_coupled_substeps(mpm_handle_t e, int n, const mpm_coupled_params_t* 
             pw.gated = 0;
             launch_contact_watch(e, pw, watch_base);
             spec = true;
+            spec_check = false;
+            spec_quiet_left = e->ct_quiet_left;   // (what the solve's publication said is left of the quiet time)
         }
     }
     HIP_TRY(hipGetLastError());
