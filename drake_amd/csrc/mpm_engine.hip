@@ -2353,6 +2353,11 @@ int mpm_run_coupled_substeps(mpm_handle_t e, int n, const mpm_coupled_params_t* 
     REQUIRE(n_colliders == 0 || colliders, "null collider array");
     REQUIRE(n_colliders <= 1024, "too many colliders");
     REQUIRE(!e->dp.dist.on, "mpm_run_coupled_substeps: not on a partitioned domain (use the phase calls)");
+    if (n_colliders == 0) {   // nothing to couple with: contact-free substeps
+        if (results)
+            for (int s = 0; s < n; ++s) results[s] = mpm_coupled_result_t{};
+        return mpm_run_substeps(e, n, prm->dt, prm->mpm_bc);
+    }
     GridColliders gc;
     if (int rc = grid_colliders_for(e, prm->mpm_bc, &gc)) return rc;
     const float dt = prm->dt;

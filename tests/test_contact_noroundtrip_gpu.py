@@ -268,6 +268,18 @@ def test_contact_free_stretches_through_resorts():
     assert cb["contact_free"] >= n - 2 and cb["solves"] <= 2, cb
 
 
+def test_coupled_substeps_without_colliders_are_contact_free_substeps():
+    from drake_amd import scenes
+    sheets = scenes.cloth_stack(2, 30, 6, z0=Z_FLOOR, side=0.3, seed=2, vel_amp=0.2)
+    a, b = _engine(None, sheets), _engine(None, sheets)
+    a.run_substeps(12, DT, -1)
+    rb = b.run_coupled_substeps(12, DT, [], MU, K, D)
+    a.gpu_sync()
+    b.gpu_sync()
+    assert all(r["contacts"] == 0 and r["iterations"] == 0 for r in rb) and b.contact_counters()["solves"] == 0
+    _same(_state(a), _state(b))
+
+
 def _coupled_with(g, colliders, n, exact):
     out = []
     for _ in range(n):
