@@ -140,6 +140,7 @@ SYMBOLS = [
     "mpm_dist_plan_migration", "mpm_debug_throw", "mpm_debug_fail_alloc", "mpm_set_fast_math", "mpm_get_fast_math",
     "mpm_get_contact_pair_count", "mpm_download_contact_log", "mpm_last_contact_counts",
     "mpm_debug_contact_counters", "mpm_run_coupled_substeps", "mpm_chain_direct_prepare", "mpm_chain_direct_connect",
+    "mpm_debug_contact_count",
 ]
 
 EXCHANGE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t)
@@ -237,6 +238,7 @@ def load_library(build: bool = True):
         "mpm_last_contact_counts": [vp, P(C.c_uint32), P(C.c_uint32), P(i)],
         "mpm_download_contact_log": [vp, vp, sz, P(sz)],
         "mpm_debug_contact_counters": [vp, P(C.c_uint64)],
+        "mpm_debug_contact_count": [vp, i, i],
         "mpm_run_coupled_substeps": [vp, i, vp, sz, vp, vp],
         "mpm_get_fast_math": [vp, P(i)],
         "mpm_substep_begin_halo": [vp, f, i, P(C.c_int), P(C.c_int), P(C.c_int), P(C.c_void_p), sz],
@@ -552,6 +554,10 @@ class GpuMpm:
         self._ck(self.lib.mpm_debug_contact_counters(self.h, out))
         return dict(solves=int(out[0]), reused=int(out[1]), refused_stale=int(out[2]), repeated_overflow=int(out[3]),
                     contact_free=int(out[4]), contact_free_repeated=int(out[5]))
+
+    def debug_contact_count(self, count: int = -1, stamp_delta: int = 0):
+        """tests: tamper with the pair count that generate_contact_pairs(want_count=False) left on the device"""
+        self._ck(self.lib.mpm_debug_contact_count(self.h, count, stamp_delta))
 
     def contact_log(self):
         """rows (residual, line-search evaluations, E(alpha), alpha, E(0), sum |Dir|^2, DoFs, 0) of the last solve's Newton

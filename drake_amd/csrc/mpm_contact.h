@@ -64,7 +64,9 @@ static int ensure_contact_capacity(mpm_engine* e, size_t n) {
         }
     }
     {
-        const size_t want = sort_hist_ints(b.cap);   // (sized for the capacity: the count may live on the device)
+        // (sized for every launch bound n <= capacity: the count may live on the device, and a bound below 2^18 pairs
+        // makes MORE tiles than the capacity itself when that lies above -- smaller tiles --: round 6, a latent overrun)
+        const size_t want = sort_hist_ints_upto(b.cap);
         if (want > b.cap_hist) {
             if (int rc = grow(&b.sort_hist, want)) return rc;
             b.cap_hist = want;
@@ -195,7 +197,14 @@ static int resolve_contact_count(mpm_engine* e) {
         int three[3] = {0, 0, 0};   // n, n_wanted, gen_fault
         D2H(e, three, &b.st->n, 12);
         if (!three[2]) {
-            b.n = (size_t)std::max(three[0], 0);
+            // (a count off the device: checked before anything is sized from it or indexed with it)
+            if (three[0] < 0 || (size_t)three[0] > b.cap) {
+                b.n = 0;
+                b.dev_counted = false;
+                return fail(MPM_ERR_CAPACITY, "contact pairs: the count on the device (" + std::to_string(three[0]) +
+                                                  ") is outside the capacity of the pair buffers (" + std::to_string(b.cap) + ")");
+            }
+            b.n = (size_t)three[0];
             b.dev_counted = false;
             return 0;
         }
@@ -241,8 +250,9 @@ static int generate_contacts_launch(mpm_engine* e) {
     c.st = b.st;
     c.slot = b.slot; c.body = b.body; c.dist = b.dist; c.normal = b.normal; c.pos = b.pos;
     c.rigid_v = b.rigid_v; c.p_WB = b.p_WB; c.vel = b.vel;
+    b.gen_stamp += 1;   // (the solve that follows names this generation: k_ct_keys refuses a count another one left)
     hipLaunchKernelGGL(k_ct_gen_write, dim3(e->g_np), dim3(256), 0, s, p, (const int*)e->d_pids_api, tab, (const int*)b.gen_cnt,
-                       (const int*)b.gen_sums, nb, (int)std::min<size_t>(b.cap, 0x7FFFFFFF), b.api_idx, c);
+                       (const int*)b.gen_sums, nb, (int)std::min<size_t>(b.cap, 0x7FFFFFFF), b.api_idx, c, b.gen_stamp);
     HIP_TRY(hipGetLastError());
     b.dev_counted = true;
     b.n = 0;
@@ -336,7 +346,9 @@ static ContactDev make_contact_dev(mpm_engine* e, float dt, float mu, float k, f
     c.mbox = b.d_mbox;
     c.ctl = e->dp.ctl;
     c.prev_key = b.prev_key; c.prev_api = b.prev_api; c.prev_body = b.prev_body;
-    c.body_tau = b.body_tau; c.body_f = b.body_f; c.n_bodies = (int)b.n_bodies;
+    c.body_acc = b.body_acc; c.n_bodies = (int)b.n_bodies;
+    c.imp_fix = e->dp.fix_p;
+    b.imp_unfix = e->dp.unfix_p;
     return c;
 }
 
@@ -527,6 +539,20 @@ static int update_contact(mpm_engine* e, int frame, int substep, float dt, float
         if (int rc = solve_once(e, dt, mu, stiffness, damping, exact, max_iters, full_setup, &oc, &s_res, &s_ls, &s_energy,
                                 &s_alpha_last, &s_E0_last))
             return rc;
+        if (oc.mb.done == CT_DONE_CORRUPT) {
+            // the count on the device is not one the solve may index with; nothing ran, nothing is repeated: the pairs
+            // have to be made again (mpm_generate_contact_pairs / mpm_copy_contact_pairs) before the next solve
+            const long long raw = (long long)(int)oc.mb.count;
+            b.dev_counted = false;
+            b.n = 0;
+            b.last_unchanged = false;
+            if (raw < 0 || (size_t)raw > b.cap)
+                return fail(MPM_ERR_CAPACITY, "contact solve: the pair count on the device (" + std::to_string(raw) +
+                                                  ") is outside the capacity that sized the per-pair buffers (" + std::to_string(b.cap) +
+                                                  "): nothing was indexed with it, nothing was solved; make the pairs again");
+            return fail(MPM_ERR_INTERNAL, "contact solve: the pair count on the device was not written by the pair generation this "
+                                          "solve was enqueued for (a stale count): nothing was solved; make the pairs again");
+        }
         if (oc.mb.done == CT_DONE_FAULT) {
             e->ct_counters[3] += 1;
             if (int rc = ensure_contact_capacity(e, (size_t)oc.mb.count)) return rc;
@@ -695,7 +721,7 @@ static int solve_once(mpm_engine* e, float dt, float mu, float stiffness, float 
     {
         ContactDev c_in = make_contact_dev(e, dt, mu, stiffness, damping, max_iters, /* sorted = */ false);
         hipLaunchKernelGGL(k_ct_keys, dim3(1024), dim3(256), 0, s, p, c_in, (const uint32_t*)b.api_idx, (const int*)e->d_pids_api, b.slot,
-                           b.published, b.solves, bits, (int)std::min<size_t>(n, 0x7FFFFFFF), reuse ? 1 : 0, full_setup ? 1 : 0);
+                           b.published, b.solves, bits, (int)std::min<size_t>(n, 0x7FFFFFFF), reuse ? 1 : 0, full_setup ? 1 : 0, b.gen_stamp);
     }
     if (!reuse) {
         // CT_NO_CELL has all those bits set and more: it sorts behind every real cell as long as
@@ -897,7 +923,8 @@ static int solve_once(mpm_engine* e, float dt, float mu, float stiffness, float 
     // over and the device's queue is short -- a long kernel first gives the host time to enqueue what follows; the
     // impulses read the grid velocities and the contact arrays, which GridToParticle does not touch)
     // (not behind a solve that refused itself: the caller repeats that one, and GridToParticle belongs behind the repeat)
-    if (e->ct_before_impulse && (host_driven || (oc->mb.done != CT_DONE_FAULT && oc->mb.done != CT_DONE_STALE))) e->ct_before_impulse();
+    if (e->ct_before_impulse && (host_driven || (oc->mb.done != CT_DONE_FAULT && oc->mb.done != CT_DONE_STALE && oc->mb.done != CT_DONE_CORRUPT)))
+        e->ct_before_impulse();
     hipLaunchKernelGGL(k_ct_impulse, dim3(std::min(gc, 256u)), dim3(256), 0, s, p, c);
     HIP_TRY(hipGetLastError());
     if (host_driven) {

@@ -79,6 +79,8 @@ struct ContactState {       // device-resident solver state
     int n;                  // contacts the solve works on (<= capacity)
     int n_wanted;           // pairs the scene has (mpm_generate_contact_pairs)
     int gen_fault;          // n_wanted > capacity
+    unsigned n_stamp;       // number of the pair generation that wrote the three words above (k_ct_gen_write's argument): the
+                            // solve is enqueued for ONE generation and refuses a count that another one left (k_ct_keys)
     unsigned seq;           // publications in the mailbox so far (k_ct_decide, k_ct_exact_finish); the host re-bases it
                             // with every solve (k_ct_keys)
     // settled scenes: the pair list of this solve equals the previous solve's entry by entry (same particle, same body,
@@ -93,6 +95,13 @@ constexpr int CT_DONE_FAULT = 4;     // ContactState::done: the pair buffers ove
 constexpr int CT_DONE_STALE = 5;     // ... a speculated set-up (previous solve's order reused) did not match, nothing was solved
 constexpr int CT_DONE_GATED = 6;     // ... the substep was enqueued without its re-sort launches and found a re-sort pending: all of
                                      // it skipped itself (DP::gated), the host runs it again with the re-sort in front
+constexpr int CT_DONE_CORRUPT = 7;   // ... the pair count on the device is not one this solve may index with: negative, larger than
+                                     // the capacity that sized the per-pair buffers (MPM_ERR_CAPACITY), or left by another pair
+                                     // generation than the one the solve was enqueued for (MPM_ERR_INTERNAL).  Nothing was solved,
+                                     // nothing was indexed with it, and the host does NOT repeat the call: it reports the error.
+                                     // (Round 5's memory access fault -- DESIGN.md section 3.3 -- was a launch that indexed a
+                                     // per-pair array from its workgroup number alone; the invariant since: EVERY index into a
+                                     // per-pair array is formed from ct_count(), which is clamped to ContactDev::stride.)
 
 // Mailbox in host-mapped pinned memory: what the host polls instead of copying the state back after every batch of
 // iterations (a blit kernel of ~4 us on the engine's stream per read-back, 8 - 20 per solve).  Four
@@ -152,8 +161,8 @@ struct ContactDev {
     uint32_t *prev_key, *prev_api, *prev_body;
     float* it_log;          // [CT_LOG][CT_LOG_F] per Newton iteration: residual, line-search evaluations, E(alpha), alpha,
                             // E(0), sum |Dir|^2, DoFs (both searches; mpm_download_contact_log)
-    float* body_tau;
-    float* body_f;
+    long long* body_acc;    // [n_bodies][6] (tau, f) impulse sums in 64-bit fixed point (k_ct_impulse)
+    double imp_fix;         // its scale (DP::fix_p: the momentum scale of ParticleToGrid's tiles)
     int n_bodies;
 };
 
@@ -211,18 +220,22 @@ struct ContactBuffers {
     unsigned published = 0;             // publications enqueued so far (the device's ContactState::seq follows it)
     unsigned solves = 0;                // mpm_update_contact calls so far (numbers the "unchanged" test)
     bool dev_counted = false;           // the pairs in the buffers were counted on the device and the host has not read the count
+    unsigned gen_stamp = 0;             // pair generations launched so far (ContactState::n_stamp follows it)
     uint32_t *prev_key = nullptr, *prev_api = nullptr, *prev_body = nullptr;
     // the colliders of the last mpm_generate_contact_pairs (a buffer overflow repeats the generation)
     std::vector<Collider> last_colliders;
     bool sorted_in_alt = false;         // the sorted (key, order) of the last set-up sit in key2 / order2
     bool last_unchanged = false;        // the last solve found its pair list equal to its predecessor's
-    float* body_tau = nullptr;  // F_Bq_W_tau
-    float* body_f = nullptr;    // F_Bq_W_f
+    // F_Bq_W_tau / F_Bq_W_f of the reference (cuda_mpm_model.cuh: float arrays fed by float atomics, whose sums depend on
+    // the order of arrival): accumulated in 64-bit fixed point -- integer sums, exact and independent of the order --
+    // and converted when ExternelBodyForceToHost downloads them.  [body][tau xyz, f xyz]
+    long long* body_acc = nullptr;
+    double imp_unfix = 0.0;     // 1 / scale of what has been accumulated since the last reset
 
     void release() {
         void* ptrs[] = {api_idx, colliders, gen_cnt, gen_sums, slot, body, dist, normal, pos, rigid_v, p_WB, vel, vel0, key, order, key2, order2, sort_hist,
                         cnode, cfx, cmass, cphi0, cR, cv0, crv, cvel, run, node_flag, flag_bits, node_list, node_runs, seg_part, gD, hg,
-                        zone_buf[0], zone_buf[1], zone_buf[2], zone_buf[3], part, part_dir, st, it_log, body_tau, body_f,
+                        zone_buf[0], zone_buf[1], zone_buf[2], zone_buf[3], part, part_dir, st, it_log, body_acc,
                         prev_key, prev_api, prev_body};
         for (void* q : ptrs)
             if (q) (void)hipFree(q);
@@ -235,19 +248,14 @@ struct ContactBuffers {
     }
     int resize_bodies(size_t nb, hipStream_t s) {
         if (nb > cap_bodies) {
-            if (body_tau) (void)hipFree(body_tau);
-            if (body_f) (void)hipFree(body_f);
-            body_tau = body_f = nullptr;
-            if (hipMalloc((void**)&body_tau, nb * 12) != hipSuccess) return -2;
-            if (hipMalloc((void**)&body_f, nb * 12) != hipSuccess) return -2;
+            if (body_acc) (void)hipFree(body_acc);
+            body_acc = nullptr;
+            if (hipMalloc((void**)&body_acc, nb * 6 * sizeof(long long)) != hipSuccess) return -2;
             cap_bodies = nb;
         }
         n_bodies = nb;
         // reset at the beginning of each time step (cuda_mpm_model.cu:334-337)
-        if (cap_bodies) {
-            if (hipMemsetAsync(body_tau, 0, cap_bodies * 12, s) != hipSuccess) return -2;
-            if (hipMemsetAsync(body_f, 0, cap_bodies * 12, s) != hipSuccess) return -2;
-        }
+        if (cap_bodies && hipMemsetAsync(body_acc, 0, cap_bodies * 6 * sizeof(long long), s) != hipSuccess) return -2;
         return 0;
     }
 };
@@ -321,7 +329,11 @@ MPM_DEV const Collider& collider_of(const ColliderTable& t, int j) { return t.de
 
 // this solve's contact count: the host's when it knows it, else the device's (mpm_generate_contact_pairs without a
 // read-back)
-MPM_DEV int ct_count(const ContactDev& c) { return c.n >= 0 ? c.n : c.st->n; }
+// ALWAYS inside the capacity that sized the per-pair arrays (ContactDev::stride), whatever the word on the device holds:
+// a count that is negative or larger is a corrupt one -- k_ct_keys refuses the solve for it (CT_DONE_CORRUPT) --, but no
+// kernel may index with it before, after or instead of that refusal.
+MPM_DEV int ct_count_raw(const ContactDev& c) { return c.n >= 0 ? c.n : c.st->n; }
+MPM_DEV int ct_count(const ContactDev& c) { return min(max(ct_count_raw(c), 0), c.stride); }
 
 // P1: number of penetrated colliders per particle slot (the caller's slot order), 0 in the padding of the scan's storage.
 // With the scan inside 4096-blocks in ONE launch (round 5: a kernel boundary and k_scan_blocks' 5 us less per coupled
@@ -412,7 +424,8 @@ __global__ __launch_bounds__(256) void k_ct_watch(DP p, ColliderTable cols, unsi
 // them with a single-workgroup kernel in between); workgroup 0 leaves the pair count where the solve reads it --
 // ContactState::n / n_wanted / gen_fault -- instead of sending it to the host.
 __global__ __launch_bounds__(256) void k_ct_gen_write(DP p, const int* pids_api, ColliderTable cols, const int* offs,
-                                                      const int* sums, int nb, int cap, uint32_t* api_idx, ContactDev c) {
+                                                      const int* sums, int nb, int cap, uint32_t* api_idx, ContactDev c,
+                                                      unsigned stamp) {
     __shared__ int s_part[4];
     const int first = (int)(blockIdx.x * 256u) >> 12;   // 4096-block of this workgroup's first slot; a workgroup of 256 slots
                                                          // never straddles two (4096 is a multiple of 256)
@@ -440,6 +453,7 @@ __global__ __launch_bounds__(256) void k_ct_gen_write(DP p, const int* pids_api,
         st->n_wanted = total;
         st->n = min(total, cap);
         st->gen_fault = total > cap ? 1 : 0;
+        st->n_stamp = stamp;
     }
     const int s = blockIdx.x * 256 + threadIdx.x;
     if (s >= p.NpG) return;
@@ -501,9 +515,13 @@ MPM_DEV void contact_base(const DP& p, const float* pos, uint32_t* b) {
 // the previous list with this one: "unchanged" would be a tautology)
 __global__ __launch_bounds__(256) void k_ct_keys(DP p, ContactDev c, const uint32_t* api_slot, const int* pids_api, uint32_t* slot_out,
                                                  unsigned seq_base, unsigned solve_no, int key_bits, int count_bound, int reuse,
-                                                 int force_changed) {
+                                                 int force_changed, unsigned gen_stamp) {
     ContactState* st = c.st;
-    const int n = ct_count(c);
+    const int n_raw = ct_count_raw(c);
+    const int n = ct_count(c);   // (clamped: nothing below indexes with the raw word)
+    // the count must be one this solve may use: inside the capacity, and -- counted on the device -- written by the pair
+    // generation the host enqueued this solve for
+    const bool corrupt = n_raw != n || (c.n < 0 && st->n_stamp != gen_stamp);
     const unsigned n_active = p.ctl->n_active;
     if (blockIdx.x == 0) {
         // every word in front of ContactState::n starts a solve as zero, except `done`: finished at once when there is
@@ -516,7 +534,8 @@ __global__ __launch_bounds__(256) void k_ct_keys(DP p, ContactDev c, const uint3
         const bool narrow = !reuse && ((key_bits < 31 && ((unsigned long long)n_active * 64ull > (1ull << key_bits))) || n > count_bound);
         // (p.gated: the substep went without its re-sort launches; k_grid, in front of this kernel, has left its verdict)
         const bool gated = p.gated && p.ctl->skip_this;
-        const int done0 = gated ? CT_DONE_GATED : (fault ? CT_DONE_FAULT : (narrow ? CT_DONE_STALE : (n == 0 ? 1 : 0)));
+        const int done0 = corrupt ? CT_DONE_CORRUPT
+                                  : (gated ? CT_DONE_GATED : (fault ? CT_DONE_FAULT : (narrow ? CT_DONE_STALE : (n == 0 ? 1 : 0))));
         // (a reused set-up keeps its node list, and with it the count of listed nodes)
         constexpr int W_NODES = (int)(offsetof(ContactState, n_nodes) / 4);
         if ((int)threadIdx.x < NW) {
@@ -529,7 +548,8 @@ __global__ __launch_bounds__(256) void k_ct_keys(DP p, ContactDev c, const uint3
             st->seq = seq_base;
             st->solve_no = solve_no;
             st->n_active = n_active;
-            if (c.n >= 0) st->n = c.n;
+            if (c.n >= 0) st->n = n;
+            if (corrupt) st->n_wanted = n_raw;   // (what the publication reports: ct_publish)
             const unsigned rebuilds = (unsigned)p.ctl->rebuilds;
             if (force_changed || n != st->prev_n || rebuilds != st->setup_rebuilds) st->changed_solve = solve_no;
             st->prev_n = n;
@@ -546,12 +566,21 @@ __global__ __launch_bounds__(256) void k_ct_keys(DP p, ContactDev c, const uint3
         }
     }
     bool differs = false;
+    if (corrupt) return;   // (every later kernel of the solve returns on ContactState::done)
+    bool bad_api = false;
     for (int k = i0; k < n; k += gs) {
         uint32_t b[3];
         contact_base(p, c.pos + (size_t)k * 3, b);
         const int cc = compact_cell(p, b[0], b[1], b[2]);
         const uint32_t key = cc < 0 ? CT_NO_CELL : (uint32_t)cc;
-        const uint32_t api = api_slot[k], body = c.body[k];
+        uint32_t api = api_slot[k];
+        const uint32_t body = c.body[k];
+        // (an entry that names no particle -- only a pair list that was never written can hold one: uploaded lists are
+        // checked on the host, generated ones are slots by construction -- must not become an index)
+        if (api >= (uint32_t)p.NpG) {
+            bad_api = true;
+            api = 0u;
+        }
         if (!reuse) {   // (reused set-up: the sorted keys and the order of the last full set-up stay where they are)
             c.key[k] = key;
             c.order[k] = (uint32_t)k;
@@ -565,6 +594,7 @@ __global__ __launch_bounds__(256) void k_ct_keys(DP p, ContactDev c, const uint3
     // (a plain store of the same value by every wave that saw a difference: thousands of same-address atomics would
     // serialise at ~50 ns each)
     if (__ballot(differs) && (threadIdx.x & 63) == 0) st->changed_solve = solve_no;
+    if (__ballot(bad_api) && (threadIdx.x & 63) == 0) atomicOr(&p.ctl->error, ERR_CAPACITY);
 }
 
 MPM_DEV float stencil_weight(const float* wx, const float* wy, const float* wz, int n) {
@@ -1489,7 +1519,7 @@ MPM_DEV void ct_publish(const ContactDev& c) {
     st->seq = seq;
     const int done = st->done;
     const unsigned long long hi = (unsigned long long)seq << 32;
-    const unsigned cnt = (unsigned)(done == CT_DONE_FAULT ? st->n_wanted : st->n);
+    const unsigned cnt = (unsigned)(done == CT_DONE_FAULT || done == CT_DONE_CORRUPT ? st->n_wanted : st->n);
     const unsigned nodes = ((unsigned)st->n_nodes & 0x7FFFFFFFu) | (st->changed_solve != st->solve_no ? 0x80000000u : 0u);
     unsigned long long* w = c.mbox->w;
     __hip_atomic_store(&w[1], hi | (unsigned long long)__float_as_uint(st->residual), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -1718,16 +1748,26 @@ __global__ void k_ct_exact_finish(ContactDev c) {
     if (c.mbox) ct_publish(c);   // (the host learns "finished" from this launch, not from the next pattern's first decision)
 }
 
-// apply_contact_impulse_to_rigid_bodies (cuda_mpm_kernels.cuh:1616-1658).  Impulses are summed
-// per workgroup in LDS (bodies 0..31) before they touch the per-body accumulators: thousands of
-// float atomics on one address serialise at the memory side.
+// apply_contact_impulse_to_rigid_bodies (cuda_mpm_kernels.cuh:1616-1658).  The reference adds six floats per contact to
+// the per-body accumulators with float atomics: sums whose last bits depend on the order of arrival.  Here every
+// contribution is converted to 64-bit fixed point (the momentum scale of ParticleToGrid's tiles, DP::fix_p: total mass x
+// 2^-47 of resolution) and added as an INTEGER -- per workgroup in LDS first (bodies 0..31; thousands of atomics on one
+// address serialise at the memory side, and ds_add_u64 costs a twentieth of a float LDS atomic on this part), then once
+// per workgroup and component to the accumulators: exact sums, the same bits whatever the order (round 6: two engines fed
+// the same solve report the same impulses to the bit, which round 5's float atomics only did by luck of the scheduler).
 constexpr int CT_LDS_BODIES = 32;
+MPM_DEV long long imp_fixed(double v, double scale, bool& bad) {
+    const double q = v * scale;
+    bad |= !(fabs(q) < 0x1p62);   // (NaN included)
+    return fabs(q) < 0x1p62 ? __double2ll_rn(q) : 0ll;
+}
 // (with the contact velocities after the solve, contact_vel, gathered here: k_ct_gather_vel's job)
 __global__ __launch_bounds__(256) void k_ct_impulse(DP p, ContactDev c) {
-    __shared__ float s_acc[CT_LDS_BODIES][6];
-    for (int q = threadIdx.x; q < CT_LDS_BODIES * 6; q += 256) (&s_acc[0][0])[q] = 0.f;
+    __shared__ unsigned long long s_acc[CT_LDS_BODIES][6];
+    for (int q = threadIdx.x; q < CT_LDS_BODIES * 6; q += 256) (&s_acc[0][0])[q] = 0ull;
     __syncthreads();
     const int cn = c.st->done >= CT_DONE_FAULT ? 0 : ct_count(c);   // (a solve that did not run leaves no impulse: the host repeats it)
+    bool bad = false;
     for (int j = blockIdx.x * 256 + threadIdx.x; j < cn; j += gridDim.x * 256) {
         const int k = (int)c.order[j];   // sorted position j is the caller's contact k
         const float m = c.cmass[j];
@@ -1742,25 +1782,27 @@ __global__ __launch_bounds__(256) void k_ct_impulse(DP p, ContactDev c) {
         }
         const float h[3] = {r[1] * l[2] - l[1] * r[2], r[2] * l[0] - l[2] * r[0], r[0] * l[1] - l[0] * r[1]};
         const uint32_t b = c.body[k];
-        if (b < (uint32_t)CT_LDS_BODIES) {
+        if (b >= (uint32_t)c.n_bodies) continue;
+        unsigned long long* dst = b < (uint32_t)CT_LDS_BODIES ? &s_acc[b][0] : reinterpret_cast<unsigned long long*>(c.body_acc + (size_t)b * 6);
 #pragma unroll
-            for (int a = 0; a < 3; ++a) {
-                atomicAdd(&s_acc[b][a], h[a]);
-                atomicAdd(&s_acc[b][3 + a], l[a]);
-            }
-        } else if (b < (uint32_t)c.n_bodies) {
-#pragma unroll
-            for (int a = 0; a < 3; ++a) {
-                atomicAdd(&c.body_tau[b * 3 + a], h[a]);
-                atomicAdd(&c.body_f[b * 3 + a], l[a]);
+        for (int a = 0; a < 3; ++a) {
+            const unsigned long long qh = (unsigned long long)imp_fixed((double)h[a], c.imp_fix, bad);
+            const unsigned long long ql = (unsigned long long)imp_fixed((double)l[a], c.imp_fix, bad);
+            if (b < (uint32_t)CT_LDS_BODIES) {
+                __hip_atomic_fetch_add(dst + a, qh, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                __hip_atomic_fetch_add(dst + 3 + a, ql, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            } else {
+                __hip_atomic_fetch_add(dst + a, qh, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_fetch_add(dst + 3 + a, ql, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
         }
     }
+    if (__ballot(bad) && (threadIdx.x & 63) == 0) atomicOr(&p.ctl->error, ERR_RANGE);
     __syncthreads();
     for (int q = threadIdx.x; q < min(c.n_bodies, CT_LDS_BODIES) * 6; q += 256) {
-        const int b = q / 6, a = q % 6;
-        const float v = s_acc[b][a];
-        if (v != 0.f) atomicAdd(a < 3 ? &c.body_tau[b * 3 + a] : &c.body_f[b * 3 + a - 3], v);
+        const unsigned long long v = (&s_acc[0][0])[q];
+        if (v != 0ull)
+            __hip_atomic_fetch_add(reinterpret_cast<unsigned long long*>(c.body_acc) + q, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 

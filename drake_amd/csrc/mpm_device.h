@@ -232,6 +232,11 @@ struct DP {
     int halo_pn, halo_plo[2], halo_phi[2], halo_pshift[2];
     unsigned halo_pcap;
     uint32_t* halo_pbuf[2];
+    // ... and where their entry counters live: null = word 0 of the buffer itself (buffers in this device's memory: RCCL,
+    // staged transports); the DIRECT transport packs into the NEIGHBOUR's memory and counts in a word of its own -- a
+    // returning atomic on a peer's memory is not something every interconnect guarantees --, and
+    // k_halo_signal stores the final count into the neighbour's header behind the kernel boundary
+    uint32_t* halo_pcnt[2];
     int* cellcnt[2];       // [type][cell key]; zero outside a rebuild
     int* blkcnt[2];        // [type][block id]; zero outside a rebuild
     int* blkstart[2];

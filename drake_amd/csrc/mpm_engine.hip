@@ -984,8 +984,15 @@ static int replay_keyed(mpm_engine* e, mpm_engine::KeyedGraph& kg, const std::ve
 }
 static uint64_t bits_of(float f) { uint32_t u; std::memcpy(&u, &f, 4); return u; }
 
+static int substep_begin_halo(mpm_handle_t e, float dt, int n, const int* bx_lo, const int* bx_hi, const int* shift_bx,
+                              void* const* send_bufs, size_t cap, uint32_t* const* counters);
 int mpm_substep_begin_halo(mpm_handle_t e, float dt, int n, const int* bx_lo, const int* bx_hi, const int* shift_bx,
                            void* const* send_bufs, size_t cap) try {
+    return substep_begin_halo(e, dt, n, bx_lo, bx_hi, shift_bx, send_bufs, cap, nullptr);
+} MPM_CATCH_ALL
+// counters: per zone the word the pack counts its entries in (null: word 0 of the send buffer itself)
+static int substep_begin_halo(mpm_handle_t e, float dt, int n, const int* bx_lo, const int* bx_hi, const int* shift_bx,
+                              void* const* send_bufs, size_t cap, uint32_t* const* counters) {
     READY(e);
     may_resort(e, dt);
     REQUIRE(n >= 0 && n <= 2 && (n == 0 || (bx_lo && bx_hi && shift_bx && send_bufs)), "bad halo zone list");
@@ -999,11 +1006,12 @@ int mpm_substep_begin_halo(mpm_handle_t e, float dt, int n, const int* bx_lo, co
     std::vector<uint64_t> key = {1, bits_of(dt), (uint64_t)n, (uint64_t)cap, (uint64_t)(uintptr_t)e->stream, (uint64_t)lean};
     for (int i = 0; i < n; ++i) {
         REQUIRE(send_bufs[i], "null halo buffer");
-        pp.halo_hdr[i] = static_cast<uint32_t*>(send_bufs[i]);
+        pp.halo_hdr[i] = counters && counters[i] ? counters[i] : static_cast<uint32_t*>(send_bufs[i]);
         p.halo_plo[i] = bx_lo[i]; p.halo_phi[i] = bx_hi[i]; p.halo_pshift[i] = shift_bx[i];
         p.halo_pbuf[i] = static_cast<uint32_t*>(send_bufs[i]);
+        p.halo_pcnt[i] = counters ? counters[i] : nullptr;
         key.insert(key.end(), {(uint64_t)(uint32_t)bx_lo[i], (uint64_t)(uint32_t)bx_hi[i], (uint64_t)(uint32_t)shift_bx[i],
-                               (uint64_t)(uintptr_t)send_bufs[i]});
+                               (uint64_t)(uintptr_t)send_bufs[i], (uint64_t)(uintptr_t)p.halo_pcnt[i]});
     }
     auto body = [&]() {
         e->dp.lean_resort = !e->dp.dist.on;   // (CalcFemStateAndForce follows at once)
@@ -1017,7 +1025,7 @@ int mpm_substep_begin_halo(mpm_handle_t e, float dt, int n, const int* bx_lo, co
         hipLaunchKernelGGL(k_grid<0>, dim3(e->g_grid), dim3(256), 0, e->stream, p, GridColliders{});
     };
     if (e->use_halo_graphs) {
-        if (int rc = replay_keyed(e, e->halo_graph[0], key, body)) return rc;
+        if (int rc = replay_keyed(e, e->halo_graph[2 * e->halo_graph_parity], key, body)) return rc;
     } else {
         body();
     }
@@ -1026,7 +1034,7 @@ int mpm_substep_begin_halo(mpm_handle_t e, float dt, int n, const int* bx_lo, co
     e->halo_nz = n;
     for (int i = 0; i < n; ++i) { e->halo_zlo[i] = bx_lo[i]; e->halo_zhi[i] = bx_hi[i]; }
     return 0;
-} MPM_CATCH_ALL
+}
 
 // Between begin and end: the part of the grid update and of G2P that does not depend on the
 // neighbours' sums, to be overlapped with the exchange.  Zones = the ranges given to begin.
@@ -1086,7 +1094,7 @@ int mpm_substep_end_halo(mpm_handle_t e, float dt, int bc, int n, const void* co
         launch_g2p_with(e, p, dt);
     };
     if (e->use_halo_graphs && !split) {
-        if (int rc = replay_keyed(e, e->halo_graph[1], key, body)) return rc;
+        if (int rc = replay_keyed(e, e->halo_graph[2 * e->halo_graph_parity + 1], key, body)) return rc;
     } else {
         body();
     }
@@ -1121,6 +1129,7 @@ int mpm_chain_destroy(mpm_handle_t e) try {
     for (int k = 0; k < 2; ++k)
         if (c.peer_mapped[k] && c.peer_base[k] && !(k == 1 && c.peer_base[1] == c.peer_base[0])) (void)hipIpcCloseMemHandle(c.peer_base[k]);
     if (c.direct_base) (void)hipFree(c.direct_base);
+    if (c.direct_cnt) (void)hipFree(c.direct_cnt);
     c = mpm_engine::Chain();
     return 0;
 } MPM_CATCH_ALL
@@ -1200,12 +1209,26 @@ int mpm_chain_direct_prepare(mpm_handle_t e, char handle_out[64]) try {
     static_assert(sizeof(hipIpcMemHandle_t) == 64, "IPC handle size");
     if (!c.direct_base) {
         const size_t bytes = direct_total_bytes(c);
-        // fine-grained: a peer's stores into it are not shadowed by stale lines of this device's L2
-        if (hipExtMallocWithFlags(&c.direct_base, bytes, hipDeviceMallocFinegrained) != hipSuccess) {
+        // FINE-GRAINED, or not at all: the protocol's consumer (k_grid<2>) reads the count, the ids and the sums with plain
+        // loads and relies on a peer's stores not being shadowed by stale lines of this device's L2.  A coarse-grained
+        // region would add stale halo sums without any error flag, so a refused allocation is an error of
+        // this call -- the caller stays on RCCL (the connect protocol allows that: mpm_chain_direct_connect(NULL, NULL)).
+        // MPM_DIRECT_COARSE_OK=1 accepts plain device memory for rehearsals on ONE device, where both ends share the L2.
+        const hipError_t fg = hipExtMallocWithFlags(&c.direct_base, bytes, hipDeviceMallocFinegrained);
+        if (fg != hipSuccess) {
             (void)hipGetLastError();
+            c.direct_base = nullptr;
+            if (!getenv("MPM_DIRECT_COARSE_OK"))
+                return fail(MPM_ERR_HIP, std::string("mpm_chain_direct_prepare: fine-grained device memory is not available (") +
+                                             hipGetErrorString(fg) + "): the direct halo exchange needs it; stay on the RCCL transport");
             HIP_TRY(hipMalloc(&c.direct_base, bytes));
+            c.direct_coarse = true;
         }
         HIP_TRY(hipMemsetAsync(c.direct_base, 0, bytes, e->stream));
+        if (!c.direct_cnt) {
+            HIP_TRY(hipMalloc((void**)&c.direct_cnt, 64));
+            HIP_TRY(hipMemsetAsync(c.direct_cnt, 0, 64, e->stream));
+        }
         HIP_TRY(hipStreamSynchronize(e->stream));
     }
     hipIpcMemHandle_t h;
@@ -1347,12 +1370,15 @@ int mpm_chain_substeps(mpm_handle_t e, int n, float dt, int bc) try {
             const uint32_t seq = (uint32_t)c.steps;
             void *dsb[2], *drb[2];
             uint32_t *sig[2] = {nullptr, nullptr}, *mine[2] = {nullptr, nullptr};
+            uint32_t *cnt[2] = {nullptr, nullptr}, *hdr[2] = {nullptr, nullptr}, *counters[2] = {nullptr, nullptr};
             int k = 0;
             if (c.left >= 0) {   // my left zone goes to the left neighbour's "from the right" buffer
                 dsb[k] = direct_buffer(c, c.peer_base[0], 1, parity);
                 drb[k] = direct_buffer(c, c.direct_base, 0, parity);
                 sig[0] = direct_flag(c, c.peer_base[0], 1);
                 mine[0] = direct_flag(c, c.direct_base, 0);
+                cnt[0] = c.direct_cnt; hdr[0] = static_cast<uint32_t*>(dsb[k]);
+                counters[k] = cnt[0];
                 ++k;
             }
             if (c.right >= 0) {
@@ -1360,10 +1386,16 @@ int mpm_chain_substeps(mpm_handle_t e, int n, float dt, int bc) try {
                 drb[k] = direct_buffer(c, c.direct_base, 1, parity);
                 sig[1] = direct_flag(c, c.peer_base[1], 0);
                 mine[1] = direct_flag(c, c.direct_base, 1);
+                cnt[1] = c.direct_cnt + 8; hdr[1] = static_cast<uint32_t*>(dsb[k]);
+                counters[k] = cnt[1];
                 ++k;
             }
-            if (int rc = mpm_substep_begin_halo(e, dt, nz, lo, hi, sh, dsb, c.cap)) return rc;
-            if (!c.direct_mute) hipLaunchKernelGGL(k_halo_signal, dim3(1), dim3(64), 0, e->stream, sig[0], sig[1], seq);
+            e->halo_graph_parity = parity;
+            struct ParityReset { mpm_engine* e; ~ParityReset() { e->halo_graph_parity = 0; } } parity_reset{e};
+            if (int rc = substep_begin_halo(e, dt, nz, lo, hi, sh, dsb, c.cap, counters)) return rc;
+            if (!c.direct_mute)
+                hipLaunchKernelGGL(k_halo_signal, dim3(1), dim3(64), 0, e->stream, sig[0], sig[1], seq, (const uint32_t*)cnt[0], hdr[0],
+                                   (const uint32_t*)cnt[1], hdr[1], (unsigned)c.cap);
             hipLaunchKernelGGL(k_halo_wait, dim3(1), dim3(64), 0, e->stream, (const uint32_t*)mine[0], (const uint32_t*)mine[1], seq,
                                (unsigned long long)((double)c.direct_timeout_s * 1e8), e->dp.ctl);
             const int rc_end = mpm_substep_end_halo(e, dt, bc, nz, drb, c.cap);
@@ -1678,8 +1710,15 @@ int mpm_external_body_force_to_host(mpm_handle_t e, float* tau_out, float* f_out
     READY(e);
     HIP_TRY(hipStreamSynchronize(e->stream));
     if (e->cb.n_bodies == 0) return 0;
-    if (tau_out) D2H(e, tau_out, e->cb.body_tau, e->cb.n_bodies * 12);
-    if (f_out) D2H(e, f_out, e->cb.body_f, e->cb.n_bodies * 12);
+    // (accumulated as integers in 64-bit fixed point, k_ct_impulse: the same bits whatever order the contacts arrived in)
+    std::vector<long long> acc(e->cb.n_bodies * 6);
+    D2H(e, acc.data(), e->cb.body_acc, acc.size() * sizeof(long long));
+    const double unfix = e->cb.imp_unfix > 0.0 ? e->cb.imp_unfix : e->dp.unfix_p;
+    for (size_t b = 0; b < e->cb.n_bodies; ++b)
+        for (int a = 0; a < 3; ++a) {
+            if (tau_out) tau_out[b * 3 + a] = (float)((double)acc[b * 6 + a] * unfix);
+            if (f_out) f_out[b * 3 + a] = (float)((double)acc[b * 6 + 3 + a] * unfix);
+        }
     return 0;
 } MPM_CATCH_ALL
 
@@ -2293,6 +2332,23 @@ int mpm_last_contact_counts(mpm_handle_t e, uint32_t* contacts_out, uint32_t* no
 int mpm_debug_contact_counters(mpm_handle_t e, uint64_t out4[6]) try {
     REQUIRE(e && out4, "null argument");
     for (int k = 0; k < 6; ++k) out4[k] = e->ct_counters[k];
+    return 0;
+} MPM_CATCH_ALL
+
+// Tests of the invariant "no kernel indexes a per-pair array with a count it has not clamped": overwrites the pair count
+// that mpm_generate_contact_pairs left on the device (count >= 0) and / or moves the stamp of the generation that wrote
+// it (stamp_delta != 0: the count of "another" generation, i.e. a stale one).  The next mpm_update_contact must refuse.
+int mpm_debug_contact_count(mpm_handle_t e, int count, int stamp_delta) try {
+    READY(e);
+    REQUIRE(e->cb.st && e->cb.dev_counted, "mpm_debug_contact_count: needs pairs counted on the device (mpm_generate_contact_pairs without a count)");
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    if (count >= 0) H2D(e, &e->cb.st->n, &count, sizeof(int));
+    if (stamp_delta) {
+        unsigned stamp = 0;
+        D2H(e, &stamp, &e->cb.st->n_stamp, sizeof(unsigned));
+        stamp += (unsigned)stamp_delta;
+        H2D(e, &e->cb.st->n_stamp, &stamp, sizeof(unsigned));
+    }
     return 0;
 } MPM_CATCH_ALL
 

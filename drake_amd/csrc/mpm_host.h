@@ -155,6 +155,8 @@ struct mpm_engine {
         bool peer_mapped[2] = {false, false};      // ... through hipIpcOpenMemHandle (else: this rank itself)
         float direct_timeout_s = 5.f;
         bool direct_mute = false;   // MPM_HALO_DEBUG_MUTE (tests): the signal kernel is left out
+        uint32_t* direct_cnt = nullptr;   // [2] entry counters of the two zones a substep packs, in THIS device's memory
+        bool direct_coarse = false;       // the region is NOT fine-grained (MPM_DIRECT_COARSE_OK=1: one-device rehearsals only)
     } chain;
     bool halo_mid_done = false;   // mpm_substep_mid_halo ran in this substep
     int halo_nz = 0, halo_zlo[2] = {0, 0}, halo_zhi[2] = {0, 0};
@@ -172,10 +174,13 @@ struct mpm_engine {
     int step_graph_len = 1;
     hipStream_t step_graph_stream = nullptr;
     // the two halves of the multi-GPU substep as replayable graphs (host enqueue time matters there)
+    // (one pair per parity of the direct transport's receive slots: its buffer addresses alternate with every substep,
+    // and a single cached graph would be re-captured every time -- ADVICE r5)
     struct KeyedGraph {
         hipGraphExec_t exec = nullptr;
         std::vector<uint64_t> key;
-    } halo_graph[2];
+    } halo_graph[4];
+    int halo_graph_parity = 0;   // which pair the next begin / end halo call replays (mpm_chain_substeps, direct transport)
     int max_valence = 0;       // most faces around one vertex of the mesh (Finalize): above 8, k_vforce stays (see fused_forces)
     int last_tile_kernel = 0;  // 1 = P2G, 2 = G2P (see launch_p2g)
     // launch geometry

@@ -20,7 +20,7 @@ struct Material {
 //   FM = 0  correctly rounded division and square root (what the reference's expressions mean; an IEEE division is ten
 //           vector instructions -- v_div_scale x2, v_rcp, four fma, v_div_fmas, v_div_fixup --, sqrtf eight).  THE DEFAULT
 //           since round 5: with it one substep agrees with a plain-C restatement of the reference at north_star's plain 1e-5
-//           wherever float arithmetic can deliver that (tests/test_ieee_variant_gpu.py, tests/helpers.py); every other
+//           wherever float arithmetic can deliver that (tests/test_fast_math_gpu.py: both arithmetics on the same states; tests/helpers.py: NOISE_FLOOR / floor_decides); every other
 //           user of these helpers (Finalize's k_init_faces, the 3x3 solve of the contact direction) always runs it.
 //   FM = 1  the hardware approximations (1 ulp each) followed by ONE Newton step in fused multiply-adds: 3 - 4
 //           instructions instead of 8 - 10, results within ~0.6 ulp; with 19 divisions and 10 square roots per face

@@ -21,6 +21,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <algorithm>
 #include <utility>
 
 #include "mpm_device.h"
@@ -341,6 +342,13 @@ static inline size_t sort_hist_ints(size_t n) {
     const size_t items = sort_items_for(n);
     const size_t tiles = (n + 64 * items - 1) / (64 * items);
     return ((size_t)1 << SORT_MAX_DIGIT_BITS) * (tiles + 1);
+}
+
+// ... for ANY count up to n (the tile size changes at 2^18 pairs: a count just below makes four times the tiles of one
+// just above)
+static inline size_t sort_hist_ints_upto(size_t n) {
+    const size_t knee = (size_t)1 << 18;
+    return n > knee ? std::max(sort_hist_ints(n), sort_hist_ints(knee)) : sort_hist_ints(n);
 }
 
 template <int DB>

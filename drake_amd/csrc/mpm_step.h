@@ -971,7 +971,7 @@ __global__ __launch_bounds__(256) void k_grid(DP p, GridColliders gc) {
                     if (nbx < 0 || nbx >= p.nb) continue;
                     uint32_t* buf = p.halo_pbuf[k];
                     unsigned slot = 0;
-                    if (cell == 0) slot = atomicAdd(&buf[0], 1u);
+                    if (cell == 0) slot = atomicAdd(p.halo_pcnt[k] ? p.halo_pcnt[k] : &buf[0], 1u);   // (a LOCAL word: see DP::halo_pcnt)
                     slot = __builtin_amdgcn_readfirstlane(slot);
                     if (slot >= p.halo_pcap) {
                         if (cell == 0) atomicOr(&p.ctl->error, ERR_CAPACITY);
@@ -1308,8 +1308,13 @@ struct HaloBufs {
 // it has made those stores complete; the system-scope fence and release store order the flag behind them for an observer
 // on another device.  (Cross-device ordering cannot be observed on a box with one GPU: the protocol, not its memory
 // model, is what the one-GPU tests exercise -- DESIGN.md section 5.)
-__global__ void k_halo_signal(uint32_t* flag_a, uint32_t* flag_b, uint32_t seq) {
+// (cnt_* / hdr_*: the pack kernel counted its entries in words of THIS device's memory -- no returning atomic on peer
+// memory --; the counts go into the neighbours' buffer headers here, in front of the flags)
+__global__ void k_halo_signal(uint32_t* flag_a, uint32_t* flag_b, uint32_t seq, const uint32_t* cnt_a, uint32_t* hdr_a,
+                              const uint32_t* cnt_b, uint32_t* hdr_b, unsigned cap) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    if (hdr_a) __hip_atomic_store(hdr_a, min(*cnt_a, cap), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (hdr_b) __hip_atomic_store(hdr_b, min(*cnt_b, cap), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     __threadfence_system();
     if (flag_a) __hip_atomic_store(flag_a, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     if (flag_b) __hip_atomic_store(flag_b, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);

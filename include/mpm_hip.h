@@ -306,7 +306,7 @@ MPM_API int mpm_set_deterministic(mpm_handle_t h, int on);
  * cuda_mpm_kernels.cuh:72-181 through math_tools.cuh:456-597).
  *   on = 0 (default): correctly rounded, as the reference's expressions read.  One substep then agrees with a plain-C
  *     restatement of the reference at north_star's "float state within 1e-5 relative" wherever float arithmetic can
- *     deliver that (tests/test_ieee_variant_gpu.py).
+ *     deliver that (tests/test_fast_math_gpu.py; tests/helpers.py: NOISE_FLOOR, floor_decides).
  *   on = 1: the hardware's 1-ulp reciprocal / reciprocal square root followed by one Newton step (results within
  *     ~0.6 ulp): 2.4 us per substep less at 1M particles (k_fem 910 -> 630 vector instructions per face); the
  *     velocities of one substep then differ from the strict path's by about the float rounding noise of that substep
@@ -375,6 +375,14 @@ MPM_API int mpm_last_contact_counts(mpm_handle_t h, uint32_t *contacts_out, uint
  * substeps of mpm_run_coupled_substeps that were enqueued contact-free (no particle in any collider when the substep before
  * ended), of them skipped on the device and repeated as coupled substeps}. */
 MPM_API int mpm_debug_contact_counters(mpm_handle_t h, uint64_t out6[6]);
+/* Tests of the invariant that no kernel of the solve indexes a per-pair array with a count it has not clamped to the
+ * capacity that sized the array (the reference sizes its launches from a host count, cuda_mpm_solver.cu:222-232; here the
+ * count of device-made pairs never leaves the device).  Overwrites the count mpm_generate_contact_pairs left on the device
+ * (count >= 0) and / or shifts the number of the pair generation that wrote it (stamp_delta != 0: "a count some other
+ * generation left", i.e. a stale one).  The next mpm_update_contact must refuse: MPM_ERR_CAPACITY for a count outside
+ * [0, capacity], MPM_ERR_INTERNAL for a stale one -- nothing indexed, nothing solved; pairs made again afterwards solve as
+ * if nothing had happened.  Needs pairs counted on the device (n_contacts_out == NULL). */
+MPM_API int mpm_debug_contact_count(mpm_handle_t h, int count, int stamp_delta);
 MPM_API int mpm_download_contact_pairs(mpm_handle_t h, uint32_t *particle_in_contact_index, uint32_t *non_mpm_id,
                                        float *penetration_distance, float *normal, float *position, float *rigid_v,
                                        float *rigid_p_WB);

@@ -20,8 +20,16 @@
  * tests/golden/survey_known_answers.json) and by physical invariants.
  * Anything not covered by those known answers is "parity unpinned".
  *
- * With OMP_NUM_THREADS=1 (or orc_set_threads(1)) every sum is evaluated in
- * particle / contact order, i.e. deterministically.
+ * Determinism (round 6): every float sum has a FIXED order, whatever the thread
+ * count.  The vertex forces of CalcFemStateAndForce are computed per face in
+ * parallel and added in face order by one thread; ParticleToGrid has an ordered
+ * variant (orc_particle_to_grid_ordered: particle order, one thread) that
+ * oracle.py uses by default; the contact solve is serial.  The reference's own
+ * order is that of its float atomics, i.e. undefined: any fixed order is a
+ * legitimate realisation of it, and a checker that is itself a random draw
+ * forces statistical tolerances on the tests.  orc_particle_to_grid
+ * (OpenMP atomics: order of arrival) and the coloured scatter stay for the
+ * cpu_baseline leg and for the tests that compare the variants.
  */
 #include <math.h>
 #include <tgmath.h>   /* sqrt, fabs, fmin ... follow the type of `real` */
@@ -485,6 +493,8 @@ ORC_API void orc_calc_fem_state_and_force(const orc_params *p, size_t n_faces, c
                                           const int *imap, const real *vol, const real *Caff,
                                           const real *DmInv, real *pos, real *vel, real *Fdef,
                                           real *forces, real *taus, real dt) {
+    /* the nine corner-force components of every face, added to the vertices in face order below */
+    real *Gall = (real *)malloc((n_faces ? n_faces : 1) * 9 * sizeof(real));
 #pragma omp parallel for schedule(static)
     for (long f = 0; f < (long)n_faces; ++f) {
         const int fp = imap[f];
@@ -537,15 +547,20 @@ ORC_API void orc_calc_fem_state_and_force(const orc_params *p, size_t n_faces, c
         const real VP01[6] = {VP[0], VP[1], VP[3], VP[4], VP[6], VP[7]};
         real G[9];
         mm(3, 2, 3, VP01, gN, G);
+        for (int i = 0; i < 9; ++i) Gall[f * 9 + i] = G[i];
+    }
+    /* the reference's 9 float atomics per face (:283-291), in face order: the same bits for any thread count */
+    for (size_t f = 0; f < n_faces; ++f) {
+        const int v0 = imap[indices[f * 3]], v1 = imap[indices[f * 3 + 1]],
+                  v2 = imap[indices[f * 3 + 2]];
+        const real *G = &Gall[f * 9];
         for (int i = 0; i < 3; ++i) {
-#pragma omp atomic
             forces[v0 * 3 + i] += -G[i * 3 + 0];
-#pragma omp atomic
             forces[v1 * 3 + i] += -G[i * 3 + 1];
-#pragma omp atomic
             forces[v2 * 3 + i] += -G[i * 3 + 2];
         }
     }
+    free(Gall);
 }
 
 /* ------------------------------------------------------------------ */
@@ -573,13 +588,13 @@ ORC_API void orc_clean_grid(uint32_t touched_cells, const uint32_t *ids, uint32_
  * (the warp-level run reduction of :438-457,520-528 only regroups the same
  * additions).  Grid sums are accumulated in particle order when single
  * threaded. */
-ORC_API void orc_particle_to_grid(const orc_params *p, size_t n, const real *pos, const real *vel,
-                                  const real *vol, const real *Caff, const real *forces,
-                                  const real *taus, uint32_t *flags, real *gm, real *gmv,
-                                  real dt) {
+static void p2g_loop(const orc_params *p, size_t n, const real *pos, const real *vel,
+                     const real *vol, const real *Caff, const real *forces,
+                     const real *taus, uint32_t *flags, real *gm, real *gmv,
+                     real dt, int ordered) {
     const real dxinv = p_dxinv(p), dx = p_dx(p), dinv = p_dinv(p);
     const int gax = p->gravity_axis;
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) if (!ordered)
     for (long q = 0; q < (long)n; ++q) {
         uint32_t base[3];
         real fx[3], w[3][3];
@@ -623,6 +638,22 @@ ORC_API void orc_particle_to_grid(const orc_params *p, size_t n, const real *pos
                     gmv[c * 3 + 2] += val[3];
                 }
     }
+}
+
+/* the sums in the order of arrival of the threads' atomics (the reference: float atomics, :520-528) */
+ORC_API void orc_particle_to_grid(const orc_params *p, size_t n, const real *pos, const real *vel,
+                                  const real *vol, const real *Caff, const real *forces,
+                                  const real *taus, uint32_t *flags, real *gm, real *gmv,
+                                  real dt) {
+    p2g_loop(p, n, pos, vel, vol, Caff, forces, taus, flags, gm, gmv, dt, 0);
+}
+
+/* the same sums in PARTICLE ORDER (one thread): what the parity tests compare against -- the same bits on every run */
+ORC_API void orc_particle_to_grid_ordered(const orc_params *p, size_t n, const real *pos,
+                                          const real *vel, const real *vol, const real *Caff,
+                                          const real *forces, const real *taus, uint32_t *flags,
+                                          real *gm, real *gmv, real dt) {
+    p2g_loop(p, n, pos, vel, vol, Caff, forces, taus, flags, gm, gmv, dt, 1);
 }
 
 

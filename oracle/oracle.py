@@ -269,12 +269,18 @@ class OracleMpm:
 
     # -- GpuMpmSolver::ParticleToGrid (cuda_mpm_solver.cu:86-105)
     fast_scatter = False  # True: the multi-core variant (cpu_baseline only)
+    # True (the default): every node sum of ParticleToGrid is added in particle order by one thread -- the same bits on
+    # every run and for every thread count.  False: OpenMP atomics in order of arrival (the reference's float atomics have
+    # no order either); the parity tests keep one smoke variant each on that draw.  CalcFemStateAndForce's vertex forces
+    # and the contact solve have a fixed order always (mpm_oracle.c header, "Determinism").
+    ordered_scatter = True
 
     def particle_to_grid(self, dt: float):
         if self.g_cnt > 0:
             self.L.orc_clean_grid(C.c_uint32(self.g_cnt * 64), _u(self.g_ids), _u(self.g_flags), self._f(self.g_m),
                                   self._f(self.g_mv))
-        fn = self.L.orc_particle_to_grid_colored if self.fast_scatter else self.L.orc_particle_to_grid
+        fn = self.L.orc_particle_to_grid_colored if self.fast_scatter else (
+            self.L.orc_particle_to_grid_ordered if self.ordered_scatter else self.L.orc_particle_to_grid)
         fn(C.byref(self.p), C.c_size_t(self.n_particles), self._f(self.pos), self._f(self.vel),
                                     self._f(self.vol), self._f(self.C), self._f(self.forces), self._f(self.taus), _u(self.g_flags),
                                     self._f(self.g_m), self._f(self.g_mv), self._cf(dt))

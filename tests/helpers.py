@@ -34,9 +34,13 @@ _MATERIAL_FIELDS = dict(youngs_modulus="youngs", poisson_ratio="poisson", densit
 BAGGING_MATERIAL = dict(K=4e5, V=0.2, sdf_friction=1.0)
 
 
-def build_pair(domain_bits=6, layers=3, res=20, z0=0.5, side=0.3, seed=7, vel_amp=0.2, material=None, sheets=None):
+def build_pair(domain_bits=6, layers=3, res=20, z0=0.5, side=0.3, seed=7, vel_amp=0.2, material=None, sheets=None,
+               deterministic=False):
     """Same cloth stack on the oracle and on the engine.  `material`: dict of mpm_material_t fields
-    applied to both sides."""
+    applied to both sides.  `deterministic`: the engine runs in mpm_set_deterministic mode from Finalize's own first
+    sort on (canonical particle order inside every cell, fixed-point tile sums); the oracle's sums have a fixed order
+    always (oracle.OracleMpm.ordered_scatter), so a comparison of the two then yields THE SAME NUMBER ON EVERY RUN and
+    its bound is a fixed multiple of a fixed yardstick, not a quantile over draws."""
     from drake_amd import GpuMpm
 
     if sheets is None:
@@ -49,6 +53,8 @@ def build_pair(domain_bits=6, layers=3, res=20, z0=0.5, side=0.3, seed=7, vel_am
             setattr(gm, k, v)
             setattr(o.p, _MATERIAL_FIELDS[k], v)
     g = GpuMpm(domain_bits, gm)
+    if deterministic:
+        g.set_deterministic(True)
     for pos, vel, idx in sheets:
         o.add_qr_cloth(pos, vel, idx)
         g.add_qr_cloth(pos, vel, idx)

@@ -20,23 +20,33 @@ def converged_reference(o, o64, ro, solve64):
     return o64, 1.0
 
 
-def close_rel(a, b, frac, what):
+def close_rel(a, b, frac, what, deterministic=True):
     """Relative bounds on top of the solver-tolerance bound (a regression of the Newton path must not
-    hide inside the tail tolerance): rms(a - b) <= frac * rms(b); all but a per-mille of the entries within
-    3 * frac * max|b| and none beyond 8 * frac (two solves that stop at different points of the noise-limited tail differ
-    most at single contacts: measured over several runs of the 1M-particle config 3: 0.9 - 3.5 % rms, up to 12 % of
-    max|v| at one contact; the soft parameters: 1.3 % rms)."""
+    hide inside the tail tolerance): rms(a - b) <= frac * rms(b), and single entries against max|b|.
+
+    deterministic (engine in mpm_set_deterministic mode, the oracle's sums in fixed order: the comparison is ONE number,
+    the same on every run -- VERDICT r5 item 2): at most 3 entries beyond 3 * frac of max|ref| (a COUNT, not a
+    quantile), none beyond 4 * frac.
+    otherwise (the smoke variant on the default engine, whose particle order inside a cell -- and with it the length of
+    the noise-limited tail of the solve -- differs from run to run): round 5's bounds, all but a per-mille of the entries
+    within 3 * frac and none beyond 8 * frac (measured over several runs of the 1M-particle config 3: 0.9 - 3.5 % rms,
+    up to 12 % of max|v| at one contact)."""
     from tests.helpers import MARGINS
     a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
     err, ref = float(np.abs(a - b).max()), float(np.abs(b).max())
     rms_e, rms_b = float(np.sqrt(np.mean((a - b) ** 2))), float(np.sqrt(np.mean(b ** 2)))
     MARGINS.append((rms_e / (frac * rms_b + 1e-300), what + " (rms, relative)", frac, rms_e / (rms_b + 1e-300), err / (ref + 1e-300)))
     assert rms_e <= frac * rms_b, f"{what}: rms error {rms_e:.3e} > {frac:.0%} of rms(ref) {rms_b:.3e}"
-    # (single entries: all but a per-mille within 3 * frac of max|ref|; the one contact where the two tails stopped furthest
-    # apart has been seen at 2.4 %, 5.2 %, 5.6 % and -- once in nine runs of the suite -- 12.2 % of max|v|: within 8 * frac)
-    q999 = float(np.quantile(np.abs(a - b), 0.999))
-    assert q999 <= 3 * frac * ref, f"{what}: 99.9th percentile {q999:.3e} > {3 * frac:.0%} of max|ref| {ref:.3e}"
-    assert err <= 8 * frac * ref, f"{what}: {err:.3e} > {8 * frac:.0%} of max|ref| {ref:.3e}"
+    beyond = int(np.count_nonzero(np.abs(a - b) > 3 * frac * ref))
+    cap = 4.0 if deterministic else 8.0
+    MARGINS.append((err / (cap * frac * ref + 1e-300), what + f" (largest single entry, {'deterministic' if deterministic else 'default engine'})",
+                    cap * frac, err / (ref + 1e-300), err / (ref + 1e-300)))
+    if deterministic:
+        assert beyond <= 3, f"{what}: {beyond} entries beyond {3 * frac:.0%} of max|ref| {ref:.3e}"
+    else:
+        q999 = float(np.quantile(np.abs(a - b), 0.999))
+        assert q999 <= 3 * frac * ref, f"{what}: 99.9th percentile {q999:.3e} > {3 * frac:.0%} of max|ref| {ref:.3e}"
+    assert err <= cap * frac * ref, f"{what}: {err:.3e} > {cap * frac:.0%} of max|ref| {ref:.3e}"
 
 pytestmark = pytest.mark.gpu
 DT = 1e-3
@@ -77,14 +87,17 @@ def _diagnose(g, o):
 CONTACT_PARAMS = {"soft": (1e5, 1e-3, 1e-3), "config3": (1e6, 1e-5, 2e-4)}
 
 
-@pytest.mark.parametrize("exact", [False, True])
-@pytest.mark.parametrize("params,mu", [("soft", 0.0), ("soft", 0.5), ("config3", 1.0)])
-def test_update_contact_matches_oracle(exact, params, mu):
+# (deterministic: engine in mpm_set_deterministic mode against the oracle's fixed-order sums -- one number per comparison,
+# the same on every run; the last entry is the smoke variant on the default engine with round 5's bounds)
+@pytest.mark.parametrize("exact,params,mu,deterministic", [
+    (False, "soft", 0.0, True), (True, "soft", 0.0, True), (False, "soft", 0.5, True), (True, "soft", 0.5, True),
+    (False, "config3", 1.0, True), (True, "config3", 1.0, True), (False, "config3", 1.0, False)])
+def test_update_contact_matches_oracle(exact, params, mu, deterministic):
     from drake_amd import ARR as A
     from oracle import oracle as orc
     stiffness, damping, DT = CONTACT_PARAMS[params]
     # two sheets straddling the floor, moving down and sideways
-    o, g = build_pair(layers=2, res=20, z0=Z_FLOOR - 0.004, vel_amp=0.3)
+    o, g = build_pair(layers=2, res=20, z0=Z_FLOOR - 0.004, vel_amp=0.3, deterministic=deterministic)
     o.vel[:, 2] -= 0.5
     o.vel[:, 0] += 0.3
     for step in range(3):
@@ -149,8 +162,8 @@ def test_update_contact_matches_oracle(exact, params, mu):
         close(tau_g, o.F_tau, scale=max(float(np.abs(o.F_tau).max()), fscale), rtol=imp_rtol, what="body angular impulse")
         # whatever the tail tolerance allows, a converged solve is within 4 % rms of the reference's contact velocities
         # (12 % of the largest one at any single contact) and within 2 % (6 %) on the impulses
-        close_rel(g.download(A.CONTACT_VEL), o.c_vel, 0.04 * stalled, "contact vel")
-        close_rel(f_g, o.F_f, 0.02, "body impulse")
+        close_rel(g.download(A.CONTACT_VEL), o.c_vel, 0.04 * stalled, "contact vel", deterministic)
+        close_rel(f_g, o.F_f, 0.02, "body impulse", deterministic)
         # the floor pushes up
         assert f_g[0, 2] < 0  # impulse ON the body is downward
         o.grid_to_particle(DT)
@@ -292,11 +305,11 @@ def test_five_newton_iterations_match_oracle(exact, iters):
     close(f_g, o.F_f, scale=float(np.abs(o.F_f).max()), rtol=10 * rt, what=f"{iters}-iteration body impulse")
 
 
-def _history_scene():
+def _history_scene(deterministic=True):
     from drake_amd import ARR as A
     from oracle import oracle as orc
     from tests.helpers import oracle_copy
-    o, g = build_pair(layers=4, res=40, side=0.15, z0=Z_FLOOR - 0.02, vel_amp=0.3)
+    o, g = build_pair(layers=4, res=40, side=0.15, z0=Z_FLOOR - 0.02, vel_amp=0.3, deterministic=deterministic)
     o.vel[:, 2] -= 0.5
     o.vel[:, 0] += 0.3
     g.upload_particle_state(o.pos, o.vel, o.C, None, o.F)
@@ -314,8 +327,18 @@ def _history_scene():
     return o, o64, g
 
 
-@pytest.mark.parametrize("exact", [False, True])
-def test_twenty_newton_iterations_decision_by_decision(exact):
+# Bounds of the 20-iteration history in units of its yardstick (the running maximum of |oracle32 - oracle64|).
+# Deterministic mode: engine and oracle are both pure functions of the scene, every ratio below is ONE number, the same on
+# every run (gpurun_out/parity_margins.txt of two consecutive runs agree to the digit), so the bound is a fixed multiple
+# at EVERY iteration.  The smoke variant on the default engine (particle order inside a cell from atomics: the chaotic
+# iteration amplifies that last-bit difference like any other) keeps round 5's three statements.
+HISTORY_EARLY = 5.0     # iterations 0 - 5, before rounding has grown: both modes
+HISTORY_EVERY = 10.0    # deterministic mode: every iteration
+HISTORY_FIELDS = 4.0    # deterministic mode: rms |engine - oracle32| of the fields after 20 iterations, in rms |oracle32 - oracle64|
+
+
+@pytest.mark.parametrize("exact,deterministic", [(False, True), (True, True), (False, False)])
+def test_twenty_newton_iterations_decision_by_decision(exact, deterministic):
     """the contact decisions pinned over the WHOLE iteration history, not at the last step.  The
     reference takes its decisions on the host, one set per Newton iteration (cuda_mpm_solver.cu:472-528 backtracking,
     :383-471 exact search, :567-570 stopping test); the engine takes them on the device and logs them
@@ -325,22 +348,23 @@ def test_twenty_newton_iterations_decision_by_decision(exact):
         by `E1 <= E0`: one different decision anywhere would show), DoFs exactly;
       * residual, E(0), E(alpha), sum |Dir|^2 to the digits the float and the double build of the ORACLE share: the
         relaxed Jacobi iteration is not contractive over these iterations (a perturbation of the direction field grows
-        about threefold per iteration, see the field comparison below), so the yardstick of iteration i is the largest
-        distance |oracle32 - oracle64| of iterations 0 .. i (plus 2e-6 relative): within 5 of them while the rounding has
-        not grown yet (iterations 0-5), a median over the history of at most 2, no iteration beyond 40 (the distance of
-        two realisations of a chaotic iteration has a heavy tail: see the comment at the check);
+        about threefold per iteration), so the yardstick of iteration i is the largest distance |oracle32 - oracle64| of
+        iterations 0 .. i (plus 2e-6 relative).  Deterministic mode (round 6): within HISTORY_EARLY yardsticks in
+        iterations 0 - 5 and within HISTORY_EVERY at EVERY iteration -- both sides are pure functions of the scene
+        (the oracle's sums have a fixed order, the engine runs in mpm_set_deterministic mode), so these are fixed
+        numbers, not draws.  The smoke variant on the default engine keeps round 5's statements (early <= 5, median
+        <= 2, no iteration beyond 40: there one of the two sides IS a draw);
       * exact search: alpha is a continuous function of the state, so it drifts apart with the fields (engine and float
         oracle agree to 1e-5 for eight iterations and to nothing after fifteen -- as do the two builds of the oracle): the
         same yardstick, plus 2e-4 (the root finder works on dE/dalpha, a float sum that is noise below ~1e-6 of its terms,
         and ends wherever the noise leaves it after up to 200 evaluations, on both sides); the evaluation count is
         reported, not compared.
-    The FIELDS after 20 iterations (directions, grid velocities) are two chaotic difference fields; their maxima
-    fluctuate (0.8 .. 6 between runs and builds), their root mean squares less: rms |engine - oracle32| <= 8 rms
-    |oracle32 - oracle64| (typically 0.3 .. 1.5; the tail is the chaos's, see the check)."""
+    The FIELDS after 20 iterations (directions, grid velocities): rms |engine - oracle32| <= HISTORY_FIELDS rms
+    |oracle32 - oracle64| in deterministic mode (8 on the default engine)."""
     from drake_amd import ARR as A
     stiffness, damping, DT = CONTACT_PARAMS["config3"]
     iters = 20
-    o, o64, g = _history_scene()
+    o, o64, g = _history_scene(deterministic)
     ro = o.update_contact(DT, 1.0, stiffness, damping, exact_line_search=exact, max_iters=iters)
     r64 = o64.update_contact(DT, 1.0, stiffness, damping, exact_line_search=exact, max_iters=iters)
     rg = g.update_contact(DT, 1.0, stiffness, damping, exact_line_search=exact, max_newton_iterations=iters)
@@ -354,6 +378,18 @@ def test_twenty_newton_iterations_decision_by_decision(exact):
         print(f"{i:3d} {L32[i, 0]:10.3e} {Lg[i, 3]:10.3e} {int(L32[i, 5]):2d}/{int(Lg[i, 1]):2d} {L32[i, 6]:11.4e} {Lg[i, 0]:11.4e} "
               f"{L64[i, 6]:11.4e} {L32[i, 2]:13.6e} {Lg[i, 2]:13.6e}")
     assert np.array_equal(Lg[:, col["dofs"][1]], L32[:, col["dofs"][0]])
+    mode = ("deterministic" if deterministic else "default engine") + (", exact" if exact else ", backtracking")
+
+    def bounded(ratio, what):
+        """the statement of this mode about a history of ratios; returns error / allowed for the margins table"""
+        early, med, peak = float(ratio[:6].max()), float(np.median(ratio)), float(ratio.max())
+        print(f"20-iteration history ({mode}) {what}: early {early:.3f}, median {med:.3f}, peak {peak:.3f} yardsticks")
+        if deterministic:
+            assert early <= HISTORY_EARLY and peak <= HISTORY_EVERY, (what, early, peak, ratio)
+            return max(early / HISTORY_EARLY, peak / HISTORY_EVERY)
+        assert early <= 5.0 and med <= 2.0 and peak <= 40.0, (what, early, med, peak, ratio)
+        return max(early / 5.0, med / 2.0, peak / 40.0)
+
     # the yardstick of iteration i: the largest |oracle32 - oracle64| of iterations 0 .. i (the distance grows with the
     # iterations, and at a single iteration the two may happen to coincide)
     runmax = lambda x: np.maximum.accumulate(np.abs(x))
@@ -364,28 +400,19 @@ def test_twenty_newton_iterations_decision_by_decision(exact):
         tol_a = 5.0 * runmax(L32[:, 0] - L64[:, 0]) + 2e-4
         upto = int(np.argmax(tol_a > 0.1)) if np.any(tol_a > 0.1) else iters
         assert upto >= 8, tol_a
-        # (the same three statements as for the scalars below, for the same reason)
         ratio_a = (np.abs(Lg[:, 3] - L32[:, 0]) / (runmax(L32[:, 0] - L64[:, 0]) + 4e-5))[:upto]
-        assert ratio_a[:6].max() <= 5.0 and np.median(ratio_a) <= 2.0 and ratio_a.max() <= 40.0, (ratio_a, Lg[:, 3], L32[:, 0], L64[:, 0])
+        bounded(ratio_a, "alpha")
     else:
         assert np.array_equal(Lg[:, 3], L32[:, 0]), (Lg[:, 3], L32[:, 0])          # every accepted step
         assert np.array_equal(Lg[:, 1], L32[:, 5])                                  # every evaluation count
         assert np.array_equal(L32[:, 0], L64[:, 0].astype(np.float32))              # (the premise: the double build decides alike)
-    # The scalars of every iteration, in units of the yardstick.  Three statements, because the distance between two
-    # realisations of a chaotic iteration has a heavy tail (scratch/history_ratio.py: the ratio of |engine - oracle32| to
-    # the yardstick is 0 .. 1 in iterations 0-6, and from iteration 8 on mostly 0.2 .. 3 with single iterations at 6 and,
-    # once in sixteen runs, 14 -- where the float and the double oracle happen to lie close together at that iteration):
-    #   before the rounding has grown (iterations 0-5)  <= 5 yardsticks at every iteration,
-    #   over the whole history                          median <= 2, and no iteration beyond 40.
+    from tests.helpers import MARGINS
     for name in ("residual", "E0", "E1", "nd"):
         a, b, c = Lg[:, col[name][1]], L32[:, col[name][0]], L64[:, col[name][0]]
         yard = runmax(b - c) + 0.2 * (2e-4 if exact else 1e-5) * np.abs(b) + 1e-30
-        ratio = (np.abs(a - b) / yard)[:upto]
-        early, med, peak = float(ratio[:6].max()), float(np.median(ratio)), float(ratio.max())
-        worst = max(early / 5.0, med / 2.0, peak / 40.0)
-        from tests.helpers import MARGINS
-        MARGINS.append((worst, f"20-iteration history ({'exact' if exact else 'backtracking'}): {name}", 3.0, worst, float(np.max(np.abs(a - b) / (np.abs(b) + 1e-30)))))
-        assert early <= 5.0 and med <= 2.0 and peak <= 40.0, (name, early, med, peak, ratio)
+        worst = bounded((np.abs(a - b) / yard)[:upto], name)
+        MARGINS.append((worst, f"20-iteration history ({mode}): {name}", HISTORY_EVERY if deterministic else 40.0, worst,
+                        float(np.max(np.abs(a - b) / (np.abs(b) + 1e-30)))))
     # the last row is what the call itself reports
     cs = g.contact_stats()
     assert cs["alpha"] == np.float32(Lg[-1, 3]) and rg["residual"] == np.float32(Lg[-1, 0])
@@ -395,20 +422,23 @@ def test_twenty_newton_iterations_decision_by_decision(exact):
     scale_D = float(np.abs(o.g_D).max())
     noise_D, noise_v = rms(o64.g_D - o.g_D), rms((o64.g_mv - o.g_mv) * wgt)
     err_D, err_v = rms(g.download(A.GRID_DIR) - o.g_D), rms((g.download(A.GRID_MOMENTUM) - o.g_mv) * wgt)
-    print(f"20 iterations ({'exact' if exact else 'backtracking'}): |Dir| {scale_D:.3g}; rms float vs double oracle: Dir {noise_D:.2e}, "
+    print(f"20 iterations ({mode}): |Dir| {scale_D:.3g}; rms float vs double oracle: Dir {noise_D:.2e}, "
           f"grid v {noise_v:.2e}; rms engine vs float oracle: Dir {err_D:.2e} ({err_D / noise_D:.2f} x), grid v {err_v:.2e} ({err_v / noise_v:.2f} x)")
     if not exact:
         assert noise_D > 1e-4 * scale_D          # (the premise: rounding alone has grown this far)
-        # (both sides of the quotient are draws from the same heavy-tailed distribution -- the oracle's own OpenMP sums
-        # differ from run to run: over 40 runs the quotient was 0.3 .. 1.5 for the directions with one 3.3, 0.3 .. 2.9 for the
-        # grid velocities with one 4.6; scratch/history_repeat.py)
-        assert err_D <= 8.0 * noise_D and err_v <= 8.0 * noise_v, (err_D, noise_D, err_v, noise_v)
+        k = HISTORY_FIELDS if deterministic else 8.0
+        MARGINS.append((max(err_D / noise_D, err_v / noise_v) / k, f"20-iteration fields ({mode})", k, err_D / noise_D, err_v / noise_v))
+        assert err_D <= k * noise_D and err_v <= k * noise_v, (err_D, noise_D, err_v, noise_v)
 
 
-def test_config3_full_size_against_the_oracle():
+@pytest.mark.parametrize("deterministic", [True, False])
+def test_config3_full_size_against_the_oracle(deterministic):
     """BASELINE config 3 at its full size: the 1M-particle stack (999,952 particles, 128^3) with its lowest
     sheets below a floor, the bagging demo's contact parameters (k = 1e6, d = 1e-5, mu = 1, dt = 2e-4).
-    One Newton iteration against the oracle at rounding level, then the converged solve."""
+    One Newton iteration against the oracle at rounding level, then the converged solve.
+    deterministic: engine in mpm_set_deterministic mode against the oracle's fixed-order sums -- every margin is the
+    same number on every run, single contacts within 4 x 4 % of max|v| (close_rel); the other variant is the smoke run
+    on the default engine with round 5's bounds."""
     from drake_amd import ARR as A, scenes
     from oracle import oracle as orc
     stiffness, damping, DT = CONTACT_PARAMS["config3"]
@@ -417,7 +447,7 @@ def test_config3_full_size_against_the_oracle():
     for pos, vel, idx in sheets:
         vel[:, 2] -= 0.5
         vel[:, 0] += 0.3
-    o, g = build_pair(sheets=sheets, domain_bits=bits)
+    o, g = build_pair(sheets=sheets, domain_bits=bits, deterministic=deterministic)
     assert g.n_particles == 999952
 
     def prepare():
@@ -463,12 +493,12 @@ def test_config3_full_size_against_the_oracle():
     close(g.download(A.CONTACT_VEL), o.c_vel, scale=1.0, rtol=tol, what="1m contact vel")
     # (like `tol` above: an oracle that stalled above the solver's tolerance -- up to MAX_STALL times -- stopped that much
     # further from the solution; 2.1 - 3.5 % rms over fourteen runs of the suite)
-    close_rel(g.download(A.CONTACT_VEL), o.c_vel, 0.04 * stalled, "1m contact vel")
+    close_rel(g.download(A.CONTACT_VEL), o.c_vel, 0.04 * stalled, "1m contact vel", deterministic)
     tau_g, f_g = g.external_body_force_to_host()
     assert f_g[0, 2] < 0
     close(f_g, o.F_f, scale=float(np.abs(o.F_f).max()), rtol=IMPULSE_RTOL * tol / solve_tolerance(g.contact_stats()["dofs"]),
           what="1m body impulse")
-    close_rel(f_g, o.F_f, 0.02, "1m body impulse")
+    close_rel(f_g, o.F_f, 0.02, "1m body impulse", deterministic)
     g.gpu_sync()
     assert g.stats()["error_flags"] == 0
 

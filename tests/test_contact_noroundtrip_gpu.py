@@ -72,13 +72,11 @@ def _state(g):
 
 
 def _same(a, b):
-    """particle state to the bit; the per-body impulses to rounding (k_ct_impulse adds them with float atomics, in LDS and
-    then per body: the one sum of the contact path whose order is not fixed -- as in the reference,
-    cuda_mpm_kernels.cuh:1616-1658)"""
-    for k in ("pos", "vel", "F"):
+    """particle state AND per-body impulses to the bit (round 6: k_ct_impulse adds the impulses as 64-bit fixed-point
+    integers -- exact sums, whatever order the contacts arrive in; the reference's float atomics,
+    cuda_mpm_kernels.cuh:1616-1658, and round 5's had no fixed order)"""
+    for k in ("pos", "vel", "F", "tau", "f"):
         assert np.array_equal(a[k], b[k]), k
-    for k in ("tau", "f"):
-        np.testing.assert_allclose(a[k], b[k], rtol=2e-5, atol=1e-6 * float(np.abs(b[k]).max()), err_msg=k)
 
 
 def _rows(rs, *keys):
@@ -349,3 +347,62 @@ def test_coupled_substeps_through_resorts(gate_always):
         assert b.contact_counters()["refused_stale"] >= 1, (b.contact_counters(), sb["rebuilds"])
     _same_rows(ra, rb, "iterations", "contacts", "residual")
     _same(_state(a), _state(b))
+
+
+def test_a_pair_count_the_solve_may_not_index_with_is_refused_with_an_error_code(monkeypatch):
+    """VERDICT r5 item 3 (the memory access fault of round 5's scratch, DESIGN.md section 3.3: a launch that formed an index
+    into a per-pair array from its workgroup number instead of from the clamped count).  The invariant: every kernel that
+    reads the device-side pair count clamps it to the capacity that sized the per-pair buffers, and a count it may not use
+    -- larger than the capacity, or written by another pair generation than the one the solve was enqueued for -- makes the
+    solve refuse itself with an error code before anything is indexed.  With MPM_POISON=1 every buffer that is not
+    zero-initialised starts as 0xFF bytes, so an index formed from something never written would leave the arrays."""
+    from drake_amd import Collider, MpmError
+    monkeypatch.setenv("MPM_POISON", "1")
+    floor = [Collider(0, body=0, p_WB=(0.5, 0.5, Z_FLOOR))]
+    sheets = _pressed_stack()
+    g, ref = _engine(sheets=sheets), _engine(sheets=sheets)
+
+    def to_the_solve(e):
+        e.rebuild_mapping(False)
+        e.calc_fem_state_and_force(DT)
+        e.particle_to_grid(DT)
+        e.update_grid(-1)
+        e.generate_contact_pairs(floor, want_count=False)
+
+    # one good coupled substep on both (buffers allocated, a previous solve's count and set-up in place)
+    for e in (g, ref):
+        to_the_solve(e)
+        r = e.update_contact(DT, MU, K, D)
+        assert r["iterations"] > 0
+        e.grid_to_particle(DT)
+    n_good = g.contact_stats()["contacts"]
+    assert n_good > 500
+    # (1) a count far beyond the capacity of the per-pair buffers
+    to_the_solve(g)
+    g.debug_contact_count(count=50_000_000)
+    with pytest.raises(MpmError) as err:
+        g.update_contact(DT, MU, K, D)
+    assert err.value.code == -4, err.value          # MPM_ERR_CAPACITY
+    # (2) the largest int there is (index arithmetic in 32 bits would wrap around with it)
+    g.generate_contact_pairs(floor, want_count=False)
+    g.debug_contact_count(count=0x7FFFFFFF)
+    with pytest.raises(MpmError) as err:
+        g.update_contact(DT, MU, K, D)
+    assert err.value.code == -4, err.value
+    # (3) a count inside the capacity that the generation of THIS solve did not write (a stale one)
+    g.generate_contact_pairs(floor, want_count=False)
+    g.debug_contact_count(count=n_good, stamp_delta=-1)
+    with pytest.raises(MpmError) as err:
+        g.update_contact(DT, MU, K, D)
+    assert err.value.code == -10, err.value         # MPM_ERR_INTERNAL
+    # nothing was solved, nothing was written: with the pairs made again the substep is the untampered engine's, bit for bit
+    g.generate_contact_pairs(floor, want_count=False)
+    r_g = g.update_contact(DT, MU, K, D)
+    g.grid_to_particle(DT)
+    to_the_solve(ref)
+    r_ref = ref.update_contact(DT, MU, K, D)
+    ref.grid_to_particle(DT)
+    assert (r_g["iterations"], r_g["residual"]) == (r_ref["iterations"], r_ref["residual"])
+    g.gpu_sync(); ref.gpu_sync()
+    assert g.stats()["error_flags"] == 0
+    _same(_state(g), _state(ref))

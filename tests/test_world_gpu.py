@@ -316,3 +316,50 @@ def test_an_owned_vertex_that_misses_a_face_is_reported_by_the_resort():
     assert not flags & 8, flags   # ... and not a NaN that ParticleToGrid found later (ERR_RANGE)
     for g in engines:
         g.destroy()
+
+
+def test_a_migration_header_that_lies_about_its_records_raises_a_flag_and_stores_nothing_out_of_bounds(monkeypatch):
+    """ADVICE r5 (the abort of round 4): which of the two candidate mechanisms can the COMMITTED code
+    still produce -- an exception across the C boundary, or an out-of-bounds store of k_dist_apply?  The host side is
+    replayed in tests/test_error_paths.py (plan_migration with the counts of the faulty tree: the need is clamped to the
+    scene, nothing is sized from an unchecked number, no exception).  This is the device side: a received buffer whose
+    HEADER says "vertices" while its records are faces the rank does not hold -- the host sizes the vertex slots from the
+    header, k_dist_apply appends faces, and its per-slot bound (mpm_dist.h: `slot >= Nf`) is the only thing between the
+    append and the end of the face arrays.  With MPM_POISON=1 (0xFF fill of everything not zero-initialised) and the
+    slot space shrunk to the rank's share: the bound holds -- MPM_ERR_CAPACITY, no store, the device alive, the engine's
+    arrays untouched."""
+    import torch
+    from drake_amd import ARR, MpmError, scenes
+    monkeypatch.setenv("MPM_POISON", "1")
+    bits = 6
+    sheets = scenes.cloth_stack(2, 40, bits, z0=0.5, side=0.25, seed=5, vel_amp=0.2, center=(0.36, 0.5))
+    geo = dict(cuts=[0, 8, 16], zone_blocks=2, ghost_cells=0, ghost_margin_cells=0, migrate_every=0)
+    roles0, w = _run_world(bits, sheets, geo, steps=2, capacity_blocks=512, migrate_capacity=8192)
+    c1 = w.chains[1]
+    g1 = c1.e
+    st = g1.stats()
+    nf = g1.n_faces
+    roles = g1.dist_roles()
+    absent_faces = np.nonzero(roles[:nf] == 0)[0]
+    free_face_slots = st["face_slots"] - st["active_faces"]
+    n_rec = free_face_slots + 500
+    assert absent_faces.size > n_rec and n_rec < c1.mig_cap, (absent_faces.size, n_rec)
+    # records: 9 float4 each behind a 16-byte header; word 0 = original id, word 1 = role (2 = ghost), the rest zeros
+    rec = np.zeros((n_rec, 9, 4), np.float32)
+    rec[:, 0, 0] = absent_faces[:n_rec].astype(np.int32).view(np.float32)
+    rec[:, 0, 1] = np.full(n_rec, 2, np.int32).view(np.float32)
+    rec[:, 1, 3] = 1e-6     # |vol|
+    hdr = np.array([n_rec, 0, 0, 0], np.uint32)      # THE LIE: "n_rec records, none of them a face"
+    buf = np.concatenate([hdr.view(np.uint8), rec.reshape(-1).view(np.uint8)])
+    pos_before = g1.download(ARR.POSITIONS).copy()
+    with torch.cuda.stream(w.stream):
+        c1.mig_recv[c1.left][:buf.size].copy_(torch.from_numpy(buf).to(c1.mig_recv[c1.left].device), non_blocking=True)
+        g1.dist_migrate_apply(c1.mig_recv[c1.left].data_ptr(), None, c1.mig_cap)
+    with pytest.raises(MpmError) as err:
+        g1.gpu_sync()
+    assert err.value.code == -4, err.value        # MPM_ERR_CAPACITY: the per-slot bound, not a fault
+    st2 = g1.stats()
+    assert st2["error_flags"] & 2                   # ERR_CAPACITY
+    # the device is alive and what the rank held is where it was (the appended faces went into FREE slots only)
+    held = roles != 0
+    assert np.array_equal(g1.download(ARR.POSITIONS)[held], pos_before[held])
