@@ -140,7 +140,8 @@ SYMBOLS = [
     "mpm_dist_plan_migration", "mpm_debug_throw", "mpm_debug_fail_alloc", "mpm_set_fast_math", "mpm_get_fast_math",
     "mpm_get_contact_pair_count", "mpm_download_contact_log", "mpm_last_contact_counts",
     "mpm_debug_contact_counters", "mpm_run_coupled_substeps", "mpm_chain_direct_prepare", "mpm_chain_direct_connect",
-    "mpm_debug_contact_count",
+    "mpm_debug_contact_count", "mpm_chain_direct_base", "mpm_chain_direct_connect_local", "mpm_team_prepare", "mpm_team_connect",
+    "mpm_world_coupled_substeps",
 ]
 
 EXCHANGE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t)
@@ -239,6 +240,11 @@ def load_library(build: bool = True):
         "mpm_download_contact_log": [vp, vp, sz, P(sz)],
         "mpm_debug_contact_counters": [vp, P(C.c_uint64)],
         "mpm_debug_contact_count": [vp, i, i],
+        "mpm_chain_direct_base": [vp, P(vp)],
+        "mpm_chain_direct_connect_local": [vp, vp, vp],
+        "mpm_team_prepare": [vp, sz, vp, P(vp)],
+        "mpm_team_connect": [vp, vp, P(vp)],
+        "mpm_world_coupled_substeps": [P(vp), i, i, vp, sz, vp, P(vp)],
         "mpm_run_coupled_substeps": [vp, i, vp, sz, vp, vp],
         "mpm_get_fast_math": [vp, P(i)],
         "mpm_substep_begin_halo": [vp, f, i, P(C.c_int), P(C.c_int), P(C.c_int), P(C.c_void_p), sz],
@@ -549,6 +555,23 @@ class GpuMpm:
             self._n_contacts = out[-1]["contacts"]
         return out
 
+    @staticmethod
+    def world_coupled_substeps(engines, n, dt, colliders, friction_mu, stiffness, damping, mpm_bc=-1, exact_line_search=False,
+                               max_newton_iterations=0):
+        """n coupled substeps of an in-process world (the ranks of ONE partition in this process, all on one stream):
+        mpm_world_coupled_substeps; -> per rank the list of per-substep result dicts"""
+        lib = engines[0].lib
+        if isinstance(colliders, C.Array):
+            arr, nc = colliders, len(colliders)
+        else:
+            arr, nc = (Collider * max(len(colliders), 1))(*colliders), len(colliders)
+        prm = CoupledParams(dt, mpm_bc, friction_mu, stiffness, damping, 1 if exact_line_search else 0, max_newton_iterations)
+        hs = (C.c_void_p * len(engines))(*[e.h for e in engines])
+        res = [(CoupledResult * max(n, 1))() for _ in engines]
+        ptrs = (C.c_void_p * len(engines))(*[C.cast(r, C.c_void_p) for r in res])
+        engines[0]._ck(lib.mpm_world_coupled_substeps(hs, len(engines), n, C.byref(prm), nc, arr, ptrs))
+        return [[dict(iterations=r.iterations, contacts=r.contacts, nodes=r.nodes, residual=r.residual) for r in rr[:n]] for rr in res]
+
     def contact_counters(self) -> dict:
         out = (C.c_uint64 * 6)()
         self._ck(self.lib.mpm_debug_contact_counters(self.h, out))
@@ -762,6 +785,32 @@ class GpuMpm:
 
     def chain_direct_connect(self, left: bytes | None, right: bytes | None):
         self._ck(self.lib.mpm_chain_direct_connect(self.h, C.c_char_p(left) if left else None, C.c_char_p(right) if right else None))
+
+    def chain_direct_base(self) -> int:
+        """address of this rank's direct-halo region (for neighbours that live in the same process)"""
+        out = C.c_void_p()
+        self._ck(self.lib.mpm_chain_direct_base(self.h, C.byref(out)))
+        return int(out.value)
+
+    def chain_direct_connect_local(self, left_base: int | None, right_base: int | None):
+        self._ck(self.lib.mpm_chain_direct_connect_local(self.h, C.c_void_p(left_base) if left_base else None,
+                                                         C.c_void_p(right_base) if right_base else None))
+
+    def team_prepare(self, zone_capacity_blocks: int = 512):
+        """TEAM transport of the distributed contact solve: allocates this rank's region; -> (64-byte IPC handle, address)"""
+        buf = C.create_string_buffer(64)
+        base = C.c_void_p()
+        self._ck(self.lib.mpm_team_prepare(self.h, zone_capacity_blocks, buf, C.byref(base)))
+        return buf.raw, int(base.value)
+
+    def team_connect(self, handles=None, local_bases=None):
+        """handles: the ranks' IPC handles in rank order (own entry ignored); local_bases: addresses of the regions of ranks
+        that live in this process (None elsewhere)"""
+        hb = b"".join((h if h else b"\0" * 64) for h in handles) if handles else None
+        lb = None
+        if local_bases:
+            lb = (C.c_void_p * len(local_bases))(*[C.c_void_p(b) if b else None for b in local_bases])
+        self._ck(self.lib.mpm_team_connect(self.h, C.c_char_p(hb) if hb else None, lb))
 
     def chain_enable_migration(self, every: int, capacity_particles: int):
         self._ck(self.lib.mpm_chain_enable_migration(self.h, every, capacity_particles))

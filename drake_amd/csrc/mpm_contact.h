@@ -431,15 +431,27 @@ static int dist_allreduce(mpm_engine* e, double* dev, size_t n) {
 // (batch sizes: MPM_CT_BATCH="first,next" overrides the defaults, for measurements)
 static int ct_batch(const mpm_engine* e, int which, int dflt) { return e->ct_batch[which] > 0 ? e->ct_batch[which] : dflt; }
 
+// speculate = false: one pattern at a time, each waited for before the next is enqueued -- every rank of a partitioned
+// domain then enqueues EXACTLY the same number of patterns (what it sees after pattern k does not depend on how fast its
+// host polls), which patterns that contain a COLLECTIVE need: with speculation two ranks may see "finished" one
+// publication apart and enqueue different numbers of ncclAllReduce calls (round 6: found by reading, the path had only
+// ever run on a ring of one).
 template <class Pattern>
 static int run_batches(mpm_engine* e, Pattern&& pattern, int first_batch, int batch, int max_iters, MailboxState* out,
-                       int max_patterns = 1 << 30) {
+                       int max_patterns = 1 << 30, bool speculate = true) {
     ContactBuffers& b = e->cb;
     int launched = 0;
     auto enqueue = [&](int count) {
         for (int q = 0; q < count; ++q) b.published += (unsigned)pattern(launched + q);
         launched += count;
     };
+    if (!speculate) {
+        while (true) {
+            enqueue(1);
+            if (int rc = wait_mailbox(e, b.published, out)) return rc;
+            if (out->done || out->iters >= max_iters || launched > max_patterns) return 0;
+        }
+    }
     enqueue(first_batch);
     while (true) {
         const unsigned older = b.published;                // the last publication of what is enqueued so far
@@ -508,6 +520,8 @@ static int solve_once(mpm_engine* e, float dt, float mu, float stiffness, float 
                       SolveOutcome* oc, std::vector<float>* s_res, std::vector<int>* s_ls, std::vector<float>* s_energy,
                       float* s_alpha_last, float* s_E0_last);
 static int contact_stats_from_device(mpm_engine* e);
+static int team_solve(const std::vector<mpm_engine*>& L, float dt, float mu, float stiffness, float damping, int exact, int max_iters,
+                      const std::function<void(size_t)>& before_impulse, std::vector<SolveOutcome>* ocs);
 
 static int update_contact(mpm_engine* e, int frame, int substep, float dt, float mu, float stiffness, float damping,
                           int dump, int exact, int max_iters, int* iters_out, float* residual_out) {
@@ -516,6 +530,17 @@ static int update_contact(mpm_engine* e, int frame, int substep, float dt, float
     if (b.n_bodies == 0) {
         // the reference requires ReallocateExternelBodies first; size the accumulators to the ids in use
         return fail(MPM_ERR_INVALID, "call mpm_reallocate_external_bodies before mpm_update_contact");
+    }
+    if (e->dp.dist.on && e->team.on) {
+        // partitioned domain with the TEAM transport: device resident, every rank takes part whatever its own pair count
+        std::vector<SolveOutcome> ocs;
+        std::function<void(size_t)> hook;
+        if (e->ct_before_impulse) hook = [e](size_t) { e->ct_before_impulse(); };
+        if (int rc = team_solve({e}, dt, mu, stiffness, damping, exact, max_iters, hook, &ocs)) return rc;
+        if (iters_out) *iters_out = ocs[0].mb.iters;
+        if (residual_out) *residual_out = ocs[0].mb.residual;
+        if (dump) return fail(MPM_ERR_INVALID, "the JSON statistics dump is not available on a partitioned domain");
+        return 0;
     }
     e->last_contact_dt = dt; e->last_contact_mu = mu; e->last_contact_k = stiffness; e->last_contact_d = damping;
     const bool dist = e->dp.dist.on && (e->dp.dist.world > 1 || e->ct_force_dist);
@@ -721,7 +746,7 @@ static int solve_once(mpm_engine* e, float dt, float mu, float stiffness, float 
     {
         ContactDev c_in = make_contact_dev(e, dt, mu, stiffness, damping, max_iters, /* sorted = */ false);
         hipLaunchKernelGGL(k_ct_keys, dim3(1024), dim3(256), 0, s, p, c_in, (const uint32_t*)b.api_idx, (const int*)e->d_pids_api, b.slot,
-                           b.published, b.solves, bits, (int)std::min<size_t>(n, 0x7FFFFFFF), reuse ? 1 : 0, full_setup ? 1 : 0, b.gen_stamp);
+                           b.published, b.solves, bits, (int)std::min<size_t>(n, 0x7FFFFFFF), reuse ? 1 : 0, full_setup ? 1 : 0, b.gen_stamp, 0);
     }
     if (!reuse) {
         // CT_NO_CELL has all those bits set and more: it sorts behind every real cell as long as
@@ -861,8 +886,10 @@ static int solve_once(mpm_engine* e, float dt, float mu, float stiffness, float 
         // (a search that never terminates cannot happen -- the root finder stops after 200 evaluations, which in
         // float it often needs: |dx| < 3e-9 is out of reach -- but the launches are bounded too: every Newton
         // iteration may take 200 / PROBES + 1 patterns)
+        // (patterns with ncclAllReduce in them: every rank must enqueue the same number -- no speculation beyond one rank)
+        const bool collective = dist && p.dist.world > 1;
         if (int rc = run_batches(e, pattern, ct_batch(e, 0, 1), ct_batch(e, 1, 1), max_iters, &oc->mb,
-                                 (200 / PROBES + 2) * max_iters + 64))
+                                 (200 / PROBES + 2) * max_iters + 64, !collective))
             return rc;
         if (rc_pattern) return rc_pattern;
         iters = oc->mb.iters;
@@ -943,6 +970,265 @@ static int solve_once(mpm_engine* e, float dt, float mu, float stiffness, float 
         b.n_hint = oc->mb.count;
         // (how many blocks were active: from the control block as this solve's kernels saw it -- a word of the mailbox)
         b.n_active_hint = oc->mb.n_active;
+    }
+    return 0;
+}
+
+
+// ---- TEAM solve: the distributed contact solve, device resident (mpm_team.h) ------------------------------------------
+static TeamDev team_dev(const mpm_engine* e) {
+    TeamDev t{};
+    const mpm_engine::Team& tm = e->team;
+    const Dist& d = e->dp.dist;
+    t.on = tm.on ? 1 : 0;
+    t.rank = tm.rank; t.world = tm.world;
+    t.left = d.has_left ? tm.rank - 1 : -1;
+    t.right = d.has_right ? tm.rank + 1 : -1;
+    t.ts = tm.ts;
+    for (int r = 0; r < TEAM_MAX; ++r) t.peer[r] = static_cast<char*>(tm.peer[r]);
+    t.zone_cap = (unsigned)tm.zone_cap;
+    t.zone_bytes = tm.zone_bytes;
+    t.timeout_ticks = (unsigned long long)((double)tm.timeout_s * 1e8);
+    const int Z = d.zone_cells / 4;
+    t.lo[0] = d.own_lo / 4 - Z; t.hi[0] = d.own_lo / 4 + Z - 1;
+    t.lo[1] = d.own_hi / 4 - Z; t.hi[1] = d.own_hi / 4 + Z - 1;
+    return t;
+}
+
+// One attempt of the solve on every LOCAL rank of the team (`L`: one engine in a process-per-GPU run, all of them in an
+// in-process world), enqueued PHASE BY PHASE across the local ranks: with one rank that is simply the rank's own order;
+// with several ranks on ONE stream every signal is enqueued before the wait that needs it, so the waits return at once
+// and the same kernels serve both set-ups.  The host waits for nothing but the mailbox of the first local rank (all ranks
+// take the same decisions from the same global sums, in the same pattern).
+// `before_impulse(i)`: launched for rank i between the solve's last update and its impulses (GridToParticle), unless the
+// solve refused itself.
+static int team_solve_once(const std::vector<mpm_engine*>& L, float dt, float mu, float stiffness, float damping, int exact, int max_iters,
+                           bool full_setup, std::vector<SolveOutcome>* ocs, const std::function<void(size_t)>& before_impulse) {
+    struct Rank {
+        mpm_engine* e;
+        ContactDev c;
+        TeamDev t;
+        size_t n;
+        unsigned gc, n_tile_wg;
+    };
+    std::vector<Rank> R(L.size());
+    ocs->assign(L.size(), SolveOutcome());
+    const int n_con_wg = CT_ROWS_CON, n_grid_wg = CT_ROWS, n_dir_wg = CT_DIR_WG;
+    // ---- S1: keys, state reset, this rank's status on its way to every rank ---------------------------------------------
+    for (size_t i = 0; i < L.size(); ++i) {
+        mpm_engine* e = L[i];
+        ContactBuffers& b = e->cb;
+        Rank& r = R[i];
+        r.e = e;
+        r.t = team_dev(e);
+        e->last_contact_reused = false;
+        e->last_contact_gated = false;
+        size_t n = b.n;
+        if (b.dev_counted) n = b.n_hint && !full_setup ? std::min<size_t>(b.cap, b.n_hint + b.n_hint / 8 + 256) : b.cap;
+        n = std::max<size_t>(n, 1);
+        r.n = n;
+        r.gc = (unsigned)std::min<size_t>((n + 255) / 256, 2048);
+        r.n_tile_wg = (unsigned)std::max<size_t>(1, std::min<size_t>((n + CT_TILE - 1) / CT_TILE, CT_TILE_WG));
+        b.solves += 1;
+        const DP& p = e->dp;
+        const size_t blocks = b.n_active_hint && !full_setup ? std::min<size_t>((size_t)b.n_active_hint * 2, p.capA) : p.capA;
+        int bits = 1;
+        while (((size_t)1 << bits) < blocks * 64) ++bits;
+        ContactDev c_in = make_contact_dev(e, dt, mu, stiffness, damping, max_iters, /* sorted = */ false);
+        hipLaunchKernelGGL(k_ct_keys, dim3(1024), dim3(256), 0, e->stream, p, c_in, (const uint32_t*)b.api_idx, (const int*)e->d_pids_api,
+                           b.slot, b.published, b.solves, bits, (int)std::min<size_t>(n, 0x7FFFFFFF), 0, full_setup ? 1 : 0, b.gen_stamp, 1);
+        hipLaunchKernelGGL(k_team_status<0>, dim3(1), dim3(64), 0, e->stream, c_in, r.t, e->dp.ctl);
+        // (the sort below runs whatever the status says: it only moves keys inside the buffers)
+        bool in_alt = false;
+        if (radix_sort_pairs(e->stream, b.key, b.order, b.key2, b.order2, b.sort_hist, n, std::min(bits + 1, 31), &in_alt,
+                             b.dev_counted ? &b.st->n : nullptr))
+            return fail(MPM_ERR_HIP, "contact sort failed");
+        b.sorted_in_alt = in_alt;
+        r.c = make_contact_dev(e, dt, mu, stiffness, damping, max_iters);
+    }
+    // ---- S2: the status of all ranks, constants in sorted order, node flags on their way to the neighbours ---------------
+    for (Rank& r : R) {
+        mpm_engine* e = r.e;
+        hipStream_t s = e->stream;
+        const DP& p = e->dp;
+        hipLaunchKernelGGL(k_team_status<1>, dim3(1), dim3(64), 0, s, r.c, r.t, e->dp.ctl);
+        hipLaunchKernelGGL(k_ct_prepare<false>, dim3(r.gc), dim3(256), 0, s, p, r.c);
+        // a node in a zone may be reached by the neighbour's contacts only: both ranks need it listed
+        hipLaunchKernelGGL(k_ct_flags_to_field, dim3(512), dim3(256), 0, s, p, r.c, 0);
+        hipLaunchKernelGGL(k_team_zone_pack<3>, dim3(e->g_grid, 2), dim3(256), 0, s, p, r.c, r.t, (const float4*)e->cb.hg, 0);
+        hipLaunchKernelGGL(k_team_zone_signal, dim3(1), dim3(64), 0, s, r.c, r.t, 0);
+    }
+    // ---- S3: the neighbours' flags, node list ---------------------------------------------------------------------------
+    for (Rank& r : R) {
+        mpm_engine* e = r.e;
+        hipStream_t s = e->stream;
+        const DP& p = e->dp;
+        hipLaunchKernelGGL(k_team_zone_wait, dim3(1), dim3(64), 0, s, r.c, r.t, 0, e->dp.ctl);
+        hipLaunchKernelGGL(k_team_zone_add<3>, dim3(64, 2), dim3(256), 0, s, p, r.c, r.t, e->cb.hg, 0);
+        hipLaunchKernelGGL(k_ct_flags_to_field, dim3(512), dim3(256), 0, s, p, r.c, 1);
+        hipLaunchKernelGGL(k_ct_flag_bits, dim3(256), dim3(256), 0, s, p, r.c);
+        hipLaunchKernelGGL(k_ct_node_list, dim3((unsigned)((p.capA + 255) / 256)), dim3(256), 0, s, p, r.c);
+        hipLaunchKernelGGL(k_ct_node_runs, dim3(1024), dim3(256), 0, s, p, r.c);
+    }
+    // ---- Newton iterations ---------------------------------------------------------------------------------------------
+    // direction: contacts -> per-cell sums -> this rank's (H, G) per node | zone exchange | solve per node
+    auto direction_out = [&](Rank& r, int first, int lazy) {
+        mpm_engine* e = r.e;
+        hipStream_t s = e->stream;
+        const DP& p = e->dp;
+        hipLaunchKernelGGL(k_ct_tile, dim3(r.n_tile_wg), dim3(256), 0, s, p, r.c, first, lazy);
+        hipLaunchKernelGGL(k_ct_node_dir<1>, dim3(n_dir_wg), dim3(CT_WG), 0, s, p, r.c, 0);
+        hipLaunchKernelGGL(k_team_zone_pack<3>, dim3(e->g_grid, 2), dim3(256), 0, s, p, r.c, r.t, (const float4*)e->cb.hg, 1);
+        hipLaunchKernelGGL(k_team_zone_signal, dim3(1), dim3(64), 0, s, r.c, r.t, 1);
+    };
+    auto direction_in = [&](Rank& r, int lazy) {
+        mpm_engine* e = r.e;
+        hipStream_t s = e->stream;
+        const DP& p = e->dp;
+        hipLaunchKernelGGL(k_team_zone_wait, dim3(1), dim3(64), 0, s, r.c, r.t, 1, e->dp.ctl);
+        hipLaunchKernelGGL(k_team_zone_add<3>, dim3(64, 2), dim3(256), 0, s, p, r.c, r.t, e->cb.hg, 1);
+        hipLaunchKernelGGL(k_ct_node_dir<2>, dim3(n_dir_wg), dim3(CT_WG), 0, s, p, r.c, lazy);
+    };
+    const int PROBES = 6;
+    auto pattern = [&](int index) -> int {
+        if (!exact) {
+            // (lazy update as on one GPU: the accepted step reaches the grid in the next iteration's k_ct_node_dir<2>)
+            const int lazy = index == 0 ? 0 : 1;
+            for (Rank& r : R) direction_out(r, index == 0, lazy);
+            for (Rank& r : R) {
+                direction_in(r, lazy);
+                hipLaunchKernelGGL(k_ct_ls, dim3(n_con_wg + n_grid_wg), dim3(CT_WG), 0, r.e->stream, r.e->dp, r.c, n_con_wg, 0, 0.f);
+                hipLaunchKernelGGL(k_ct_decide, dim3(1), dim3(1024), 0, r.e->stream, r.c, n_dir_wg, n_con_wg, n_grid_wg, 0, 4, r.t);
+            }
+            for (Rank& r : R)
+                hipLaunchKernelGGL(k_ct_decide, dim3(1), dim3(1024), 0, r.e->stream, r.c, n_dir_wg, n_con_wg, n_grid_wg, 0, 3, r.t);
+            return 2;
+        }
+        // exact line search: direction, PROBES x (energies at st->alpha_probe | all ranks' sums | state machine), apply, close
+        for (Rank& r : R) direction_out(r, index == 0, 0);
+        for (Rank& r : R) direction_in(r, 0);
+        for (int k = 0; k < PROBES; ++k) {
+            for (Rank& r : R) {
+                hipLaunchKernelGGL(k_ct_ls, dim3(n_con_wg + n_grid_wg), dim3(CT_WG), 0, r.e->stream, r.e->dp, r.c, n_con_wg, 2, 0.f);
+                hipLaunchKernelGGL(k_ct_decide, dim3(1), dim3(1024), 0, r.e->stream, r.c, n_dir_wg, n_con_wg, n_grid_wg, 2, 4, r.t);
+            }
+            for (Rank& r : R)
+                hipLaunchKernelGGL(k_ct_decide, dim3(1), dim3(1024), 0, r.e->stream, r.c, n_dir_wg, n_con_wg, n_grid_wg, 2, 3, r.t);
+        }
+        for (Rank& r : R) {
+            hipLaunchKernelGGL(k_ct_apply, dim3(CT_ROWS), dim3(CT_WG), 0, r.e->stream, r.e->dp, r.c, 1);
+            hipLaunchKernelGGL(k_ct_exact_finish, dim3(1), dim3(64), 0, r.e->stream, r.c);
+        }
+        return 2 * PROBES + 1;
+    };
+    {
+        const int max_patterns = exact ? (200 / PROBES + 2) * max_iters + 64 : 1 << 30;
+        int launched = 0;
+        std::vector<unsigned> older(L.size());
+        auto enqueue = [&](int count) {
+            for (int q = 0; q < count; ++q) {
+                const int pub = pattern(launched + q);
+                for (mpm_engine* e : L) e->cb.published += (unsigned)pub;
+            }
+            launched += count;
+        };
+        enqueue(exact ? ct_batch(L[0], 0, 1) : ct_batch(L[0], 0, 2));
+        while (true) {
+            for (size_t i = 0; i < L.size(); ++i) older[i] = L[i]->cb.published;
+            enqueue(ct_batch(L[0], 1, 1));   // speculative: idle (exchanges included) if the previous batch finished
+            MailboxState& mb = (*ocs)[0].mb;
+            if (int rc = wait_mailbox(L[0], older[0], &mb)) return rc;
+            if (mb.done || mb.iters >= max_iters || launched > max_patterns) break;
+        }
+        // (the other local ranks' words of the same publication: the same decisions, their own counts)
+        for (size_t i = 1; i < L.size(); ++i)
+            if (int rc = wait_mailbox(L[i], older[i], &(*ocs)[i].mb)) return rc;
+    }
+    // ---- the last step, GridToParticle, impulses -----------------------------------------------------------------------
+    for (size_t i = 0; i < L.size(); ++i) {
+        Rank& r = R[i];
+        mpm_engine* e = r.e;
+        const int done = (*ocs)[i].mb.done;
+        if (!exact) hipLaunchKernelGGL(k_ct_apply, dim3(CT_ROWS), dim3(CT_WG), 0, e->stream, e->dp, r.c, 2);
+        if (before_impulse && done != CT_DONE_FAULT && done != CT_DONE_STALE && done != CT_DONE_CORRUPT) before_impulse(i);
+        hipLaunchKernelGGL(k_ct_impulse, dim3(std::min(r.gc, 256u)), dim3(256), 0, e->stream, e->dp, r.c);
+        HIP_TRY(hipGetLastError());
+        e->cb.n_hint = (*ocs)[i].mb.count;
+        e->cb.n_active_hint = (*ocs)[i].mb.n_active;
+    }
+    return 0;
+}
+
+// The solve of all local ranks, refusals repeated (as update_contact does for one engine): the ranks agree on a refusal on
+// the device (k_team_status), so every rank's host sees the same code and all repeat together.
+static int team_solve(const std::vector<mpm_engine*>& L, float dt, float mu, float stiffness, float damping, int exact, int max_iters,
+                      const std::function<void(size_t)>& before_impulse, std::vector<SolveOutcome>* ocs) {
+    if (max_iters <= 0) max_iters = 2000;  // cuda_mpm_solver.cu:234
+    for (mpm_engine* e : L) {
+        REQUIRE(e->team.on && e->dp.dist.on, "team solve: mpm_dist_init and mpm_team_connect first");
+        REQUIRE(e->cb.n_bodies > 0, "call mpm_reallocate_external_bodies before the contact solve");
+        GrowPoison gp(e);
+        // (a rank without a single pair so far takes part all the same: its buffers must exist)
+        if (int rc = ensure_contact_capacity(e, std::max<size_t>(e->cb.cap, e->ct_initial_capacity ? e->ct_initial_capacity
+                                                                                                    : std::max<size_t>(4096, e->np / 16))))
+            return rc;
+        e->last_contact_dt = dt; e->last_contact_mu = mu; e->last_contact_k = stiffness; e->last_contact_d = damping;
+    }
+    bool full_setup = false;
+    for (int attempt = 0;; ++attempt) {
+        REQUIRE(attempt < 8, "contact solve: the set-up keeps being refused");
+        if (int rc = team_solve_once(L, dt, mu, stiffness, damping, exact, max_iters, full_setup, ocs, before_impulse)) return rc;
+        const int done = (*ocs)[0].mb.done;
+        if (done == CT_DONE_CORRUPT) {
+            for (mpm_engine* e : L) {
+                e->cb.dev_counted = false;
+                e->cb.n = 0;
+            }
+            return fail(MPM_ERR_CAPACITY, "contact solve: a rank's pair count on the device is not one the solve may index with "
+                                          "(outside the capacity of its buffers, or stale): nothing was solved on any rank; make the pairs again");
+        }
+        if (done == CT_DONE_FAULT) {
+            for (size_t i = 0; i < L.size(); ++i) {
+                mpm_engine* e = L[i];
+                GrowPoison gp(e);
+                e->ct_counters[3] += 1;
+                if (int rc = ensure_contact_capacity(e, std::max<size_t>((size_t)(*ocs)[i].mb.count, e->cb.cap))) return rc;
+                if (e->cb.dev_counted)   // (pairs made on the device: again, into the grown buffers; nothing has used them yet)
+                    if (int rc = generate_contacts_launch(e)) return rc;
+            }
+            full_setup = true;
+            continue;
+        }
+        if (done == CT_DONE_STALE) {
+            for (mpm_engine* e : L) {
+                e->ct_counters[2] += 1;
+                e->cb.n_active_hint = 0;
+            }
+            full_setup = true;
+            continue;
+        }
+        break;
+    }
+    for (size_t i = 0; i < L.size(); ++i) {
+        mpm_engine* e = L[i];
+        ContactBuffers& b = e->cb;
+        const MailboxState& mb = (*ocs)[i].mb;
+        e->ct_quiet_left = mb.quiet_left;
+        e->ct_counters[0] += 1;
+        if (b.dev_counted) {
+            b.n = mb.count;
+            b.dev_counted = false;
+        }
+        b.last_iters = mb.iters;
+        b.last_unchanged = false;
+        mpm_contact_stats_t& cs = e->last_contact;
+        cs = mpm_contact_stats_t{};
+        cs.iterations = mb.iters;
+        cs.contacts = (uint32_t)b.n;
+        cs.nodes = mb.nodes;
+        cs.residual = mb.residual;
+        e->last_contact_on_device = true;
+        e->last_contact_exact = exact != 0;
     }
     return 0;
 }

@@ -29,6 +29,7 @@
 #include "mpm_device.h"
 #include "mpm_sort.h"
 #include "mpm_rootfind.h"
+#include "mpm_team_dev.h"
 
 namespace mpm {
 
@@ -515,7 +516,7 @@ MPM_DEV void contact_base(const DP& p, const float* pos, uint32_t* b) {
 // the previous list with this one: "unchanged" would be a tautology)
 __global__ __launch_bounds__(256) void k_ct_keys(DP p, ContactDev c, const uint32_t* api_slot, const int* pids_api, uint32_t* slot_out,
                                                  unsigned seq_base, unsigned solve_no, int key_bits, int count_bound, int reuse,
-                                                 int force_changed, unsigned gen_stamp) {
+                                                 int force_changed, unsigned gen_stamp, int team) {
     ContactState* st = c.st;
     const int n_raw = ct_count_raw(c);
     const int n = ct_count(c);   // (clamped: nothing below indexes with the raw word)
@@ -534,8 +535,10 @@ __global__ __launch_bounds__(256) void k_ct_keys(DP p, ContactDev c, const uint3
         const bool narrow = !reuse && ((key_bits < 31 && ((unsigned long long)n_active * 64ull > (1ull << key_bits))) || n > count_bound);
         // (p.gated: the substep went without its re-sort launches; k_grid, in front of this kernel, has left its verdict)
         const bool gated = p.gated && p.ctl->skip_this;
+        // (team: a rank without contacts takes part in the solve all the same -- its zone nodes see the neighbour's contacts,
+        // its rows count in every sum --; "nobody has a contact" is decided by all ranks together, k_team_status)
         const int done0 = corrupt ? CT_DONE_CORRUPT
-                                  : (gated ? CT_DONE_GATED : (fault ? CT_DONE_FAULT : (narrow ? CT_DONE_STALE : (n == 0 ? 1 : 0))));
+                                  : (gated ? CT_DONE_GATED : (fault ? CT_DONE_FAULT : (narrow ? CT_DONE_STALE : (n == 0 && !team ? 1 : 0))));
         // (a reused set-up keeps its node list, and with it the count of listed nodes)
         constexpr int W_NODES = (int)(offsetof(ContactState, n_nodes) / 4);
         if ((int)threadIdx.x < NW) {
@@ -638,9 +641,12 @@ __global__ __launch_bounds__(256) void k_ct_prepare(DP p, ContactDev c) {
         if (blockIdx.x == 0 && threadIdx.x == 0) c.st->done = CT_DONE_STALE;
         return;
     }
+    // (a count the solve may not index with: k_ct_keys has written no keys and no order for it -- what the sort left in
+    // `order` is whatever the buffers held.  Round 6: this kernel ran on regardless and formed addresses from it)
+    if (c.st->done == CT_DONE_CORRUPT) return;
     const PSet& S = p.set[p.ctl->cur];
     for (int j = blockIdx.x * 256 + threadIdx.x; j < n; j += gridDim.x * 256) {
-    const int k = (int)c.order[j];
+    const int k = min((int)(c.order[j] & 0x7FFFFFFFu), N - 1);   // (an index into the per-pair arrays: never outside them)
     const uint32_t key = c.key[j];
     // runs of equal keys
     if (!REUSE && key != CT_NO_CELL) {
@@ -1543,28 +1549,26 @@ struct CtSnap {
 };
 MPM_DEV CtSnap ct_snapshot(const ContactState* st) { return CtSnap{st->ls_phase, st->iters, st->ls_total, st->E0}; }
 
+// phase: 0 = sum and decide in one go; partitioned domain: 1 = only leave this rank's sums in st->red (the host, or
+// ncclAllReduce on the engine's stream, adds the ranks' up); 2 = decide from the global sums put back into st->red;
+// TEAM transport (mpm_team.h): 4 = this rank's sums straight into every rank's slot (+ flags); 3 = wait for all ranks'
+// sums, add them in rank order, decide.
 template <int NT>
-MPM_DEV void ct_decide_from(const ContactDev& c, int exact, int phase, bool deep_pass, double v, double d0, double d1,
-                            double (*s_sum)[CT_PART], double (*s_dir)[2], CtSnap sn);
-
-template <int NT>
-MPM_DEV void ct_decide(const ContactDev& c, int n_dir_wg, int n_con_wg, int n_grid_wg, int exact, int phase,
-                       double (*s_sum)[CT_PART], double (*s_dir)[2]) {
-    ContactState* st = c.st;
-    double v = 0, d0 = 0, d1 = 0;
-    const bool deep_pass = !exact && st->ls_phase == 4;
-    if (phase != 2) ct_thread_sums<NT>(c, n_dir_wg, n_con_wg, n_grid_wg, exact, deep_pass, v, d0, d1);
-    ct_decide_from<NT>(c, exact, phase, deep_pass, v, d0, d1, s_sum, s_dir, ct_snapshot(st));
-}
-
-template <int NT>
-MPM_DEV void ct_decide_from(const ContactDev& c, int exact, int phase, bool deep_pass, double v, double d0, double d1,
+MPM_DEV void ct_decide_from(const ContactDev& c, const TeamDev& tm, int exact, int phase, bool deep_pass, double v, double d0, double d1,
                             double (*s_sum)[CT_PART], double (*s_dir)[2], CtSnap sn) {
     ContactState* st = c.st;
     // entries 0..28: energies; 29: norm_dir; 30: dofs
     if (phase == 2) {
         if (threadIdx.x >= 64) return;
         v = threadIdx.x < 32 ? st->red[threadIdx.x] : 0.0;
+    } else if (phase == 3) {
+        if (threadIdx.x >= 64) return;
+        bool ok = true;
+        v = team_collect_sums(tm, const_cast<Ctl*>(c.ctl), &ok);
+        if (!ok) {   // a rank never arrived (MPM_ERR_HALO is raised): the solve ends here, nothing waits again
+            if (threadIdx.x == 0) st->done = 1;
+            return;
+        }
     } else {
     const int lgNE = exact ? 2 : (deep_pass ? 5 : 3);
     const int RG = NT >> lgNE;
@@ -1598,6 +1602,10 @@ MPM_DEV void ct_decide_from(const ContactDev& c, int exact, int phase, bool deep
     }
     if (phase == 1) {
         if (threadIdx.x < 32) st->red[threadIdx.x] = v;
+        return;
+    }
+    if (phase == 4) {
+        team_push_sums(tm, threadIdx.x < 32 ? v : 0.0);
         return;
     }
     }
@@ -1678,7 +1686,7 @@ MPM_DEV void ct_decide_from(const ContactDev& c, int exact, int phase, bool deep
 }
 
 __global__ __launch_bounds__(1024) void k_ct_decide(ContactDev c, int n_dir_wg, int n_con_wg, int n_grid_wg, int exact,
-                                                    int phase = 0) {
+                                                    int phase = 0, TeamDev tm = TeamDev{}) {
     __shared__ double s_sum[32][CT_PART];
     __shared__ double s_dir[16][2];
     ContactState* st = c.st;
@@ -1689,7 +1697,8 @@ __global__ __launch_bounds__(1024) void k_ct_decide(ContactDev c, int n_dir_wg, 
     const CtSnap sn = ct_snapshot(st);
     const int ls_phase = sn.ls_phase;
     double v = 0, d0 = 0, d1 = 0;
-    if (phase != 2) ct_thread_sums<1024>(c, n_dir_wg, n_con_wg, n_grid_wg, exact, false, v, d0, d1);
+    const bool sums_here = phase != 2 && phase != 3;
+    if (sums_here) ct_thread_sums<1024>(c, n_dir_wg, n_con_wg, n_grid_wg, exact, false, v, d0, d1);
     if (done && !c.force) {
         // "finish after this update" becomes "finished" once that update (k_ct_apply of the
         // previous iteration) has run
@@ -1700,8 +1709,8 @@ __global__ __launch_bounds__(1024) void k_ct_decide(ContactDev c, int n_dir_wg, 
         return;
     }
     const bool deep_pass = !exact && ls_phase == 4;
-    if (deep_pass && phase != 2) ct_thread_sums<1024>(c, n_dir_wg, n_con_wg, n_grid_wg, exact, true, v, d0, d1);
-    ct_decide_from<1024>(c, exact, phase, deep_pass, v, d0, d1, s_sum, s_dir, sn);
+    if (deep_pass && sums_here) ct_thread_sums<1024>(c, n_dir_wg, n_con_wg, n_grid_wg, exact, true, v, d0, d1);
+    ct_decide_from<1024>(c, tm, exact, phase, deep_pass, v, d0, d1, s_sum, s_dir, sn);
     // (thread 0 is the lane that took the decision: its own stores to the state precede this in program order)
     if (threadIdx.x == 0 && c.mbox) ct_publish(c);
 }
@@ -1769,7 +1778,7 @@ __global__ __launch_bounds__(256) void k_ct_impulse(DP p, ContactDev c) {
     const int cn = c.st->done >= CT_DONE_FAULT ? 0 : ct_count(c);   // (a solve that did not run leaves no impulse: the host repeats it)
     bool bad = false;
     for (int j = blockIdx.x * 256 + threadIdx.x; j < cn; j += gridDim.x * 256) {
-        const int k = (int)c.order[j];   // sorted position j is the caller's contact k
+        const int k = min((int)(c.order[j] & 0x7FFFFFFFu), c.stride - 1);   // sorted position j is the caller's contact k
         const float m = c.cmass[j];
         float v[3];
         gather_contact_velocity(p, c, j, v);

@@ -1053,7 +1053,12 @@ int mpm_substep_mid_halo(mpm_handle_t e, float dt, int bc) try {
     return 0;
 } MPM_CATCH_ALL
 
+static int substep_end_halo(mpm_handle_t e, float dt, int bc, int n, const void* const* recv_bufs, size_t cap, bool with_g2p);
 int mpm_substep_end_halo(mpm_handle_t e, float dt, int bc, int n, const void* const* recv_bufs, size_t cap) try {
+    return substep_end_halo(e, dt, bc, n, recv_bufs, cap, true);
+} MPM_CATCH_ALL
+// with_g2p = false: the grid update only -- a coupled substep puts the contact solve between it and GridToParticle
+static int substep_end_halo(mpm_handle_t e, float dt, int bc, int n, const void* const* recv_bufs, size_t cap, bool with_g2p) {
     READY(e);
     REQUIRE(n >= 0 && n <= 2 && (n == 0 || recv_bufs), "bad halo buffer list");
     REQUIRE(e->grid_state == 3, "mpm_substep_end_halo without mpm_substep_begin_halo");
@@ -1062,7 +1067,7 @@ int mpm_substep_end_halo(mpm_handle_t e, float dt, int bc, int n, const void* co
     HaloBufs b{};
     const int lean = e->chain_lean && !e->dp.dist.on;
     std::vector<uint64_t> key = {2, bits_of(dt), (uint64_t)(uint32_t)bc, (uint64_t)n, (uint64_t)cap,
-                                 (uint64_t)(uintptr_t)e->stream, e->grid_colliders_version, (uint64_t)lean};
+                                 (uint64_t)(uintptr_t)e->stream, e->grid_colliders_version, (uint64_t)lean, (uint64_t)with_g2p};
     for (int i = 0; i < n; ++i) {
         REQUIRE(recv_bufs[i], "null halo buffer");
         b.buf[i] = static_cast<const uint32_t*>(recv_bufs[i]);
@@ -1091,7 +1096,7 @@ int mpm_substep_end_halo(mpm_handle_t e, float dt, int bc, int n, const void* co
     auto body = [&]() {
         if (n > 0 && !folded) hipLaunchKernelGGL(k_halo_add2, dim3(64, n), dim3(256), 0, e->stream, p, b, (unsigned)cap);
         hipLaunchKernelGGL(k_grid<2>, dim3(e->g_grid), dim3(256), 0, e->stream, pg, gc);
-        launch_g2p_with(e, p, dt);
+        if (with_g2p) launch_g2p_with(e, p, dt);
     };
     if (e->use_halo_graphs && !split) {
         if (int rc = replay_keyed(e, e->halo_graph[2 * e->halo_graph_parity + 1], key, body)) return rc;
@@ -1100,9 +1105,9 @@ int mpm_substep_end_halo(mpm_handle_t e, float dt, int bc, int n, const void* co
     }
     e->halo_mid_done = false;
     e->grid_state = 2;
-    e->substeps += 1;
+    if (with_g2p) e->substeps += 1;
     return 0;
-} MPM_CATCH_ALL
+}
 
 int mpm_chain_unique_id(char id_out[128]) try {
     REQUIRE(id_out, "null argument");
@@ -1131,6 +1136,14 @@ int mpm_chain_destroy(mpm_handle_t e) try {
     if (c.direct_base) (void)hipFree(c.direct_base);
     if (c.direct_cnt) (void)hipFree(c.direct_cnt);
     c = mpm_engine::Chain();
+    {
+        mpm_engine::Team& t = e->team;
+        for (int r = 0; r < TEAM_MAX; ++r)
+            if (t.mapped[r] && t.peer[r]) (void)hipIpcCloseMemHandle(t.peer[r]);
+        if (t.base) (void)hipFree(t.base);
+        if (t.ts) (void)hipFree(t.ts);
+        t = mpm_engine::Team();
+    }
     return 0;
 } MPM_CATCH_ALL
 
@@ -1282,6 +1295,171 @@ int mpm_chain_direct_connect(mpm_handle_t e, const char left_handle[64], const c
     return 0;
 } MPM_CATCH_ALL
 
+// Neighbours that live in THIS process (an in-process world: several engines of one partition on one stream, for tests and
+// rehearsals of more ranks than a box admits processes): their regions are plain pointers, a HIP IPC handle of one's own
+// process cannot be opened.  mpm_chain_direct_base hands a rank's region out, mpm_chain_direct_connect_local takes the
+// neighbours'.
+int mpm_chain_direct_base(mpm_handle_t e, void** base_out) try {
+    READY(e);
+    REQUIRE(base_out, "null argument");
+    REQUIRE(e->chain.direct_base, "mpm_chain_direct_prepare first");
+    *base_out = e->chain.direct_base;
+    return 0;
+} MPM_CATCH_ALL
+
+int mpm_chain_direct_connect_local(mpm_handle_t e, void* left_base, void* right_base) try {
+    READY(e);
+    mpm_engine::Chain& c = e->chain;
+    REQUIRE(c.direct_base, "mpm_chain_direct_prepare first");
+    REQUIRE((c.left < 0 || left_base) && (c.right < 0 || right_base), "missing region of a neighbour");
+    for (int k = 0; k < 2; ++k) {
+        if (c.peer_mapped[k] && c.peer_base[k] && !(k == 1 && c.peer_base[1] == c.peer_base[0])) (void)hipIpcCloseMemHandle(c.peer_base[k]);
+        c.peer_mapped[k] = false;
+    }
+    c.peer_base[0] = c.left >= 0 ? left_base : nullptr;
+    c.peer_base[1] = c.right >= 0 ? right_base : nullptr;
+    c.direct = true;
+    return 0;
+} MPM_CATCH_ALL
+
+// ---- TEAM transport of the distributed contact solve (mpm_team.h) --------------------------------------------------------
+int mpm_team_prepare(mpm_handle_t e, size_t zone_capacity_blocks, char handle_out[64], void** base_out) try {
+    READY(e);
+    REQUIRE(e->dp.dist.on, "mpm_dist_init first");
+    REQUIRE(e->dp.dist.world <= TEAM_MAX, "the team transport serves the ranks of one node (at most 8)");
+    REQUIRE(zone_capacity_blocks > 0 && zone_capacity_blocks < (1u << 20), "bad zone capacity");
+    mpm_engine::Team& t = e->team;
+    REQUIRE(!t.on, "mpm_team_prepare after mpm_team_connect");
+    if (!t.base) {
+        t.rank = e->dp.dist.rank;
+        t.world = e->dp.dist.world;
+        t.zone_cap = zone_capacity_blocks;
+        t.zone_bytes = team_zone_slot_bytes(zone_capacity_blocks);
+        const size_t bytes = team_region_bytes(t.zone_bytes);
+        // fine-grained or not at all, as for the direct halo (mpm_chain_direct_prepare)
+        const hipError_t fg = hipExtMallocWithFlags(&t.base, bytes, hipDeviceMallocFinegrained);
+        if (fg != hipSuccess) {
+            (void)hipGetLastError();
+            t.base = nullptr;
+            if (!getenv("MPM_DIRECT_COARSE_OK"))
+                return fail(MPM_ERR_HIP, std::string("mpm_team_prepare: fine-grained device memory is not available (") + hipGetErrorString(fg) +
+                                             "): the team transport needs it; the solve stays on the host-driven transports");
+            HIP_TRY(hipMalloc(&t.base, bytes));
+            t.coarse = true;
+        }
+        HIP_TRY(hipMemsetAsync(t.base, 0, bytes, e->stream));
+        HIP_TRY(hipMalloc((void**)&t.ts, sizeof(TeamState)));
+        HIP_TRY(hipMemsetAsync(t.ts, 0, sizeof(TeamState), e->stream));
+        HIP_TRY(hipStreamSynchronize(e->stream));
+        if (const char* s2 = getenv("MPM_HALO_TIMEOUT_S")) t.timeout_s = std::max(.001f, (float)atof(s2));
+    }
+    if (handle_out) {
+        hipIpcMemHandle_t h;
+        HIP_TRY(hipIpcGetMemHandle(&h, t.base));
+        std::memcpy(handle_out, &h, 64);
+    }
+    if (base_out) *base_out = t.base;
+    return 0;
+} MPM_CATCH_ALL
+
+// handles: world x 64 bytes (the IPC handles of all ranks, own slot ignored) or NULL; local_bases: world pointers or NULL --
+// a rank of this process is named by its region's pointer (mpm_team_prepare's base_out), every other one by its handle
+int mpm_team_connect(mpm_handle_t e, const char* handles, void* const* local_bases) try {
+    READY(e);
+    mpm_engine::Team& t = e->team;
+    REQUIRE(t.base, "mpm_team_prepare first");
+    for (int r = 0; r < t.world; ++r) {
+        if (r == t.rank) {
+            t.peer[r] = t.base;
+            continue;
+        }
+        if (t.mapped[r] && t.peer[r]) (void)hipIpcCloseMemHandle(t.peer[r]);
+        t.mapped[r] = false;
+        t.peer[r] = nullptr;
+        if (local_bases && local_bases[r]) {
+            t.peer[r] = local_bases[r];
+            continue;
+        }
+        REQUIRE(handles, "missing IPC handle of a rank");
+        hipIpcMemHandle_t h;
+        std::memcpy(&h, handles + (size_t)r * 64, 64);
+        const hipError_t err = hipIpcOpenMemHandle(&t.peer[r], h, hipIpcMemLazyEnablePeerAccess);
+        if (err != hipSuccess) {
+            (void)hipGetLastError();
+            t.peer[r] = nullptr;
+            return fail(MPM_ERR_HIP, std::string("mpm_team_connect: hipIpcOpenMemHandle: ") + hipGetErrorString(err) +
+                                         " (a rank's region cannot be mapped: another node, or a handle of this very process)");
+        }
+        t.mapped[r] = true;
+    }
+    t.on = true;
+    return 0;
+} MPM_CATCH_ALL
+
+// The two halves of a chain substep over the DIRECT transport (see mpm_chain_substeps): begin = re-sort checks, FEM,
+// ParticleToGrid, raw sums packed into the neighbours' slots of this substep's parity, signal; end = wait, add + grid
+// update (+ GridToParticle).  Between them a coupled substep runs nothing that touches the grid.
+static int chain_zones(const mpm_engine::Chain& c, int* lo, int* hi, int* sh) {
+    int nz = 0;
+    if (c.left >= 0) { lo[nz] = c.zone_lo[0]; hi[nz] = c.zone_hi[0]; sh[nz] = +c.pitch; ++nz; }
+    if (c.right >= 0) { lo[nz] = c.zone_lo[1]; hi[nz] = c.zone_hi[1]; sh[nz] = -c.pitch; ++nz; }
+    return nz;
+}
+static int chain_direct_begin(mpm_engine* e, float dt) {
+    mpm_engine::Chain& c = e->chain;
+    REQUIRE(c.direct, "mpm_chain_direct_connect first");
+    int lo[2], hi[2], sh[2];
+    const int nz = chain_zones(c, lo, hi, sh);
+    c.mig_elapsed += dt;
+    c.steps += 1;
+    const int parity = (int)(c.steps & 1u);
+    const uint32_t seq = (uint32_t)c.steps;
+    void* dsb[2] = {nullptr, nullptr};
+    uint32_t *sig[2] = {nullptr, nullptr}, *cnt[2] = {nullptr, nullptr}, *hdr[2] = {nullptr, nullptr}, *counters[2] = {nullptr, nullptr};
+    int k = 0;
+    if (c.left >= 0) {   // my left zone goes to the left neighbour's "from the right" buffer
+        dsb[k] = direct_buffer(c, c.peer_base[0], 1, parity);
+        sig[0] = direct_flag(c, c.peer_base[0], 1);
+        cnt[0] = c.direct_cnt; hdr[0] = static_cast<uint32_t*>(dsb[k]);
+        counters[k] = cnt[0];
+        ++k;
+    }
+    if (c.right >= 0) {
+        dsb[k] = direct_buffer(c, c.peer_base[1], 0, parity);
+        sig[1] = direct_flag(c, c.peer_base[1], 0);
+        cnt[1] = c.direct_cnt + 8; hdr[1] = static_cast<uint32_t*>(dsb[k]);
+        counters[k] = cnt[1];
+        ++k;
+    }
+    e->halo_graph_parity = parity;
+    const int rc = substep_begin_halo(e, dt, nz, lo, hi, sh, dsb, c.cap, counters);
+    e->halo_graph_parity = 0;
+    if (rc) return rc;
+    if (!c.direct_mute && nz > 0)
+        hipLaunchKernelGGL(k_halo_signal, dim3(1), dim3(64), 0, e->stream, sig[0], sig[1], seq, (const uint32_t*)cnt[0], hdr[0],
+                           (const uint32_t*)cnt[1], hdr[1], (unsigned)c.cap);
+    return 0;
+}
+static int chain_direct_end(mpm_engine* e, float dt, int bc, bool with_g2p) {
+    mpm_engine::Chain& c = e->chain;
+    int lo[2], hi[2], sh[2];
+    const int nz = chain_zones(c, lo, hi, sh);
+    const int parity = (int)(c.steps & 1u);
+    const uint32_t seq = (uint32_t)c.steps;
+    void* drb[2] = {nullptr, nullptr};
+    uint32_t* mine[2] = {nullptr, nullptr};
+    int k = 0;
+    if (c.left >= 0) { drb[k++] = direct_buffer(c, c.direct_base, 0, parity); mine[0] = direct_flag(c, c.direct_base, 0); }
+    if (c.right >= 0) { drb[k++] = direct_buffer(c, c.direct_base, 1, parity); mine[1] = direct_flag(c, c.direct_base, 1); }
+    if (nz > 0)
+        hipLaunchKernelGGL(k_halo_wait, dim3(1), dim3(64), 0, e->stream, (const uint32_t*)mine[0], (const uint32_t*)mine[1], seq,
+                           (unsigned long long)((double)c.direct_timeout_s * 1e8), e->dp.ctl);
+    e->halo_graph_parity = parity;
+    const int rc = substep_end_halo(e, dt, bc, nz, drb, c.cap, with_g2p);
+    e->halo_graph_parity = 0;
+    return rc;
+}
+
 int mpm_chain_substeps(mpm_handle_t e, int n, float dt, int bc) try {
     READY(e);
     mpm_engine::Chain& c = e->chain;
@@ -1358,51 +1536,20 @@ int mpm_chain_substeps(mpm_handle_t e, int n, float dt, int bc) try {
                 if (int rc = mpm_dist_retune(e, t, dt, nullptr)) return rc;   // (band widths for the migrations to come)
             }
         }
-        c.mig_elapsed += dt;
-        c.steps += 1;
         e->chain_lean = s + 1 < n;   // (reset below; the two calls are public entry points of their own as well)
         if (c.direct && nz > 0) {
             // DIRECT: the pack kernel stores into the neighbours' receive buffers of this substep's parity (two in
             // rotation: a neighbour may still be reading the other one -- it cannot be reading this one: its read of
             // substep s - 2 precedes its signal of s - 1, which this rank's update of s - 1 has waited for), a one-thread
             // kernel raises the flags over there, a one-wave kernel waits for this rank's.
-            const int parity = (int)(c.steps & 1u);
-            const uint32_t seq = (uint32_t)c.steps;
-            void *dsb[2], *drb[2];
-            uint32_t *sig[2] = {nullptr, nullptr}, *mine[2] = {nullptr, nullptr};
-            uint32_t *cnt[2] = {nullptr, nullptr}, *hdr[2] = {nullptr, nullptr}, *counters[2] = {nullptr, nullptr};
-            int k = 0;
-            if (c.left >= 0) {   // my left zone goes to the left neighbour's "from the right" buffer
-                dsb[k] = direct_buffer(c, c.peer_base[0], 1, parity);
-                drb[k] = direct_buffer(c, c.direct_base, 0, parity);
-                sig[0] = direct_flag(c, c.peer_base[0], 1);
-                mine[0] = direct_flag(c, c.direct_base, 0);
-                cnt[0] = c.direct_cnt; hdr[0] = static_cast<uint32_t*>(dsb[k]);
-                counters[k] = cnt[0];
-                ++k;
-            }
-            if (c.right >= 0) {
-                dsb[k] = direct_buffer(c, c.peer_base[1], 0, parity);
-                drb[k] = direct_buffer(c, c.direct_base, 1, parity);
-                sig[1] = direct_flag(c, c.peer_base[1], 0);
-                mine[1] = direct_flag(c, c.direct_base, 1);
-                cnt[1] = c.direct_cnt + 8; hdr[1] = static_cast<uint32_t*>(dsb[k]);
-                counters[k] = cnt[1];
-                ++k;
-            }
-            e->halo_graph_parity = parity;
-            struct ParityReset { mpm_engine* e; ~ParityReset() { e->halo_graph_parity = 0; } } parity_reset{e};
-            if (int rc = substep_begin_halo(e, dt, nz, lo, hi, sh, dsb, c.cap, counters)) return rc;
-            if (!c.direct_mute)
-                hipLaunchKernelGGL(k_halo_signal, dim3(1), dim3(64), 0, e->stream, sig[0], sig[1], seq, (const uint32_t*)cnt[0], hdr[0],
-                                   (const uint32_t*)cnt[1], hdr[1], (unsigned)c.cap);
-            hipLaunchKernelGGL(k_halo_wait, dim3(1), dim3(64), 0, e->stream, (const uint32_t*)mine[0], (const uint32_t*)mine[1], seq,
-                               (unsigned long long)((double)c.direct_timeout_s * 1e8), e->dp.ctl);
-            const int rc_end = mpm_substep_end_halo(e, dt, bc, nz, drb, c.cap);
+            int rc_d = chain_direct_begin(e, dt);
+            if (!rc_d) rc_d = chain_direct_end(e, dt, bc, true);
             e->chain_lean = 0;
-            if (rc_end) return rc_end;
+            if (rc_d) return rc_d;
             continue;
         }
+        c.mig_elapsed += dt;
+        c.steps += 1;
         if (int rc = mpm_substep_begin_halo(e, dt, nz, lo, hi, sh, sb, c.cap)) {
             e->chain_lean = 0;
             return rc;
@@ -2387,7 +2534,8 @@ int mpm_update_contact(mpm_handle_t e, int frame, int substep, float dt, float m
     if (iters_out) *iters_out = 0;
     if (residual_out) *residual_out = 0.f;
     e->last_contact = mpm_contact_stats_t{};
-    if (!e->cb.dev_counted && e->cb.n == 0) return 0;  // cuda_mpm_solver.cu:216-217
+    // (a rank of a TEAM takes part in the solve whatever its own pair count: "no contacts" is decided by all ranks together)
+    if (!e->cb.dev_counted && e->cb.n == 0 && !(e->dp.dist.on && e->team.on)) return 0;  // cuda_mpm_solver.cu:216-217
     REQUIRE(e->grid_state == 2, "UpdateContact before UpdateGrid");
     return update_contact(e, frame, substep, dt, mu, stiffness, damping, dump, exact, max_iters, iters_out,
                           residual_out);
@@ -2402,13 +2550,82 @@ int mpm_update_contact(mpm_handle_t e, int frame, int substep, float dt, float m
 // has converged -- and has the next substep's long kernels (FEM, ParticleToGrid) enqueued before the short ones of the
 // contact set-up are due; between two substeps of the call GridToParticle and ParticleToGrid leave out what only a
 // download would read (DP::lean_g2p), as mpm_run_substeps does.
+// Coupled substeps of a PARTITIONED domain (BASELINE config 5's path): the same loop body on every
+// local rank of the team, enqueued phase by phase across them -- halo of the raw node sums over the DIRECT transport, grid
+// update, pairs of the particles each rank owns (counted on the device), the TEAM solve (mpm_team.h: zone exchange of the
+// per-node Hessian / gradient sums with the neighbours and rank-ordered sums of the line-search rows, all on the engines'
+// streams), GridToParticle, impulses (per-rank partial sums).  The host waits once per substep, for the mailbox.  No
+// migration in here: the caller runs the substeps between two migrations in one call (DomainChain / LocalWorld decide when
+// one is due); no contact-free speculation either -- "does any rank have a pair" is part of the solve's first exchange.
+static int team_coupled_substeps(const std::vector<mpm_engine*>& L, int n, const mpm_coupled_params_t* prm, size_t n_colliders,
+                                 const mpm_collider_t* colliders, mpm_coupled_result_t* const* results) {
+    const float dt = prm->dt;
+    for (mpm_engine* e : L) {
+        REQUIRE(e->dp.dist.on && e->team.on && e->chain.direct,
+                "coupled substeps on a partitioned domain need the direct halo (mpm_chain_direct_connect) and the team transport (mpm_team_connect)");
+        REQUIRE(e->chain.pitch == 0, "coupled substeps: a partitioned domain has pitch 0");
+    }
+    GridColliders gc;
+    if (int rc = grid_colliders_for(L[0], prm->mpm_bc, &gc)) return rc;
+    for (int s = 0; s < n; ++s) {
+        for (mpm_engine* e : L) {
+            may_resort(e, dt);
+            e->chain_lean = 0;
+            if (int rc = chain_direct_begin(e, dt)) return rc;
+        }
+        for (mpm_engine* e : L)
+            if (int rc = chain_direct_end(e, dt, prm->mpm_bc, false)) return rc;
+        for (mpm_engine* e : L)
+            if (int rc = generate_contacts(e, n_colliders, colliders, nullptr)) return rc;
+        std::vector<SolveOutcome> ocs;
+        auto g2p = [&](size_t i) { launch_g2p(L[i], dt); };
+        if (int rc = team_solve(L, dt, prm->friction_mu, prm->stiffness, prm->damping, prm->exact_line_search, prm->max_newton_iterations,
+                                g2p, &ocs))
+            return rc;
+        for (size_t i = 0; i < L.size(); ++i) {
+            mpm_engine* e = L[i];
+            e->substeps += 1;
+            e->grid_state = 2;
+            if (results && results[i]) {
+                mpm_coupled_result_t& r = results[i][s];
+                r.iterations = ocs[i].mb.iters;
+                r.contacts = e->last_contact.contacts;
+                r.nodes = e->last_contact.nodes;
+                r.residual = ocs[i].mb.residual;
+                r.setup_reused = 0;
+            }
+        }
+    }
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+// The ranks of ONE partition that live in this process (an in-process world: tests and rehearsals with more ranks than a
+// box admits processes), all on one stream: n coupled substeps of the whole world in one call.  results: n_local arrays of
+// n entries, or NULL.
+int mpm_world_coupled_substeps(mpm_handle_t* handles, int n_local, int n, const mpm_coupled_params_t* prm, size_t n_colliders,
+                               const mpm_collider_t* colliders, mpm_coupled_result_t* const* results) try {
+    REQUIRE(handles && n_local >= 1 && n_local <= TEAM_MAX && prm && n >= 0, "bad arguments");
+    REQUIRE(n_colliders > 0 && colliders && n_colliders <= 1024, "bad collider array");
+    std::vector<mpm_engine*> L(handles, handles + n_local);
+    for (mpm_engine* e : L) {
+        READY(e);
+        REQUIRE(e->stream == L[0]->stream, "an in-process world runs on ONE stream (mpm_set_stream)");
+    }
+    return team_coupled_substeps(L, n, prm, n_colliders, colliders, results);
+} MPM_CATCH_ALL
+
 int mpm_run_coupled_substeps(mpm_handle_t e, int n, const mpm_coupled_params_t* prm, size_t n_colliders,
                              const mpm_collider_t* colliders, mpm_coupled_result_t* results) try {
     READY(e);
     REQUIRE(prm && n >= 0, "bad arguments");
     REQUIRE(n_colliders == 0 || colliders, "null collider array");
     REQUIRE(n_colliders <= 1024, "too many colliders");
-    REQUIRE(!e->dp.dist.on, "mpm_run_coupled_substeps: not on a partitioned domain (use the phase calls)");
+    if (e->dp.dist.on) {
+        REQUIRE(n_colliders > 0, "coupled substeps on a partitioned domain need colliders (contact-free: mpm_chain_substeps)");
+        mpm_coupled_result_t* one[1] = {results};
+        return team_coupled_substeps({e}, n, prm, n_colliders, colliders, results ? one : nullptr);
+    }
     if (n_colliders == 0) {   // nothing to couple with: contact-free substeps
         if (results)
             for (int s = 0; s < n; ++s) results[s] = mpm_coupled_result_t{};

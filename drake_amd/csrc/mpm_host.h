@@ -16,6 +16,7 @@
 #include "mpm_rebuild.h"
 #include "mpm_step.h"
 #include "mpm_contact_dev.h"
+#include "mpm_team.h"
 #include "mpm_trace.h"
 
 using namespace mpm;
@@ -158,6 +159,19 @@ struct mpm_engine {
         uint32_t* direct_cnt = nullptr;   // [2] entry counters of the two zones a substep packs, in THIS device's memory
         bool direct_coarse = false;       // the region is NOT fine-grained (MPM_DIRECT_COARSE_OK=1: one-device rehearsals only)
     } chain;
+    // TEAM transport of the distributed contact solve (mpm_team.h, mpm_team_prepare / _connect): this rank's region, every
+    // rank's region as mapped here, the device-side exchange counters
+    struct Team {
+        bool on = false;
+        int rank = 0, world = 1;
+        void* base = nullptr;                 // this rank's region (fine-grained device memory)
+        void* peer[TEAM_MAX] = {};            // every rank's, as this rank addresses it (peer[rank] == base)
+        bool mapped[TEAM_MAX] = {};           // ... through hipIpcOpenMemHandle (else: a pointer of this process)
+        size_t zone_cap = 0, zone_bytes = 0;
+        TeamState* ts = nullptr;
+        bool coarse = false;                  // NOT fine-grained (MPM_DIRECT_COARSE_OK=1: one-device rehearsals only)
+        float timeout_s = 5.f;
+    } team;
     bool halo_mid_done = false;   // mpm_substep_mid_halo ran in this substep
     int halo_nz = 0, halo_zlo[2] = {0, 0}, halo_zhi[2] = {0, 0};
     unsigned g_rb = 2048;  // workgroups of the particle-parallel re-sort kernels

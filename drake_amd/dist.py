@@ -213,6 +213,8 @@ class DomainChain(HaloChain):
         super().__init__(engine, rank, world, cut_lo_block=cuts[rank], cut_hi_block=cuts[rank + 1], pitch_blocks=0,
                          zone_blocks=zone_blocks, capacity_blocks=capacity_blocks, device=device, group=group,
                          split=split, backend=backend)
+        self._cuts, self._zone_blocks = list(cuts), zone_blocks
+        self.team = False
         self.migrate_every, self.mig_cap = int(migrate_every), int(migrate_capacity)
         self.steps = 0
         self.migrations = 0
@@ -253,6 +255,81 @@ class DomainChain(HaloChain):
             dist.all_reduce(t, group=self.group)
 
         self.e.dist_set_transport(exchange, allreduce, zone_capacity_blocks)
+
+    def enable_team(self, zone_capacity_blocks: int = 512):
+        """Device-resident coupled substeps on this partition (mpm_team.h): the per-substep halo over the DIRECT transport
+        and the contact solve's exchanges over the TEAM transport -- peer stores + sequence flags on the engine's stream,
+        regions mapped through HIP IPC handles that travel over this chain's process group.  Every rank calls it; returns
+        False (and leaves every rank on the host-driven transports) when any rank could not set it up."""
+        e = self.e
+        ok, why, hd, ht = True, "", None, None
+        try:
+            e.chain_init(None, self.rank, self.world, self._cuts[self.rank], self._cuts[self.rank + 1], 0, self._zone_blocks, self.cap)
+            hd = e.chain_direct_prepare()
+            ht, _ = e.team_prepare(zone_capacity_blocks)
+        except Exception as ex:  # noqa: BLE001  (e.g. no fine-grained memory: all ranks must fall back together)
+            ok, why = False, str(ex)
+        got = [None] * self.world
+        dist.all_gather_object(got, (ok, why, hd, ht), group=self.group)
+        if all(g[0] for g in got):
+            try:
+                e.chain_direct_connect(got[self.left][2] if self.left is not None else None,
+                                       got[self.right][2] if self.right is not None else None)
+                e.team_connect([g[3] for g in got])
+            except Exception as ex:  # noqa: BLE001
+                ok, why = False, str(ex)
+        else:
+            ok = False
+            why = "; ".join(g[1] for g in got if not g[0])
+        flags = [None] * self.world
+        dist.all_gather_object(flags, ok, group=self.group)
+        self.team = all(flags)
+        self.team_error = why
+        if not self.team:
+            try:
+                e.chain_destroy()
+            except Exception:  # noqa: BLE001
+                pass
+        return self.team
+
+    def _substeps_until_migration(self, n: int, dt: float) -> int:
+        """how many of the next n substeps run before a migration is due (0: one is due now)"""
+        k = 0
+        steps, elapsed = self.steps, self.mig_elapsed
+        while k < n:
+            self.last_dt = dt
+            if self.world > 1:
+                due = (steps > 0 and steps % self.migrate_every == 0) if self.migrate_every > 0 else not (elapsed + dt <= self.mig_budget)
+                if due and k == 0:
+                    return 0
+                if due:
+                    break
+            k += 1
+            steps += 1
+            elapsed += dt
+        return k
+
+    def coupled_substeps(self, n: int, dt: float, colliders, friction_mu, stiffness, damping, mpm_bc=-1, exact_line_search=False,
+                         max_newton_iterations=0):
+        """n coupled substeps of the partition (deformable_driver.h:240-258 per substep, on every rank): migrations when they
+        are due, the substeps between two migrations in ONE call of mpm_run_coupled_substeps (device resident: enable_team).
+        -> this rank's per-substep results"""
+        assert getattr(self, "team", False), "enable_team() first"
+        out, left = [], n
+        while left > 0:
+            k = self._substeps_until_migration(left, dt)
+            if k == 0:
+                self.migrate()
+                if self.migrate_every > 0:      # (the fixed cadence counts substeps: this one runs now)
+                    k = min(left, self.migrate_every)
+                else:
+                    k = max(1, self._substeps_until_migration(left, dt))
+            out += self.e.run_coupled_substeps(k, dt, colliders, friction_mu, stiffness, damping, mpm_bc, exact_line_search,
+                                               max_newton_iterations)
+            self.steps += k
+            self.mig_elapsed += k * dt
+            left -= k
+        return out
 
     def migrate(self):
         if self.world == 1:
@@ -422,6 +499,51 @@ class LocalWorld:
     def run_substeps(self, n: int, dt: float, mpm_bc: int = -1):
         for _ in range(n):
             self.substep(dt, mpm_bc)
+
+    def enable_team(self, zone_capacity_blocks: int = 512):
+        """The direct halo and the TEAM transport between the ranks of this process (regions named by pointer): what
+        DomainChain.enable_team sets up between processes through IPC handles."""
+        with torch.cuda.stream(self.stream):
+            for c in self.chains:
+                c.e.chain_init(None, c.rank, self.world, c._cuts[c.rank], c._cuts[c.rank + 1], 0, c._zone_blocks, c.cap)
+                c.e.chain_direct_prepare()
+            halo = [c.e.chain_direct_base() for c in self.chains]
+            regions = []
+            for c in self.chains:
+                c.e.chain_direct_connect_local(halo[c.left] if c.left is not None else None, halo[c.right] if c.right is not None else None)
+                regions.append(c.e.team_prepare(zone_capacity_blocks)[1])
+            for c in self.chains:
+                c.e.team_connect(None, [None if r == c.rank else regions[r] for r in range(self.world)])
+                c.team = True
+        self.stream.synchronize()
+
+    def coupled_substeps(self, n: int, dt: float, colliders, friction_mu, stiffness, damping, mpm_bc=-1, exact_line_search=False,
+                         max_newton_iterations=0):
+        """n coupled substeps of the whole world (mpm_world_coupled_substeps: every phase enqueued for all ranks in turn on
+        the one stream), migrations when they are due.  -> per rank the list of per-substep results"""
+        from drake_amd import GpuMpm
+        engines = [c.e for c in self.chains]
+        out = [[] for _ in engines]
+        left = n
+        with torch.cuda.stream(self.stream):
+            while left > 0:
+                ks = [c._substeps_until_migration(left, dt) for c in self.chains]
+                k = min(ks)
+                if k == 0:
+                    self._migrate()
+                    if self.chains[0].migrate_every > 0:
+                        k = min(left, self.chains[0].migrate_every)
+                    else:
+                        k = max(1, min(c._substeps_until_migration(left, dt) for c in self.chains))
+                res = GpuMpm.world_coupled_substeps(engines, k, dt, colliders, friction_mu, stiffness, damping, mpm_bc,
+                                                    exact_line_search, max_newton_iterations)
+                for i, r in enumerate(res):
+                    out[i] += r
+                for c in self.chains:
+                    c.steps += k
+                    c.mig_elapsed += k * dt
+                left -= k
+        return out
 
     def sync(self):
         for c in self.chains:

@@ -458,6 +458,9 @@ typedef struct {
 } mpm_coupled_result_t;
 MPM_API int mpm_run_coupled_substeps(mpm_handle_t h, int n, const mpm_coupled_params_t *params, size_t n_colliders,
                                      const mpm_collider_t *colliders, mpm_coupled_result_t *results);
+/* (partitioned domains: see mpm_team_prepare below) */
+MPM_API int mpm_world_coupled_substeps(mpm_handle_t *handles, int n_local, int n, const mpm_coupled_params_t *params,
+                                       size_t n_colliders, const mpm_collider_t *colliders, mpm_coupled_result_t *const *results);
 
 /* Runs n substeps with HIP events around every kernel group on the engine's
  * stream and returns the mean milliseconds per substep of each phase
@@ -530,6 +533,38 @@ MPM_API int mpm_chain_destroy(mpm_handle_t h);
  * two devices, which this build has never run on. */
 MPM_API int mpm_chain_direct_prepare(mpm_handle_t h, char handle_out[64]);
 MPM_API int mpm_chain_direct_connect(mpm_handle_t h, const char left_handle[64], const char right_handle[64]);
+/* Round 6: the region must be FINE-GRAINED device memory -- mpm_chain_direct_prepare returns MPM_ERR_HIP when the runtime
+ * refuses it (a coarse-grained region would let stale lines of the receiver's L2 shadow a peer's stores: wrong sums, no
+ * error flag), and the caller then keeps every rank on RCCL; MPM_DIRECT_COARSE_OK=1 accepts plain device memory for
+ * rehearsals on ONE device.  The pack counts its entries in this device's memory and the count travels with the signal: no
+ * returning atomic on peer memory.
+ * Neighbours that live in THIS process (an in-process world: several ranks of one partition on one stream) are named by
+ * pointer -- a HIP IPC handle of one's own process cannot be opened: mpm_chain_direct_base hands a rank's region out,
+ * mpm_chain_direct_connect_local takes the neighbours' (NULL where there is none). */
+MPM_API int mpm_chain_direct_base(mpm_handle_t h, void **base_out);
+MPM_API int mpm_chain_direct_connect_local(mpm_handle_t h, void *left_base, void *right_base);
+
+/* TEAM transport of the distributed contact solve (round 6; the reference has one device, settings.h:40, and reads its
+ * global scalars back per Newton iteration, cuda_mpm_solver.cu:318-319, 359-363, 515-517, 567-570): on a partitioned
+ * domain the per-node Hessian / gradient sums of the zone blocks go to the two neighbours and the line-search sums to
+ * every rank as stores into each other's memory + sequence flags ON THE ENGINE'S STREAM; every rank adds all ranks' sums
+ * in rank order (identical bits, identical `E1 <= E0` decisions, no collective library), whether any rank has a pair at
+ * all and whether any rank must refuse its solve (buffers overflowed, a wrong guess of its host) is agreed the same way,
+ * and the host only polls the mailbox, as on one GPU.  Needs mpm_dist_init; at most 8 ranks (one node).
+ *   mpm_team_prepare(h, zone_capacity_blocks, handle_out, base_out)   allocates this rank's region (fine-grained, as
+ *        above), returns its IPC handle (64 bytes, may be NULL) and its address (for ranks of the same process, may be NULL)
+ *   mpm_team_connect(h, handles, local_bases)   handles: world x 64 bytes in rank order (own entry ignored) or NULL;
+ *        local_bases: world pointers or NULL -- a rank of this process is named by its region's address, any other by
+ *        its handle.
+ * With the team connected, mpm_update_contact on a partitioned engine runs the device-resident solve (EVERY rank must
+ * call it in every coupled substep, with or without pairs of its own), and mpm_run_coupled_substeps accepts a partitioned
+ * engine whose halo runs over the direct transport: n coupled substeps per call, no migration inside (the caller runs the
+ * substeps between two migrations in one call), no contact-free speculation.  mpm_world_coupled_substeps does the same for
+ * the n_local ranks of an in-process world (all on one stream), enqueued phase by phase across the ranks; results: n_local
+ * arrays of n entries, or NULL.  Validated between processes sharing one GPU and in in-process worlds: the protocol, the
+ * indexing, the rank-order sums -- NOT the ordering of peer stores across two devices. */
+MPM_API int mpm_team_prepare(mpm_handle_t h, size_t zone_capacity_blocks, char handle_out[64], void **base_out);
+MPM_API int mpm_team_connect(mpm_handle_t h, const char *handles, void *const *local_bases);
 
 /* ---- multi-GPU, ONE domain cut into x slabs (strong scaling) ------------------------------
  * Every rank is created and finalised with the WHOLE scene (same mpm_add_qr_cloth calls: replicated

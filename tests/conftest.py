@@ -12,6 +12,16 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+@pytest.fixture(autouse=True)
+def _reset_margin_tag():
+    yield
+    try:
+        from tests import helpers
+        helpers.tag_default_engine(False)
+    except Exception:  # noqa: BLE001
+        pass
+
+
 @pytest.fixture(scope="session")
 def golden():
     import json

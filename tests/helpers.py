@@ -6,6 +6,15 @@ from oracle import oracle as orc
 
 RTOL = 1e-5  # BASELINE.json north_star: "float state within 1e-5 relative"
 MARGINS = []  # (error / allowed, what) of every comparison, reported at the end of the session
+# appended to the name of every comparison while a test's smoke variant on the DEFAULT engine runs (particle order inside a
+# cell from atomics: its margins differ from run to run; the deterministic variants' do not -- gpurun_out/parity_margins.txt
+# of two runs agree on every line without this tag); reset after every test (tests/conftest.py)
+TAG = ""
+
+
+def tag_default_engine(on=True):
+    global TAG
+    TAG = " [default engine: varies from run to run]" if on else ""
 
 
 def close(a, b, scale=None, rtol=RTOL, what=""):
@@ -21,7 +30,7 @@ def close(a, b, scale=None, rtol=RTOL, what=""):
     err = float(np.max(np.abs(a - b)))
     plain = float(np.max(np.abs(b)))
     # (error / allowed, what, tolerance, error relative to the test's scale, error relative to plain max|ref|)
-    MARGINS.append((err / (rtol * scale + 1e-30), what, rtol, err / (scale + 1e-300), err / (plain + 1e-300)))
+    MARGINS.append((err / (rtol * scale + 1e-30), what + TAG, rtol, err / (scale + 1e-300), err / (plain + 1e-300)))
     assert np.all(np.isfinite(a)), what
     assert err <= rtol * scale + 1e-30, f"{what}: max err {err:.3e} > {rtol:.0e} * scale {scale:.3e}"
 
