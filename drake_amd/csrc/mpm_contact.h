@@ -1140,9 +1140,14 @@ static int team_solve_once(const std::vector<mpm_engine*>& L, float dt, float mu
             if (int rc = wait_mailbox(L[0], older[0], &mb)) return rc;
             if (mb.done || mb.iters >= max_iters || launched > max_patterns) break;
         }
-        // (the other local ranks' words of the same publication: the same decisions, their own counts)
-        for (size_t i = 1; i < L.size(); ++i)
-            if (int rc = wait_mailbox(L[i], older[i], &(*ocs)[i].mb)) return rc;
+        // (the other local ranks' words of THE SAME publication -- the one the first rank's poll happened to see, which may
+        // be later than the one it waited for --: the same decisions, their own counts)
+        const unsigned ahead = (*ocs)[0].mb.seq - older[0];
+        for (size_t i = 1; i < L.size(); ++i) {
+            if (int rc = wait_mailbox(L[i], older[i] + ahead, &(*ocs)[i].mb)) return rc;
+            if ((*ocs)[i].mb.done != (*ocs)[0].mb.done && (*ocs)[i].mb.seq == older[i] + ahead)
+                return fail(MPM_ERR_INTERNAL, "team solve: two ranks of one process disagree about the state of the solve");
+        }
     }
     // ---- the last step, GridToParticle, impulses -----------------------------------------------------------------------
     for (size_t i = 0; i < L.size(); ++i) {
