@@ -294,6 +294,72 @@ def contact_leg(device, steps=20, warmup=5):
                 workload="cloth_1m on a half-space, pairs from mpm_generate_contact_pairs (device)")
 
 
+def team_contact_leg(rank, world, local_rank, config, steps=10, warmup=3):
+    """BASELINE.json configs[4] (config 5: a cloth and a 16-link manipulator, two-way coupled, on several GPUs) as far as
+    the hot path goes: the cloth stack of `config` pressed on a floor (body 0) under 16 capsules (bodies 1..16) that move
+    with prescribed velocities, partitioned like the headline run, coupled substeps through DomainChain.coupled_substeps:
+    the per-substep halo over the DIRECT transport and the contact solve's exchanges over the TEAM transport
+    (drake_amd/csrc/mpm_team.h) -- peer stores + sequence flags on the engines' streams, the host polls the mailbox only --,
+    migrations between the batches.  Every rank calls this.  UNMEASURED ON HARDWARE with world > 1: on this pool the ranks
+    share one GPU (a rehearsal of the protocol: rc 0, contacts, iterations), the milliseconds mean nothing."""
+    import torch
+    import torch.distributed as dist
+    from drake_amd import Collider, GpuMpm, scenes
+    from drake_amd.dist import DomainChain, strong_geometry
+    bits, layers, res = scenes.CONFIGS[config]
+    floor_z, k, d, mu, dt = 0.25, 1e6, 1e-5, 1.0, 2e-4
+    geo = strong_geometry(bits, world)
+    g = GpuMpm(bits, device=local_rank)
+    sheets = scenes.cloth_stack(layers, res, bits, z0=floor_z - 0.004)
+    for pos, vel, idx in sheets:
+        vel[:, 2] -= 0.5
+    scenes.populate(g, sheets)
+    g.reallocate_external_bodies(17)
+    chain = DomainChain(g, rank, world, geo["cuts"], geo["zone_blocks"], geo["ghost_cells"], geo["ghost_margin_cells"], 1024,
+                        geo["migrate_every"], 65536, device=torch.device("cuda", local_rank))
+    ok = chain.enable_team(1024)
+    if not ok:
+        return dict(error="team transport not available: " + chain.team_error)
+    top = floor_z - 0.004 + layers * 0.5 / (1 << bits)
+    Ry = (0.0, 1.0, 0.0, 0.0, 0.0, 1.0, 1.0, 0.0, 0.0)    # the capsules' axes along y
+
+    def colliders(t):
+        cols = [Collider(0, body=0, p_WB=(0.5, 0.5, floor_z))]
+        for j in range(16):   # a row of links along x, alternately moving left and right: some straddle every cut
+            vx = 0.5 if j % 2 == 0 else -0.5
+            cols.append(Collider(3, body=1 + j, p_WB=(0.27 + 0.03 * j + vx * t, 0.5, top + 0.006), R_WB=Ry, dims=(0.012, 0.2, 0.0),
+                                 v=(vx, 0.0, 0.0)))
+        return cols
+
+    chain.coupled_substeps(warmup, dt, colliders(0.0), mu, k, d)
+    g.gpu_sync()
+    dist.barrier()
+    t0 = time.perf_counter()
+    rs = chain.coupled_substeps(steps, dt, colliders(warmup * dt), mu, k, d)
+    g.gpu_sync()
+    dist.barrier()
+    el = time.perf_counter() - t0
+    t = torch.tensor([el, float(sum(r["contacts"] for r in rs))], dtype=torch.float64)
+    dist.all_reduce(t[:1], op=dist.ReduceOp.MAX)
+    dist.all_reduce(t[1:], op=dist.ReduceOp.SUM)
+    tau, f = g.external_body_force_to_host()
+    fs = torch.from_numpy(np.ascontiguousarray(f, dtype=np.float64))
+    dist.all_reduce(fs, op=dist.ReduceOp.SUM)
+    st = g.stats()
+    assert st["error_flags"] == 0, st
+    out = dict(ms_per_substep=float(t[0]) / steps * 1e3, contacts=float(t[1]) / steps, newton_iterations=float(np.mean([r["iterations"] for r in rs])),
+               steps=steps, warmup=warmup, bodies=17, migrations=chain.migrations,
+               bodies_with_an_impulse=int(np.count_nonzero(np.abs(fs.numpy()).max(axis=1) > 0)),
+               transport="halo: peer stores + flags (mpm_chain_direct); solve: zone exchange + rank-ordered sums as peer stores + flags "
+                         "(mpm_team); host: mailbox polling only",
+               params=dict(stiffness=k, damping=d, friction_mu=mu, dt=dt, floor_z=floor_z, line_search="backtracking"),
+               workload=f"{config} on a half-space under 16 moving capsules, partitioned into {world} x slabs, pairs made on the device",
+               note="unmeasured on hardware with world > 1: on this pool the ranks share one GPU (a rehearsal)")
+    g.chain_destroy()
+    g.destroy()
+    return out
+
+
 def launch_ranks(n, argv):
     """`python bench.py --gpus N` without torchrun: start N rank processes of this same script
     (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in their environment, rendezvous on 127.0.0.1) and
@@ -706,6 +772,16 @@ def main():
                                "the vertex-force slot is empty (the vertex lanes of k_p2g do that work): its interval is "
                                "the cost of an event pair; phase_ms are raw intervals")
 
+    team_contact = None
+    engine_fast_math = g.fast_math
+    if world > 1 and strong and not args.no_contact_leg:
+        if native:
+            g.chain_destroy()
+        g.destroy()
+        try:
+            team_contact = team_contact_leg(rank, world, local_rank, args.config)
+        except Exception as exc:  # noqa: BLE001  (the headline line must come out whatever this leg does)
+            team_contact = dict(error=repr(exc))
     if rank == 0:
         if world == 1:
             par = "single GPU"
@@ -719,7 +795,7 @@ def main():
                    n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=el / args.steps * 1e3,
                    higher_is_better=True, scaling="strong" if strong or world == 1 and args.scaling == "strong" else "weak",
                    vs_baseline=None, dtype="f32", data="synthetic",
-                   arithmetic=("fast math (mpm_set_fast_math: hardware reciprocal / rsqrt + one Newton step in k_fem)" if g.fast_math
+                   arithmetic=("fast math (mpm_set_fast_math: hardware reciprocal / rsqrt + one Newton step in k_fem)" if engine_fast_math
                                else "correctly rounded divisions and square roots in k_fem (the default; MPM_FAST_MATH=1 / "
                                     "mpm_set_fast_math select the approximations: k_fem 1.7 us shorter in the kernel traces)"),
                    config=dict(workload=f"{args.config}: {npart} particles ({nf} faces + {nv} vertices), "
@@ -734,6 +810,8 @@ def main():
             out["steady_state"] = steady
         if ref_pattern is not None:
             out["reference_call_pattern"] = ref_pattern
+        if team_contact is not None:
+            out["contact"] = team_contact
         if not args.no_contact_leg and world == 1:
             g.destroy()
             out["contact"] = contact_leg(local_rank)
