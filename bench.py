@@ -316,7 +316,7 @@ def team_contact_leg(rank, world, local_rank, config, steps=10, warmup=3):
     scenes.populate(g, sheets)
     g.reallocate_external_bodies(17)
     chain = DomainChain(g, rank, world, geo["cuts"], geo["zone_blocks"], geo["ghost_cells"], geo["ghost_margin_cells"], 1024,
-                        geo["migrate_every"], 65536, device=torch.device("cuda", local_rank))
+                        geo["migrate_every"], 1 << 18, device=torch.device("cuda", local_rank))
     ok = chain.enable_team(1024)
     if not ok:
         return dict(error="team transport not available: " + chain.team_error)
