@@ -1,33 +1,40 @@
-"""What a rank of the weak-scaling chain runs per substep, measured on one GPU: the 1M workload as a ring of one (the
-rank is its own neighbour on both sides) -- with RCCL sending to itself, and with the DIRECT exchange (stores into the
-"neighbour's" buffer + sequence flags, mpm_chain_direct_*) -- against the plain batched substeps."""
+"""What a rank of the chain runs per substep, measured on one GPU: the 1M workload as a ring of one (the rank is its own
+neighbour on both sides) -- over RCCL (send / recv to itself on the engine's stream), over the DIRECT exchange (stores into
+the "neighbour's" buffer + sequence flags, mpm_chain_direct_*), and the direct exchange as round 5 had it (every block a
+raw sum until the second grid kernel: MPM_HALO_NO_INTERIOR=1) -- against the plain batched substeps, all engines alive at
+once and timed in turn, several rounds (the boxes of the pool differ by +-8 us: only figures of one run compare)."""
 import os, sys, time
 import torch  # noqa: F401  (before RCCL is bound)
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from drake_amd import GpuMpm, scenes
 bits, layers, res = scenes.CONFIGS["cloth_1m"]
 nb = (1 << bits) // 4
-def engine():
-    g = GpuMpm(bits)
+N = int(os.environ.get("CHAIN_COST_SUBSTEPS", "40"))
+def engine(env=None):
+    old = {k: os.environ.get(k) for k in (env or {})}
+    os.environ.update(env or {})
+    try:
+        g = GpuMpm(bits)   # (environment switches are read per handle)
+    finally:
+        for k, v in old.items():
+            if v is None: os.environ.pop(k, None)
+            else: os.environ[k] = v
     scenes.populate(g, scenes.cloth_stack(layers, res, bits, seed=1234))
     return g
-g = engine()
-g.chain_init(GpuMpm.chain_unique_id(), 0, 1, nb // 4, 3 * nb // 4, nb // 2, 2, 1024, periodic=True)
-g.chain_substeps(5, 1e-3, -1); g.gpu_sync()
-for k in range(3):
-    t0 = time.perf_counter(); g.chain_substeps(20, 1e-3, -1); g.gpu_sync(); el = time.perf_counter() - t0
-    print("chain (ring of one): %.1f us/substep" % (el / 20 * 1e6), g.stats()["error_flags"], flush=True)
-g.chain_destroy(); g.destroy()
-g = engine()
-g.chain_init(None, 0, 1, nb // 4, 3 * nb // 4, nb // 2, 2, 1024, periodic=True)
-g.chain_direct_prepare(); g.chain_direct_connect(None, None)
-g.chain_substeps(5, 1e-3, -1); g.gpu_sync()
-for k in range(3):
-    t0 = time.perf_counter(); g.chain_substeps(20, 1e-3, -1); g.gpu_sync(); el = time.perf_counter() - t0
-    print("chain (ring of one, direct): %.1f us/substep" % (el / 20 * 1e6), g.stats()["error_flags"], flush=True)
-g.chain_destroy(); g.destroy()
-g = engine()
-g.run_substeps(5, 1e-3, -1); g.gpu_sync()
-for k in range(3):
-    t0 = time.perf_counter(); g.run_substeps(20, 1e-3, -1); g.gpu_sync(); el = time.perf_counter() - t0
-    print("plain: %.1f us/substep" % (el / 20 * 1e6), flush=True)
+def ring(g, direct):
+    g.chain_init(None if direct else GpuMpm.chain_unique_id(), 0, 1, nb // 4, 3 * nb // 4, nb // 2, 2, 1024, periodic=True)
+    if direct:
+        g.chain_direct_prepare(); g.chain_direct_connect(None, None)
+    return g
+runs = {
+    "plain (mpm_run_substeps)": (engine(), lambda g, n: g.run_substeps(n, 1e-3, -1)),
+    "ring of one, RCCL": (ring(engine(), False), lambda g, n: g.chain_substeps(n, 1e-3, -1)),
+    "ring of one, direct": (ring(engine(), True), lambda g, n: g.chain_substeps(n, 1e-3, -1)),
+    "ring of one, direct, round 5's grid kernels": (ring(engine({"MPM_HALO_NO_INTERIOR": "1"}), True), lambda g, n: g.chain_substeps(n, 1e-3, -1)),
+}
+for name, (g, f) in runs.items():
+    f(g, 5); g.gpu_sync()
+for rnd in range(4):
+    for name, (g, f) in runs.items():
+        t0 = time.perf_counter(); f(g, N); g.gpu_sync(); el = time.perf_counter() - t0
+        print(f"round {rnd}: {name}: {el / N * 1e6:.1f} us/substep (error flags {g.stats()['error_flags']}, re-sorts so far {g.stats()['rebuilds']})", flush=True)
