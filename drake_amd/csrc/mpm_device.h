@@ -227,7 +227,6 @@ struct DP {
     // per launch: restrict k_grid<2> / k_g2p to the part of the grid that does (1) or does not (0)
     // depend on the halo exchange; -1 = everything.  Zones are x-block ranges [lo, hi].
     int halo_cls, halo_nz, halo_zlo[2], halo_zhi[2];
-    int halo_interior;     // per launch of k_grid<0>: update the blocks outside the zones halo_zlo..zhi right away (see k_grid)
     // per launch of k_grid<0> in a chain substep: the zones whose raw node sums go straight into the send buffers
     // (what k_halo_pack2 does as a kernel of its own for the public mpm_halo_pack)
     int halo_pn, halo_plo[2], halo_phi[2], halo_pshift[2];

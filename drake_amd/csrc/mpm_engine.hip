@@ -984,18 +984,15 @@ static int replay_keyed(mpm_engine* e, mpm_engine::KeyedGraph& kg, const std::ve
 }
 static uint64_t bits_of(float f) { uint32_t u; std::memcpy(&u, &f, 4); return u; }
 
-constexpr int NO_INTERIOR = -0x7FFFFFFF;
 static int substep_begin_halo(mpm_handle_t e, float dt, int n, const int* bx_lo, const int* bx_hi, const int* shift_bx,
-                              void* const* send_bufs, size_t cap, uint32_t* const* counters, int interior_bc);
+                              void* const* send_bufs, size_t cap, uint32_t* const* counters);
 int mpm_substep_begin_halo(mpm_handle_t e, float dt, int n, const int* bx_lo, const int* bx_hi, const int* shift_bx,
                            void* const* send_bufs, size_t cap) try {
-    return substep_begin_halo(e, dt, n, bx_lo, bx_hi, shift_bx, send_bufs, cap, nullptr, NO_INTERIOR);
+    return substep_begin_halo(e, dt, n, bx_lo, bx_hi, shift_bx, send_bufs, cap, nullptr);
 } MPM_CATCH_ALL
 // counters: per zone the word the pack counts its entries in (null: word 0 of the send buffer itself)
-// interior_bc: the mpm_bc of the grid update that follows (mpm_chain_substeps knows it): the blocks OUTSIDE the zones are
-// updated by k_grid<0> itself and the end half only touches the zone blocks; NO_INTERIOR: everything stays raw sums
 static int substep_begin_halo(mpm_handle_t e, float dt, int n, const int* bx_lo, const int* bx_hi, const int* shift_bx,
-                              void* const* send_bufs, size_t cap, uint32_t* const* counters, int interior_bc) {
+                              void* const* send_bufs, size_t cap, uint32_t* const* counters) {
     READY(e);
     may_resort(e, dt);
     REQUIRE(n >= 0 && n <= 2 && (n == 0 || (bx_lo && bx_hi && shift_bx && send_bufs)), "bad halo zone list");
@@ -1004,18 +1001,9 @@ static int substep_begin_halo(mpm_handle_t e, float dt, int n, const int* bx_lo,
     DP pp = e->dp;  // ... and k_p2g, in front of it, resets their entry counters
     p.halo_pn = n;
     p.halo_pcap = (unsigned)cap;
-    GridColliders gc_interior{};
-    const bool interior = interior_bc != NO_INTERIOR && n > 0 && !e->halo_no_interior;
-    if (interior) {
-        if (int rc = grid_colliders_for(e, interior_bc, &gc_interior)) return rc;
-        p.halo_interior = 1;
-        p.halo_nz = n;
-        for (int i = 0; i < n; ++i) { p.halo_zlo[i] = bx_lo[i]; p.halo_zhi[i] = bx_hi[i]; }
-    }
     // (mpm_chain_substeps: another substep of the same batch follows, see DP::lean_g2p)
     const int lean = e->chain_lean && !e->dp.dist.on;
-    std::vector<uint64_t> key = {1, bits_of(dt), (uint64_t)n, (uint64_t)cap, (uint64_t)(uintptr_t)e->stream, (uint64_t)lean,
-                                 (uint64_t)interior, (uint64_t)(uint32_t)interior_bc, interior ? e->grid_colliders_version : 0};
+    std::vector<uint64_t> key = {1, bits_of(dt), (uint64_t)n, (uint64_t)cap, (uint64_t)(uintptr_t)e->stream, (uint64_t)lean};
     for (int i = 0; i < n; ++i) {
         REQUIRE(send_bufs[i], "null halo buffer");
         pp.halo_hdr[i] = counters && counters[i] ? counters[i] : static_cast<uint32_t*>(send_bufs[i]);
@@ -1034,7 +1022,7 @@ static int substep_begin_halo(mpm_handle_t e, float dt, int n, const int* bx_lo,
         launch_fem_p2g(e, dt);
         for (int i = 0; i < 2; ++i) e->dp.halo_hdr[i] = nullptr;
         e->dp.lean_g2p = 0;
-        hipLaunchKernelGGL(k_grid<0>, dim3(e->g_grid), dim3(256), 0, e->stream, p, gc_interior);
+        hipLaunchKernelGGL(k_grid<0>, dim3(e->g_grid), dim3(256), 0, e->stream, p, GridColliders{});
     };
     if (e->use_halo_graphs) {
         if (int rc = replay_keyed(e, e->halo_graph[2 * e->halo_graph_parity], key, body)) return rc;
@@ -1043,8 +1031,6 @@ static int substep_begin_halo(mpm_handle_t e, float dt, int n, const int* bx_lo,
     }
     e->grid_state = 3;
     e->halo_mid_done = false;
-    e->halo_interior_done = interior;
-    e->halo_interior_bc = interior_bc;
     e->halo_nz = n;
     for (int i = 0; i < n; ++i) { e->halo_zlo[i] = bx_lo[i]; e->halo_zhi[i] = bx_hi[i]; }
     return 0;
@@ -1055,7 +1041,6 @@ static int substep_begin_halo(mpm_handle_t e, float dt, int n, const int* bx_lo,
 int mpm_substep_mid_halo(mpm_handle_t e, float dt, int bc) try {
     READY(e);
     REQUIRE(e->grid_state == 3 && !e->halo_mid_done, "mpm_substep_mid_halo needs mpm_substep_begin_halo first");
-    REQUIRE(!e->halo_interior_done, "mpm_substep_mid_halo: the interior of this substep's grid is updated already");
     GridColliders gc;
     if (int rc = grid_colliders_for(e, bc, &gc)) return rc;
     DP p = e->dp;
@@ -1081,17 +1066,14 @@ static int substep_end_halo(mpm_handle_t e, float dt, int bc, int n, const void*
     if (int rc = grid_colliders_for(e, bc, &gc)) return rc;
     HaloBufs b{};
     const int lean = e->chain_lean && !e->dp.dist.on;
-    const bool split = e->halo_mid_done;
-    const bool interior_done = e->halo_interior_done && !split;
-    REQUIRE(!interior_done || bc == e->halo_interior_bc, "the grid update of a chain substep changed its mpm_bc between the two halves");
     std::vector<uint64_t> key = {2, bits_of(dt), (uint64_t)(uint32_t)bc, (uint64_t)n, (uint64_t)cap,
-                                 (uint64_t)(uintptr_t)e->stream, e->grid_colliders_version, (uint64_t)lean, (uint64_t)with_g2p,
-                                 (uint64_t)interior_done};
+                                 (uint64_t)(uintptr_t)e->stream, e->grid_colliders_version, (uint64_t)lean, (uint64_t)with_g2p};
     for (int i = 0; i < n; ++i) {
         REQUIRE(recv_bufs[i], "null halo buffer");
         b.buf[i] = static_cast<const uint32_t*>(recv_bufs[i]);
         key.push_back((uint64_t)(uintptr_t)recv_bufs[i]);
     }
+    const bool split = e->halo_mid_done;
     DP p = e->dp;
     p.lean_g2p = lean;
     if (split) {   // the interior is done: only what the received sums touch is left
@@ -1102,11 +1084,6 @@ static int substep_end_halo(mpm_handle_t e, float dt, int bc, int n, const void*
     // The received sums are added inside the grid update (k_grid<2> looks its zone blocks up in the buffers): one launch
     // less per substep than add + update.  Needs the zones of the matching mpm_substep_begin_halo, buffer i <-> zone i.
     DP pg = p;
-    if (interior_done) {   // k_grid<0> has updated everything outside the zones already: the zone blocks are what is left
-        pg.halo_cls = 1;
-        pg.halo_nz = e->halo_nz;
-        for (int i = 0; i < e->halo_nz; ++i) { pg.halo_zlo[i] = e->halo_zlo[i]; pg.halo_zhi[i] = e->halo_zhi[i]; }
-    }
     const bool folded = n > 0 && n == e->halo_nz;
     if (folded) {
         pg.halo_pn = n;
@@ -1127,7 +1104,6 @@ static int substep_end_halo(mpm_handle_t e, float dt, int bc, int n, const void*
         body();
     }
     e->halo_mid_done = false;
-    e->halo_interior_done = false;
     e->grid_state = 2;
     if (with_g2p) e->substeps += 1;
     return 0;
@@ -1429,7 +1405,7 @@ static int chain_zones(const mpm_engine::Chain& c, int* lo, int* hi, int* sh) {
     if (c.right >= 0) { lo[nz] = c.zone_lo[1]; hi[nz] = c.zone_hi[1]; sh[nz] = -c.pitch; ++nz; }
     return nz;
 }
-static int chain_direct_begin(mpm_engine* e, float dt, int bc) {
+static int chain_direct_begin(mpm_engine* e, float dt) {
     mpm_engine::Chain& c = e->chain;
     REQUIRE(c.direct, "mpm_chain_direct_connect first");
     int lo[2], hi[2], sh[2];
@@ -1456,7 +1432,7 @@ static int chain_direct_begin(mpm_engine* e, float dt, int bc) {
         ++k;
     }
     e->halo_graph_parity = parity;
-    const int rc = substep_begin_halo(e, dt, nz, lo, hi, sh, dsb, c.cap, counters, bc);
+    const int rc = substep_begin_halo(e, dt, nz, lo, hi, sh, dsb, c.cap, counters);
     e->halo_graph_parity = 0;
     if (rc) return rc;
     if (!c.direct_mute && nz > 0)
@@ -1566,7 +1542,7 @@ int mpm_chain_substeps(mpm_handle_t e, int n, float dt, int bc) try {
             // rotation: a neighbour may still be reading the other one -- it cannot be reading this one: its read of
             // substep s - 2 precedes its signal of s - 1, which this rank's update of s - 1 has waited for), a one-thread
             // kernel raises the flags over there, a one-wave kernel waits for this rank's.
-            int rc_d = chain_direct_begin(e, dt, bc);
+            int rc_d = chain_direct_begin(e, dt);
             if (!rc_d) rc_d = chain_direct_end(e, dt, bc, true);
             e->chain_lean = 0;
             if (rc_d) return rc_d;
@@ -1574,7 +1550,7 @@ int mpm_chain_substeps(mpm_handle_t e, int n, float dt, int bc) try {
         }
         c.mig_elapsed += dt;
         c.steps += 1;
-        if (int rc = substep_begin_halo(e, dt, nz, lo, hi, sh, sb, c.cap, nullptr, bc)) {
+        if (int rc = mpm_substep_begin_halo(e, dt, nz, lo, hi, sh, sb, c.cap)) {
             e->chain_lean = 0;
             return rc;
         }
@@ -1592,7 +1568,7 @@ int mpm_chain_substeps(mpm_handle_t e, int n, float dt, int bc) try {
             RCCL_TRY(rc_g);
             RCCL_TRY(rc_e);
         }
-        const int rc_end = substep_end_halo(e, dt, bc, nz, rb, c.cap, true);
+        const int rc_end = mpm_substep_end_halo(e, dt, bc, nz, rb, c.cap);
         e->chain_lean = 0;
         if (rc_end) return rc_end;
     }
@@ -2595,7 +2571,7 @@ static int team_coupled_substeps(const std::vector<mpm_engine*>& L, int n, const
         for (mpm_engine* e : L) {
             may_resort(e, dt);
             e->chain_lean = 0;
-            if (int rc = chain_direct_begin(e, dt, prm->mpm_bc)) return rc;
+            if (int rc = chain_direct_begin(e, dt)) return rc;
         }
         for (mpm_engine* e : L)
             if (int rc = chain_direct_end(e, dt, prm->mpm_bc, false)) return rc;

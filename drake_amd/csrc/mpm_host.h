@@ -173,9 +173,6 @@ struct mpm_engine {
         float timeout_s = 5.f;
     } team;
     bool halo_mid_done = false;   // mpm_substep_mid_halo ran in this substep
-    bool halo_interior_done = false;   // k_grid<0> of this chain substep has updated the blocks outside the zones (DP::halo_interior)
-    int halo_interior_bc = 0;
-    bool halo_no_interior = getenv("MPM_HALO_NO_INTERIOR") != nullptr;   // (A/B: round 5's split of the work between the two grid kernels)
     int halo_nz = 0, halo_zlo[2] = {0, 0}, halo_zhi[2] = {0, 0};
     unsigned g_rb = 2048;  // workgroups of the particle-parallel re-sort kernels
     int grid_state = 0;  // 0 nothing, 1 slabs valid (after P2G), 2 grid updated

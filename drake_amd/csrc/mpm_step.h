@@ -960,17 +960,7 @@ __global__ __launch_bounds__(256) void k_grid(DP p, GridColliders gc) {
             __builtin_amdgcn_wave_barrier();   // the list is reused by the wave's next block
         }
         const size_t gi = (size_t)a * 64 + cell;
-        // MODE 0 of a chain substep with halo_interior (round 6): only the blocks of the exchanged zones stay raw sums; every
-        // other block depends on no neighbour and is updated HERE, so that the kernel behind the exchange (k_grid<2> with
-        // halo_cls = 1) touches the zone blocks alone -- a tenth of the grid instead of all of it, ~3 us of a chain rank's
-        // fixed cost
-        bool raw_only = MODE == 0;
-        if (MODE == 0 && p.halo_interior) {
-            int hx, hy, hz;
-            block_coords(p.act_block[a], hx, hy, hz);
-            raw_only = in_halo_zone(p, hx);   // wave-uniform
-        }
-        if (MODE == 0 && raw_only) {
+        if (MODE == 0) {
             p.gv[gi] = s;
             if (p.halo_pn > 0) {   // chain substep: blocks next to a cut go into the send buffers from here
                 int bx, by, bz;

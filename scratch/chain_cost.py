@@ -1,8 +1,10 @@
 """What a rank of the chain runs per substep, measured on one GPU: the 1M workload as a ring of one (the rank is its own
-neighbour on both sides) -- over RCCL (send / recv to itself on the engine's stream), over the DIRECT exchange (stores into
-the "neighbour's" buffer + sequence flags, mpm_chain_direct_*), and the direct exchange as round 5 had it (every block a
-raw sum until the second grid kernel: MPM_HALO_NO_INTERIOR=1) -- against the plain batched substeps, all engines alive at
-once and timed in turn, several rounds (the boxes of the pool differ by +-8 us: only figures of one run compare)."""
+neighbour on both sides) -- over RCCL (send / recv to itself on the engine's stream) and over the DIRECT exchange (stores
+into the "neighbour's" buffer + sequence flags, mpm_chain_direct_*) -- against the plain batched substeps, all engines alive
+at once and timed in turn, several rounds (the boxes of the pool differ by +-8 us: only figures of one run compare).
+(profiles/r06_ring_of_one_interior_ab.txt: the same with a fourth engine whose first grid kernel updated the blocks outside
+the zones itself, so that the kernel behind the exchange touched the zone blocks only -- 112.8 / 115.5 / 117.8 / 117.5 us
+against 113.5 / 115.4 / 115.8 / 117.4: nothing; the change was taken out again, DESIGN_HISTORY.md section 8.)"""
 import os, sys, time
 import torch  # noqa: F401  (before RCCL is bound)
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -30,7 +32,6 @@ runs = {
     "plain (mpm_run_substeps)": (engine(), lambda g, n: g.run_substeps(n, 1e-3, -1)),
     "ring of one, RCCL": (ring(engine(), False), lambda g, n: g.chain_substeps(n, 1e-3, -1)),
     "ring of one, direct": (ring(engine(), True), lambda g, n: g.chain_substeps(n, 1e-3, -1)),
-    "ring of one, direct, round 5's grid kernels": (ring(engine({"MPM_HALO_NO_INTERIOR": "1"}), True), lambda g, n: g.chain_substeps(n, 1e-3, -1)),
 }
 for name, (g, f) in runs.items():
     f(g, 5); g.gpu_sync()
