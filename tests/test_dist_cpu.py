@@ -292,3 +292,109 @@ def test_a_chain_on_an_nccl_group_never_touches_the_default_group():
     assert sorted(g for r in range(world) for g in got[r][0]) == list(range(300))
     for r in range(world):
         assert "all_reduce" in got[r][1] and "batch_isend_irecv" in got[r][1]
+
+
+# ---- DomainChain.enable_team / coupled_substeps: the host logic of the device-resident coupled path ----------------------
+class FakeTeamEngine(FakeDomainEngine):
+    """Stand-in for the calls of the TEAM set-up and of mpm_run_coupled_substeps on a partitioned engine: what is checked
+    here is the host logic around them -- all ranks or none switch to the team transport, the substeps between two
+    migrations go into ONE call, the cadence is the chain's."""
+
+    def __init__(self, n_particles, nb, fail_prepare=False):
+        super().__init__(n_particles, nb)
+        self.fail_prepare = fail_prepare
+
+    def chain_init(self, uid, rank, world, cut_lo, cut_hi, pitch, zone, cap):
+        assert uid is None and pitch == 0
+        self.calls.append(("chain_init", cut_lo, cut_hi))
+
+    def chain_direct_prepare(self):
+        return bytes([self.rank]) * 64
+
+    def team_prepare(self, zone_capacity_blocks):
+        if self.fail_prepare:
+            raise RuntimeError("no fine-grained memory on this rank")
+        return bytes([100 + self.rank]) * 64, 0
+
+    def chain_direct_connect(self, left, right):
+        self.calls.append(("direct_connect", left[0] if left else None, right[0] if right else None))
+
+    def team_connect(self, handles, local_bases=None):
+        self.calls.append(("team_connect", tuple(h[0] for h in handles)))
+
+    def chain_destroy(self):
+        self.calls.append("chain_destroy")
+
+    def run_coupled_substeps(self, k, dt, colliders, mu, stiffness, damping, mpm_bc, exact, max_iters):
+        self.calls.append(("coupled", k))
+        for _ in range(k):
+            for g in self.x:
+                self.x[g] += 0.7
+        return [dict(iterations=1, contacts=0, nodes=0, residual=0.0, setup_reused=False) for _ in range(k)]
+
+
+def _team_worker(rank, world, cuts, port, q, migrate_every, failing_rank):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.pop("MPM_MIG_SAFETY", None)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from drake_amd.dist import DomainChain
+    eng = FakeTeamEngine(300, cuts[-1], fail_prepare=rank == failing_rank)
+    eng.dist_migration_quiet_time = lambda: (rank + 2) * 3.0e-3
+    chain = DomainChain(eng, rank, world, cuts, zone_blocks=2, ghost_cells=2, ghost_margin_cells=2, capacity_blocks=16,
+                        migrate_every=migrate_every, migrate_capacity=128)
+    ok = chain.enable_team(64)
+    res = []
+    if ok:
+        res += chain.coupled_substeps(5, 1e-3, [], 0.5, 1e5, 1e-3)
+        res += chain.coupled_substeps(7, 1e-3, [], 0.5, 1e5, 1e-3)
+    q.put((rank, ok, chain.team_error, set(eng.owned), eng.calls, len(res)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,cuts,migrate_every,failing_rank", [(2, [0, 8, 16], 3, None), (3, [0, 6, 10, 16], 0, None),
+                                                                     (3, [0, 6, 10, 16], 0, 1)])
+def test_team_setup_is_all_or_none_and_coupled_substeps_batch_between_migrations(world, cuts, migrate_every, failing_rank):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 30100 + world + (os.getpid() % 200) + (40 if migrate_every == 0 else 0) + (80 if failing_rank is not None else 0)
+    procs = [ctx.Process(target=_team_worker, args=(r, world, cuts, port, q, migrate_every, failing_rank)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = {}
+    for _ in range(world):
+        item = q.get(timeout=120)
+        got[item[0]] = item[1:]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    if failing_rank is not None:
+        # one rank could not set its region up: NO rank switches, every rank has released what it had prepared and names the reason
+        for r in range(world):
+            ok, why, owned, calls, n_res = got[r]
+            assert not ok and "fine-grained" in why and "chain_destroy" in calls and n_res == 0
+            assert not any(isinstance(c, tuple) and c[0] in ("team_connect", "coupled") for c in calls)
+        return
+    assert sorted(g for r in range(world) for g in got[r][2]) == list(range(300))   # one owner per particle
+    for r in range(world):
+        ok, why, owned, calls, n_res = got[r]
+        assert ok and n_res == 12
+        # every rank mapped its neighbours' halo regions and ALL ranks' team regions, by the handles that travelled
+        dc = [c for c in calls if isinstance(c, tuple) and c[0] == "direct_connect"][0]
+        assert dc[1:] == (r - 1 if r > 0 else None, r + 1 if r < world - 1 else None)
+        tc = [c for c in calls if isinstance(c, tuple) and c[0] == "team_connect"][0]
+        assert tc[1] == tuple(100 + k for k in range(world))
+        # the 12 substeps in batches that end where a migration is due: a migration before substeps (0,) 3, 6, 9 as in the
+        # contact-free chain (test above), and the call boundary at 5 splits a batch
+        want = [3, 6, 9] if migrate_every else [0, 3, 6, 9]
+        seq, done, packs_at = [], 0, []
+        for c in calls:
+            if c == "pack":
+                packs_at.append(done)
+            elif isinstance(c, tuple) and c[0] == "coupled":
+                seq.append(c[1])
+                done += c[1]
+        assert done == 12 and packs_at == want, (packs_at, seq)
+        assert seq == [3, 2, 1, 3, 3], seq
