@@ -83,6 +83,22 @@ def measured_traffic(kernel, config):
         return None
 
 
+def measured_kernel_ns(kernel, config):
+    """Average duration (ns) of `kernel` in the committed rocprofv3 --kernel-trace --stats run of this same command
+    (profiles/rNN_kernel_stats.csv, carried into profiles/pmc_traffic.json by scripts/pmc_summary.py), or None."""
+    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    try:
+        with open(path) as f:
+            t = json.load(f)
+        if t.get("config") != config:
+            return None
+        ks = t["kernels"]
+        v = (ks[kernel] if kernel in ks else ks[kernel.split("<")[0]]).get("avg_duration_ns")
+        return float(v) if v else None
+    except (OSError, KeyError, ValueError, TypeError):
+        return None
+
+
 def host_description():
     """CPU model and the cores this process may use (north_star: "core count stated")."""
     model, sockets, cores_per_socket, threads_per_core = "unknown", None, None, None
@@ -738,8 +754,16 @@ def main():
     ev_ms = phases["vforce"]
     dom_ms = phases[dom]
     dom_net_ms = max(dom_ms - ev_ms, 1e-6)
-    ach = ab[dom] / (dom_ms * 1e-3) / 1e9
+    ach_raw = ab[dom] / (dom_ms * 1e-3) / 1e9
     ach_net = ab[dom] / (dom_net_ms * 1e-3) / 1e9
+    # ONE fraction for the dominant kernel: the one on the kernel's average duration in the committed
+    # rocprofv3 kernel trace of this command (profiles/rNN_kernel_stats.csv).  The live HIP-event interval of this run
+    # brackets it -- the raw interval holds two event packets on top of the kernel, the net one subtracts a measured event
+    # pair, which over-corrects -- and is kept under names of its own (`live_event_interval`); without a committed trace for
+    # this configuration the raw interval, the conservative figure, stands in.
+    prof_ns = measured_kernel_ns(KERNEL_OF[dom], args.config) if world == 1 else None
+    kernel_ms = prof_ns * 1e-6 if prof_ns else dom_ms
+    ach = ab[dom] / (kernel_ms * 1e-3) / 1e9
     # the whole job: every particle once per substep (strong: one copy; weak: one copy per rank)
     copies = 1 if (strong or world == 1) else world
     # (cells: rank 0's count; a partitioned domain has about `world` times as many, a 1% term)
@@ -760,11 +784,21 @@ def main():
                     traffic_source="profiles/pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this "
                                    "command, collected by scripts/collect_profiles.sh and committed (replayed, not "
                                    "measured in this run)",
-                    algorithmic_bytes_per_launch=ab[dom], kernel_ms=dom_ms,
-                    kernel_ms_note="HIP-event interval around the kernel, raw (event packets included): an upper bound",
-                    achieved_net=ach_net, frac_net=ach_net / HBM_PEAK_GBS, kernel_ms_net=dom_net_ms, event_pair_ms=ev_ms,
+                    algorithmic_bytes_per_launch=ab[dom], kernel_ms=kernel_ms,
+                    kernel_ms_source=("average duration of this kernel in the committed rocprofv3 --kernel-trace --stats run of this "
+                                      "command (profiles/pmc_traffic.json <- profiles/rNN_kernel_stats.csv)") if prof_ns else
+                                     "HIP-event interval around the kernel in this run, raw (no committed trace for this configuration)",
+                    live_event_interval=dict(
+                        raw_ms=dom_ms, net_ms=dom_net_ms, event_pair_ms=ev_ms, frac_on_raw=ach_raw / HBM_PEAK_GBS,
+                        frac_on_net=ach_net / HBM_PEAK_GBS,
+                        brackets_the_trace=(dom_net_ms <= kernel_ms * 1.05 and kernel_ms <= dom_ms * 1.05) if prof_ns else None,
+                        note="HIP events on the engine's stream around the kernel, measured in THIS run (mpm_profile_substeps): "
+                             "raw = with the two event packets, net = minus one measured back-to-back event pair"),
                     substep_achieved=job_bytes / (el / args.steps) / 1e9,
-                    substep_frac=job_bytes / (el / args.steps) / 1e9 / (HBM_PEAK_GBS * world), phase_ms=phases,
+                    substep_frac=job_bytes / (el / args.steps) / 1e9 / (HBM_PEAK_GBS * world),
+                    steady_state_frac=(job_bytes / (steady["ms_per_step"] * 1e-3) / 1e9 / HBM_PEAK_GBS) if steady else None,
+                    reference_call_pattern_frac=(job_bytes / (ref_pattern["ms_per_step"] * 1e-3) / 1e9 / HBM_PEAK_GBS) if ref_pattern else None,
+                    phase_ms=phases,
                     phase_note="separate pass with HIP events around every phase (mpm_profile_substeps); it launches the "
                                "re-sort kernels with every substep; the timed run launches none while the quiet time of the "
                                "last re-sort lasts (the stats() call in front of the window re-arms it: normally no check "
