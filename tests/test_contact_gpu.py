@@ -25,8 +25,9 @@ def close_rel(a, b, frac, what, deterministic=True):
     hide inside the tail tolerance): rms(a - b) <= frac * rms(b), and single entries against max|b|.
 
     deterministic (engine in mpm_set_deterministic mode, the oracle's sums in fixed order: the comparison is ONE number,
-    the same on every run -- VERDICT r5 item 2): at most 3 entries beyond 3 * frac of max|ref| (a COUNT, not a
-    quantile), none beyond 4 * frac.
+    the same on every run -- VERDICT r5 item 2; profiles/r06_parity_margins_deterministic.txt, two runs
+    identical to the digit): NO entry beyond 2 * frac of max|ref| (measured: 0.2 frac on the small scenes, 0.64 frac at
+    the one worst contact of the 1M-particle config 3).
     otherwise (the smoke variant on the default engine, whose particle order inside a cell -- and with it the length of
     the noise-limited tail of the solve -- differs from run to run): round 5's bounds, all but a per-mille of the entries
     within 3 * frac and none beyond 8 * frac (measured over several runs of the 1M-particle config 3: 0.9 - 3.5 % rms,
@@ -39,13 +40,10 @@ def close_rel(a, b, frac, what, deterministic=True):
     rms_e, rms_b = float(np.sqrt(np.mean((a - b) ** 2))), float(np.sqrt(np.mean(b ** 2)))
     MARGINS.append((rms_e / (frac * rms_b + 1e-300), what + " (rms, relative)", frac, rms_e / (rms_b + 1e-300), err / (ref + 1e-300)))
     assert rms_e <= frac * rms_b, f"{what}: rms error {rms_e:.3e} > {frac:.0%} of rms(ref) {rms_b:.3e}"
-    beyond = int(np.count_nonzero(np.abs(a - b) > 3 * frac * ref))
-    cap = 4.0 if deterministic else 8.0
+    cap = 2.0 if deterministic else 8.0
     MARGINS.append((err / (cap * frac * ref + 1e-300), what + " (largest single entry)",
                     cap * frac, err / (ref + 1e-300), err / (ref + 1e-300)))
-    if deterministic:
-        assert beyond <= 3, f"{what}: {beyond} entries beyond {3 * frac:.0%} of max|ref| {ref:.3e}"
-    else:
+    if not deterministic:
         q999 = float(np.quantile(np.abs(a - b), 0.999))
         assert q999 <= 3 * frac * ref, f"{what}: 99.9th percentile {q999:.3e} > {3 * frac:.0%} of max|ref| {ref:.3e}"
     assert err <= cap * frac * ref, f"{what}: {err:.3e} > {cap * frac:.0%} of max|ref| {ref:.3e}"
@@ -340,7 +338,8 @@ HISTORY_EARLY = 5.0     # iterations 0 - 5, before rounding has grown: both mode
 HISTORY_EVERY = 16.0    # deterministic mode: every iteration (measured, the same on every run: sum |Dir|^2 10.59 and the residual
                         # 9.33 at the one iteration where the float and the double oracle happen to lie close together, E(0)
                         # and E(alpha) 2.87; the exact search 0.8 - 1.06 throughout)
-HISTORY_FIELDS = 4.0    # deterministic mode: rms |engine - oracle32| of the fields after 20 iterations, in rms |oracle32 - oracle64|
+HISTORY_FIELDS = 2.5    # deterministic mode: rms |engine - oracle32| of the fields after 20 iterations, in rms |oracle32 - oracle64|
+                        # (measured 1.24 for the grid velocities, 0.26 for the directions)
 
 
 @pytest.mark.parametrize("exact,deterministic", [(False, True), (True, True), (False, False)])
@@ -443,7 +442,7 @@ def test_config3_full_size_against_the_oracle(deterministic):
     sheets below a floor, the bagging demo's contact parameters (k = 1e6, d = 1e-5, mu = 1, dt = 2e-4).
     One Newton iteration against the oracle at rounding level, then the converged solve.
     deterministic: engine in mpm_set_deterministic mode against the oracle's fixed-order sums -- every margin is the
-    same number on every run, single contacts within 4 x 4 % of max|v| (close_rel); the other variant is the smoke run
+    same number on every run, single contacts within 2 x 4 % of max|v| (close_rel); the other variant is the smoke run
     on the default engine with round 5's bounds."""
     from drake_amd import ARR as A, scenes
     from oracle import oracle as orc
