@@ -227,7 +227,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 // A/B switches of the round-3 P2G experiments (defaults = what ships; scratch/ab_build.py builds variants,
-// scratch/ab_run.py times them on one box; results in DESIGN.md section 8)
+// scratch/ab_run.py times them on one box; results in DESIGN_HISTORY.md section 8)
 #ifndef MPM_P2G_STG16
 #define MPM_P2G_STG16 1
 #endif

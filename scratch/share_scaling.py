@@ -1,4 +1,4 @@
-"""What the substep kernels of ONE rank cost as its share of the 1M workload shrinks (does P2G get
+"""What the substep kernels of ONE rank cost as its share of the 1M workload shrinks (DESIGN_HISTORY.md section 5.6: does P2G get
 faster on a smaller share?).  The middle rank of `world` x-slabs (dist.strong_geometry), no exchange, event times of
 mpm_profile_substeps (raw intervals, the empty vertex-force slot = cost of an event pair).  MPM_ITEM_GROUPS varies the
 size of the work items (read when the engine is created)."""

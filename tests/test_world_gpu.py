@@ -319,7 +319,7 @@ def test_an_owned_vertex_that_misses_a_face_is_reported_by_the_resort():
 
 
 def test_a_migration_header_that_lies_about_its_records_raises_a_flag_and_stores_nothing_out_of_bounds(monkeypatch):
-    """ADVICE r5 (the abort of round 4): which of the two candidate mechanisms can the COMMITTED code
+    """ADVICE r5 (the abort of round 4: DESIGN_HISTORY.md section 5.3, "Round 5"): which of the two candidate mechanisms can the COMMITTED code
     still produce -- an exception across the C boundary, or an out-of-bounds store of k_dist_apply?  The host side is
     replayed in tests/test_error_paths.py (plan_migration with the counts of the faulty tree: the need is clamped to the
     scene, nothing is sized from an unchecked number, no exception).  This is the device side: a received buffer whose
