@@ -556,6 +556,8 @@ MPM_API int mpm_chain_direct_connect_local(mpm_handle_t h, void *left_base, void
  *   mpm_team_connect(h, handles, local_bases)   handles: world x 64 bytes in rank order (own entry ignored) or NULL;
  *        local_bases: world pointers or NULL -- a rank of this process is named by its region's address, any other by
  *        its handle.
+ * mpm_chain_destroy -- and mpm_chain_init, which starts from a clean chain -- release the team's region too: set the chain up
+ * first (mpm_chain_init, mpm_chain_direct_*), then the team.
  * With the team connected, mpm_update_contact on a partitioned engine runs the device-resident solve (EVERY rank must
  * call it in every coupled substep, with or without pairs of its own), and mpm_run_coupled_substeps accepts a partitioned
  * engine whose halo runs over the direct transport: n coupled substeps per call, no migration inside (the caller runs the
