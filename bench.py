@@ -325,6 +325,9 @@ def team_contact_leg(rank, world, local_rank, config, steps=10, warmup=3):
     bits, layers, res = scenes.CONFIGS[config]
     floor_z, k, d, mu, dt = 0.25, 1e6, 1e-5, 1.0, 2e-4
     geo = strong_geometry(bits, world)
+    # (every wait of the peer-store transports is bounded; this leg has never met two devices, so the bound is short here: a
+    # flag that does not become visible costs seconds, not minutes, and the leg reports the error instead of a number)
+    os.environ.setdefault("MPM_HALO_TIMEOUT_S", "1.0")
     g = GpuMpm(bits, device=local_rank)
     sheets = scenes.cloth_stack(layers, res, bits, z0=floor_z - 0.004)
     for pos, vel, idx in sheets:
@@ -347,8 +350,21 @@ def team_contact_leg(rank, world, local_rank, config, steps=10, warmup=3):
                                  v=(vx, 0.0, 0.0)))
         return cols
 
-    chain.coupled_substeps(warmup, dt, colliders(0.0), mu, k, d)
-    g.gpu_sync()
+    err = None
+    try:
+        chain.coupled_substeps(warmup, dt, colliders(0.0), mu, k, d)
+        g.gpu_sync()
+    except Exception as exc:  # noqa: BLE001  (e.g. MPM_ERR_HALO: a peer's flag never arrived)
+        err = repr(exc)
+    bad = torch.tensor([1.0 if err else 0.0])
+    dist.all_reduce(bad, op=dist.ReduceOp.MAX)
+    if float(bad.item()) > 0:     # all ranks leave together
+        try:
+            g.chain_destroy()
+            g.destroy()
+        except Exception:  # noqa: BLE001
+            pass
+        return dict(error="the warm-up of the team contact leg failed on at least one rank" + (": " + err if err else ""))
     dist.barrier()
     t0 = time.perf_counter()
     rs = chain.coupled_substeps(steps, dt, colliders(warmup * dt), mu, k, d)

@@ -533,13 +533,13 @@ static int update_contact(mpm_engine* e, int frame, int substep, float dt, float
     }
     if (e->dp.dist.on && e->team.on) {
         // partitioned domain with the TEAM transport: device resident, every rank takes part whatever its own pair count
+        REQUIRE(!dump, "the JSON statistics dump is not available on a partitioned domain");
         std::vector<SolveOutcome> ocs;
         std::function<void(size_t)> hook;
         if (e->ct_before_impulse) hook = [e](size_t) { e->ct_before_impulse(); };
         if (int rc = team_solve({e}, dt, mu, stiffness, damping, exact, max_iters, hook, &ocs)) return rc;
         if (iters_out) *iters_out = ocs[0].mb.iters;
         if (residual_out) *residual_out = ocs[0].mb.residual;
-        if (dump) return fail(MPM_ERR_INVALID, "the JSON statistics dump is not available on a partitioned domain");
         return 0;
     }
     e->last_contact_dt = dt; e->last_contact_mu = mu; e->last_contact_k = stiffness; e->last_contact_d = damping;
