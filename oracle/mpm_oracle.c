@@ -18,7 +18,10 @@
  * restatement is pinned by the known answers that the survey captured from
  * the reference kernels (stored in
  * tests/golden/survey_known_answers.json) and by physical invariants.
- * Anything not covered by those known answers is "parity unpinned".
+ * Anything not covered by those known answers is "parity unpinned"; where no
+ * vectors exist the restatement is pinned to the PUBLISHED MODEL instead
+ * (tests/test_oracle_model.py: stress = gradient of an independently written
+ * energy, vertex forces = -dE/dx, APIC transfer identities).
  *
  * Determinism (round 6): every float sum has a FIXED order, whatever the thread
  * count.  The vertex forces of CalcFemStateAndForce are computed per face in

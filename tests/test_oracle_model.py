@@ -1,0 +1,220 @@
+"""The oracle's cloth stress and vertex forces against the PUBLISHED MODEL instead of against vectors (the reference holds
+none for its MPM kernels): the reference's constitutive update (cuda_mpm_kernels.cuh:72-181, :183-294)
+implements the codimensional cloth model of Jiang, Gast, Teran, "Anisotropic elastoplasticity for cloth, knit and hair
+frictional contact" (SIGGRAPH 2017): F = QR, an in-plane fixed-corotated energy on the 2 x 2 block of R (Lame parameters
+from E, nu), a normal penalty f(R22) = K/3 (1 - R22)^3 for R22 < 1 (f' = -K (1 - R22)^2, :118-121), no shear energy for
+gamma = 0, first Piola-Kirchhoff stress P = d psi / d F, vertex forces -V P[:, 0:2] grad N.
+
+Here the ENERGY is written down independently -- singular values of the 3 x 2 matrix of deformed tangents for the
+in-plane part, the distance of the third column from their plane for R22: numpy, no QR, nothing taken from the oracle --
+and differentiated NUMERICALLY in double precision:
+  * compute_dphi_dF(F) (the whole chain givens_QR -> svd2x2 -> fixed_corotated_PK1_2D -> Q A R^-T) == d psi / d F;
+  * the vertex forces of CalcFemStateAndForce on a deformed mesh == -d/dx sum_faces V psi(F(x)) with the normal column held;
+  * the return mapping (gamma = 0) leaves the tangents alone, makes the third column normal to their plane and caps R22 at 1.
+A transcription error anywhere in the restated chain breaks the gradient property; agreement pins the restatement to the
+model the reference implements, which is as far as pinning goes without reference vectors."""
+import ctypes as C
+
+import numpy as np
+
+from oracle import oracle as orc
+
+RNG = np.random.default_rng(20261005)
+
+
+def _params(bits=6):
+    p = orc.default_params(bits)
+    return p, float(p.youngs) / (2 * (1 + float(p.poisson))), float(p.youngs) * float(p.poisson) / ((1 + float(p.poisson)) * (1 - 2 * float(p.poisson))), float(p.K)
+
+
+def psi(F, mu, la, K):
+    """energy density of the cloth model for a 3 x 3 deformation gradient (columns d1, d2: deformed tangents; d3: normal fibre)"""
+    F = np.asarray(F, np.float64).reshape(3, 3)
+    s = np.linalg.svd(F[:, :2], compute_uv=False)
+    e = mu * ((s[0] - 1.0) ** 2 + (s[1] - 1.0) ** 2) + 0.5 * la * (s[0] * s[1] - 1.0) ** 2
+    n = np.cross(F[:, 0], F[:, 1])
+    r22 = float(F[:, 2] @ n) / np.linalg.norm(n)
+    if r22 < 1.0:
+        e += K / 3.0 * (1.0 - r22) ** 3
+    return e
+
+
+def _dphi(p, F):
+    out = np.zeros(9, np.float64)
+    Fc = np.ascontiguousarray(F, np.float64).reshape(9)
+    orc.lib64().orc_kat_dphi_dF(C.byref(p), Fc.ctypes.data_as(C.POINTER(C.c_double)), out.ctypes.data_as(C.POINTER(C.c_double)))
+    return out.reshape(3, 3)
+
+
+def test_stress_is_the_gradient_of_the_cloth_energy():
+    p, mu, la, K = _params()
+    worst = 0.0
+    for trial in range(200):
+        # near a rotation times a stretch: in-plane strains up to 20 %, the normal fibre compressed (R22 < 1) or stretched
+        A = np.eye(3) + 0.2 * RNG.standard_normal((3, 3))
+        if trial % 2:
+            A[:, 2] *= 1.3           # R22 > 1: no normal penalty
+        Q, _ = np.linalg.qr(RNG.standard_normal((3, 3)))
+        F = Q @ A
+        if np.linalg.det(F) < 0.2:
+            continue
+        P = _dphi(p, F)
+        h = 1e-6
+        Pn = np.zeros((3, 3))
+        for i in range(3):
+            for j in range(3):
+                Fp, Fm = F.copy(), F.copy()
+                Fp[i, j] += h
+                Fm[i, j] -= h
+                Pn[i, j] = (psi(Fp, mu, la, K) - psi(Fm, mu, la, K)) / (2 * h)
+        scale = max(np.abs(Pn).max(), mu * 1e-3)
+        worst = max(worst, float(np.abs(P - Pn).max() / scale))
+    assert worst < 2e-6, worst
+
+
+def test_vertex_forces_are_minus_the_gradient_of_the_total_energy():
+    """CalcFemStateAndForce on a deformed 7 x 7 sheet (double build, dt = 0: the affine update of the normal column is the
+    identity): f_vertex == -d/dx sum_f V_f psi([Ds(x) Dm^-1 | d3_f]), d3_f the normal columns the call left."""
+    from drake_amd import scenes
+    p, mu, la, K = _params()
+    res = 7
+    pos, idx = scenes.cloth_sheet(res, 0.2, 0.5)
+    o = orc.OracleMpm(6, real=np.float64)
+    o.add_qr_cloth(pos, np.zeros_like(pos), idx)
+    o.finalize()
+    nf, nv = o.n_faces, o.n_verts
+    # deform: stretch, shear, a bump out of the plane, noise
+    x = o.pos[nf:].copy()
+    x[:, 0] = 0.5 + (x[:, 0] - 0.5) * 1.07 + 0.03 * (x[:, 1] - 0.5)
+    x[:, 2] += 0.02 * np.sin(12 * x[:, 0]) * np.cos(9 * x[:, 1])
+    x += 2e-4 * RNG.standard_normal(x.shape)
+    o.pos[nf:] = x
+    # normal fibres: half compressed (penalty active), half stretched, slightly tilted
+    F0 = o.F.copy().reshape(nf, 3, 3)
+    F0[:, :, 2] *= np.where(np.arange(nf) % 2 == 0, 0.9, 1.05)[:, None]
+    F0[:, :, 2] += 0.02 * RNG.standard_normal((nf, 3))
+    o.F[:] = F0.reshape(nf, 9)
+    o.rebuild_mapping(False)
+    o.calc_fem_state_and_force(0.0)
+    f = o.forces[nf:].copy()
+    Fnew = o.F.reshape(nf, 3, 3).copy()
+    tri = (o.indices.reshape(nf, 3) - nf).astype(np.int64)
+    Dmi = o.DmInv.reshape(nf, 2, 2)
+    vol = o.vol[:nf].copy()
+    assert np.abs(f).max() > 0
+
+    def energy(xv):
+        e = 0.0
+        for k in range(nf):
+            a, b, c = tri[k]
+            Ds = np.stack([xv[b] - xv[a], xv[c] - xv[a]], axis=1)
+            Fk = np.concatenate([Ds @ Dmi[k], Fnew[k][:, 2:3]], axis=1)
+            e += vol[k] * psi(Fk, mu, la, K)
+        return e
+
+    # (the call's own in-plane columns are Ds Dm^-1 of the same positions)
+    a, b, c = tri[5]
+    np.testing.assert_allclose(np.stack([x[b] - x[a], x[c] - x[a]], axis=1) @ Dmi[5], Fnew[5][:, :2], atol=1e-12)
+    h = 1e-7
+    fn = np.zeros_like(f)
+    for v in range(nv):
+        for d in range(3):
+            xp, xm = x.copy(), x.copy()
+            xp[v, d] += h
+            xm[v, d] -= h
+            fn[v, d] = -(energy(xp) - energy(xm)) / (2 * h)
+    scale = np.abs(fn).max()
+    assert np.abs(f - fn).max() < 5e-6 * scale, (np.abs(f - fn).max(), scale)
+
+
+def test_return_mapping_keeps_the_tangents_and_caps_the_normal_stretch():
+    p, mu, la, K = _params()
+    for trial in range(100):
+        A = np.eye(3) + 0.25 * RNG.standard_normal((3, 3))
+        Q, _ = np.linalg.qr(RNG.standard_normal((3, 3)))
+        F = Q @ A
+        if np.linalg.det(F) < 0.2:
+            continue
+        G = np.ascontiguousarray(F.reshape(9))
+        orc.lib64().orc_kat_project_strain(C.byref(p), G.ctypes.data_as(C.POINTER(C.c_double)))
+        G = G.reshape(3, 3)
+        np.testing.assert_allclose(G[:, :2], F[:, :2], atol=1e-12)          # the tangents are the mesh's, untouched
+        n = np.cross(F[:, 0], F[:, 1])
+        n /= np.linalg.norm(n)
+        r22 = float(F[:, 2] @ n)
+        np.testing.assert_allclose(G[:, 2], min(r22, 1.0) * n, atol=1e-12)  # no shear, normal stretch capped at 1
+
+
+def test_transfers_reproduce_affine_fields_and_conserve_momentum():
+    """The APIC / MLS-MPM transfers with quadratic B-splines (Jiang et al. 2015, Hu et al. 2018: what
+    cuda_mpm_kernels.cuh:418-543 and :798-924 implement), checked on their defining properties instead of on vectors:
+      * GridToParticle of an AFFINE grid velocity field v(x_i) = a + A x_i returns v_p = a + A x_p exactly and the raw
+        velocity gradient A (partition of unity, exact first moment, second moment dx^2 / 4 of the quadratic spline); the
+        stored C is the reference's RPIC blend 0.9 A - 0.1 A^T for V = 0.8 (:899-906);
+      * ParticleToGrid conserves mass and linear momentum (with gravity and the forces' impulse), and the total
+        ANGULAR momentum about the origin including the affine part  sum m (x x v) + sum m C : (dx^2 / 4) eps  (the APIC
+        invariant), for face particles without stress and vertex particles without force."""
+    from drake_amd import scenes
+    bits = 6
+    dx = 1.0 / (1 << bits)
+    o = orc.OracleMpm(bits, real=np.float64)
+    pos, idx = scenes.cloth_sheet(12, 0.21, 0.47)
+    pos = pos + 0.3 * dx * RNG.standard_normal(pos.shape).astype(np.float32)
+    o.add_qr_cloth(pos, np.zeros_like(pos), idx)
+    o.finalize()
+    n = o.n_particles
+    # ---- G2P on an affine field -----------------------------------------------------------------------------------
+    a = np.array([0.3, -0.2, 0.5])
+    A = RNG.standard_normal((3, 3))
+    # (the field is set on the nodes the particles' stencils touch)
+    base = np.floor(o.pos / dx - 0.5).astype(np.int64)
+    nodes = set()
+    for b in base:
+        for i in range(3):
+            for j in range(3):
+                for k in range(3):
+                    nodes.add((int(b[0]) + i, int(b[1]) + j, int(b[2]) + k))
+    o.g_m[:] = 0
+    o.g_mv[:] = 0
+    for (x, y, z) in nodes:
+        c = orc.cell_index(x, y, z)
+        o.g_m[c] = 1.0
+        o.g_mv[c] = a + A @ (np.array([x, y, z], np.float64) * dx)
+    x_before = o.pos.copy()
+    o.grid_to_particle(0.0)
+    np.testing.assert_allclose(o.vel, a + x_before @ A.T, atol=1e-12)
+    V = float(o.p.V)
+    ca, cb = (V + 1) / 2, (V - 1) / 2
+    np.testing.assert_allclose(o.C.reshape(n, 3, 3), np.broadcast_to(ca * A + cb * A.T, (n, 3, 3)), atol=1e-10)
+    # ---- P2G conservation -----------------------------------------------------------------------------------------
+    o.vel[:] = 0.5 * RNG.standard_normal((n, 3))
+    o.C[:] = 3.0 * RNG.standard_normal((n, 9))
+    o.rebuild_mapping(False)
+    o.forces[:] = 0
+    o.taus[:] = 0
+    o.g_m[:] = 0
+    o.g_mv[:] = 0
+    o.g_flags[:] = 0
+    o.g_cnt = 0
+    dt = 1e-3
+    o.particle_to_grid(dt)
+    m = o.vol * float(o.p.density)
+    g = np.zeros(3)
+    g[int(o.p.gravity_axis)] = float(o.p.gravity)
+    np.testing.assert_allclose(o.g_m.sum(), m.sum(), rtol=1e-13)
+    np.testing.assert_allclose(o.g_mv.sum(0), (m[:, None] * (o.vel + g * dt)).sum(0), rtol=1e-11, atol=1e-16)
+    # angular momentum about the origin: nodes at i dx carry (m v)_i; particles carry x x m v + the affine part
+    touched = np.nonzero(o.g_m > 0)[0]
+    L_grid = np.zeros(3)
+    for c in touched:
+        xi = np.array(orc.inverse_cell_index(int(c)), np.float64) * dx
+        L_grid += np.cross(xi, o.g_mv[c])
+    L_p = np.zeros(3)
+    eps = np.zeros((3, 3, 3))
+    eps[0, 1, 2] = eps[1, 2, 0] = eps[2, 0, 1] = 1
+    eps[0, 2, 1] = eps[2, 1, 0] = eps[1, 0, 2] = -1
+    for q in range(n):
+        Cq = o.C[q].reshape(3, 3)
+        L_p += m[q] * np.cross(o.pos[q], o.vel[q] + g * dt)
+        L_p += m[q] * (dx * dx / 4.0) * np.einsum("abc,cb->a", eps, Cq)
+    np.testing.assert_allclose(L_grid, L_p, rtol=1e-9, atol=1e-14)
