@@ -218,3 +218,52 @@ def test_transfers_reproduce_affine_fields_and_conserve_momentum():
         L_p += m[q] * np.cross(o.pos[q], o.vel[q] + g * dt)
         L_p += m[q] * (dx * dx / 4.0) * np.einsum("abc,cb->a", eps, Cq)
     np.testing.assert_allclose(L_grid, L_p, rtol=1e-9, atol=1e-14)
+
+
+def test_contact_impulses_are_minus_the_gradient_of_the_cost_and_the_hessian_is_their_jacobian():
+    """The SAP-style contact model of UpdateContact (compute_contact_grad_and_hess, cuda_mpm_kernels.cuh:956-1040; the cost
+    l(v), :1425-1435; Castro et al., "An unconstrained convex formulation of compliant contact", 2022: compliant normal
+    impulse with linear damping, regularised friction lagged on the previous normal impulse): in double precision, over
+    random states, the gradient the solver uses is -dl/dv and its Hessian is the Jacobian of that gradient -- for active
+    contacts; a contact whose lagged normal velocity says "separating faster than v_hat" contributes nothing."""
+    p = orc.default_params(7)
+    L = orc.lib64()
+    d_ = C.c_double
+    ptr = lambda a: a.ctypes.data_as(C.POINTER(C.c_double))
+    L.orc_kat_contact_cost.restype = C.c_double
+
+    def grad_hess(phi0, dt, k, d, mu, v0, v):
+        H, g = np.zeros(9), np.zeros(3)
+        L.orc_kat_contact_grad_hess(C.byref(p), d_(phi0), d_(dt), d_(k), d_(d), d_(mu), ptr(np.ascontiguousarray(v0)), ptr(np.ascontiguousarray(v)), ptr(H), ptr(g))
+        return H.reshape(3, 3), g
+
+    def cost(phi0, dt, k, d, mu, v0, v):
+        return float(L.orc_kat_contact_cost(C.byref(p), d_(phi0), d_(dt), d_(k), d_(d), d_(mu), ptr(np.ascontiguousarray(v0)), ptr(np.ascontiguousarray(v))))
+
+    active = 0
+    for trial in range(300):
+        phi0 = float(RNG.uniform(1e-4, 4e-3))
+        dt = float(RNG.choice([2e-4, 1e-3]))
+        k, d, mu = float(RNG.choice([1e5, 1e6])), float(RNG.choice([1e-5, 1e-3])), float(RNG.choice([0.0, 0.5, 1.0]))
+        v0 = np.array([RNG.normal(0, 0.3), RNG.normal(0, 0.3), RNG.normal(-0.2, 0.5)])
+        v = np.array([RNG.normal(0, 0.3), RNG.normal(0, 0.3), RNG.normal(-0.2, 0.3)])
+        v_hat = min(phi0 / dt, 1.0 / d)
+        H, g = grad_hess(phi0, dt, k, d, mu, v0, v)
+        if v0[2] > v_hat:
+            assert not H.any() and not g.any()
+            continue
+        if v[2] > v_hat - 1e-3:     # (the cost is clamped at v_n = v_hat: stay on the smooth side for the differences)
+            continue
+        active += 1
+        h = 1e-6
+        gn, Hn = np.zeros(3), np.zeros((3, 3))
+        for a in range(3):
+            vp, vm = v.copy(), v.copy()
+            vp[a] += h
+            vm[a] -= h
+            gn[a] = -(cost(phi0, dt, k, d, mu, v0, vp) - cost(phi0, dt, k, d, mu, v0, vm)) / (2 * h)
+            Hn[:, a] = (grad_hess(phi0, dt, k, d, mu, v0, vp)[1] - grad_hess(phi0, dt, k, d, mu, v0, vm)[1]) / (2 * h)
+        gs = max(np.abs(g).max(), 1e-12)
+        np.testing.assert_allclose(g, gn, atol=2e-6 * gs + 1e-9)
+        np.testing.assert_allclose(H, Hn, atol=2e-6 * max(np.abs(H).max(), 1e-12) + 1e-9)
+    assert active > 100
