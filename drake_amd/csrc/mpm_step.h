@@ -1316,6 +1316,9 @@ __global__ void k_halo_signal(uint32_t* flag_a, uint32_t* flag_b, uint32_t seq, 
     if (hdr_a) __hip_atomic_store(hdr_a, min(*cnt_a, cap), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     if (hdr_b) __hip_atomic_store(hdr_b, min(*cnt_b, cap), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     __threadfence_system();
+    // (MI355X_MICROARCH.md, "Compiler hazard": the wait behind the write-back may be dropped when the wave's vmcnt is
+    // provably empty -- the flag could then overtake the data; an inline-asm wait is invisible to that pass)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (flag_a) __hip_atomic_store(flag_a, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     if (flag_b) __hip_atomic_store(flag_b, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }

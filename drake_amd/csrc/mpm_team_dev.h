@@ -76,6 +76,9 @@ MPM_DEV void team_push_sums(const TeamDev& t, double v) {
                                __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
     __threadfence_system();   // (one wave: the fence is the wave's, it covers every lane's stores)
+    // (MI355X_MICROARCH.md, "Compiler hazard": the wait behind the write-back may be dropped when the wave's vmcnt is
+    // provably empty -- the flag could then overtake the data; an inline-asm wait is invisible to that pass)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     for (int d = 0; d < t.world; ++d)
         if (lane == 0) __hip_atomic_store(team_sum_flag(t.peer[d], t.zone_bytes, t.rank), q + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
