@@ -367,10 +367,24 @@ def team_contact_leg(rank, world, local_rank, config, steps=10, warmup=3):
         return dict(error="the warm-up of the team contact leg failed on at least one rank" + (": " + err if err else ""))
     dist.barrier()
     t0 = time.perf_counter()
-    rs = chain.coupled_substeps(steps, dt, colliders(warmup * dt), mu, k, d)
-    g.gpu_sync()
-    dist.barrier()
+    rs = []
+    try:
+        rs = chain.coupled_substeps(steps, dt, colliders(warmup * dt), mu, k, d)
+        g.gpu_sync()
+    except Exception as exc:  # noqa: BLE001  (every wait inside is bounded: a rank that fails alone gets here, and so do the others)
+        err = repr(exc)
     el = time.perf_counter() - t0
+    # (no collective between the start of the timed calls and this one: whatever a rank met, it arrives here, and the
+    # reduction is the closing barrier of the timed region)
+    bad = torch.tensor([1.0 if err else 0.0])
+    dist.all_reduce(bad, op=dist.ReduceOp.MAX)
+    if float(bad.item()) > 0:
+        try:
+            g.chain_destroy()
+            g.destroy()
+        except Exception:  # noqa: BLE001
+            pass
+        return dict(error="the timed coupled substeps of the team contact leg failed on at least one rank" + (": " + err if err else ""))
     t = torch.tensor([el, float(sum(r["contacts"] for r in rs))], dtype=torch.float64)
     dist.all_reduce(t[:1], op=dist.ReduceOp.MAX)
     dist.all_reduce(t[1:], op=dist.ReduceOp.SUM)
@@ -488,7 +502,10 @@ def main():
         sys.stdout.flush()
         saved_stdout = os.dup(1)
         os.dup2(2, 1)
-        dist.init_process_group("gloo")
+        # (a collective that a rank never joins -- it failed alone in the optional team leg -- gives up after ten minutes
+        # instead of gloo's thirty: the headline line is computed before that leg and still comes out)
+        import datetime
+        dist.init_process_group("gloo", timeout=datetime.timedelta(seconds=600))
 
     from drake_amd import GpuMpm, scenes
     from drake_amd.dist import DomainChain, HaloChain, strong_geometry
