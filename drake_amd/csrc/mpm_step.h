@@ -339,6 +339,13 @@ MPM_DEV unsigned tile_reach_mask(int rx, int ry, int rz) {
 #ifndef MPM_P2G_PIPE2
 #define MPM_P2G_PIPE2 0      // 1 (experiment): MFMA operands fetched two steps ahead in two named register sets
 #endif
+#ifndef MPM_P2G_SWAP
+// 1 (round 6): the contraction transposed -- the particles' 16 columns are the A operand of the MFMA and the 27 weights the
+// B operand, so that a lane's four accumulator registers are the four TERMS (1, i, j, k) of one (node, component) instead of
+// four node rows of one term: the fold over the terms is four products and three sums in the lane (same pairing as the
+// quad exchange it replaces: bit-identical) instead of 4 + 6 selects + 3 DPP adds, per cell and MFMA.
+#define MPM_P2G_SWAP 1
+#endif
 #ifndef MPM_P2G_PREFETCH
 // 0 (what ships since round 4): a group's records are loaded when its turn comes.  Rounds 1-3 fetched them one group
 // ahead; with four waves per SIMD the other waves cover the two round trips anyway, and the 25 registers the prefetched
@@ -366,6 +373,13 @@ constexpr int P2G_WAVES = MPM_P2G_WAVES, P2G_THREADS = 64 * P2G_WAVES;
 //      in magnitude; beyond that its LAST bit (2^-53 of the sum, rounded to float afterwards) may depend on the order.
 //      The default: without the canonical particle order of deterministic mode the order INSIDE a cell already
 //      differs from run to run at float level.
+// one step of the per-cell contraction: acc += W^T Y (MPM_P2G_SWAP: rows = the 16 columns of the staged particles,
+// columns = 16 node rows) or acc += W Y^T (rows = nodes)
+#if MPM_P2G_SWAP
+#define MPM_P2G_MFMA(w, y, acc) __builtin_amdgcn_mfma_f32_16x16x4f32(y, w, acc, 0, 0, 0)
+#else
+#define MPM_P2G_MFMA(w, y, acc) __builtin_amdgcn_mfma_f32_16x16x4f32(w, y, acc, 0, 0, 0)
+#endif
 template <int FORCES, int EXACT>
 __global__ __launch_bounds__(P2G_THREADS) __attribute__((amdgpu_waves_per_eu(P2G_WAVES / 2, P2G_WAVES / 2))) void k_p2g(DP p, float dt) {
     if (gated_out(p)) return;
@@ -408,6 +422,17 @@ __global__ __launch_bounds__(P2G_THREADS) __attribute__((amdgpu_waves_per_eu(P2G
     int delta[2];        // float offset of this lane's node/component in the tile, -1 if none
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
+#if MPM_P2G_SWAP
+        // lane (j16, g4) of MFMA t ends up with the four terms of node 16 t + j16, component g4
+        const int n = 16 * t + j16;
+        const int ni = n / 9, nj = (n / 3) % 3, nk = n % 3;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            fac[t][r] = n >= 27 ? 0.f : (r == 0 ? 1.f : (float)(r == 1 ? ni : (r == 2 ? nj : nk)));
+            if (MPM_P2G_STG16 && g4 == 3 && r != 0) fac[t][r] = 0.f;   // (columns 13..15 carry fx, fy, fz)
+        }
+        delta[t] = n < 27 ? ((ni * TILE_W + nj) * TILE_W + nk) * 4 + g4 : -1;
+#else
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int n = 16 * t + 4 * g4 + r;
@@ -417,9 +442,10 @@ __global__ __launch_bounds__(P2G_THREADS) __attribute__((amdgpu_waves_per_eu(P2G
         }
         const int n = 16 * t + 4 * g4 + tt;
         delta[t] = n < 27 ? (((n / 9) * TILE_W + (n / 3) % 3) * TILE_W + n % 3) * 4 + dcomp : -1;
+#endif
     }
     {
-        const float fscale = EXACT ? (float)(dcomp == 3 ? p.fix_m : p.fix_p) : 1.f;
+        const float fscale = EXACT ? (float)((MPM_P2G_SWAP ? g4 : dcomp) == 3 ? p.fix_m : p.fix_p) : 1.f;
 #pragma unroll
         for (int t = 0; t < 2; ++t)
 #pragma unroll
@@ -665,8 +691,8 @@ __global__ __launch_bounds__(P2G_THREADS) __attribute__((amdgpu_waves_per_eu(P2G
                                       __builtin_elementwise_fma(__builtin_elementwise_fma(cy2, fy2, cy1), fy2, cy0) *
                                       __builtin_elementwise_fma(__builtin_elementwise_fma(cz2, fz2, cz1), fz2, cz0);
                     if (!ok) y = 0.f;
-                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(w01.x, y, acc0, 0, 0, 0);
-                    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(w01.y, y, acc1, 0, 0, 0);
+                    acc0 = MPM_P2G_MFMA(w01.x, y, acc0);
+                    acc1 = MPM_P2G_MFMA(w01.y, y, acc1);
                 };
                 for (int s = s0; s < s1; s += 8) {
                     step(s, afx, afy, afz, ay);
@@ -720,11 +746,11 @@ __global__ __launch_bounds__(P2G_THREADS) __attribute__((amdgpu_waves_per_eu(P2G
                         // (the first step of a cell accumulates onto the constant 0 -- an inline operand of the MFMA --
                         // instead of onto eight registers that have to be cleared first)
                         const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
-                        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(w0, y, zero, 0, 0, 0);
-                        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(w1, y, zero, 0, 0, 0);
+                        acc0 = MPM_P2G_MFMA(w0, y, zero);
+                        acc1 = MPM_P2G_MFMA(w1, y, zero);
                     } else {
-                        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(w0, y, acc0, 0, 0, 0);
-                        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(w1, y, acc1, 0, 0, 0);
+                        acc0 = MPM_P2G_MFMA(w0, y, acc0);
+                        acc1 = MPM_P2G_MFMA(w1, y, acc1);
                     }
                 };
                 {
@@ -750,6 +776,15 @@ __global__ __launch_bounds__(P2G_THREADS) __attribute__((amdgpu_waves_per_eu(P2G
 #pragma unroll
                 for (int t = 0; t < 2; ++t) {
                     const f32x4 a = t ? acc1 : acc0;
+#if MPM_P2G_SWAP
+                    // the four terms of this lane's (node, component): products, then the sums paired as (0 + 1) + (2 + 3)
+                    float val;
+                    {
+#pragma clang fp contract(off)
+                        const float x0 = a[0] * fac[t][0], x1 = a[1] * fac[t][1], x2 = a[2] * fac[t][2], x3 = a[3] * fac[t][3];
+                        val = (x0 + x1) + (x2 + x3);
+                    }
+#else
                     // Lane (g4, dcomp, tt) of a quad holds the four terms' products of rows r = 0..3 and has to end up
                     // with the sum over the quad's four lanes of row r = tt: a 4 x 4 transpose-and-add in two
                     // exchanges (lane ^ 1, then lane ^ 2), each lane passing on what its partner keeps -- 4 + 2
@@ -760,6 +795,7 @@ __global__ __launch_bounds__(P2G_THREADS) __attribute__((amdgpu_waves_per_eu(P2G
                     const float ua = (b0 ? x1 : x0) + quad_perm<0xB1>(b0 ? x0 : x1);   // row b0, lanes l and l ^ 1
                     const float ub = (b0 ? x3 : x2) + quad_perm<0xB1>(b0 ? x2 : x3);   // row 2 + b0
                     const float val = (b1 ? ub : ua) + quad_perm<0x4E>(b1 ? ua : ub);
+#endif
                     if (delta[t] >= 0 && !(diag_flags(p) & 16)) {
                         if (EXACT) lds_add_fixed(tb + delta[t], val, fix_worst);
                         else __hip_atomic_fetch_add(reinterpret_cast<double*>(tb + delta[t]), (double)val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
