@@ -400,7 +400,6 @@ __global__ __launch_bounds__(P2G_THREADS) __attribute__((amdgpu_waves_per_eu(P2G
     const float gdt = p.M.gravity * dt;
     const float sdt = -dt * p.Dinv;
     float* stage = stage_all[wv];
-    const unsigned long long lt_mask = (1ull << lane) - 1ull;
 
     // ---- lane constants of the contraction ---------------------------------
     const int j16 = lane & 15, g4 = lane >> 4, tt = lane & 3, dcomp = (lane >> 2) & 3;
@@ -581,14 +580,14 @@ __global__ __launch_bounds__(P2G_THREADS) __attribute__((amdgpu_waves_per_eu(P2G
                 float fext[3] = {0.f, 0.f, 0.f};
                 // (explicit fused multiply-adds where a sum of products could be fused in more than one way: left to the
                 // compiler, the choice -- and the last bit of the result -- changes from build to build with the code around it)
+#pragma unroll
+                for (int r = 0; r < 9; ++r) B[r] = cur.C[r] * m;
                 if (is_face) {
 #pragma unroll
                     for (int r = 0; r < 3; ++r)
 #pragma unroll
-                        for (int c = 0; c < 3; ++c) B[r * 3 + c] = fmaf(sdt, cur.ta[r] * cur.tb[c], cur.C[r * 3 + c] * m);
+                        for (int c = 0; c < 3; ++c) B[r * 3 + c] = fmaf(sdt, cur.ta[r] * cur.tb[c], B[r * 3 + c]);
                 } else {
-#pragma unroll
-                    for (int r = 0; r < 9; ++r) B[r] = cur.C[r] * m;
 #pragma unroll
                     for (int r = 0; r < 3; ++r) fext[r] = cur.frc[r] * dt;
                 }
@@ -637,8 +636,13 @@ __global__ __launch_bounds__(P2G_THREADS) __attribute__((amdgpu_waves_per_eu(P2G
                 int base = 0;
                 while (todo) {
                     const int lk = __builtin_amdgcn_readlane(key, __builtin_ctzll(todo));
-                    const unsigned long long same = __ballot(key == lk) & todo;
-                    if ((same >> lane) & 1ull) pos = base + (int)__popcll(same & lt_mask);
+                    const bool mine = key == lk;
+                    const unsigned long long same = __ballot(mine) & todo;
+                    // (an active lane whose key is lk is in `same`: a key leaves `todo` with all of its lanes at once; the
+                    // position of an inactive lane is never used.  Rank inside the run: v_mbcnt counts the bits below the
+                    // lane and adds the run's base in the same two instructions)
+                    const int rank = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(same >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)same, (unsigned)base));
+                    if (mine) pos = rank;
                     base += (int)__popcll(same);
                     todo &= ~same;
                 }
@@ -723,7 +727,7 @@ __global__ __launch_bounds__(P2G_THREADS) __attribute__((amdgpu_waves_per_eu(P2G
                 // operands of a step are fetched one step ahead (the first step's during the previous
                 // cell's epilogue), so the LDS latency hides behind the MFMAs
                 auto one_step = [&](int s, bool first_step) {
-                    const bool ok = s + g4 < s1;
+                    const bool ok = g4 < s1 - s;   // (rows of this cell; the difference is wave-uniform: one vector instruction)
                     const float fx = nfx, fy = nfy, fz = nfz;
                     float y = ny;
                     {
