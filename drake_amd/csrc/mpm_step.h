@@ -403,6 +403,7 @@ __global__ __launch_bounds__(P2G_THREADS) __attribute__((amdgpu_waves_per_eu(P2G
 
     // ---- lane constants of the contraction ---------------------------------
     const int j16 = lane & 15, g4 = lane >> 4, tt = lane & 3, dcomp = (lane >> 2) & 3;
+    (void)tt; (void)dcomp;   // (only the untransposed contraction, MPM_P2G_SWAP=0, uses them)
     float ax[2][3], ay[2][3], az[2][3];  // A operand: weight polynomials of node rows j16 and 16 + j16
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
