@@ -346,6 +346,9 @@ MPM_DEV unsigned tile_reach_mask(int rx, int ry, int rz) {
 // quad exchange it replaces: bit-identical) instead of 4 + 6 selects + 3 DPP adds, per cell and MFMA.
 #define MPM_P2G_SWAP 1
 #endif
+#ifndef MPM_P2G_LOOP3
+#define MPM_P2G_LOOP3 1   // (round 6) first / middle / last steps of a cell as three bodies, see the contraction loop
+#endif
 #ifndef MPM_P2G_PREFETCH
 // 0 (what ships since round 4): a group's records are loaded when its turn comes.  Rounds 1-3 fetched them one group
 // ahead; with four waves per SIMD the other waves cover the two round trips anyway, and the 25 registers the prefetched
@@ -758,6 +761,42 @@ __global__ __launch_bounds__(P2G_THREADS) __attribute__((amdgpu_waves_per_eu(P2G
                         acc1 = MPM_P2G_MFMA(w1, y, acc1);
                     }
                 };
+#if MPM_P2G_LOOP3
+                {
+                    // Three kinds of step: the first accumulates onto the inline constant 0 (no eight moves to clear the
+                    // accumulators of every cell), only the last one has rows of the NEXT cell to mask (a cell's rows are
+                    // contiguous: every row of an earlier step is the cell's own).  Same operations on the same operands.
+                    auto step3 = [&](int s, bool first_step, bool last_step) {
+                        const float fx = nfx, fy = nfy, fz = nfz;
+                        float y = ny;
+                        {
+                            const float* sn = stage + (s + 4 + g4) * STG;
+                            nfx = sn[STG_FX]; nfy = sn[STG_FX + 1]; nfz = sn[STG_FX + 2]; ny = sn[j16];
+                        }
+                        const f32x2 fx2 = {fx, fx}, fy2 = {fy, fy}, fz2 = {fz, fz};
+                        const f32x2 w01 = __builtin_elementwise_fma(__builtin_elementwise_fma(cx2, fx2, cx1), fx2, cx0) *
+                                          __builtin_elementwise_fma(__builtin_elementwise_fma(cy2, fy2, cy1), fy2, cy0) *
+                                          __builtin_elementwise_fma(__builtin_elementwise_fma(cz2, fz2, cz1), fz2, cz0);
+                        if (last_step && !(g4 < s1 - s)) y = 0.f;
+                        if (first_step) {
+                            const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+                            acc0 = MPM_P2G_MFMA(w01.x, y, zero);
+                            acc1 = MPM_P2G_MFMA(w01.y, y, zero);
+                        } else {
+                            acc0 = MPM_P2G_MFMA(w01.x, y, acc0);
+                            acc1 = MPM_P2G_MFMA(w01.y, y, acc1);
+                        }
+                    };
+                    const int last = s0 + ((s1 - s0 - 1) & ~3);   // (a cell has at least one particle: s0 < s1)
+                    if (last == s0) {
+                        step3(s0, true, true);
+                    } else {
+                        step3(s0, true, false);
+                        for (int s = s0 + 4; s < last; s += 4) step3(s, false, false);
+                        step3(last, false, true);
+                    }
+                }
+#else
                 {
                     int s = (diag_flags(p) & 8) ? s1 : s0;
                     if (MPM_P2G_PEEL && s < s1) {   // (a cell has at least one particle: s0 < s1)
@@ -766,6 +805,7 @@ __global__ __launch_bounds__(P2G_THREADS) __attribute__((amdgpu_waves_per_eu(P2G
                     }
                     for (; s < s1; s += 4) one_step(s, false);
                 }
+#endif
                 // the loop leaves row block (last step + 4) preloaded; the next cell starts at s1
                 if (((s1 - s0) & 3) != 0 || (diag_flags(p) & 8)) {
                     const float* sn = stage + (s1 + g4) * STG;
