@@ -809,10 +809,12 @@ def main():
     roofline = dict(bound="hbm", kernel=KERNEL_OF[dom], achieved=ach, peak=HBM_PEAK_GBS, unit="GB/s",
                     frac=ach / HBM_PEAK_GBS, traffic=measured_traffic(KERNEL_OF[dom], args.config) if world == 1 else None,
                     valu_issue_ms=valu_issue_ms,
-                    valu_issue_note="SQ_INSTS_VALU of profiles/sq_counters.json (replayed) x 4 cycles / 1024 SIMDs / 2.4 GHz: "
-                                    "against kernel_ms it says how much of the kernel is vector-instruction issue -- k_p2g is "
-                                    "issue-bound on its ~800 vector instructions per 64 particles, not HBM-bound, although the "
-                                    "path's roofline is HBM's",
+                    valu_issue_note="SQ_INSTS_VALU of profiles/sq_counters.json (replayed) x 4 cycles / 1024 SIMDs / 2.4 GHz (the "
+                                    "kernel runs nearer 2.05 GHz: SQ_WAVE_CYCLES): against kernel_ms it says how much of the "
+                                    "kernel is vector-instruction issue -- k_p2g spends about half of its time issuing its "
+                                    "~580 vector instructions per 64 particles and the rest on the MFMA pipe and on latencies "
+                                    "that four waves per SIMD do not hide; it is not HBM-bound, although the path's roofline is "
+                                    "HBM's",
                     algorithmic_bytes_per_launch_with_vertex_row=p2g_with_vertex_row if dom == "p2g" else None,
                     traffic_source="profiles/pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this "
                                    "command, collected by scripts/collect_profiles.sh and committed (replayed, not "
