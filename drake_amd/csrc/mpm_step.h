@@ -346,6 +346,9 @@ MPM_DEV unsigned tile_reach_mask(int rx, int ry, int rz) {
 // quad exchange it replaces: bit-identical) instead of 4 + 6 selects + 3 DPP adds, per cell and MFMA.
 #define MPM_P2G_SWAP 1
 #endif
+#ifndef MPM_P2G_REACH_TABLE
+#define MPM_P2G_REACH_TABLE 1   // (round 6) the reach mask of a cell read from a per-lane table instead of ~25 scalar instructions
+#endif
 #ifndef MPM_P2G_LOOP3
 #define MPM_P2G_LOOP3 1   // (round 6) first / middle / last steps of a cell as three bodies, see the contraction loop
 #endif
@@ -454,6 +457,10 @@ __global__ __launch_bounds__(P2G_THREADS) __attribute__((amdgpu_waves_per_eu(P2G
 #pragma unroll
             for (int r = 0; r < 4; ++r) fac[t][r] *= fscale;
     }
+#if MPM_P2G_REACH_TABLE
+    // lane l = (ix, iy, iz) in 2-bit fields: the neighbour blocks reached from base cells (2 ix.., 2 iy.., 2 iz..) of the tile
+    const unsigned reach_of_lane = tile_reach_mask(2 * (lane >> 4), 2 * ((lane >> 2) & 3), 2 * (lane & 3));
+#endif
     // A step reads 4 staged rows; rows that do not belong to the cell (the next cell's particles,
     // rows never written) are masked in the B operand only, so every row must hold finite numbers
     for (int k = lane; k < (64 + 8) * STG; k += 64) stage[k] = 0.f;
@@ -816,7 +823,12 @@ __global__ __launch_bounds__(P2G_THREADS) __attribute__((amdgpu_waves_per_eu(P2G
                 s0 = s1;
                 // rows = nodes, columns = (component d, term tt): fold the 4 terms of each component
                 const int crx = ckey >> 6, cry = (ckey >> 3) & 7, crz = ckey & 7;
+#if MPM_P2G_REACH_TABLE
+                // the mask depends on (rx >> 1, ry >> 1, rz >> 1) only: 64 combinations, one per lane of `reach_of_lane`
+                mymask |= (unsigned)__builtin_amdgcn_readlane((int)reach_of_lane, ((ckey >> 3) & 0x30) | ((ckey >> 2) & 0xC) | ((ckey >> 1) & 3));
+#else
                 mymask |= tile_reach_mask(crx, cry, crz);   // wave-uniform: scalar unit
+#endif
                 long long* tb = tile + ((crx * TILE_W + cry) * TILE_W + crz) * 4;
 #pragma unroll
                 for (int t = 0; t < 2; ++t) {
