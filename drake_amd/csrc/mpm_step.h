@@ -207,19 +207,18 @@ __global__ __launch_bounds__(256) void k_vforce(DP p) {
 // as a slab.  Inside the item the transfer is organised per
 // base cell: all particles that share a base cell scatter to the same 27 nodes,
 //     node(n) += sum_p w_n(p) * (m_p, q_p + Bdx_p * (i,j,k)_n)
-// which is a small dense contraction  [27 x P] * [P x 13]  (13 = mass, 3
-// momentum terms, 9 affine terms).  It runs on the f32 matrix pipe
-// (v_mfma_f32_16x16x4_f32: exact f32 FMA chains, the VALU rate, but the sum over
-// particles needs no cross-lane shuffles and no per-particle LDS atomics).
+// which is a small dense contraction over the cell's P particles: 16 staged columns per particle (3 x (momentum
+// term, 3 affine terms), mass) against 27 weights.  It runs on the f32 matrix pipe (v_mfma_f32_16x16x4_f32: exact f32
+// FMA chains, the VALU rate, but the sum over particles needs no cross-lane shuffles and no per-particle LDS atomics).
 // Every wave works on its own 64-particle groups, without workgroup barriers:
-//   1. every lane loads one particle (four 16-byte records, prefetched one group
-//      ahead), finds its base cell in the tile and builds its 13-vector,
-//   2. the wave groups its 64 particles by base cell (ballot loop) and stages
+//   1. every lane loads one particle (four 16-byte records), finds its base cell in the tile and builds its columns,
+//   2. the wave groups its 64 particles by base cell (ballot loop, ranks by v_mbcnt) and stages
 //      them in a wave-private LDS area,
-//   3. per cell: 4 particles per MFMA step, 2 MFMAs per step (node rows 0-15
-//      and 16-26), then the 4 terms of every (node, component) are folded with
-//      DPP and added to the tile: 2 ds_add_u64 (64 distinct words each) per cell,
-//      in 64-bit fixed point (exact, order independent).
+//   3. per cell: 4 particles per MFMA step, 2 MFMAs per step (nodes 0-15 and 16-26).  Since round 6 the staged
+//      columns are the A operand and the weights the B operand (MPM_P2G_SWAP): a lane's four accumulator registers
+//      are then the four TERMS (1, i, j, k) of one (node, component), folded in the lane with 4 products and 3
+//      sums -- rounds 1-5 had nodes as rows and folded across a quad with DPP -- and added to the tile: 2 LDS
+//      atomics (64 distinct words each) per cell, doubles or 64-bit fixed point (EXACT).
 // Replaces the warp-segmented scatter of cuda_mpm_kernels.cuh:418-543; the
 // order of particles inside a block is irrelevant.
 // ---------------------------------------------------------------------------
