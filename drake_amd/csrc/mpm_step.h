@@ -736,6 +736,7 @@ __global__ __launch_bounds__(P2G_THREADS) __attribute__((amdgpu_waves_per_eu(P2G
                 if (prof) { pc[4] += 1; pc[5] += (unsigned)((s1 - s0 + 3) >> 2); tq[2] = __builtin_readcyclecounter(); }
                 // operands of a step are fetched one step ahead (the first step's during the previous
                 // cell's epilogue), so the LDS latency hides behind the MFMAs
+#if !MPM_P2G_LOOP3
                 auto one_step = [&](int s, bool first_step) {
                     const bool ok = g4 < s1 - s;   // (rows of this cell; the difference is wave-uniform: one vector instruction)
                     const float fx = nfx, fy = nfy, fz = nfz;
@@ -767,6 +768,7 @@ __global__ __launch_bounds__(P2G_THREADS) __attribute__((amdgpu_waves_per_eu(P2G
                         acc1 = MPM_P2G_MFMA(w1, y, acc1);
                     }
                 };
+#endif
 #if MPM_P2G_LOOP3
                 {
                     // Three kinds of step: the first accumulates onto the inline constant 0 (no eight moves to clear the
